@@ -1,0 +1,165 @@
+"""
+Host-side scenario tables and synthetic warm starts for the OBCA parking path.
+
+Restates, as plain numpy, the input construction either side of the hot path:
+  * obst_hrep            <- /root/reference/AutonomousParking/obstHrep.jl:31-102
+  * BACKWARDS / PARALLEL <- /root/reference/AutonomousParking/main.jl:43-73,99-108,151-162,210-213
+  * warm starts: the reference takes them from Hybrid A* (main.jl:216-248), which is
+    out of scope.  Here a line/arc/line Reeds-Shepp-like
+    primitive plays that role; it is resampled to a fixed horizon N and the nominal
+    sampling time is chosen so that the path speed is 0.5 m/s, the reference's
+    nominal value (0.1 m x 3 per 0.6 s, main.jl:46-50,66).
+Nothing here touches the GPU; it only produces the (x0, xF, H-rep, rx, ry, ryaw, xWS, uWS)
+arrays the reference entry points take.
+"""
+import numpy as np
+
+L_WHEELBASE = 2.7                      # main.jl:63
+EGO = np.array([3.7, 1.0, 1.0, 1.0])   # main.jl:73
+XYBOUNDS = np.array([-15.0, 15.0, 1.0, 10.0])  # main.jl:210
+
+
+def obst_hrep(nOb, vOb, lOb):
+    """vertices (clock-wise, vOb[i] per obstacle) -> stacked half-space rows A p <= b."""
+    vOb = [int(v) for v in np.asarray(vOb).ravel()]
+    assert nOb == len(lOb)
+    rows_A, rows_b = [], []
+    for i in range(nOb):
+        for j in range(vOb[i] - 1):
+            v1 = np.asarray(lOb[i][j], float); v2 = np.asarray(lOb[i][j + 1], float)
+            if v1[0] == v2[0]:                       # vertical edge
+                if v2[1] < v1[1]:
+                    a, bb = [1.0, 0.0], v1[0]
+                else:
+                    a, bb = [-1.0, 0.0], -v1[0]
+            elif v1[1] == v2[1]:                     # horizontal edge
+                if v1[0] < v2[0]:
+                    a, bb = [0.0, 1.0], v1[1]
+                else:
+                    a, bb = [0.0, -1.0], -v1[1]
+            else:                                    # general edge y = s x + c
+                s, c = np.linalg.solve(np.array([[v1[0], 1.0], [v2[0], 1.0]]), np.array([v1[1], v2[1]]))
+                if v1[0] < v2[0]:
+                    a, bb = [-s, 1.0], c
+                else:
+                    a, bb = [s, -1.0], -c
+            rows_A.append(a); rows_b.append(bb)
+    return np.array(rows_A, float), np.array(rows_b, float)
+
+
+BACKWARDS = dict(
+    name="backwards", Ts=0.6, Ts_fix=0.55, nOb=3, vOb=[3, 3, 2],
+    lOb=[[[-20, 5], [-1.3, 5], [-1.3, -5]], [[1.3, -5], [1.3, 5], [20, 5]], [[20, 11], [-20, 11]]],
+    xF=np.array([0.0, 1.3, np.pi / 2, 0.0]), x0=np.array([-6.0, 9.5, 0.0, 0.0]))
+
+PARALLEL = dict(
+    name="parallel", Ts=0.9, Ts_fix=0.95, nOb=4, vOb=[3, 3, 2, 2],
+    lOb=[[[-20, 5], [-3.0, 5], [-3.0, 0]], [[3.0, 0], [3.0, 5], [20, 5]], [[-3, 2.5], [3, 2.5]],
+         [[20, 11], [-20, 11]]],
+    xF=np.array([-L_WHEELBASE / 2, 4.0, 0.0, 0.0]), x0=np.array([-6.0, 9.5, 0.0, 0.0]))
+
+
+def scenario_hrep(sc):
+    A, b = obst_hrep(sc["nOb"], sc["vOb"], sc["lOb"])
+    vrows = np.asarray(sc["vOb"]) - 1          # vObMPC = vOb-1  (main.jl:101)
+    return A, b, vrows
+
+
+# --------------------------------------------------------------------------- paths
+def _sample_path(segs, n_pts):
+    """segs: list of ('line', p0(2), heading, length, direction) / ('arc', center(2), R, th0, th1, direction, turn)
+    direction = +1 forward / -1 reverse.  Returns X,Y,yaw,dir,curvature sampled uniformly in arc length."""
+    lens = []
+    for s in segs:
+        lens.append(s[3] if s[0] == "line" else abs(s[4] - s[3]) * s[2])
+    tot = float(sum(lens))
+    ss = np.linspace(0.0, tot, n_pts)
+    X = np.zeros(n_pts); Y = np.zeros(n_pts); yaw = np.zeros(n_pts); dr = np.zeros(n_pts); kap = np.zeros(n_pts)
+    cum = np.concatenate([[0.0], np.cumsum(lens)])
+    for i, s_ in enumerate(ss):
+        k = min(np.searchsorted(cum, s_, side="right") - 1, len(segs) - 1)
+        k = max(k, 0)
+        while lens[k] == 0 and k < len(segs) - 1:
+            k += 1
+        loc = s_ - cum[k]
+        sg = segs[k]
+        if sg[0] == "line":
+            _, p0, hd, ln, d = sg
+            X[i] = p0[0] + d * loc * np.cos(hd); Y[i] = p0[1] + d * loc * np.sin(hd)
+            yaw[i] = hd; dr[i] = d; kap[i] = 0.0
+        else:
+            _, cen, R, th0, th1, d, side = sg
+            th = th0 + (th1 - th0) * (loc / lens[k] if lens[k] > 0 else 0.0)
+            # side=+1: left-turn circle  p = c + R(sin th, -cos th); side=-1: right-turn circle p = c + R(-sin th, cos th)
+            X[i] = cen[0] + side * R * np.sin(th); Y[i] = cen[1] - side * R * np.cos(th)
+            yaw[i] = th; dr[i] = d; kap[i] = side / R
+    return X, Y, yaw, dr, kap, tot
+
+
+def _finish(X, Y, yaw, dr, kap, tot, N, v_nom=0.5):
+    Ts = tot / (N * v_nom)
+    # speed: +-v_nom with zero at both ends; linear ramps limited by 0.4 m/s^2 handled by the NLP itself
+    v = dr * v_nom
+    v[0] = 0.0; v[-1] = 0.0
+    for i in range(1, N):
+        if dr[i] != dr[i - 1]:
+            v[i] = 0.0
+    a = np.diff(v) / Ts
+    a = np.clip(a, -0.4, 0.4)
+    delta = np.arctan(kap[:-1] * L_WHEELBASE)          # tan(delta)/L = curvature
+    delta = np.clip(delta, -0.6, 0.6)
+    xWS = np.stack([X, Y, yaw, v], 1)
+    uWS = np.stack([delta, a], 1)
+    return Ts, xWS, uWS
+
+
+def warm_start_backwards(x0, xF, N, R=4.5):
+    """line (forward or reverse along the lane) -> reverse quarter arc -> reverse line into the slot."""
+    X0, Y0 = float(x0[0]), float(x0[1])
+    xg, yg = float(xF[0]), float(xF[1])
+    xa = xg + R                       # arc starts at (xg+R, Y0) heading 0, ends at (xg, Y0-R) heading pi/2
+    ya = Y0 - R
+    segs = []
+    d1 = 1.0 if X0 < xa else -1.0
+    segs.append(("line", (X0, Y0), 0.0, abs(xa - X0), d1))
+    segs.append(("arc", (xa, ya), R, 0.0, np.pi / 2, -1.0, -1.0))
+    segs.append(("line", (xg, ya), np.pi / 2, max(ya - yg, 0.0), -1.0))
+    X, Y, yaw, dr, kap, tot = _sample_path(segs, N + 1)
+    Ts, xWS, uWS = _finish(X, Y, yaw, dr, kap, tot, N)
+    return Ts, xWS, uWS
+
+
+def warm_start_parallel(x0, xF, N, R=4.5):
+    """line along the lane -> reverse S-curve (right-turn arc then left-turn arc) into the bay."""
+    X0, Y0 = float(x0[0]), float(x0[1])
+    xg, yg = float(xF[0]), float(xF[1])
+    dy = Y0 - yg
+    th = np.arccos(max(-1.0, 1.0 - dy / (2 * R)))
+    dx = 2 * R * np.sin(th)
+    xs = xg + dx
+    d1 = 1.0 if X0 < xs else -1.0
+    segs = [("line", (X0, Y0), 0.0, abs(xs - X0), d1)]
+    # reversing from heading 0 with heading increasing: right-turn circle (side=-1), centre below the lane
+    segs.append(("arc", (xs, Y0 - R), R, 0.0, th, -1.0, -1.0))
+    # then heading decreasing back to 0 while reversing: left-turn circle (side=+1), centre above the goal
+    segs.append(("arc", (xg, yg + R), R, th, 0.0, -1.0, +1.0))
+    X, Y, yaw, dr, kap, tot = _sample_path(segs, N + 1)
+    Ts, xWS, uWS = _finish(X, Y, yaw, dr, kap, tot, N)
+    return Ts, xWS, uWS
+
+
+def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False):
+    """Synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0."""
+    rng = np.random.default_rng(seed)
+    A, b, vrows = scenario_hrep(sc)
+    ws = warm_start_backwards if sc["name"] == "backwards" else warm_start_parallel
+    x0 = np.zeros((B, 4)); xF = np.zeros((B, 4)); Ts = np.zeros(B)
+    xWS = np.zeros((B, N + 1, 4)); uWS = np.zeros((B, N, 2))
+    for i in range(B):
+        x0[i] = [rng.uniform(-10, 10), rng.uniform(6.5, 9.5), rng.uniform(-0.2, 0.2), 0.0]
+        xF[i] = sc["xF"]
+        if goal_jitter:
+            xF[i, 0] = rng.uniform(-1.85, -0.85)
+        Ts[i], xWS[i], uWS[i] = ws(x0[i], xF[i], N)
+    return dict(x0=x0, xF=xF, Ts=Ts, xWS=xWS, uWS=uWS, A=A, b=b, vOb=vrows, N=N, L=L_WHEELBASE,
+                ego=EGO.copy(), XYbounds=XYBOUNDS.copy())
