@@ -1,0 +1,82 @@
+/*
+ * obca_hip.h -- C ABI of libobca_hip.so: batched OBCA parking signed-distance NLP on AMD MI355X (gfx950).
+ *
+ * The reference (XiaojingGeorgeZhang/OBCA) has no FFI of its own; its boundary for this path is three positional Julia
+ * functions.  Each entry point below is what a `ccall` from a Julia shim binds to replace one of them:
+ *
+ *   obca_parking_signed_dist_batch  <->  ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS)
+ *                                        AutonomousParking/ParkingSignedDist.jl:29-314  (call site main.jl:269)
+ *   obca_dualmult_ws_batch          <->  DualMultWS(N,nOb,vOb,A,b,rx,ry,ryaw)   AutonomousParking/DualMultWS.jl:29-86
+ *                                        (call site ParkingSignedDist.jl:219; `ego` is an explicit argument here, the
+ *                                        reference reads a global, DualMultWS.jl:39-45)
+ *
+ * Conventions: all arrays are caller-allocated host memory, fp64, "stage-contiguous" = exactly the memory of the
+ * reference's column-major Julia arrays (x is 4 x (N+1): X1,Y1,psi1,v1,X2,...), with the batch as the slowest dimension,
+ * so B=1 is the reference layout.  Per-instance obstacle sets are packed back to back: instance i has nOb[i] obstacles with
+ * row counts vOb[ob_off[i] .. ob_off[i]+nOb[i]) and its M_i = sum of those rows of A (2 doubles per row: A[k,1],A[k,2]) and b
+ * start at row row_off[i]; ob_off / row_off are the running sums (the library computes them).  lWS/lp are M_i x (N+1),
+ * nWS/np are 4 nOb_i x (N+1), packed per instance in the same order.
+ * Return value 0 = the call executed (per-instance outcome is in exitflag[] / info[]); negative = API or device error,
+ * text in obca_last_error().  No exceptions cross the boundary.  One context is used by one host thread at a time.
+ * The library never falls back to a CPU path: without a usable gfx950 device obca_create fails.
+ */
+#ifndef OBCA_HIP_H
+#define OBCA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBCA_VMAX 4      /* max half-space rows per obstacle */
+#define OBCA_NOBMAX 10   /* max obstacles per instance */
+#define OBCA_NMAX 1024   /* max horizon */
+
+typedef struct obca_ctx obca_ctx;
+typedef struct obca_batch obca_batch;
+
+/* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults. */
+typedef struct obca_opts {
+    double tol; int max_iter;
+    double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
+    double dw_min, dw0, dw_max, kw_inc0, kw_inc, kw_dec, dc_bar, kappa_c;
+    double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
+    double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
+} obca_opts;
+
+int obca_create(obca_ctx **out, int device);
+int obca_destroy(obca_ctx *ctx);
+const char *obca_last_error(const obca_ctx *ctx);   /* ctx may be NULL: error of the last failed obca_create */
+int obca_default_opts(obca_opts *o);
+int obca_device_name(const obca_ctx *ctx, char *buf, int buflen);
+
+/* ---- synchronous host-pointer API (what the Julia shim calls) ---- */
+int obca_dualmult_ws_batch(obca_ctx *ctx, int B, int N, const double ego[4], const int *nOb, const int *vOb, const double *A,
+                           const double *b, const double *rx, const double *ry, const double *ryaw /* (N+1) x B each */,
+                           double *lWS, double *nWS, double *d /* nOb_i x (N+1) packed, may be NULL */);
+
+int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts /* B */, double L, const double ego[4],
+                                   const double XYbounds[4], int fixTime, const double *x0 /* 4 x B */, const double *xF /* 4 x B */,
+                                   const int *nOb /* B */, const int *vOb, const double *A, const double *b, const double *rx,
+                                   const double *ry, const double *ryaw, const double *xWS /* 4 x (N+1) x B */,
+                                   const double *uWS /* 2 x N x B */, const double *lWS, const double *nWS /* NULL: run DualMultWS */,
+                                   const obca_opts *opts /* NULL: defaults */, double *xp, double *up, double *timeScale /* (N+1) x B */,
+                                   int *exitflag /* B */, double *lp, double *np, double *slp /* nOb_i x (N+1) packed, may be NULL */,
+                                   double *info /* 8 x B {status,iters,objective,pinf,dinf,mu,nreg,exitflag}, may be NULL */);
+
+/* ---- device-resident batch API (benchmarks, receding-horizon callers): upload once, solve many times ---- */
+int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out);
+int obca_batch_destroy(obca_batch *bt);
+int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double ego[4], const double XYbounds[4], int fixTime,
+                      const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A, const double *b,
+                      const double *rx, const double *ry, const double *ryaw, const double *xWS, const double *uWS,
+                      const double *lWS, const double *nWS);
+int obca_batch_solve(obca_batch *bt, const obca_opts *opts);   /* asynchronous on the context's stream: warm start -> (DualMultWS) -> IPM */
+int obca_batch_sync(obca_batch *bt);
+int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms);   /* HIP-event durations of the last solve */
+int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *np,
+                        double *slp, double *info);
+int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

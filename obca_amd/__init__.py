@@ -1,0 +1,11 @@
+"""obca_amd -- MI355X-native batched OBCA (optimization-based collision avoidance) parking NLP solver.
+
+Host-side mirror of the reference's Julia entry points over the C ABI of libobca_hip.so (include/obca_hip.h).
+The HIP library is the only compute path: importing works anywhere, but every solve raises if the library or a gfx950
+device is missing -- there is no CPU fallback.
+"""
+from .api import (ObcaError, Context, Batch, ParkingSignedDist, DualMultWS, parking_signed_dist_batch, dualmult_ws_batch,
+                  default_opts, library_path, build_library)
+
+__all__ = ["ObcaError", "Context", "Batch", "ParkingSignedDist", "DualMultWS", "parking_signed_dist_batch",
+           "dualmult_ws_batch", "default_opts", "library_path", "build_library"]

@@ -1,0 +1,284 @@
+"""
+ctypes binding of libobca_hip.so and the Python mirror of the reference's entry points for the signed-distance path:
+
+    ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS)
+        -> xp (4,N+1), up (2,N), timeScale, exitflag, time, lp (M,N+1), np (4nOb,N+1)
+        same positional arguments, shapes and exit-flag meaning as
+        /root/reference/AutonomousParking/ParkingSignedDist.jl:29,297-313
+    DualMultWS(N,nOb,vOb,A,b,rx,ry,ryaw, ego) -> lp (N+1,M), np (N+1,4nOb)
+        /root/reference/AutonomousParking/DualMultWS.jl:29,81-84 (the reference reads `ego` from global scope, :39-45)
+
+plus batched variants (leading batch dimension) that keep everything resident on the GPU between upload and download.
+"""
+import ctypes as C
+import os
+import subprocess
+import time
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIBPATH = os.path.join(_CSRC, "libobca_hip.so")
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int)
+_lib = None
+
+
+class ObcaError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int)] + \
+        [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
+                                   "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
+                                   "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()]
+
+
+def library_path():
+    return _LIBPATH
+
+
+def build_library(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_solver.h", "obca_model.h")] + \
+           [os.path.join(_HERE, "..", "include", "obca_hip.h")]
+    if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(s) for s in srcs):
+        return _LIBPATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I" + os.path.join(_HERE, "..", "include"), "-o", _LIBPATH, os.path.join(_CSRC, "obca_hip.hip")]
+    subprocess.check_call(cmd)
+    return _LIBPATH
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise ObcaError(f"{_LIBPATH} is missing: build it with obca_amd.build_library() / __graft_entry__.build(); "
+                        "there is no CPU fallback")
+    lib = C.CDLL(_LIBPATH)
+    lib.obca_last_error.restype = C.c_char_p
+    lib.obca_last_error.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
+           "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_batch_create", "obca_batch_destroy",
+           "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
+           "obca_batch_scratch_bytes"]
+
+
+def default_opts():
+    o = Opts()
+    _load().obca_default_opts(C.byref(o))
+    return o
+
+
+def _d(a):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_D)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_I)
+
+
+class Context:
+    def __init__(self, device=0):
+        lib = _load()
+        self._h = C.c_void_p()
+        rc = lib.obca_create(C.byref(self._h), C.c_int(int(device)))
+        if rc != 0:
+            raise ObcaError("obca_create failed: " + (lib.obca_last_error(None) or b"").decode())
+        self.device = int(device)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise ObcaError(f"{what} failed ({rc}): " + (_load().obca_last_error(self._h) or b"").decode())
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        _load().obca_device_name(self._h, buf, 256)
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            _load().obca_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def _ctx(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def _norm_obstacles(B, vOb, A, b):
+    """Accept one shared obstacle set (vOb 1-D, A (M,2)) or per-instance lists; return packed per-instance arrays."""
+    if isinstance(vOb, (list, tuple)) and len(vOb) == B and np.ndim(vOb[0]) >= 1:
+        nObs = np.array([len(np.ravel(v)) for v in vOb], np.int32)
+        vflat = np.concatenate([np.ravel(v) for v in vOb]).astype(np.int32)
+        Aflat = np.concatenate([np.asarray(a, float).reshape(-1, 2) for a in A])
+        bflat = np.concatenate([np.ravel(np.asarray(x, float)) for x in b])
+        return nObs, vflat, Aflat, bflat
+    v = np.ravel(np.asarray(vOb)).astype(np.int32)
+    M = int(v.sum())
+    A = np.asarray(A, float).reshape(M, 2); b = np.ravel(np.asarray(b, float))
+    return np.full(B, len(v), np.int32), np.tile(v, B), np.tile(A, (B, 1)), np.tile(b, B)
+
+
+def _row_counts(nObs, vflat):
+    starts = np.concatenate([[0], np.cumsum(nObs)[:-1]])
+    return np.array([vflat[s:s + n].sum() for s, n in zip(starts, nObs)], np.int64)
+
+
+class Batch:
+    """Device-resident batch: upload once, solve (repeatedly), download."""
+
+    def __init__(self, ctx, B, N):
+        self.ctx, self.B, self.N = ctx, int(B), int(N)
+        self._h = C.c_void_p()
+        ctx._check(_load().obca_batch_create(ctx._h, C.c_int(self.B), C.c_int(self.N), C.byref(self._h)), "obca_batch_create")
+
+    def upload(self, x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None):
+        """lWS/nWS, when given, are packed per instance as (N+1, M_i) / (N+1, 4 nOb_i) row-major blocks (= the reference's
+        column-major l (M x N+1) and n (4nOb x N+1))."""
+        B, N = self.B, self.N
+        nObs, vflat, Aflat, bflat = _norm_obstacles(B, vOb, A, b)
+        self.nObs, self.vflat = nObs, vflat
+        self.Ms = _row_counts(nObs, vflat)
+        Ts = np.broadcast_to(np.asarray(Ts, float), (B,))
+        if lWS is not None and not isinstance(lWS, np.ndarray):
+            lWS = np.concatenate([np.ravel(x) for x in lWS]); nWS = np.concatenate([np.ravel(x) for x in nWS])
+        keep = [_d(Ts), _d(ego), _d(XYbounds), _d(np.reshape(x0, (B, 4))), _d(np.reshape(xF, (B, 4))), _i(nObs), _i(vflat),
+                _d(Aflat), _d(bflat), _d(np.reshape(rx, (B, N + 1))), _d(np.reshape(ry, (B, N + 1))), _d(np.reshape(ryaw, (B, N + 1))),
+                _d(np.asarray(xWS, float).reshape(B, -1, 4)[:, :N + 1]), _d(np.asarray(uWS, float).reshape(B, -1, 2)[:, :N]),
+                _d(lWS), _d(nWS)]
+        p = [k[1] for k in keep]
+        rc = _load().obca_batch_upload(self._h, p[0], C.c_double(float(L)), p[1], p[2], C.c_int(int(fixTime)), p[3], p[4], p[5], p[6],
+                                       p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15])
+        self.ctx._check(rc, "obca_batch_upload")
+
+    def solve(self, opts=None, sync=True):
+        self.ctx._check(_load().obca_batch_solve(self._h, C.byref(opts) if opts is not None else None), "obca_batch_solve")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self.ctx._check(_load().obca_batch_sync(self._h), "obca_batch_sync")
+
+    def kernel_ms(self):
+        """(ipm_ms, dualws_ms) of the last solve, measured with HIP events on the launch stream."""
+        a, b = C.c_float(0), C.c_float(0)
+        self.ctx._check(_load().obca_batch_kernel_ms(self._h, C.byref(a), C.byref(b)), "obca_batch_kernel_ms")
+        return a.value, b.value
+
+    def scratch_bytes(self):
+        v = C.c_longlong(0)
+        _load().obca_batch_scratch_bytes(self._h, C.byref(v))
+        return v.value
+
+    def download(self):
+        B, N = self.B, self.N
+        Mt, nt = int(self.Ms.sum()), int(self.nObs.sum())
+        xp = np.zeros((B, N + 1, 4)); up = np.zeros((B, N, 2)); ts = np.zeros((B, N + 1)); ef = np.zeros(B, np.int32)
+        lp = np.zeros(Mt * (N + 1)); npp = np.zeros(4 * nt * (N + 1)); sl = np.zeros(nt * (N + 1)); info = np.zeros((B, 8))
+        rc = _load().obca_batch_download(self._h, xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D),
+                                         ef.ctypes.data_as(_I), lp.ctypes.data_as(_D), npp.ctypes.data_as(_D), sl.ctypes.data_as(_D),
+                                         info.ctypes.data_as(_D))
+        self.ctx._check(rc, "obca_batch_download")
+        lps, nps, sls = [], [], []          # per instance, reference shapes (M,N+1) / (4nOb,N+1) / (nOb,N+1)
+        ro = oo = 0
+        for m, n in zip(self.Ms, self.nObs):
+            lps.append(lp[ro * (N + 1):(ro + m) * (N + 1)].reshape(N + 1, m).T.copy())
+            nps.append(npp[4 * oo * (N + 1):4 * (oo + n) * (N + 1)].reshape(N + 1, 4 * n).T.copy())
+            sls.append(sl[oo * (N + 1):(oo + n) * (N + 1)].reshape(N + 1, n).T.copy())
+            ro += m; oo += n
+        return dict(xp=np.transpose(xp, (0, 2, 1)).copy(), up=np.transpose(up, (0, 2, 1)).copy(), timeScale=ts, exitflag=ef,
+                    lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
+
+    def close(self):
+        if self._h:
+            _load().obca_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
+                              opts=None, device=0):
+    """Batched ParkingSignedDist: x0,xF (B,4); rx,ry,ryaw (B,N+1); xWS (B,N+1,4); uWS (B,>=N,2); Ts scalar or (B,).
+    Obstacles: one shared set (vOb 1-D, A (M,2), b (M,)) or per-instance lists.  lWS/nWS=None runs DualMultWS on the GPU."""
+    B = np.reshape(x0, (-1, 4)).shape[0]
+    bt = Batch(_ctx(device), B, N)
+    try:
+        bt.upload(x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS, nWS)
+        t0 = time.perf_counter()
+        bt.solve(opts)
+        dt = time.perf_counter() - t0
+        out = bt.download()
+        out["time"] = dt
+        return out
+    finally:
+        bt.close()
+
+
+def ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, opts=None, device=0):
+    """Drop-in for ParkingSignedDist.jl:29 (one instance).  Returns (xp, up, timeScalep, exitflag, time, lp, np)."""
+    assert int(nOb) == len(np.ravel(vOb))
+    r = parking_signed_dist_batch(np.reshape(x0, (1, 4)), np.reshape(xF, (1, 4)), N, Ts, L, ego, XYbounds, vOb, A, b,
+                                  np.reshape(np.ravel(rx)[:N + 1], (1, -1)), np.reshape(np.ravel(ry)[:N + 1], (1, -1)),
+                                  np.reshape(np.ravel(ryaw)[:N + 1], (1, -1)), fixTime, np.asarray(xWS, float)[None, :N + 1],
+                                  np.asarray(uWS, float)[None, :N], opts=opts, device=device)
+    ts = np.ones((1, N + 1)) if fixTime else r["timeScale"][0]          # ParkingSignedDist.jl:304-308
+    return r["xp"][0], r["up"][0], ts, int(r["exitflag"][0]), r["time"], r["lp"][0], r["np"][0]
+
+
+def dualmult_ws_batch(N, vOb, A, b, rx, ry, ryaw, ego, device=0):
+    """Batched DualMultWS: rx,ry,ryaw (B,N+1) -> lWS list of (N+1,M), nWS list of (N+1,4nOb), d list of (N+1,nOb)."""
+    rx = np.atleast_2d(np.asarray(rx, float)); B = rx.shape[0]
+    ctx = _ctx(device)
+    nObs, vflat, Aflat, bflat = _norm_obstacles(B, vOb, A, b)
+    Ms = _row_counts(nObs, vflat)
+    Mt, nt = int(Ms.sum()), int(nObs.sum())
+    lw = np.zeros(Mt * (N + 1)); nw = np.zeros(4 * nt * (N + 1)); dd = np.zeros(nt * (N + 1))
+    keep = [_d(ego), _i(nObs), _i(vflat), _d(Aflat), _d(bflat), _d(rx), _d(np.atleast_2d(ry)), _d(np.atleast_2d(ryaw))]
+    p = [k[1] for k in keep]
+    rc = _load().obca_dualmult_ws_batch(ctx._h, C.c_int(B), C.c_int(N), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                        lw.ctypes.data_as(_D), nw.ctypes.data_as(_D), dd.ctypes.data_as(_D))
+    ctx._check(rc, "obca_dualmult_ws_batch")
+    ls, ns, ds = [], [], []
+    ro = oo = 0
+    for m, n in zip(Ms, nObs):
+        ls.append(lw[ro * (N + 1):(ro + m) * (N + 1)].reshape(N + 1, m).copy())
+        ns.append(nw[4 * oo * (N + 1):4 * (oo + n) * (N + 1)].reshape(N + 1, 4 * n).copy())
+        ds.append(dd[oo * (N + 1):(oo + n) * (N + 1)].reshape(N + 1, n).copy())
+        ro += m; oo += n
+    return ls, ns, ds
+
+
+def DualMultWS(N, nOb, vOb, A, b, rx, ry, ryaw, ego, device=0):
+    """Drop-in for DualMultWS.jl:29 -> (lp (N+1,M), np (N+1,4nOb)); `ego` is explicit (the reference uses a global)."""
+    assert int(nOb) == len(np.ravel(vOb))
+    ls, ns, _ = dualmult_ws_batch(N, vOb, A, b, np.ravel(rx)[None, :N + 1], np.ravel(ry)[None, :N + 1],
+                                  np.ravel(ryaw)[None, :N + 1], ego, device)
+    return ls[0], ns[0]

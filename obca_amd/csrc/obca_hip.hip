@@ -1,0 +1,326 @@
+// obca_hip.hip -- HIP kernels and the C ABI of libobca_hip.so (gfx950 only; see include/obca_hip.h).
+//
+// Kernels
+//   obca_parking_ipm_kernel : one 64-lane workgroup (one wavefront) per problem instance, persistent over the whole
+//                             interior-point solve (obca_solver.h).  grid = B, block = 64.
+//   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
+// Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
+//   prob  header+rx,ry,ryaw   [411]      z  primal-dual iterate [6554]      d  search direction [3804 used]
+//   as    assembled stage records (N+1) x 88 [7128]     rs  Riccati records (N+1) x 116 [9396]
+//   oc    condensed obstacle records (N+1) x nOb x 12 [2916]    traj (N+2) x 6
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "obca_solver.h"
+#include "../../include/obca_hip.h"
+
+using namespace obca;
+
+static_assert(sizeof(obca_opts) == sizeof(Opts), "obca_opts must mirror obca::Opts");
+static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX, "ABI limits must match the kernels");
+
+struct DevBufs {
+    double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws;
+    size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
+};
+
+__global__ __launch_bounds__(64) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o) {
+    __shared__ Shared sh;
+    const int inst = blockIdx.x;
+    if (inst >= B) return;
+    Inst I;
+    I.prob = b.prob + (size_t)inst * b.s_prob;
+    I.z = b.z + (size_t)inst * b.s_z; I.d = b.d + (size_t)inst * b.s_z;
+    I.as = b.as + (size_t)inst * b.s_as; I.rs = b.rs + (size_t)inst * b.s_rs; I.oc = b.oc + (size_t)inst * b.s_oc;
+    I.traj = b.traj + (size_t)inst * b.s_traj;
+    I.c.N = N;
+    solve_instance(I, sh, o, b.info + (size_t)inst * 8);
+}
+
+// one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
+__global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObMax, DevBufs b, double *zdst, size_t s_zdst) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)(N + 1) * nObMax;
+    if (gid >= (long long)B * per) return;
+    const int inst = (int)(gid / per); const int rem = (int)(gid % per);
+    const int k = rem / nObMax, j = rem % nObMax;
+    const double *p = b.prob + (size_t)inst * b.s_prob;
+    const int nOb = (int)p[PH_NOB], M = (int)p[PH_M];
+    if (j >= nOb) return;
+    const int v = (int)p[PH_VOB + j], r0 = (int)p[PH_ROFF + j];
+    double a1[OB_VMAX], a2[OB_VMAX], bj[OB_VMAX], g[4];
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) { bool on = i < v; a1[i] = on ? p[PH_A + 2 * (r0 + i)] : 0.0; a2[i] = on ? p[PH_A + 2 * (r0 + i) + 1] : 0.0; bj[i] = on ? p[PH_B + r0 + i] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) g[i] = p[PH_G + i];
+    const double rx = p[OB_HDR + k], ry = p[OB_HDR + (N + 1) + k], ryaw = p[OB_HDR + 2 * (N + 1) + k], off = p[PH_OFF];
+    double sn, cs; sincos(ryaw, &sn, &cs);
+    double lam[OB_VMAX], mu[4], dv;
+    dualws_one(v, a1, a2, bj, g, rx + cs * off, ry + sn * off, cs, sn, lam, mu, &dv);
+    Lay l; make_layout(N, nOb, M, l);
+    double *z = zdst + (size_t)inst * s_zdst;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) z[l.lam + k * M + r0 + i] = lam[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) z[l.mu + 4 * (k * nOb + j) + i] = mu[i];
+    if (b.dws) b.dws[(size_t)inst * per + rem] = dv;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct obca_ctx { int device; hipStream_t stream; std::string err; std::string name; };
+static std::string g_create_err;
+
+struct obca_batch {
+    obca_ctx *ctx; int B, N, nObMax, MMax, zlen, have_duals, uploaded;
+    DevBufs d;
+    std::vector<int> nOb, M, obOff, rowOff;
+    std::vector<double> Ts; int fixTime;
+    hipEvent_t e0, e1, e2;
+    long long bytes;
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+
+extern "C" {
+
+int obca_default_opts(obca_opts *o) {
+    if (!o) return -1;
+    o->tol = 1e-5; o->max_iter = 200;                 /* ParkingSignedDist.jl:42 */
+    o->mu_init = 0.1; o->kappa_eps = 10; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99;
+    o->bound_push = 1e-2; o->bound_frac = 1e-2;
+    o->dw_min = 1e-12;                                 /* min_hessian_perturbation, :43 */
+    o->dw0 = 1e-4; o->dw_max = 1e40; o->kw_inc0 = 100; o->kw_inc = 8; o->kw_dec = 1.0 / 3;
+    o->dc_bar = 1e-7;                                  /* jacobian_regularization_value, :43 */
+    o->kappa_c = 0.25;
+    o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
+    o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
+    o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
+    return 0;
+}
+
+int obca_create(obca_ctx **out, int device) {
+    if (!out) return -1;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_err = "no HIP device available (libobca_hip has no CPU fallback)"; return -2; }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return -1; }
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; return -2; }
+    if (std::string(pr.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; return -2;
+    }
+    obca_ctx *c = new obca_ctx();
+    c->device = device; c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")";
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return -2; }
+    *out = c;
+    return 0;
+}
+int obca_destroy(obca_ctx *c) { if (!c) return -1; hipSetDevice(c->device); hipStreamDestroy(c->stream); delete c; return 0; }
+const char *obca_last_error(const obca_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+int obca_device_name(const obca_ctx *c, char *buf, int n) { if (!c || !buf || n <= 0) return -1; snprintf(buf, n, "%s", c->name.c_str()); return 0; }
+
+int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
+    if (!ctx || !out) return -1;
+    if (B < 1 || N < 2 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 2<=N<=OBCA_NMAX"; return -1; }
+    obca_batch *bt = new obca_batch();
+    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0;
+    memset(&bt->d, 0, sizeof bt->d);
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipEventCreate(&bt->e0)); HIPCHK(ctx, hipEventCreate(&bt->e1)); HIPCHK(ctx, hipEventCreate(&bt->e2));
+    *out = bt;
+    return 0;
+}
+static void free_dev(obca_batch *bt) {
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws};
+    for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+}
+int obca_batch_destroy(obca_batch *bt) {
+    if (!bt) return -1;
+    hipSetDevice(bt->ctx->device);
+    free_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); hipEventDestroy(bt->e2);
+    delete bt; return 0;
+}
+int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
+
+int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double ego[4], const double XYb[4], int fixTime,
+                      const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A, const double *b,
+                      const double *rx, const double *ry, const double *ryaw, const double *xWS, const double *uWS,
+                      const double *lWS, const double *nWS) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    const int B = bt->B, N = bt->N, N1 = N + 1;
+    if (!Ts || !ego || !XYb || !nOb || !vOb || !A || !b || !rx || !ry || !ryaw) { ctx->err = "obca_batch_upload: NULL argument"; return -1; }
+    bt->nOb.assign(B, 0); bt->M.assign(B, 0); bt->obOff.assign(B + 1, 0); bt->rowOff.assign(B + 1, 0);
+    int nObMax = 0, MMax = 0;
+    for (int i = 0; i < B; i++) {
+        int n = nOb[i];
+        if (n < 1 || n > OBCA_NOBMAX) { ctx->err = "obca_batch_upload: nOb out of range 1..OBCA_NOBMAX"; return -1; }
+        int m = 0;
+        for (int j = 0; j < n; j++) { int v = vOb[bt->obOff[i] + j]; if (v < 1 || v > OBCA_VMAX) { ctx->err = "obca_batch_upload: vOb out of range 1..OBCA_VMAX"; return -1; } m += v; }
+        bt->nOb[i] = n; bt->M[i] = m; bt->obOff[i + 1] = bt->obOff[i] + n; bt->rowOff[i + 1] = bt->rowOff[i] + m;
+        if (n > nObMax) nObMax = n; if (m > MMax) MMax = m;
+    }
+    Lay lmax; make_layout(N, nObMax, MMax, lmax);
+    hipSetDevice(ctx->device);
+    if (!bt->uploaded || nObMax != bt->nObMax || MMax != bt->MMax) {
+        free_dev(bt);
+        bt->nObMax = nObMax; bt->MMax = MMax; bt->zlen = lmax.len;
+        DevBufs &d = bt->d;
+        d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
+        d.s_oc = (size_t)N1 * nObMax * OB_OC; d.s_traj = (size_t)(N + 2) * 6;
+        size_t tot = 0;
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(ctx, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
+        ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
+        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
+        ALLOC(d.info, (size_t)B * 8); ALLOC(d.dws, (size_t)B * N1 * nObMax);
+#undef ALLOC
+        bt->bytes = (long long)tot;
+    }
+    const DevBufs &d = bt->d;
+    std::vector<double> hp((size_t)B * d.s_prob, 0.0), hz((size_t)B * d.s_z, 0.0);
+    const double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];     /* ParkingSignedDist.jl:182-188 */
+    for (int i = 0; i < B; i++) {
+        double *p = hp.data() + (size_t)i * d.s_prob;
+        const int n = bt->nOb[i], m = bt->M[i];
+        p[PH_TS] = Ts[i]; p[PH_L] = L;
+        p[PH_G] = L_ev / 2; p[PH_G + 1] = W_ev / 2; p[PH_G + 2] = L_ev / 2; p[PH_G + 3] = W_ev / 2;
+        p[PH_OFF] = (ego[0] + ego[2]) / 2 - ego[2];
+        p[PH_XL] = XYb[0]; p[PH_XL + 1] = XYb[2]; p[PH_XL + 2] = -1e300; p[PH_XL + 3] = -1.0;     /* :104-106 */
+        p[PH_XU] = XYb[1]; p[PH_XU + 1] = XYb[3]; p[PH_XU + 2] = 1e300; p[PH_XU + 3] = 2.0;
+        for (int q = 0; q < 4; q++) { p[PH_X0 + q] = x0 ? x0[4 * i + q] : 0.0; p[PH_XF + q] = xF ? xF[4 * i + q] : 0.0; }
+        p[PH_FIX] = fixTime ? 1 : 0; p[PH_NOB] = n; p[PH_M] = m;
+        int ro = 0;
+        for (int j = 0; j < n; j++) { int v = vOb[bt->obOff[i] + j]; p[PH_VOB + j] = v; p[PH_ROFF + j] = ro; ro += v; }
+        p[PH_ROFF + n] = ro;
+        for (int r = 0; r < m; r++) { p[PH_A + 2 * r] = A[2 * (bt->rowOff[i] + r)]; p[PH_A + 2 * r + 1] = A[2 * (bt->rowOff[i] + r) + 1]; p[PH_B + r] = b[bt->rowOff[i] + r]; }
+        for (int k = 0; k < N1; k++) { p[OB_HDR + k] = rx[(size_t)i * N1 + k]; p[OB_HDR + N1 + k] = ry[(size_t)i * N1 + k]; p[OB_HDR + 2 * N1 + k] = ryaw[(size_t)i * N1 + k]; }
+        Lay l; make_layout(N, n, m, l);
+        double *z = hz.data() + (size_t)i * d.s_z;
+        if (xWS) memcpy(z + l.x, xWS + (size_t)i * 4 * N1, sizeof(double) * 4 * N1);
+        if (uWS) memcpy(z + l.u, uWS + (size_t)i * 2 * N, sizeof(double) * 2 * N);
+        z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
+        if (lWS && nWS) {
+            memcpy(z + l.lam, lWS + (size_t)bt->rowOff[i] * N1, sizeof(double) * m * N1);
+            memcpy(z + l.mu, nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * n * N1);
+        }
+    }
+    bt->have_duals = (lWS && nWS) ? 1 : 0; bt->fixTime = fixTime ? 1 : 0;
+    bt->Ts.assign(Ts, Ts + B);
+    HIPCHK(ctx, hipMemcpyAsync(d.prob, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d.z0, hz.data(), hz.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    bt->uploaded = 1;
+    return 0;
+}
+
+static int launch_dualws(obca_batch *bt, double *zdst) {
+    obca_ctx *ctx = bt->ctx;
+    long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
+    int blocks = (int)((tot + 255) / 256);
+    hipLaunchKernelGGL(obca_dualws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    if (!bt->uploaded) { ctx->err = "obca_batch_solve: nothing uploaded"; return -1; }
+    obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
+    Opts ko; memcpy(&ko, &o, sizeof ko);
+    hipSetDevice(ctx->device);
+    const DevBufs &d = bt->d;
+    HIPCHK(ctx, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
+    if (!bt->have_duals) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
+    HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
+    hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(64), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(bt->e2, ctx->stream));
+    return 0;
+}
+int obca_batch_sync(obca_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }
+int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms) {
+    if (!bt) return -1;
+    float a = 0, b = 0;
+    HIPCHK(bt->ctx, hipEventElapsedTime(&a, bt->e0, bt->e1)); HIPCHK(bt->ctx, hipEventElapsedTime(&b, bt->e1, bt->e2));
+    if (dualws_ms) *dualws_ms = a; if (ipm_ms) *ipm_ms = b;
+    return 0;
+}
+
+int obca_batch_download(obca_batch *bt, double *xp, double *up, double *ts, int *exitflag, double *lp, double *np, double *slp, double *info) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    const int B = bt->B, N = bt->N, N1 = N + 1;
+    const DevBufs &d = bt->d;
+    hipSetDevice(ctx->device);
+    std::vector<double> hz((size_t)B * d.s_z), hi((size_t)B * 8);
+    HIPCHK(ctx, hipMemcpyAsync(hz.data(), d.z, hz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hi.data(), d.info, hi.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < B; i++) {
+        Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
+        const double *z = hz.data() + (size_t)i * d.s_z;
+        if (xp) memcpy(xp + (size_t)i * 4 * N1, z + l.x, sizeof(double) * 4 * N1);
+        if (up) memcpy(up + (size_t)i * 2 * N, z + l.u, sizeof(double) * 2 * N);
+        if (ts) for (int k = 0; k < N1; k++) ts[(size_t)i * N1 + k] = bt->fixTime ? 1.0 : z[l.t];   /* ParkingSignedDist.jl:304-308 */
+        if (lp) memcpy(lp + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+        if (np) memcpy(np + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
+        if (slp) memcpy(slp + (size_t)bt->obOff[i] * N1, z + l.sl, sizeof(double) * bt->nOb[i] * N1);
+        if (exitflag) exitflag[i] = (int)hi[(size_t)i * 8 + 7];
+        if (info) memcpy(info + (size_t)i * 8, hi.data() + (size_t)i * 8, sizeof(double) * 8);
+    }
+    return 0;
+}
+
+int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
+                                   int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
+                                   const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
+                                   const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
+                                   double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
+    if (!ctx) return -1;
+    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_signed_dist_batch: NULL argument"; return -1; }
+    obca_batch *bt = nullptr;
+    int rc = obca_batch_create(ctx, B, N, &bt);
+    if (rc) return rc;
+    rc = obca_batch_upload(bt, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS);
+    if (!rc) rc = obca_batch_solve(bt, opts);
+    if (!rc) rc = obca_batch_sync(bt);
+    if (!rc) rc = obca_batch_download(bt, xp, up, timeScale, exitflag, lp, np, slp, info);
+    obca_batch_destroy(bt);
+    return rc;
+}
+
+int obca_dualmult_ws_batch(obca_ctx *ctx, int B, int N, const double ego[4], const int *nOb, const int *vOb, const double *A,
+                           const double *b, const double *rx, const double *ry, const double *ryaw, double *lWS, double *nWS, double *dd) {
+    if (!ctx) return -1;
+    if (!lWS || !nWS) { ctx->err = "obca_dualmult_ws_batch: NULL output"; return -1; }
+    obca_batch *bt = nullptr;
+    int rc = obca_batch_create(ctx, B, N, &bt);
+    if (rc) return rc;
+    std::vector<double> Ts(B, 1.0); const double XYb[4] = {0, 0, 0, 0};
+    rc = obca_batch_upload(bt, Ts.data(), 1.0, ego, XYb, 0, nullptr, nullptr, nOb, vOb, A, b, rx, ry, ryaw, nullptr, nullptr, nullptr, nullptr);
+    if (!rc) rc = launch_dualws(bt, bt->d.z);
+    if (!rc) rc = obca_batch_sync(bt);
+    if (!rc) {
+        const int N1 = N + 1;
+        std::vector<double> hz((size_t)B * bt->d.s_z), hd((size_t)B * N1 * bt->nObMax);
+        if (hipMemcpy(hz.data(), bt->d.z, hz.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hd.data(), bt->d.dws, hd.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "obca_dualmult_ws_batch: copy back failed"; rc = -2; }
+        for (int i = 0; i < B && !rc; i++) {
+            Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
+            const double *z = hz.data() + (size_t)i * bt->d.s_z;
+            memcpy(lWS + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+            memcpy(nWS + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
+            if (dd) for (int k = 0; k < N1; k++) for (int j = 0; j < bt->nOb[i]; j++)
+                dd[(size_t)bt->obOff[i] * N1 + (size_t)k * bt->nOb[i] + j] = hd[(size_t)i * N1 * bt->nObMax + (size_t)k * bt->nObMax + j];
+        }
+    }
+    obca_batch_destroy(bt);
+    return rc;
+}
+
+}  // extern "C"

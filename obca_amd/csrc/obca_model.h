@@ -1,0 +1,570 @@
+// obca_model.h -- per-lane model pieces of the OBCA parking signed-distance NLP (gfx950 device code).
+//
+// Everything in this header is executed by ONE lane on ONE work item (a stage, or a (stage, obstacle) block):
+// closed-form values, Jacobians and Lagrangian Hessians of
+//   * the kinematic-bicycle multiple-shooting map            (reference: AutonomousParking/ParkingSignedDist.jl:139-155)
+//   * the dual-variable hyperplane-separation rows           (reference: ParkingSignedDist.jl:182-208)
+// and the condensation of one (stage, obstacle) block (lambda_j, mu_j, sl_j, slack, 4 multipliers) onto the pose
+// (X, Y, psi) of its stage.  No dynamic indexing: all loops run to the compile-time bounds OB_VMAX / 4 / 3 so that the
+// small matrices stay in VGPRs.
+#pragma once
+#include <math.h>
+
+#ifndef OBCA_FN
+#define OBCA_FN static inline
+#endif
+
+#define OB_VMAX 4
+#define OB_NOBMAX 10
+#define OB_MMAX 40
+
+namespace obca {
+
+struct Consts {               // uniform per instance
+    double Ts, L, g[4], off, xl[4], xu[4], x0[4], xF[4];
+    int fixTime, nOb, M, N;
+    double wa, wpsi;          // ParkingSignedDist.jl:78-92 (fixTime switches the weights)
+};
+
+#define OB_UL0 (-0.6)
+#define OB_UU0 (0.6)
+#define OB_UL1 (-0.4)
+#define OB_UU1 (0.4)
+#define OB_TL 0.8
+#define OB_TU 1.2
+#define OB_SSB 0.6
+#define OB_DMIN 0.05
+
+// ---------------------------------------------------------------- bicycle model, vars (psi, v, delta, a, t)
+struct DynOut {
+    double F[4];
+    double dF[4][5];   // d(F_i - x_i)/d(psi,v,delta,a,t)
+};
+
+OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], double t, double F[4]) {
+    double tau = c.Ts * t, s = x[3] + 0.5 * tau * u[1], T = tan(u[0]);
+    double phi = x[2] + tau * x[3] * T / (2 * c.L), sn, cs;
+    sincos(phi, &sn, &cs);
+    F[0] = x[0] + tau * s * cs; F[1] = x[1] + tau * s * sn; F[2] = x[2] + tau * s * T / c.L; F[3] = x[3] + tau * u[1];
+}
+
+// first derivatives and  HL = sum_i w_i Hess(F_i)  (5x5, symmetric, full storage)
+OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], double t, const double w[4], DynOut &o,
+                        double HL[5][5]) {
+    double Ts = c.Ts, L = c.L, v = x[3], a = u[1];
+    double tau = Ts * t, s = v + 0.5 * tau * a, T = tan(u[0]), Tp = 1 + T * T;
+    double phi = x[2] + tau * v * T / (2 * L), sn, cs;
+    sincos(phi, &sn, &cs);
+    o.F[0] = x[0] + tau * s * cs; o.F[1] = x[1] + tau * s * sn; o.F[2] = x[2] + tau * s * T / L; o.F[3] = v + tau * a;
+    const double dtau[5] = {0, 0, 0, 0, Ts};
+    const double ds[5] = {0, 1, 0, 0.5 * tau, 0.5 * Ts * a};
+    const double dphi[5] = {1, tau * T / (2 * L), tau * v * Tp / (2 * L), 0, Ts * v * T / (2 * L)};
+    const double dT[5] = {0, 0, Tp, 0, 0};
+    const double g1[3] = {s * cs, tau * cs, -tau * s * sn};
+    const double g2[3] = {s * sn, tau * sn, tau * s * cs};
+    const double g3[3] = {s * T / L, tau * T / L, tau * s / L};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        o.dF[0][i] = g1[0] * dtau[i] + g1[1] * ds[i] + g1[2] * dphi[i];
+        o.dF[1][i] = g2[0] * dtau[i] + g2[1] * ds[i] + g2[2] * dphi[i];
+        o.dF[2][i] = g3[0] * dtau[i] + g3[1] * ds[i] + g3[2] * dT[i];
+        o.dF[3][i] = 0;
+    }
+    o.dF[3][3] = tau; o.dF[3][4] = Ts * a;
+    // second derivatives: H = sum_ab G_ab dm_a dm_b^T + sum_a g_a Hess(m_a),  m = (tau, s, phi|T)
+    const double G1[3][3] = {{0, cs, -s * sn}, {cs, 0, -tau * sn}, {-s * sn, -tau * sn, -tau * s * cs}};
+    const double G2[3][3] = {{0, sn, s * cs}, {sn, 0, tau * cs}, {s * cs, tau * cs, -tau * s * sn}};
+    const double G3[3][3] = {{0, T / L, s / L}, {T / L, 0, tau / L}, {s / L, tau / L, 0}};
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const double mi[3] = {dtau[i], ds[i], dphi[i]}, mj[3] = {dtau[j], ds[j], dphi[j]};
+            const double ni[3] = {dtau[i], ds[i], dT[i]}, nj[3] = {dtau[j], ds[j], dT[j]};
+            double h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    h1 += G1[p][q] * mi[p] * mj[q];
+                    h2 += G2[p][q] * mi[p] * mj[q];
+                    h3 += G3[p][q] * ni[p] * nj[q];
+                }
+            // Hess(s): (a,t)=Ts/2 ; Hess(phi): (v,d)=tau Tp/2L, (v,t)=Ts T/2L, (d,d)=tau v T Tp/L, (d,t)=Ts v Tp/2L ; Hess(T): (d,d)=2 T Tp
+            double Hs = ((i == 3 && j == 4) || (i == 4 && j == 3)) ? 0.5 * Ts : 0.0;
+            double Hp = 0;
+            if ((i == 1 && j == 2) || (i == 2 && j == 1)) Hp = tau * Tp / (2 * L);
+            if ((i == 1 && j == 4) || (i == 4 && j == 1)) Hp = Ts * T / (2 * L);
+            if (i == 2 && j == 2) Hp = tau * v * T * Tp / L;
+            if ((i == 2 && j == 4) || (i == 4 && j == 2)) Hp = Ts * v * Tp / (2 * L);
+            double HT = (i == 2 && j == 2) ? 2 * T * Tp : 0.0;
+            h1 += g1[1] * Hs + g1[2] * Hp;
+            h2 += g2[1] * Hs + g2[2] * Hp;
+            h3 += g3[1] * Hs + g3[2] * HT;
+            double h4 = ((i == 3 && j == 4) || (i == 4 && j == 3)) ? Ts : 0.0;
+            HL[i][j] = w[0] * h1 + w[1] * h2 + w[2] * h3 + w[3] * h4;
+        }
+}
+
+// ---------------------------------------------------------------- small dense helpers (compile-time sizes)
+template <int NMAX>
+OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower triangle in, L (strict lower) and D (diag) out
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) {
+        if (j < n) {
+            double d = A[j * NMAX + j];
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) if (k < j) d -= A[j * NMAX + k] * A[j * NMAX + k] * A[k * NMAX + k];
+            if (!(d > 0)) bad = 1;
+            A[j * NMAX + j] = d;
+#pragma unroll
+            for (int i = 0; i < NMAX; i++) if (i > j && i < n) {
+                double s = A[i * NMAX + j];
+#pragma unroll
+                for (int k = 0; k < NMAX; k++) if (k < j) s -= A[i * NMAX + k] * A[j * NMAX + k] * A[k * NMAX + k];
+                A[i * NMAX + j] = s / d;
+            }
+        }
+    }
+    return bad;   // 1 if some pivot is not strictly positive (or NaN)
+}
+template <int NMAX>
+OBCA_FN void ldl_solve(int n, const double *A, double *b) {
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) if (i < n) {
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) if (k < i) b[i] -= A[i * NMAX + k] * b[k];
+    }
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) if (i < n) b[i] /= A[i * NMAX + i];
+#pragma unroll
+    for (int ii = 0; ii < NMAX; ii++) {
+        int i = NMAX - 1 - ii;
+        if (i < n) {
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) if (k > i && k < n) b[i] -= A[k * NMAX + i] * b[k];
+        }
+    }
+}
+OBCA_FN int chol2(double q00, double q10, double q11, double Lc[3]) {
+    if (!(q00 > 0)) return 0;
+    Lc[0] = sqrt(q00); Lc[1] = q10 / Lc[0];
+    double d = q11 - Lc[1] * Lc[1];
+    if (!(d > 0)) return 0;
+    Lc[2] = sqrt(d);
+    return 1;
+}
+OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
+    b0 /= Lc[0]; b1 = (b1 - Lc[1] * b0) / Lc[2];
+    b1 /= Lc[2]; b0 = (b0 - Lc[1] * b1) / Lc[0];
+}
+OBCA_FN void hh_apply(int v, const double *w, double *x) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) s += w[i] * x[i];
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) x[i] -= 2 * s * w[i];
+}
+
+// ---------------------------------------------------------------- one (stage, obstacle) block
+struct ObsIn {
+    int v;
+    double a1[OB_VMAX], a2[OB_VMAX], b[OB_VMAX];
+    double lam[OB_VMAX], zl[OB_VMAX], mu[4], zm[4], y[4];
+    double sl, so, zso, X, Y, psi;
+};
+
+// the four rows c1..c4 (ParkingSignedDist.jl:198-206, c4 has the slack `so` and dmin moved to the left)
+OBCA_FN void obs_rows(const Consts &c, const ObsIn &in, double r[4]) {
+    double p1 = 0, p2 = 0, beta = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    double sn, cs;
+    sincos(in.psi, &sn, &cs);
+    r[0] = p1 * p1 + p2 * p2 - 1;
+    r[1] = in.mu[0] - in.mu[2] + cs * p1 + sn * p2;
+    r[2] = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
+    r[3] = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * c.off) * p1 +
+           (in.Y + sn * c.off) * p2 - beta + in.sl - OB_DMIN - in.so;
+}
+
+struct ObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
+
+struct ObsCond {          // result of the condensation onto the pose
+    double Hpp[6];        // symmetric 3x3: 00 01 02 11 12 22
+    double gz[3];         // Jp^T y   (part of grad L w.r.t. the pose)
+    double gcorr[3];      // condensed right-hand-side correction (subtract from the barrier-form gradient)
+};
+struct ObsStep { double dlam[OB_VMAX], dmu[4], dsl, dso, dy[4]; };
+
+// MODE 0: condense (fills cond, stats) ; MODE 1: back-substitute for a given pose step dp (fills step)
+template <int MODE>
+OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
+                       const double dp[3], ObsStep *step) {
+    const int v = in.v;
+    double p1 = 0, p2 = 0, beta = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    double sn, cs;
+    sincos(in.psi, &sn, &cs);
+    const double off = c.off;
+    double cr[4];
+    cr[0] = p1 * p1 + p2 * p2 - 1;
+    cr[1] = in.mu[0] - in.mu[2] + cs * p1 + sn * p2;
+    cr[2] = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
+    cr[3] = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * off) * p1 +
+            (in.Y + sn * off) * p2 - beta + in.sl - OB_DMIN - in.so;
+    const double *y = in.y;
+    // Jacobians
+    double Jl[4][OB_VMAX];
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) {
+        double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
+        Jl[0][i] = 2 * (p1 * a1 + p2 * a2);
+        Jl[1][i] = cs * a1 + sn * a2;
+        Jl[2][i] = -sn * a1 + cs * a2;
+        Jl[3][i] = (in.X + cs * off) * a1 + (in.Y + sn * off) * a2 - (i < v ? in.b[i] : 0.0);
+    }
+    // rows 2..4 w.r.t. pose (X,Y,psi): only these entries are non-zero
+    const double jp2 = -sn * p1 + cs * p2, jp3 = -cs * p1 - sn * p2;
+    const double Jp[3][3] = {{0, 0, jp2}, {0, 0, jp3}, {p1, p2, off * jp2}};
+    // d rows 2..4 / d mu
+    const double Jmu[3][4] = {{1, 0, -1, 0}, {0, 1, 0, -1}, {-c.g[0], -c.g[1], -c.g[2], -c.g[3]}};
+    // local stationarity residuals, diagonals
+    double Dso = in.zso / in.so + dw, Dsl = 2e4 + dw;
+    double r_so = -y[3] - mu_b / in.so, r_sl = 1e2 + 2e4 * in.sl + y[3];
+    double Dmu[4], r_mu[4], Dlam[OB_VMAX], r_lam[OB_VMAX];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
+        r_mu[i] = jy - mu_b / in.mu[i]; Dmu[i] = in.zm[i] / in.mu[i] + dw;
+        if (MODE == 0) {
+            double rz = fabs(jy - in.zm[i]); if (rz > st->dmax) st->dmax = rz;
+            double cc = in.mu[i] * in.zm[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+            st->sumz += fabs(in.zm[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) {
+        if (i < v) {
+            double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
+            r_lam[i] = jy - mu_b / in.lam[i]; Dlam[i] = in.zl[i] / in.lam[i] + dw;
+            if (MODE == 0) {
+                double rz = fabs(jy - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
+                double cc = in.lam[i] * in.zl[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+                st->sumz += fabs(in.zl[i]);
+            }
+        } else { r_lam[i] = 0; Dlam[i] = 1; }
+    }
+    if (MODE == 0) {
+        double rz = fabs(-y[3] - in.zso); if (rz > st->dmax) st->dmax = rz;
+        if (fabs(r_sl) > st->dmax) st->dmax = fabs(r_sl);
+        double cc = in.so * in.zso; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+        st->sumz += fabs(in.zso);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { if (fabs(cr[r]) > st->pmax) st->pmax = fabs(cr[r]); st->sumy += fabs(y[r]); }
+    }
+    // rows 2..4 after eliminating so, sl, mu:   Jl dlam + Jp dpose - T dy = r234
+    double Tm[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; s_++) {
+            double a_ = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * Jmu[s_][i] / Dmu[i];
+            Tm[r * 3 + s_] = a_ + (r == s_ ? dc : 0.0);
+        }
+    Tm[8] += 1.0 / Dso + 1.0 / Dsl;
+    double r234[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double a_ = -cr[r + 1];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] / Dmu[i];
+        r234[r] = a_;
+    }
+    r234[2] += -r_so / Dso + r_sl / Dsl;
+    int bad = ldl_fact<3>(3, Tm);
+    // W = T^{-1} [Jl234 | Jp234 | r234]
+    double W[3][OB_VMAX + 4];
+#pragma unroll
+    for (int cI = 0; cI < OB_VMAX + 4; cI++) {
+        double col[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) col[r] = cI < OB_VMAX ? Jl[r + 1][cI] : (cI < OB_VMAX + 3 ? Jp[r][cI - OB_VMAX] : r234[r]);
+        ldl_solve<3>(3, Tm, col);
+#pragma unroll
+        for (int r = 0; r < 3; r++) W[r][cI] = col[r];
+    }
+    // (lambda, y1) block in the null space of q = Jl[0]
+    double Kb[OB_VMAX * OB_VMAX], Cp[OB_VMAX][3], rk[OB_VMAX + 1];
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) {
+        double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
+#pragma unroll
+        for (int m = 0; m < OB_VMAX; m++) {
+            double b1 = m < v ? in.a1[m] : 0.0, b2 = m < v ? in.a2[m] : 0.0;
+            double a_ = y[0] * 2 * (a1 * b1 + a2 * b2);
+#pragma unroll
+            for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][m];
+            Kb[i * OB_VMAX + m] = a_;
+        }
+        Kb[i * OB_VMAX + i] += Dlam[i];
+        const double Hlp[3] = {y[3] * a1, y[3] * a2,
+                               y[1] * (-sn * a1 + cs * a2) + y[2] * (-cs * a1 - sn * a2) + y[3] * off * (-sn * a1 + cs * a2)};
+#pragma unroll
+        for (int cI = 0; cI < 3; cI++) {
+            double a_ = Hlp[cI];
+#pragma unroll
+            for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][OB_VMAX + cI];
+            Cp[i][cI] = i < v ? a_ : 0.0;
+        }
+        double a_ = -r_lam[i];
+#pragma unroll
+        for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][OB_VMAX + 3];
+        rk[i] = i < v ? a_ : 0.0;
+    }
+    rk[OB_VMAX] = -cr[0];
+    // Householder Qh q = alpha e1
+    double hw[OB_VMAX], nq = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) nq += Jl[0][i] * Jl[0][i];
+    nq = sqrt(nq);
+    double alpha = Jl[0][0] > 0 ? -nq : nq, nw = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
+    nw = sqrt(nw);
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) hw[i] = nw > 0 ? hw[i] / nw : 0.0;
+    // Ht = Qh Kb Qh
+#pragma unroll
+    for (int j = 0; j < OB_VMAX; j++) {
+        double col[OB_VMAX];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) col[i] = Kb[i * OB_VMAX + j];
+        hh_apply(v, hw, col);
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) Kb[i * OB_VMAX + j] = col[i];
+    }
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) hh_apply(v, hw, Kb + i * OB_VMAX);
+    double a00 = Kb[0], det = a00 * (-dc) - alpha * alpha;
+    if (!(det < 0)) bad = 1;
+    const double Mi0 = -dc / det, Mi1 = -alpha / det, Mi2 = a00 / det;
+    double hc[OB_VMAX - 1], Hr[(OB_VMAX - 1) * (OB_VMAX - 1)];
+#pragma unroll
+    for (int i = 0; i < OB_VMAX - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * OB_VMAX] : 0.0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX - 1; i++)
+#pragma unroll
+        for (int j = 0; j < OB_VMAX - 1; j++) Hr[i * (OB_VMAX - 1) + j] = Kb[(i + 1) * OB_VMAX + (j + 1)] - Mi0 * hc[i] * hc[j];
+    if (v > 1) bad |= ldl_fact<OB_VMAX - 1>(v - 1, Hr);
+    // solve K^{-1} col  for col = [r_lam(v); r_y]
+    auto ksolve = [&](double *col /* OB_VMAX+1 */) {
+        hh_apply(v, hw, col);
+        double g0 = col[0], gy = col[OB_VMAX];
+        double t0 = Mi0 * g0 + Mi1 * gy;
+        double rr[OB_VMAX - 1];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX - 1; i++) rr[i] = (i + 1 < v) ? col[i + 1] - hc[i] * t0 : 0.0;
+        if (v > 1) ldl_solve<OB_VMAX - 1>(v - 1, Hr, rr);
+        double hl = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX - 1; i++) if (i + 1 < v) hl += hc[i] * rr[i];
+        g0 -= hl;
+        col[0] = Mi0 * g0 + Mi1 * gy;
+        col[OB_VMAX] = Mi1 * g0 + Mi2 * gy;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX - 1; i++) col[i + 1] = (i + 1 < v) ? rr[i] : 0.0;
+        hh_apply(v, hw, col);
+    };
+    if (MODE == 0) {
+        st->bad |= bad;
+        // Z = K^{-1} [Cp | rk]
+        double Z[OB_VMAX + 1][4];
+#pragma unroll
+        for (int cI = 0; cI < 4; cI++) {
+            double col[OB_VMAX + 1];
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) col[i] = cI < 3 ? Cp[i][cI] : rk[i];
+            col[OB_VMAX] = cI < 3 ? 0.0 : rk[OB_VMAX];
+            ksolve(col);
+#pragma unroll
+            for (int i = 0; i <= OB_VMAX; i++) Z[i][cI] = col[i];
+        }
+        const double Hpp22 = y[1] * (-cs * p1 - sn * p2) + y[2] * (sn * p1 - cs * p2) + y[3] * off * (-cs * p1 - sn * p2);
+        int q = 0;
+#pragma unroll
+        for (int a_ = 0; a_ < 3; a_++) {
+#pragma unroll
+            for (int b_ = 0; b_ < 3; b_++) if (b_ >= a_) {
+                double s_ = (a_ == 2 && b_ == 2) ? Hpp22 : 0.0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][OB_VMAX + b_];
+#pragma unroll
+                for (int i = 0; i < OB_VMAX; i++) s_ -= Cp[i][a_] * Z[i][b_];
+                cond->Hpp[q++] = s_;
+            }
+            double s_ = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][OB_VMAX + 3];
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) s_ -= Cp[i][a_] * Z[i][3];
+            cond->gcorr[a_] = s_;
+            cond->gz[a_] = Jp[0][a_] * y[1] + Jp[1][a_] * y[2] + Jp[2][a_] * y[3];
+        }
+    } else {
+        double col[OB_VMAX + 1];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) col[i] = rk[i] - (Cp[i][0] * dp[0] + Cp[i][1] * dp[1] + Cp[i][2] * dp[2]);
+        col[OB_VMAX] = rk[OB_VMAX];
+        ksolve(col);
+        double r3[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            // dy234 = T^{-1}(Jl dlam + Jp dp - r234) = W[:, :v] dlam + W[:, v:v+3] dp - W[:, v+3]
+            double a_ = -W[r][OB_VMAX + 3];
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) a_ += W[r][i] * col[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) a_ += W[r][OB_VMAX + i] * dp[i];
+            r3[r] = a_;
+        }
+        step->dy[0] = col[OB_VMAX]; step->dy[1] = r3[0]; step->dy[2] = r3[1]; step->dy[3] = r3[2];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) step->dlam[i] = col[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double jy = Jmu[0][i] * r3[0] + Jmu[1][i] * r3[1] + Jmu[2][i] * r3[2];
+            step->dmu[i] = (-r_mu[i] - jy) / Dmu[i];
+        }
+        step->dsl = (-r_sl - r3[2]) / Dsl;
+        step->dso = (r3[2] - r_so) / Dso;
+    }
+}
+
+// ---------------------------------------------------------------- DualMultWS: one (pose, obstacle) convex problem
+// max d = -g'mu + (A e - b)'lam  s.t. |A'lam|^2<=1, G'mu + R'A'lam = 0, lam,mu>=0   (DualMultWS.jl:52-73)
+// feasible-start primal-dual path following (sigma = 0.1) down to an average complementarity of 1e-9.
+OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double *bj, const double g[4], double ex, double ey,
+                        double cs, double sn, double *lam, double *mu, double *dout) {
+    double Q0[OB_VMAX], Q1[OB_VMAX], cl[OB_VMAX], amax = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) {
+        double x1 = i < v ? a1[i] : 0.0, x2 = i < v ? a2[i] : 0.0;
+        Q0[i] = cs * x1 + sn * x2; Q1[i] = -sn * x1 + cs * x2;
+        cl[i] = x1 * ex + x2 * ey - (i < v ? bj[i] : 0.0);
+        double nr = sqrt(x1 * x1 + x2 * x2); if (nr > amax) amax = nr;
+    }
+    double zl[OB_VMAX], zm[4], zh = 1, eta0 = 0, eta1 = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) { lam[i] = i < v ? 0.5 / (v * fmax(amax, 1e-12)) : 0.0; zl[i] = 1; }
+    {
+        double q0 = 0, q1 = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) { q0 += Q0[i] * lam[i]; q1 += Q1[i] * lam[i]; }
+        mu[0] = 1 + fmax(0.0, -q0); mu[2] = mu[0] + q0; mu[1] = 1 + fmax(0.0, -q1); mu[3] = mu[1] + q1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) zm[i] = 1;
+    }
+    const double Em0[4] = {1, 0, -1, 0}, Em1[4] = {0, 1, 0, -1};
+    for (int it = 0; it < 60; it++) {
+        double p1 = 0, p2 = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) if (i < v) { p1 += a1[i] * lam[i]; p2 += a2[i] * lam[i]; }
+        double h = 1 - p1 * p1 - p2 * p2;
+        double gap = h * zh;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) if (i < v) gap += lam[i] * zl[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) gap += mu[i] * zm[i];
+        double mbar = gap / (v + 5);
+        double gh[OB_VMAX], rl[OB_VMAX], rm[4], rmax = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) {
+            if (i < v) {
+                gh[i] = -2 * (p1 * a1[i] + p2 * a2[i]);
+                rl[i] = -cl[i] + Q0[i] * eta0 + Q1[i] * eta1 - zl[i] - zh * gh[i];
+                if (fabs(rl[i]) > rmax) rmax = fabs(rl[i]);
+            } else { gh[i] = 0; rl[i] = 0; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { rm[i] = g[i] + Em0[i] * eta0 + Em1[i] * eta1 - zm[i]; if (fabs(rm[i]) > rmax) rmax = fabs(rm[i]); }
+        if (mbar < 1e-9 && rmax < 1e-9) break;
+        double mt = 0.1 * mbar;
+        double Hl[OB_VMAX * OB_VMAX], bl[OB_VMAX], Dm[4], bm[4];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) {
+#pragma unroll
+            for (int j = 0; j < OB_VMAX; j++)
+                Hl[i * OB_VMAX + j] = (i < v && j < v) ? zh * 2 * (a1[i] * a1[j] + a2[i] * a2[j]) + (zh / h) * gh[i] * gh[j] : 0.0;
+            if (i < v) { Hl[i * OB_VMAX + i] += zl[i] / lam[i]; bl[i] = -(rl[i] + zl[i] - mt / lam[i] + (zh - mt / h) * gh[i]); }
+            else bl[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { Dm[i] = zm[i] / mu[i]; bm[i] = -(rm[i] + zm[i] - mt / mu[i]); }
+        if (ldl_fact<OB_VMAX>(v, Hl)) break;
+        double HiQ0[OB_VMAX], HiQ1[OB_VMAX], Hib[OB_VMAX];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) { HiQ0[i] = Q0[i]; HiQ1[i] = Q1[i]; Hib[i] = bl[i]; }
+        ldl_solve<OB_VMAX>(v, Hl, HiQ0); ldl_solve<OB_VMAX>(v, Hl, HiQ1); ldl_solve<OB_VMAX>(v, Hl, Hib);
+        double S00 = 0, S01 = 0, S11 = 0, rs0 = 0, rs1 = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) if (i < v) {
+            S00 += Q0[i] * HiQ0[i]; S01 += Q0[i] * HiQ1[i]; S11 += Q1[i] * HiQ1[i];
+            rs0 += Q0[i] * Hib[i]; rs1 += Q1[i] * Hib[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            S00 += Em0[i] * Em0[i] / Dm[i]; S01 += Em0[i] * Em1[i] / Dm[i]; S11 += Em1[i] * Em1[i] / Dm[i];
+            rs0 += Em0[i] * bm[i] / Dm[i]; rs1 += Em1[i] * bm[i] / Dm[i];
+        }
+        double Lc[3];
+        if (!chol2(S00, S01, S11, Lc)) break;
+        double de0 = rs0, de1 = rs1;
+        chol2_solve(Lc, de0, de1);
+        double dl[OB_VMAX], dm[4], dzl[OB_VMAX], dzm[4], ghd = 0;
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) {
+            dl[i] = i < v ? Hib[i] - HiQ0[i] * de0 - HiQ1[i] * de1 : 0.0;
+            dzl[i] = i < v ? mt / lam[i] - zl[i] - zl[i] / lam[i] * dl[i] : 0.0;
+            ghd += gh[i] * dl[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dm[i] = (bm[i] - Em0[i] * de0 - Em1[i] * de1) / Dm[i];
+            dzm[i] = mt / mu[i] - zm[i] - zm[i] / mu[i] * dm[i];
+        }
+        double dzh = mt / h - zh - zh / h * ghd;
+        double a = 1, tb = 0.995, cc;
+#define OB_FTB(val, dv) { cc = (dv) < 0 ? -tb * (val) / (dv) : 1e300; if (cc < a) a = cc; }
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) if (i < v) { OB_FTB(lam[i], dl[i]); OB_FTB(zl[i], dzl[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { OB_FTB(mu[i], dm[i]); OB_FTB(zm[i], dzm[i]); }
+        OB_FTB(zh, dzh);
+#undef OB_FTB
+        for (int bt = 0; bt < 60; bt++) {
+            double q1 = 0, q2 = 0;
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) if (i < v) { q1 += a1[i] * (lam[i] + a * dl[i]); q2 += a2[i] * (lam[i] + a * dl[i]); }
+            if (1 - q1 * q1 - q2 * q2 >= (1 - tb) * h) break;
+            a *= 0.7;
+        }
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) if (i < v) { lam[i] += a * dl[i]; zl[i] += a * dzl[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { mu[i] += a * dm[i]; zm[i] += a * dzm[i]; }
+        zh += a * dzh; eta0 += a * de0; eta1 += a * de1;
+    }
+    double dv = 0;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) if (i < v) dv += cl[i] * lam[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) dv -= g[i] * mu[i];
+    *dout = dv;
+}
+
+}  // namespace obca

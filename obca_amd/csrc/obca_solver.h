@@ -1,0 +1,1032 @@
+// obca_solver.h -- one OBCA parking NLP instance solved by ONE 64-lane wavefront (gfx950).
+//
+// Programming model: the whole solve runs inside one workgroup of exactly 64 threads (one wave).  Code outside a
+// PAR(lane){...} region is wave-uniform (every lane computes the same scalars); PAR regions distribute work items
+// (stages, (stage,obstacle) blocks, matrix entries) over the 64 lanes; data crosses lanes only through LDS (`Shared`) or
+// the per-instance global scratch, never through registers held across a SYNC().
+//   * (stage, obstacle) blocks  -> one lane per block        (condensation / back-substitution, obca_model.h)
+//   * stages                    -> one lane per stage        (bicycle model derivatives, costs, bounds)
+//   * Riccati recursion         -> sequential in the stage index, the 8x(8+6) extended stage matrices spread over the lanes
+//   * reductions (norms, step lengths, objective) -> 64-lane butterfly
+// The algorithm is the primal-dual interior-point method stated in DESIGN.md (IPOPT's Algorithm A with the option
+// values of ParkingSignedDist.jl:41-43).
+//
+// The same source is compiled by tests/emu (g++, -DOBCA_EMU) where PAR is a plain loop over 64 lanes: that build exists
+// only so that the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
+#pragma once
+#ifdef OBCA_EMU
+#define OBCA_FN static inline
+#define OBCA_HD static inline
+#define PAR(lane) for (int lane = 0; lane < 64; ++lane)
+#define SYNC() ((void)0)
+#define LANE0 1
+#else
+#define OBCA_FN __device__ __forceinline__
+#define OBCA_HD __host__ __device__ inline
+#define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define SYNC() __syncthreads()
+#define LANE0 (threadIdx.x == 0)
+#endif
+#include "obca_model.h"
+
+namespace obca {
+
+#define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
+#define OB_AS 88     // doubles per assembled stage record
+#define OB_RS 116    // doubles per Riccati stage record
+#define OB_OC 12     // doubles per condensed obstacle record
+#define OB_HDR 168   // doubles of problem header (scalars + A + b) in front of rx, ry, ryaw
+// header indices
+#define PH_TS 0
+#define PH_L 1
+#define PH_G 2
+#define PH_OFF 6
+#define PH_XL 7
+#define PH_XU 11
+#define PH_X0 15
+#define PH_XF 19
+#define PH_FIX 23
+#define PH_NOB 24
+#define PH_M 25
+#define PH_VOB 26
+#define PH_ROFF 36
+#define PH_A 48
+#define PH_B 128
+// stage record
+#define AS_H 0
+#define AS_HB 36
+#define AS_HT 44
+#define AS_DF 52
+#define AS_DD 72
+#define AS_SIG 76
+#define AS_RG 77
+#define AS_GG 78
+#define AS_DSS 81
+#define AS_RSS 82
+// Riccati record
+#define RS_K 0
+#define RS_KF 12
+#define RS_PX 24
+#define RS_PV 48
+#define RS_CL 72     // closed loop: Acl (6x6) then bcl (6)
+#define OB_FILT 224
+
+struct Opts {
+    double tol; int max_iter;
+    double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
+    double dw_min, dw0, dw_max, kw_inc0, kw_inc, kw_dec, dc_bar, kappa_c;
+    double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
+    double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
+};
+
+struct Lay {
+    int x, u, t, lam, mu, sl, so, ss, pi, nu, yg, yo, zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, nprimal, len;
+};
+OBCA_HD void make_layout(int N, int nOb, int M, Lay &l) {
+    int N1 = N + 1, o = 0;
+    l.x = o; o += 4 * N1; l.u = o; o += 2 * N; l.t = o; o += 1;
+    l.lam = o; o += M * N1; l.mu = o; o += 4 * nOb * N1; l.sl = o; o += nOb * N1;
+    l.so = o; o += nOb * N1; l.ss = o; o += N; l.nprimal = o;
+    l.pi = o; o += 4 * N; l.nu = o; o += 4; l.yg = o; o += N; l.yo = o; o += 4 * nOb * N1;
+    l.zxL = o; o += 4 * N1; l.zxU = o; o += 4 * N1; l.zuL = o; o += 2 * N; l.zuU = o; o += 2 * N;
+    l.ztL = o; o += 1; l.ztU = o; o += 1; l.zlam = o; o += M * N1; l.zmu = o; o += 4 * nOb * N1;
+    l.zso = o; o += nOb * N1; l.zssL = o; o += N; l.zssU = o; o += N; l.len = o;
+}
+
+struct Shared {
+    double hdr[OB_HDR];
+    double red[16][64];
+    double rec[2][OB_AS];      // double-buffered raw stage record (Riccati backward)
+    double Pn[36], pn[6 * OB_NC], H[64], hc[8 * OB_NC], Fm[48], off[6 * OB_NC], That[6 * 14], Qhat[8 * 14];
+    double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
+    double filt[OB_FILT][2];
+    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX];
+};
+
+struct Inst {              // uniform: pointers of this instance
+    const double *prob;    // header + rx, ry, ryaw
+    double *z, *d, *as, *rs, *oc, *traj;
+    Consts c; Lay l;
+};
+
+// ---------------------------------------------------------------- reductions (64-lane butterfly; same order in the emulation)
+OBCA_FN double red_sum(const double *r) {
+#ifdef OBCA_EMU
+    double a[64], b[64];
+    for (int i = 0; i < 64; i++) a[i] = r[i];
+    for (int o = 32; o > 0; o >>= 1) { for (int i = 0; i < 64; i++) b[i] = a[i] + a[i ^ o]; for (int i = 0; i < 64; i++) a[i] = b[i]; }
+    return a[0];
+#else
+    double v = r[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
+OBCA_FN double red_max(const double *r) {   // NaN-propagating max
+#ifdef OBCA_EMU
+    double m = r[0]; for (int i = 1; i < 64; i++) m = (r[i] > m || r[i] != r[i]) ? r[i] : m; return m;
+#else
+    double v = r[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = (w > v || w != w) ? w : v; }
+    return v;
+#endif
+}
+OBCA_FN double red_min(const double *r) {
+#ifdef OBCA_EMU
+    double m = r[0]; for (int i = 1; i < 64; i++) m = (r[i] < m) ? r[i] : m; return m;
+#else
+    double v = r[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = (w < v) ? w : v; }
+    return v;
+#endif
+}
+
+OBCA_FN void load_obs(const Inst &I, const Shared &sh, const double *z, int k, int j, ObsIn &in) {
+    const Lay &l = I.l; const int nOb = I.c.nOb, M = I.c.M;
+    const int r0 = sh.roff[j], v = sh.vOb[j], bo = k * nOb + j;
+    in.v = v;
+#pragma unroll
+    for (int i = 0; i < OB_VMAX; i++) {
+        bool on = i < v;
+        in.a1[i] = on ? sh.hdr[PH_A + 2 * (r0 + i)] : 0.0; in.a2[i] = on ? sh.hdr[PH_A + 2 * (r0 + i) + 1] : 0.0;
+        in.b[i] = on ? sh.hdr[PH_B + r0 + i] : 0.0;
+        in.lam[i] = on ? z[l.lam + k * M + r0 + i] : 1.0; in.zl[i] = on ? z[l.zlam + k * M + r0 + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { in.mu[i] = z[l.mu + 4 * bo + i]; in.zm[i] = z[l.zmu + 4 * bo + i]; in.y[i] = z[l.yo + 4 * bo + i]; }
+    in.sl = z[l.sl + bo]; in.so = z[l.so + bo]; in.zso = z[l.zso + bo];
+    in.X = z[l.x + 4 * k]; in.Y = z[l.x + 4 * k + 1]; in.psi = z[l.x + 4 * k + 2];
+}
+
+struct B2 { double Sig, gz, gb; };
+OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmu, double &sumz) {
+    double dL = v - lo, dU = hi - v;
+    B2 r; r.Sig = mult * (zL / dL + zU / dU); r.gz = mult * (-zL + zU); r.gb = mult * (-mu / dL + mu / dU);
+    double c1 = dL * zL, c2 = dU * zU;
+    if (fabs(c1) > c0) c0 = fabs(c1);
+    if (fabs(c2) > c0) c0 = fabs(c2);
+    if (fabs(c1 - mu) > cmu) cmu = fabs(c1 - mu);
+    if (fabs(c2 - mu) > cmu) cmu = fabs(c2 - mu);
+    sumz += fabs(zL) + fabs(zU);
+    return r;
+}
+OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; return a_ * 8 - a_ * (a_ - 1) / 2 + (b_ - a_); }
+
+struct AsmOut { int ok; double dinf, pinf, cinf0, cinfmu, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };
+
+// ---------------------------------------------------------------- assemble the condensed Newton system
+OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc, AsmOut &out) {
+    const Consts &c = I.c; const Lay &l = I.l;
+    const int N = c.N, nOb = c.nOb, M = c.M;
+    const double *z = I.z;
+    const double t = z[l.t], q = t * c.Ts;
+    // ---- (a) obstacle blocks: one lane per (stage, obstacle)
+    PAR(lane) {
+        ObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        double fsl = 0, th = 0, bar = 0;
+        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+            int k = it / nOb, j = it - k * nOb;
+            ObsIn in; load_obs(I, sh, z, k, j, in);
+            ObsCond cd;
+            obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            double *o = I.oc + (size_t)it * OB_OC;
+#pragma unroll
+            for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
+            fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
+            double r[4]; obs_rows(c, in, r);
+            th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) bar += log(in.lam[i]);
+            bar += log(in.mu[0]) + log(in.mu[1]) + log(in.mu[2]) + log(in.mu[3]) + log(in.so);
+        }
+        sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
+        sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
+        sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
+    }
+    SYNC();
+    double dinf = red_max(sh.red[0]), pinf = red_max(sh.red[1]), c0 = red_max(sh.red[2]), cmu = red_max(sh.red[3]);
+    double sumz = red_sum(sh.red[4]), sumy = red_sum(sh.red[5]), f = red_sum(sh.red[6]), th1 = red_sum(sh.red[7]);
+    double bar = red_sum(sh.red[8]);
+    int ok = !(red_max(sh.red[9]) > 0.5);
+    SYNC();
+    // ---- (b) stages: one lane per stage
+    PAR(lane) {
+        double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
+        for (int k = lane; k <= N; k += 64) {
+            double H[8][8], hz[8], hb[8], Ht[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { hz[i] = hb[i] = Ht[i] = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) H[i][j] = 0; }
+            double x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i];
+            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            const double gx[4] = {2e-3 * (x[0] - rx), 2e-3 * (x[1] - ry), 2 * c.wpsi * (x[2] - ryaw), 2e-4 * x[3]};
+            const double hx[4] = {2e-3, 2e-3, 2 * c.wpsi, 2e-4};
+            lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                hz[i] = gx[i]; hb[i] = gx[i];
+                double Sig = 0;
+                if (i != 2 && k >= 1) {
+                    B2 b = bound2(x[i], c.xl[i], c.xu[i], z[l.zxL + 4 * k + i], z[l.zxU + 4 * k + i], mu, 1, lc0, lcmu, lsz);
+                    Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb;
+                    lbar += log(x[i] - c.xl[i]) + log(c.xu[i] - x[i]);
+                }
+                H[i][i] = hx[i] + Sig + dw;
+            }
+            for (int j = 0; j < nOb; j++) {   // condensed obstacle contributions of this stage
+                const double *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
+                H[0][0] += o[0]; H[0][1] += o[1]; H[0][2] += o[2]; H[1][1] += o[3]; H[1][2] += o[4]; H[2][2] += o[5];
+                H[1][0] += o[1]; H[2][0] += o[2]; H[2][1] += o[4];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { hz[i] += o[6 + i]; hb[i] += o[6 + i] - o[9 + i]; }
+            }
+            double *rec = I.as + (size_t)k * OB_AS;
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double e = fabs(x[i] - c.xF[i]); if (e > pmax) pmax = e; lth += e;
+                    double r = z[l.pi + 4 * (N - 1) + i] + z[l.nu + i];
+                    hz[i] += r; hb[i] += r;
+                    if (fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                    lsy += fabs(z[l.nu + i]);
+                }
+            } else {
+                const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
+                const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
+                const double cu[2] = {0.01, c.wa};
+                const double rr = 0.1 / (q * q), e1 = u[0] - w[0], e2 = u[1] - w[1], rv = rr * (e1 * e1 + e2 * e2);
+                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rv;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const double ei = i ? e2 : e1, lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
+                    const double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
+                    hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
+                    B2 b = bound2(u[i], lo, hi, z[l.zuL + 2 * k + i], z[l.zuU + 2 * k + i], mu, 1, lc0, lcmu, lsz);
+                    hz[6 + i] += b.gz; hb[6 + i] += b.gb;
+                    lbar += log(u[i] - lo) + log(hi - u[i]);
+                    H[6 + i][6 + i] += 2 * cu[i] + 2 * rr + b.Sig + dw;
+                    H[4 + i][4 + i] += 2 * rr; H[4 + i][6 + i] += -2 * rr; H[6 + i][4 + i] += -2 * rr;
+                    if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei / t; Ht[4 + i] += 4 * rr * ei / t; }
+                }
+                if (!c.fixTime) { lgtz += -2 * rv / t; lgtb += -2 * rv / t; lHtt += 6 * rv / (t * t); }
+                {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
+                    const double g = (w[0] - u[0]) / q, ss = z[l.ss + k], yg = z[l.yg + k];
+                    const double gg[3] = {1 / q, -1 / q, c.fixTime ? 0.0 : -g / t};
+                    B2 b = bound2(ss, -OB_SSB, OB_SSB, z[l.zssL + k], z[l.zssU + k], mu, 1, lc0, lcmu, lsz);
+                    lbar += log(ss + OB_SSB) + log(OB_SSB - ss);
+                    lsy += fabs(yg);
+                    const double rz = -yg + b.gz, rb = -yg + b.gb;
+                    if (fabs(rz) > dmax) dmax = fabs(rz);
+                    const double res = g - ss; if (fabs(res) > pmax) pmax = fabs(res); lth += fabs(res);
+                    const double Dss = b.Sig + dw, sig = 1.0 / (1.0 / Dss + dc), rg = res + rb / Dss;
+                    rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
+                    rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
+                    const int id[2] = {4, 6};
+#pragma unroll
+                    for (int a_ = 0; a_ < 2; a_++) {
+                        hz[id[a_]] += gg[a_] * yg; hb[id[a_]] += gg[a_] * (yg + sig * rg);
+#pragma unroll
+                        for (int b_ = 0; b_ < 2; b_++) H[id[a_]][id[b_]] += sig * gg[a_] * gg[b_];
+                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + yg * (a_ == 0 ? -1 / (q * t) : 1 / (q * t));
+                    }
+                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g / (t * t); }
+                }
+                {   // dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
+                    DynOut dy; double HL[5][5], pi[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pi[i] = z[l.pi + 4 * k + i];
+                    dyn_derivs(c, x, u, t, pi, dy, HL);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+#pragma unroll
+                        for (int j = 0; j < 5; j++) rec[AS_DF + 5 * i + j] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
+                        double r = z[l.x + 4 * (k + 1) + i] - dy.F[i];
+                        rec[AS_DD + i] = -r; if (fabs(r) > pmax) pmax = fabs(r); lth += fabs(r);
+                        lsy += fabs(pi[i]);
+                    }
+                    const int id[4] = {2, 3, 6, 7};
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; a_++) {
+#pragma unroll
+                        for (int b_ = 0; b_ < 4; b_++) H[id[a_]][id[b_]] += -HL[a_][b_];
+                        if (!c.fixTime) Ht[id[a_]] += -HL[a_][4];
+                    }
+                    if (!c.fixTime) lHtt += -HL[4][4];
+                    // J^T pi: x_k rows get +pi_{k-1} - A_k^T pi_k ; u_k rows -B_k^T pi_k ; t gets -Ft^T pi
+                    double ATpi[4] = {pi[0], pi[1], pi[2], pi[3]};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { ATpi[2] += dy.dF[i][0] * pi[i]; ATpi[3] += dy.dF[i][1] * pi[i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        double r = (k >= 1 ? z[l.pi + 4 * (k - 1) + i] : 0.0) - ATpi[i];
+                        hz[i] += r; hb[i] += r;
+                        if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        double r = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) r -= dy.dF[j][2 + i] * pi[j];
+                        hz[6 + i] += r; hb[6 + i] += r;
+                    }
+                    if (!c.fixTime) {
+                        double r = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) r += dy.dF[j][4] * pi[j];
+                        lgtz -= r; lgtb -= r;
+                    }
+                }
+                {   // dual infeasibility of u_k: own part + copy part living in stage k+1
+                    double wn[2] = {0, 0};
+                    if (k + 1 < N) {
+                        wn[0] = -2 * rr * (z[l.u + 2 * k + 2] - u[0]) + (1 / q) * z[l.yg + k + 1];
+                        wn[1] = -2 * rr * (z[l.u + 2 * k + 3] - u[1]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; if (fabs(tot) > dmax) dmax = fabs(tot); }
+                }
+            }
+            int qn = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (j >= i) rec[AS_H + (qn++)] = H[i][j];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; rec[AS_HT + i] = Ht[i]; }
+        }
+        sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmu;
+        sh.red[4][lane] = lsz; sh.red[5][lane] = lsy; sh.red[6][lane] = lf; sh.red[7][lane] = lth;
+        sh.red[8][lane] = lbar; sh.red[9][lane] = lHtt; sh.red[10][lane] = lgtb; sh.red[11][lane] = lgtz;
+    }
+    SYNC();
+    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmu = fmax(cmu, red_max(sh.red[3]));
+    sumz += red_sum(sh.red[4]); sumy += red_sum(sh.red[5]); f += red_sum(sh.red[6]); th1 += red_sum(sh.red[7]);
+    bar += red_sum(sh.red[8]);
+    double Htt = red_sum(sh.red[9]), gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
+    SYNC();
+    int nb = 6 * N + 4 * N + 2 * N + (M + 5 * nOb) * (N + 1);
+    int nm = 4 * N + 4 + N + 4 * nOb * (N + 1);
+    if (!c.fixTime) {
+        double d0 = 0, d1 = 0, d2 = 0;
+        B2 b = bound2(t, OB_TL, OB_TU, z[l.ztL], z[l.ztU], mu, N + 1, d0, d1, d2);
+        c0 = fmax(c0, d0); cmu = fmax(cmu, d1); sumz += (N + 1) * (fabs(z[l.ztL]) + fabs(z[l.ztU]));
+        nb += 2 * (N + 1);
+        double gf = (N + 1) * (0.5 + 2 * t);
+        Htt += 2.0 * (N + 1) + b.Sig + dw;
+        gtb += gf + b.gb; gtz += gf + b.gz;
+        f += (N + 1) * (0.5 * t + t * t);
+        bar += (N + 1) * (log(t - OB_TL) + log(OB_TU - t));
+        dinf = fmax(dinf, fabs(gtz));
+    } else { Htt = 1.0; gtb = 0; }
+    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
+    out.f = f; out.th1 = th1; out.bar = bar; out.Htt = Htt; out.gtb = gtb; out.nb = nb; out.nm = nm;
+}
+
+// ---------------------------------------------------------------- Riccati backward sweep
+// Stage k is condensed onto (x_k, w_k=u_{k-1}); six right-hand sides (main, t, nu1..4) ride along as extra columns and the
+// bilinear constants B(a,b) of the cost-to-go give every entry of the 5x5 (t, nu) border without a forward pass per column.
+// Returns 1 if every 2x2 input block is positive definite.
+OBCA_FN void pair_of(int p, int &a_, int &b_) { a_ = 0; b_ = 0; for (int aa = 0, cnt = 0; aa < OB_NC; aa++) for (int bb = aa; bb < OB_NC; bb++, cnt++) if (cnt == p) { a_ = aa; b_ = bb; } }
+
+OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
+    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N;
+    const double *z = I.z;
+    PAR(lane) {   // terminal cost-to-go + prefetch of record N-1
+        const double *rec = I.as + (size_t)N * OB_AS;
+        if (lane < 36) {
+            int i = lane / 6, j = lane % 6;
+            double v = rec[AS_H + hidx(i, j)];
+            if (i == j && i < 4) v += rho;
+            sh.Pn[lane] = v; sh.Bm[lane] = 0;
+        }
+        if (lane < 6) {
+            double e = lane < 4 ? -(z[l.x + 4 * N + lane] - c.xF[lane]) : 0.0;
+            sh.pn[lane * OB_NC + 0] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);
+            sh.pn[lane * OB_NC + 1] = rec[AS_HT + lane];
+            for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
+        }
+        const double *r1 = I.as + (size_t)(N - 1) * OB_AS;
+        for (int i = lane; i < OB_AS; i += 64) sh.rec[(N - 1) & 1][i] = r1[i];
+    }
+    SYNC();
+    for (int k = N - 1; k >= 0; k--) {
+        const double *rec = sh.rec[k & 1];
+        PAR(lane) {   // unpack stage data; prefetch record k-1 into the other buffer
+            double pf0 = 0, pf1 = 0;
+            if (k > 0) { const double *r1 = I.as + (size_t)(k - 1) * OB_AS; pf0 = r1[lane]; if (lane + 64 < OB_AS) pf1 = r1[lane + 64]; }
+            { int i = lane >> 3, j = lane & 7; sh.H[lane] = rec[AS_H + hidx(i, j)]; }
+            if (lane < 48) {   // Fm[a][j] : (x+,w+) <- (x,w,u)
+                int a_ = lane >> 3, j = lane & 7; double v = 0;
+                if (a_ < 4) {
+                    if (j < 4) v = (a_ == j) ? 1.0 : 0.0;
+                    if (j == 2) v += rec[AS_DF + 5 * a_ + 0];
+                    if (j == 3) v += rec[AS_DF + 5 * a_ + 1];
+                    if (j == 6) v = rec[AS_DF + 5 * a_ + 2];
+                    if (j == 7) v = rec[AS_DF + 5 * a_ + 3];
+                } else v = (j == a_ + 2) ? 1.0 : 0.0;
+                sh.Fm[lane] = v;
+                int i = lane / OB_NC, cc = lane % OB_NC;
+                sh.hc[lane] = cc == 0 ? rec[AS_HB + i] : (cc == 1 ? rec[AS_HT + i] : 0.0);
+            }
+            if (lane < 36) { int i = lane / OB_NC, cc = lane % OB_NC;
+                sh.off[lane] = (i < 4) ? (cc == 0 ? rec[AS_DD + i] : (cc == 1 ? rec[AS_DF + 5 * i + 4] : 0.0)) : 0.0; }
+            if (k > 0) { sh.rec[(k - 1) & 1][lane] = pf0; if (lane + 64 < OB_AS) sh.rec[(k - 1) & 1][lane + 64] = pf1; }
+        }
+        SYNC();
+        PAR(lane) {   // That = Pn [Fm | off] + [0 | pn]      6 x 14
+            for (int it = lane; it < 84; it += 64) {
+                int i = it / 14, cc = it % 14; double s_ = 0;
+                if (cc < 8) { for (int a_ = 0; a_ < 6; a_++) s_ += sh.Pn[i * 6 + a_] * sh.Fm[a_ * 8 + cc]; }
+                else { int col = cc - 8; s_ = sh.pn[i * OB_NC + col]; for (int a_ = 0; a_ < 6; a_++) s_ += sh.Pn[i * 6 + a_] * sh.off[a_ * OB_NC + col]; }
+                sh.That[it] = s_;
+            }
+        }
+        SYNC();
+        PAR(lane) {   // Qhat = [H | hc] + Fm^T That  (8 x 14) ; static part of the bilinear update (21 pairs)
+            for (int it = lane; it < 112 + 21; it += 64) {
+                if (it < 112) {
+                    int i = it / 14, cc = it % 14;
+                    double s_ = cc < 8 ? sh.H[i * 8 + cc] : sh.hc[i * OB_NC + (cc - 8)];
+                    for (int a_ = 0; a_ < 6; a_++) s_ += sh.Fm[a_ * 8 + i] * sh.That[a_ * 14 + cc];
+                    sh.Qhat[it] = s_;
+                } else {
+                    int p = it - 112, a_, b_; pair_of(p, a_, b_);
+                    double v = 0;   // off_a . (P off_b + p_b) + off_b . p_a
+                    for (int i = 0; i < 4; i++) v += sh.off[i * OB_NC + a_] * sh.That[i * 14 + 8 + b_] + sh.off[i * OB_NC + b_] * sh.pn[i * OB_NC + a_];
+                    sh.sB[p] = v;
+                }
+            }
+        }
+        SYNC();
+        double Lc[3];
+        if (!chol2(sh.Qhat[6 * 14 + 6], sh.Qhat[7 * 14 + 6], sh.Qhat[7 * 14 + 7], Lc)) return 0;
+        double *ro = I.rs + (size_t)k * OB_RS;
+        PAR(lane) {   // eliminate u_k: new Pn (6x6), pn (6xNC), gains, bilinear constants
+            for (int it = lane; it < 72 + 21; it += 64) {
+                if (it < 72) {
+                    int i = it / 12, cc = it % 12, qc = cc < 6 ? cc : cc + 2;
+                    double k0 = -sh.Qhat[6 * 14 + qc], k1 = -sh.Qhat[7 * 14 + qc];
+                    chol2_solve(Lc, k0, k1);
+                    double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
+                    if (cc < 6) { sh.Pn[i * 6 + cc] = v; if (i < 4) ro[RS_PX + i * 6 + cc] = v; if (i == 0) { ro[RS_K + cc] = k0; ro[RS_K + 6 + cc] = k1; } }
+                    else { int col = cc - 6; sh.pn[i * OB_NC + col] = v; if (i < 4) ro[RS_PV + i * OB_NC + col] = v; if (i == 0) { ro[RS_KF + col] = k0; ro[RS_KF + OB_NC + col] = k1; } }
+                } else {
+                    int p = it - 72, a_, b_; pair_of(p, a_, b_);
+                    double k0 = -sh.Qhat[6 * 14 + 8 + b_], k1 = -sh.Qhat[7 * 14 + 8 + b_];
+                    chol2_solve(Lc, k0, k1);
+                    double v = sh.sB[p] + sh.Qhat[6 * 14 + 8 + a_] * k0 + sh.Qhat[7 * 14 + 8 + a_] * k1;
+                    sh.Bm[a_ * 6 + b_] += v; if (a_ != b_) sh.Bm[b_ * 6 + a_] += v;
+                }
+            }
+        }
+        SYNC();
+    }
+    return 1;
+}
+
+// ---------------------------------------------------------------- border solve + forward sweep + back-substitution
+struct StepOut { int ok; double ap, az, gd; };
+
+OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
+    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const double *z = I.z; double *d = I.d;
+    so.ok = 1;
+    // ---- 5x5 border in (dt, nu): all entries are bilinear constants of the Riccati value function
+    double dt, nu[4];
+    {
+        const double *B = sh.Bm;
+        double e[4];
+        for (int i = 0; i < 4; i++) e[i] = -(z[l.x + 4 * N + i] - c.xF[i]);
+        double att = A.Htt + B[1 * 6 + 1], rt = -A.gtb - B[1 * 6 + 0];
+        double S[16], col[4], colr[4];
+        for (int a_ = 0; a_ < 4; a_++) {
+            for (int b_ = 0; b_ < 4; b_++) S[a_ * 4 + b_] = -B[(2 + a_) * 6 + (2 + b_)];
+            col[a_] = -B[(2 + a_) * 6 + 1]; colr[a_] = -(e[a_] - B[(2 + a_) * 6 + 0]);
+        }
+        if (ldl_fact<4>(4, S)) so.ok = 0;
+        ldl_solve<4>(4, S, col); ldl_solve<4>(4, S, colr);
+        double piv = att, rr = rt;
+        for (int a_ = 0; a_ < 4; a_++) { piv -= B[1 * 6 + 2 + a_] * col[a_]; rr -= B[1 * 6 + 2 + a_] * colr[a_]; }
+        if (c.fixTime) { dt = 0; for (int a_ = 0; a_ < 4; a_++) nu[a_] = colr[a_]; }
+        else {
+            if (!(piv > 0)) so.ok = 0;
+            dt = rr / piv;
+            for (int a_ = 0; a_ < 4; a_++) nu[a_] = colr[a_] - col[a_] * dt;
+        }
+    }
+    if (!so.ok) return;
+    const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
+    // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
+    PAR(lane) {
+        for (int k = lane; k < N; k += 64) {
+            const double *rec = I.as + (size_t)k * OB_AS; double *ro = I.rs + (size_t)k * OB_RS;
+            double K0[6], K1[6], kf0 = 0, kf1 = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
+#pragma unroll
+            for (int cc = 0; cc < OB_NC; cc++) { kf0 += ro[RS_KF + cc] * coef[cc]; kf1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double b0 = rec[AS_DF + 5 * i + 2], b1 = rec[AS_DF + 5 * i + 3];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
+                    if (j == 2) a_ += rec[AS_DF + 5 * i + 0];
+                    if (j == 3) a_ += rec[AS_DF + 5 * i + 1];
+                    ro[RS_CL + i * 6 + j] = a_ + b0 * K0[j] + b1 * K1[j];
+                }
+                ro[RS_CL + 36 + i] = rec[AS_DD + i] + dt * rec[AS_DF + 5 * i + 4] + b0 * kf0 + b1 * kf1;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) { ro[RS_CL + 24 + j] = K0[j]; ro[RS_CL + 30 + j] = K1[j]; }
+            ro[RS_CL + 40] = kf0; ro[RS_CL + 41] = kf1;
+        }
+        if (lane < 8) { sh.s[0][lane] = 0; sh.s[1][lane] = 0; }
+    }
+    SYNC();
+    PAR(lane) { if (lane < 42) sh.cl[0][lane] = (I.rs)[RS_CL + lane]; }
+    SYNC();
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential; stage data double-buffered through LDS)
+    for (int k = 0; k < N; k++) {
+        PAR(lane) {
+            double pf = 0;
+            if (k + 1 < N && lane < 42) pf = (I.rs + (size_t)(k + 1) * OB_RS)[RS_CL + lane];
+            if (lane < 6) {
+                const double *cl = sh.cl[k & 1], *s = sh.s[k & 1];
+                double v = cl[36 + lane];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s[j];
+                sh.s[(k + 1) & 1][lane] = v;
+                I.traj[(size_t)(k + 1) * 6 + lane] = v;
+            }
+            if (k + 1 < N && lane < 42) sh.cl[(k + 1) & 1][lane] = pf;
+        }
+        SYNC();
+    }
+    // ---- stage-parallel: primal steps of x,u; costates; bound terms of x,u ; steering rows
+    PAR(lane) {
+        double ap = 1.0, az = 1.0, gd = 0, cc_;
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < ap) ap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < az) az = cc_; }
+        const double t = z[l.t], q = t * c.Ts;
+        for (int k = lane; k <= N; k += 64) {
+            double s[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) s[i] = k ? I.traj[(size_t)k * 6 + i] : 0.0;
+            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            double x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; d[l.x + 4 * k + i] = s[i]; }
+            gd += 2e-3 * (x[0] - rx) * s[0] + 2e-3 * (x[1] - ry) * s[1] + 2 * c.wpsi * (x[2] - ryaw) * s[2] + 2e-4 * x[3] * s[3];
+            if (k >= 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (i != 2) {
+                    double dL = x[i] - c.xl[i], dU = c.xu[i] - x[i], zL = z[l.zxL + 4 * k + i], zU = z[l.zxU + 4 * k + i];
+                    gd += (-mu / dL + mu / dU) * s[i];
+                    FTBP(dL, s[i]); FTBP(dU, -s[i]);
+                    FTBZ(zL, mu / dL - zL - zL / dL * s[i]); FTBZ(zU, mu / dU - zU + zU / dU * s[i]);
+                }
+                // costate increment of the row x_k - F_{k-1}: -(Px_k s_k + pv_k . coef)   (for k=N, rs[N] is not written: use terminal data)
+            }
+            if (k < N) {
+                const double *ro = I.rs + (size_t)k * OB_RS;
+                double du[2];
+                du[0] = ro[RS_CL + 40]; du[1] = ro[RS_CL + 41];
+#pragma unroll
+                for (int j = 0; j < 6; j++) { du[0] += ro[RS_CL + 24 + j] * s[j]; du[1] += ro[RS_CL + 30 + j] * s[j]; }
+                d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
+                const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
+                const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
+                const double cu[2] = {0.01, c.wa}, rr = 0.1 / (q * q);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const double ei = u[i] - w[i], lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
+                    const double dL = u[i] - lo, dU = hi - u[i], zL = z[l.zuL + 2 * k + i], zU = z[l.zuU + 2 * k + i];
+                    gd += (2 * cu[i] * u[i] + 2 * rr * ei) * du[i] - 2 * rr * ei * s[4 + i] + (-mu / dL + mu / dU) * du[i];
+                    FTBP(dL, du[i]); FTBP(dU, -du[i]);
+                    FTBZ(zL, mu / dL - zL - zL / dL * du[i]); FTBZ(zU, mu / dU - zU + zU / dU * du[i]);
+                }
+                // steering row back-substitution
+                const double *rec = I.as + (size_t)k * OB_AS;
+                const double lin = rec[AS_GG] * s[4] + rec[AS_GG + 1] * du[0] + rec[AS_GG + 2] * dt;
+                const double dyg = rec[AS_SIG] * (lin + rec[AS_RG]);
+                const double dss = (dyg - rec[AS_RSS]) / rec[AS_DSS];
+                d[l.yg + k] = dyg; d[l.ss + k] = dss;
+                const double ss = z[l.ss + k], zL = z[l.zssL + k], zU = z[l.zssU + k], dL = ss + OB_SSB, dU = OB_SSB - ss;
+                gd += (-mu / dL + mu / dU) * dss;
+                FTBP(dL, dss); FTBP(dU, -dss);
+                FTBZ(zL, mu / dL - zL - zL / dL * dss); FTBZ(zU, mu / dU - zU + zU / dU * dss);
+                // costate of x_{k+1} - F_k
+                double sn[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) sn[i] = I.traj[(size_t)(k + 1) * 6 + i];
+                if (k + 1 < N) {
+                    const double *r1 = I.rs + (size_t)(k + 1) * OB_RS;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        double a_ = 0;
+#pragma unroll
+                        for (int cc = 0; cc < OB_NC; cc++) a_ += r1[RS_PV + i * OB_NC + cc] * coef[cc];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) a_ += r1[RS_PX + i * 6 + j] * sn[j];
+                        d[l.pi + 4 * k + i] = -a_;
+                    }
+                } else {   // terminal cost-to-go: P_N = H_N(+rho), p_N = (hb_N - rho e, Ht_N, e_i)
+                    const double *rN = I.as + (size_t)N * OB_AS;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        double e = -(z[l.x + 4 * N + i] - c.xF[i]);
+                        double a_ = (rN[AS_HB + i] - rho * e) + rN[AS_HT + i] * dt + nu[i];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) a_ += (rN[AS_H + hidx(i, j)] + ((i == j) ? rho : 0.0)) * sn[j];
+                        d[l.pi + 4 * k + i] = -a_;
+                    }
+                }
+            }
+        }
+        sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;
+#undef FTBP
+#undef FTBZ
+    }
+    SYNC();
+    double ap = red_min(sh.red[0]), az = red_min(sh.red[1]), gd = red_sum(sh.red[2]);
+    SYNC();
+    // ---- obstacle blocks: back-substitution (the block is re-factorised instead of being stored)
+    PAR(lane) {
+        double lap = 1.0, laz = 1.0, lgd = 0, cc_;
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < lap) lap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < laz) laz = cc_; }
+        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+            int k = it / nOb, j = it - k * nOb;
+            ObsIn in; load_obs(I, sh, z, k, j, in);
+            const double dp[3] = {d[l.x + 4 * k], d[l.x + 4 * k + 1], d[l.x + 4 * k + 2]};
+            ObsStep st;
+            obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
+            const int r0 = sh.roff[j];
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) {
+                d[l.lam + k * M + r0 + i] = st.dlam[i];
+                lgd -= mu / in.lam[i] * st.dlam[i];
+                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                d[l.mu + 4 * it + i] = st.dmu[i]; d[l.yo + 4 * it + i] = st.dy[i];
+                lgd -= mu / in.mu[i] * st.dmu[i];
+                FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], mu / in.mu[i] - in.zm[i] - in.zm[i] / in.mu[i] * st.dmu[i]);
+            }
+            d[l.sl + it] = st.dsl; d[l.so + it] = st.dso;
+            lgd += (1e2 + 2e4 * in.sl) * st.dsl - mu / in.so * st.dso;
+            FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
+        }
+        sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
+#undef FTBP
+#undef FTBZ
+    }
+    SYNC();
+    ap = fmin(ap, red_min(sh.red[0])); az = fmin(az, red_min(sh.red[1])); gd += red_sum(sh.red[2]);
+    SYNC();
+    // ---- t and nu (uniform)
+    if (!c.fixTime) {
+        const double t = z[l.t], q = t * c.Ts, dL = t - OB_TL, dU = OB_TU - t, zL = z[l.ztL], zU = z[l.ztU];
+        // d f / d t needs sum_k -2 rv_k / t : recompute from the gradient bookkeeping:  gtb = sum(-2rv/t) + steer/dyn/J^T y terms.
+        // The barrier-function gradient (no constraint terms) is formed separately below.
+        (void)q;
+        double cc_;
+        cc_ = dt < 0 ? -tau * dL / dt : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = -dt < 0 ? -tau * dU / (-dt) : 1e300; if (cc_ < ap) ap = cc_;
+        double dzL = mu / dL - zL - zL / dL * dt, dzU = mu / dU - zU + zU / dU * dt;
+        cc_ = dzL < 0 ? -tau * zL / dzL : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzU < 0 ? -tau * zU / dzU : 1e300; if (cc_ < az) az = cc_;
+    }
+    PAR(lane) {   // rate-cost part of d phi / d t
+        double g = 0;
+        if (!c.fixTime) {
+            const double t = z[l.t], q = t * c.Ts, rr = 0.1 / (q * q);
+            for (int k = lane; k < N; k += 64) {
+                double e1 = z[l.u + 2 * k] - (k ? z[l.u + 2 * k - 2] : 0.0), e2 = z[l.u + 2 * k + 1] - (k ? z[l.u + 2 * k - 1] : 0.0);
+                g += -2 * rr * (e1 * e1 + e2 * e2) / t;
+            }
+        }
+        sh.red[0][lane] = g;
+        if (lane < 4) d[l.nu + lane] = nu[lane];
+        if (lane == 4) d[l.t] = dt;
+    }
+    SYNC();
+    if (!c.fixTime) {
+        const double t = z[l.t];
+        double gt = red_sum(sh.red[0]) + (N + 1) * (0.5 + 2 * t) + (N + 1) * (-mu / (t - OB_TL) + mu / (OB_TU - t));
+        gd += gt * dt;
+    }
+    SYNC();
+    so.ap = ap; so.az = az; so.gd = gd;
+}
+
+// ---------------------------------------------------------------- objective / constraint 1-norm / barrier at z + alpha d (primal part)
+OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, double &th1, double &bar) {
+    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const double *z = I.z, *d = I.d;
+    const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts;
+    PAR(lane) {
+        double lf = 0, lth = 0, lbar = 0;
+        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+            int k = it / nOb, j = it - k * nOb;
+            ObsIn in; load_obs(I, sh, z, k, j, in);
+            const int r0 = sh.roff[j];
+#pragma unroll
+            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) { in.lam[i] += alpha * d[l.lam + k * M + r0 + i]; lbar += log(in.lam[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { in.mu[i] += alpha * d[l.mu + 4 * it + i]; lbar += log(in.mu[i]); }
+            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it]; lbar += log(in.so);
+            in.X += alpha * d[l.x + 4 * k]; in.Y += alpha * d[l.x + 4 * k + 1]; in.psi += alpha * d[l.x + 4 * k + 2];
+            double r[4]; obs_rows(c, in, r);
+            lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
+            lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
+        }
+        for (int k = lane; k <= N; k += 64) {
+            double x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i] + alpha * d[l.x + 4 * k + i];
+            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
+            if (k >= 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (i != 2) lbar += log(x[i] - c.xl[i]) + log(c.xu[i] - x[i]);
+            }
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) lth += fabs(x[i] - c.xF[i]);
+            } else {
+                const double u[2] = {z[l.u + 2 * k] + alpha * d[l.u + 2 * k], z[l.u + 2 * k + 1] + alpha * d[l.u + 2 * k + 1]};
+                const double w[2] = {k ? z[l.u + 2 * k - 2] + alpha * d[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] + alpha * d[l.u + 2 * k - 1] : 0.0};
+                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + 0.1 * ((u[0] - w[0]) * (u[0] - w[0]) + (u[1] - w[1]) * (u[1] - w[1])) / (q * q);
+                lbar += log(u[0] - OB_UL0) + log(OB_UU0 - u[0]) + log(u[1] - OB_UL1) + log(OB_UU1 - u[1]);
+                const double ss = z[l.ss + k] + alpha * d[l.ss + k];
+                lbar += log(ss + OB_SSB) + log(OB_SSB - ss);
+                lth += fabs((w[0] - u[0]) / q - ss);
+                double F[4]; dyn_value(c, x, u, t, F);
+#pragma unroll
+                for (int i = 0; i < 4; i++) lth += fabs(z[l.x + 4 * (k + 1) + i] + alpha * d[l.x + 4 * (k + 1) + i] - F[i]);
+            }
+        }
+        sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
+    }
+    SYNC();
+    f = red_sum(sh.red[0]); th1 = red_sum(sh.red[1]); bar = red_sum(sh.red[2]);
+    SYNC();
+    if (!c.fixTime) { f += (N + 1) * (0.5 * t + t * t); bar += (N + 1) * (log(t - OB_TL) + log(OB_TU - t)); }
+}
+
+// ---------------------------------------------------------------- accept the step
+OBCA_FN double clampz(double zz, double dist, double mu, double ks) { double lo = mu / (ks * dist), hi = ks * mu / dist; return zz < lo ? lo : (zz > hi ? hi : zz); }
+
+OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, double az, double mu, double ks) {
+    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    double *z = I.z; const double *d = I.d;
+    PAR(lane) {
+        // one-sided (>=0) groups: lam, mu, so
+        for (int i = lane; i < M * (N + 1); i += 64) {
+            double v = z[l.lam + i], dv = d[l.lam + i], zz = z[l.zlam + i];
+            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            z[l.lam + i] = v; z[l.zlam + i] = clampz(zz, v, mu, ks);
+        }
+        for (int i = lane; i < 4 * nOb * (N + 1); i += 64) {
+            double v = z[l.mu + i], dv = d[l.mu + i], zz = z[l.zmu + i];
+            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            z[l.mu + i] = v; z[l.zmu + i] = clampz(zz, v, mu, ks);
+            z[l.yo + i] += ay * d[l.yo + i];
+        }
+        for (int i = lane; i < nOb * (N + 1); i += 64) {
+            double v = z[l.so + i], dv = d[l.so + i], zz = z[l.zso + i];
+            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            z[l.so + i] = v; z[l.zso + i] = clampz(zz, v, mu, ks);
+            z[l.sl + i] += alpha * d[l.sl + i];
+        }
+        for (int k = lane; k <= N; k += 64) {
+            if (k >= 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int idx = 4 * k + i; double v = z[l.x + idx], dv = d[l.x + idx];
+                    if (i != 2) {
+                        double dL = v - c.xl[i], dU = c.xu[i] - v, zL = z[l.zxL + idx], zU = z[l.zxU + idx];
+                        zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                        v += alpha * dv;
+                        z[l.zxL + idx] = clampz(zL, v - c.xl[i], mu, ks); z[l.zxU + idx] = clampz(zU, c.xu[i] - v, mu, ks);
+                    } else v += alpha * dv;
+                    z[l.x + idx] = v;
+                }
+            }
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    int idx = 2 * k + i; double v = z[l.u + idx], dv = d[l.u + idx];
+                    const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
+                    double dL = v - lo, dU = hi - v, zL = z[l.zuL + idx], zU = z[l.zuU + idx];
+                    zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                    v += alpha * dv;
+                    z[l.u + idx] = v; z[l.zuL + idx] = clampz(zL, v - lo, mu, ks); z[l.zuU + idx] = clampz(zU, hi - v, mu, ks);
+                }
+                {
+                    double v = z[l.ss + k], dv = d[l.ss + k], dL = v + OB_SSB, dU = OB_SSB - v, zL = z[l.zssL + k], zU = z[l.zssU + k];
+                    zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                    v += alpha * dv;
+                    z[l.ss + k] = v; z[l.zssL + k] = clampz(zL, v + OB_SSB, mu, ks); z[l.zssU + k] = clampz(zU, OB_SSB - v, mu, ks);
+                }
+                z[l.yg + k] += ay * d[l.yg + k];
+#pragma unroll
+                for (int i = 0; i < 4; i++) z[l.pi + 4 * k + i] += ay * d[l.pi + 4 * k + i];
+            }
+        }
+        if (lane < 4) z[l.nu + lane] += ay * d[l.nu + lane];
+        if (lane == 5 && !c.fixTime) {
+            double v = z[l.t], dv = d[l.t], dL = v - OB_TL, dU = OB_TU - v, zL = z[l.ztL], zU = z[l.ztU];
+            zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+            v += alpha * dv;
+            z[l.t] = v; z[l.ztL] = clampz(zL, v - OB_TL, mu, ks); z[l.ztU] = clampz(zU, OB_TU - v, mu, ks);
+        }
+    }
+    SYNC();
+}
+
+// ---------------------------------------------------------------- starting point (IPOPT sec. 3.6: push into the bounds, z=1, y=0)
+OBCA_FN double push2(double v, double lo, double hi, double k1, double k2) {
+    double pl = fmin(k1 * fmax(1.0, fabs(lo)), k2 * (hi - lo)), pu = fmin(k1 * fmax(1.0, fabs(hi)), k2 * (hi - lo));
+    if (v < lo + pl) v = lo + pl;
+    if (v > hi - pu) v = hi - pu;
+    return v;
+}
+OBCA_FN void init_point(const Inst &I, Shared &sh, const Opts &o) {
+    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    double *z = I.z;
+    PAR(lane) {
+        if (lane < 4) z[l.x + lane] = c.x0[lane];
+        if (lane == 4 && c.fixTime) z[l.t] = 1.0;
+        for (int i = l.pi + lane; i < l.zxL; i += 64) z[i] = 0.0;
+        for (int i = l.zxL + lane; i < l.len; i += 64) z[i] = 1.0;
+    }
+    SYNC();
+    const double q = z[l.t] * c.Ts;
+    PAR(lane) {   // slacks take the row values at the (un-pushed) warm start
+        for (int k = lane; k < N; k += 64) z[l.ss + k] = ((k ? z[l.u + 2 * k - 2] : 0.0) - z[l.u + 2 * k]) / q;
+        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+            int k = it / nOb, j = it - k * nOb;
+            ObsIn in; load_obs(I, sh, z, k, j, in);
+            in.so = 0;
+            double r[4]; obs_rows(c, in, r);
+            z[l.so + it] = r[3];
+        }
+    }
+    SYNC();
+    PAR(lane) {   // push into the interior
+        for (int k = lane; k <= N; k += 64) {
+            if (k >= 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (i != 2) z[l.x + 4 * k + i] = push2(z[l.x + 4 * k + i], c.xl[i], c.xu[i], o.bound_push, o.bound_frac);
+            }
+            if (k < N) {
+                z[l.u + 2 * k] = push2(z[l.u + 2 * k], OB_UL0, OB_UU0, o.bound_push, o.bound_frac);
+                z[l.u + 2 * k + 1] = push2(z[l.u + 2 * k + 1], OB_UL1, OB_UU1, o.bound_push, o.bound_frac);
+                z[l.ss + k] = push2(z[l.ss + k], -OB_SSB, OB_SSB, o.bound_push, o.bound_frac);
+            }
+        }
+        if (lane == 4 && !c.fixTime) z[l.t] = push2(z[l.t], OB_TL, OB_TU, o.bound_push, o.bound_frac);
+        for (int i = lane; i < M * (N + 1); i += 64) z[l.lam + i] = fmax(z[l.lam + i], o.bound_push);
+        for (int i = lane; i < 4 * nOb * (N + 1); i += 64) z[l.mu + i] = fmax(z[l.mu + i], o.bound_push);
+        for (int i = lane; i < nOb * (N + 1); i += 64) z[l.so + i] = fmax(z[l.so + i], o.bound_push);
+    }
+    SYNC();
+}
+
+// ---------------------------------------------------------------- the interior-point driver
+enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
+struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
+
+OBCA_FN void ipm_attempt(const Inst &I, Shared &sh, const Opts &o, Result &R) {
+    init_point(I, sh, o);
+    double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
+    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
+    AsmOut A;
+    double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
+    for (;;) {
+        double dc = o.dc_bar * pow(mu, o.kappa_c);
+        assemble(I, sh, mu, 0.0, dc, A);
+        if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
+        f = A.f; pinf = A.pinf; dinf = A.dinf;
+        const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
+        const double sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
+        const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
+        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
+        if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
+        if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
+        // barrier update
+        int mu_changed = 0;
+        {
+            double cm = A.cinfmu;
+            for (;;) {
+                double Emu = fmax(A.dinf / sd, fmax(A.pinf, cm / sc));
+                if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
+                    double mu_new = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                    // |v z - mu_new| <= |v z - mu| + (mu - mu_new): recompute exactly on the next assemble; here use the bound-free
+                    // identity max|vz-mu_new| via the stored extremes is not available, so re-assemble below.
+                    mu = mu_new; tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
+                    AsmOut A2; assemble(I, sh, mu, 0.0, o.dc_bar * pow(mu, o.kappa_c), A2); cm = A2.cinfmu;
+                } else break;
+            }
+        }
+        dc = o.dc_bar * pow(mu, o.kappa_c);
+        // search direction with inertia correction (IPOPT Algorithm IC)
+        double dw = 0; int ok = 0; StepOut S;
+        for (int tr = 0; tr < 60; tr++) {
+            if (tr > 0 || mu_changed) assemble(I, sh, mu, dw, dc, A);
+            int a_ = A.ok;
+            if (a_) a_ = riccati_backward(I, sh, o.rho_term);
+            if (a_) {
+                solve_direction(I, sh, A, mu, dw, dc, o.rho_term, tau, S); a_ = S.ok;
+            }
+            if (a_) { ok = 1; break; }
+            nreg++;
+            if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);
+            else dw *= (dw_last == 0 ? o.kw_inc0 : o.kw_inc);
+            if (dw > o.dw_max) break;
+        }
+        if (!ok) { status = ST_ERROR; break; }
+        if (dw > 0) dw_last = dw;
+        const double th = A.th1, phi = A.f - mu * A.bar, gd = S.gd;
+        double amin;
+        if (gd < 0) {
+            amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
+            if (th <= th_min) amin = fmin(amin, o.delta * pow(th, o.s_theta) / pow(-gd, o.s_phi));
+        } else amin = o.gamma_theta;
+        amin *= o.gamma_alpha;
+        double alpha = S.ap; int acc = 0;
+        while (alpha >= amin) {
+            double ft, tht, bart;
+            eval_trial(I, sh, alpha, ft, tht, bart);
+            double pht = ft - mu * bart;
+            if (ft == ft && tht == tht && pht == pht && tht < th_max) {
+                int okf = 1;
+                for (int i = 0; i < nf && okf; i++) if (!(tht < sh.filt[i][0] || pht < sh.filt[i][1])) okf = 0;
+                if (okf) {
+                    int sw = gd < 0 && alpha * pow(-gd, o.s_phi) > o.delta * pow(th, o.s_theta);
+                    int armijo = pht <= phi + o.eta_phi * alpha * gd;
+                    if (th <= th_min && sw) { if (armijo) { acc = 1; break; } }
+                    else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
+                        acc = 1;
+                        if (!(sw && armijo) && nf < OB_FILT) {
+                            PAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
+                            SYNC();
+                            nf++;
+                        }
+                        break;
+                    }
+                }
+            }
+            alpha *= 0.5;
+        }
+        if (!acc) { status = ST_ERROR; break; }   // IPOPT would enter restoration here
+        apply_step(I, sh, alpha, fmin(alpha, S.az), S.az, mu, o.kappa_sigma);
+        it++;
+    }
+    R.status = status; R.iters = it; R.nreg = nreg; R.obj = f; R.pinf = pinf; R.dinf = dinf; R.mu = mu;
+}
+
+// Full solve of one instance: first attempt, and on Error/UserLimit one re-solve from the last iterate
+// (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
+OBCA_FN void solve_instance(Inst &I, Shared &sh, const Opts &o, double *info) {
+    PAR(lane) {
+        for (int i = lane; i < OB_HDR; i += 64) sh.hdr[i] = I.prob[i];
+    }
+    SYNC();
+    PAR(lane) {
+        if (lane <= OB_NOBMAX) sh.roff[lane] = (int)sh.hdr[PH_ROFF + lane];
+        if (lane < OB_NOBMAX) sh.vOb[lane] = (int)sh.hdr[PH_VOB + lane];
+    }
+    SYNC();
+    Consts &c = I.c;
+    c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
+    for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
+    c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
+    c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
+    make_layout(c.N, c.nOb, c.M, I.l);
+    Result R;
+    ipm_attempt(I, sh, o, R);
+    int ef = (R.status == ST_OPTIMAL), iters = R.iters, nreg = R.nreg;
+    if (!ef) {
+        Result R2;
+        ipm_attempt(I, sh, o, R2);
+        iters += R2.iters; nreg += R2.nreg;
+        if (R2.status == ST_OPTIMAL) ef = 1;
+        R = R2;
+    }
+    PAR(lane) {
+        if (lane == 0) { info[0] = R.status; info[1] = iters; info[2] = R.obj; info[3] = R.pinf; info[4] = R.dinf; info[5] = R.mu; info[6] = nreg; info[7] = ef; }
+    }
+    SYNC();
+}
+
+}  // namespace obca

@@ -1,0 +1,81 @@
+"""
+Host-side packing of OBCA parking instances into the flat fp64 buffers the HIP solver reads.
+
+  prob[inst] = [ header (OB_HDR=168 doubles: scalars, obstacle H-rep rows) | rx | ry | ryaw ]      (N+1 each)
+  z[inst]    = one primal-dual iterate, stage-contiguous (= the reference's column-major x, u, l, n arrays):
+               x 4(N+1) | u 2N | t | lam M(N+1) | mu 4nOb(N+1) | sl nOb(N+1) | so nOb(N+1) | ss N |
+               pi 4N | nu 4 | yg N | yo 4nOb(N+1) | bound multipliers ...
+The argument conventions are those of ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS)
+(/root/reference/AutonomousParking/ParkingSignedDist.jl:29).
+"""
+import numpy as np
+
+OB_VMAX, OB_NOBMAX, OB_MMAX, OB_HDR = 4, 10, 40, 168
+PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=36, A=48, B=128)
+LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU nprimal len").split()
+
+
+def layout(N, nOb, M):
+    N1 = N + 1
+    sizes = [4 * N1, 2 * N, 1, M * N1, 4 * nOb * N1, nOb * N1, nOb * N1, N, 4 * N, 4, N, 4 * nOb * N1,
+             4 * N1, 4 * N1, 2 * N, 2 * N, 1, 1, M * N1, 4 * nOb * N1, nOb * N1, N, N]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    L = dict(zip(LAYOUT_FIELDS[:23], off[:23].tolist()))
+    L["nprimal"] = int(off[8]); L["len"] = int(off[23])
+    return L
+
+
+def check_obstacles(vOb):
+    vOb = np.asarray(vOb, dtype=np.int64).ravel()
+    if len(vOb) < 1 or len(vOb) > OB_NOBMAX:
+        raise ValueError(f"nOb must be in 1..{OB_NOBMAX}")
+    if vOb.min() < 1 or vOb.max() > OB_VMAX:
+        raise ValueError(f"rows per obstacle must be in 1..{OB_VMAX}")
+    return vOb
+
+
+def pack_problem(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime):
+    vOb = check_obstacles(vOb)
+    nOb, M = len(vOb), int(vOb.sum())
+    A = np.asarray(A, float).reshape(M, 2); b = np.asarray(b, float).ravel()
+    ego = np.asarray(ego, float).ravel(); XYb = np.asarray(XYbounds, float).ravel()
+    p = np.zeros(OB_HDR + 3 * (N + 1))
+    p[PH["TS"]] = Ts; p[PH["L"]] = L
+    W_ev, L_ev = ego[1] + ego[3], ego[0] + ego[2]                      # ParkingSignedDist.jl:182-188
+    p[PH["G"]:PH["G"] + 4] = [L_ev / 2, W_ev / 2, L_ev / 2, W_ev / 2]
+    p[PH["OFF"]] = (ego[0] + ego[2]) / 2 - ego[2]
+    p[PH["XL"]:PH["XL"] + 4] = [XYb[0], XYb[2], -1e300, -1.0]          # :104-106
+    p[PH["XU"]:PH["XU"] + 4] = [XYb[1], XYb[3], 1e300, 2.0]
+    p[PH["X0"]:PH["X0"] + 4] = np.asarray(x0, float).ravel()
+    p[PH["XF"]:PH["XF"] + 4] = np.asarray(xF, float).ravel()
+    p[PH["FIX"]] = int(fixTime); p[PH["NOB"]] = nOb; p[PH["M"]] = M
+    p[PH["VOB"]:PH["VOB"] + nOb] = vOb
+    p[PH["ROFF"]:PH["ROFF"] + nOb + 1] = np.concatenate([[0], np.cumsum(vOb)])
+    p[PH["A"]:PH["A"] + 2 * M] = A.reshape(-1)
+    p[PH["B"]:PH["B"] + M] = b
+    p[OB_HDR:OB_HDR + N + 1] = np.asarray(rx, float).ravel()[:N + 1]
+    p[OB_HDR + N + 1:OB_HDR + 2 * (N + 1)] = np.asarray(ry, float).ravel()[:N + 1]
+    p[OB_HDR + 2 * (N + 1):] = np.asarray(ryaw, float).ravel()[:N + 1]
+    return p
+
+
+def pack_start(N, nOb, M, xWS, uWS, lWS, nWS, zlen=None):
+    """warm start -> iterate buffer (reference :213-222: timeScale=1, x=xWS', u=uWS[1:N,:]', l=lWS', n=nWS')."""
+    L = layout(N, nOb, M)
+    z = np.zeros(zlen or L["len"])
+    z[L["x"]:L["x"] + 4 * (N + 1)] = np.asarray(xWS, float)[:N + 1].reshape(-1)
+    z[L["u"]:L["u"] + 2 * N] = np.asarray(uWS, float)[:N].reshape(-1)
+    z[L["t"]] = 1.0
+    z[L["lam"]:L["lam"] + M * (N + 1)] = np.asarray(lWS, float).reshape(-1)
+    z[L["mu"]:L["mu"] + 4 * nOb * (N + 1)] = np.asarray(nWS, float).reshape(-1)
+    return z
+
+
+def unpack_solution(z, N, nOb, M):
+    L = layout(N, nOb, M)
+    xp = z[L["x"]:L["x"] + 4 * (N + 1)].reshape(N + 1, 4).T.copy()
+    up = z[L["u"]:L["u"] + 2 * N].reshape(N, 2).T.copy()
+    lp = z[L["lam"]:L["lam"] + M * (N + 1)].reshape(N + 1, M).T.copy()
+    npp = z[L["mu"]:L["mu"] + 4 * nOb * (N + 1)].reshape(N + 1, 4 * nOb).T.copy()
+    sl = z[L["sl"]:L["sl"] + nOb * (N + 1)].reshape(N + 1, nOb).T.copy()
+    return xp, up, float(z[L["t"]]), lp, npp, sl

@@ -64,7 +64,7 @@ void obca_oracle_default_opts(opts_t *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4;
-    o->rho_term = 1e3; o->lsq_init = 1; o->verbose = 0;
+    o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
 }
 
 /* ------------------------------------------------------------------ iterate layout (one flat vector) */
