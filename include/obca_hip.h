@@ -28,7 +28,7 @@ extern "C" {
 
 #define OBCA_VMAX 4      /* max half-space rows per obstacle */
 #define OBCA_NOBMAX 10   /* max obstacles per instance */
-#define OBCA_NMAX 1024   /* max horizon */
+#define OBCA_NMAX 128    /* max horizon (the reference's planners give N ~ 50-90) */
 
 typedef struct obca_ctx obca_ctx;
 typedef struct obca_batch obca_batch;
@@ -75,6 +75,7 @@ int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms);   /* 
 int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *np,
                         double *slp, double *info);
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes);
+int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-phase shader cycles, zero unless built with -DOBCA_PROFILE */);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIBPATH = os.path.join(_CSRC, "libobca_hip.so")
+_LIBPATH = os.environ.get("OBCA_HIP_LIBRARY") or os.path.join(_CSRC, "libobca_hip.so")   # override: diagnostic builds
 _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int)
 _lib = None
@@ -68,7 +68,7 @@ def _load():
 EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
-           "obca_batch_scratch_bytes"]
+           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles"]
 
 
 def default_opts():
@@ -187,6 +187,12 @@ class Batch:
         a, b = C.c_float(0), C.c_float(0)
         self.ctx._check(_load().obca_batch_kernel_ms(self._h, C.byref(a), C.byref(b)), "obca_batch_kernel_ms")
         return a.value, b.value
+
+    def phase_cycles(self):
+        """(B,16) per-phase shader-cycle counters of the last solve; all zero unless the library was built with -DOBCA_PROFILE."""
+        out = np.zeros((self.B, 16))
+        self.ctx._check(_load().obca_batch_debug_phase_cycles(self._h, out.ctypes.data_as(_D)), "obca_batch_debug_phase_cycles")
+        return out
 
     def scratch_bytes(self):
         v = C.c_longlong(0)

@@ -20,24 +20,35 @@
 using namespace obca;
 
 static_assert(sizeof(obca_opts) == sizeof(Opts), "obca_opts must mirror obca::Opts");
-static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX, "ABI limits must match the kernels");
+static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
-    double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws;
+    double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;
     size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
 };
 
 __global__ __launch_bounds__(64) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o) {
-    __shared__ Shared sh;
     const int inst = blockIdx.x;
     if (inst >= B) return;
-    Inst I;
-    I.prob = b.prob + (size_t)inst * b.s_prob;
-    I.z = b.z + (size_t)inst * b.s_z; I.d = b.d + (size_t)inst * b.s_z;
-    I.as = b.as + (size_t)inst * b.s_as; I.rs = b.rs + (size_t)inst * b.s_rs; I.oc = b.oc + (size_t)inst * b.s_oc;
-    I.traj = b.traj + (size_t)inst * b.s_traj;
-    I.c.N = N;
-    solve_instance(I, sh, o, b.info + (size_t)inst * 8);
+    if (threadIdx.x == 0) {
+        Inst &I = g_sh.inst;
+        I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
+        I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
+        I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
+        I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc); I.traj = (gdbl *)(b.traj + (size_t)inst * b.s_traj);
+#ifdef OBCA_PROFILE
+        I.tlast = clock64();
+#endif
+    }
+#ifdef OBCA_PROFILE
+    if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = 0;
+#endif
+    __syncthreads();
+    solve_instance(N, o, b.info + (size_t)inst * 8);
+#ifdef OBCA_PROFILE
+    __syncthreads();
+    if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
+#endif
 }
 
 // one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
@@ -124,7 +135,7 @@ int obca_device_name(const obca_ctx *c, char *buf, int n) { if (!c || !buf || n 
 
 int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
     if (!ctx || !out) return -1;
-    if (B < 1 || N < 2 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 2<=N<=OBCA_NMAX"; return -1; }
+    if (B < 1 || N < 0 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
     bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0;
     memset(&bt->d, 0, sizeof bt->d);
@@ -134,7 +145,7 @@ int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 }
 int obca_batch_destroy(obca_batch *bt) {
@@ -142,6 +153,11 @@ int obca_batch_destroy(obca_batch *bt) {
     hipSetDevice(bt->ctx->device);
     free_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); hipEventDestroy(bt->e2);
     delete bt; return 0;
+}
+int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
+    if (!bt || !out) return -1;
+    HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
 }
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 
@@ -175,7 +191,7 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(ctx, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
         ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
-        ALLOC(d.info, (size_t)B * 8); ALLOC(d.dws, (size_t)B * N1 * nObMax);
+        ALLOC(d.info, (size_t)B * 8); ALLOC(d.dws, (size_t)B * N1 * nObMax); ALLOC(d.prof, (size_t)B * 16);
 #undef ALLOC
         bt->bytes = (long long)tot;
     }
@@ -229,6 +245,7 @@ int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
     if (!bt) return -1;
     obca_ctx *ctx = bt->ctx;
     if (!bt->uploaded) { ctx->err = "obca_batch_solve: nothing uploaded"; return -1; }
+    if (bt->N < 2) { ctx->err = "obca_batch_solve: the NLP needs a horizon N>=2"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(ctx->device);

@@ -17,21 +17,48 @@
 #ifdef OBCA_EMU
 #define OBCA_FN static inline
 #define OBCA_HD static inline
+#define OBCA_PHASE static
 #define PAR(lane) for (int lane = 0; lane < 64; ++lane)
 #define SYNC() ((void)0)
 #define LANE0 1
+#define LDS_SYNC() ((void)0)
+#define OBCA_NL 64          // per-lane variables that live across a SYNC are arrays over the lanes in the emulation
+#define LI(lane) (lane)
 #else
 #define OBCA_FN __device__ __forceinline__
 #define OBCA_HD __host__ __device__ inline
+// Phase entry points are real (non-inlined) device functions: each gets its own register allocation, so the unrolled
+// per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
+#define OBCA_PHASE __device__ __noinline__
 #define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define SYNC() __syncthreads()
 #define LANE0 (threadIdx.x == 0)
+// The workgroup is ONE wavefront: its LDS operations execute in program order, so lanes only need the compiler to keep that
+// order (wavefront-scope fences emit no instruction).  Unlike __syncthreads() this does not drain outstanding global loads,
+// which lets the software-pipelined HBM gathers of the sequential sweeps stay in flight across phases.  Use it only where the
+// cross-lane traffic of the surrounding phases goes through LDS.
+#ifdef OBCA_LDS_SYNC_FULL
+#define LDS_SYNC() __syncthreads()
+#else
+#define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+#define OBCA_NL 1
+#define LI(lane) 0
 #endif
 #include "obca_model.h"
+// Pointers into the per-instance HBM buffers carry the global address space explicitly: they are kept in LDS (Shared::inst),
+// and a pointer loaded from memory would otherwise be "generic" -> flat_load/flat_store, whose completion is tied to the LDS
+// counter (lgkmcnt) and would serialise every LDS read behind the outstanding HBM gathers.
+#ifdef OBCA_EMU
+typedef double gdbl;
+#else
+typedef __attribute__((address_space(1))) double gdbl;
+#endif
 
 namespace obca {
 
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
+#define OB_NMAX 128  // longest horizon (the forward-sweep trajectory lives in LDS)
 #define OB_AS 88     // doubles per assembled stage record
 #define OB_RS 116    // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
@@ -93,21 +120,42 @@ OBCA_HD void make_layout(int N, int nOb, int M, Lay &l) {
     l.zso = o; o += nOb * N1; l.zssL = o; o += N; l.zssU = o; o += N; l.len = o;
 }
 
+struct AsmOut { int ok; double dinf, pinf, cinf0, cinfmu, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };
+struct StepOut { int ok; double ap, az, gd; };
+struct Consts; struct Lay;
+struct Inst {              // uniform: pointers of this instance
+    const gdbl *prob;      // header + rx, ry, ryaw
+    gdbl *z, *d, *as, *rs, *oc, *traj;
+    mutable long long tlast;           // diagnostic builds (-DOBCA_PROFILE): time stamp of the previous phase boundary
+};
+
 struct Shared {
     double hdr[OB_HDR];
     double red[16][64];
-    double rec[2][OB_AS];      // double-buffered raw stage record (Riccati backward)
-    double Pn[36], pn[6 * OB_NC], H[64], hc[8 * OB_NC], Fm[48], off[6 * OB_NC], That[6 * 14], Qhat[8 * 14];
+    double stg[2][196];        // double-buffered unpacked stage data of the Riccati backward sweep (SG_* offsets)
+    double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
     double filt[OB_FILT][2];
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX];
+    Consts c; Lay l;
+    double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
+    Inst inst; AsmOut A, A2; StepOut S; double trial[4];   // phase inputs/outputs (wave-uniform, exchanged through LDS)
+    double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
 };
 
-struct Inst {              // uniform: pointers of this instance
-    const double *prob;    // header + rx, ry, ryaw
-    double *z, *d, *as, *rs, *oc, *traj;
-    Consts c; Lay l;
-};
+#ifdef OBCA_EMU
+static Shared g_sh;
+#else
+__shared__ Shared g_sh;     // the one LDS block of the workgroup (= one wavefront = one problem instance)
+#endif
+
+// phase ids of the diagnostic cycle counters
+enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_SEQ, PF_BS_STAGE, PF_BS_OBS, PF_TRIAL, PF_APPLY, PF_OTHER, PF_RIC_P1, PF_RIC_P2, PF_N };
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
+#define PROF(I, id) do { long long now_ = clock64(); if (LANE0) sh.prof[id] += (double)(now_ - (I).tlast); (I).tlast = now_; } while (0)
+#else
+#define PROF(I, id) ((void)0)
+#endif
 
 // ---------------------------------------------------------------- reductions (64-lane butterfly; same order in the emulation)
 OBCA_FN double red_sum(const double *r) {
@@ -141,8 +189,8 @@ OBCA_FN double red_min(const double *r) {
 #endif
 }
 
-OBCA_FN void load_obs(const Inst &I, const Shared &sh, const double *z, int k, int j, ObsIn &in) {
-    const Lay &l = I.l; const int nOb = I.c.nOb, M = I.c.M;
+OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int j, ObsIn &in) {
+    const Lay &l = sh.l; const int nOb = sh.c.nOb, M = sh.c.M;
     const int r0 = sh.roff[j], v = sh.vOb[j], bo = k * nOb + j;
     in.v = v;
 #pragma unroll
@@ -172,13 +220,12 @@ OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double m
 }
 OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; return a_ * 8 - a_ * (a_ - 1) / 2 + (b_ - a_); }
 
-struct AsmOut { int ok; double dinf, pinf, cinf0, cinfmu, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };
 
 // ---------------------------------------------------------------- assemble the condensed Newton system
 OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc, AsmOut &out) {
-    const Consts &c = I.c; const Lay &l = I.l;
+    const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
-    const double *z = I.z;
+    const gdbl *z = I.z;
     const double t = z[l.t], q = t * c.Ts;
     // ---- (a) obstacle blocks: one lane per (stage, obstacle)
     PAR(lane) {
@@ -189,7 +236,7 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
             ObsIn in; load_obs(I, sh, z, k, j, in);
             ObsCond cd;
             obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
-            double *o = I.oc + (size_t)it * OB_OC;
+            gdbl *o = I.oc + (size_t)it * OB_OC;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
 #pragma unroll
@@ -211,6 +258,7 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
     double bar = red_sum(sh.red[8]);
     int ok = !(red_max(sh.red[9]) > 0.5);
     SYNC();
+    PROF(I, PF_ASM_OBS);
     // ---- (b) stages: one lane per stage
     PAR(lane) {
         double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
@@ -239,13 +287,13 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
                 H[i][i] = hx[i] + Sig + dw;
             }
             for (int j = 0; j < nOb; j++) {   // condensed obstacle contributions of this stage
-                const double *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
+                const gdbl *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
                 H[0][0] += o[0]; H[0][1] += o[1]; H[0][2] += o[2]; H[1][1] += o[3]; H[1][2] += o[4]; H[2][2] += o[5];
                 H[1][0] += o[1]; H[2][0] += o[2]; H[2][1] += o[4];
 #pragma unroll
                 for (int i = 0; i < 3; i++) { hz[i] += o[6 + i]; hb[i] += o[6 + i] - o[9 + i]; }
             }
-            double *rec = I.as + (size_t)k * OB_AS;
+            gdbl *rec = I.as + (size_t)k * OB_AS;
             if (k == N) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -385,19 +433,64 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
     } else { Htt = 1.0; gtb = 0; }
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = Htt; out.gtb = gtb; out.nb = nb; out.nm = nm;
+    PROF(I, PF_ASM_STAGE);
 }
 
 // ---------------------------------------------------------------- Riccati backward sweep
 // Stage k is condensed onto (x_k, w_k=u_{k-1}); six right-hand sides (main, t, nu1..4) ride along as extra columns and the
 // bilinear constants B(a,b) of the cost-to-go give every entry of the 5x5 (t, nu) border without a forward pass per column.
 // Returns 1 if every 2x2 input block is positive definite.
-OBCA_FN void pair_of(int p, int &a_, int &b_) { a_ = 0; b_ = 0; for (int aa = 0, cnt = 0; aa < OB_NC; aa++) for (int bb = aa; bb < OB_NC; bb++, cnt++) if (cnt == p) { a_ = aa; b_ = bb; } }
+OBCA_FN void pair_of(int p, int &a_, int &b_) {   // p-th pair (a<=b) of the 6 columns, row-major upper triangle
+    a_ = (p >= 6) + (p >= 11) + (p >= 15) + (p >= 18) + (p >= 20);
+    b_ = p - (6 * a_ - a_ * (a_ - 1) / 2) + a_;
+}
+
+// unpacked stage data in LDS (one of two buffers): H (8x8 full), FA = [Fm | off] (6x14), hc (8x6)
+#define SG_H 0
+#define SG_FA 64
+#define SG_HC 148
+#define SG_SIZE 196
+struct UnpackPlan { int idx[4]; double flag[4], kc[4]; };   // value j of this lane = kc[j] + flag[j] * rec[idx[j]]
+OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
+    { int i = lane >> 3, j = lane & 7; p.idx[0] = AS_H + hidx(i, j); p.flag[0] = 1.0; p.kc[0] = 0.0; }
+    for (int r = 0; r < 2; r++) {   // FA entries lane, lane+64 (< 84)
+        int it = lane + 64 * r, idx = AS_DD; double fl = 0.0, kc = 0.0;
+        if (it < 84) {
+            int a_ = it / 14, cc = it % 14;
+            if (cc < 8) {
+                if (a_ < 4) {
+                    if (cc < 4) kc = (a_ == cc) ? 1.0 : 0.0;
+                    if (cc == 2) { idx = AS_DF + 5 * a_ + 0; fl = 1.0; }
+                    if (cc == 3) { idx = AS_DF + 5 * a_ + 1; fl = 1.0; }
+                    if (cc == 6) { idx = AS_DF + 5 * a_ + 2; fl = 1.0; }
+                    if (cc == 7) { idx = AS_DF + 5 * a_ + 3; fl = 1.0; }
+                } else kc = (cc == a_ + 2) ? 1.0 : 0.0;
+            } else if (a_ < 4) { int col = cc - 8; if (col == 0) { idx = AS_DD + a_; fl = 1.0; } if (col == 1) { idx = AS_DF + 5 * a_ + 4; fl = 1.0; } }
+        }
+        p.idx[1 + r] = idx; p.flag[1 + r] = fl; p.kc[1 + r] = kc;
+    }
+    { int idx = AS_DD; double fl = 0.0;
+      if (lane < 48) { int i = lane / OB_NC, cc = lane % OB_NC; if (cc == 0) { idx = AS_HB + i; fl = 1.0; } if (cc == 1) { idx = AS_HT + i; fl = 1.0; } }
+      p.idx[3] = idx; p.flag[3] = fl; p.kc[3] = 0.0; }
+}
+OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[4]) {   // four independent, branch-free gathers
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = p.kc[j] + p.flag[j] * rec[p.idx[j]];
+}
+OBCA_FN void stage_unpack_store(double *sg, int lane, const double v[4]) {
+    sg[SG_H + lane] = v[0]; sg[SG_FA + lane] = v[1];
+    if (lane + 64 < 84) sg[SG_FA + lane + 64] = v[2];
+    if (lane < 48) sg[SG_HC + lane] = v[3];
+}
 
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
-    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N;
-    const double *z = I.z;
-    PAR(lane) {   // terminal cost-to-go + prefetch of record N-1
-        const double *rec = I.as + (size_t)N * OB_AS;
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N;
+    const gdbl *z = I.z;
+    double nv[OBCA_NL][4];   // software pipeline: stage data gathered from HBM one full stage before it is needed
+    UnpackPlan plan[OBCA_NL];
+    PAR(lane) {   // terminal cost-to-go; unpack stage N-1; start the loads of stage N-2
+        stage_unpack_plan(lane, plan[LI(lane)]);
+        const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
             double v = rec[AS_H + hidx(i, j)];
@@ -410,91 +503,93 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
             sh.pn[lane * OB_NC + 1] = rec[AS_HT + lane];
             for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
         }
-        const double *r1 = I.as + (size_t)(N - 1) * OB_AS;
-        for (int i = lane; i < OB_AS; i += 64) sh.rec[(N - 1) & 1][i] = r1[i];
+        double v[4]; stage_unpack_load(I.as + (size_t)(N - 1) * OB_AS, plan[LI(lane)], v);
+        stage_unpack_store(sh.stg[(N - 1) & 1], lane, v);
+        if (N >= 2) stage_unpack_load(I.as + (size_t)(N - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
     }
     SYNC();
     for (int k = N - 1; k >= 0; k--) {
-        const double *rec = sh.rec[k & 1];
-        PAR(lane) {   // unpack stage data; prefetch record k-1 into the other buffer
-            double pf0 = 0, pf1 = 0;
-            if (k > 0) { const double *r1 = I.as + (size_t)(k - 1) * OB_AS; pf0 = r1[lane]; if (lane + 64 < OB_AS) pf1 = r1[lane + 64]; }
-            { int i = lane >> 3, j = lane & 7; sh.H[lane] = rec[AS_H + hidx(i, j)]; }
-            if (lane < 48) {   // Fm[a][j] : (x+,w+) <- (x,w,u)
-                int a_ = lane >> 3, j = lane & 7; double v = 0;
-                if (a_ < 4) {
-                    if (j < 4) v = (a_ == j) ? 1.0 : 0.0;
-                    if (j == 2) v += rec[AS_DF + 5 * a_ + 0];
-                    if (j == 3) v += rec[AS_DF + 5 * a_ + 1];
-                    if (j == 6) v = rec[AS_DF + 5 * a_ + 2];
-                    if (j == 7) v = rec[AS_DF + 5 * a_ + 3];
-                } else v = (j == a_ + 2) ? 1.0 : 0.0;
-                sh.Fm[lane] = v;
-                int i = lane / OB_NC, cc = lane % OB_NC;
-                sh.hc[lane] = cc == 0 ? rec[AS_HB + i] : (cc == 1 ? rec[AS_HT + i] : 0.0);
-            }
-            if (lane < 36) { int i = lane / OB_NC, cc = lane % OB_NC;
-                sh.off[lane] = (i < 4) ? (cc == 0 ? rec[AS_DD + i] : (cc == 1 ? rec[AS_DF + 5 * i + 4] : 0.0)) : 0.0; }
-            if (k > 0) { sh.rec[(k - 1) & 1][lane] = pf0; if (lane + 64 < OB_AS) sh.rec[(k - 1) & 1][lane + 64] = pf1; }
-        }
-        SYNC();
-        PAR(lane) {   // That = Pn [Fm | off] + [0 | pn]      6 x 14
-            for (int it = lane; it < 84; it += 64) {
-                int i = it / 14, cc = it % 14; double s_ = 0;
-                if (cc < 8) { for (int a_ = 0; a_ < 6; a_++) s_ += sh.Pn[i * 6 + a_] * sh.Fm[a_ * 8 + cc]; }
-                else { int col = cc - 8; s_ = sh.pn[i * OB_NC + col]; for (int a_ = 0; a_ < 6; a_++) s_ += sh.Pn[i * 6 + a_] * sh.off[a_ * OB_NC + col]; }
-                sh.That[it] = s_;
-            }
-        }
-        SYNC();
-        PAR(lane) {   // Qhat = [H | hc] + Fm^T That  (8 x 14) ; static part of the bilinear update (21 pairs)
-            for (int it = lane; it < 112 + 21; it += 64) {
-                if (it < 112) {
-                    int i = it / 14, cc = it % 14;
-                    double s_ = cc < 8 ? sh.H[i * 8 + cc] : sh.hc[i * OB_NC + (cc - 8)];
-                    for (int a_ = 0; a_ < 6; a_++) s_ += sh.Fm[a_ * 8 + i] * sh.That[a_ * 14 + cc];
-                    sh.Qhat[it] = s_;
-                } else {
-                    int p = it - 112, a_, b_; pair_of(p, a_, b_);
-                    double v = 0;   // off_a . (P off_b + p_b) + off_b . p_a
-                    for (int i = 0; i < 4; i++) v += sh.off[i * OB_NC + a_] * sh.That[i * 14 + 8 + b_] + sh.off[i * OB_NC + b_] * sh.pn[i * OB_NC + a_];
-                    sh.sB[p] = v;
+        const double *sg = sh.stg[k & 1];
+        PAR(lane) {   // Qhat = [H | hc] + F^T (Pn [F | off] + [0 | pn])  (8 x 14): one lane per (column, row pair)
+            if (lane < 56) {
+                const int cc = lane % 14, ip = lane / 14;        // rows ip and ip+4
+                double t[6];
+#pragma unroll
+                for (int a_ = 0; a_ < 6; a_++) {
+                    double acc = cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)];
+#pragma unroll
+                    for (int b_ = 0; b_ < 6; b_++) acc += sh.Pn[a_ * 6 + b_] * sg[SG_FA + b_ * 14 + cc];
+                    t[a_] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int i = ip + 4 * r;
+                    double acc = cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)];
+#pragma unroll
+                    for (int a_ = 0; a_ < 6; a_++) acc += sg[SG_FA + a_ * 14 + i] * t[a_];
+                    sh.Qhat[i * 14 + cc] = acc;
+                }
+                if (cc >= 8 && ip == 0) {   // partial sums of the bilinear update: off_m . (P off_b + p_b) and off_m . p_b, m = 0,1
+                    const int b_ = cc - 8;
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        double u1 = 0, u2 = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const double o = sg[SG_FA + i * 14 + 8 + m]; u1 += o * t[i]; u2 += o * sh.pn[i * OB_NC + b_]; }
+                        sh.sB[m * 6 + b_] = u1; sh.sB[12 + m * 6 + b_] = u2;
+                    }
                 }
             }
         }
-        SYNC();
+        LDS_SYNC();
+        PROF(I, PF_RIC_P1);
         double Lc[3];
-        if (!chol2(sh.Qhat[6 * 14 + 6], sh.Qhat[7 * 14 + 6], sh.Qhat[7 * 14 + 7], Lc)) return 0;
-        double *ro = I.rs + (size_t)k * OB_RS;
-        PAR(lane) {   // eliminate u_k: new Pn (6x6), pn (6xNC), gains, bilinear constants
-            for (int it = lane; it < 72 + 21; it += 64) {
-                if (it < 72) {
-                    int i = it / 12, cc = it % 12, qc = cc < 6 ? cc : cc + 2;
-                    double k0 = -sh.Qhat[6 * 14 + qc], k1 = -sh.Qhat[7 * 14 + qc];
-                    chol2_solve(Lc, k0, k1);
-                    double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
-                    if (cc < 6) { sh.Pn[i * 6 + cc] = v; if (i < 4) ro[RS_PX + i * 6 + cc] = v; if (i == 0) { ro[RS_K + cc] = k0; ro[RS_K + 6 + cc] = k1; } }
-                    else { int col = cc - 6; sh.pn[i * OB_NC + col] = v; if (i < 4) ro[RS_PV + i * OB_NC + col] = v; if (i == 0) { ro[RS_KF + col] = k0; ro[RS_KF + OB_NC + col] = k1; } }
-                } else {
-                    int p = it - 72, a_, b_; pair_of(p, a_, b_);
-                    double k0 = -sh.Qhat[6 * 14 + 8 + b_], k1 = -sh.Qhat[7 * 14 + 8 + b_];
-                    chol2_solve(Lc, k0, k1);
-                    double v = sh.sB[p] + sh.Qhat[6 * 14 + 8 + a_] * k0 + sh.Qhat[7 * 14 + 8 + a_] * k1;
-                    sh.Bm[a_ * 6 + b_] += v; if (a_ != b_) sh.Bm[b_ * 6 + a_] += v;
+        if (!chol2(sh.Qhat[6 * 14 + 6], sh.Qhat[7 * 14 + 6], sh.Qhat[7 * 14 + 7], Lc)) { PROF(I, PF_RIC_BWD); return 0; }
+        // inverse of Quu from its Cholesky factor: Quu^{-1} = [g00 g01; g01 g11]
+        const double il0 = 1.0 / Lc[0], il2 = 1.0 / Lc[2];
+        const double g11 = il2 * il2, g01 = -Lc[1] * il0 * g11, g00 = il0 * il0 + Lc[1] * Lc[1] * il0 * il0 * g11;
+        gdbl *ro = I.rs + (size_t)k * OB_RS;
+        PAR(lane) {   // eliminate u_k: lanes 0..35 -> P[i][cc] and pn[i][cc]; lanes 36..56 -> bilinear constants
+            // first retire the gathers issued one stage ago (before this phase issues any store: the memory counter is in-order)
+            if (k > 0) {
+                stage_unpack_store(sh.stg[(k - 1) & 1], lane, nv[LI(lane)]);
+                if (k > 1) stage_unpack_load(I.as + (size_t)(k - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
+            }
+            if (lane < 36) {
+                const int i = lane / 6, cc = lane % 6;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int qc = r ? cc + 8 : cc;
+                    const double q6 = sh.Qhat[6 * 14 + qc], q7 = sh.Qhat[7 * 14 + qc];
+                    const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
+                    const double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
+                    if (r == 0) { sh.Pn[i * 6 + cc] = v; if (i < 4) ro[RS_PX + i * 6 + cc] = v; if (i == 0) { ro[RS_K + cc] = k0; ro[RS_K + 6 + cc] = k1; } }
+                    else { sh.pn[i * OB_NC + cc] = v; if (i < 4) ro[RS_PV + i * OB_NC + cc] = v; if (i == 0) { ro[RS_KF + cc] = k0; ro[RS_KF + OB_NC + cc] = k1; } }
                 }
+            } else if (lane < 57) {
+                int a_, b_; pair_of(lane - 36, a_, b_);
+                const double q6 = sh.Qhat[6 * 14 + 8 + b_], q7 = sh.Qhat[7 * 14 + 8 + b_];
+                const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
+                double v = sh.Qhat[6 * 14 + 8 + a_] * k0 + sh.Qhat[7 * 14 + 8 + a_] * k1;
+                // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the columns 0 (main) and 1 (t) only
+                if (a_ < 2) v += sh.sB[a_ * 6 + b_];
+                if (b_ < 2) v += sh.sB[12 + b_ * 6 + a_];
+                sh.Bm[a_ * 6 + b_] += v; if (a_ != b_) sh.Bm[b_ * 6 + a_] += v;
             }
         }
-        SYNC();
+        LDS_SYNC();
+        PROF(I, PF_RIC_P2);
     }
+    SYNC();
+    PROF(I, PF_RIC_BWD);
     return 1;
 }
 
 // ---------------------------------------------------------------- border solve + forward sweep + back-substitution
-struct StepOut { int ok; double ap, az, gd; };
 
 OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
-    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    const double *z = I.z; double *d = I.d;
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const gdbl *z = I.z; gdbl *d = I.d;
     so.ok = 1;
     // ---- 5x5 border in (dt, nu): all entries are bilinear constants of the Riccati value function
     double dt, nu[4];
@@ -524,7 +619,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
     // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
     PAR(lane) {
         for (int k = lane; k < N; k += 64) {
-            const double *rec = I.as + (size_t)k * OB_AS; double *ro = I.rs + (size_t)k * OB_RS;
+            const gdbl *rec = I.as + (size_t)k * OB_AS; gdbl *ro = I.rs + (size_t)k * OB_RS;
             double K0[6], K1[6], kf0 = 0, kf1 = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
@@ -551,23 +646,32 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
     SYNC();
     PAR(lane) { if (lane < 42) sh.cl[0][lane] = (I.rs)[RS_CL + lane]; }
     SYNC();
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential; stage data double-buffered through LDS)
-    for (int k = 0; k < N; k++) {
-        PAR(lane) {
-            double pf = 0;
-            if (k + 1 < N && lane < 42) pf = (I.rs + (size_t)(k + 1) * OB_RS)[RS_CL + lane];
-            if (lane < 6) {
-                const double *cl = sh.cl[k & 1], *s = sh.s[k & 1];
-                double v = cl[36 + lane];
+    PROF(I, PF_BORDER_CL);
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential).  The closed-loop data of step k+2 is gathered from HBM
+    // while step k runs (per-lane register pipeline); the trajectory stays in LDS, so the loop issues no global store.
+    {
+        double pf[OBCA_NL];
+        PAR(lane) { pf[LI(lane)] = (N > 1 && lane < 42) ? (I.rs + (size_t)OB_RS)[RS_CL + lane] : 0.0; if (lane < 6) sh.traj[lane] = 0.0; }
+        LDS_SYNC();
+        for (int k = 0; k < N; k++) {
+            PAR(lane) {
+                if (lane < 6) {
+                    const double *cl = sh.cl[k & 1], *s_ = sh.traj + (size_t)k * 6;
+                    double v = cl[36 + lane];
 #pragma unroll
-                for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s[j];
-                sh.s[(k + 1) & 1][lane] = v;
-                I.traj[(size_t)(k + 1) * 6 + lane] = v;
+                    for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s_[j];
+                    sh.traj[(size_t)(k + 1) * 6 + lane] = v;
+                }
+                if (k + 1 < N && lane < 42) {
+                    sh.cl[(k + 1) & 1][lane] = pf[LI(lane)];
+                    if (k + 2 < N) pf[LI(lane)] = (I.rs + (size_t)(k + 2) * OB_RS)[RS_CL + lane];
+                }
             }
-            if (k + 1 < N && lane < 42) sh.cl[(k + 1) & 1][lane] = pf;
+            LDS_SYNC();
         }
-        SYNC();
     }
+    SYNC();
+    PROF(I, PF_FWD_SEQ);
     // ---- stage-parallel: primal steps of x,u; costates; bound terms of x,u ; steering rows
     PAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
@@ -577,7 +681,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
         for (int k = lane; k <= N; k += 64) {
             double s[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) s[i] = k ? I.traj[(size_t)k * 6 + i] : 0.0;
+            for (int i = 0; i < 6; i++) s[i] = sh.traj[(size_t)k * 6 + i];
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
             double x[4];
 #pragma unroll
@@ -594,7 +698,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
                 // costate increment of the row x_k - F_{k-1}: -(Px_k s_k + pv_k . coef)   (for k=N, rs[N] is not written: use terminal data)
             }
             if (k < N) {
-                const double *ro = I.rs + (size_t)k * OB_RS;
+                const gdbl *ro = I.rs + (size_t)k * OB_RS;
                 double du[2];
                 du[0] = ro[RS_CL + 40]; du[1] = ro[RS_CL + 41];
 #pragma unroll
@@ -612,7 +716,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
                     FTBZ(zL, mu / dL - zL - zL / dL * du[i]); FTBZ(zU, mu / dU - zU + zU / dU * du[i]);
                 }
                 // steering row back-substitution
-                const double *rec = I.as + (size_t)k * OB_AS;
+                const gdbl *rec = I.as + (size_t)k * OB_AS;
                 const double lin = rec[AS_GG] * s[4] + rec[AS_GG + 1] * du[0] + rec[AS_GG + 2] * dt;
                 const double dyg = rec[AS_SIG] * (lin + rec[AS_RG]);
                 const double dss = (dyg - rec[AS_RSS]) / rec[AS_DSS];
@@ -624,9 +728,9 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
                 // costate of x_{k+1} - F_k
                 double sn[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) sn[i] = I.traj[(size_t)(k + 1) * 6 + i];
+                for (int i = 0; i < 6; i++) sn[i] = sh.traj[(size_t)(k + 1) * 6 + i];
                 if (k + 1 < N) {
-                    const double *r1 = I.rs + (size_t)(k + 1) * OB_RS;
+                    const gdbl *r1 = I.rs + (size_t)(k + 1) * OB_RS;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         double a_ = 0;
@@ -637,7 +741,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
                         d[l.pi + 4 * k + i] = -a_;
                     }
                 } else {   // terminal cost-to-go: P_N = H_N(+rho), p_N = (hb_N - rho e, Ht_N, e_i)
-                    const double *rN = I.as + (size_t)N * OB_AS;
+                    const gdbl *rN = I.as + (size_t)N * OB_AS;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         double e = -(z[l.x + 4 * N + i] - c.xF[i]);
@@ -656,6 +760,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
     SYNC();
     double ap = red_min(sh.red[0]), az = red_min(sh.red[1]), gd = red_sum(sh.red[2]);
     SYNC();
+    PROF(I, PF_BS_STAGE);
     // ---- obstacle blocks: back-substitution (the block is re-factorised instead of being stored)
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
@@ -725,12 +830,13 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
     }
     SYNC();
     so.ap = ap; so.az = az; so.gd = gd;
+    PROF(I, PF_BS_OBS);
 }
 
 // ---------------------------------------------------------------- objective / constraint 1-norm / barrier at z + alpha d (primal part)
 OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, double &th1, double &bar) {
-    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    const double *z = I.z, *d = I.d;
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const gdbl *z = I.z, *d = I.d;
     const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts;
     PAR(lane) {
         double lf = 0, lth = 0, lbar = 0;
@@ -780,14 +886,15 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
     f = red_sum(sh.red[0]); th1 = red_sum(sh.red[1]); bar = red_sum(sh.red[2]);
     SYNC();
     if (!c.fixTime) { f += (N + 1) * (0.5 * t + t * t); bar += (N + 1) * (log(t - OB_TL) + log(OB_TU - t)); }
+    PROF(I, PF_TRIAL);
 }
 
 // ---------------------------------------------------------------- accept the step
 OBCA_FN double clampz(double zz, double dist, double mu, double ks) { double lo = mu / (ks * dist), hi = ks * mu / dist; return zz < lo ? lo : (zz > hi ? hi : zz); }
 
 OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, double az, double mu, double ks) {
-    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    double *z = I.z; const double *d = I.d;
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    gdbl *z = I.z; const gdbl *d = I.d;
     PAR(lane) {
         // one-sided (>=0) groups: lam, mu, so
         for (int i = lane; i < M * (N + 1); i += 64) {
@@ -851,6 +958,7 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
         }
     }
     SYNC();
+    PROF(I, PF_APPLY);
 }
 
 // ---------------------------------------------------------------- starting point (IPOPT sec. 3.6: push into the bounds, z=1, y=0)
@@ -860,9 +968,10 @@ OBCA_FN double push2(double v, double lo, double hi, double k1, double k2) {
     if (v > hi - pu) v = hi - pu;
     return v;
 }
-OBCA_FN void init_point(const Inst &I, Shared &sh, const Opts &o) {
-    const Consts &c = I.c; const Lay &l = I.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    double *z = I.z;
+struct PushOpts { double bound_push, bound_frac; };
+OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    gdbl *z = I.z;
     PAR(lane) {
         if (lane < 4) z[l.x + lane] = c.x0[lane];
         if (lane == 4 && c.fixTime) z[l.t] = 1.0;
@@ -902,19 +1011,28 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const Opts &o) {
     SYNC();
 }
 
+// ---------------------------------------------------------------- phase entry points (non-inlined; state lives in g_sh)
+OBCA_PHASE void ph_init(double bound_push, double bound_frac) { Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac}; PROF(sh.inst, PF_OTHER); init_point(sh.inst, sh, po); PROF(sh.inst, PF_INIT); }
+OBCA_PHASE void ph_assemble(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_PHASE int ph_riccati(double rho) { Shared &sh = g_sh; return riccati_backward(sh.inst, sh, rho); }
+OBCA_PHASE void ph_direction(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; solve_direction(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
+OBCA_PHASE void ph_trial(double alpha) { Shared &sh = g_sh; eval_trial(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double ks) { Shared &sh = g_sh; apply_step(sh.inst, sh, alpha, ay, az, mu, ks); }
+
 // ---------------------------------------------------------------- the interior-point driver
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
 
-OBCA_FN void ipm_attempt(const Inst &I, Shared &sh, const Opts &o, Result &R) {
-    init_point(I, sh, o);
+OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
+    Shared &sh = g_sh;
+    ph_init(o.bound_push, o.bound_frac);
     double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
     int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
-    AsmOut A;
+    const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
     for (;;) {
         double dc = o.dc_bar * pow(mu, o.kappa_c);
-        assemble(I, sh, mu, 0.0, dc, A);
+        ph_assemble(mu, 0.0, dc, 0);
         if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
@@ -923,31 +1041,28 @@ OBCA_FN void ipm_attempt(const Inst &I, Shared &sh, const Opts &o, Result &R) {
         if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
         if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
         if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
-        // barrier update
+        // barrier update: mu <- max(tol/10, min(kappa_mu mu, mu^theta_mu)) while the barrier problem is solved to kappa_eps mu
         int mu_changed = 0;
         {
             double cm = A.cinfmu;
             for (;;) {
-                double Emu = fmax(A.dinf / sd, fmax(A.pinf, cm / sc));
+                double Emu = fmax(dinf / sd, fmax(pinf, cm / sc));
                 if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
-                    double mu_new = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-                    // |v z - mu_new| <= |v z - mu| + (mu - mu_new): recompute exactly on the next assemble; here use the bound-free
-                    // identity max|vz-mu_new| via the stored extremes is not available, so re-assemble below.
-                    mu = mu_new; tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
-                    AsmOut A2; assemble(I, sh, mu, 0.0, o.dc_bar * pow(mu, o.kappa_c), A2); cm = A2.cinfmu;
+                    mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                    tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
+                    ph_assemble(mu, 0.0, o.dc_bar * pow(mu, o.kappa_c), 1);   // complementarity error w.r.t. the new mu
+                    cm = sh.A2.cinfmu;
                 } else break;
             }
         }
         dc = o.dc_bar * pow(mu, o.kappa_c);
         // search direction with inertia correction (IPOPT Algorithm IC)
-        double dw = 0; int ok = 0; StepOut S;
+        double dw = 0; int ok = 0;
         for (int tr = 0; tr < 60; tr++) {
-            if (tr > 0 || mu_changed) assemble(I, sh, mu, dw, dc, A);
+            if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
             int a_ = A.ok;
-            if (a_) a_ = riccati_backward(I, sh, o.rho_term);
-            if (a_) {
-                solve_direction(I, sh, A, mu, dw, dc, o.rho_term, tau, S); a_ = S.ok;
-            }
+            if (a_) a_ = ph_riccati(o.rho_term);
+            if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
             if (a_) { ok = 1; break; }
             nreg++;
             if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);
@@ -956,18 +1071,17 @@ OBCA_FN void ipm_attempt(const Inst &I, Shared &sh, const Opts &o, Result &R) {
         }
         if (!ok) { status = ST_ERROR; break; }
         if (dw > 0) dw_last = dw;
-        const double th = A.th1, phi = A.f - mu * A.bar, gd = S.gd;
+        const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
         double amin;
         if (gd < 0) {
             amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
             if (th <= th_min) amin = fmin(amin, o.delta * pow(th, o.s_theta) / pow(-gd, o.s_phi));
         } else amin = o.gamma_theta;
         amin *= o.gamma_alpha;
-        double alpha = S.ap; int acc = 0;
+        double alpha = sh.S.ap; int acc = 0;
         while (alpha >= amin) {
-            double ft, tht, bart;
-            eval_trial(I, sh, alpha, ft, tht, bart);
-            double pht = ft - mu * bart;
+            ph_trial(alpha);
+            const double ft = sh.trial[0], tht = sh.trial[1], pht = ft - mu * sh.trial[2];
             if (ft == ft && tht == tht && pht == pht && tht < th_max) {
                 int okf = 1;
                 for (int i = 0; i < nf && okf; i++) if (!(tht < sh.filt[i][0] || pht < sh.filt[i][1])) okf = 0;
@@ -989,36 +1103,39 @@ OBCA_FN void ipm_attempt(const Inst &I, Shared &sh, const Opts &o, Result &R) {
             alpha *= 0.5;
         }
         if (!acc) { status = ST_ERROR; break; }   // IPOPT would enter restoration here
-        apply_step(I, sh, alpha, fmin(alpha, S.az), S.az, mu, o.kappa_sigma);
+        ph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
         it++;
     }
     R.status = status; R.iters = it; R.nreg = nreg; R.obj = f; R.pinf = pinf; R.dinf = dinf; R.mu = mu;
 }
 
-// Full solve of one instance: first attempt, and on Error/UserLimit one re-solve from the last iterate
-// (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
-OBCA_FN void solve_instance(Inst &I, Shared &sh, const Opts &o, double *info) {
+// Full solve of one instance (pointers already in g_sh.inst): first attempt, and on Error/UserLimit one re-solve from the last
+// iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
+OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
+    Shared &sh = g_sh;
     PAR(lane) {
-        for (int i = lane; i < OB_HDR; i += 64) sh.hdr[i] = I.prob[i];
+        for (int i = lane; i < OB_HDR; i += 64) sh.hdr[i] = sh.inst.prob[i];
     }
     SYNC();
     PAR(lane) {
         if (lane <= OB_NOBMAX) sh.roff[lane] = (int)sh.hdr[PH_ROFF + lane];
         if (lane < OB_NOBMAX) sh.vOb[lane] = (int)sh.hdr[PH_VOB + lane];
+        if (lane == 0) {
+            Consts &c = sh.c;
+            c.N = N; c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
+            for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
+            c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
+            c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
+            make_layout(c.N, c.nOb, c.M, sh.l);
+        }
     }
     SYNC();
-    Consts &c = I.c;
-    c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
-    for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
-    c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
-    c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
-    make_layout(c.N, c.nOb, c.M, I.l);
     Result R;
-    ipm_attempt(I, sh, o, R);
+    ipm_attempt(o, R);
     int ef = (R.status == ST_OPTIMAL), iters = R.iters, nreg = R.nreg;
     if (!ef) {
         Result R2;
-        ipm_attempt(I, sh, o, R2);
+        ipm_attempt(o, R2);
         iters += R2.iters; nreg += R2.nreg;
         if (R2.status == ST_OPTIMAL) ef = 1;
         R = R2;

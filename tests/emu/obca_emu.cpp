@@ -17,18 +17,18 @@ static void alloc_scratch(int N, int len, Scratch &s) {
 }
 static void free_scratch(Scratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.traj); }
 
-static void setup(Inst &I, Shared &sh, int N, const double *prob, Scratch &s) {
+static void setup(int N, const double *prob, Scratch &s) {
+    Shared &sh = g_sh; Inst &I = sh.inst;
     I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
-    I.c.N = N;
     for (int i = 0; i < OB_HDR; i++) sh.hdr[i] = prob[i];
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
-    Consts &c = I.c;
+    Consts &c = sh.c; c.N = N;
     c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
     for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
     c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
     c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
-    make_layout(c.N, c.nOb, c.M, I.l);
+    make_layout(c.N, c.nOb, c.M, sh.l);
 }
 
 extern "C" {
@@ -39,7 +39,7 @@ int emu_newton(int N, const double *prob, const double *zin, int len, double mu,
                double *dout, double *aux /* dinf,pinf,cinf0,cinfmu,f,th1,bar,ap,az,gd */) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len);
-    Inst I; static Shared sh; setup(I, sh, N, prob, s);
+    setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
     AsmOut A; assemble(I, sh, mu, dw, dc, A);
     int ok = A.ok;
     StepOut S; S.ap = S.az = S.gd = 0;
@@ -55,7 +55,7 @@ int emu_newton(int N, const double *prob, const double *zin, int len, double mu,
 int emu_eval_trial(int N, const double *prob, const double *zin, const double *din, int len, double alpha, double *out3) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len); memcpy(s.d, din, sizeof(double) * len);
-    Inst I; static Shared sh; setup(I, sh, N, prob, s);
+    setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
     eval_trial(I, sh, alpha, out3[0], out3[1], out3[2]);
     free_scratch(s);
     return 0;
@@ -65,8 +65,8 @@ int emu_eval_trial(int N, const double *prob, const double *zin, const double *d
 int emu_solve(int N, const double *prob, const double *zinit, int len, const void *opts, double *zout, double *info) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zinit, sizeof(double) * len);
-    Inst I; static Shared sh; I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj; I.c.N = N;
-    solve_instance(I, sh, *(const Opts *)opts, info);
+    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+    solve_instance(N, *(const Opts *)opts, info);
     memcpy(zout, s.z, sizeof(double) * len);
     free_scratch(s);
     return 0;

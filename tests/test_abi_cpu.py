@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/obca_hip.h declares, and fails loudly."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import obca_amd
+    path = obca_amd.build_library()
+    assert os.path.exists(path)
+    return C.CDLL(path)
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "obca_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(obca_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), s
+    from obca_amd.api import EXPORTS
+    assert sorted(EXPORTS) == syms
+
+
+def test_opts_struct_matches_and_defaults(lib):
+    from obca_amd.api import Opts
+    o = Opts()
+    assert lib.obca_default_opts(C.byref(o)) == 0
+    # the reference's IPOPT options (ParkingSignedDist.jl:41-43)
+    assert o.tol == 1e-5 and o.max_iter == 200 and o.dw_min == 1e-12 and o.dc_bar == 1e-7
+    import oracle as O
+    oo = O.default_opts()
+    for n, _ in Opts._fields_:
+        assert getattr(o, n) == getattr(oo, n), n
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import obca_amd
+    with pytest.raises(obca_amd.ObcaError):
+        obca_amd.Context(0)
+    with pytest.raises(obca_amd.ObcaError):
+        obca_amd.DualMultWS(1, 1, [1], [[0, 1]], [5.0], [0, 0], [0, 0], [0, 0], [3.7, 1, 1, 1])
+
+
+def test_product_does_not_import_oracle():
+    # the product package must never reach into oracle/ (or tests/emu)
+    pkg = os.path.join(ROOT, "obca_amd")
+    for dp_, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dp_, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "obca_oracle" not in src, f
+                assert "libobca_emu" not in src, f

@@ -1,0 +1,96 @@
+"""The HIP solver source, compiled as a host emulation (64 lanes as a loop), against the oracle: kernel LOGIC without a GPU."""
+import ctypes as C
+import numpy as np
+from obca_amd import scenarios as S, packing as P
+
+D = C.POINTER(C.c_double)
+dp = lambda a: a.ctypes.data_as(D)
+
+
+class EOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int)] + \
+        [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
+                                   "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
+                                   "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()]
+
+
+def test_layouts_agree(oracle):
+    for N, v in ((5, [2, 2, 1]), (80, [2, 2, 1, 1]), (12, [4]), (7, [1] * 10)):
+        a = oracle.layout(N, v); b = P.layout(N, len(v), sum(v))
+        assert all(a[k] == b[k] for k in a)
+
+
+def test_emu_newton_direction_matches_oracle(oracle, emu, backwards):
+    rng = np.random.default_rng(3)
+    for N in (3, 9):
+        sc = S.BACKWARDS; A, b, v = backwards["A"], backwards["b"], backwards["vOb"]; nOb = len(v); M = int(v.sum())
+        x0 = np.array([-5, 9.0, -0.1, 0.]); Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); Ts = 0.7
+        L = P.layout(N, nOb, M)
+        z = np.zeros(L["len"])
+        X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 4)); X[0] = x0
+        z[L["x"]:L["u"]] = X.reshape(-1)
+        z[L["u"]:L["t"]] = np.clip(uWS + 0.05 * rng.standard_normal((N, 2)), -0.3, 0.3).reshape(-1)
+        z[L["t"]] = 0.95
+        z[L["lam"]:L["sl"]] = rng.uniform(0.1, 1, L["sl"] - L["lam"])
+        z[L["sl"]:L["so"]] = 0.01 * rng.standard_normal(L["so"] - L["sl"])
+        z[L["so"]:L["ss"]] = rng.uniform(0.1, 1, L["ss"] - L["so"])
+        z[L["ss"]:L["pi"]] = rng.uniform(-0.3, 0.3, N)
+        z[L["pi"]:L["zxL"]] = rng.standard_normal(L["zxL"] - L["pi"])
+        z[L["zxL"]:] = rng.uniform(0.1, 2, L["len"] - L["zxL"])
+        mu, dw, dc = 0.05, 5.0, 1e-7
+        ok, d, errs = oracle.newton(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc)
+        prob = P.pack_problem(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        d2 = np.zeros_like(z); aux = np.zeros(10)
+        ok2 = emu.emu_newton(C.c_int(N), dp(prob), dp(z), C.c_int(L["len"]), C.c_double(mu), C.c_double(dw), C.c_double(dc),
+                             C.c_double(1e3), C.c_double(0.99), dp(d2), dp(aux))
+        assert ok == 1 and ok2 == 1
+        nd = L["zxL"]
+        assert np.abs(d[:nd] - d2[:nd]).max() < 1e-9 * max(1.0, np.abs(d[:nd]).max())
+        assert np.allclose(aux[:3], errs, rtol=1e-10)
+        # objective / constraint norm / barrier of eval_trial at alpha=0 equal the assembly's
+        out = np.zeros(3)
+        emu.emu_eval_trial(C.c_int(N), dp(prob), dp(z), dp(d2), C.c_int(L["len"]), C.c_double(0.0), dp(out))
+        assert np.allclose(out, aux[4:7], rtol=1e-12)
+
+
+def test_emu_full_solve_matches_oracle(oracle, emu, backwards):
+    N, B = 20, 3
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+    oo = oracle.default_opts(); eo = EOpts()
+    for n, _ in EOpts._fields_:
+        setattr(eo, n, getattr(oo, n))
+    assert emu.emu_opts_size() == C.sizeof(eo)
+    for i in range(B):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                              xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        zo = np.zeros_like(z0); info = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+        assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"]
+        assert np.abs(xp - r["xp"]).max() < 1e-8 and np.abs(up - r["up"]).max() < 1e-8 and abs(t - r["t"]) < 1e-10
+        assert np.abs(lp - r["lp"]).max() < 1e-7 and np.abs(npp - r["np"]).max() < 1e-7
+
+
+def test_emu_dualws_matches_oracle(oracle, emu, backwards):
+    A, b, v = backwards["A"], backwards["b"], backwards["vOb"]
+    rng = np.random.default_rng(5)
+    g = np.array([2.35, 1.0, 2.35, 1.0])
+    for _ in range(20):
+        X, Y, psi = rng.uniform(-10, 10), rng.uniform(5.5, 10), rng.uniform(-np.pi, np.pi)
+        lo, no, do = oracle.dualmult_ws(0, v, A, b, [X], [Y], [psi], S.EGO)
+        r0 = 0
+        for j, vj in enumerate(v):
+            a1 = np.ascontiguousarray(A[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(A[r0:r0 + vj, 1]); bj = np.ascontiguousarray(b[r0:r0 + vj])
+            lam = np.zeros(4); mu = np.zeros(4); d = C.c_double(0)
+            cs, sn = np.cos(psi), np.sin(psi)
+            emu.emu_dualws(C.c_int(int(vj)), dp(a1), dp(a2), dp(bj), dp(g), C.c_double(X + 1.35 * cs), C.c_double(Y + 1.35 * sn),
+                           C.c_double(cs), C.c_double(sn), dp(lam), dp(mu), C.byref(d))
+            assert abs(d.value - do[0, j]) < 1e-10 and np.abs(lam[:vj] - lo[0, r0:r0 + vj]).max() < 1e-9
+            assert np.abs(mu - no[0, 4 * j:4 * j + 4]).max() < 1e-9
+            r0 += vj

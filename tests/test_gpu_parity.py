@@ -1,0 +1,158 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Every call goes through the C ABI of libobca_hip.so; the oracle is
+only the checker.  Tolerances: the HIP path and the oracle implement the same iteration in fp64, so agreement is far inside
+the stated parity tolerance (objective 1e-4 rel., states/inputs 1e-3 abs.); the tests assert 1e-6."""
+import numpy as np
+import pytest
+from conftest import golden
+from obca_amd import scenarios as S
+
+pytestmark = pytest.mark.gpu
+TOL_X, TOL_F = 1e-6, 1e-8
+
+
+@pytest.fixture(scope="module")
+def OA():
+    import obca_amd
+    obca_amd.Context(0).close()      # fails loudly if the HIP library / device is missing
+    return obca_amd
+
+
+def _solve_batch(OA, bt, fixTime=0, lWS=None, nWS=None, opts=None):
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    return OA.parking_signed_dist_batch(bt["x0"], bt["xF"], bt["N"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                        bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], fixTime, xWS, bt["uWS"], lWS, nWS, opts), xWS
+
+
+def test_dualws_matches_oracle_and_geometry(OA, oracle):
+    N, B = 80, 64
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"]
+    ls, ns, ds = OA.dualmult_ws_batch(N, bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], bt["ego"])
+    for i in range(0, B, 7):
+        lo, no, do = oracle.dualmult_ws(N, bt["vOb"], bt["A"], bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], bt["ego"])
+        assert np.abs(ds[i] - do).max() < 1e-9 and np.abs(ls[i] - lo).max() < 1e-8 and np.abs(ns[i] - no).max() < 1e-8
+    # known answers: single half-plane obstacle = closed-form rectangle/half-plane gap
+    g = golden("dualws_known.npz"); n = len(g["d"])
+    ls, ns, ds = OA.dualmult_ws_batch(0, [[1]] * n, [a[None, :] for a in g["a"]], [[bb] for bb in g["beta"]],
+                                      g["poses"][:, 0:1], g["poses"][:, 1:2], g["poses"][:, 2:3], S.EGO)
+    assert np.abs(np.array([d[0, 0] for d in ds]) - g["d"]).max() < 2e-7
+
+
+def test_parking_matches_oracle_config2(OA, oracle):
+    N, B = 80, 16
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    out, xWS = _solve_batch(OA, bt)
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert out["exitflag"][i] == r["exitflag"] == 1
+        assert out["iters"][i] == r["iters"]
+        assert abs(out["obj"][i] - r["obj"]) <= TOL_F * max(1, abs(r["obj"]))
+        assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and np.abs(out["up"][i] - r["up"]).max() < TOL_X
+        assert np.abs(out["timeScale"][i] - r["timeScale"]).max() < 1e-9
+        assert np.abs(out["lp"][i] - r["lp"]).max() < 1e-5 and np.abs(out["np"][i] - r["np"]).max() < 1e-5
+
+
+def test_parking_matches_golden_fixture(OA):
+    g = golden("oracle_cfg2.npz")
+    B, N = int(g["B"]), int(g["N"])
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    out, _ = _solve_batch(OA, bt)
+    assert np.array_equal(out["exitflag"], g["exitflag"]) and np.array_equal(out["iters"], g["iters"])
+    assert np.abs(out["xp"] - g["xp"]).max() < TOL_X and np.abs(out["up"] - g["up"]).max() < TOL_X
+    assert np.abs(out["obj"] - g["obj"]).max() < 1e-7
+
+
+def test_full_size_properties_config2(OA):
+    """B=1024 (BASELINE config 2): size-independent properties -- every converged instance passes the reference's own
+    acceptance test (ParkingConstraints.jl @5e-5) and the full checker; boundary conditions hold exactly; solving twice is
+    deterministic."""
+    import checkers as K
+    N, B = 80, 1024
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    out, _ = _solve_batch(OA, bt)
+    ok = out["exitflag"] == 1
+    assert ok.mean() >= 0.97
+    assert np.abs(out["xp"][:, :, 0] - bt["x0"]).max() == 0.0
+    assert np.abs(out["xp"][ok][:, :, N] - bt["xF"][ok]).max() < 5e-5
+    for i in np.flatnonzero(ok)[::8]:
+        args = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"], bt["A"], bt["b"],
+                out["xp"][i], out["up"][i], out["lp"][i], out["np"][i], out["timeScale"][i], 0)
+        viol = K.parking_constraints_full(*args, out["sl"][i])
+        assert K.feasible(viol, tol=1e-4), (i, viol)      # every row incl. the slack, at IPOPT's constr_viol_tol
+        if viol["penetration"] <= 0:                      # ParkingConstraints.jl ignores the slack (Q5): it can only pass when
+            assert K.parking_constraints_ref(*args, 1) == 1, i   # no pose (incl. the fixed start pose) needs positive slack
+    out2, _ = _solve_batch(OA, bt)
+    assert np.array_equal(out["iters"], out2["iters"]) and np.abs(out["xp"] - out2["xp"]).max() == 0.0
+
+
+def test_single_instance_wrapper_and_shapes(OA, oracle, backwards):
+    N = 40; sc = S.BACKWARDS; x0 = sc["x0"]
+    Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); xWS[0] = x0
+    xp, up, ts, ef, tm, lp, npp = OA.ParkingSignedDist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], 3,
+                                                       backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2],
+                                                       0, xWS, uWS)
+    assert xp.shape == (4, N + 1) and up.shape == (2, N) and ts.shape == (N + 1,) and lp.shape == (5, N + 1) and npp.shape == (12, N + 1)
+    r = oracle.parking_signed_dist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
+                                   backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS)
+    assert ef == r["exitflag"] == 1 and np.abs(xp - r["xp"]).max() < TOL_X and tm > 0
+    l1, n1 = OA.DualMultWS(N, 3, backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], backwards["ego"])
+    assert l1.shape == (N + 1, 5) and n1.shape == (N + 1, 12)          # DualMultWS.jl:81-84 returns the transposed shapes
+
+
+def test_fixtime_and_supplied_duals(OA, oracle):
+    N, B = 30, 6
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=5)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    duals = [oracle.dualmult_ws(N, bt["vOb"], bt["A"], bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], bt["ego"]) for i in range(B)]
+    out, _ = _solve_batch(OA, bt, fixTime=1, lWS=[d[0] for d in duals], nWS=[d[1] for d in duals])
+    assert np.all(out["timeScale"] == 1.0)
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 1, xWS[i], bt["uWS"][i], duals[i][0], duals[i][1])
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"]
+        if r["exitflag"]:
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+
+
+def test_mixed_obstacle_counts_ragged_batch(OA, oracle):
+    """per-instance obstacle sets of different size in ONE batch (irregular H-rep packing)"""
+    N = 40; full = S.scenario_hrep(S.BACKWARDS)
+    A, b, v = full
+    sets = [([2, 2, 1], A, b), ([2, 2], A[:4], b[:4]), ([1], A[4:5], b[4:5]), ([2, 1], np.vstack([A[:2], A[4:5]]), np.concatenate([b[:2], b[4:5]]))]
+    B = 8
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=11)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    vl = [sets[i % 4][0] for i in range(B)]; Al = [sets[i % 4][1] for i in range(B)]; bl = [sets[i % 4][2] for i in range(B)]
+    out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], vl, Al, bl,
+                                       xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], vl[i], Al[i], bl[i],
+                                       xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert out["lp"][i].shape == (sum(vl[i]), N + 1) and out["np"][i].shape == (4 * len(vl[i]), N + 1)
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"]
+        if r["exitflag"]:
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+
+
+def test_bad_inputs_fail_loudly_not_crash(OA):
+    N = 10; bt = S.make_batch(S.BACKWARDS, 2, N)
+    xWS = bt["xWS"].copy()
+    with pytest.raises(OA.ObcaError):      # 5 rows in one obstacle > OBCA_VMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [5], np.zeros((5, 2)), np.zeros(5),
+                                     xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    with pytest.raises(OA.ObcaError):      # 11 obstacles > OBCA_NOBMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [1] * 11, np.ones((11, 2)), np.zeros(11),
+                                     xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    bad = bt["x0"].copy(); bad[0, 0] = np.nan  # NaN input: exitflag 0 for that instance, the other one still solves
+    out = OA.parking_signed_dist_batch(bad, bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                       xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    assert out["exitflag"][0] == 0 and out["exitflag"][1] in (0, 1)
+
+
+def test_iteration_limit_and_retry_exitflag(OA, oracle):
+    N, B = 30, 4
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=3)
+    o = OA.default_opts(); o.max_iter = 3
+    out, _ = _solve_batch(OA, bt, opts=o)
+    assert np.all(out["exitflag"] == 0) and np.all(out["iters"] == 6) and np.all(out["status"] == 1)   # two attempts (:256-290)
