@@ -473,14 +473,14 @@ OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
       if (lane < 48) { int i = lane / OB_NC, cc = lane % OB_NC; if (cc == 0) { idx = AS_HB + i; fl = 1.0; } if (cc == 1) { idx = AS_HT + i; fl = 1.0; } }
       p.idx[3] = idx; p.flag[3] = fl; p.kc[3] = 0.0; }
 }
-OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[4]) {   // four independent, branch-free gathers
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = p.kc[j] + p.flag[j] * rec[p.idx[j]];
+OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[4]) {   // four independent, branch-free gathers;
+#pragma unroll                                                                           // the raw values are only touched at store time
+    for (int j = 0; j < 4; j++) v[j] = rec[p.idx[j]];
 }
-OBCA_FN void stage_unpack_store(double *sg, int lane, const double v[4]) {
-    sg[SG_H + lane] = v[0]; sg[SG_FA + lane] = v[1];
-    if (lane + 64 < 84) sg[SG_FA + lane + 64] = v[2];
-    if (lane < 48) sg[SG_HC + lane] = v[3];
+OBCA_FN void stage_unpack_store(double *sg, int lane, const UnpackPlan &p, const double v[4]) {
+    sg[SG_H + lane] = v[0]; sg[SG_FA + lane] = p.kc[1] + p.flag[1] * v[1];
+    if (lane + 64 < 84) sg[SG_FA + lane + 64] = p.kc[2] + p.flag[2] * v[2];
+    if (lane < 48) sg[SG_HC + lane] = p.flag[3] * v[3];
 }
 
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
@@ -504,7 +504,7 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
             for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
         }
         double v[4]; stage_unpack_load(I.as + (size_t)(N - 1) * OB_AS, plan[LI(lane)], v);
-        stage_unpack_store(sh.stg[(N - 1) & 1], lane, v);
+        stage_unpack_store(sh.stg[(N - 1) & 1], lane, plan[LI(lane)], v);
         if (N >= 2) stage_unpack_load(I.as + (size_t)(N - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
     }
     SYNC();
@@ -543,16 +543,17 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
         }
         LDS_SYNC();
         PROF(I, PF_RIC_P1);
-        double Lc[3];
-        if (!chol2(sh.Qhat[6 * 14 + 6], sh.Qhat[7 * 14 + 6], sh.Qhat[7 * 14 + 7], Lc)) { PROF(I, PF_RIC_BWD); return 0; }
-        // inverse of Quu from its Cholesky factor: Quu^{-1} = [g00 g01; g01 g11]
-        const double il0 = 1.0 / Lc[0], il2 = 1.0 / Lc[2];
-        const double g11 = il2 * il2, g01 = -Lc[1] * il0 * g11, g00 = il0 * il0 + Lc[1] * Lc[1] * il0 * il0 * g11;
+        // Quu = [q00 q10; q10 q11] must be positive definite; its inverse [g00 g01; g01 g11] from the two Schur pivots (no sqrt needed)
+        const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
+        if (!(q00 > 0)) { PROF(I, PF_RIC_BWD); return 0; }
+        const double iq00 = 1.0 / q00, m10 = q10 * iq00, sch = q11 - m10 * q10;
+        if (!(sch > 0)) { PROF(I, PF_RIC_BWD); return 0; }
+        const double g11 = 1.0 / sch, g01 = -m10 * g11, g00 = iq00 - m10 * g01;
         gdbl *ro = I.rs + (size_t)k * OB_RS;
         PAR(lane) {   // eliminate u_k: lanes 0..35 -> P[i][cc] and pn[i][cc]; lanes 36..56 -> bilinear constants
             // first retire the gathers issued one stage ago (before this phase issues any store: the memory counter is in-order)
             if (k > 0) {
-                stage_unpack_store(sh.stg[(k - 1) & 1], lane, nv[LI(lane)]);
+                stage_unpack_store(sh.stg[(k - 1) & 1], lane, plan[LI(lane)], nv[LI(lane)]);
                 if (k > 1) stage_unpack_load(I.as + (size_t)(k - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
             }
             if (lane < 36) {
