@@ -71,59 +71,58 @@ OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], d
         o.dF[3][i] = 0;
     }
     o.dF[3][3] = tau; o.dF[3][4] = Ts * a;
-    // second derivatives: H = sum_ab G_ab dm_a dm_b^T + sum_a g_a Hess(m_a),  m = (tau, s, phi|T)
-    const double G1[3][3] = {{0, cs, -s * sn}, {cs, 0, -tau * sn}, {-s * sn, -tau * sn, -tau * s * cs}};
-    const double G2[3][3] = {{0, sn, s * cs}, {sn, 0, tau * cs}, {s * cs, tau * cs, -tau * s * sn}};
-    const double G3[3][3] = {{0, T / L, s / L}, {T / L, 0, tau / L}, {s / L, tau / L, 0}};
+    // second derivatives: Hess(F_i) = sum_ab G_ab dm_a dm_b^T + sum_a g_a Hess(m_a), m = (tau, s, phi) for F_X, F_Y and (tau, s, T)
+    // for F_psi.  Only HL = sum_i w_i Hess(F_i) is needed, so the weights are folded into two quadratic forms.
+    const double G12[3][3] = {{0, w[0] * cs + w[1] * sn, w[0] * (-s * sn) + w[1] * (s * cs)},
+                              {w[0] * cs + w[1] * sn, 0, w[0] * (-tau * sn) + w[1] * (tau * cs)},
+                              {w[0] * (-s * sn) + w[1] * (s * cs), w[0] * (-tau * sn) + w[1] * (tau * cs), w[0] * (-tau * s * cs) + w[1] * (-tau * s * sn)}};
+    const double G3w[3][3] = {{0, w[2] * T / L, w[2] * s / L}, {w[2] * T / L, 0, w[2] * tau / L}, {w[2] * s / L, w[2] * tau / L, 0}};
+    const double gs = w[0] * g1[1] + w[1] * g2[1] + w[2] * g3[1];      // weight of Hess(s)
+    const double gp = w[0] * g1[2] + w[1] * g2[2];                      // weight of Hess(phi)
+    const double gT = w[2] * g3[2];                                     // weight of Hess(T)
+    double U12[3][5], U3[3][5];
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            U12[a_][j] = G12[a_][0] * dtau[j] + G12[a_][1] * ds[j] + G12[a_][2] * dphi[j];
+            U3[a_][j] = G3w[a_][0] * dtau[j] + G3w[a_][1] * ds[j] + G3w[a_][2] * dT[j];
+        }
 #pragma unroll
     for (int i = 0; i < 5; i++)
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const double mi[3] = {dtau[i], ds[i], dphi[i]}, mj[3] = {dtau[j], ds[j], dphi[j]};
-            const double ni[3] = {dtau[i], ds[i], dT[i]}, nj[3] = {dtau[j], ds[j], dT[j]};
-            double h1 = 0, h2 = 0, h3 = 0;
-#pragma unroll
-            for (int p = 0; p < 3; p++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    h1 += G1[p][q] * mi[p] * mj[q];
-                    h2 += G2[p][q] * mi[p] * mj[q];
-                    h3 += G3[p][q] * ni[p] * nj[q];
-                }
-            // Hess(s): (a,t)=Ts/2 ; Hess(phi): (v,d)=tau Tp/2L, (v,t)=Ts T/2L, (d,d)=tau v T Tp/L, (d,t)=Ts v Tp/2L ; Hess(T): (d,d)=2 T Tp
-            double Hs = ((i == 3 && j == 4) || (i == 4 && j == 3)) ? 0.5 * Ts : 0.0;
-            double Hp = 0;
-            if ((i == 1 && j == 2) || (i == 2 && j == 1)) Hp = tau * Tp / (2 * L);
-            if ((i == 1 && j == 4) || (i == 4 && j == 1)) Hp = Ts * T / (2 * L);
-            if (i == 2 && j == 2) Hp = tau * v * T * Tp / L;
-            if ((i == 2 && j == 4) || (i == 4 && j == 2)) Hp = Ts * v * Tp / (2 * L);
-            double HT = (i == 2 && j == 2) ? 2 * T * Tp : 0.0;
-            h1 += g1[1] * Hs + g1[2] * Hp;
-            h2 += g2[1] * Hs + g2[2] * Hp;
-            h3 += g3[1] * Hs + g3[2] * HT;
-            double h4 = ((i == 3 && j == 4) || (i == 4 && j == 3)) ? Ts : 0.0;
-            HL[i][j] = w[0] * h1 + w[1] * h2 + w[2] * h3 + w[3] * h4;
-        }
+        for (int j = 0; j < 5; j++)
+            HL[i][j] = dtau[i] * (U12[0][j] + U3[0][j]) + ds[i] * (U12[1][j] + U3[1][j]) + dphi[i] * U12[2][j] + dT[i] * U3[2][j];
+    // Hess(s): (a,t)=Ts/2 ; Hess(phi): (v,d)=tau Tp/2L, (v,t)=Ts T/2L, (d,d)=tau v T Tp/L, (d,t)=Ts v Tp/2L ; Hess(T): (d,d)=2 T Tp ; Hess(F_v): (a,t)=Ts
+    const double hat = gs * 0.5 * Ts + w[3] * Ts;
+    HL[3][4] += hat; HL[4][3] += hat;
+    const double hvd = gp * tau * Tp / (2 * L), hvt = gp * Ts * T / (2 * L), hdt = gp * Ts * v * Tp / (2 * L);
+    HL[1][2] += hvd; HL[2][1] += hvd; HL[1][4] += hvt; HL[4][1] += hvt; HL[2][4] += hdt; HL[4][2] += hdt;
+    HL[2][2] += gp * tau * v * T * Tp / L + gT * 2 * T * Tp;
 }
 
 // ---------------------------------------------------------------- small dense helpers (compile-time sizes)
 template <int NMAX>
-OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower triangle in, L (strict lower) and D (diag) out
+OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower triangle in; out: L (strict lower), 1/D (diagonal)
     int bad = 0;
+    double D[NMAX];
 #pragma unroll
     for (int j = 0; j < NMAX; j++) {
+        D[j] = 1.0;
         if (j < n) {
             double d = A[j * NMAX + j];
 #pragma unroll
-            for (int k = 0; k < NMAX; k++) if (k < j) d -= A[j * NMAX + k] * A[j * NMAX + k] * A[k * NMAX + k];
+            for (int k = 0; k < NMAX; k++) if (k < j) d -= A[j * NMAX + k] * A[j * NMAX + k] * D[k];
             if (!(d > 0)) bad = 1;
-            A[j * NMAX + j] = d;
+            D[j] = d;
+            const double id = 1.0 / d;
+            A[j * NMAX + j] = id;
 #pragma unroll
             for (int i = 0; i < NMAX; i++) if (i > j && i < n) {
                 double s = A[i * NMAX + j];
 #pragma unroll
-                for (int k = 0; k < NMAX; k++) if (k < j) s -= A[i * NMAX + k] * A[j * NMAX + k] * A[k * NMAX + k];
-                A[i * NMAX + j] = s / d;
+                for (int k = 0; k < NMAX; k++) if (k < j) s -= A[i * NMAX + k] * A[j * NMAX + k] * D[k];
+                A[i * NMAX + j] = s * id;
             }
         }
     }
@@ -137,7 +136,7 @@ OBCA_FN void ldl_solve(int n, const double *A, double *b) {
         for (int k = 0; k < NMAX; k++) if (k < i) b[i] -= A[i * NMAX + k] * b[k];
     }
 #pragma unroll
-    for (int i = 0; i < NMAX; i++) if (i < n) b[i] /= A[i * NMAX + i];
+    for (int i = 0; i < NMAX; i++) if (i < n) b[i] *= A[i * NMAX + i];
 #pragma unroll
     for (int ii = 0; ii < NMAX; ii++) {
         int i = NMAX - 1 - ii;
@@ -232,13 +231,14 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
     // d rows 2..4 / d mu
     const double Jmu[3][4] = {{1, 0, -1, 0}, {0, 1, 0, -1}, {-c.g[0], -c.g[1], -c.g[2], -c.g[3]}};
     // local stationarity residuals, diagonals
-    double Dso = in.zso / in.so + dw, Dsl = 2e4 + dw;
-    double r_so = -y[3] - mu_b / in.so, r_sl = 1e2 + 2e4 * in.sl + y[3];
-    double Dmu[4], r_mu[4], Dlam[OB_VMAX], r_lam[OB_VMAX];
+    const double iso = 1.0 / in.so;
+    const double iDso = 1.0 / (in.zso * iso + dw), iDsl = 1.0 / (2e4 + dw);
+    double r_so = -y[3] - mu_b * iso, r_sl = 1e2 + 2e4 * in.sl + y[3];
+    double iDmu[4], r_mu[4], Dlam[OB_VMAX], r_lam[OB_VMAX];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
-        r_mu[i] = jy - mu_b / in.mu[i]; Dmu[i] = in.zm[i] / in.mu[i] + dw;
+        { const double im = 1.0 / in.mu[i]; r_mu[i] = jy - mu_b * im; iDmu[i] = 1.0 / (in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); if (rz > st->dmax) st->dmax = rz;
             double cc = in.mu[i] * in.zm[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
@@ -249,7 +249,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
     for (int i = 0; i < OB_VMAX; i++) {
         if (i < v) {
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
-            r_lam[i] = jy - mu_b / in.lam[i]; Dlam[i] = in.zl[i] / in.lam[i] + dw;
+            { const double il = 1.0 / in.lam[i]; r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
                 double cc = in.lam[i] * in.zl[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
@@ -273,19 +273,19 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
         for (int s_ = 0; s_ < 3; s_++) {
             double a_ = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * Jmu[s_][i] / Dmu[i];
+            for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * Jmu[s_][i] * iDmu[i];
             Tm[r * 3 + s_] = a_ + (r == s_ ? dc : 0.0);
         }
-    Tm[8] += 1.0 / Dso + 1.0 / Dsl;
+    Tm[8] += iDso + iDsl;
     double r234[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         double a_ = -cr[r + 1];
 #pragma unroll
-        for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] / Dmu[i];
+        for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] * iDmu[i];
         r234[r] = a_;
     }
-    r234[2] += -r_so / Dso + r_sl / Dsl;
+    r234[2] += -r_so * iDso + r_sl * iDsl;
     int bad = ldl_fact<3>(3, Tm);
     // W = T^{-1} [Jl234 | Jp234 | r234]
     double W[3][OB_VMAX + 4];
@@ -336,8 +336,9 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
 #pragma unroll
     for (int i = 0; i < OB_VMAX; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
     nw = sqrt(nw);
+    { const double inw = nw > 0 ? 1.0 / nw : 0.0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) hw[i] = nw > 0 ? hw[i] / nw : 0.0;
+      for (int i = 0; i < OB_VMAX; i++) hw[i] *= inw; }
     // Ht = Qh Kb Qh
 #pragma unroll
     for (int j = 0; j < OB_VMAX; j++) {
@@ -352,7 +353,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
     for (int i = 0; i < OB_VMAX; i++) hh_apply(v, hw, Kb + i * OB_VMAX);
     double a00 = Kb[0], det = a00 * (-dc) - alpha * alpha;
     if (!(det < 0)) bad = 1;
-    const double Mi0 = -dc / det, Mi1 = -alpha / det, Mi2 = a00 / det;
+    const double idet = 1.0 / det, Mi0 = -dc * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
     double hc[OB_VMAX - 1], Hr[(OB_VMAX - 1) * (OB_VMAX - 1)];
 #pragma unroll
     for (int i = 0; i < OB_VMAX - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * OB_VMAX] : 0.0;
@@ -438,10 +439,10 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             double jy = Jmu[0][i] * r3[0] + Jmu[1][i] * r3[1] + Jmu[2][i] * r3[2];
-            step->dmu[i] = (-r_mu[i] - jy) / Dmu[i];
+            step->dmu[i] = (-r_mu[i] - jy) * iDmu[i];
         }
-        step->dsl = (-r_sl - r3[2]) / Dsl;
-        step->dso = (r3[2] - r_so) / Dso;
+        step->dsl = (-r_sl - r3[2]) * iDsl;
+        step->dso = (r3[2] - r_so) * iDso;
     }
 }
 

@@ -208,8 +208,8 @@ OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int
 
 struct B2 { double Sig, gz, gb; };
 OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmu, double &sumz) {
-    double dL = v - lo, dU = hi - v;
-    B2 r; r.Sig = mult * (zL / dL + zU / dU); r.gz = mult * (-zL + zU); r.gb = mult * (-mu / dL + mu / dU);
+    const double dL = v - lo, dU = hi - v, iL = 1.0 / dL, iU = 1.0 / dU;
+    B2 r; r.Sig = mult * (zL * iL + zU * iU); r.gz = mult * (-zL + zU); r.gb = mult * mu * (iU - iL);
     double c1 = dL * zL, c2 = dU * zU;
     if (fabs(c1) > c0) c0 = fabs(c1);
     if (fabs(c2) > c0) c0 = fabs(c2);
@@ -891,7 +891,9 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
 }
 
 // ---------------------------------------------------------------- accept the step
-OBCA_FN double clampz(double zz, double dist, double mu, double ks) { double lo = mu / (ks * dist), hi = ks * mu / dist; return zz < lo ? lo : (zz > hi ? hi : zz); }
+OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu / dist, lo = q / ks, hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
+// bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
+OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = 1.0 / dist; return zz + az * (mu * id - zz - zz * id * dv); }
 
 OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, double az, double mu, double ks) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
@@ -900,18 +902,18 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
         // one-sided (>=0) groups: lam, mu, so
         for (int i = lane; i < M * (N + 1); i += 64) {
             double v = z[l.lam + i], dv = d[l.lam + i], zz = z[l.zlam + i];
-            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.lam + i] = v; z[l.zlam + i] = clampz(zz, v, mu, ks);
         }
         for (int i = lane; i < 4 * nOb * (N + 1); i += 64) {
             double v = z[l.mu + i], dv = d[l.mu + i], zz = z[l.zmu + i];
-            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.mu + i] = v; z[l.zmu + i] = clampz(zz, v, mu, ks);
             z[l.yo + i] += ay * d[l.yo + i];
         }
         for (int i = lane; i < nOb * (N + 1); i += 64) {
             double v = z[l.so + i], dv = d[l.so + i], zz = z[l.zso + i];
-            zz += az * (mu / v - zz - zz / v * dv); v += alpha * dv;
+            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.so + i] = v; z[l.zso + i] = clampz(zz, v, mu, ks);
             z[l.sl + i] += alpha * d[l.sl + i];
         }
@@ -922,7 +924,7 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
                     int idx = 4 * k + i; double v = z[l.x + idx], dv = d[l.x + idx];
                     if (i != 2) {
                         double dL = v - c.xl[i], dU = c.xu[i] - v, zL = z[l.zxL + idx], zU = z[l.zxU + idx];
-                        zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                        zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
                         v += alpha * dv;
                         z[l.zxL + idx] = clampz(zL, v - c.xl[i], mu, ks); z[l.zxU + idx] = clampz(zU, c.xu[i] - v, mu, ks);
                     } else v += alpha * dv;
@@ -935,13 +937,13 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
                     int idx = 2 * k + i; double v = z[l.u + idx], dv = d[l.u + idx];
                     const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     double dL = v - lo, dU = hi - v, zL = z[l.zuL + idx], zU = z[l.zuU + idx];
-                    zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                    zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
                     v += alpha * dv;
                     z[l.u + idx] = v; z[l.zuL + idx] = clampz(zL, v - lo, mu, ks); z[l.zuU + idx] = clampz(zU, hi - v, mu, ks);
                 }
                 {
                     double v = z[l.ss + k], dv = d[l.ss + k], dL = v + OB_SSB, dU = OB_SSB - v, zL = z[l.zssL + k], zU = z[l.zssU + k];
-                    zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+                    zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
                     v += alpha * dv;
                     z[l.ss + k] = v; z[l.zssL + k] = clampz(zL, v + OB_SSB, mu, ks); z[l.zssU + k] = clampz(zU, OB_SSB - v, mu, ks);
                 }
@@ -953,7 +955,7 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
         if (lane < 4) z[l.nu + lane] += ay * d[l.nu + lane];
         if (lane == 5 && !c.fixTime) {
             double v = z[l.t], dv = d[l.t], dL = v - OB_TL, dU = OB_TU - v, zL = z[l.ztL], zU = z[l.ztU];
-            zL += az * (mu / dL - zL - zL / dL * dv); zU += az * (mu / dU - zU + zU / dU * dv);
+            zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
             v += alpha * dv;
             z[l.t] = v; z[l.ztL] = clampz(zL, v - OB_TL, mu, ks); z[l.ztU] = clampz(zU, OB_TU - v, mu, ks);
         }

@@ -114,43 +114,42 @@ def _finish(X, Y, yaw, dr, kap, tot, N, v_nom=0.5):
 
 
 def _lane_change(p0, dy, R, direction):
-    """two-arc lane change of lateral offset dy >= 0 (to the left when driving forward, i.e. towards +y at heading 0) starting at
-    p0 with heading 0; direction=+1 forward (moves +x), -1 reverse (moves -x).  Returns the segments and the end point."""
-    th = np.arccos(max(-1.0, 1.0 - dy / (2 * R)))
+    """two-arc lane change by the lateral offset dy (sign = towards +y / -y) starting at p0 with heading 0;
+    direction=+1 forward (moves +x), -1 reverse (moves -x).  Returns the segments and the end point."""
+    sg = 1.0 if dy >= 0 else -1.0
+    th = np.arccos(max(-1.0, 1.0 - abs(dy) / (2 * R)))
     dx = 2 * R * np.sin(th)
     x0_, y0_ = p0
-    if direction > 0:
-        # forward: left-turn arc (heading 0 -> th), then right-turn arc (th -> 0)
-        segs = [("arc", (x0_, y0_ + R), R, 0.0, th, 1.0, +1.0),
-                ("arc", (x0_ + dx, y0_ + dy - R), R, th, 0.0, 1.0, -1.0)]
-        return segs, (x0_ + dx, y0_ + dy)
-    # reverse (moving towards -x while shifting towards +y): heading goes 0 -> -th -> 0
-    segs = [("arc", (x0_, y0_ + R), R, 0.0, -th, -1.0, +1.0),
-            ("arc", (x0_ - dx, y0_ + dy - R), R, -th, 0.0, -1.0, -1.0)]
-    return segs, (x0_ - dx, y0_ + dy)
+    tm = sg * direction * th          # heading at the inflection point
+    segs = [("arc", (x0_, y0_ + sg * R), R, 0.0, tm, direction, sg),
+            ("arc", (x0_ + direction * dx, y0_ + dy - sg * R), R, tm, 0.0, direction, -sg)]
+    return segs, (x0_ + direction * dx, y0_ + dy)
 
 
-def warm_start_backwards(x0, xF, N, R=4.5, lane_min=8.4):
-    """[lane change up to y >= lane_min if the start is low in the lane] -> line along the lane -> reverse quarter arc ->
-    reverse line into the slot.  (The quarter arc clears the slot corners only when it starts high enough in the lane.)"""
+def warm_start_backwards(x0, xF, N, R=4.5, lane=8.4):
+    """[lane change to y = lane] -> line along the lane -> reverse quarter arc -> reverse line into the slot.
+    The quarter arc of radius R clears the slot corners (needs lane - R > 3.6) and the top wall (needs lane - R < 4.25) only when it
+    starts from this lane, so starts elsewhere in the aisle first shift to it (forward if there is room ahead, else in reverse)."""
     X0, Y0 = float(x0[0]), float(x0[1])
     xg, yg = float(xF[0]), float(xF[1])
-    Ya = max(Y0, lane_min)
+    Ya = lane
     xa = xg + R                       # arc starts at (xg+R, Ya) heading 0, ends at (xg, Ya-R) heading pi/2
     ya = Ya - R
     segs = []
     dy = Ya - Y0
     px, py = X0, Y0
-    if dy > 1e-9:
-        th = np.arccos(max(-1.0, 1.0 - dy / (2 * R))); dxn = 2 * R * np.sin(th)
-        if X0 >= xa + dxn or X0 + dxn > 14.0:   # far right of the arc start (or no room ahead): shift up while reversing
-            sg, (px, py) = _lane_change((px, py), dy, R, -1)
+    if abs(dy) > 0.02:
+        th = np.arccos(max(-1.0, 1.0 - abs(dy) / (2 * R))); dxn = 2 * R * np.sin(th)
+        if X0 >= xa + dxn or X0 + dxn > 14.0:   # far right of the arc start (or no room ahead): shift while reversing
+            sg, (px, py) = _lane_change((px, py), dy, R, -1.0)
             segs += sg
-        else:                         # shift up driving forward (after a straight run if there is room)
+        else:                         # shift driving forward (after a straight run if there is room)
             if X0 < xa - dxn:
                 segs.append(("line", (px, py), 0.0, xa - dxn - X0, 1.0)); px = xa - dxn
-            sg, (px, py) = _lane_change((px, py), dy, R, +1)
+            sg, (px, py) = _lane_change((px, py), dy, R, +1.0)
             segs += sg
+    else:
+        Ya = Y0; ya = Ya - R
     d1 = 1.0 if px < xa else -1.0
     segs.append(("line", (px, py), 0.0, abs(xa - px), d1))
     segs.append(("arc", (xa, ya), R, 0.0, np.pi / 2, -1.0, -1.0))
