@@ -27,7 +27,7 @@ struct DevBufs {
     size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
 };
 
-__global__ __launch_bounds__(64) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o) {
+__global__ __launch_bounds__(OB_NT, OB_NT / 64) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
     if (threadIdx.x == 0) {
@@ -254,7 +254,7 @@ int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
     HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
     if (!bt->have_duals) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
-    hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(64), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
+    hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(bt->e2, ctx->stream));
     return 0;

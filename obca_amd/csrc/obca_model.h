@@ -158,27 +158,32 @@ OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
     b0 /= Lc[0]; b1 = (b1 - Lc[1] * b0) / Lc[2];
     b1 /= Lc[2]; b0 = (b0 - Lc[1] * b1) / Lc[0];
 }
+template <int VM>
 OBCA_FN void hh_apply(int v, const double *w, double *x) {
     double s = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) s += w[i] * x[i];
+    for (int i = 0; i < VM; i++) if (i < v) s += w[i] * x[i];
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) x[i] -= 2 * s * w[i];
+    for (int i = 0; i < VM; i++) if (i < v) x[i] -= 2 * s * w[i];
 }
 
 // ---------------------------------------------------------------- one (stage, obstacle) block
+// VM = compile-time bound on the half-space rows per obstacle (2 for the shipped parking scenarios, 4 in general): all small
+// matrices of a block are sized by it, which decides whether the block fits the register file without spilling.
+template <int VM>
 struct ObsIn {
     int v;
-    double a1[OB_VMAX], a2[OB_VMAX], b[OB_VMAX];
-    double lam[OB_VMAX], zl[OB_VMAX], mu[4], zm[4], y[4];
+    double a1[VM], a2[VM], b[VM];
+    double lam[VM], zl[VM], mu[4], zm[4], y[4];
     double sl, so, zso, X, Y, psi;
 };
 
 // the four rows c1..c4 (ParkingSignedDist.jl:198-206, c4 has the slack `so` and dmin moved to the left)
-OBCA_FN void obs_rows(const Consts &c, const ObsIn &in, double r[4]) {
+template <int VM>
+OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    for (int i = 0; i < VM; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
     double sn, cs;
     sincos(in.psi, &sn, &cs);
     r[0] = p1 * p1 + p2 * p2 - 1;
@@ -195,16 +200,17 @@ struct ObsCond {          // result of the condensation onto the pose
     double gz[3];         // Jp^T y   (part of grad L w.r.t. the pose)
     double gcorr[3];      // condensed right-hand-side correction (subtract from the barrier-form gradient)
 };
-struct ObsStep { double dlam[OB_VMAX], dmu[4], dsl, dso, dy[4]; };
+template <int VM>
+struct ObsStep { double dlam[VM], dmu[4], dsl, dso, dy[4]; };
 
 // MODE 0: condense (fills cond, stats) ; MODE 1: back-substitute for a given pose step dp (fills step)
-template <int MODE>
-OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
-                       const double dp[3], ObsStep *step) {
+template <int MODE, int VM>
+OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
+                       const double dp[3], ObsStep<VM> *step) {
     const int v = in.v;
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    for (int i = 0; i < VM; i++) if (i < v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
     double sn, cs;
     sincos(in.psi, &sn, &cs);
     const double off = c.off;
@@ -216,9 +222,9 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
             (in.Y + sn * off) * p2 - beta + in.sl - OB_DMIN - in.so;
     const double *y = in.y;
     // Jacobians
-    double Jl[4][OB_VMAX];
+    double Jl[4][VM];
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) {
+    for (int i = 0; i < VM; i++) {
         double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
         Jl[0][i] = 2 * (p1 * a1 + p2 * a2);
         Jl[1][i] = cs * a1 + sn * a2;
@@ -234,7 +240,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
     const double iso = 1.0 / in.so;
     const double iDso = 1.0 / (in.zso * iso + dw), iDsl = 1.0 / (2e4 + dw);
     double r_so = -y[3] - mu_b * iso, r_sl = 1e2 + 2e4 * in.sl + y[3];
-    double iDmu[4], r_mu[4], Dlam[OB_VMAX], r_lam[OB_VMAX];
+    double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
@@ -246,7 +252,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
         }
     }
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) {
+    for (int i = 0; i < VM; i++) {
         if (i < v) {
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
             { const double il = 1.0 / in.lam[i]; r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
@@ -288,112 +294,112 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
     r234[2] += -r_so * iDso + r_sl * iDsl;
     int bad = ldl_fact<3>(3, Tm);
     // W = T^{-1} [Jl234 | Jp234 | r234]
-    double W[3][OB_VMAX + 4];
+    double W[3][VM + 4];
 #pragma unroll
-    for (int cI = 0; cI < OB_VMAX + 4; cI++) {
+    for (int cI = 0; cI < VM + 4; cI++) {
         double col[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) col[r] = cI < OB_VMAX ? Jl[r + 1][cI] : (cI < OB_VMAX + 3 ? Jp[r][cI - OB_VMAX] : r234[r]);
+        for (int r = 0; r < 3; r++) col[r] = cI < VM ? Jl[r + 1][cI] : (cI < VM + 3 ? Jp[r][cI - VM] : r234[r]);
         ldl_solve<3>(3, Tm, col);
 #pragma unroll
         for (int r = 0; r < 3; r++) W[r][cI] = col[r];
     }
     // (lambda, y1) block in the null space of q = Jl[0]
-    double Kb[OB_VMAX * OB_VMAX], Cp[OB_VMAX][3], rk[OB_VMAX + 1];
+    double Kb[VM * VM], Cp[VM][3], rk[VM + 1];
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) {
+    for (int i = 0; i < VM; i++) {
         double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
 #pragma unroll
-        for (int m = 0; m < OB_VMAX; m++) {
+        for (int m = 0; m < VM; m++) {
             double b1 = m < v ? in.a1[m] : 0.0, b2 = m < v ? in.a2[m] : 0.0;
             double a_ = y[0] * 2 * (a1 * b1 + a2 * b2);
 #pragma unroll
             for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][m];
-            Kb[i * OB_VMAX + m] = a_;
+            Kb[i * VM + m] = a_;
         }
-        Kb[i * OB_VMAX + i] += Dlam[i];
+        Kb[i * VM + i] += Dlam[i];
         const double Hlp[3] = {y[3] * a1, y[3] * a2,
                                y[1] * (-sn * a1 + cs * a2) + y[2] * (-cs * a1 - sn * a2) + y[3] * off * (-sn * a1 + cs * a2)};
 #pragma unroll
         for (int cI = 0; cI < 3; cI++) {
             double a_ = Hlp[cI];
 #pragma unroll
-            for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][OB_VMAX + cI];
+            for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + cI];
             Cp[i][cI] = i < v ? a_ : 0.0;
         }
         double a_ = -r_lam[i];
 #pragma unroll
-        for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][OB_VMAX + 3];
+        for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + 3];
         rk[i] = i < v ? a_ : 0.0;
     }
-    rk[OB_VMAX] = -cr[0];
+    rk[VM] = -cr[0];
     // Householder Qh q = alpha e1
-    double hw[OB_VMAX], nq = 0;
+    double hw[VM], nq = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) nq += Jl[0][i] * Jl[0][i];
+    for (int i = 0; i < VM; i++) if (i < v) nq += Jl[0][i] * Jl[0][i];
     nq = sqrt(nq);
     double alpha = Jl[0][0] > 0 ? -nq : nq, nw = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
+    for (int i = 0; i < VM; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
     nw = sqrt(nw);
     { const double inw = nw > 0 ? 1.0 / nw : 0.0;
 #pragma unroll
-      for (int i = 0; i < OB_VMAX; i++) hw[i] *= inw; }
+      for (int i = 0; i < VM; i++) hw[i] *= inw; }
     // Ht = Qh Kb Qh
 #pragma unroll
-    for (int j = 0; j < OB_VMAX; j++) {
-        double col[OB_VMAX];
+    for (int j = 0; j < VM; j++) {
+        double col[VM];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) col[i] = Kb[i * OB_VMAX + j];
-        hh_apply(v, hw, col);
+        for (int i = 0; i < VM; i++) col[i] = Kb[i * VM + j];
+        hh_apply<VM>(v, hw, col);
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) Kb[i * OB_VMAX + j] = col[i];
+        for (int i = 0; i < VM; i++) Kb[i * VM + j] = col[i];
     }
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) hh_apply(v, hw, Kb + i * OB_VMAX);
+    for (int i = 0; i < VM; i++) hh_apply<VM>(v, hw, Kb + i * VM);
     double a00 = Kb[0], det = a00 * (-dc) - alpha * alpha;
     if (!(det < 0)) bad = 1;
     const double idet = 1.0 / det, Mi0 = -dc * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
-    double hc[OB_VMAX - 1], Hr[(OB_VMAX - 1) * (OB_VMAX - 1)];
+    double hc[VM - 1], Hr[(VM - 1) * (VM - 1)];
 #pragma unroll
-    for (int i = 0; i < OB_VMAX - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * OB_VMAX] : 0.0;
+    for (int i = 0; i < VM - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * VM] : 0.0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX - 1; i++)
+    for (int i = 0; i < VM - 1; i++)
 #pragma unroll
-        for (int j = 0; j < OB_VMAX - 1; j++) Hr[i * (OB_VMAX - 1) + j] = Kb[(i + 1) * OB_VMAX + (j + 1)] - Mi0 * hc[i] * hc[j];
-    if (v > 1) bad |= ldl_fact<OB_VMAX - 1>(v - 1, Hr);
+        for (int j = 0; j < VM - 1; j++) Hr[i * (VM - 1) + j] = Kb[(i + 1) * VM + (j + 1)] - Mi0 * hc[i] * hc[j];
+    if (v > 1) bad |= ldl_fact<(VM > 1 ? VM - 1 : 1)>(v - 1, Hr);
     // solve K^{-1} col  for col = [r_lam(v); r_y]
-    auto ksolve = [&](double *col /* OB_VMAX+1 */) {
-        hh_apply(v, hw, col);
-        double g0 = col[0], gy = col[OB_VMAX];
+    auto ksolve = [&](double *col /* VM+1 */) {
+        hh_apply<VM>(v, hw, col);
+        double g0 = col[0], gy = col[VM];
         double t0 = Mi0 * g0 + Mi1 * gy;
-        double rr[OB_VMAX - 1];
+        double rr[VM - 1];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX - 1; i++) rr[i] = (i + 1 < v) ? col[i + 1] - hc[i] * t0 : 0.0;
-        if (v > 1) ldl_solve<OB_VMAX - 1>(v - 1, Hr, rr);
+        for (int i = 0; i < VM - 1; i++) rr[i] = (i + 1 < v) ? col[i + 1] - hc[i] * t0 : 0.0;
+        if (v > 1) ldl_solve<(VM > 1 ? VM - 1 : 1)>(v - 1, Hr, rr);
         double hl = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX - 1; i++) if (i + 1 < v) hl += hc[i] * rr[i];
+        for (int i = 0; i < VM - 1; i++) if (i + 1 < v) hl += hc[i] * rr[i];
         g0 -= hl;
         col[0] = Mi0 * g0 + Mi1 * gy;
-        col[OB_VMAX] = Mi1 * g0 + Mi2 * gy;
+        col[VM] = Mi1 * g0 + Mi2 * gy;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX - 1; i++) col[i + 1] = (i + 1 < v) ? rr[i] : 0.0;
-        hh_apply(v, hw, col);
+        for (int i = 0; i < VM - 1; i++) col[i + 1] = (i + 1 < v) ? rr[i] : 0.0;
+        hh_apply<VM>(v, hw, col);
     };
     if (MODE == 0) {
         st->bad |= bad;
         // Z = K^{-1} [Cp | rk]
-        double Z[OB_VMAX + 1][4];
+        double Z[VM + 1][4];
 #pragma unroll
         for (int cI = 0; cI < 4; cI++) {
-            double col[OB_VMAX + 1];
+            double col[VM + 1];
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) col[i] = cI < 3 ? Cp[i][cI] : rk[i];
-            col[OB_VMAX] = cI < 3 ? 0.0 : rk[OB_VMAX];
+            for (int i = 0; i < VM; i++) col[i] = cI < 3 ? Cp[i][cI] : rk[i];
+            col[VM] = cI < 3 ? 0.0 : rk[VM];
             ksolve(col);
 #pragma unroll
-            for (int i = 0; i <= OB_VMAX; i++) Z[i][cI] = col[i];
+            for (int i = 0; i <= VM; i++) Z[i][cI] = col[i];
         }
         const double Hpp22 = y[1] * (-cs * p1 - sn * p2) + y[2] * (sn * p1 - cs * p2) + y[3] * off * (-cs * p1 - sn * p2);
         int q = 0;
@@ -403,39 +409,39 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn &in, double mu_b, double dw,
             for (int b_ = 0; b_ < 3; b_++) if (b_ >= a_) {
                 double s_ = (a_ == 2 && b_ == 2) ? Hpp22 : 0.0;
 #pragma unroll
-                for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][OB_VMAX + b_];
+                for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][VM + b_];
 #pragma unroll
-                for (int i = 0; i < OB_VMAX; i++) s_ -= Cp[i][a_] * Z[i][b_];
+                for (int i = 0; i < VM; i++) s_ -= Cp[i][a_] * Z[i][b_];
                 cond->Hpp[q++] = s_;
             }
             double s_ = 0;
 #pragma unroll
-            for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][OB_VMAX + 3];
+            for (int r = 0; r < 3; r++) s_ += Jp[r][a_] * W[r][VM + 3];
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) s_ -= Cp[i][a_] * Z[i][3];
+            for (int i = 0; i < VM; i++) s_ -= Cp[i][a_] * Z[i][3];
             cond->gcorr[a_] = s_;
             cond->gz[a_] = Jp[0][a_] * y[1] + Jp[1][a_] * y[2] + Jp[2][a_] * y[3];
         }
     } else {
-        double col[OB_VMAX + 1];
+        double col[VM + 1];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) col[i] = rk[i] - (Cp[i][0] * dp[0] + Cp[i][1] * dp[1] + Cp[i][2] * dp[2]);
-        col[OB_VMAX] = rk[OB_VMAX];
+        for (int i = 0; i < VM; i++) col[i] = rk[i] - (Cp[i][0] * dp[0] + Cp[i][1] * dp[1] + Cp[i][2] * dp[2]);
+        col[VM] = rk[VM];
         ksolve(col);
         double r3[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             // dy234 = T^{-1}(Jl dlam + Jp dp - r234) = W[:, :v] dlam + W[:, v:v+3] dp - W[:, v+3]
-            double a_ = -W[r][OB_VMAX + 3];
+            double a_ = -W[r][VM + 3];
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) a_ += W[r][i] * col[i];
+            for (int i = 0; i < VM; i++) a_ += W[r][i] * col[i];
 #pragma unroll
-            for (int i = 0; i < 3; i++) a_ += W[r][OB_VMAX + i] * dp[i];
+            for (int i = 0; i < 3; i++) a_ += W[r][VM + i] * dp[i];
             r3[r] = a_;
         }
-        step->dy[0] = col[OB_VMAX]; step->dy[1] = r3[0]; step->dy[2] = r3[1]; step->dy[3] = r3[2];
+        step->dy[0] = col[VM]; step->dy[1] = r3[0]; step->dy[2] = r3[1]; step->dy[3] = r3[2];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) step->dlam[i] = col[i];
+        for (int i = 0; i < VM; i++) step->dlam[i] = col[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             double jy = Jmu[0][i] * r3[0] + Jmu[1][i] * r3[1] + Jmu[2][i] * r3[2];

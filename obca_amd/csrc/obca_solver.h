@@ -14,11 +14,17 @@
 // The same source is compiled by tests/emu (g++, -DOBCA_EMU) where PAR is a plain loop over 64 lanes: that build exists
 // only so that the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
 #pragma once
+#ifndef OB_NT
+#define OB_NT 128    // threads per problem instance (1 or 2 wavefronts): lane-parallel phases use all of them, sequential sweeps wave 0
+#endif
 #ifdef OBCA_EMU
 #define OBCA_FN static inline
 #define OBCA_HD static inline
 #define OBCA_PHASE static
-#define PAR(lane) for (int lane = 0; lane < 64; ++lane)
+#define PAR(lane) for (int lane = 0; lane < OB_NT; ++lane)
+#define PAR64(lane) for (int lane = 0; lane < 64; ++lane)       // inside a WAVE0 section
+#define WAVE0_BEGIN {
+#define WAVE0_END }
 #define SYNC() ((void)0)
 #define LANE0 1
 #define LDS_SYNC() ((void)0)
@@ -31,6 +37,9 @@
 // per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
 #define OBCA_PHASE __device__ __noinline__
 #define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
+#define WAVE0_END }
 #define SYNC() __syncthreads()
 #define LANE0 (threadIdx.x == 0)
 // The workgroup is ONE wavefront: its LDS operations execute in program order, so lanes only need the compiler to keep that
@@ -131,15 +140,15 @@ struct Inst {              // uniform: pointers of this instance
 
 struct Shared {
     double hdr[OB_HDR];
-    double red[16][64];
+    double red[16][OB_NT];
     double stg[2][196];        // double-buffered unpacked stage data of the Riccati backward sweep (SG_* offsets)
     double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
     double filt[OB_FILT][2];
-    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX];
+    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
-    Inst inst; AsmOut A, A2; StepOut S; double trial[4];   // phase inputs/outputs (wave-uniform, exchanged through LDS)
+    Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2;   // phase inputs/outputs (wave-uniform, exchanged through LDS)
     double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
 };
 
@@ -158,43 +167,39 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
 #endif
 
 // ---------------------------------------------------------------- reductions (64-lane butterfly; same order in the emulation)
-OBCA_FN double red_sum(const double *r) {
+// reductions over the OB_NT lanes of the instance: fold the second wavefront's slots onto the first, then a 64-lane butterfly
+// (same association order in the emulation, so results are bit-identical)
 #ifdef OBCA_EMU
-    double a[64], b[64];
-    for (int i = 0; i < 64; i++) a[i] = r[i];
-    for (int o = 32; o > 0; o >>= 1) { for (int i = 0; i < 64; i++) b[i] = a[i] + a[i ^ o]; for (int i = 0; i < 64; i++) a[i] = b[i]; }
-    return a[0];
+#define RED_IMPL(NAME, COMB)                                                                                     \
+    OBCA_FN double NAME(const double *r) {                                                                       \
+        double a[64], b[64];                                                                                     \
+        for (int i = 0; i < 64; i++) { a[i] = r[i]; if (OB_NT > 64) { double w = r[i + 64 * (OB_NT > 64)], v = a[i]; a[i] = COMB; } } \
+        for (int o = 32; o > 0; o >>= 1) {                                                                       \
+            for (int i = 0; i < 64; i++) { double v = a[i], w = a[i ^ o]; b[i] = COMB; }                         \
+            for (int i = 0; i < 64; i++) a[i] = b[i];                                                            \
+        }                                                                                                        \
+        return a[0];                                                                                             \
+    }
 #else
-    double v = r[threadIdx.x];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define RED_IMPL(NAME, COMB)                                                                                     \
+    OBCA_FN double NAME(const double *r) {                                                                       \
+        double v = r[threadIdx.x & 63];                                                                          \
+        if (OB_NT > 64) { double w = r[(threadIdx.x & 63) + 64 * (OB_NT > 64)]; v = COMB; }                      \
+        for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = COMB; }                          \
+        return v;                                                                                                \
+    }
 #endif
-}
-OBCA_FN double red_max(const double *r) {   // NaN-propagating max
-#ifdef OBCA_EMU
-    double m = r[0]; for (int i = 1; i < 64; i++) m = (r[i] > m || r[i] != r[i]) ? r[i] : m; return m;
-#else
-    double v = r[threadIdx.x];
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = (w > v || w != w) ? w : v; }
-    return v;
-#endif
-}
-OBCA_FN double red_min(const double *r) {
-#ifdef OBCA_EMU
-    double m = r[0]; for (int i = 1; i < 64; i++) m = (r[i] < m) ? r[i] : m; return m;
-#else
-    double v = r[threadIdx.x];
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = (w < v) ? w : v; }
-    return v;
-#endif
-}
+RED_IMPL(red_sum, (v + w))
+RED_IMPL(red_max, ((w > v || w != w) ? w : v))      // NaN-propagating max
+RED_IMPL(red_min, ((w < v) ? w : v))
 
-OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int j, ObsIn &in) {
+template <int VM>
+OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int j, ObsIn<VM> &in) {
     const Lay &l = sh.l; const int nOb = sh.c.nOb, M = sh.c.M;
     const int r0 = sh.roff[j], v = sh.vOb[j], bo = k * nOb + j;
     in.v = v;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) {
+    for (int i = 0; i < VM; i++) {
         bool on = i < v;
         in.a1[i] = on ? sh.hdr[PH_A + 2 * (r0 + i)] : 0.0; in.a2[i] = on ? sh.hdr[PH_A + 2 * (r0 + i) + 1] : 0.0;
         in.b[i] = on ? sh.hdr[PH_B + r0 + i] : 0.0;
@@ -222,7 +227,9 @@ OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; ret
 
 
 // ---------------------------------------------------------------- assemble the condensed Newton system
-OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc, AsmOut &out) {
+// part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
+template <int VM>
+OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z;
@@ -231,21 +238,21 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
     PAR(lane) {
         ObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
         double fsl = 0, th = 0, bar = 0;
-        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
-            ObsIn in; load_obs(I, sh, z, k, j, in);
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             ObsCond cd;
-            obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            obs_block<0, VM>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
             gdbl *o = I.oc + (size_t)it * OB_OC;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
 #pragma unroll
             for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
             fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
-            double r[4]; obs_rows(c, in, r);
+            double r[4]; obs_rows<VM>(c, in, r);
             th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) bar += log(in.lam[i]);
+            for (int i = 0; i < VM; i++) if (i < in.v) bar += log(in.lam[i]);
             bar += log(in.mu[0]) + log(in.mu[1]) + log(in.mu[2]) + log(in.mu[3]) + log(in.so);
         }
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
@@ -253,21 +260,34 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
         sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
     }
     SYNC();
-    double dinf = red_max(sh.red[0]), pinf = red_max(sh.red[1]), c0 = red_max(sh.red[2]), cmu = red_max(sh.red[3]);
-    double sumz = red_sum(sh.red[4]), sumy = red_sum(sh.red[5]), f = red_sum(sh.red[6]), th1 = red_sum(sh.red[7]);
-    double bar = red_sum(sh.red[8]);
-    int ok = !(red_max(sh.red[9]) > 0.5);
+    AsmOut &P = sh.Ap;
+    P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cinfmu = red_max(sh.red[3]);
+    P.sumz = red_sum(sh.red[4]); P.sumy = red_sum(sh.red[5]); P.f = red_sum(sh.red[6]); P.th1 = red_sum(sh.red[7]);
+    P.bar = red_sum(sh.red[8]);
+    P.ok = !(red_max(sh.red[9]) > 0.5);
     SYNC();
     PROF(I, PF_ASM_OBS);
+}
+
+// part (b): one lane per stage; combines with the partial results of part (a)
+OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, AsmOut &out) {
+    const Consts &c = sh.c; const Lay &l = sh.l;
+    const int N = c.N, nOb = c.nOb, M = c.M;
+    const gdbl *z = I.z;
+    const double t = z[l.t], q = t * c.Ts;
+    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
+           th1 = sh.Ap.th1, bar = sh.Ap.bar;
+    const int ok = sh.Ap.ok;
     // ---- (b) stages: one lane per stage
     PAR(lane) {
         double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
-        for (int k = lane; k <= N; k += 64) {
-            double H[8][8], hz[8], hb[8], Ht[8];
+        for (int k = lane; k <= N; k += OB_NT) {
+            double Hp[36], hz[8], hb[8], Ht[8];     // Hp: packed upper triangle of the symmetric 8x8 stage Hessian (HH(i,j), i<=j)
+#define HH(i, j) Hp[hidx((i), (j))]
 #pragma unroll
-            for (int i = 0; i < 8; i++) { hz[i] = hb[i] = Ht[i] = 0;
+            for (int i = 0; i < 8; i++) hz[i] = hb[i] = Ht[i] = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) H[i][j] = 0; }
+            for (int i = 0; i < 36; i++) Hp[i] = 0;
             double x[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i];
@@ -284,12 +304,11 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
                     Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb;
                     lbar += log(x[i] - c.xl[i]) + log(c.xu[i] - x[i]);
                 }
-                H[i][i] = hx[i] + Sig + dw;
+                HH(i, i) = hx[i] + Sig + dw;
             }
             for (int j = 0; j < nOb; j++) {   // condensed obstacle contributions of this stage
                 const gdbl *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
-                H[0][0] += o[0]; H[0][1] += o[1]; H[0][2] += o[2]; H[1][1] += o[3]; H[1][2] += o[4]; H[2][2] += o[5];
-                H[1][0] += o[1]; H[2][0] += o[2]; H[2][1] += o[4];
+                HH(0, 0) += o[0]; HH(0, 1) += o[1]; HH(0, 2) += o[2]; HH(1, 1) += o[3]; HH(1, 2) += o[4]; HH(2, 2) += o[5];
 #pragma unroll
                 for (int i = 0; i < 3; i++) { hz[i] += o[6 + i]; hb[i] += o[6 + i] - o[9 + i]; }
             }
@@ -317,8 +336,8 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
                     B2 b = bound2(u[i], lo, hi, z[l.zuL + 2 * k + i], z[l.zuU + 2 * k + i], mu, 1, lc0, lcmu, lsz);
                     hz[6 + i] += b.gz; hb[6 + i] += b.gb;
                     lbar += log(u[i] - lo) + log(hi - u[i]);
-                    H[6 + i][6 + i] += 2 * cu[i] + 2 * rr + b.Sig + dw;
-                    H[4 + i][4 + i] += 2 * rr; H[4 + i][6 + i] += -2 * rr; H[6 + i][4 + i] += -2 * rr;
+                    HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
+                    HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr;
                     if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei / t; Ht[4 + i] += 4 * rr * ei / t; }
                 }
                 if (!c.fixTime) { lgtz += -2 * rv / t; lgtb += -2 * rv / t; lHtt += 6 * rv / (t * t); }
@@ -339,7 +358,7 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
                     for (int a_ = 0; a_ < 2; a_++) {
                         hz[id[a_]] += gg[a_] * yg; hb[id[a_]] += gg[a_] * (yg + sig * rg);
 #pragma unroll
-                        for (int b_ = 0; b_ < 2; b_++) H[id[a_]][id[b_]] += sig * gg[a_] * gg[b_];
+                        for (int b_ = 0; b_ < 2; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += sig * gg[a_] * gg[b_];
                         if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + yg * (a_ == 0 ? -1 / (q * t) : 1 / (q * t));
                     }
                     if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g / (t * t); }
@@ -361,7 +380,7 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
 #pragma unroll
                     for (int a_ = 0; a_ < 4; a_++) {
 #pragma unroll
-                        for (int b_ = 0; b_ < 4; b_++) H[id[a_]][id[b_]] += -HL[a_][b_];
+                        for (int b_ = 0; b_ < 4; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += -HL[a_][b_];
                         if (!c.fixTime) Ht[id[a_]] += -HL[a_][4];
                     }
                     if (!c.fixTime) lHtt += -HL[4][4];
@@ -399,11 +418,9 @@ OBCA_FN void assemble(const Inst &I, Shared &sh, double mu, double dw, double dc
                     for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; if (fabs(tot) > dmax) dmax = fabs(tot); }
                 }
             }
-            int qn = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) if (j >= i) rec[AS_H + (qn++)] = H[i][j];
+            for (int i = 0; i < 36; i++) rec[AS_H + i] = Hp[i];
+#undef HH
 #pragma unroll
             for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; rec[AS_HT + i] = Ht[i]; }
         }
@@ -483,12 +500,12 @@ OBCA_FN void stage_unpack_store(double *sg, int lane, const UnpackPlan &p, const
     if (lane < 48) sg[SG_HC + lane] = p.flag[3] * v[3];
 }
 
-OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
+OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // runs on wavefront 0 only
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N;
     const gdbl *z = I.z;
     double nv[OBCA_NL][4];   // software pipeline: stage data gathered from HBM one full stage before it is needed
     UnpackPlan plan[OBCA_NL];
-    PAR(lane) {   // terminal cost-to-go; unpack stage N-1; start the loads of stage N-2
+    PAR64(lane) {   // terminal cost-to-go; unpack stage N-1; start the loads of stage N-2
         stage_unpack_plan(lane, plan[LI(lane)]);
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
@@ -507,10 +524,10 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
         stage_unpack_store(sh.stg[(N - 1) & 1], lane, plan[LI(lane)], v);
         if (N >= 2) stage_unpack_load(I.as + (size_t)(N - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
     }
-    SYNC();
+    LDS_SYNC();
     for (int k = N - 1; k >= 0; k--) {
         const double *sg = sh.stg[k & 1];
-        PAR(lane) {   // Qhat = [H | hc] + F^T (Pn [F | off] + [0 | pn])  (8 x 14): one lane per (column, row pair)
+        PAR64(lane) {   // Qhat = [H | hc] + F^T (Pn [F | off] + [0 | pn])  (8 x 14): one lane per (column, row pair)
             if (lane < 56) {
                 const int cc = lane % 14, ip = lane / 14;        // rows ip and ip+4
                 double t[6];
@@ -550,7 +567,7 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
         if (!(sch > 0)) { PROF(I, PF_RIC_BWD); return 0; }
         const double g11 = 1.0 / sch, g01 = -m10 * g11, g00 = iq00 - m10 * g01;
         gdbl *ro = I.rs + (size_t)k * OB_RS;
-        PAR(lane) {   // eliminate u_k: lanes 0..35 -> P[i][cc] and pn[i][cc]; lanes 36..56 -> bilinear constants
+        PAR64(lane) {   // eliminate u_k: lanes 0..35 -> P[i][cc] and pn[i][cc]; lanes 36..56 -> bilinear constants
             // first retire the gathers issued one stage ago (before this phase issues any store: the memory counter is in-order)
             if (k > 0) {
                 stage_unpack_store(sh.stg[(k - 1) & 1], lane, plan[LI(lane)], nv[LI(lane)]);
@@ -581,14 +598,23 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
         LDS_SYNC();
         PROF(I, PF_RIC_P2);
     }
-    SYNC();
     PROF(I, PF_RIC_BWD);
     return 1;
 }
 
+OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
+    WAVE0_BEGIN
+        const int ok = riccati_body(I, sh, rho);
+        PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
+    WAVE0_END
+    SYNC();
+    return sh.ric_ok;
+}
+
 // ---------------------------------------------------------------- border solve + forward sweep + back-substitution
 
-OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
+// part 1: border, closed loop, forward sweep, stage-parallel back-substitution; leaves partial (ap, az, gd) and (dt, nu) in LDS
+OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
     so.ok = 1;
@@ -619,7 +645,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
     const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
     // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
     PAR(lane) {
-        for (int k = lane; k < N; k += 64) {
+        for (int k = lane; k < N; k += OB_NT) {
             const gdbl *rec = I.as + (size_t)k * OB_AS; gdbl *ro = I.rs + (size_t)k * OB_RS;
             double K0[6], K1[6], kf0 = 0, kf1 = 0;
 #pragma unroll
@@ -645,32 +671,53 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
         if (lane < 8) { sh.s[0][lane] = 0; sh.s[1][lane] = 0; }
     }
     SYNC();
-    PAR(lane) { if (lane < 42) sh.cl[0][lane] = (I.rs)[RS_CL + lane]; }
-    SYNC();
     PROF(I, PF_BORDER_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential).  The closed-loop data of step k+2 is gathered from HBM
-    // while step k runs (per-lane register pipeline); the trajectory stays in LDS, so the loop issues no global store.
-    {
-        double pf[OBCA_NL];
-        PAR(lane) { pf[LI(lane)] = (N > 1 && lane < 42) ? (I.rs + (size_t)OB_RS)[RS_CL + lane] : 0.0; if (lane < 6) sh.traj[lane] = 0.0; }
-        LDS_SYNC();
-        for (int k = 0; k < N; k++) {
-            PAR(lane) {
-                if (lane < 6) {
-                    const double *cl = sh.cl[k & 1], *s_ = sh.traj + (size_t)k * 6;
-                    double v = cl[36 + lane];
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential, wavefront 0).  The closed-loop maps are staged through LDS in
+    // chunks of FW_CH stages (ring of two chunks in the reduction scratch, which is idle here): the 64 lanes gather the NEXT chunk
+    // from HBM into registers at the start of a chunk and park it in LDS at its end, so the per-step loop only touches LDS and the
+    // HBM latency is paid once per chunk, overlapped with FW_CH steps of work.  The trajectory stays in LDS.
+#define FW_CH 16
+#define FW_PER ((FW_CH * 42 + 63) / 64)
+    WAVE0_BEGIN
+        double pf[OBCA_NL][FW_PER];
+        double *ring = &sh.red[0][0];                      // 2 * FW_CH * 42 doubles <= 16 * OB_NT
+        PAR64(lane) {
+            if (lane < 6) sh.traj[lane] = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s_[j];
-                    sh.traj[(size_t)(k + 1) * 6 + lane] = v;
+            for (int r = 0; r < FW_PER; r++) {             // chunk 0 straight into the ring
+                int e = lane + 64 * r, st = e / 42, j = e % 42;
+                if (e < FW_CH * 42 && st < N) ring[e] = (I.rs + (size_t)st * OB_RS)[RS_CL + j];
+            }
+        }
+        LDS_SYNC();
+        for (int k0 = 0; k0 < N; k0 += FW_CH) {
+            const int cb = (k0 / FW_CH) & 1;
+            PAR64(lane) {                                   // issue the gathers of the next chunk
+#pragma unroll
+                for (int r = 0; r < FW_PER; r++) {
+                    int e = lane + 64 * r, st = k0 + FW_CH + e / 42, j = e % 42;
+                    pf[LI(lane)][r] = (e < FW_CH * 42 && st < N) ? (I.rs + (size_t)st * OB_RS)[RS_CL + j] : 0.0;
                 }
-                if (k + 1 < N && lane < 42) {
-                    sh.cl[(k + 1) & 1][lane] = pf[LI(lane)];
-                    if (k + 2 < N) pf[LI(lane)] = (I.rs + (size_t)(k + 2) * OB_RS)[RS_CL + lane];
+            }
+            for (int k = k0; k < k0 + FW_CH && k < N; k++) {
+                PAR64(lane) {
+                    if (lane < 6) {
+                        const double *cl = ring + (size_t)(cb * FW_CH + (k - k0)) * 42, *s_ = sh.traj + (size_t)k * 6;
+                        double v = cl[36 + lane];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s_[j];
+                        sh.traj[(size_t)(k + 1) * 6 + lane] = v;
+                    }
                 }
+                LDS_SYNC();
+            }
+            PAR64(lane) {                                   // park the next chunk in the other half of the ring
+#pragma unroll
+                for (int r = 0; r < FW_PER; r++) { int e = lane + 64 * r; if (e < FW_CH * 42) ring[(size_t)(1 - cb) * FW_CH * 42 + e] = pf[LI(lane)][r]; }
             }
             LDS_SYNC();
         }
-    }
+    WAVE0_END
     SYNC();
     PROF(I, PF_FWD_SEQ);
     // ---- stage-parallel: primal steps of x,u; costates; bound terms of x,u ; steering rows
@@ -679,7 +726,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < ap) ap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < az) az = cc_; }
         const double t = z[l.t], q = t * c.Ts;
-        for (int k = lane; k <= N; k += 64) {
+        for (int k = lane; k <= N; k += OB_NT) {
             double s[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) s[i] = sh.traj[(size_t)k * 6 + i];
@@ -759,23 +806,33 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
 #undef FTBZ
     }
     SYNC();
-    double ap = red_min(sh.red[0]), az = red_min(sh.red[1]), gd = red_sum(sh.red[2]);
+    so.ap = red_min(sh.red[0]); so.az = red_min(sh.red[1]); so.gd = red_sum(sh.red[2]);
+    PAR(lane) { if (lane == 0) { sh.coef[0] = dt; sh.coef[1] = nu[0]; sh.coef[2] = nu[1]; sh.coef[3] = nu[2]; sh.coef[4] = nu[3]; } }
     SYNC();
     PROF(I, PF_BS_STAGE);
+}
+
+// part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
+template <int VM>
+OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const gdbl *z = I.z; gdbl *d = I.d;
+    double ap = so.ap, az = so.az, gd = so.gd;
+    const double dt = sh.coef[0], nu[4] = {sh.coef[1], sh.coef[2], sh.coef[3], sh.coef[4]};
     // ---- obstacle blocks: back-substitution (the block is re-factorised instead of being stored)
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < lap) lap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < laz) laz = cc_; }
-        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
-            ObsIn in; load_obs(I, sh, z, k, j, in);
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             const double dp[3] = {d[l.x + 4 * k], d[l.x + 4 * k + 1], d[l.x + 4 * k + 2]};
-            ObsStep st;
-            obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
+            ObsStep<VM> st;
+            obs_block<1, VM>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
             const int r0 = sh.roff[j];
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) {
+            for (int i = 0; i < VM; i++) if (i < in.v) {
                 d[l.lam + k * M + r0 + i] = st.dlam[i];
                 lgd -= mu / in.lam[i] * st.dlam[i];
                 FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
@@ -814,7 +871,7 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
         double g = 0;
         if (!c.fixTime) {
             const double t = z[l.t], q = t * c.Ts, rr = 0.1 / (q * q);
-            for (int k = lane; k < N; k += 64) {
+            for (int k = lane; k < N; k += OB_NT) {
                 double e1 = z[l.u + 2 * k] - (k ? z[l.u + 2 * k - 2] : 0.0), e2 = z[l.u + 2 * k + 1] - (k ? z[l.u + 2 * k - 1] : 0.0);
                 g += -2 * rr * (e1 * e1 + e2 * e2) / t;
             }
@@ -835,27 +892,28 @@ OBCA_FN void solve_direction(const Inst &I, Shared &sh, const AsmOut &A, double 
 }
 
 // ---------------------------------------------------------------- objective / constraint 1-norm / barrier at z + alpha d (primal part)
+template <int VM>
 OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, double &th1, double &bar) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z, *d = I.d;
     const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts;
     PAR(lane) {
         double lf = 0, lth = 0, lbar = 0;
-        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
-            ObsIn in; load_obs(I, sh, z, k, j, in);
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             const int r0 = sh.roff[j];
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) if (i < in.v) { in.lam[i] += alpha * d[l.lam + k * M + r0 + i]; lbar += log(in.lam[i]); }
+            for (int i = 0; i < VM; i++) if (i < in.v) { in.lam[i] += alpha * d[l.lam + k * M + r0 + i]; lbar += log(in.lam[i]); }
 #pragma unroll
             for (int i = 0; i < 4; i++) { in.mu[i] += alpha * d[l.mu + 4 * it + i]; lbar += log(in.mu[i]); }
             in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it]; lbar += log(in.so);
             in.X += alpha * d[l.x + 4 * k]; in.Y += alpha * d[l.x + 4 * k + 1]; in.psi += alpha * d[l.x + 4 * k + 2];
-            double r[4]; obs_rows(c, in, r);
+            double r[4]; obs_rows<VM>(c, in, r);
             lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
             lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
         }
-        for (int k = lane; k <= N; k += 64) {
+        for (int k = lane; k <= N; k += OB_NT) {
             double x[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i] + alpha * d[l.x + 4 * k + i];
@@ -900,24 +958,24 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
     gdbl *z = I.z; const gdbl *d = I.d;
     PAR(lane) {
         // one-sided (>=0) groups: lam, mu, so
-        for (int i = lane; i < M * (N + 1); i += 64) {
+        for (int i = lane; i < M * (N + 1); i += OB_NT) {
             double v = z[l.lam + i], dv = d[l.lam + i], zz = z[l.zlam + i];
             zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.lam + i] = v; z[l.zlam + i] = clampz(zz, v, mu, ks);
         }
-        for (int i = lane; i < 4 * nOb * (N + 1); i += 64) {
+        for (int i = lane; i < 4 * nOb * (N + 1); i += OB_NT) {
             double v = z[l.mu + i], dv = d[l.mu + i], zz = z[l.zmu + i];
             zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.mu + i] = v; z[l.zmu + i] = clampz(zz, v, mu, ks);
             z[l.yo + i] += ay * d[l.yo + i];
         }
-        for (int i = lane; i < nOb * (N + 1); i += 64) {
+        for (int i = lane; i < nOb * (N + 1); i += OB_NT) {
             double v = z[l.so + i], dv = d[l.so + i], zz = z[l.zso + i];
             zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.so + i] = v; z[l.zso + i] = clampz(zz, v, mu, ks);
             z[l.sl + i] += alpha * d[l.sl + i];
         }
-        for (int k = lane; k <= N; k += 64) {
+        for (int k = lane; k <= N; k += OB_NT) {
             if (k >= 1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -972,30 +1030,31 @@ OBCA_FN double push2(double v, double lo, double hi, double k1, double k2) {
     return v;
 }
 struct PushOpts { double bound_push, bound_frac; };
+template <int VM>
 OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     gdbl *z = I.z;
     PAR(lane) {
         if (lane < 4) z[l.x + lane] = c.x0[lane];
         if (lane == 4 && c.fixTime) z[l.t] = 1.0;
-        for (int i = l.pi + lane; i < l.zxL; i += 64) z[i] = 0.0;
-        for (int i = l.zxL + lane; i < l.len; i += 64) z[i] = 1.0;
+        for (int i = l.pi + lane; i < l.zxL; i += OB_NT) z[i] = 0.0;
+        for (int i = l.zxL + lane; i < l.len; i += OB_NT) z[i] = 1.0;
     }
     SYNC();
     const double q = z[l.t] * c.Ts;
     PAR(lane) {   // slacks take the row values at the (un-pushed) warm start
-        for (int k = lane; k < N; k += 64) z[l.ss + k] = ((k ? z[l.u + 2 * k - 2] : 0.0) - z[l.u + 2 * k]) / q;
-        for (int it = lane; it < (N + 1) * nOb; it += 64) {
+        for (int k = lane; k < N; k += OB_NT) z[l.ss + k] = ((k ? z[l.u + 2 * k - 2] : 0.0) - z[l.u + 2 * k]) / q;
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
-            ObsIn in; load_obs(I, sh, z, k, j, in);
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             in.so = 0;
-            double r[4]; obs_rows(c, in, r);
+            double r[4]; obs_rows<VM>(c, in, r);
             z[l.so + it] = r[3];
         }
     }
     SYNC();
     PAR(lane) {   // push into the interior
-        for (int k = lane; k <= N; k += 64) {
+        for (int k = lane; k <= N; k += OB_NT) {
             if (k >= 1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) if (i != 2) z[l.x + 4 * k + i] = push2(z[l.x + 4 * k + i], c.xl[i], c.xu[i], o.bound_push, o.bound_frac);
@@ -1007,19 +1066,36 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
             }
         }
         if (lane == 4 && !c.fixTime) z[l.t] = push2(z[l.t], OB_TL, OB_TU, o.bound_push, o.bound_frac);
-        for (int i = lane; i < M * (N + 1); i += 64) z[l.lam + i] = fmax(z[l.lam + i], o.bound_push);
-        for (int i = lane; i < 4 * nOb * (N + 1); i += 64) z[l.mu + i] = fmax(z[l.mu + i], o.bound_push);
-        for (int i = lane; i < nOb * (N + 1); i += 64) z[l.so + i] = fmax(z[l.so + i], o.bound_push);
+        for (int i = lane; i < M * (N + 1); i += OB_NT) z[l.lam + i] = fmax(z[l.lam + i], o.bound_push);
+        for (int i = lane; i < 4 * nOb * (N + 1); i += OB_NT) z[l.mu + i] = fmax(z[l.mu + i], o.bound_push);
+        for (int i = lane; i < nOb * (N + 1); i += OB_NT) z[l.so + i] = fmax(z[l.so + i], o.bound_push);
     }
     SYNC();
 }
 
 // ---------------------------------------------------------------- phase entry points (non-inlined; state lives in g_sh)
-OBCA_PHASE void ph_init(double bound_push, double bound_frac) { Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac}; PROF(sh.inst, PF_OTHER); init_point(sh.inst, sh, po); PROF(sh.inst, PF_INIT); }
-OBCA_PHASE void ph_assemble(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_PHASE void ph_init(double bound_push, double bound_frac) {
+    Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac}; PROF(sh.inst, PF_OTHER);
+    if (sh.vm2) init_point<2>(sh.inst, sh, po); else init_point<OB_VMAX>(sh.inst, sh, po);
+    PROF(sh.inst, PF_INIT);
+}
+OBCA_PHASE void ph_assemble_obs2(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<2>(sh.inst, sh, mu, dw, dc); }
+OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc); }
+OBCA_FN void ph_assemble_obs(double mu, double dw, double dc) { if (g_sh.vm2) ph_assemble_obs2(mu, dw, dc); else ph_assemble_obs4(mu, dw, dc); }
+OBCA_PHASE void ph_assemble_stage(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_FN void ph_assemble(double mu, double dw, double dc, int second) { ph_assemble_obs(mu, dw, dc); ph_assemble_stage(mu, dw, dc, second); }
 OBCA_PHASE int ph_riccati(double rho) { Shared &sh = g_sh; return riccati_backward(sh.inst, sh, rho); }
-OBCA_PHASE void ph_direction(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; solve_direction(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
-OBCA_PHASE void ph_trial(double alpha) { Shared &sh = g_sh; eval_trial(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_PHASE void ph_direction_main(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs2(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_FN void ph_direction_obs(double mu, double dw, double dc, double tau) { if (g_sh.vm2) ph_direction_obs2(mu, dw, dc, tau); else ph_direction_obs4(mu, dw, dc, tau); }
+OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double tau) {
+    ph_direction_main(mu, dw, dc, rho, tau);
+    if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
+}
+OBCA_PHASE void ph_trial2(double alpha) { Shared &sh = g_sh; eval_trial<2>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_FN void ph_trial(double alpha) { if (g_sh.vm2) ph_trial2(alpha); else ph_trial4(alpha); }
 OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double ks) { Shared &sh = g_sh; apply_step(sh.inst, sh, alpha, ay, az, mu, ks); }
 
 // ---------------------------------------------------------------- the interior-point driver
@@ -1117,7 +1193,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
 OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
     Shared &sh = g_sh;
     PAR(lane) {
-        for (int i = lane; i < OB_HDR; i += 64) sh.hdr[i] = sh.inst.prob[i];
+        for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
     }
     SYNC();
     PAR(lane) {
@@ -1130,6 +1206,8 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
             c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
             c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
             make_layout(c.N, c.nOb, c.M, sh.l);
+            int vmx = 0; for (int j = 0; j < c.nOb; j++) { int v = (int)sh.hdr[PH_VOB + j]; if (v > vmx) vmx = v; }
+            sh.vm2 = vmx <= 2;
         }
     }
     SYNC();

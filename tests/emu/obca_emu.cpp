@@ -29,6 +29,8 @@ static void setup(int N, const double *prob, Scratch &s) {
     c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
     c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
     make_layout(c.N, c.nOb, c.M, sh.l);
+    int vmx = 0; for (int j = 0; j < c.nOb; j++) if (sh.vOb[j] > vmx) vmx = sh.vOb[j];
+    sh.vm2 = vmx <= 2;
 }
 
 extern "C" {
@@ -40,11 +42,14 @@ int emu_newton(int N, const double *prob, const double *zin, int len, double mu,
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len);
     setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
-    AsmOut A; assemble(I, sh, mu, dw, dc, A);
+    AsmOut A;
+    if (sh.vm2) assemble_obs<2>(I, sh, mu, dw, dc); else assemble_obs<OB_VMAX>(I, sh, mu, dw, dc);
+    assemble_stage(I, sh, mu, dw, dc, A);
     int ok = A.ok;
     StepOut S; S.ap = S.az = S.gd = 0;
     if (ok) ok = riccati_backward(I, sh, rho);
-    if (ok) { solve_direction(I, sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; }
+    if (ok) { direction_main(I, sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; }
+    if (ok) { if (sh.vm2) direction_obs<2>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX>(I, sh, mu, dw, dc, tau, S); }
     memcpy(dout, s.d, sizeof(double) * len);
     aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = A.cinfmu; aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
     aux[7] = S.ap; aux[8] = S.az; aux[9] = S.gd;
@@ -56,7 +61,7 @@ int emu_eval_trial(int N, const double *prob, const double *zin, const double *d
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len); memcpy(s.d, din, sizeof(double) * len);
     setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
-    eval_trial(I, sh, alpha, out3[0], out3[1], out3[2]);
+    if (sh.vm2) eval_trial<2>(I, sh, alpha, out3[0], out3[1], out3[2]); else eval_trial<OB_VMAX>(I, sh, alpha, out3[0], out3[1], out3[2]);
     free_scratch(s);
     return 0;
 }
