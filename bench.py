@@ -12,9 +12,9 @@ interior-point kernel + stream sync.  `value` counts CONVERGED solves (exitflag 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
 Extra objects in the JSON line:
-  roofline     : dominant kernel = obca_parking_ipm_kernel.  It is fp64 VALU/latency bound: "achieved" =
-                 executed-algorithm flops (Model B of SURVEY.md 8d, F_PASS per factorisation pass x passes actually taken, read
-                 back from the kernel's iteration/regularisation counters) / HIP-event duration of that kernel.
+  roofline     : dominant kernel = obca_parking_ipm_kernel: "achieved" = algorithmic HBM bytes (B_PASS per
+                 factorisation pass x passes actually taken, read back from the kernel's iteration/regularisation counters) /
+                 HIP-event duration of that kernel; the executed-algorithm fp64 flop rate is reported next to it.
   cpu_baseline : the CPU oracle (C restatement, NOT IPOPT) on a bounded sample of the same instances, on the box's host cores.
 """
 import argparse
@@ -36,6 +36,27 @@ SEED = 20260925
 #   + Riccati backward 80 x 3500 + forward/closed-loop 80 x 400 + line-search evaluations ~27e3
 F_PASS = 243 * 1300 + 81 * 3000 + 80 * 3500 + 80 * 400 + 27e3
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = matrix peak (AMD datasheet; the microarch guide lists no fp64 figure)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic HBM bytes per factorisation pass of one instance: the iterate, direction, assembled stage records,
+# Riccati records and condensed obstacle records live in HBM (0.32 MB/instance does not fit LDS) and each is streamed a fixed number of
+# times per pass: ~56.5k doubles read + ~29.5k doubles written
+B_PASS = (56500 + 29550) * 8.0
+
+
+def committed_pmc_traffic():
+    """HBM bytes per launch of obca_parking_ipm_kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_*.csv; FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md, checked on the D2D copy in the
+    same trace).  Not collected live: bench.py cannot run under rocprofv3 by itself."""
+    import csv
+    try:
+        vals = {}
+        for name, fn in (("FETCH_SIZE", "r01_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_pmc_write_size.csv")):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+                if r["Kernel_Name"].startswith("obca_parking_ipm_kernel") and r["Counter_Name"] == name:
+                    vals[name] = float(r["Counter_Value"]) * 1024.0
+        return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+    except Exception:
+        return None
 
 
 def _cpu_worker(args):
@@ -136,7 +157,8 @@ def main():
         conv_all, iters_all, passes_all = float(conv), float(out["iters"].sum()), passes
     if rank == 0:
         k_ms = float(np.mean(ipm_ms))
-        achieved = passes * F_PASS / (k_ms * 1e-3) / 1e12      # rank 0's kernel: flops of the passes it took / its duration
+        tflops = passes * F_PASS / (k_ms * 1e-3) / 1e12        # rank 0's kernel: flops of the passes it took / its duration
+        gbs = passes * B_PASS / (k_ms * 1e-3) / 1e9            # algorithmic HBM bytes of those passes / its duration
         line = {
             "metric": "OBCA NLP solves/sec (N=80, 3 obs, batch)", "value": round(conv_all * a.steps / dt, 2), "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -146,11 +168,15 @@ def main():
                        "batch_per_gpu": B, "horizon": N_HORIZON, "sharding": f"independent instances, {world} rank(s), no data-path collective",
                        "converged": int(conv_all), "instances": B * world, "mean_iterations": round(iters_all / (B * world), 2),
                        "max_iterations_rank0": int(out["iters"].max())},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP64_PEAK_TFLOPS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": committed_pmc_traffic(),
                          "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
-                         "model": "executed-algorithm fp64 flops (SURVEY 8d Model B): F_PASS=%.3g per factorisation pass x %d passes "
-                                  "(iterations + inertia retries, read from the kernel); fp64 VALU work, no MFMA issued" % (F_PASS, int(passes))},
+                         "fp64_tflops": round(tflops, 3), "fp64_frac": round(tflops / FP64_PEAK_TFLOPS, 5),
+                         "model": "per factorisation pass of one instance: B_PASS=%.3g algorithmic HBM bytes and F_PASS=%.3g executed fp64 flops "
+                                  "(SURVEY 8d Model B), x %d passes (iterations + inertia retries, read back from the kernel). The larger of the "
+                                  "two fractions is reported as the bound; neither is tight: the kernel is latency-bound (one or two waves per "
+                                  "SIMD, 81 dependent stages per pass) and ends with the slowest instance of the batch. traffic = PMC bytes of "
+                                  "one launch from profiles/r01_pmc_*.csv (committed, not live)" % (B_PASS, F_PASS, int(passes))},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
