@@ -1,0 +1,86 @@
+"""CPU tests of the quadcopter oracle (QuadcopterSignedDist path): Newton direction vs dense autograd KKT, full solve, feasibility."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def Q():
+    import oracle_quad
+    oracle_quad.lib()
+    return oracle_quad
+
+
+def test_quad_newton_direction_vs_dense_autograd(Q):
+    torch = pytest.importorskip("torch")
+    from nlp_ref_quad import QuadNLP
+    rng = np.random.default_rng(2)
+    N, Ts, R, ob = 7, 0.3, 0.25, Q.OB_CLAMPED
+    x0 = Q.X0.copy(); x0[9:12] = [0.1, -0.2, 0.15]       # non-zero stage-1 rates exercise the single-index quirk
+    nlp = QuadNLP(x0, Q.XF, N, Ts, R, ob); L = Q.layout(N); n, m = L["n"], L["m"]
+    assert n == nlp.n + 12 and m == nlp.m
+    xWS = Q.warm_start(x0, Q.XF, N)
+    v = np.zeros(n)
+    X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 12)); X[1:, 3:6] = 0.1 * rng.standard_normal((N, 3)); X[0] = x0
+    v[L["x"]:L["x"] + 12 * (N + 1)] = X.reshape(-1)
+    v[L["u"]:L["u"] + 4 * N] = rng.uniform(3, 6, 4 * N); v[L["t"]] = 1.1
+    for k, cnt in (("lam", 30), ("s", 5), ("so", 5)):
+        v[L[k]:L[k] + cnt * (N + 1)] = rng.uniform(0.1, 1, cnt * (N + 1))
+    y = rng.standard_normal(m); zL = rng.uniform(0.1, 2, n); zU = rng.uniform(0.1, 2, n)
+    mu, dw, dc = 0.1, 500.0, 1e-6
+    ok, dv, dy, errs = Q.newton(N, Ts, R, x0, Q.XF, ob, v, y, zL, zU, mu, dw, dc)
+    assert ok == 1
+    vv = v[12:]; zLr = zL[12:].copy(); zUr = zU[12:].copy()
+    f, g, c, J, H = nlp.eval_all(vv, y)
+    IL = np.isfinite(nlp.lb); IU = np.isfinite(nlp.ub); zLr[~IL] = 0; zUr[~IU] = 0
+    dL = np.where(IL, vv - nlp.lb, 1.0); dU = np.where(IU, nlp.ub - vv, 1.0)
+    Sig = nlp.mult * (np.where(IL, zLr / dL, 0) + np.where(IU, zUr / dU, 0))
+    gphi = g - mu * nlp.mult * np.where(IL, 1 / dL, 0) + mu * nlp.mult * np.where(IU, 1 / dU, 0)
+    dcv = np.concatenate([np.zeros(12 * N + 12), dc * np.ones(10 * (N + 1))])
+    K = np.block([[H + np.diag(Sig + dw), J.T], [J, -np.diag(dcv)]])
+    sol = np.linalg.solve(K, -np.concatenate([gphi + J.T @ y, c]))
+    ev = np.linalg.eigvalsh(K)
+    assert (ev > 0).sum() == nlp.n and (ev < 0).sum() == nlp.m
+    assert np.abs(dv[12:] - sol[:nlp.n]).max() < 1e-9 * max(1, np.abs(sol[:nlp.n]).max())
+    assert np.abs(dy - sol[nlp.n:]).max() < 1e-8 * max(1, np.abs(sol[nlp.n:]).max())
+    rd = g + J.T @ y - nlp.mult * zLr + nlp.mult * zUr
+    assert abs(errs[0] - np.abs(rd).max()) < 1e-9 * np.abs(rd).max() and abs(errs[1] - np.abs(c).max()) < 1e-12
+
+
+def test_quad_shipped_scenario_solves_and_is_feasible(Q):
+    """mainQuadcopter.jl scenario (boxes as clamped by the plot call); way-point warm start instead of 3-D A*"""
+    N = 60; Ts = round(0.25 * 80 / N * 100) / 100          # mainQuadcopter.jl:131
+    via = [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)]
+    xWS = Q.warm_start(Q.X0, Q.XF, N, via)
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    assert r["exitflag"] == 1 and r["status"] == 0 and r["slack"].sum() < 1e-3        # :229-234, :285-288
+    xp, up, ts, lp = r["xp"], r["up"], r["timeScale"], r["lp"]
+    assert xp.shape == (12, N + 1) and up.shape == (4, N) and lp.shape == (30, N + 1)
+    assert np.abs(xp[:, 0] - Q.X0).max() == 0 and np.abs(xp[:, N] - Q.XF).max() < 1e-4
+    # a-posteriori feasibility in the spirit of constrSatisfaction.jl (tolerance 1e-3): bounds, dynamics, separation rows
+    assert up.min() >= 1.2 - 1e-3 and up.max() <= 7.8 + 1e-3 and 0.5 - 1e-3 <= ts[0] <= 2 + 1e-3
+    from nlp_ref_quad import XLB, XUB
+    assert (xp >= XLB[:, None] - 1e-3).all() and (xp <= XUB[:, None] + 1e-3).all()
+    import torch
+    from nlp_ref_quad import QuadNLP
+    nlp = QuadNLP(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED)
+    v = np.concatenate([xp.T[1:].reshape(-1), up.T.reshape(-1), [ts[0]], lp.T.reshape(-1), r["slack"].T.reshape(-1), np.zeros(5 * (N + 1))])
+    c = nlp.c(torch.tensor(v)).numpy()
+    assert np.abs(c[:12 * N + 12]).max() < 1e-3                     # dynamics + terminal
+    cob = c[12 * N + 12:].reshape(N + 1, 5, 2)
+    assert np.abs(cob[:, :, 0]).max() < 1e-3 and cob[:, :, 1].min() > -1e-3     # |A'lam|=1 ; separation >= R (row slack = 0 here)
+    # the ball really clears every box: Euclidean point-box distance >= R
+    for k in range(N + 1):
+        for j in range(5):
+            hi = Q.OB_CLAMPED[j, :3]; lo = -Q.OB_CLAMPED[j, 3:]
+            d = np.linalg.norm(xp[:3, k] - np.clip(xp[:3, k], lo, hi))
+            assert d >= Q.EGO_R - 2e-3, (k, j, d)
+
+
+def test_quad_reference_start_is_rank_deficient(Q):
+    """documents why the dual warm start exists: at lambda = 0.05 (QuadcopterSignedDist.jl:204-208) A'lambda = 0 and the row
+    |A'lambda|^2 == 1 has a zero gradient; without IPOPT's restoration phase the solve stalls"""
+    N = 20; Ts = 1.0
+    xWS = Q.warm_start(Q.X0, Q.XF, N, [(2.25, 1.5, 0.3), (7.25, 4.5, 2.5)])
+    o = Q.default_opts(); o.max_iter = 60
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, o, dual_ws=0)
+    assert r["exitflag"] == 0
