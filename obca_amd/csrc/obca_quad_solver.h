@@ -1,0 +1,849 @@
+// obca_quad_solver.h -- one quadcopter signed-distance NLP instance (QuadcopterSignedDist.jl) solved by one 128-thread workgroup.
+//
+// Same programming model, interior-point algorithm and phase structure as obca_solver.h (parking); what differs is the model
+// (12 states, 4 rotor speeds, 5 box obstacles with 6 multipliers each, slack >= 0), hence the sizes: Riccati state 16 (x and the
+// copy of u_{k-1}), 4 inputs, 14 right-hand sides (main, t, nu_1..12), a 13x13 (t, nu) border, and a dense pre-zeroed stage record.
+#pragma once
+#include "obca_solver.h"
+#include "obca_quad_model.h"
+
+namespace obca {
+namespace quad {
+
+#define QNMAX 64                     // longest horizon (the forward-sweep trajectory lives in LDS)
+#define QSR 736                      // doubles per stage record: H 20x20 | Fh 16x18 | hc 20x2
+#define QSR_H 0
+#define QSR_F 400                    // Fh[a][c]: c<12 x columns (A), 12..15 u columns (B / identity), 16 = d, 17 = Ft
+#define QSR_HC 688                   // hc[i][0] = gradient (barrier form), hc[i][1] = d/dt column
+#define QRR 768                      // doubles per Riccati record
+#define QRR_K 0                      // K 4x16
+#define QRR_KF 64                    // feed-forward 4x14
+#define QRR_PX 120                   // rows 0..11 of P (12x16)
+#define QRR_PV 312                   // rows 0..11 of p (12x14)
+#define QRR_CL 480                   // closed loop: Acl 16x16 then bcl 16
+#define QFILT 224
+#define QFC 18                       // columns of Fh
+#define QQC (QZ + QC)                // columns of the extended matrix (34)
+
+struct QLay { int x, u, t, lam, s, so, n, pi, nu, yo, m, zL, zU, len; };   // iterate buffer: v[n] | y[m] | zL[n] | zU[n]
+OBCA_HD void q_make_layout(int N, QLay &l) {
+    int o = 0, N1 = N + 1;
+    l.x = o; o += QX * N1; l.u = o; o += QU * N; l.t = o; o += 1; l.lam = o; o += QL * QOB * N1; l.s = o; o += QOB * N1; l.so = o; o += QOB * N1; l.n = o;
+    l.pi = o; o += QX * N; l.nu = o; o += QX; l.yo = o; o += 2 * QOB * N1; l.m = o - l.n;
+    l.zL = o; o += l.n; l.zU = o; o += l.n; l.len = o;
+}
+// direction buffer: dv[n] then dy[m] (same offsets as v / y)
+
+struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R, x0[12], xF[12], ob[30], xWS..., see host packing
+#define QPH_TS 0
+#define QPH_R 1
+#define QPH_X0 2
+#define QPH_XF 14
+#define QPH_OB 26
+#define QPH_TWS 56
+#define QPH_DWS 57
+#define QPH_SIZE 64
+
+struct QShared {
+    QConsts c; QLay l; QInst inst; AsmOut A, A2, Ap; StepOut S; double trial[4];
+    double ob[QOB * QL];
+    double red[16][OB_NT];               // reductions; during the sweeps the same memory holds That|Qhat or the forward-sweep ring
+    double Pn[QS * QS], pn[QS * QC], sg[QSR], Khat[QU * 30], Bm[QC * QC], sB[4 * QC], Lq[QU * QU];
+    double bord[13 * 13 + 3 * 13], coef[QC];
+    double traj[(QNMAX + 2) * QS];
+    double filt[QFILT][2];
+    int ric_ok, bord_ok;
+};
+#ifdef OBCA_EMU
+static QShared gq_sh;
+#else
+__shared__ QShared gq_sh;
+#endif
+
+// bounds of primal variable i
+struct QBnd { double lo, hi; int hasL, hasU; double mult; };
+OBCA_FN QBnd q_bounds(const QLay &l, int N, int i) {
+    QBnd b; b.lo = 0; b.hi = 0; b.hasL = 0; b.hasU = 0; b.mult = 1;
+    if (i < l.u) { int k = i / QX, cI = i - k * QX; if (k >= 1) { b.lo = q_xlb(cI); b.hi = q_xub(cI); b.hasL = b.hasU = 1; } }
+    else if (i < l.t) { b.lo = Q_ULO; b.hi = Q_UHI; b.hasL = b.hasU = 1; }
+    else if (i == l.t) { b.lo = Q_TLO; b.hi = Q_THI; b.hasL = b.hasU = 1; b.mult = N + 1; }
+    else { b.hasL = 1; }
+    return b;
+}
+
+OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &in) {
+    const QLay &l = sh.l; const int bo = k * QOB + j;
+#pragma unroll
+    for (int i = 0; i < QL; i++) { in.b[i] = sh.ob[j * QL + i]; in.lam[i] = z[l.lam + QL * bo + i]; in.zl[i] = z[l.zL + l.lam + QL * bo + i]; }
+    in.s = z[l.s + bo]; in.zs = z[l.zL + l.s + bo]; in.so = z[l.so + bo]; in.zso = z[l.zL + l.so + bo];
+    in.y[0] = z[l.yo + 2 * bo]; in.y[1] = z[l.yo + 2 * bo + 1];
+    in.p[0] = z[l.x + QX * k]; in.p[1] = z[l.x + QX * k + 1]; in.p[2] = z[l.x + QX * k + 2];
+}
+
+// ---------------------------------------------------------------- assemble, part (a): box blocks
+OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
+    const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z;
+    PAR(lane) {
+        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        double fsl = 0, th = 0, bar = 0;
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in);
+            ObsCond cd;
+            q_obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            gdbl *o = sh.inst.oc + (size_t)it * OB_OC;
+#pragma unroll
+            for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
+            fsl += 1e2 * in.s + 1e3 * in.s * in.s;
+            double r[2], q[3]; q_obs_rows(c, in, r, q);
+            th += fabs(r[0]) + fabs(r[1]);
+#pragma unroll
+            for (int i = 0; i < QL; i++) { fsl += 1e-4 * in.lam[i] * in.lam[i]; bar += log(in.lam[i]); }
+            bar += log(in.s) + log(in.so);
+        }
+        sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
+        sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
+        sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
+    }
+    SYNC();
+    AsmOut &P = sh.Ap;
+    P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cinfmu = red_max(sh.red[3]);
+    P.sumz = red_sum(sh.red[4]); P.sumy = red_sum(sh.red[5]); P.f = red_sum(sh.red[6]); P.th1 = red_sum(sh.red[7]);
+    P.bar = red_sum(sh.red[8]); P.ok = !(red_max(sh.red[9]) > 0.5);
+    SYNC();
+}
+
+// ---------------------------------------------------------------- assemble, part (b): stages (writes the non-zeros of the dense record)
+OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmOut &out) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
+    const double t = z[l.t], tau = t * c.Ts;
+    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
+           th1 = sh.Ap.th1, bar = sh.Ap.bar;
+    const int ok = sh.Ap.ok;
+    PAR(lane) {
+        double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lgtb = 0, lgtz = 0;
+        for (int k = lane; k <= N; k += OB_NT) {
+            gdbl *rec = sh.inst.as + (size_t)k * QSR;
+            double x[QX], hz[QX], hb[QX], xd[QX], Hpos[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < QX; i++) {
+                x[i] = z[l.x + QX * k + i];
+                const double gx = i >= 9 ? 2e-4 * x[i] : 0.0;
+                hz[i] = gx; hb[i] = gx; xd[i] = (i >= 9 ? 2e-4 : 0.0) + dw;
+                if (i >= 9) lf += 1e-4 * x[i] * x[i];
+                if (k >= 1) {
+                    B2 b = bound2(x[i], q_xlb(i), q_xub(i), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmu, lsz);
+                    xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; lbar += log(x[i] - q_xlb(i)) + log(q_xub(i) - x[i]);
+                }
+            }
+            for (int j = 0; j < QOB; j++) {
+                const gdbl *o = sh.inst.oc + (size_t)(k * QOB + j) * OB_OC;
+#pragma unroll
+                for (int i = 0; i < 6; i++) Hpos[i] += o[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { hz[i] += o[6 + i]; hb[i] += o[6 + i] - o[9 + i]; }
+            }
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < QX; i++) {
+                    const double e = fabs(x[i] - c.xF[i]); if (e > pmax) pmax = e; lth += e;
+                    const double r = z[l.pi + QX * (N - 1) + i] + z[l.nu + i];
+                    hz[i] += r; hb[i] += r; if (fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                    lsy += fabs(z[l.nu + i]);
+                    rec[QSR_H + i * QZ + i] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
+                    rec[QSR_HC + 2 * i] = hb[i]; rec[QSR_HC + 2 * i + 1] = 0.0;
+                }
+                rec[QSR_H + 0 * QZ + 1] = Hpos[1]; rec[QSR_H + 1 * QZ + 0] = Hpos[1]; rec[QSR_H + 0 * QZ + 2] = Hpos[2]; rec[QSR_H + 2 * QZ + 0] = Hpos[2];
+                rec[QSR_H + 1 * QZ + 2] = Hpos[4]; rec[QSR_H + 2 * QZ + 1] = Hpos[4];
+                continue;
+            }
+            double u[QU], pi[QX], g[QX], dg[9][QV], HG[55];
+#pragma unroll
+            for (int j = 0; j < QU; j++) u[j] = z[l.u + QU * k + j];
+#pragma unroll
+            for (int i = 0; i < QX; i++) { pi[i] = z[l.pi + QX * k + i]; lsy += fabs(pi[i]); }
+            dyn_g_derivs(c, x, u, pi, g, dg, HG);
+            // residual, F columns d / Ft, A, B
+#pragma unroll
+            for (int i = 0; i < QX; i++) {
+                const double r = z[l.x + QX * (k + 1) + i] - x[i] - tau * g[i];
+                if (fabs(r) > pmax) pmax = fabs(r); lth += fabs(r);
+                rec[QSR_F + i * QFC + 16] = -r; rec[QSR_F + i * QFC + 17] = c.Ts * g[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) rec[QSR_F + i * QFC + 6 + i] = tau;
+#pragma unroll
+            for (int i = 3; i < QX; i++)
+#pragma unroll
+                for (int a = 0; a < QV; a++) {
+                    const int id = q_vidx(a);
+                    if (id < QX) rec[QSR_F + i * QFC + id] = (id == i ? 1.0 : 0.0) + tau * dg[i - 3][a];
+                    else rec[QSR_F + i * QFC + 12 + (id - QS)] = tau * dg[i - 3][a];
+                }
+            // J^T pi for x_k, u_k, t ; Hessian cross terms with t
+            double Ht[QZ];
+#pragma unroll
+            for (int i = 0; i < QZ; i++) Ht[i] = 0;
+            double ATpi[QX];
+#pragma unroll
+            for (int i = 0; i < QX; i++) ATpi[i] = pi[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { ATpi[6 + i] += tau * pi[i]; Ht[6 + i] += -c.Ts * pi[i]; }
+            double BTpi[QU] = {0, 0, 0, 0}, gtl = 0;
+#pragma unroll
+            for (int a = 0; a < QV; a++) {
+                double s_ = 0;
+#pragma unroll
+                for (int i = 3; i < QX; i++) s_ += dg[i - 3][a] * pi[i];
+                const int id = q_vidx(a);
+                if (id < QX) ATpi[id] += tau * s_; else BTpi[id - QS] += tau * s_;
+                Ht[id] += -c.Ts * s_;
+            }
+#pragma unroll
+            for (int i = 0; i < QX; i++) gtl += c.Ts * g[i] * pi[i];
+            lgtz -= gtl; lgtb -= gtl;
+#pragma unroll
+            for (int i = 0; i < QX; i++) {
+                const double r = (k >= 1 ? z[l.pi + QX * (k - 1) + i] : 0.0) - ATpi[i];
+                hz[i] += r; hb[i] += r; if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+            }
+            // inputs: costs, bounds, copy terms
+            double hzu[QU], hbu[QU], hzw[QU], ud[QU], wn[QU];
+#pragma unroll
+            for (int j = 0; j < QU; j++) {
+                B2 b = bound2(u[j], Q_ULO, Q_UHI, z[l.zL + l.u + QU * k + j], z[l.zU + l.u + QU * k + j], mu, 1, lc0, lcmu, lsz);
+                lbar += log(u[j] - Q_ULO) + log(Q_UHI - u[j]);
+                double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
+                lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
+                if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
+                hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = hu + b.Sig + dw;
+                wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - z[l.u + QU * (k + 1) + j]) : 0.0;     // copy part living in stage k+1
+                const double tot = hzu[j] + wn[j]; if (fabs(tot) > dmax) dmax = fabs(tot);
+            }
+            // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
+#pragma unroll
+            for (int i = 0; i < QX; i++) rec[QSR_H + i * QZ + i] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
+            rec[QSR_H + 0 * QZ + 1] = Hpos[1]; rec[QSR_H + 1 * QZ + 0] = Hpos[1]; rec[QSR_H + 0 * QZ + 2] = Hpos[2]; rec[QSR_H + 2 * QZ + 0] = Hpos[2];
+            rec[QSR_H + 1 * QZ + 2] = Hpos[4]; rec[QSR_H + 2 * QZ + 1] = Hpos[4];
+#pragma unroll
+            for (int a = 0; a < QV; a++)
+#pragma unroll
+                for (int b_ = 0; b_ < QV; b_++) {
+                    const int ia = q_vidx(a), ib = q_vidx(b_);
+                    double v = -tau * HG[q_pidx(a, b_)];
+                    if (a == b_) v += (ia < QX) ? xd[ia] : ud[ia - QS];
+                    rec[QSR_H + ia * QZ + ib] = v;
+                }
+#pragma unroll
+            for (int j = 0; j < QU; j++) {
+                const double ww = k >= 1 ? 2e-2 : 0.0;
+                rec[QSR_H + (QX + j) * QZ + (QX + j)] = ww; rec[QSR_H + (QX + j) * QZ + (QS + j)] = -ww; rec[QSR_H + (QS + j) * QZ + (QX + j)] = -ww;
+            }
+            // gradients / t-columns
+#pragma unroll
+            for (int i = 0; i < QX; i++) { rec[QSR_HC + 2 * i] = hb[i]; rec[QSR_HC + 2 * i + 1] = Ht[i]; }
+#pragma unroll
+            for (int j = 0; j < QU; j++) {
+                rec[QSR_HC + 2 * (QX + j)] = hzw[j]; rec[QSR_HC + 2 * (QX + j) + 1] = 0.0;
+                rec[QSR_HC + 2 * (QS + j)] = hbu[j]; rec[QSR_HC + 2 * (QS + j) + 1] = Ht[QS + j];
+            }
+        }
+        sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmu;
+        sh.red[4][lane] = lsz; sh.red[5][lane] = lsy; sh.red[6][lane] = lf; sh.red[7][lane] = lth;
+        sh.red[8][lane] = lbar; sh.red[10][lane] = lgtb; sh.red[11][lane] = lgtz;
+    }
+    SYNC();
+    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmu = fmax(cmu, red_max(sh.red[3]));
+    sumz += red_sum(sh.red[4]); sumy += red_sum(sh.red[5]); f += red_sum(sh.red[6]); th1 += red_sum(sh.red[7]); bar += red_sum(sh.red[8]);
+    double gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
+    SYNC();
+    double d0 = 0, d1 = 0, d2 = 0;
+    B2 b = bound2(t, Q_TLO, Q_THI, z[l.zL + l.t], z[l.zU + l.t], mu, N + 1, d0, d1, d2);
+    c0 = fmax(c0, d0); cmu = fmax(cmu, d1); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
+    const double gf = (N + 1) * (0.25 + 10 * t);
+    gtb += gf + b.gb; gtz += gf + b.gz;
+    f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+    dinf = fmax(dinf, fabs(gtz));
+    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
+    out.f = f; out.th1 = th1; out.bar = bar; out.Htt = 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
+    out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2) * QOB * (N + 1);
+    out.nm = QX * N + QX + 2 * QOB * (N + 1);
+}
+
+// ---------------------------------------------------------------- Riccati backward sweep (wavefront 0)
+#define QTH(a, cI) That[(a) * QQC + (cI)]
+#define QQH(i, cI) Qhat[(i) * QQC + (cI)]
+OBCA_FN double q_fh(const double *sg, int a, int cI) {   // entry (a, cI) of [F | off] with cI over the 34 extended columns
+    if (cI < QX) return a < QX ? sg[QSR_F + a * QFC + cI] : 0.0;
+    if (cI < QS) return 0.0;                                   // w columns: the copy does not propagate
+    if (cI < QZ) return a < QX ? sg[QSR_F + a * QFC + 12 + (cI - QS)] : ((a - QX) == (cI - QS) ? 1.0 : 0.0);
+    if (cI < QZ + 2) return a < QX ? sg[QSR_F + a * QFC + 16 + (cI - QZ)] : 0.0;
+    return 0.0;
+}
+OBCA_FN void q_pair(int p, int &a_, int &b_) { a_ = 0; int rem = p; while (rem >= QC - a_) { rem -= QC - a_; a_++; } b_ = a_ + rem; }
+
+OBCA_FN int q_riccati_body(QShared &sh, double rho) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
+    double *That = &sh.red[0][0], *Qhat = That + QS * QQC;      // 544 + 680 doubles <= 16 * OB_NT
+    double nv[OBCA_NL][12];
+    PAR64(lane) {
+        const gdbl *rec = sh.inst.as + (size_t)N * QSR;
+        for (int it = lane; it < QS * QS; it += 64) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
+        for (int it = lane; it < QS * QC; it += 64) {
+            int i = it / QC, cc = it % QC; double v = 0;
+            if (i < QX) { if (cc == 0) v = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
+            sh.pn[it] = v;
+        }
+        for (int it = lane; it < QC * QC; it += 64) sh.Bm[it] = 0;
+        const gdbl *r1 = sh.inst.as + (size_t)(N - 1) * QSR;
+        for (int i = lane; i < QSR; i += 64) sh.sg[i] = r1[i];
+        if (N >= 2) { const gdbl *r2 = sh.inst.as + (size_t)(N - 2) * QSR;
+#pragma unroll
+            for (int r = 0; r < 12; r++) { int i = lane + 64 * r; nv[LI(lane)][r] = i < QSR ? r2[i] : 0.0; } }
+    }
+    LDS_SYNC();
+    for (int k = N - 1; k >= 0; k--) {
+        const double *sg = sh.sg;
+        PAR64(lane) {   // A: That = Pn [F | off] + [0 | pn]   (16 x 34)
+            for (int it = lane; it < QS * QQC; it += 64) {
+                const int a = it / QQC, cI = it % QQC;
+                double acc = cI >= QZ ? sh.pn[a * QC + (cI - QZ)] : 0.0;
+                if (cI < QX || (cI >= QS && cI < QZ + 2)) {
+#pragma unroll 4
+                    for (int b_ = 0; b_ < QS; b_++) acc += sh.Pn[a * QS + b_] * q_fh(sg, b_, cI);
+                }
+                QTH(a, cI) = acc;
+            }
+        }
+        LDS_SYNC();
+        PAR64(lane) {   // B: Qhat = [H | hc] + F^T That  (20 x 34); static parts of the bilinear update for the pairs with a in {0,1}
+            for (int it = lane; it < QZ * QQC; it += 64) {
+                const int i = it / QQC, cI = it % QQC;
+                double acc = cI < QZ ? sg[QSR_H + i * QZ + cI] : (cI < QZ + 2 ? sg[QSR_HC + 2 * i + (cI - QZ)] : 0.0);
+                if (i < QX || i >= QS) {
+#pragma unroll 4
+                    for (int a = 0; a < QS; a++) acc += q_fh(sg, a, i) * QTH(a, cI);
+                }
+                QQH(i, cI) = acc;
+            }
+            if (lane < 2 * QC) {   // sB[m][b] = off_m . That[:, 20+b] ; sB[2+m][b] = off_m . pn[:, b]   (m = 0: d, 1: Ft)
+                const int m = lane / QC, b_ = lane % QC; double u1 = 0, u2 = 0;
+                for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1 += o * QTH(i, QZ + b_); u2 += o * sh.pn[i * QC + b_]; }
+                sh.sB[m * QC + b_] = u1; sh.sB[(2 + m) * QC + b_] = u2;
+            }
+        }
+        LDS_SYNC();
+        // C: Quu = Qhat[16..19][16..19] -> LDL (uniform), gains for the 30 columns (16 state columns + 14 right-hand sides)
+        double Lq[QU * QU];
+#pragma unroll
+        for (int i = 0; i < QU; i++)
+#pragma unroll
+            for (int j = 0; j < QU; j++) Lq[i * QU + j] = QQH(QS + i, QS + j);
+#ifdef OBCA_EMU
+        if (getenv("OBCA_DBG")) { fprintf(stderr, "k=%d Quu diag %g %g %g %g\n", k, QQH(16,16), QQH(17,17), QQH(18,18), QQH(19,19)); }
+#endif
+        if (ldl_fact<QU>(QU, Lq)) return 0;
+        gdbl *ro = sh.inst.rs + (size_t)k * QRR;
+        PAR64(lane) {
+            if (lane < 30) {
+                const int qc = lane < QS ? lane : QZ + (lane - QS);
+                double b[QU];
+#pragma unroll
+                for (int i = 0; i < QU; i++) b[i] = -QQH(QS + i, qc);
+                ldl_solve<QU>(QU, Lq, b);
+#pragma unroll
+                for (int i = 0; i < QU; i++) { sh.Khat[i * 30 + lane] = b[i]; if (lane < QS) ro[QRR_K + i * QS + lane] = b[i]; else ro[QRR_KF + i * QC + (lane - QS)] = b[i]; }
+            }
+        }
+        LDS_SYNC();
+        PAR64(lane) {   // D: new Pn, pn; bilinear constants; park the next stage record
+            for (int it = lane; it < QS * 30; it += 64) {
+                const int i = it / 30, cc = it % 30, qc = cc < QS ? cc : QZ + (cc - QS);
+                double v = QQH(i, qc);
+#pragma unroll
+                for (int a = 0; a < QU; a++) v += QQH(i, QS + a) * sh.Khat[a * 30 + cc];
+                if (cc < QS && cc != i) {   // keep the value function exactly symmetric
+                    double w_ = QQH(cc, i);
+#pragma unroll
+                    for (int a = 0; a < QU; a++) w_ += QQH(cc, QS + a) * sh.Khat[a * 30 + i];
+                    v = 0.5 * (v + w_);
+                }
+                if (cc < QS) { sh.Pn[i * QS + cc] = v; if (i < QX) ro[QRR_PX + i * QS + cc] = v; }
+                else { sh.pn[i * QC + (cc - QS)] = v; if (i < QX) ro[QRR_PV + i * QC + (cc - QS)] = v; }
+            }
+            for (int p = lane; p < QC * (QC + 1) / 2; p += 64) {
+                int a_, b_; q_pair(p, a_, b_);
+                double v = 0;
+#pragma unroll
+                for (int i = 0; i < QU; i++) v += QQH(QS + i, QZ + a_) * sh.Khat[i * 30 + QS + b_];
+                if (a_ < 2) v += sh.sB[a_ * QC + b_];
+                if (b_ < 2) v += sh.sB[(2 + b_) * QC + a_];
+                sh.Bm[a_ * QC + b_] += v; if (a_ != b_) sh.Bm[b_ * QC + a_] += v;
+            }
+            if (k > 0) {
+#pragma unroll
+                for (int r = 0; r < 12; r++) { int i = lane + 64 * r; if (i < QSR) sh.sg[i] = nv[LI(lane)][r]; }
+                if (k > 1) { const gdbl *r2 = sh.inst.as + (size_t)(k - 2) * QSR;
+#pragma unroll
+                    for (int r = 0; r < 12; r++) { int i = lane + 64 * r; nv[LI(lane)][r] = i < QSR ? r2[i] : 0.0; } }
+            }
+        }
+        LDS_SYNC();
+    }
+    return 1;
+}
+OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
+    WAVE0_BEGIN
+        const int ok = q_riccati_body(sh, rho);
+        PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
+    WAVE0_END
+    SYNC();
+    return sh.ric_ok;
+}
+
+// ---------------------------------------------------------------- border, forward sweep, stage-parallel back-substitution
+OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
+    so.ok = 1;
+    // ---- 13x13 border in (dt, nu) from the bilinear constants: eliminate nu (S = -B(nu,nu) must be PD) then t.  Wavefront 0.
+    WAVE0_BEGIN
+        double *S = sh.bord, *col = sh.bord + 169, *colr = col + 13;   // S 12x12 (stride 12)
+        PAR64(lane) {
+            for (int it = lane; it < 144; it += 64) { int a = it / 12, b_ = it % 12; S[it] = -sh.Bm[(2 + a) * QC + (2 + b_)]; }
+            if (lane < 12) { col[lane] = -sh.Bm[(2 + lane) * QC + 1]; colr[lane] = -((-(z[l.x + QX * N + lane] - c.xF[lane])) - sh.Bm[(2 + lane) * QC + 0]); }
+            if (lane == 0) sh.bord_ok = 1;
+        }
+        LDS_SYNC();
+        for (int j = 0; j < 12; j++) {   // cooperative LDL^T (L in the strict lower triangle, D on the diagonal)
+            PAR64(lane) {
+                if (lane == 0) { double dj = S[j * 12 + j]; for (int kk = 0; kk < j; kk++) dj -= S[j * 12 + kk] * S[j * 12 + kk] * S[kk * 12 + kk]; if (!(dj > 0)) sh.bord_ok = 0; S[j * 12 + j] = dj; }
+            }
+            LDS_SYNC();
+            PAR64(lane) {
+                if (lane > j && lane < 12) { double s_ = S[lane * 12 + j]; for (int kk = 0; kk < j; kk++) s_ -= S[lane * 12 + kk] * S[j * 12 + kk] * S[kk * 12 + kk]; S[lane * 12 + j] = s_ / S[j * 12 + j]; }
+            }
+            LDS_SYNC();
+        }
+        PAR64(lane) {
+            if (lane < 2) {   // two right-hand sides
+                double *b_ = lane ? colr : col;
+                for (int i = 0; i < 12; i++) for (int kk = 0; kk < i; kk++) b_[i] -= S[i * 12 + kk] * b_[kk];
+                for (int i = 0; i < 12; i++) b_[i] /= S[i * 12 + i];
+                for (int i = 11; i >= 0; i--) for (int kk = i + 1; kk < 12; kk++) b_[i] -= S[kk * 12 + i] * b_[kk];
+            }
+        }
+        LDS_SYNC();
+        PAR64(lane) {
+            if (lane == 0) {
+                double piv = A.Htt + sh.Bm[1 * QC + 1], rr = -A.gtb - sh.Bm[1 * QC + 0];
+                for (int a = 0; a < 12; a++) { piv -= sh.Bm[1 * QC + 2 + a] * col[a]; rr -= sh.Bm[1 * QC + 2 + a] * colr[a]; }
+                if (!(piv > 0)) sh.bord_ok = 0;
+                const double dt = rr / piv;
+                sh.coef[0] = 1.0; sh.coef[1] = dt;
+                for (int a = 0; a < 12; a++) sh.coef[2 + a] = colr[a] - col[a] * dt;
+            }
+        }
+    WAVE0_END
+    SYNC();
+    if (!sh.bord_ok) { so.ok = 0; return; }
+    const double dt = sh.coef[1];
+    // ---- closed-loop maps per stage: Acl = [A + B K ; K], bcl = [B kf + d + dt Ft ; kf]
+    PAR(lane) {
+        for (int k = lane; k < N; k += OB_NT) {
+            const gdbl *rec = sh.inst.as + (size_t)k * QSR; gdbl *ro = sh.inst.rs + (size_t)k * QRR;
+            double kf[QU];
+#pragma unroll
+            for (int i = 0; i < QU; i++) { double s_ = 0; for (int cc = 0; cc < QC; cc++) s_ += ro[QRR_KF + i * QC + cc] * sh.coef[cc]; kf[i] = s_; }
+            for (int i = 0; i < QX; i++) {
+                double Bi[QU];
+#pragma unroll
+                for (int a = 0; a < QU; a++) Bi[a] = rec[QSR_F + i * QFC + 12 + a];
+                for (int j = 0; j < QS; j++) {
+                    double s_ = j < QX ? rec[QSR_F + i * QFC + j] : 0.0;
+#pragma unroll
+                    for (int a = 0; a < QU; a++) s_ += Bi[a] * ro[QRR_K + a * QS + j];
+                    ro[QRR_CL + i * QS + j] = s_;
+                }
+                double s_ = rec[QSR_F + i * QFC + 16] + dt * rec[QSR_F + i * QFC + 17];
+#pragma unroll
+                for (int a = 0; a < QU; a++) s_ += Bi[a] * kf[a];
+                ro[QRR_CL + QS * QS + i] = s_;
+            }
+            for (int a = 0; a < QU; a++) { for (int j = 0; j < QS; j++) ro[QRR_CL + (QX + a) * QS + j] = ro[QRR_K + a * QS + j]; ro[QRR_CL + QS * QS + QX + a] = kf[a]; }
+        }
+    }
+    SYNC();
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k on wavefront 0; maps staged through LDS in chunks (ring in the reduction scratch)
+#define QFW_CH 3
+#define QFW_SZ 272
+#define QFW_PER ((QFW_CH * QFW_SZ + 63) / 64)
+    WAVE0_BEGIN
+        double pf[OBCA_NL][QFW_PER];
+        double *ring = &sh.red[0][0];
+        PAR64(lane) {
+            if (lane < QS) sh.traj[lane] = 0.0;
+#pragma unroll
+            for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r, st = e / QFW_SZ, j = e % QFW_SZ; if (e < QFW_CH * QFW_SZ && st < N) ring[e] = (sh.inst.rs + (size_t)st * QRR)[QRR_CL + j]; }
+        }
+        LDS_SYNC();
+        for (int k0 = 0; k0 < N; k0 += QFW_CH) {
+            const int cb = (k0 / QFW_CH) & 1;
+            PAR64(lane) {
+#pragma unroll
+                for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r, st = k0 + QFW_CH + e / QFW_SZ, j = e % QFW_SZ;
+                    pf[LI(lane)][r] = (e < QFW_CH * QFW_SZ && st < N) ? (sh.inst.rs + (size_t)st * QRR)[QRR_CL + j] : 0.0; }
+            }
+            for (int k = k0; k < k0 + QFW_CH && k < N; k++) {
+                PAR64(lane) {
+                    if (lane < QS) {
+                        const double *cl = ring + (size_t)(cb * QFW_CH + (k - k0)) * QFW_SZ, *s_ = sh.traj + (size_t)k * QS;
+                        double v = cl[QS * QS + lane];
+#pragma unroll
+                        for (int j = 0; j < QS; j++) v += cl[lane * QS + j] * s_[j];
+                        sh.traj[(size_t)(k + 1) * QS + lane] = v;
+                    }
+                }
+                LDS_SYNC();
+            }
+            PAR64(lane) {
+#pragma unroll
+                for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r; if (e < QFW_CH * QFW_SZ) ring[(size_t)(1 - cb) * QFW_CH * QFW_SZ + e] = pf[LI(lane)][r]; }
+            }
+            LDS_SYNC();
+        }
+    WAVE0_END
+    SYNC();
+    // ---- stage-parallel: steps of x, u; costate increments; step-length / descent partials of x, u
+    PAR(lane) {
+        double ap = 1.0, az = 1.0, gd = 0, cc_;
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < ap) ap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < az) az = cc_; }
+        for (int k = lane; k <= N; k += OB_NT) {
+            const double *s = sh.traj + (size_t)k * QS;
+            for (int i = 0; i < QX; i++) {
+                const double xv = z[l.x + QX * k + i], dx = s[i];
+                d[l.x + QX * k + i] = dx;
+                if (i >= 9) gd += 2e-4 * xv * dx;
+                if (k >= 1) {
+                    const double dL = xv - q_xlb(i), dU = q_xub(i) - xv, zL = z[l.zL + l.x + QX * k + i], zU = z[l.zU + l.x + QX * k + i];
+                    gd += (-mu / dL + mu / dU) * dx;
+                    FTBP(dL, dx); FTBP(dU, -dx);
+                    FTBZ(zL, mu / dL - zL - zL / dL * dx); FTBZ(zU, mu / dU - zU + zU / dU * dx);
+                }
+            }
+            if (k < N) {
+                const gdbl *ro = sh.inst.rs + (size_t)k * QRR;
+                for (int j = 0; j < QU; j++) {
+                    double du = ro[QRR_CL + QS * QS + QX + j];
+                    for (int i = 0; i < QS; i++) du += ro[QRR_CL + (QX + j) * QS + i] * s[i];
+                    d[l.u + QU * k + j] = du;
+                    const double uv = z[l.u + QU * k + j];
+                    double gu = -2e-3 * (c.wH - uv);
+                    if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - uv; gu -= 2e-2 * e; gd += 2e-2 * e * s[QX + j]; }
+                    const double dL = uv - Q_ULO, dU = Q_UHI - uv, zL = z[l.zL + l.u + QU * k + j], zU = z[l.zU + l.u + QU * k + j];
+                    gd += (gu - mu / dL + mu / dU) * du;
+                    FTBP(dL, du); FTBP(dU, -du);
+                    FTBZ(zL, mu / dL - zL - zL / dL * du); FTBZ(zU, mu / dU - zU + zU / dU * du);
+                }
+                const double *sn = sh.traj + (size_t)(k + 1) * QS;
+                if (k + 1 < N) {
+                    const gdbl *r1 = sh.inst.rs + (size_t)(k + 1) * QRR;
+                    for (int i = 0; i < QX; i++) {
+                        double a_ = 0;
+                        for (int cc = 0; cc < QC; cc++) a_ += r1[QRR_PV + i * QC + cc] * sh.coef[cc];
+                        for (int j = 0; j < QS; j++) a_ += r1[QRR_PX + i * QS + j] * sn[j];
+                        d[l.pi + QX * k + i] = -a_;
+                    }
+                } else {
+                    const gdbl *rN = sh.inst.as + (size_t)N * QSR;
+                    for (int i = 0; i < QX; i++) {
+                        const double e = -(z[l.x + QX * N + i] - c.xF[i]);
+                        double a_ = (rN[QSR_HC + 2 * i] - rho * e) + sh.coef[2 + i];
+                        for (int j = 0; j < QX; j++) a_ += (rN[QSR_H + i * QZ + j] + (i == j ? rho : 0.0)) * sn[j];
+                        d[l.pi + QX * k + i] = -a_;
+                    }
+                }
+            }
+        }
+        sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;
+        if (lane < QX) d[l.nu + lane] = sh.coef[2 + lane];
+        if (lane == QX) d[l.t] = dt;
+#undef FTBP
+#undef FTBZ
+    }
+    SYNC();
+    so.ap = red_min(sh.red[0]); so.az = red_min(sh.red[1]); so.gd = red_sum(sh.red[2]);
+    SYNC();
+}
+
+OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
+    double ap = so.ap, az = so.az, gd = so.gd;
+    const double dt = sh.coef[1];
+    PAR(lane) {
+        double lap = 1.0, laz = 1.0, lgd = 0, cc_;
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < lap) lap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < laz) laz = cc_; }
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in);
+            const double dp[3] = {d[l.x + QX * k], d[l.x + QX * k + 1], d[l.x + QX * k + 2]};
+            QObsStep st;
+            q_obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
+#pragma unroll
+            for (int i = 0; i < QL; i++) {
+                d[l.lam + QL * it + i] = st.dlam[i];
+                lgd += (2e-4 * in.lam[i] - mu / in.lam[i]) * st.dlam[i];
+                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
+            }
+            d[l.s + it] = st.ds; d[l.so + it] = st.dso; d[l.yo + 2 * it] = st.dy[0]; d[l.yo + 2 * it + 1] = st.dy[1];
+            lgd += (1e2 + 2e3 * in.s - mu / in.s) * st.ds - mu / in.so * st.dso;
+            FTBP(in.s, st.ds); FTBZ(in.zs, mu / in.s - in.zs - in.zs / in.s * st.ds);
+            FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
+        }
+        sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
+#undef FTBP
+#undef FTBZ
+    }
+    SYNC();
+    ap = fmin(ap, red_min(sh.red[0])); az = fmin(az, red_min(sh.red[1])); gd += red_sum(sh.red[2]);
+    SYNC();
+    {
+        const double t = z[l.t], dL = t - Q_TLO, dU = Q_THI - t, zL = z[l.zL + l.t], zU = z[l.zU + l.t];
+        double cc_;
+        cc_ = dt < 0 ? -tau * dL / dt : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = -dt < 0 ? -tau * dU / (-dt) : 1e300; if (cc_ < ap) ap = cc_;
+        const double dzL = mu / dL - zL - zL / dL * dt, dzU = mu / dU - zU + zU / dU * dt;
+        cc_ = dzL < 0 ? -tau * zL / dzL : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzU < 0 ? -tau * zU / dzU : 1e300; if (cc_ < az) az = cc_;
+        gd += ((N + 1) * (0.25 + 10 * t) + (N + 1) * (-mu / dL + mu / dU)) * dt;
+    }
+    so.ap = ap; so.az = az; so.gd = gd;
+}
+
+// ---------------------------------------------------------------- objective / constraint 1-norm / barrier at v + alpha dv
+OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, double &bar) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z, *d = sh.inst.d;
+    const double t = z[l.t] + alpha * d[l.t], tau = t * c.Ts;
+    PAR(lane) {
+        double lf = 0, lth = 0, lbar = 0;
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in);
+#pragma unroll
+            for (int i = 0; i < QL; i++) { in.lam[i] += alpha * d[l.lam + QL * it + i]; lbar += log(in.lam[i]); lf += 1e-4 * in.lam[i] * in.lam[i]; }
+            in.s += alpha * d[l.s + it]; in.so += alpha * d[l.so + it]; lbar += log(in.s) + log(in.so);
+#pragma unroll
+            for (int i = 0; i < 3; i++) in.p[i] += alpha * d[l.x + QX * k + i];
+            double r[2], q[3]; q_obs_rows(c, in, r, q);
+            lth += fabs(r[0]) + fabs(r[1]);
+            lf += 1e2 * in.s + 1e3 * in.s * in.s;
+        }
+        for (int k = lane; k <= N; k += OB_NT) {
+            double x[QX];
+#pragma unroll
+            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i] + alpha * d[l.x + QX * k + i]; if (k >= 1) lbar += log(x[i] - q_xlb(i)) + log(q_xub(i) - x[i]); }
+            lf += 1e-4 * (x[9] * x[9] + x[10] * x[10] + x[11] * x[11]);
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < QX; i++) lth += fabs(x[i] - c.xF[i]);
+            } else {
+                double u[QU], g[QX];
+#pragma unroll
+                for (int j = 0; j < QU; j++) {
+                    u[j] = z[l.u + QU * k + j] + alpha * d[l.u + QU * k + j];
+                    lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]); lbar += log(u[j] - Q_ULO) + log(Q_UHI - u[j]);
+                    if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] + alpha * d[l.u + QU * (k - 1) + j] - u[j]; lf += 1e-2 * e * e; }
+                }
+                dyn_g_value(c, x, u, g);
+#pragma unroll
+                for (int i = 0; i < QX; i++) lth += fabs(z[l.x + QX * (k + 1) + i] + alpha * d[l.x + QX * (k + 1) + i] - x[i] - tau * g[i]);
+            }
+        }
+        sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
+    }
+    SYNC();
+    f = red_sum(sh.red[0]); th1 = red_sum(sh.red[1]); bar = red_sum(sh.red[2]);
+    SYNC();
+    f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+}
+
+// ---------------------------------------------------------------- accept the step (generic over the primal vector)
+OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, double mu, double ks) {
+    const QLay &l = sh.l; const int N = sh.c.N; gdbl *z = sh.inst.z; const gdbl *d = sh.inst.d;
+    PAR(lane) {
+        for (int i = lane; i < l.n; i += OB_NT) {
+            const QBnd b = q_bounds(l, N, i);
+            double v = z[i]; const double dv = d[i];
+            if (i < QX) continue;                        // x_0 is a constant
+            if (b.hasL) { double zz = zstep(z[l.zL + i], v - b.lo, dv, mu, az); z[l.zL + i] = clampz(zz, v + alpha * dv - b.lo, mu, ks); }
+            if (b.hasU) { double zz = zstep(z[l.zU + i], b.hi - v, -dv, mu, az); z[l.zU + i] = clampz(zz, b.hi - (v + alpha * dv), mu, ks); }
+            z[i] = v + alpha * dv;
+        }
+        for (int i = lane; i < l.m; i += OB_NT) z[l.n + i] += ay * d[l.n + i];
+    }
+    SYNC();
+}
+
+// ---------------------------------------------------------------- starting point
+OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, double timeWS, int dual_ws) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; gdbl *z = sh.inst.z;
+    PAR(lane) {
+        for (int i = lane; i < QX * (N + 1); i += OB_NT) z[l.x + i] = i < QX ? c.x0[i] : sh.inst.prob[QPH_SIZE + i];   // xWS, :201
+        for (int i = lane; i < QU * N; i += OB_NT) z[l.u + i] = c.wH;                       // QuadcopterSignedDist.jl:202
+        if (lane == 0) z[l.t] = timeWS;                                                   // :199
+        for (int i = lane; i < QOB * (N + 1); i += OB_NT) z[l.s + i] = 1.0;                // :210
+        for (int i = lane; i < l.m; i += OB_NT) z[l.n + i] = 0.0;
+        for (int i = lane; i < l.n; i += OB_NT) { z[l.zL + i] = 1.0; z[l.zU + i] = 1.0; }
+        // stage / Riccati records: zero once, constants of the dense layout
+        for (int i = lane; i < (N + 1) * QSR; i += OB_NT) sh.inst.as[i] = 0.0;
+    }
+    SYNC();
+    PAR(lane) {
+        for (int k = lane; k <= N; k += OB_NT) {
+            gdbl *rec = sh.inst.as + (size_t)k * QSR;
+            for (int i = 0; i < 3; i++) { rec[QSR_F + i * QFC + i] = 1.0; rec[QSR_F + (6 + i) * QFC + (6 + i)] = 1.0; }   // the other diagonal entries are rewritten every pass
+        }
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            double lam[QL], p[3] = {z[l.x + QX * k], z[l.x + QX * k + 1], z[l.x + QX * k + 2]};
+            if (dual_ws) q_dual_ws(&sh.ob[j * QL], p, lam);
+            else { for (int i = 0; i < QL; i++) lam[i] = 0.05; }                           // :204-208
+            for (int i = 0; i < QL; i++) z[l.lam + QL * it + i] = lam[i];
+        }
+    }
+    SYNC();
+    PAR(lane) {   // row slack = row value at the start, then everything is pushed inside its bounds
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in); in.so = 0;
+            double r[2], q[3]; q_obs_rows(c, in, r, q);
+            z[l.so + it] = r[1];
+        }
+    }
+    SYNC();
+    PAR(lane) {
+        for (int i = lane; i < l.n; i += OB_NT) {
+            if (i < QX) continue;
+            const QBnd b = q_bounds(l, N, i);
+            if (b.hasL && b.hasU) z[i] = push2(z[i], b.lo, b.hi, bound_push, bound_frac);
+            else if (b.hasL) z[i] = fmax(z[i], b.lo + bound_push * fmax(1.0, fabs(b.lo)));
+        }
+    }
+    SYNC();
+}
+
+// ---------------------------------------------------------------- phase entry points and driver
+OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); }
+OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { q_assemble_obs(gq_sh, mu, dw, dc); }
+OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
+OBCA_PHASE int qph_riccati(double rho) { return q_riccati_backward(gq_sh, rho); }
+OBCA_PHASE void qph_direction_main(double mu, double dw, double dc, double rho, double tau) { QShared &sh = gq_sh; q_direction_main(sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
+OBCA_PHASE void qph_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs(sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void qph_trial(double alpha) { QShared &sh = gq_sh; q_eval_trial(sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { q_apply_step(gq_sh, alpha, ay, az, mu, ks); }
+
+// info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
+OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
+    QShared &sh = gq_sh;
+    PAR(lane) {
+        if (lane == 0) {
+            QConsts &c = sh.c; const gdbl *p = sh.inst.prob;
+            c.N = N; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
+            for (int i = 0; i < QX; i++) { c.x0[i] = p[QPH_X0 + i]; c.xF[i] = p[QPH_XF + i]; }
+            for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];                          // single-index x[10..12] = stage 1
+            for (int i = 0; i < QOB * QL; i++) sh.ob[i] = p[QPH_OB + i];
+            q_make_layout(N, sh.l);
+        }
+    }
+    SYNC();
+    qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS]);
+    double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
+    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
+    const AsmOut &A = sh.A;
+    double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
+    for (;;) {
+        double dc = o.dc_bar * pow(mu, o.kappa_c);
+        qph_assemble(mu, 0.0, dc, 0);
+        if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
+        f = A.f; pinf = A.pinf; dinf = A.dinf;
+        const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
+        const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
+        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
+        if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
+        if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
+        int mu_changed = 0;
+        {
+            double cm = A.cinfmu;
+            for (;;) {
+                const double Emu = fmax(dinf / sd, fmax(pinf, cm / sc));
+                if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
+                    mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+                    tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
+                    qph_assemble(mu, 0.0, o.dc_bar * pow(mu, o.kappa_c), 1);
+                    cm = sh.A2.cinfmu;
+                } else break;
+            }
+        }
+        dc = o.dc_bar * pow(mu, o.kappa_c);
+        double dw = 0; int ok = 0;
+        for (int tr = 0; tr < 60; tr++) {
+            if (tr > 0 || mu_changed) qph_assemble(mu, dw, dc, 0);
+            int a_ = A.ok;
+            if (a_) a_ = qph_riccati(o.rho_term);
+            if (a_) { qph_direction_main(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+            if (a_) { qph_direction_obs(mu, dw, dc, tau); ok = 1; break; }
+            nreg++;
+            if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last); else dw *= (dw_last == 0 ? o.kw_inc0 : o.kw_inc);
+            if (dw > o.dw_max) break;
+        }
+        if (!ok) { status = ST_ERROR; break; }
+        if (dw > 0) dw_last = dw;
+        const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
+        double amin;
+        if (gd < 0) { amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd)); if (th <= th_min) amin = fmin(amin, o.delta * pow(th, o.s_theta) / pow(-gd, o.s_phi)); }
+        else amin = o.gamma_theta;
+        amin *= o.gamma_alpha;
+        double alpha = sh.S.ap; int acc = 0;
+        while (alpha >= amin) {
+            qph_trial(alpha);
+            const double ft = sh.trial[0], tht = sh.trial[1], pht = ft - mu * sh.trial[2];
+            if (ft == ft && tht == tht && pht == pht && tht < th_max) {
+                int okf = 1;
+                for (int i = 0; i < nf && okf; i++) if (!(tht < sh.filt[i][0] || pht < sh.filt[i][1])) okf = 0;
+                if (okf) {
+                    const int sw = gd < 0 && alpha * pow(-gd, o.s_phi) > o.delta * pow(th, o.s_theta), armijo = pht <= phi + o.eta_phi * alpha * gd;
+                    if (th <= th_min && sw) { if (armijo) { acc = 1; break; } }
+                    else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
+                        acc = 1;
+                        if (!(sw && armijo) && nf < QFILT) {
+                            PAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
+                            SYNC();
+                            nf++;
+                        }
+                        break;
+                    }
+                }
+            }
+            alpha *= 0.5;
+        }
+        if (!acc) { status = ST_ERROR; break; }
+        qph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
+        it++;
+    }
+    // exit flag: 1 = Optimal, 2 = Optimal but sum(slack) > 1e-3, 0 otherwise
+    PAR(lane) { double s_ = 0; for (int i = lane; i < QOB * (N + 1); i += OB_NT) s_ += sh.inst.z[sh.l.s + i]; sh.red[0][lane] = s_; }
+    SYNC();
+    const double ssum = red_sum(sh.red[0]);
+    SYNC();
+    int ef = status == ST_OPTIMAL ? 1 : 0;
+    if (ef == 1 && ssum > 1e-3) ef = 2;
+    PAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f; info[3] = pinf; info[4] = dinf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
+    SYNC();
+}
+
+}  // namespace quad
+}  // namespace obca

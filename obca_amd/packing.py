@@ -79,3 +79,34 @@ def unpack_solution(z, N, nOb, M):
     npp = z[L["mu"]:L["mu"] + 4 * nOb * (N + 1)].reshape(N + 1, 4 * nOb).T.copy()
     sl = z[L["sl"]:L["sl"] + nOb * (N + 1)].reshape(N + 1, nOb).T.copy()
     return xp, up, float(z[L["t"]]), lp, npp, sl
+
+
+# ---------------------------------------------------------------- quadcopter path (obca_amd/csrc/obca_quad_solver.h)
+QPH_TS, QPH_R, QPH_X0, QPH_XF, QPH_OB, QPH_TWS, QPH_DWS, QPH_SIZE = 0, 1, 2, 14, 26, 56, 57, 64
+QUAD_NMAX = 64
+
+
+def quad_layout(N):
+    """iterate buffer of one quadcopter instance: v[n] | y[m] | zL[n] | zU[n] (q_make_layout in obca_quad_solver.h)"""
+    N1 = N + 1; o = 0; L = {}
+    for k, cnt in (("x", 12 * N1), ("u", 4 * N), ("t", 1), ("lam", 30 * N1), ("s", 5 * N1), ("so", 5 * N1)):
+        L[k] = o; o += cnt
+    L["n"] = o
+    for k, cnt in (("pi", 12 * N), ("nu", 12), ("yo", 10 * N1)):
+        L[k] = o; o += cnt
+    L["m"] = o - L["n"]
+    L["zL"] = o; o += L["n"]; L["zU"] = o; o += L["n"]; L["len"] = o
+    return L
+
+
+def quad_problem_len(N):
+    return QPH_SIZE + 12 * (N + 1)
+
+
+def pack_quad_problem(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=1):
+    """problem record of one quadcopter instance: header, then xWS stage-contiguous (N+1, 12). ob: 5 x 6 [max; -min]."""
+    p = np.zeros(quad_problem_len(N))
+    p[QPH_TS] = Ts; p[QPH_R] = R; p[QPH_X0:QPH_X0 + 12] = x0; p[QPH_XF:QPH_XF + 12] = xF
+    p[QPH_OB:QPH_OB + 30] = np.asarray(ob, float).reshape(30); p[QPH_TWS] = timeWS; p[QPH_DWS] = float(int(dual_ws))
+    p[QPH_SIZE:] = np.asarray(xWS, float)[:N + 1].reshape(-1)
+    return p

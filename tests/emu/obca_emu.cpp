@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <cstdio>
 #include "../../obca_amd/csrc/obca_solver.h"
+#include "../../obca_amd/csrc/obca_quad_solver.h"
 using namespace obca;
 
 struct Scratch { double *z, *d, *as, *rs, *oc, *traj; };
@@ -83,6 +85,60 @@ int emu_dualws(int v, const double *a1, const double *a2, const double *b, const
     dualws_one(v, a1, a2, b, g, ex, ey, cs, sn, l4, m4, d);
     for (int i = 0; i < v; i++) lam[i] = l4[i];
     for (int i = 0; i < 4; i++) mu[i] = m4[i];
+    return 0;
+}
+
+// ---------------------------------------------------------------- quadcopter path (obca_quad_solver.h)
+struct QScratch { double *z, *d, *as, *rs, *oc; };
+static void q_alloc(int N, QScratch &s, quad::QLay &l) {
+    quad::q_make_layout(N, l);
+    s.z = (double *)calloc(l.len, 8); s.d = (double *)calloc(l.n + l.m, 8);
+    s.as = (double *)calloc((size_t)(N + 1) * QSR, 8); s.rs = (double *)calloc((size_t)(N + 1) * QRR, 8);
+    s.oc = (double *)calloc((size_t)(N + 1) * QOB * OB_OC, 8);
+}
+static void q_free(QScratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); free(s.oc); }
+static void q_setup(int N, const double *prob, QScratch &s) {
+    quad::QShared &sh = quad::gq_sh; quad::QConsts &c = sh.c;
+    sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
+    c.N = N; c.Ts = prob[QPH_TS]; c.R = prob[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
+    for (int i = 0; i < QX; i++) { c.x0[i] = prob[QPH_X0 + i]; c.xF[i] = prob[QPH_XF + i]; }
+    for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];
+    for (int i = 0; i < QOB * QL; i++) sh.ob[i] = prob[QPH_OB + i];
+    quad::q_make_layout(N, sh.l);
+}
+int emu_quad_layout(int N, int *out) { quad::QLay l; quad::q_make_layout(N, l); memcpy(out, &l, sizeof l); return (int)(sizeof l / sizeof(int)); }
+
+// one Newton direction at a full primal-dual point: zin in the device layout v | y | zL | zU, dout = dv | dy
+int emu_quad_newton(int N, const double *prob, const double *zin, double mu, double dw, double dc, double rho, double tau, double *dout, double *aux /* 11 */) {
+    QScratch s; quad::QLay l; q_alloc(N, s, l);
+    memcpy(s.z, zin, sizeof(double) * l.len);
+    q_setup(N, prob, s); quad::QShared &sh = quad::gq_sh;
+    // constants of the dense stage record (the solver writes them in its init phase)
+    for (int k = 0; k <= N; k++) for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSR + QSR_F + i * QFC + i] = 1.0; s.as[(size_t)k * QSR + QSR_F + (6 + i) * QFC + 6 + i] = 1.0; }
+    quad::q_assemble_obs(sh, mu, dw, dc);
+    AsmOut A; quad::q_assemble_stage(sh, mu, dw, dc, A);
+    int ok = A.ok;
+    StepOut S; S.ap = S.az = S.gd = 0; S.ok = 1;
+    int fail = ok ? 0 : 1;
+    if (ok) { ok = quad::q_riccati_backward(sh, rho); if (!ok) fail = 2; }
+    if (ok) { quad::q_direction_main(sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; if (!ok) fail = 3; }
+    if (ok) quad::q_direction_obs(sh, mu, dw, dc, tau, S);
+    aux[10] = fail;
+    memcpy(dout, s.d, sizeof(double) * (l.n + l.m));
+    aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = A.cinfmu; aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
+    aux[7] = S.ap; aux[8] = S.az; aux[9] = S.gd;
+    q_free(s);
+    return ok;
+}
+
+// full solve from the problem record (header + xWS); zout in the device layout
+int emu_quad_solve(int N, const double *prob, const void *opts, double *zout, double *info) {
+    QScratch s; quad::QLay l; q_alloc(N, s, l);
+    quad::QShared &sh = quad::gq_sh;
+    sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
+    quad::q_solve_instance(N, *(const Opts *)opts, info);
+    memcpy(zout, s.z, sizeof(double) * l.len);
+    q_free(s);
     return 0;
 }
 }

@@ -1,0 +1,68 @@
+"""Quadcopter path: the HIP solver source (obca_quad_solver.h) compiled as a host emulation, against the quadcopter oracle."""
+import ctypes as C
+import numpy as np
+import pytest
+from obca_amd import packing as P
+from test_emu_cpu import EOpts, dp
+
+
+@pytest.fixture(scope="module")
+def Q():
+    import oracle_quad
+    oracle_quad.lib()
+    return oracle_quad
+
+
+VIA = [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)]
+
+
+def test_quad_layouts_agree(Q, emu):
+    for N in (3, 16, 60):
+        a = Q.layout(N); b = P.quad_layout(N)
+        out = np.zeros(16, np.int32); cnt = emu.emu_quad_layout(C.c_int(N), out.ctypes.data_as(C.POINTER(C.c_int)))
+        assert cnt == 14 and out[:14].tolist() == [b[k] for k in "x u t lam s so n pi nu yo m zL zU len".split()]
+        assert all(a[k] == b[k] for k in "x u t lam s so n m".split())
+        assert all(a[k] + b["n"] == b[k] for k in ("pi", "nu", "yo"))      # the oracle numbers the multipliers from 0
+
+
+def test_emu_quad_newton_direction_matches_oracle(Q, emu):
+    rng = np.random.default_rng(2)
+    N, Ts, R, ob = 7, 0.3, 0.25, Q.OB_CLAMPED
+    x0 = Q.X0.copy(); x0[9:12] = [0.1, -0.2, 0.15]       # non-zero stage-1 rates exercise the single-index quirk
+    L = Q.layout(N); n, m = L["n"], L["m"]
+    xWS = Q.warm_start(x0, Q.XF, N)
+    v = np.zeros(n)
+    X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 12)); X[1:, 3:6] = 0.1 * rng.standard_normal((N, 3)); X[0] = x0
+    v[L["x"]:L["x"] + 12 * (N + 1)] = X.reshape(-1)
+    v[L["u"]:L["u"] + 4 * N] = rng.uniform(3, 6, 4 * N); v[L["t"]] = 1.1
+    for k, cnt in (("lam", 30), ("s", 5), ("so", 5)):
+        v[L[k]:L[k] + cnt * (N + 1)] = rng.uniform(0.1, 1, cnt * (N + 1))
+    y = rng.standard_normal(m); zL = rng.uniform(0.1, 2, n); zU = rng.uniform(0.1, 2, n)
+    mu, dw, dc = 0.1, 500.0, 1e-6
+    ok, dv, dy, errs = Q.newton(N, Ts, R, x0, Q.XF, ob, v, y, zL, zU, mu, dw, dc)
+    z = np.concatenate([v, y, zL, zU]); assert len(z) == P.quad_layout(N)["len"]
+    prob = P.pack_quad_problem(x0, Q.XF, N, Ts, R, ob, xWS, 1.0)
+    d = np.zeros(n + m); aux = np.zeros(11)
+    ok2 = emu.emu_quad_newton(C.c_int(N), dp(prob), dp(z), C.c_double(mu), C.c_double(dw), C.c_double(dc), C.c_double(1e3), C.c_double(0.99), dp(d), dp(aux))
+    assert ok == 1 and ok2 == 1
+    assert np.abs(d[:n] - dv).max() < 1e-10 * max(1.0, np.abs(dv).max())
+    assert np.abs(d[n:] - dy).max() < 1e-10 * max(1.0, np.abs(dy).max())
+    assert np.allclose(aux[:3], errs, rtol=1e-10)
+
+
+@pytest.mark.parametrize("N", [16, 30])
+def test_emu_quad_full_solve_matches_oracle(Q, emu, N):
+    Ts = round(0.25 * 80 / N * 100) / 100
+    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    oo = Q.default_opts(); eo = EOpts()
+    for f, _ in EOpts._fields_:
+        setattr(eo, f, getattr(oo, f))
+    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    z = np.zeros(L["len"]); info = np.zeros(8)
+    emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
+    assert r["exitflag"] == 1 and info[0] == 0 and info[7] == 1
+    assert int(info[1]) == r["iters"]
+    assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"])
+    xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T; up = z[L["u"]:L["t"]].reshape(N, 4).T
+    assert np.abs(xp - r["xp"]).max() < 1e-4 and np.abs(up - r["up"]).max() < 1e-5 and abs(z[L["t"]] - r["t"]) < 1e-9
