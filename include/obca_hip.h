@@ -77,6 +77,34 @@ int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScal
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes);
 int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-phase shader cycles, zero unless built with -DOBCA_PROFILE */);
 
+/* ---- quadcopter path:  QuadcopterSignedDist(x0,xF,N,Ts,R,ob1,ob2,ob3,ob4,ob5,xWS,uWS,timeWS)
+ *      QuadcopterNavigation/QuadcopterSignedDist.jl:25-298 (call site mainQuadcopter.jl:152).
+ * x is 12 x (N+1) stage-contiguous, u 4 x N; ob is 6 x 5 per instance: ob1..ob5 back to back, each [xmax,ymax,zmax,-xmin,-ymin,-zmin]
+ * (the `b` of A = [I;-I], :162-166); lp is 30 x (N+1): [l1;l2;l3;l4;l5] stacked as the reference returns it (:295).
+ * uWS is accepted for signature parity and ignored like the reference does (:202 starts every input at the hover speed).
+ * dual_ws != 0 starts the multipliers at the closed-form point-to-box dual solution (recommended; the reference's lambda = 0.05
+ * start has a rank-deficient Jacobian and relies on IPOPT's restoration phase, which this solver does not have -- DESIGN.md).
+ * exitflag: 1 = solved, 2 = solved but sum(slack) > 1e-3 (:285-288), 0 = failed.  max_iter default 3000, see obca_quadcopter_default_opts. */
+#define OBCA_QUAD_NMAX 64
+typedef struct obca_quad_batch obca_quad_batch;
+int obca_quadcopter_default_opts(obca_opts *o);
+int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts /* B */, double R, const double *x0 /* 12 x B */,
+                                      const double *xF /* 12 x B */, const double *ob /* 6 x 5 x B */, const double *xWS /* 12 x (N+1) x B */,
+                                      const double *uWS /* ignored, may be NULL */, const double *timeWS /* B */, int dual_ws,
+                                      const obca_opts *opts /* NULL: defaults */, double *xp, double *up, double *timeScale /* (N+1) x B */,
+                                      int *exitflag /* B */, double *lp /* 30 x (N+1) x B */, double *slack /* 5 x (N+1) x B, may be NULL */,
+                                      double *info /* 8 x B, may be NULL */);
+int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out);
+int obca_quad_batch_destroy(obca_quad_batch *bt);
+int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
+                           const double *xWS, const double *timeWS, int dual_ws);
+int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts);   /* asynchronous on the context's stream */
+int obca_quad_batch_sync(obca_quad_batch *bt);
+int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms);
+int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *slack,
+                             double *info);
+int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,10 @@ ctypes binding of libobca_hip.so and the Python mirror of the reference's entry 
     DualMultWS(N,nOb,vOb,A,b,rx,ry,ryaw, ego) -> lp (N+1,M), np (N+1,4nOb)
         /root/reference/AutonomousParking/DualMultWS.jl:29,81-84 (the reference reads `ego` from global scope, :39-45)
 
+    QuadcopterSignedDist(x0,xF,N,Ts,R,ob1,ob2,ob3,ob4,ob5,xWS,uWS,timeWS)
+        -> xp (12,N+1), up (4,N), timeScale, exitflag, time, lp (30,N+1), status string
+        /root/reference/QuadcopterNavigation/QuadcopterSignedDist.jl:25,298
+
 plus batched variants (leading batch dimension) that keep everything resident on the GPU between upload and download.
 """
 import ctypes as C
@@ -41,7 +45,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_solver.h", "obca_model.h")] + \
+    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
            [os.path.join(_HERE, "..", "include", "obca_hip.h")]
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(s) for s in srcs):
         return _LIBPATH
@@ -68,7 +72,10 @@ def _load():
 EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
-           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles"]
+           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
+           "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
+           "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
+           "obca_quad_batch_download", "obca_quad_batch_scratch_bytes"]
 
 
 def default_opts():
@@ -288,3 +295,97 @@ def DualMultWS(N, nOb, vOb, A, b, rx, ry, ryaw, ego, device=0):
     ls, ns, _ = dualmult_ws_batch(N, vOb, A, b, np.ravel(rx)[None, :N + 1], np.ravel(ry)[None, :N + 1],
                                   np.ravel(ryaw)[None, :N + 1], ego, device)
     return ls[0], ns[0]
+
+
+# ---------------------------------------------------------------- quadcopter path (QuadcopterSignedDist.jl)
+def quadcopter_default_opts():
+    o = Opts()
+    _load().obca_quadcopter_default_opts(C.byref(o))
+    return o
+
+
+class QuadBatch:
+    """Device-resident batch of quadcopter signed-distance NLPs (obca_quad_batch_* in include/obca_hip.h)."""
+
+    def __init__(self, ctx, B, N):
+        self.ctx, self.B, self.N = ctx, int(B), int(N)
+        self._h = C.c_void_p()
+        ctx._check(_load().obca_quad_batch_create(ctx._h, C.c_int(self.B), C.c_int(self.N), C.byref(self._h)), "obca_quad_batch_create")
+
+    def upload(self, x0, xF, Ts, R, ob, xWS, timeWS, dual_ws=True):
+        B, N = self.B, self.N
+        Tsv = np.broadcast_to(np.asarray(Ts, float), (B,)).copy(); tw = np.broadcast_to(np.asarray(timeWS, float), (B,)).copy()
+        obv = np.broadcast_to(np.asarray(ob, float).reshape(-1, 30) if np.size(ob) != 30 else np.asarray(ob, float).reshape(1, 30), (B, 30)).copy()
+        xw = np.ascontiguousarray(np.asarray(xWS, float)[:, :N + 1]); assert xw.shape == (B, N + 1, 12)
+        keep = [_d(Tsv), _d(np.reshape(x0, (B, 12))), _d(np.reshape(xF, (B, 12))), _d(obv), _d(xw), _d(tw)]
+        p = [k[1] for k in keep]
+        rc = _load().obca_quad_batch_upload(self._h, p[0], C.c_double(R), p[1], p[2], p[3], p[4], p[5], C.c_int(int(bool(dual_ws))))
+        self.ctx._check(rc, "obca_quad_batch_upload")
+
+    def solve(self, opts=None, sync=True):
+        self.ctx._check(_load().obca_quad_batch_solve(self._h, C.byref(opts) if opts is not None else None), "obca_quad_batch_solve")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self.ctx._check(_load().obca_quad_batch_sync(self._h), "obca_quad_batch_sync")
+
+    def kernel_ms(self):
+        a = C.c_float(0)
+        self.ctx._check(_load().obca_quad_batch_kernel_ms(self._h, C.byref(a)), "obca_quad_batch_kernel_ms")
+        return a.value
+
+    def scratch_bytes(self):
+        v = C.c_longlong(0)
+        _load().obca_quad_batch_scratch_bytes(self._h, C.byref(v))
+        return v.value
+
+    def download(self):
+        B, N = self.B, self.N
+        xp = np.zeros((B, N + 1, 12)); up = np.zeros((B, N, 4)); ts = np.zeros((B, N + 1)); ef = np.zeros(B, np.int32)
+        lp = np.zeros((B, N + 1, 30)); sl = np.zeros((B, N + 1, 5)); info = np.zeros((B, 8))
+        rc = _load().obca_quad_batch_download(self._h, xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D), ef.ctypes.data_as(_I),
+                                              lp.ctypes.data_as(_D), sl.ctypes.data_as(_D), info.ctypes.data_as(_D))
+        self.ctx._check(rc, "obca_quad_batch_download")
+        T = lambda a: np.transpose(a, (0, 2, 1)).copy()
+        return dict(xp=T(xp), up=T(up), timeScale=ts, exitflag=ef, lp=T(lp), slack=T(sl), info=info, iters=info[:, 1].astype(int),
+                    obj=info[:, 2], status=info[:, 0].astype(int))
+
+    def close(self):
+        if self._h:
+            _load().obca_quad_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, opts=None, device=0):
+    """Batched QuadcopterSignedDist: x0,xF (B,12); ob (5,6) shared or (B,5,6); xWS (B,N+1,12); Ts, timeWS scalar or (B,)."""
+    B = np.reshape(x0, (-1, 12)).shape[0]
+    bt = QuadBatch(_ctx(device), B, N)
+    try:
+        bt.upload(x0, xF, Ts, R, ob, xWS, timeWS, dual_ws)
+        t0 = time.perf_counter()
+        bt.solve(opts)
+        dt = time.perf_counter() - t0
+        out = bt.download()
+        out["time"] = dt
+        return out
+    finally:
+        bt.close()
+
+
+_QUAD_STATUS = {0: "Optimal", 1: "UserLimit", 2: "Error"}
+
+
+def QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS, opts=None, device=0, dual_ws=True):
+    """Drop-in for QuadcopterSignedDist.jl:25 (one instance; xWS is (N+1,12) here, the reference's is 12 x (N+1) column-major,
+    i.e. the same memory).  Returns (xp, up, timeScalep, exitflag, time, lp, status) like :298; uWS is ignored like :202."""
+    ob = np.stack([np.ravel(o)[:6] for o in (ob1, ob2, ob3, ob4, ob5)])
+    r = quadcopter_signed_dist_batch(np.reshape(x0, (1, 12)), np.reshape(xF, (1, 12)), N, Ts, R, ob, np.asarray(xWS, float)[None, :N + 1],
+                                     timeWS, dual_ws, opts, device)
+    return r["xp"][0], r["up"][0], r["timeScale"][0], int(r["exitflag"][0]), r["time"], r["lp"][0], _QUAD_STATUS[int(r["status"][0])]

@@ -15,11 +15,13 @@
 #include <vector>
 #include <string>
 #include "obca_solver.h"
+#include "obca_quad_solver.h"
 #include "../../include/obca_hip.h"
 
 using namespace obca;
 
 static_assert(sizeof(obca_opts) == sizeof(Opts), "obca_opts must mirror obca::Opts");
+static_assert(OBCA_QUAD_NMAX == QNMAX, "ABI limits must match the kernels");
 static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
@@ -78,6 +80,25 @@ __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObM
 #pragma unroll
     for (int i = 0; i < 4; i++) z[l.mu + 4 * (k * nOb + j) + i] = mu[i];
     if (b.dws) b.dws[(size_t)inst * per + rem] = dv;
+}
+
+// quadcopter path: one 128-thread workgroup per instance, persistent over the interior-point solve (obca_quad_solver.h)
+struct QDevBufs {
+    double *prob, *z, *d, *as, *rs, *oc, *info;
+    size_t s_prob, s_z, s_d, s_as, s_rs, s_oc;
+};
+__global__ __launch_bounds__(OB_NT, OB_NT / 64) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
+    const int inst = blockIdx.x;
+    if (inst >= B) return;
+    if (threadIdx.x == 0) {
+        quad::QInst &I = quad::gq_sh.inst;
+        I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
+        I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_d);
+        I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
+        I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc);
+    }
+    __syncthreads();
+    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -337,6 +358,121 @@ int obca_dualmult_ws_batch(obca_ctx *ctx, int B, int N, const double ego[4], con
         }
     }
     obca_batch_destroy(bt);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- quadcopter path */
+struct obca_quad_batch {
+    obca_ctx *ctx; int B, N, uploaded;
+    QDevBufs d; hipEvent_t e0, e1; long long bytes;
+};
+static void qfree_dev(obca_quad_batch *bt) {
+    double **ps[] = {&bt->d.prob, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info};
+    for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+}
+int obca_quadcopter_default_opts(obca_opts *o) {
+    if (obca_default_opts(o)) return -1;
+    o->max_iter = 3000; o->dw_min = 1e-10;            /* QuadcopterSignedDist.jl:28-31: no max_iter (IPOPT default), min_hessian_perturbation 1e-10 */
+    return 0;
+}
+int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
+    if (!ctx || !out) return -1;
+    if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { ctx->err = "obca_quad_batch_create: need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
+    obca_quad_batch *bt = new obca_quad_batch();
+    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0; memset(&bt->d, 0, sizeof bt->d);
+    hipSetDevice(ctx->device);
+    quad::QLay l; quad::q_make_layout(N, l);
+    QDevBufs &d = bt->d; const size_t N1 = N + 1;
+    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSR; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
+    size_t tot = 0;
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { ctx->err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
+    ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
+    ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8);
+#undef ALLOC
+    bt->bytes = (long long)tot;
+    if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess) { ctx->err = "hipEventCreate failed"; qfree_dev(bt); delete bt; return -2; }
+    *out = bt;
+    return 0;
+}
+int obca_quad_batch_destroy(obca_quad_batch *bt) {
+    if (!bt) return -1;
+    hipSetDevice(bt->ctx->device); qfree_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); delete bt; return 0;
+}
+int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
+int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
+                           const double *xWS, const double *timeWS, int dual_ws) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    if (!Ts || !x0 || !xF || !ob || !xWS || !timeWS) { ctx->err = "obca_quad_batch_upload: NULL argument"; return -1; }
+    const int B = bt->B, N1 = bt->N + 1; const QDevBufs &d = bt->d;
+    std::vector<double> hp((size_t)B * d.s_prob, 0.0);
+    for (int i = 0; i < B; i++) {
+        double *p = hp.data() + (size_t)i * d.s_prob;
+        p[QPH_TS] = Ts[i]; p[QPH_R] = R; p[QPH_TWS] = timeWS[i]; p[QPH_DWS] = dual_ws ? 1.0 : 0.0;
+        memcpy(p + QPH_X0, x0 + (size_t)QX * i, sizeof(double) * QX); memcpy(p + QPH_XF, xF + (size_t)QX * i, sizeof(double) * QX);
+        memcpy(p + QPH_OB, ob + (size_t)QOB * QL * i, sizeof(double) * QOB * QL);
+        memcpy(p + QPH_SIZE, xWS + (size_t)QX * N1 * i, sizeof(double) * QX * N1);
+    }
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(d.prob, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    bt->uploaded = 1;
+    return 0;
+}
+int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    if (!bt->uploaded) { ctx->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
+    obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
+    Opts ko; memcpy(&ko, &o, sizeof ko);
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
+    return 0;
+}
+int obca_quad_batch_sync(obca_quad_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }
+int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms) {
+    if (!bt || !ipm_ms) return -1;
+    HIPCHK(bt->ctx, hipEventElapsedTime(ipm_ms, bt->e0, bt->e1));
+    return 0;
+}
+int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double *ts, int *exitflag, double *lp, double *slp, double *info) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx; const int B = bt->B, N = bt->N, N1 = N + 1; const QDevBufs &d = bt->d;
+    quad::QLay l; quad::q_make_layout(N, l);
+    hipSetDevice(ctx->device);
+    std::vector<double> hz((size_t)B * d.s_z), hi((size_t)B * 8);
+    HIPCHK(ctx, hipMemcpyAsync(hz.data(), d.z, hz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hi.data(), d.info, hi.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < B; i++) {
+        const double *z = hz.data() + (size_t)i * d.s_z;
+        if (xp) memcpy(xp + (size_t)i * QX * N1, z + l.x, sizeof(double) * QX * N1);
+        if (up) memcpy(up + (size_t)i * QU * N, z + l.u, sizeof(double) * QU * N);
+        if (ts) for (int k = 0; k < N1; k++) ts[(size_t)i * N1 + k] = z[l.t];                       /* QuadcopterSignedDist.jl:293 */
+        if (lp) memcpy(lp + (size_t)i * QL * QOB * N1, z + l.lam, sizeof(double) * QL * QOB * N1);    /* [l1;..;l5] stacked, :295 */
+        if (slp) memcpy(slp + (size_t)i * QOB * N1, z + l.s, sizeof(double) * QOB * N1);
+        if (exitflag) exitflag[i] = (int)hi[(size_t)i * 8 + 7];
+        if (info) memcpy(info + (size_t)i * 8, hi.data() + (size_t)i * 8, sizeof(double) * 8);
+    }
+    return 0;
+}
+int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
+                                      const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
+                                      const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp,
+                                      double *slp, double *info) {
+    if (!ctx) return -1;
+    (void)uWS;                                         /* the reference ignores it too: inputs start at the hover speed, :202 */
+    obca_quad_batch *bt = nullptr;
+    int rc = obca_quad_batch_create(ctx, B, N, &bt);
+    if (rc) return rc;
+    rc = obca_quad_batch_upload(bt, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws);
+    if (!rc) rc = obca_quad_batch_solve(bt, opts);
+    if (!rc) rc = obca_quad_batch_sync(bt);
+    if (!rc) rc = obca_quad_batch_download(bt, xp, up, timeScale, exitflag, lp, slp, info);
+    obca_quad_batch_destroy(bt);
     return rc;
 }
 

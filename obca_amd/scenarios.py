@@ -193,3 +193,40 @@ def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False):
         Ts[i], xWS[i], uWS[i] = ws(x0[i], xF[i], N)
     return dict(x0=x0, xF=xF, Ts=Ts, xWS=xWS, uWS=uWS, A=A, b=b, vOb=vrows, N=N, L=L_WHEELBASE,
                 ego=EGO.copy(), XYbounds=XYBOUNDS.copy())
+
+
+# ---------------------------------------------------------------- quadcopter scenario (mainQuadcopter.jl:36-54, 131-138)
+QUAD_X0 = np.array([1, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0.0])
+QUAD_XF = np.array([9, 3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0.0])
+QUAD_R = 0.25
+# the five boxes [xmax,ymax,zmax,-xmin,-ymin,-zmin] after the in-place clamping to the room done by the plot call that precedes
+# the signed-distance solve in the reference's main: wall with a window + the room around it
+QUAD_OB = np.array([[2.5, 10, 5, -2, 0, -0.6], [7.5, 10, 5, -7, -5, 0], [7.5, 4, 5, -7, 0, 0], [7.5, 5, 2, -7, -4, 0], [7.5, 5, 5, -7, -4, -3]], float)
+QUAD_VIA = [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)]   # under the first wall, through the window of the second
+
+
+def quad_sample_time(N):
+    return round(0.25 * 80 / N * 100) / 100          # mainQuadcopter.jl:131
+
+
+def quad_warm_start(x0, xF, N, via=QUAD_VIA):
+    """positions along straight segments x0 -> via points -> xF at constant spacing, all other states 0 (the reference uses a 3-D
+    A* path, mainQuadcopter.jl:134-138; out of scope here)."""
+    pts = [np.asarray(x0, float)[:3]] + [np.asarray(p, float) for p in (via or [])] + [np.asarray(xF, float)[:3]]
+    seg = np.array([np.linalg.norm(pts[i + 1] - pts[i]) for i in range(len(pts) - 1)]); cum = np.concatenate([[0], np.cumsum(seg)])
+    xWS = np.zeros((N + 1, 12))
+    for k, s in enumerate(np.linspace(0, cum[-1], N + 1)):
+        i = min(np.searchsorted(cum, s, side="right") - 1, len(seg) - 1)
+        a = (s - cum[i]) / seg[i] if seg[i] > 0 else 0.0
+        xWS[k, :3] = pts[i] + a * (pts[i + 1] - pts[i])
+    return xWS
+
+
+def make_quad_batch(B, N=60, seed=20260925, jitter=0.3):
+    """B instances of the shipped quadcopter scenario with start and goal positions jittered uniformly by +-jitter (instance 0 exact)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(QUAD_X0, (B, 1)); xF = np.tile(QUAD_XF, (B, 1))
+    if B > 1:
+        x0[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3)); xF[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3))
+    xWS = np.stack([quad_warm_start(x0[i], xF[i], N) for i in range(B)])
+    return dict(x0=x0, xF=xF, N=N, Ts=quad_sample_time(N), R=QUAD_R, ob=QUAD_OB.copy(), xWS=xWS, timeWS=1.0)

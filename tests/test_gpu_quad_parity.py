@@ -1,0 +1,62 @@
+"""GPU parity of the quadcopter path (QuadcopterSignedDist) through the C ABI against the quadcopter oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Q():
+    import oracle_quad
+    oracle_quad.lib()
+    return oracle_quad
+
+
+def _clearance(xp, ob):
+    """Euclidean distance of every stage position to every box: (N+1, 5)"""
+    p = xp[:3].T[:, None, :]; hi = ob[None, :, :3]; lo = -ob[None, :, 3:]
+    return np.linalg.norm(p - np.clip(p, lo, hi), axis=2)
+
+
+def test_quad_shipped_scenario_matches_oracle(Q):
+    import obca_amd
+    from obca_amd import scenarios as S
+    N = 60; Ts = S.quad_sample_time(N)
+    xWS = S.quad_warm_start(S.QUAD_X0, S.QUAD_XF, N)
+    assert np.array_equal(xWS, Q.warm_start(Q.X0, Q.XF, N, S.QUAD_VIA)) and np.array_equal(S.QUAD_OB, Q.OB_CLAMPED)
+    ob = S.QUAD_OB
+    xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterSignedDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *ob, xWS, np.zeros((N, 4)), 1.0)
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, ob, xWS, 1.0)
+    assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
+    assert xp.shape == (12, N + 1) and up.shape == (4, N) and lp.shape == (30, N + 1) and ts.shape == (N + 1,)
+    assert np.abs(xp - r["xp"]).max() < 1e-5 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(ts - r["timeScale"]).max() < 1e-8
+    assert np.abs(lp - r["lp"]).max() < 1e-4
+    assert _clearance(xp, ob).min() >= S.QUAD_R - 2e-3
+
+
+def test_quad_batch_parity_and_feasibility(Q):
+    import obca_amd
+    from obca_amd import scenarios as S
+    B, N = 48, 30
+    bt = S.make_quad_batch(B, N)
+    out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
+    ok = out["exitflag"] == 1
+    assert ok.mean() >= 0.9, (ok.mean(), out["iters"])
+    n_it = 0
+    for i in range(6):
+        r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
+        assert r["exitflag"] == out["exitflag"][i]
+        if r["exitflag"] == 1:
+            assert abs(out["obj"][i] - r["obj"]) < 1e-6 * abs(r["obj"])
+            assert np.abs(out["xp"][i] - r["xp"]).max() < 1e-3 and abs(out["timeScale"][i, 0] - r["t"]) < 1e-6
+            n_it += int(out["iters"][i] == r["iters"])
+    assert n_it >= 4          # identical iteration counts except where round-off flips an inertia test
+    # size-independent properties on every converged instance: bounds, terminal state, dynamics residual, clearance >= R
+    from nlp_ref_quad import XLB, XUB
+    import oracle_quad
+    for i in np.where(ok)[0]:
+        xp, up, t = out["xp"][i], out["up"][i], out["timeScale"][i, 0]
+        assert np.abs(xp[:, 0] - bt["x0"][i]).max() == 0 and np.abs(xp[:, N] - bt["xF"][i]).max() < 1e-4
+        assert (xp >= XLB[:, None] - 1e-6).all() and (xp <= XUB[:, None] + 1e-6).all() and up.min() >= 1.2 - 1e-6 and up.max() <= 7.8 + 1e-6
+        assert _clearance(xp, bt["ob"]).min() >= bt["R"] - 2e-3
+        assert out["slack"][i].sum() <= 1e-3
