@@ -80,4 +80,20 @@ function DualMultWS(N, nOb, vOb, A, b, rx, ry, ryaw; ego=Main.ego)
     return permutedims(lw), permutedims(nw)                        # DualMultWS.jl:81-84 returns the transposes
 end
 
+
+"Drop-in for QuadcopterSignedDist.jl:25 (one instance): same arguments, same 7-tuple (xp, up, timeScalep, exitflag, time, lp, status)."
+function QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true)
+    xp = zeros(12, N + 1); up = zeros(4, N); ts = zeros(N + 1); ef = zeros(Cint, 1); lp = zeros(30, N + 1); info = zeros(8)
+    ob = f64(vcat(vec(ob1), vec(ob2), vec(ob3), vec(ob4), vec(ob5)))     # 6 x 5: [xmax,ymax,zmax,-xmin,-ymin,-zmin] per box (:162-166)
+    t0 = time()
+    rc = ccall((:obca_quadcopter_signed_dist_batch, LIB), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx().h, 1, N, [Float64(Ts)], Float64(R), f64(vec(x0)), f64(vec(xF)), ob, vec(permutedims(f64(xWS)[1:N+1, :])), C_NULL,
+               [Float64(timeWS)], dual_ws ? 1 : 0, C_NULL, xp, up, ts, ef, lp, C_NULL, info)
+    rc == 0 || error("obca_quadcopter_signed_dist_batch failed: " * lasterr(ctx()))
+    status = info[1] == 0 ? "Optimal" : (info[1] == 1 ? "UserLimit" : "Error")
+    return xp, up, ts, Int(ef[1]), time() - t0, lp, status            # QuadcopterSignedDist.jl:298
+end
+
 end # module
