@@ -28,6 +28,10 @@
 #define SYNC() ((void)0)
 #define LANE0 1
 #define LDS_SYNC() ((void)0)
+#define VM_DRAIN() ((void)0)
+#define LDS_BARRIER() ((void)0)
+#define OBCA_NLT OB_NT
+#define UNIFORM(x) (x)
 #define OBCA_NL 64          // per-lane variables that live across a SYNC are arrays over the lanes in the emulation
 #define LI(lane) (lane)
 #else
@@ -35,7 +39,7 @@
 #define OBCA_HD __host__ __device__ inline
 // Phase entry points are real (non-inlined) device functions: each gets its own register allocation, so the unrolled
 // per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
-#define OBCA_PHASE __device__ __noinline__
+#define OBCA_PHASE static __device__ __noinline__
 #define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
@@ -51,6 +55,11 @@
 #else
 #define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
+#define VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   // s_waitcnt vmcnt(0): all outstanding global loads / stores of this wave
+// workgroup barrier for phases that exchange data through LDS only: unlike __syncthreads() it does not drain the global-memory counter
+#define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#define OBCA_NLT 1
+#define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // value known to be wave-uniform: keep it in an SGPR (scalar branches, scalar loop counters)
 #define OBCA_NL 1
 #define LI(lane) 0
 #endif
@@ -105,6 +114,7 @@ namespace obca {
 #define RS_PX 24
 #define RS_PV 48
 #define RS_CL 72     // closed loop: Acl (6x6) then bcl (6)
+#define RS_PAD 115   // unused slot: target of the dummy stores of lanes without an item
 #define OB_FILT 224
 
 struct Opts {
@@ -141,7 +151,7 @@ struct Inst {              // uniform: pointers of this instance
 struct Shared {
     double hdr[OB_HDR];
     double red[16][OB_NT];
-    double stg[2][196];        // double-buffered unpacked stage data of the Riccati backward sweep (SG_* offsets)
+    double stg[2][200];        // double-buffered unpacked stage data (+ pad slot for lanes without an item) of the Riccati backward sweep (SG_* offsets)
     double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
     double filt[OB_FILT][2];
@@ -467,45 +477,125 @@ OBCA_FN void pair_of(int p, int &a_, int &b_) {   // p-th pair (a<=b) of the 6 c
 #define SG_FA 64
 #define SG_HC 148
 #define SG_SIZE 196
-struct UnpackPlan { int idx[4]; double flag[4], kc[4]; };   // value j of this lane = kc[j] + flag[j] * rec[idx[j]]
-OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
-    { int i = lane >> 3, j = lane & 7; p.idx[0] = AS_H + hidx(i, j); p.flag[0] = 1.0; p.kc[0] = 0.0; }
-    for (int r = 0; r < 2; r++) {   // FA entries lane, lane+64 (< 84)
-        int it = lane + 64 * r, idx = AS_DD; double fl = 0.0, kc = 0.0;
-        if (it < 84) {
-            int a_ = it / 14, cc = it % 14;
-            if (cc < 8) {
-                if (a_ < 4) {
-                    if (cc < 4) kc = (a_ == cc) ? 1.0 : 0.0;
-                    if (cc == 2) { idx = AS_DF + 5 * a_ + 0; fl = 1.0; }
-                    if (cc == 3) { idx = AS_DF + 5 * a_ + 1; fl = 1.0; }
-                    if (cc == 6) { idx = AS_DF + 5 * a_ + 2; fl = 1.0; }
-                    if (cc == 7) { idx = AS_DF + 5 * a_ + 3; fl = 1.0; }
-                } else kc = (cc == a_ + 2) ? 1.0 : 0.0;
-            } else if (a_ < 4) { int col = cc - 8; if (col == 0) { idx = AS_DD + a_; fl = 1.0; } if (col == 1) { idx = AS_DF + 5 * a_ + 4; fl = 1.0; } }
-        }
-        p.idx[1 + r] = idx; p.flag[1 + r] = fl; p.kc[1 + r] = kc;
+// gather plan of one lane (128 lanes, 196 staged values -> items lane and lane+128): value = kc + flag * rec[idx], stored at sg[dst]
+struct UnpackPlan { int idx[2], dst[2]; double flag[2], kc[2]; };
+OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &kc) {
+    idx = AS_DD; fl = 0.0; kc = 0.0; dst = SG_SIZE;              // default: harmless gather, store to the pad slot behind the buffer
+    if (it < 64) { idx = AS_H + hidx(it >> 3, it & 7); fl = 1.0; dst = SG_H + it; }
+    else if (it < 64 + 84) {
+        const int e = it - 64, a_ = e / 14, cc = e % 14; dst = SG_FA + e;
+        if (cc < 8) {
+            if (a_ < 4) {
+                if (cc < 4) kc = (a_ == cc) ? 1.0 : 0.0;
+                if (cc == 2) { idx = AS_DF + 5 * a_ + 0; fl = 1.0; }
+                if (cc == 3) { idx = AS_DF + 5 * a_ + 1; fl = 1.0; }
+                if (cc == 6) { idx = AS_DF + 5 * a_ + 2; fl = 1.0; }
+                if (cc == 7) { idx = AS_DF + 5 * a_ + 3; fl = 1.0; }
+            } else kc = (cc == a_ + 2) ? 1.0 : 0.0;
+        } else if (a_ < 4) { const int col = cc - 8; if (col == 0) { idx = AS_DD + a_; fl = 1.0; } if (col == 1) { idx = AS_DF + 5 * a_ + 4; fl = 1.0; } }
+    } else if (it < SG_SIZE) {
+        const int e = it - 148, i = e / OB_NC, cc = e % OB_NC; dst = SG_HC + e;
+        if (cc == 0) { idx = AS_HB + i; fl = 1.0; }
+        if (cc == 1) { idx = AS_HT + i; fl = 1.0; }
     }
-    { int idx = AS_DD; double fl = 0.0;
-      if (lane < 48) { int i = lane / OB_NC, cc = lane % OB_NC; if (cc == 0) { idx = AS_HB + i; fl = 1.0; } if (cc == 1) { idx = AS_HT + i; fl = 1.0; } }
-      p.idx[3] = idx; p.flag[3] = fl; p.kc[3] = 0.0; }
 }
-OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[4]) {   // four independent, branch-free gathers;
-#pragma unroll                                                                           // the raw values are only touched at store time
-    for (int j = 0; j < 4; j++) v[j] = rec[p.idx[j]];
+OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) stage_unpack_item(lane + OB_NT * r, p.idx[r], p.dst[r], p.flag[r], p.kc[r]);
 }
-OBCA_FN void stage_unpack_store(double *sg, int lane, const UnpackPlan &p, const double v[4]) {
-    sg[SG_H + lane] = v[0]; sg[SG_FA + lane] = p.kc[1] + p.flag[1] * v[1];
-    if (lane + 64 < 84) sg[SG_FA + lane + 64] = p.kc[2] + p.flag[2] * v[2];
-    if (lane < 48) sg[SG_HC + lane] = p.flag[3] * v[3];
+OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[2]) {   // independent, branch-free gathers;
+    v[0] = rec[p.idx[0]]; v[1] = rec[p.idx[1]];                                         // the raw values are only touched at store time
+}
+OBCA_FN void stage_unpack_store(double *sg, const UnpackPlan &p, const double v[2]) {
+    sg[p.dst[0]] = p.kc[0] + p.flag[0] * v[0]; sg[p.dst[1]] = p.kc[1] + p.flag[1] * v[1];
 }
 
-OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // runs on wavefront 0 only
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N;
+#define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
+// One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k).
+// A single wavefront is instruction-issue bound on this sweep (~400 dependent fp64 / LDS instructions per stage), so the work is cut
+// into one small item per lane and spread over both wavefronts, with LDS-only workgroup barriers in between.
+// PIPE = 1: steady state of the software pipeline -- the last phase first retires the gather of stage k-1 (issued RIC_D stages ago into
+// nv[..][slot]) into the LDS buffer and re-issues the slot for stage k-1-RIC_D.  Every global load / store is issued unconditionally
+// (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
+// memory operation the compiler's in-order vmcnt bookkeeping stays exact and old gathers retire without draining the younger ones.
+template <int PIPE>
+OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
+    const double *sg = sh.stg[k & 1];
+    double *T = sh.cl[0];                                          // 6 x 14 scratch (the closed-loop buffers are free during this sweep)
+    PAR(lane) {   // phase A: T[a][cc], lanes 0..83;  u2[m][b] = off_m . p_b, lanes 84..95
+        if (lane < 84) {
+            const int a_ = lane / 14, cc = lane % 14;
+            double acc = cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)];
+#pragma unroll
+            for (int b_ = 0; b_ < 6; b_++) acc += sh.Pn[a_ * 6 + b_] * sg[SG_FA + b_ * 14 + cc];
+            T[lane] = acc;
+        } else if (lane < 96) {
+            const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; double u2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) u2 += sg[SG_FA + i * 14 + 8 + m] * sh.pn[i * OB_NC + b_];
+            sh.sB[12 + m * 6 + b_] = u2;
+        }
+    }
+    LDS_BARRIER();
+    PAR(lane) {   // phase B: Qhat[i][cc], lanes 0..111;  u1[m][b] = off_m . T[:, 8+b], lanes 112..123
+        if (lane < 112) {
+            const int i = lane / 14, cc = lane % 14;
+            double acc = cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)];
+#pragma unroll
+            for (int a_ = 0; a_ < 6; a_++) acc += sg[SG_FA + a_ * 14 + i] * T[a_ * 14 + cc];
+            sh.Qhat[lane] = acc;
+        } else if (lane < 124) {
+            const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; double u1 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) u1 += sg[SG_FA + i * 14 + 8 + m] * T[i * 14 + 8 + b_];
+            sh.sB[m * 6 + b_] = u1;
+        }
+    }
+    LDS_BARRIER();
+    PROF(I, PF_RIC_P1);
+    // Quu = [q00 q10; q10 q11] must be positive definite; its inverse [g00 g01; g01 g11] from the two Schur pivots (no sqrt needed)
+    const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
+    const double iq00 = 1.0 / q00, m10 = q10 * iq00, sch = q11 - m10 * q10;
+    const int ok = UNIFORM((q00 > 0) && (sch > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
+    const double g11 = 1.0 / sch, g01 = -m10 * g11, g00 = iq00 - m10 * g01;
+    gdbl *ro = I.rs + (size_t)k * OB_RS;
+    PAR(lane) {   // phase C: lanes 0..35 P[i][cc], 36..71 p[i][cc], 72..92 bilinear constants
+        if (PIPE) {
+            const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
+            stage_unpack_store(sh.stg[kp & 1], plan[LI(lane)], nv[LI(lane)][slot]);
+            stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
+        }
+        const int e = lane < 72 ? lane : 0, r = e / 36, i = (e % 36) / 6, cc = e % 6, qc = r ? cc + 8 : cc;
+        const double q6 = sh.Qhat[6 * 14 + qc], q7 = sh.Qhat[7 * 14 + qc];
+        const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
+        const double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
+        if (lane < 36) sh.Pn[lane] = v; else if (lane < 72) sh.pn[lane - 36] = v;
+        const bool row = lane < 72 && i < 4, gain = lane < 72 && i == 0;      // rows 0..3 of P / p go to HBM; row 0 carries the gains
+        ro[row ? (r ? RS_PV : RS_PX) + i * 6 + cc : RS_PAD] = v;
+        ro[gain ? (r ? RS_KF : RS_K) + cc : RS_PAD] = k0;
+        ro[gain ? (r ? RS_KF + OB_NC : RS_K + 6) + cc : RS_PAD] = k1;
+        if (lane >= 72 && lane < 93) {
+            int a_, b_; pair_of(lane - 72, a_, b_);
+            const double p6 = sh.Qhat[6 * 14 + 8 + b_], p7 = sh.Qhat[7 * 14 + 8 + b_];
+            const double c0 = -(g00 * p6 + g01 * p7), c1 = -(g01 * p6 + g11 * p7);
+            double w = sh.Qhat[6 * 14 + 8 + a_] * c0 + sh.Qhat[7 * 14 + 8 + a_] * c1;
+            // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the columns 0 (main) and 1 (t) only
+            if (a_ < 2) w += sh.sB[a_ * 6 + b_];
+            if (b_ < 2) w += sh.sB[12 + b_ * 6 + a_];
+            sh.Bm[a_ * 6 + b_] += w; if (a_ != b_) sh.Bm[b_ * 6 + a_] += w;
+        }
+    }
+    LDS_BARRIER();
+    PROF(I, PF_RIC_P2);
+    return ok;
+}
+
+OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
-    double nv[OBCA_NL][4];   // software pipeline: stage data gathered from HBM one full stage before it is needed
-    UnpackPlan plan[OBCA_NL];
-    PAR64(lane) {   // terminal cost-to-go; unpack stage N-1; start the loads of stage N-2
+    double nv[OBCA_NLT][RIC_D][2];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
+    UnpackPlan plan[OBCA_NLT];
+    PAR(lane) {   // terminal cost-to-go
         stage_unpack_plan(lane, plan[LI(lane)]);
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
@@ -520,93 +610,38 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // runs on w
             sh.pn[lane * OB_NC + 1] = rec[AS_HT + lane];
             for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
         }
-        double v[4]; stage_unpack_load(I.as + (size_t)(N - 1) * OB_AS, plan[LI(lane)], v);
-        stage_unpack_store(sh.stg[(N - 1) & 1], lane, plan[LI(lane)], v);
-        if (N >= 2) stage_unpack_load(I.as + (size_t)(N - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
     }
-    LDS_SYNC();
-    for (int k = N - 1; k >= 0; k--) {
-        const double *sg = sh.stg[k & 1];
-        PAR64(lane) {   // Qhat = [H | hc] + F^T (Pn [F | off] + [0 | pn])  (8 x 14): one lane per (column, row pair)
-            if (lane < 56) {
-                const int cc = lane % 14, ip = lane / 14;        // rows ip and ip+4
-                double t[6];
+    // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
+    int k = N - 1;
+    for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
+        PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sh.stg[k & 1], plan[LI(lane)], v); }
+        LDS_BARRIER();
+        if (!riccati_stage<0>(I, sh, k, plan, nv, 0)) { PROF(I, PF_RIC_BWD); return 0; }
+    }
+    if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
+    PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
+        double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
+        stage_unpack_store(sh.stg[k & 1], plan[LI(lane)], v);
 #pragma unroll
-                for (int a_ = 0; a_ < 6; a_++) {
-                    double acc = cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)];
+        for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
+#ifndef OBCA_EMU
 #pragma unroll
-                    for (int b_ = 0; b_ < 6; b_++) acc += sh.Pn[a_ * 6 + b_] * sg[SG_FA + b_ * 14 + cc];
-                    t[a_] = acc;
-                }
+        for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j][0]), "+v"(nv[0][j][1]));
+#endif
+    }
+    LDS_BARRIER();
+    int ok = 1;
+    for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int i = ip + 4 * r;
-                    double acc = cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)];
-#pragma unroll
-                    for (int a_ = 0; a_ < 6; a_++) acc += sg[SG_FA + a_ * 14 + i] * t[a_];
-                    sh.Qhat[i * 14 + cc] = acc;
-                }
-                if (cc >= 8 && ip == 0) {   // partial sums of the bilinear update: off_m . (P off_b + p_b) and off_m . p_b, m = 0,1
-                    const int b_ = cc - 8;
-#pragma unroll
-                    for (int m = 0; m < 2; m++) {
-                        double u1 = 0, u2 = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { const double o = sg[SG_FA + i * 14 + 8 + m]; u1 += o * t[i]; u2 += o * sh.pn[i * OB_NC + b_]; }
-                        sh.sB[m * 6 + b_] = u1; sh.sB[12 + m * 6 + b_] = u2;
-                    }
-                }
-            }
-        }
-        LDS_SYNC();
-        PROF(I, PF_RIC_P1);
-        // Quu = [q00 q10; q10 q11] must be positive definite; its inverse [g00 g01; g01 g11] from the two Schur pivots (no sqrt needed)
-        const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
-        if (!(q00 > 0)) { PROF(I, PF_RIC_BWD); return 0; }
-        const double iq00 = 1.0 / q00, m10 = q10 * iq00, sch = q11 - m10 * q10;
-        if (!(sch > 0)) { PROF(I, PF_RIC_BWD); return 0; }
-        const double g11 = 1.0 / sch, g01 = -m10 * g11, g00 = iq00 - m10 * g01;
-        gdbl *ro = I.rs + (size_t)k * OB_RS;
-        PAR64(lane) {   // eliminate u_k: lanes 0..35 -> P[i][cc] and pn[i][cc]; lanes 36..56 -> bilinear constants
-            // first retire the gathers issued one stage ago (before this phase issues any store: the memory counter is in-order)
-            if (k > 0) {
-                stage_unpack_store(sh.stg[(k - 1) & 1], lane, plan[LI(lane)], nv[LI(lane)]);
-                if (k > 1) stage_unpack_load(I.as + (size_t)(k - 2) * OB_AS, plan[LI(lane)], nv[LI(lane)]);
-            }
-            if (lane < 36) {
-                const int i = lane / 6, cc = lane % 6;
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int qc = r ? cc + 8 : cc;
-                    const double q6 = sh.Qhat[6 * 14 + qc], q7 = sh.Qhat[7 * 14 + qc];
-                    const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
-                    const double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
-                    if (r == 0) { sh.Pn[i * 6 + cc] = v; if (i < 4) ro[RS_PX + i * 6 + cc] = v; if (i == 0) { ro[RS_K + cc] = k0; ro[RS_K + 6 + cc] = k1; } }
-                    else { sh.pn[i * OB_NC + cc] = v; if (i < 4) ro[RS_PV + i * OB_NC + cc] = v; if (i == 0) { ro[RS_KF + cc] = k0; ro[RS_KF + OB_NC + cc] = k1; } }
-                }
-            } else if (lane < 57) {
-                int a_, b_; pair_of(lane - 36, a_, b_);
-                const double q6 = sh.Qhat[6 * 14 + 8 + b_], q7 = sh.Qhat[7 * 14 + 8 + b_];
-                const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
-                double v = sh.Qhat[6 * 14 + 8 + a_] * k0 + sh.Qhat[7 * 14 + 8 + a_] * k1;
-                // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the columns 0 (main) and 1 (t) only
-                if (a_ < 2) v += sh.sB[a_ * 6 + b_];
-                if (b_ < 2) v += sh.sB[12 + b_ * 6 + a_];
-                sh.Bm[a_ * 6 + b_] += v; if (a_ != b_) sh.Bm[b_ * 6 + a_] += v;
-            }
-        }
-        LDS_SYNC();
-        PROF(I, PF_RIC_P2);
+        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, nv, (ju + 1) % RIC_D);
     }
     PROF(I, PF_RIC_BWD);
-    return 1;
+    return ok;
 }
 
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
-    WAVE0_BEGIN
-        const int ok = riccati_body(I, sh, rho);
-        PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
-    WAVE0_END
+    const int ok = riccati_body(I, sh, rho);
+    PAR(lane) { if (lane == 0) sh.ric_ok = ok; }
     SYNC();
     return sh.ric_ok;
 }
