@@ -104,6 +104,7 @@ int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms);
 int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *slack,
                              double *info);
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes);
+int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16; zero unless built with -DOBCA_PROFILE */);
 
 #ifdef __cplusplus
 }

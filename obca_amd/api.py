@@ -75,7 +75,7 @@ EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts"
            "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
            "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
-           "obca_quad_batch_download", "obca_quad_batch_scratch_bytes"]
+           "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
 
 
 def default_opts():
@@ -339,6 +339,11 @@ class QuadBatch:
         v = C.c_longlong(0)
         _load().obca_quad_batch_scratch_bytes(self._h, C.byref(v))
         return v.value
+
+    def phase_cycles(self):
+        out = np.zeros((self.B, 16))
+        self.ctx._check(_load().obca_quad_batch_debug_phase_cycles(self._h, out.ctypes.data_as(_D)), "obca_quad_batch_debug_phase_cycles")
+        return out
 
     def download(self):
         B, N = self.B, self.N

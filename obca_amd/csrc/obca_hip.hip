@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObM
 
 // quadcopter path: one 128-thread workgroup per instance, persistent over the interior-point solve (obca_quad_solver.h)
 struct QDevBufs {
-    double *prob, *z, *d, *as, *rs, *oc, *info;
+    double *prob, *z, *d, *as, *rs, *oc, *info, *prof;
     size_t s_prob, s_z, s_d, s_as, s_rs, s_oc;
 };
 __global__ __launch_bounds__(OB_NT, OB_NT / 64) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
@@ -96,9 +96,19 @@ __global__ __launch_bounds__(OB_NT, OB_NT / 64) void obca_quad_ipm_kernel(int B,
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_d);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
         I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc);
+#ifdef OBCA_PROFILE
+        quad::gq_sh.tlast = clock64();
+#endif
     }
+#ifdef OBCA_PROFILE
+    if (threadIdx.x < 16) quad::gq_sh.prof[threadIdx.x] = 0;
+#endif
     __syncthreads();
     quad::q_solve_instance(N, o, b.info + (size_t)inst * 8);
+#ifdef OBCA_PROFILE
+    __syncthreads();
+    if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = quad::gq_sh.prof[threadIdx.x];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -367,7 +377,7 @@ struct obca_quad_batch {
     QDevBufs d; hipEvent_t e0, e1; long long bytes;
 };
 static void qfree_dev(obca_quad_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info};
+    double **ps[] = {&bt->d.prob, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.prof};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 }
 int obca_quadcopter_default_opts(obca_opts *o) {
@@ -387,7 +397,7 @@ int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
     size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { ctx->err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
     ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
-    ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8);
+    ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8); ALLOC(d.prof, (size_t)B * 16);
 #undef ALLOC
     bt->bytes = (long long)tot;
     if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess) { ctx->err = "hipEventCreate failed"; qfree_dev(bt); delete bt; return -2; }
@@ -397,6 +407,11 @@ int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
 int obca_quad_batch_destroy(obca_quad_batch *bt) {
     if (!bt) return -1;
     hipSetDevice(bt->ctx->device); qfree_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); delete bt; return 0;
+}
+int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
+    if (!bt || !out) return -1;
+    HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
 }
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,

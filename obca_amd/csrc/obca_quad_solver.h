@@ -53,12 +53,19 @@ struct QShared {
     double traj[(QNMAX + 2) * QS];
     double filt[QFILT][2];
     int ric_ok, bord_ok;
+    double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
 #ifdef OBCA_EMU
 static QShared gq_sh;
 #else
 __shared__ QShared gq_sh;
 #endif
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
+#define QPROF(id) do { long long now_ = clock64(); if (LANE0) { gq_sh.prof[id] += (double)(now_ - gq_sh.tlast); gq_sh.tlast = now_; } } while (0)
+#else
+#define QPROF(id) ((void)0)
+#endif
+enum { QPF_INIT = 0, QPF_ASM_OBS, QPF_ASM_STAGE, QPF_RIC, QPF_BORDER, QPF_CL, QPF_FWD, QPF_BS_STAGE, QPF_BS_OBS, QPF_TRIAL, QPF_APPLY, QPF_OTHER };
 
 // bounds of primal variable i
 struct QBnd { double lo, hi; int hasL, hasU; double mult; };
@@ -273,132 +280,223 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 }
 
 // ---------------------------------------------------------------- Riccati backward sweep (wavefront 0)
-#define QTH(a, cI) That[(a) * QQC + (cI)]
+// Per stage (all 128 lanes, four short LDS phases separated by LDS-only workgroup barriers):
+//   A  That = Pn FX + [0 | pn]          16 x 18   FX = [A B d Ft ; 0 I 0 0] is the dense 16 x 18 block of the stage record
+//   B  Qhat = [H | hc | 0] + F'That     20 x 34   (rows / columns of the input copy w carry no product: F has zero columns there)
+//   C  Quu = LDL', gains Khat for the 16 state columns and the 14 right-hand sides
+//   D  new Pn, pn (16 x 30), bilinear border constants (105 pairs); park the next stage record in LDS
+// All index arithmetic of the item -> (row, column) maps is done once per sweep (QRicPlan, registers); the inner loops are
+// branch-free strided LDS reads + fp64 FMAs.  Stage records are gathered QRIC_D stages ahead (same vmcnt discipline as the
+// parking sweep: unconditional loads / stores, single-exit loop).
+#define QTC 18                       // columns of That: x (12), u (4), d, Ft
+#define QTH(a, tc) That[(a) * QTC + (tc)]
 #define QQH(i, cI) Qhat[(i) * QQC + (cI)]
-OBCA_FN double q_fh(const double *sg, int a, int cI) {   // entry (a, cI) of [F | off] with cI over the 34 extended columns
-    if (cI < QX) return a < QX ? sg[QSR_F + a * QFC + cI] : 0.0;
-    if (cI < QS) return 0.0;                                   // w columns: the copy does not propagate
-    if (cI < QZ) return a < QX ? sg[QSR_F + a * QFC + 12 + (cI - QS)] : ((a - QX) == (cI - QS) ? 1.0 : 0.0);
-    if (cI < QZ + 2) return a < QX ? sg[QSR_F + a * QFC + 16 + (cI - QZ)] : 0.0;
-    return 0.0;
-}
+#define QRIC_D 2
+#define QREC_PER ((QSR + OB_NT - 1) / OB_NT)     // doubles of one stage record per lane (6)
 OBCA_FN void q_pair(int p, int &a_, int &b_) { a_ = 0; int rem = p; while (rem >= QC - a_) { rem -= QC - a_; a_++; } b_ = a_ + rem; }
 
+// item maps, bit-packed so that the whole plan lives in 15 registers:
+//   A: row | col << 5 | (pn column + 1) << 10                       (row 31 = no item)
+//   B: h | t << 10 | (fx + 1) << 22 | (id + 1) << 27                 h: [H|hc] source offset in sg; t: offset of the T column in LDS
+//      (fx: FX column, 0 = no product; id: identity row, 0 = none); the destination is the item number itself
+//   D: i | cc << 5 | qc << 10 | rs << 16                             (i 31 = no item; rs: offset in the Riccati record)
+struct QRicPlan { unsigned a[3], b[6], d[4]; int pa, pb; };
+#define QRR_PAD 767                                  // unused slot of the Riccati record: target of dummy stores
+OBCA_FN void q_ric_plan(int lane, int off_That, int off_pn, QRicPlan &p) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int it = lane + OB_NT * r; const bool on = it < QS * QTC; const int tc = it % QTC;
+        p.a[r] = on ? (unsigned)(it / QTC) | (unsigned)tc << 5 | (unsigned)(tc >= 16 ? tc - 16 + 1 : 0) << 10 : 31u;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int it = lane + OB_NT * r; const bool on = it < QZ * QQC;
+        const int i = on ? it / QQC : 0, cI = on ? it % QQC : 0;
+        const bool wrow = i >= QX && i < QS, wcol = cI >= QX && cI < QS;
+        const int h = cI < QZ ? QSR_H + i * QZ + cI : (cI < QZ + 2 ? QSR_HC + 2 * i + (cI - QZ) : QSR - 1);   // QSR-1: a zero of the record padding
+        const int ip = i < QX ? i : i - QU;                                       // column of FX that belongs to stage-vector row i
+        const int fx = (on && !wrow && !wcol) ? ip + 1 : 0;
+        const int tc = cI < QX ? cI : (cI < QZ ? cI - QU : -1);                   // That column for x / u columns
+        const int t = cI < QZ + 2 ? off_That + (cI < QZ ? (tc < 0 ? 0 : tc) : 16 + (cI - QZ)) : off_pn + (cI - QZ);
+        const int id = (on && i >= QS && !wcol) ? QX + (i - QS) + 1 : 0;
+        p.b[r] = (unsigned)h | (unsigned)t << 10 | (unsigned)fx << 22 | (unsigned)id << 27;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int it = lane + OB_NT * r; const bool on = it < QS * 30;
+        const int i = on ? it / 30 : 0, cc = on ? it % 30 : 0, qc = cc < QS ? cc : QZ + (cc - QS);
+        const int rs = (on && i < QX) ? (cc < QS ? QRR_PX + i * QS + cc : QRR_PV + i * QC + (cc - QS)) : QRR_PAD;
+        p.d[r] = (unsigned)(on ? i : 31) | (unsigned)cc << 5 | (unsigned)qc << 10 | (unsigned)rs << 16;
+    }
+    if (lane < QC * (QC + 1) / 2) q_pair(lane, p.pa, p.pb); else { p.pa = -1; p.pb = 0; }
+}
+
+template <int PIPE>
+OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBCA_NLT], double (&nv)[OBCA_NLT][QRIC_D][QREC_PER], const int slot) {
+    double *That = &sh.red[0][0], *Qhat = That + QS * QTC;      // 288 + 680 doubles <= 16 * OB_NT
+    double *L = &sh.red[0][0];                                   // base of the plan's LDS offsets
+    const double *sg = sh.sg;
+    PAR(lane) {   // A
+        const QRicPlan &p = plan[LI(lane)];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            unsigned wa = p.a[r]; OPAQUE(wa);
+            const int a = wa & 31, tc = (wa >> 5) & 31, pc = (int)((wa >> 10) & 31) - 1;
+            if (a < QS) {
+                double acc = pc >= 0 ? sh.pn[a * QC + pc] : 0.0;
+#pragma unroll
+                for (int b_ = 0; b_ < QS; b_++) acc += sh.Pn[a * QS + b_] * sg[QSR_F + b_ * QFC + tc];
+                QTH(a, tc) = acc;
+            }
+        }
+    }
+    LDS_BARRIER();
+    const int off_pn = (int)(sh.pn - L);
+    PAR(lane) {   // B
+        const QRicPlan &p = plan[LI(lane)];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int it = lane + OB_NT * r;
+            if (it < QZ * QQC) {
+                unsigned w = p.b[r]; OPAQUE(w);
+                const int h = w & 1023, t = (w >> 10) & 4095, fx = (int)((w >> 22) & 31) - 1, id = (int)(w >> 27) - 1;
+                double acc = sg[h];
+                if (fx >= 0) {
+                    const double *tp = L + t; const int ts = t >= off_pn ? QC : QTC, fo = QSR_F + fx;
+#pragma unroll
+                    for (int a = 0; a < QX; a++) acc += sg[fo + a * QFC] * tp[a * ts];
+                    if (id >= 0) acc += tp[id * ts];
+                }
+                Qhat[it] = acc;
+            }
+        }
+        if (lane < 2 * QC) {   // sB[m][b] = off_m . That[:, rhs b] ; sB[2+m][b] = off_m . pn[:, b]   (m = 0: d, 1: Ft)
+            const int m = lane / QC, b_ = lane % QC; double u1 = 0, u2 = 0;
+            const double *tp = b_ < 2 ? That + 16 + b_ : sh.pn + b_; const int ts = b_ < 2 ? QTC : QC;
+#pragma unroll
+            for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1 += o * tp[i * ts]; u2 += o * sh.pn[i * QC + b_]; }
+            sh.sB[m * QC + b_] = u1; sh.sB[(2 + m) * QC + b_] = u2;
+        }
+    }
+    LDS_BARRIER();
+    // C: Quu -> LDL' (every lane, uniform), gains for the 30 columns (16 state columns + 14 right-hand sides)
+    double Lq[QU * QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++)
+#pragma unroll
+        for (int j = 0; j < QU; j++) Lq[i * QU + j] = QQH(QS + i, QS + j);
+    const int ok = UNIFORM(ldl_fact<QU>(QU, Lq) ? 0 : 1);        // (no early exit, see the parking sweep)
+    gdbl *ro = sh.inst.rs + (size_t)k * QRR;
+    PAR(lane) {
+        const int cc = lane < 30 ? lane : 0, qc = cc < QS ? cc : QZ + (cc - QS);
+        double b[QU];
+#pragma unroll
+        for (int i = 0; i < QU; i++) b[i] = -QQH(QS + i, qc);
+        ldl_solve<QU>(QU, Lq, b);
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            if (lane < 30) sh.Khat[i * 30 + cc] = b[i];
+            ro[lane < 30 ? (cc < QS ? QRR_K + i * QS + cc : QRR_KF + i * QC + (cc - QS)) : QRR_PAD] = b[i];
+        }
+    }
+    LDS_BARRIER();
+    PAR(lane) {   // D
+        const QRicPlan &p = plan[LI(lane)];
+        if (PIPE) {   // park the record of stage k-1 (gathered QRIC_D stages ago) and re-issue the slot
+            const int kl = k - 1 - QRIC_D > 0 ? k - 1 - QRIC_D : 0;
+            const gdbl *rn = sh.inst.as + (size_t)kl * QSR;
+#pragma unroll
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; sh.sg[e < QSR ? e : QSR - 1] = e < QSR ? nv[LI(lane)][slot][r] : 0.0; }
+#pragma unroll
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; nv[LI(lane)][slot][r] = rn[e < QSR ? e : QSR - 1]; }
+        }
+        double pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned w = p.d[r]; OPAQUE(w);
+            const int i = (w & 31) < QS ? (int)(w & 31) : 0, cc = (w >> 5) & 31, qc = (w >> 10) & 63, rs = w >> 16;
+            double v = QQH(i, qc);
+#pragma unroll
+            for (int a = 0; a < QU; a++) v += QQH(i, QS + a) * sh.Khat[a * 30 + cc];
+            if (cc < QS && cc != i) {   // keep the value function exactly symmetric
+                double w_ = QQH(cc, i);
+#pragma unroll
+                for (int a = 0; a < QU; a++) w_ += QQH(cc, QS + a) * sh.Khat[a * 30 + i];
+                v = 0.5 * (v + w_);
+            }
+            pv[r] = v;
+            ro[rs] = v;
+        }
+        double bm = 0;
+        int pa_ = p.pa, pb_ = p.pb; OPAQUE(pa_); OPAQUE(pb_);
+        if (pa_ >= 0) {
+            const int a_ = pa_, b_ = pb_;
+#pragma unroll
+            for (int i = 0; i < QU; i++) bm += QQH(QS + i, QZ + a_) * sh.Khat[i * 30 + QS + b_];
+            if (a_ < 2) bm += sh.sB[a_ * QC + b_];
+            if (b_ < 2) bm += sh.sB[(2 + b_) * QC + a_];
+            sh.Bm[a_ * QC + b_] += bm; if (a_ != b_) sh.Bm[b_ * QC + a_] += bm;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned w = p.d[r]; OPAQUE(w); const int i = w & 31, cc = (w >> 5) & 31;
+            if (i < QS) { if (cc < QS) sh.Pn[i * QS + cc] = pv[r]; else sh.pn[i * QC + (cc - QS)] = pv[r]; }
+        }
+    }
+    LDS_BARRIER();
+    return ok;
+}
+
 OBCA_FN int q_riccati_body(QShared &sh, double rho) {
-    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
-    double *That = &sh.red[0][0], *Qhat = That + QS * QQC;      // 544 + 680 doubles <= 16 * OB_NT
-    double nv[OBCA_NL][12];
-    PAR64(lane) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = UNIFORM(c.N); const gdbl *z = sh.inst.z;
+    double nv[OBCA_NLT][QRIC_D][QREC_PER];
+    QRicPlan plan[OBCA_NLT];
+    PAR(lane) {
+        q_ric_plan(lane, 0, (int)(sh.pn - &sh.red[0][0]), plan[LI(lane)]);
         const gdbl *rec = sh.inst.as + (size_t)N * QSR;
-        for (int it = lane; it < QS * QS; it += 64) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
-        for (int it = lane; it < QS * QC; it += 64) {
+        for (int it = lane; it < QS * QS; it += OB_NT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
+        for (int it = lane; it < QS * QC; it += OB_NT) {
             int i = it / QC, cc = it % QC; double v = 0;
             if (i < QX) { if (cc == 0) v = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
             sh.pn[it] = v;
         }
-        for (int it = lane; it < QC * QC; it += 64) sh.Bm[it] = 0;
-        const gdbl *r1 = sh.inst.as + (size_t)(N - 1) * QSR;
-        for (int i = lane; i < QSR; i += 64) sh.sg[i] = r1[i];
-        if (N >= 2) { const gdbl *r2 = sh.inst.as + (size_t)(N - 2) * QSR;
-#pragma unroll
-            for (int r = 0; r < 12; r++) { int i = lane + 64 * r; nv[LI(lane)][r] = i < QSR ? r2[i] : 0.0; } }
+        for (int it = lane; it < QC * QC; it += OB_NT) sh.Bm[it] = 0;
     }
-    LDS_SYNC();
-    for (int k = N - 1; k >= 0; k--) {
-        const double *sg = sh.sg;
-        PAR64(lane) {   // A: That = Pn [F | off] + [0 | pn]   (16 x 34)
-            for (int it = lane; it < QS * QQC; it += 64) {
-                const int a = it / QQC, cI = it % QQC;
-                double acc = cI >= QZ ? sh.pn[a * QC + (cI - QZ)] : 0.0;
-                if (cI < QX || (cI >= QS && cI < QZ + 2)) {
-#pragma unroll 4
-                    for (int b_ = 0; b_ < QS; b_++) acc += sh.Pn[a * QS + b_] * q_fh(sg, b_, cI);
-                }
-                QTH(a, cI) = acc;
-            }
-        }
-        LDS_SYNC();
-        PAR64(lane) {   // B: Qhat = [H | hc] + F^T That  (20 x 34); static parts of the bilinear update for the pairs with a in {0,1}
-            for (int it = lane; it < QZ * QQC; it += 64) {
-                const int i = it / QQC, cI = it % QQC;
-                double acc = cI < QZ ? sg[QSR_H + i * QZ + cI] : (cI < QZ + 2 ? sg[QSR_HC + 2 * i + (cI - QZ)] : 0.0);
-                if (i < QX || i >= QS) {
-#pragma unroll 4
-                    for (int a = 0; a < QS; a++) acc += q_fh(sg, a, i) * QTH(a, cI);
-                }
-                QQH(i, cI) = acc;
-            }
-            if (lane < 2 * QC) {   // sB[m][b] = off_m . That[:, 20+b] ; sB[2+m][b] = off_m . pn[:, b]   (m = 0: d, 1: Ft)
-                const int m = lane / QC, b_ = lane % QC; double u1 = 0, u2 = 0;
-                for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1 += o * QTH(i, QZ + b_); u2 += o * sh.pn[i * QC + b_]; }
-                sh.sB[m * QC + b_] = u1; sh.sB[(2 + m) * QC + b_] = u2;
-            }
-        }
-        LDS_SYNC();
-        // C: Quu = Qhat[16..19][16..19] -> LDL (uniform), gains for the 30 columns (16 state columns + 14 right-hand sides)
-        double Lq[QU * QU];
+    // head: synchronous gathers until the remaining stage count is a multiple of QRIC_D
+    int k = N - 1;
+    for (; k >= 0 && (k + 1) % QRIC_D != 0; k--) {
+        PAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSR; for (int i = lane; i < QSR; i += OB_NT) sh.sg[i] = r1[i]; }
+        LDS_BARRIER();
+        if (!q_riccati_stage<0>(sh, k, plan, nv, 0)) return 0;
+    }
+    if (k < 0) return 1;
+    PAR(lane) {
+        const gdbl *r1 = sh.inst.as + (size_t)k * QSR;
+        for (int i = lane; i < QSR; i += OB_NT) sh.sg[i] = r1[i];
 #pragma unroll
-        for (int i = 0; i < QU; i++)
+        for (int j = 0; j < QRIC_D; j++) {
+            const int st = k - 1 - j > 0 ? k - 1 - j : 0; const gdbl *rn = sh.inst.as + (size_t)st * QSR;
 #pragma unroll
-            for (int j = 0; j < QU; j++) Lq[i * QU + j] = QQH(QS + i, QS + j);
-#ifdef OBCA_EMU
-        if (getenv("OBCA_DBG")) { fprintf(stderr, "k=%d Quu diag %g %g %g %g\n", k, QQH(16,16), QQH(17,17), QQH(18,18), QQH(19,19)); }
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; nv[LI(lane)][(j + 1) % QRIC_D][r] = rn[e < QSR ? e : QSR - 1]; }
+        }
+#ifndef OBCA_EMU
+#pragma unroll
+        for (int j = 0; j < QRIC_D; j++)
+#pragma unroll
+            for (int r = 0; r < QREC_PER; r++) asm volatile("" : "+v"(nv[0][j][r]));
 #endif
-        if (ldl_fact<QU>(QU, Lq)) return 0;
-        gdbl *ro = sh.inst.rs + (size_t)k * QRR;
-        PAR64(lane) {
-            if (lane < 30) {
-                const int qc = lane < QS ? lane : QZ + (lane - QS);
-                double b[QU];
-#pragma unroll
-                for (int i = 0; i < QU; i++) b[i] = -QQH(QS + i, qc);
-                ldl_solve<QU>(QU, Lq, b);
-#pragma unroll
-                for (int i = 0; i < QU; i++) { sh.Khat[i * 30 + lane] = b[i]; if (lane < QS) ro[QRR_K + i * QS + lane] = b[i]; else ro[QRR_KF + i * QC + (lane - QS)] = b[i]; }
-            }
-        }
-        LDS_SYNC();
-        PAR64(lane) {   // D: new Pn, pn; bilinear constants; park the next stage record
-            for (int it = lane; it < QS * 30; it += 64) {
-                const int i = it / 30, cc = it % 30, qc = cc < QS ? cc : QZ + (cc - QS);
-                double v = QQH(i, qc);
-#pragma unroll
-                for (int a = 0; a < QU; a++) v += QQH(i, QS + a) * sh.Khat[a * 30 + cc];
-                if (cc < QS && cc != i) {   // keep the value function exactly symmetric
-                    double w_ = QQH(cc, i);
-#pragma unroll
-                    for (int a = 0; a < QU; a++) w_ += QQH(cc, QS + a) * sh.Khat[a * 30 + i];
-                    v = 0.5 * (v + w_);
-                }
-                if (cc < QS) { sh.Pn[i * QS + cc] = v; if (i < QX) ro[QRR_PX + i * QS + cc] = v; }
-                else { sh.pn[i * QC + (cc - QS)] = v; if (i < QX) ro[QRR_PV + i * QC + (cc - QS)] = v; }
-            }
-            for (int p = lane; p < QC * (QC + 1) / 2; p += 64) {
-                int a_, b_; q_pair(p, a_, b_);
-                double v = 0;
-#pragma unroll
-                for (int i = 0; i < QU; i++) v += QQH(QS + i, QZ + a_) * sh.Khat[i * 30 + QS + b_];
-                if (a_ < 2) v += sh.sB[a_ * QC + b_];
-                if (b_ < 2) v += sh.sB[(2 + b_) * QC + a_];
-                sh.Bm[a_ * QC + b_] += v; if (a_ != b_) sh.Bm[b_ * QC + a_] += v;
-            }
-            if (k > 0) {
-#pragma unroll
-                for (int r = 0; r < 12; r++) { int i = lane + 64 * r; if (i < QSR) sh.sg[i] = nv[LI(lane)][r]; }
-                if (k > 1) { const gdbl *r2 = sh.inst.as + (size_t)(k - 2) * QSR;
-#pragma unroll
-                    for (int r = 0; r < 12; r++) { int i = lane + 64 * r; nv[LI(lane)][r] = i < QSR ? r2[i] : 0.0; } }
-            }
-        }
-        LDS_SYNC();
     }
-    return 1;
+    LDS_BARRIER();
+    int ok = 1;
+    for (int kb = k; kb >= QRIC_D - 1 && ok; kb -= QRIC_D) {
+#pragma unroll
+        for (int ju = 0; ju < QRIC_D; ju++) ok &= q_riccati_stage<1>(sh, kb - ju, plan, nv, (ju + 1) % QRIC_D);
+    }
+    return ok;
 }
 OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
-    WAVE0_BEGIN
-        const int ok = q_riccati_body(sh, rho);
-        PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
-    WAVE0_END
+    const int ok = q_riccati_body(sh, rho);
+    PAR(lane) { if (lane == 0) sh.ric_ok = ok; }
     SYNC();
     return sh.ric_ok;
 }
@@ -447,6 +545,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         }
     WAVE0_END
     SYNC();
+    QPROF(QPF_BORDER);
     if (!sh.bord_ok) { so.ok = 0; return; }
     const double dt = sh.coef[1];
     // ---- closed-loop maps per stage: Acl = [A + B K ; K], bcl = [B kf + d + dt Ft ; kf]
@@ -475,6 +574,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         }
     }
     SYNC();
+    QPROF(QPF_CL);
     // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k on wavefront 0; maps staged through LDS in chunks (ring in the reduction scratch)
 #define QFW_CH 3
 #define QFW_SZ 272
@@ -515,6 +615,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         }
     WAVE0_END
     SYNC();
+    QPROF(QPF_FWD);
     // ---- stage-parallel: steps of x, u; costate increments; step-length / descent partials of x, u
     PAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
@@ -576,6 +677,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     SYNC();
     so.ap = red_min(sh.red[0]); so.az = red_min(sh.red[1]); so.gd = red_sum(sh.red[2]);
     SYNC();
+    QPROF(QPF_BS_STAGE);
 }
 
 OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
@@ -704,7 +806,8 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
     PAR(lane) {
         for (int k = lane; k <= N; k += OB_NT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSR;
-            for (int i = 0; i < 3; i++) { rec[QSR_F + i * QFC + i] = 1.0; rec[QSR_F + (6 + i) * QFC + (6 + i)] = 1.0; }   // the other diagonal entries are rewritten every pass
+            for (int i = 0; i < 3; i++) { rec[QSR_F + i * QFC + i] = 1.0; rec[QSR_F + (6 + i) * QFC + (6 + i)] = 1.0; }
+            for (int j = 0; j < QU; j++) rec[QSR_F + (QX + j) * QFC + QX + j] = 1.0;          // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
         }
         for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
             const int k = it / QOB, j = it - k * QOB;
@@ -736,15 +839,15 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
 }
 
 // ---------------------------------------------------------------- phase entry points and driver
-OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); }
-OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { q_assemble_obs(gq_sh, mu, dw, dc); }
-OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); QPROF(QPF_INIT); }
+OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
+OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
 OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
-OBCA_PHASE int qph_riccati(double rho) { return q_riccati_backward(gq_sh, rho); }
+OBCA_PHASE int qph_riccati(double rho) { const int ok = q_riccati_backward(gq_sh, rho); QPROF(QPF_RIC); return ok; }
 OBCA_PHASE void qph_direction_main(double mu, double dw, double dc, double rho, double tau) { QShared &sh = gq_sh; q_direction_main(sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
-OBCA_PHASE void qph_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs(sh, mu, dw, dc, tau, sh.S); }
-OBCA_PHASE void qph_trial(double alpha) { QShared &sh = gq_sh; q_eval_trial(sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { q_apply_step(gq_sh, alpha, ay, az, mu, ks); }
+OBCA_PHASE void qph_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs(sh, mu, dw, dc, tau, sh.S); QPROF(QPF_BS_OBS); }
+OBCA_PHASE void qph_trial(double alpha) { QShared &sh = gq_sh; QPROF(QPF_OTHER); q_eval_trial(sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); QPROF(QPF_TRIAL); }
+OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { QPROF(QPF_OTHER); q_apply_step(gq_sh, alpha, ay, az, mu, ks); QPROF(QPF_APPLY); }
 
 // info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
 OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {

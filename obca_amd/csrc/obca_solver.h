@@ -32,6 +32,7 @@
 #define LDS_BARRIER() ((void)0)
 #define OBCA_NLT OB_NT
 #define UNIFORM(x) (x)
+#define OPAQUE(x) ((void)0)
 #define OBCA_NL 64          // per-lane variables that live across a SYNC are arrays over the lanes in the emulation
 #define LI(lane) (lane)
 #else
@@ -59,6 +60,7 @@
 // workgroup barrier for phases that exchange data through LDS only: unlike __syncthreads() it does not drain the global-memory counter
 #define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define OBCA_NLT 1
+#define OPAQUE(x) asm volatile("" : "+v"(x))   // hide a loop-invariant register from LICM: what is derived from it is recomputed, not kept live
 #define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // value known to be wave-uniform: keep it in an SGPR (scalar branches, scalar loop counters)
 #define OBCA_NL 1
 #define LI(lane) 0

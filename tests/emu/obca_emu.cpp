@@ -114,7 +114,10 @@ int emu_quad_newton(int N, const double *prob, const double *zin, double mu, dou
     memcpy(s.z, zin, sizeof(double) * l.len);
     q_setup(N, prob, s); quad::QShared &sh = quad::gq_sh;
     // constants of the dense stage record (the solver writes them in its init phase)
-    for (int k = 0; k <= N; k++) for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSR + QSR_F + i * QFC + i] = 1.0; s.as[(size_t)k * QSR + QSR_F + (6 + i) * QFC + 6 + i] = 1.0; }
+    for (int k = 0; k <= N; k++) {
+        for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSR + QSR_F + i * QFC + i] = 1.0; s.as[(size_t)k * QSR + QSR_F + (6 + i) * QFC + 6 + i] = 1.0; }
+        for (int j = 0; j < QU; j++) s.as[(size_t)k * QSR + QSR_F + (QX + j) * QFC + QX + j] = 1.0;
+    }
     quad::q_assemble_obs(sh, mu, dw, dc);
     AsmOut A; quad::q_assemble_stage(sh, mu, dw, dc, A);
     int ok = A.ok;

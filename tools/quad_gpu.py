@@ -19,3 +19,10 @@ it = out["iters"]
 print(json.dumps(dict(B=B, N=N, kernel_ms=ms, wall_ms=dt * 1e3, solves_per_s=B / (ms * 1e-3), converged=float((out["exitflag"] == 1).mean()),
                       flag2=float((out["exitflag"] == 2).mean()), iters_mean=float(it.mean()), iters_max=int(it.max()), nreg_mean=float(out["info"][:, 6].mean()),
                       scratch_MB=qb.scratch_bytes() / 1e6)))
+pc = qb.phase_cycles()
+if pc.sum() > 0:
+    names = "init asm_obs asm_stage riccati border closed_loop fwd_seq bs_stage bs_obs trial apply other".split()
+    passes = out["info"][:, 1] + out["info"][:, 6]; tot = pc[:, :len(names)].sum(1)
+    print("cycles per pass: mean %.0f" % (tot / passes).mean())
+    for i, n in enumerate(names):
+        print("%-12s %5.1f%%   cycles/pass %9.0f" % (n, 100 * pc[:, i].sum() / tot.sum(), (pc[:, i] / passes).mean()))
