@@ -1,0 +1,212 @@
+// obca_planner.cpp -- host-side warm-start planner (C ABI, no GPU): a compact Hybrid A* over (x, y, yaw) for the car of the parking
+// scenarios.  It plays the role of the step BEFORE the hot path in the reference (SURVEY.md section 8f "next-2"):
+//   /root/reference/AutonomousParking/hybrid_a_star.jl (search over motion primitives, grid-based holonomic heuristic,
+//   collision check of the car rectangle against the obstacles), main.jl:216-248 (path -> rx, ry, ryaw -> down-sampling).
+// This is a re-design, not a port: obstacles are the same convex H-representations the NLP uses (A p <= b per obstacle, obstHrep.jl),
+// the collision test clips the inflated car rectangle against each obstacle's half-planes (exact for convex sets, no KD-tree of
+// sampled obstacle points), the heuristic is max(obstacle-aware 2-D Dijkstra distance of a disc robot, Euclid) and the analytic
+// Reeds-Shepp expansion is replaced by a goal tolerance (the NLP's terminal constraint closes the gap).
+// Build: g++ -O2 -shared -fPIC -o libobca_plan.so obca_planner.cpp   (tools/build.sh, __graft_entry__.build()).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+struct P2 { double x, y; };
+
+struct World {
+    int nOb; std::vector<int> v, off; std::vector<double> A, b;   // obstacle j: rows off[j] .. off[j]+v[j]
+    double xmin, xmax, ymin, ymax;                               // XYbounds of the rear-axle position
+    double ego[4], margin;                                        // front, left, rear, right extents from the rear axle; inflation
+};
+
+// convex polygon clipped by the half-plane a.p <= bb (Sutherland-Hodgman); returns the number of vertices left
+static int clip(const P2 *in, int n, double ax, double ay, double bb, P2 *out) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const P2 &p = in[i], &q = in[(i + 1) % n];
+        const double dp = ax * p.x + ay * p.y - bb, dq = ax * q.x + ay * q.y - bb;
+        if (dp <= 0) out[m++] = p;
+        if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) { const double t = dp / (dp - dq); out[m++] = {p.x + t * (q.x - p.x), p.y + t * (q.y - p.y)}; }
+    }
+    return m;
+}
+
+static bool collides(const World &w, double x, double y, double yaw) {
+    if (x < w.xmin || x > w.xmax || y < w.ymin || y > w.ymax) return true;
+    const double c = std::cos(yaw), s = std::sin(yaw), m = w.margin;
+    const double f = w.ego[0] + m, l = w.ego[1] + m, r = w.ego[2] + m, rt = w.ego[3] + m;
+    const P2 car[4] = {{x + f * c - l * s, y + f * s + l * c}, {x - r * c - l * s, y - r * s + l * c},
+                       {x - r * c + rt * s, y - r * s - rt * c}, {x + f * c + rt * s, y + f * s - rt * c}};
+    P2 bufA[16], bufB[16];
+    for (int j = 0; j < w.nOb; j++) {
+        int n = 4; std::memcpy(bufA, car, sizeof car);
+        P2 *cur = bufA, *nxt = bufB;
+        for (int i = 0; i < w.v[j] && n > 0; i++) {
+            const int rix = w.off[j] + i;
+            n = clip(cur, n, w.A[2 * rix], w.A[2 * rix + 1], w.b[rix], nxt);
+            std::swap(cur, nxt);
+        }
+        if (n >= 3) {   // non-degenerate overlap
+            double area = 0; for (int i = 0; i < n; i++) { const P2 &p = cur[i], &q = cur[(i + 1) % n]; area += p.x * q.y - q.x * p.y; }
+            if (std::fabs(area) > 1e-9) return true;
+        }
+    }
+    return false;
+}
+
+static bool disc_collides(const World &w, double x, double y, double rad) {
+    for (int j = 0; j < w.nOb; j++) {   // distance of the point to the convex set (intersection of half-planes), conservative via max row slack
+        double worst = -1e300;
+        for (int i = 0; i < w.v[j]; i++) { const int r = w.off[j] + i; const double n = std::hypot(w.A[2 * r], w.A[2 * r + 1]); worst = std::max(worst, (w.A[2 * r] * x + w.A[2 * r + 1] * y - w.b[r]) / n); }
+        if (worst < rad) {   // inside the rad-offset of every half-plane: within rad of the set unless near a corner (then slightly conservative)
+            if (worst <= 0) return true;
+            // corner case: exact distance to the set is >= worst; test the rounded corner with the two most violated rows
+            int cnt = 0; double d2 = 0;
+            for (int i = 0; i < w.v[j]; i++) { const int r = w.off[j] + i; const double n = std::hypot(w.A[2 * r], w.A[2 * r + 1]); const double e = (w.A[2 * r] * x + w.A[2 * r + 1] * y - w.b[r]) / n; if (e > 0) { d2 += e * e; cnt++; } }
+            if (cnt <= 1 || d2 < rad * rad) return true;
+        }
+    }
+    return false;
+}
+
+struct Node { double x, y, yaw, g; int parent; int8_t dir, steer; };
+static inline double wrap(double a) { while (a > M_PI) a -= 2 * M_PI; while (a < -M_PI) a += 2 * M_PI; return a; }
+
+}  // namespace
+
+extern "C" {
+
+/*
+ * Hybrid A* from start (x, y, yaw) to goal.  Obstacles as in obca_parking_signed_dist_batch (nOb, vOb = rows per obstacle, A row-major
+ * (M x 2), b).  ego = [front, left, rear, right] extents from the rear axle (main.jl:73), L = wheelbase, XYbounds = [xmin,xmax,ymin,ymax].
+ * opts (may be NULL) = {xy resolution 0.25, yaw resolution deg 7.5, primitive length 0.6, max steer 0.6, #steer samples per side 2,
+ *                       collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance deg 8, reverse cost 1.5, switch cost 2.0,
+ *                       steer cost 0.3, max expansions 400000}.
+ * Output: path[3 * k] = x, y, yaw of the k-th node and dir[k] = +1 / -1 (motion that led to the node), up to cap nodes.
+ * Returns the number of nodes (>= 2), 0 if no path was found, -1 on bad arguments, -2 if the start or the goal collides.
+ */
+int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                           const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
+                           int *expansions) {
+    if (!start || !goal || nOb < 0 || !vOb || !A || !b || !ego || !XYbounds || !path || !dir || cap < 2) return -1;
+    const double res = opts ? opts[0] : 0.25, yres = (opts ? opts[1] : 7.5) * M_PI / 180, step = opts ? opts[2] : 0.6, smax = opts ? opts[3] : 0.6;
+    const int nst = opts ? (int)opts[4] : 2; const double margin = opts ? opts[5] : 0.1, gtol = opts ? opts[6] : 0.3, ytol = (opts ? opts[7] : 8.0) * M_PI / 180;
+    const double crev = opts ? opts[8] : 1.5, csw = opts ? opts[9] : 2.0, cst = opts ? opts[10] : 0.3; const long maxexp = opts ? (long)opts[11] : 400000;
+    World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
+    for (int j = 0; j < nOb; j++) { if (vOb[j] < 1) return -1; w.off[j + 1] = w.off[j] + vOb[j]; }
+    w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
+    w.xmin = XYbounds[0]; w.xmax = XYbounds[1]; w.ymin = XYbounds[2]; w.ymax = XYbounds[3];
+    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin;
+    if (collides(w, start[0], start[1], start[2]) || collides(w, goal[0], goal[1], goal[2])) return -2;
+
+    // holonomic heuristic: Dijkstra on the xy grid from the goal for a disc of the car's half width (hybrid_a_star.jl's grid heuristic)
+    const int nx = (int)std::ceil((w.xmax - w.xmin) / res) + 1, ny = (int)std::ceil((w.ymax - w.ymin) / res) + 1;
+    std::vector<float> hmap((size_t)nx * ny, 1e9f);
+    {
+        const double rad = std::min(std::min(ego[1], ego[3]), 0.5 * (ego[0] + ego[2])) * 0.9;
+        std::vector<uint8_t> blocked((size_t)nx * ny, 0);
+        for (int iy = 0; iy < ny; iy++) for (int ix = 0; ix < nx; ix++) blocked[(size_t)iy * nx + ix] = disc_collides(w, w.xmin + ix * res, w.ymin + iy * res, rad);
+        typedef std::pair<float, int> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+        const int gx = std::min(nx - 1, std::max(0, (int)std::lround((goal[0] - w.xmin) / res))), gy = std::min(ny - 1, std::max(0, (int)std::lround((goal[1] - w.ymin) / res)));
+        hmap[(size_t)gy * nx + gx] = 0; pq.push({0.f, gy * nx + gx});
+        while (!pq.empty()) {
+            QE e = pq.top(); pq.pop();
+            if (e.first > hmap[e.second]) continue;
+            const int cx = e.second % nx, cy = e.second / nx;
+            for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+                if (!dx && !dy) continue;
+                const int qx = cx + dx, qy = cy + dy; if (qx < 0 || qy < 0 || qx >= nx || qy >= ny) continue;
+                const size_t q = (size_t)qy * nx + qx; if (blocked[q]) continue;
+                const float c = e.first + (float)(res * std::hypot(dx, dy));
+                if (c < hmap[q]) { hmap[q] = c; pq.push({c, (int)q}); }
+            }
+        }
+    }
+    auto heur = [&](double x, double y, double yaw) {
+        const int ix = std::min(nx - 1, std::max(0, (int)std::lround((x - w.xmin) / res))), iy = std::min(ny - 1, std::max(0, (int)std::lround((y - w.ymin) / res)));
+        const double h2 = hmap[(size_t)iy * nx + ix] < 1e8f ? hmap[(size_t)iy * nx + ix] : std::hypot(x - goal[0], y - goal[1]) + 5.0;
+        const double Rmin = L / std::tan(smax);
+        return std::max(h2, Rmin * std::fabs(wrap(yaw - goal[2])) * 0.5);
+    };
+    const int nyaw = (int)std::ceil(2 * M_PI / yres);
+    auto key = [&](double x, double y, double yaw) -> long long {
+        const long long ix = (long long)std::floor((x - w.xmin) / res), iy = (long long)std::floor((y - w.ymin) / res);
+        long long ia = (long long)std::floor((wrap(yaw) + M_PI) / yres); if (ia >= nyaw) ia = nyaw - 1;
+        return (iy * (nx + 1) + ix) * nyaw + ia;
+    };
+    std::vector<Node> nodes; nodes.reserve(1 << 16);
+    std::unordered_map<long long, double> best;
+    typedef std::pair<double, int> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> open;
+    nodes.push_back({start[0], start[1], wrap(start[2]), 0.0, -1, 0, 0});
+    open.push({heur(start[0], start[1], start[2]), 0}); best[key(start[0], start[1], start[2])] = 0.0;
+    long nexp = 0; int found = -1;
+    const int sub = std::max(1, (int)std::ceil(step / 0.2));
+    while (!open.empty() && nexp < maxexp) {
+        const QE e = open.top(); open.pop();
+        const Node cur = nodes[e.second];
+        { auto it = best.find(key(cur.x, cur.y, cur.yaw)); if (it != best.end() && it->second < cur.g - 1e-9) continue; }
+        if (std::hypot(cur.x - goal[0], cur.y - goal[1]) <= gtol && std::fabs(wrap(cur.yaw - goal[2])) <= ytol) { found = e.second; break; }
+        nexp++;
+        for (int d = 1; d >= -1; d -= 2)
+            for (int si = -nst; si <= nst; si++) {
+                const double steer = smax * si / nst, kap = std::tan(steer) / L;
+                double x = cur.x, y = cur.y, yaw = cur.yaw; bool ok = true;
+                for (int q = 0; q < sub && ok; q++) {
+                    const double ds = d * step / sub;
+                    if (std::fabs(kap) < 1e-9) { x += ds * std::cos(yaw); y += ds * std::sin(yaw); }
+                    else { const double y1 = yaw + ds * kap; x += (std::sin(y1) - std::sin(yaw)) / kap; y += -(std::cos(y1) - std::cos(yaw)) / kap; yaw = y1; }
+                    ok = !collides(w, x, y, yaw);
+                }
+                if (!ok) continue;
+                double g = cur.g + step * (d > 0 ? 1.0 : crev) + cst * std::fabs(steer) * step + 0.2 * std::fabs(steer - smax * cur.steer / nst);
+                if (cur.dir != 0 && cur.dir != d) g += csw;
+                const long long k = key(x, y, yaw);
+                auto it = best.find(k);
+                if (it != best.end() && it->second <= g) continue;
+                best[k] = g;
+                nodes.push_back({x, y, wrap(yaw), g, e.second, (int8_t)d, (int8_t)si});
+                open.push({g + heur(x, y, yaw), (int)nodes.size() - 1});
+            }
+    }
+    if (expansions) *expansions = (int)nexp;
+    if (found < 0) return 0;
+    std::vector<int> chain; for (int i = found; i >= 0; i = nodes[i].parent) chain.push_back(i);
+    std::reverse(chain.begin(), chain.end());
+    // densify: replay each primitive at 0.2 m so that the caller can resample by arc length
+    std::vector<double> px; std::vector<int> pd;
+    px.insert(px.end(), {nodes[chain[0]].x, nodes[chain[0]].y, nodes[chain[0]].yaw}); pd.push_back(nodes[chain.size() > 1 ? chain[1] : chain[0]].dir);
+    for (size_t c = 1; c < chain.size(); c++) {
+        const Node &p = nodes[chain[c - 1]], &n = nodes[chain[c]];
+        const double steer = smax * n.steer / nst, kap = std::tan(steer) / L;
+        double x = p.x, y = p.y, yaw = p.yaw;
+        for (int q = 0; q < sub; q++) {
+            const double ds = n.dir * step / sub;
+            if (std::fabs(kap) < 1e-9) { x += ds * std::cos(yaw); y += ds * std::sin(yaw); }
+            else { const double y1 = yaw + ds * kap; x += (std::sin(y1) - std::sin(yaw)) / kap; y += -(std::cos(y1) - std::cos(yaw)) / kap; yaw = y1; }
+            px.insert(px.end(), {x, y, yaw}); pd.push_back(n.dir);
+        }
+    }
+    const int cnt = (int)pd.size();
+    if (cnt > cap) return -1;
+    std::memcpy(path, px.data(), sizeof(double) * 3 * cnt); std::memcpy(dir, pd.data(), sizeof(int) * cnt);
+    return cnt;
+}
+
+/* 1 if the car pose collides with an obstacle (inflated by margin) or leaves XYbounds -- the planner's own test, exported for the tests */
+int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, const double *A, const double *b, const double ego[4],
+                       const double XYbounds[4], double margin) {
+    World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
+    for (int j = 0; j < nOb; j++) w.off[j + 1] = w.off[j] + vOb[j];
+    w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
+    w.xmin = XYbounds[0]; w.xmax = XYbounds[1]; w.ymin = XYbounds[2]; w.ymax = XYbounds[3];
+    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin;
+    return collides(w, x, y, yaw) ? 1 : 0;
+}
+
+}  // extern "C"

@@ -300,9 +300,19 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
             for (int i = 0; i < 8; i++) hz[i] = hb[i] = Ht[i] = 0;
 #pragma unroll
             for (int i = 0; i < 36; i++) Hp[i] = 0;
-            double x[4];
+            // every global load of this stage is issued here, before the first store to the stage record: the record may alias the
+            // iterate as far as the compiler knows, so a load placed after a store would cost its own memory round trip
+            const int kc = k < N ? k : N - 1, km = k >= 1 ? k - 1 : 0, kn = k + 1 < N ? k + 1 : kc;
+            double x[4], xn[4], pi[4], pim[4], nu4[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i];
+            for (int i = 0; i < 4; i++) {
+                x[i] = z[l.x + 4 * k + i]; xn[i] = z[l.x + 4 * (kc + 1) + i]; pi[i] = z[l.pi + 4 * kc + i]; pim[i] = z[l.pi + 4 * km + i];
+                nu4[i] = z[l.nu + i];
+            }
+            const double u[2] = {z[l.u + 2 * kc], z[l.u + 2 * kc + 1]}, um[2] = {z[l.u + 2 * km], z[l.u + 2 * km + 1]};
+            const double un[2] = {z[l.u + 2 * kn], z[l.u + 2 * kn + 1]}, ygn = z[l.yg + kn];
+            const double zuL[2] = {z[l.zuL + 2 * kc], z[l.zuL + 2 * kc + 1]}, zuU[2] = {z[l.zuU + 2 * kc], z[l.zuU + 2 * kc + 1]};
+            const double ss = z[l.ss + kc], yg = z[l.yg + kc], zssL = z[l.zssL + kc], zssU = z[l.zssU + kc];
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
             const double gx[4] = {2e-3 * (x[0] - rx), 2e-3 * (x[1] - ry), 2 * c.wpsi * (x[2] - ryaw), 2e-4 * x[3]};
             const double hx[4] = {2e-3, 2e-3, 2 * c.wpsi, 2e-4};
@@ -329,14 +339,13 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     double e = fabs(x[i] - c.xF[i]); if (e > pmax) pmax = e; lth += e;
-                    double r = z[l.pi + 4 * (N - 1) + i] + z[l.nu + i];
+                    double r = pi[i] + nu4[i];
                     hz[i] += r; hb[i] += r;
                     if (fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
-                    lsy += fabs(z[l.nu + i]);
+                    lsy += fabs(nu4[i]);
                 }
             } else {
-                const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
-                const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
+                const double w[2] = {k ? um[0] : 0.0, k ? um[1] : 0.0};
                 const double cu[2] = {0.01, c.wa};
                 const double rr = 0.1 / (q * q), e1 = u[0] - w[0], e2 = u[1] - w[1], rv = rr * (e1 * e1 + e2 * e2);
                 lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rv;
@@ -345,7 +354,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double ei = i ? e2 : e1, lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     const double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
                     hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
-                    B2 b = bound2(u[i], lo, hi, z[l.zuL + 2 * k + i], z[l.zuU + 2 * k + i], mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmu, lsz);
                     hz[6 + i] += b.gz; hb[6 + i] += b.gb;
                     lbar += log(u[i] - lo) + log(hi - u[i]);
                     HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
@@ -354,9 +363,9 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 }
                 if (!c.fixTime) { lgtz += -2 * rv / t; lgtb += -2 * rv / t; lHtt += 6 * rv / (t * t); }
                 {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
-                    const double g = (w[0] - u[0]) / q, ss = z[l.ss + k], yg = z[l.yg + k];
+                    const double g = (w[0] - u[0]) / q;
                     const double gg[3] = {1 / q, -1 / q, c.fixTime ? 0.0 : -g / t};
-                    B2 b = bound2(ss, -OB_SSB, OB_SSB, z[l.zssL + k], z[l.zssU + k], mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmu, lsz);
                     lbar += log(ss + OB_SSB) + log(OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
@@ -376,15 +385,13 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g / (t * t); }
                 }
                 {   // dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
-                    DynOut dy; double HL[5][5], pi[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) pi[i] = z[l.pi + 4 * k + i];
+                    DynOut dy; double HL[5][5];
                     dyn_derivs(c, x, u, t, pi, dy, HL);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
 #pragma unroll
                         for (int j = 0; j < 5; j++) rec[AS_DF + 5 * i + j] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
-                        double r = z[l.x + 4 * (k + 1) + i] - dy.F[i];
+                        double r = xn[i] - dy.F[i];
                         rec[AS_DD + i] = -r; if (fabs(r) > pmax) pmax = fabs(r); lth += fabs(r);
                         lsy += fabs(pi[i]);
                     }
@@ -402,7 +409,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     for (int i = 0; i < 4; i++) { ATpi[2] += dy.dF[i][0] * pi[i]; ATpi[3] += dy.dF[i][1] * pi[i]; }
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        double r = (k >= 1 ? z[l.pi + 4 * (k - 1) + i] : 0.0) - ATpi[i];
+                        double r = (k >= 1 ? pim[i] : 0.0) - ATpi[i];
                         hz[i] += r; hb[i] += r;
                         if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
                     }
@@ -423,8 +430,8 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 {   // dual infeasibility of u_k: own part + copy part living in stage k+1
                     double wn[2] = {0, 0};
                     if (k + 1 < N) {
-                        wn[0] = -2 * rr * (z[l.u + 2 * k + 2] - u[0]) + (1 / q) * z[l.yg + k + 1];
-                        wn[1] = -2 * rr * (z[l.u + 2 * k + 3] - u[1]);
+                        wn[0] = -2 * rr * (un[0] - u[0]) + (1 / q) * ygn;
+                        wn[1] = -2 * rr * (un[1] - u[1]);
                     }
 #pragma unroll
                     for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; if (fabs(tot) > dmax) dmax = fabs(tot); }

@@ -1,0 +1,118 @@
+"""
+Host-side warm-start planner: ctypes front end of libobca_plan.so (obca_amd/csrc/obca_planner.cpp, a compact Hybrid A*) and the
+conversion of its path into the (rx, ry, ryaw, xWS, uWS, Ts) arrays the signed-distance entry points take.
+
+Mirrors the step before the hot path in the reference: /root/reference/AutonomousParking/main.jl:216-252 (hybrid A* -> rx, ry, ryaw ->
+velocity profile -> down-sampling to the horizon N); SURVEY.md section 8f "next-2".  CPU only, no GPU involved.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from . import scenarios as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "obca_planner.cpp")
+_LIB = os.path.join(_HERE, "csrc", "libobca_plan.so")
+_D = C.POINTER(C.c_double); _I = C.POINTER(C.c_int)
+_lib = None
+
+
+def build_library(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", _LIB, _SRC])
+    return _LIB
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_library())
+    return _lib
+
+
+DEFAULT_OPTS = dict(xy_res=0.25, yaw_res_deg=7.5, step=0.6, max_steer=0.6, steer_samples=2, margin=0.1, goal_xy_tol=0.3,
+                    goal_yaw_tol_deg=8.0, reverse_cost=1.5, switch_cost=2.0, steer_cost=0.3, max_expansions=400000)
+
+
+def hybrid_astar(start, goal, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.XYBOUNDS, **kw):
+    """start, goal: (x, y, yaw); obstacles as H-rep rows (vOb = rows per obstacle).  Returns (path (K,3), dir (K,), expansions) or None."""
+    o = dict(DEFAULT_OPTS); o.update(kw)
+    opts = np.array([o[k] for k in DEFAULT_OPTS], float)
+    vOb = np.ascontiguousarray(vOb, np.int32); A = np.ascontiguousarray(A, float); b = np.ascontiguousarray(b, float)
+    cap = 20000; path = np.zeros((cap, 3)); dr = np.zeros(cap, np.int32); nexp = C.c_int(0)
+    s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()
+    e = np.ascontiguousarray(ego, float); xy = np.ascontiguousarray(XYbounds, float)
+    n = _load().obca_plan_hybrid_astar(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
+                                       b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D),
+                                       path.ctypes.data_as(_D), dr.ctypes.data_as(_I), C.c_int(cap), C.byref(nexp))
+    if n < 0:
+        raise ValueError({-1: "bad arguments", -2: "start or goal pose collides"}[n])
+    if n == 0:
+        return None
+    return path[:n].copy(), dr[:n].copy(), nexp.value
+
+
+def collides(pose, vOb, A, b, ego=S.EGO, XYbounds=S.XYBOUNDS, margin=0.0):
+    vOb = np.ascontiguousarray(vOb, np.int32); A = np.ascontiguousarray(A, float); b = np.ascontiguousarray(b, float)
+    e = np.ascontiguousarray(ego, float); xy = np.ascontiguousarray(XYbounds, float)
+    return bool(_load().obca_plan_collides(C.c_double(pose[0]), C.c_double(pose[1]), C.c_double(pose[2]), C.c_int(len(vOb)), vOb.ctypes.data_as(_I),
+                                           A.ctypes.data_as(_D), b.ctypes.data_as(_D), e.ctypes.data_as(_D), xy.ctypes.data_as(_D), C.c_double(margin)))
+
+
+def path_to_warm_start(path, dr, N, xF=None, v_nom=0.5, L=S.L_WHEELBASE):
+    """resample the planner path uniformly in arc length to N+1 stages (main.jl:237-252 down-samples the smoothed profile instead) and
+    derive the state / input warm start: speed +-v_nom (0 at both ends and at direction switches), steering from the path curvature.
+    xF (optional) replaces the last pose so that the warm start ends on the NLP's terminal state."""
+    P = np.asarray(path, float).copy(); dr = np.asarray(dr, float)
+    P[:, 2] = np.unwrap(P[:, 2])
+    if xF is not None:
+        P[-1, :2] = xF[:2]; P[-1, 2] = P[-2, 2] + ((xF[2] - P[-2, 2] + np.pi) % (2 * np.pi) - np.pi)
+    seg = np.hypot(np.diff(P[:, 0]), np.diff(P[:, 1])); cum = np.concatenate([[0], np.cumsum(seg)]); tot = cum[-1]
+    ss = np.linspace(0, tot, N + 1)
+    X = np.interp(ss, cum, P[:, 0]); Y = np.interp(ss, cum, P[:, 1]); yaw = np.interp(ss, cum, P[:, 2])
+    idx = np.clip(np.searchsorted(cum, ss, side="left"), 1, len(cum) - 1)
+    d = dr[idx]; d[0] = dr[min(1, len(dr) - 1)]
+    Ts = tot / (N * v_nom)
+    v = d * v_nom; v[0] = 0; v[-1] = 0
+    for i in range(1, N):
+        if d[i] != d[i + 1]:
+            v[i] = 0
+    a = np.clip(np.diff(v) / Ts, -0.4, 0.4)
+    dpsi = np.diff(yaw); dsv = np.maximum(np.diff(ss), 1e-9) * np.where(d[1:] == 0, 1, d[1:])
+    delta = np.clip(np.arctan(L * dpsi / dsv), -0.6, 0.6)
+    return Ts, np.stack([X, Y, yaw, v], 1), np.stack([delta, a], 1)
+
+
+# search settings per scenario: the 6 m bay of the parallel scenario leaves 0.65 m at either end of the car, which needs a fine grid;
+# nominal speeds follow the reference's sampling times (0.6 s and 0.9 s per 0.3 m of path, main.jl:46-50,66 and the scenario tables)
+SCENARIO_OPTS = {"backwards": (dict(), 0.5),
+                 "parallel": (dict(step=0.2, xy_res=0.1, yaw_res_deg=3.0, margin=0.02, max_expansions=2000000), 0.25)}
+
+
+def warm_start(sc, x0, xF, N, **kw):
+    """Hybrid A* warm start of one instance of a scenario table (S.BACKWARDS / S.PARALLEL): returns (Ts, xWS (N+1,4), uWS (N,2)) or None."""
+    A, b, vrows = S.scenario_hrep(sc)
+    o, v_nom = SCENARIO_OPTS.get(sc["name"], (dict(), 0.5))
+    o = dict(o); o.update(kw)
+    r = hybrid_astar(np.asarray(x0, float)[:3], np.asarray(xF, float)[:3], vrows, A, b, **o)
+    if r is None:
+        return None
+    return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom)
+
+
+def _ws_job(args):
+    name, x0, xF, N = args
+    return warm_start(S.BACKWARDS if name == "backwards" else S.PARALLEL, x0, xF, N)
+
+
+def warm_start_many(sc, x0, xF, N, workers=None):
+    """warm starts of a batch on the host cores (one search per process)."""
+    jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N) for a, g in zip(x0, xF)]
+    workers = min(len(jobs), workers or os.cpu_count() or 1)
+    if workers <= 1 or len(jobs) < 4:
+        return [_ws_job(j) for j in jobs]
+    _load()
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_ws_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))

@@ -178,19 +178,38 @@ def warm_start_parallel(x0, xF, N, R=4.5):
     return Ts, xWS, uWS
 
 
-def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False):
-    """Synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0."""
+def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, workers=None):
+    """Synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0.
+    planner=None: geometric line/arc primitives for the backwards scenario, Hybrid A* (obca_amd/planner.py) for the parallel one, whose
+    6 m bay needs a multi-manoeuvre path; planner=True/False forces the choice.  Instances for which the planner finds no path
+    are re-drawn."""
     rng = np.random.default_rng(seed)
     A, b, vrows = scenario_hrep(sc)
-    ws = warm_start_backwards if sc["name"] == "backwards" else warm_start_parallel
+    use_planner = (sc["name"] != "backwards") if planner is None else bool(planner)
     x0 = np.zeros((B, 4)); xF = np.zeros((B, 4)); Ts = np.zeros(B)
     xWS = np.zeros((B, N + 1, 4)); uWS = np.zeros((B, N, 2))
+    draw = lambda: np.array([rng.uniform(-10, 10), rng.uniform(6.5, 9.5), rng.uniform(-0.2, 0.2), 0.0])
     for i in range(B):
-        x0[i] = [rng.uniform(-10, 10), rng.uniform(6.5, 9.5), rng.uniform(-0.2, 0.2), 0.0]
+        x0[i] = draw()
         xF[i] = sc["xF"]
         if goal_jitter:
             xF[i, 0] = rng.uniform(-1.85, -0.85)
-        Ts[i], xWS[i], uWS[i] = ws(x0[i], xF[i], N)
+    if not use_planner:
+        ws = warm_start_backwards if sc["name"] == "backwards" else warm_start_parallel
+        for i in range(B):
+            Ts[i], xWS[i], uWS[i] = ws(x0[i], xF[i], N)
+    else:
+        from . import planner as PL
+        todo = list(range(B))
+        while todo:
+            res = PL.warm_start_many(sc, x0[todo], xF[todo], N, workers=workers)
+            nxt = []
+            for i, r in zip(todo, res):
+                if r is None:
+                    x0[i] = draw(); nxt.append(i)
+                else:
+                    Ts[i], xWS[i], uWS[i] = r
+            todo = nxt
     return dict(x0=x0, xF=xF, Ts=Ts, xWS=xWS, uWS=uWS, A=A, b=b, vOb=vrows, N=N, L=L_WHEELBASE,
                 ego=EGO.copy(), XYbounds=XYBOUNDS.copy())
 

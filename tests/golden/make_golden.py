@@ -4,6 +4,8 @@ Generates the fixtures under tests/golden/ (run from the repo root:  python test
   dense_N8.npz      : the dense textbook IPM (oracle/ipm_dense.py, autograd derivatives, dense LDL^T) on the backwards
                       scenario at N=8 -- the independent cross-check of the structured oracle (takes ~1 min, hence a fixture)
   oracle_cfg2.npz   : structured C oracle on the first 8 instances of config 2 (backwards parking, N=80, seed 20260925)
+  oracle_cfg3.npz   : structured C oracle on 6 instances of config 3 (parallel parking, 4 obstacles, N=80) with Hybrid A* warm starts
+                      (obca_amd/planner.py); the fixture stores the warm starts too, so the test does not depend on the planner
   dualws_known.npz  : poses + closed-form rectangle/half-plane distances for the DualMultWS known-answer test
 
 The reference itself (Julia 0.6 + JuMP + IPOPT) cannot run in this environment and ships no golden vectors
@@ -53,6 +55,21 @@ def oracle_cases(sc, B, name, goal_jitter=False):
     print(name, meta["exitflag"], meta["iters"])
 
 
+def oracle_cfg3(B=6, N=80):
+    bt = S.make_batch(S.PARALLEL, B, N)
+    keys = ("xp", "up", "lp", "np", "sl")
+    res = {k: [] for k in keys}; meta = dict(exitflag=[], iters=[], obj=[], t=[])
+    for i in range(B):
+        xWS = bt["xWS"][i]
+        r = O.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                  bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        for k in keys: res[k].append(r[k])
+        for k in meta: meta[k].append(r[k])
+    np.savez(os.path.join(OUT, "oracle_cfg3.npz"), B=B, N=N, x0=bt["x0"], xF=bt["xF"], Ts=bt["Ts"], xWS=bt["xWS"], uWS=bt["uWS"],
+             **{k: np.array(v) for k, v in res.items()}, **{k: np.array(v) for k, v in meta.items()})
+    print("oracle_cfg3.npz", meta["exitflag"], meta["iters"])
+
+
 def dualws_known():
     # single half-plane obstacle a'p <= beta (unit a), rectangle centre c = (X+1.35 cos, Y+1.35 sin), half extents (2.35, 1):
     # d = max(0, -(a'c - beta) ... ) -- the obstacle is {p : a'p <= beta}; the car is outside it when a'c - support > beta
@@ -75,5 +92,6 @@ def dualws_known():
 if __name__ == "__main__":
     dualws_known()
     oracle_cases(S.BACKWARDS, 8, "oracle_cfg2.npz")
+    oracle_cfg3()
     if "--dense" in sys.argv:
         dense_case(8)

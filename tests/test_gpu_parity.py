@@ -63,6 +63,31 @@ def test_parking_matches_golden_fixture(OA):
     assert np.abs(out["obj"] - g["obj"]).max() < 1e-7
 
 
+def test_parking_matches_oracle_config3_parallel(OA, oracle):
+    """BASELINE config 3: parallel parking, 4 obstacles / 6 half-space rows, Hybrid A* warm starts (golden fixture + a fresh batch)"""
+    import checkers as K
+    g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    bt = dict(x0=g["x0"], xF=g["xF"], Ts=g["Ts"], xWS=g["xWS"], uWS=g["uWS"], A=A, b=b, vOb=v, N=N, L=S.L_WHEELBASE, ego=S.EGO, XYbounds=S.XYBOUNDS)
+    out, _ = _solve_batch(OA, bt)
+    assert (out["exitflag"] == 1).all() and (out["iters"] == g["iters"]).all()
+    assert np.abs(out["xp"] - g["xp"]).max() < TOL_X and np.abs(out["up"] - g["up"]).max() < TOL_X
+    assert np.abs(out["obj"] - g["obj"]).max() < TOL_F * np.abs(g["obj"]).max()
+    bt = S.make_batch(S.PARALLEL, 32, N, seed=7)
+    out, xWS = _solve_batch(OA, bt)
+    assert (out["exitflag"] == 1).mean() >= 0.9
+    for i in range(0, 32, 5):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"]
+        assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+    for i in np.where(out["exitflag"] == 1)[0]:
+        ts = out["timeScale"][i]
+        args = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], 4, bt["vOb"], bt["A"], bt["b"],
+                out["xp"][i], out["up"][i], out["lp"][i], out["np"][i], ts, 0)
+        assert K.feasible(K.parking_constraints_full(*args, out["sl"][i]), tol=1e-4)
+
+
 def test_full_size_properties_config2(OA):
     """B=1024 (BASELINE config 2): size-independent properties -- every converged instance passes the reference's own
     acceptance test (ParkingConstraints.jl @5e-5) and the full checker; boundary conditions hold exactly; solving twice is

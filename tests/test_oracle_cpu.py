@@ -85,6 +85,24 @@ def test_reference_checker_accepts_oracle_solutions(oracle):
         assert g["sl"][i].min() > -0.005 - 1e-6
 
 
+def test_oracle_config3_parallel_parking_golden_and_reference_checker(oracle):
+    """BASELINE config 3: the parallel scenario (4 obstacles, main.jl:151-162) from Hybrid A* warm starts stored in the fixture"""
+    import checkers as K
+    g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    assert len(v) == 4 and int(v.sum()) == 6                                   # SURVEY 8: nOb = 4, M = 6
+    for i in range(B):
+        xWS = g["xWS"][i]
+        r = oracle.parking_signed_dist(g["x0"][i], g["xF"][i], N, g["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b,
+                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, g["uWS"][i])
+        assert r["exitflag"] == 1 == g["exitflag"][i] and r["iters"] == g["iters"][i]
+        assert np.abs(r["xp"] - g["xp"][i]).max() < 1e-9 and np.abs(r["up"] - g["up"][i]).max() < 1e-9
+        ts = np.full(N + 1, r["t"])
+        args = (g["x0"][i], g["xF"][i], N, g["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 4, v, A, b, r["xp"], r["up"], r["lp"], r["np"], ts, 0)
+        assert K.feasible(K.parking_constraints_full(*args, r["sl"]))          # every row of the NLP, with the slack
+        assert r["sl"].max() < 0.02                                            # penetration below 2 cm: the bay is 1.3 m longer than the car
+
+
 def test_newton_direction_vs_dense_autograd(oracle, backwards):
     """closed-form derivatives + condensation + Riccati + border == dense solve of the autograd KKT system"""
     torch = pytest.importorskip("torch")

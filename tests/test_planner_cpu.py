@@ -1,0 +1,46 @@
+"""Host-side Hybrid A* warm-start planner (obca_amd/planner.py, csrc/obca_planner.cpp): the step before the hot path."""
+import numpy as np
+import pytest
+from obca_amd import scenarios as S, planner as PL
+
+
+@pytest.mark.parametrize("sc", [S.BACKWARDS, S.PARALLEL], ids=["backwards", "parallel"])
+def test_plan_is_collision_free_and_reaches_the_goal(sc):
+    A, b, v = S.scenario_hrep(sc)
+    o, _ = PL.SCENARIO_OPTS[sc["name"]]
+    path, dr, nexp = PL.hybrid_astar(sc["x0"][:3], sc["xF"][:3], v, A, b, **o)
+    assert np.allclose(path[0], sc["x0"][:3]) and nexp > 0
+    assert np.hypot(*(path[-1, :2] - sc["xF"][:2])) <= 0.3 + 1e-9
+    assert abs((path[-1, 2] - sc["xF"][2] + np.pi) % (2 * np.pi) - np.pi) <= np.deg2rad(8) + 1e-9
+    assert not any(PL.collides(p, v, A, b) for p in path)                      # exact rectangle / convex-set test, no inflation
+    assert set(np.unique(dr)) <= {-1, 1}
+    # kinematics: consecutive poses lie on arcs no tighter than the minimum turning radius (0.2 m sub-steps)
+    ds = np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1])); dpsi = np.abs(np.diff(np.unwrap(path[:, 2])))
+    assert ds.max() < 0.21 and (dpsi <= 0.2 * np.tan(0.6) / S.L_WHEELBASE + 1e-9).all()      # 0.2 m of arc per sub-step
+    # the parallel bay is too short for a single reverse S-curve: the plan changes direction at least twice
+    if sc["name"] == "parallel":
+        assert (np.diff(dr) != 0).sum() >= 2
+
+
+def test_collision_test_known_answers():
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    assert not PL.collides(S.PARALLEL["xF"], v, A, b) and not PL.collides(S.PARALLEL["x0"], v, A, b)
+    assert PL.collides([-1.35, 2.9, 0.0], v, A, b)              # rear-right corner below the bay floor y = 2.5 + width
+    assert PL.collides([0.0, 4.0, 0.0], v, A, b)                # nose through the right wall x = 3
+    assert PL.collides([0.0, 20.0, 0.0], v, A, b)               # outside XYbounds
+    with pytest.raises(ValueError):
+        PL.hybrid_astar([0.0, 4.0, 0.0], S.PARALLEL["xF"][:3], v, A, b)
+
+
+def test_path_to_warm_start_shapes_and_consistency():
+    sc = S.PARALLEL; N = 80
+    Ts, xWS, uWS = PL.warm_start(sc, sc["x0"], sc["xF"], N)
+    assert xWS.shape == (N + 1, 4) and uWS.shape == (N, 2) and Ts > 0
+    assert np.allclose(xWS[0, :3], sc["x0"][:3]) and np.allclose(xWS[-1, :3], sc["xF"][:3], atol=1e-12)
+    assert xWS[0, 3] == 0 and xWS[-1, 3] == 0 and np.abs(xWS[:, 3]).max() <= 0.25 + 1e-12
+    assert np.abs(uWS[:, 0]).max() <= 0.6 and np.abs(uWS[:, 1]).max() <= 0.4
+    step = np.hypot(np.diff(xWS[:, 0]), np.diff(xWS[:, 1]))
+    assert step.max() < 1.5 * step.mean()                                       # uniform in arc length
+    # batch helper: same result per instance, in order
+    r = PL.warm_start_many(sc, np.stack([sc["x0"]] * 4), np.stack([sc["xF"]] * 4), N, workers=2)
+    assert all(np.array_equal(q[1], xWS) for q in r)
