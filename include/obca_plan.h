@@ -1,0 +1,33 @@
+/*
+ * obca_plan.h -- C ABI of libobca_plan.so: host-side (CPU) warm-start planner for the parking scenarios.
+ *
+ * Replaces, for the purposes of producing the warm start the signed-distance NLP needs, the planner the reference calls before the
+ * hot path:  hybrid_a_star(...) at AutonomousParking/main.jl:216-236 (hybrid_a_star.jl, with collision_check.jl / reeds_shepp.jl /
+ * a_star.jl behind it).  It is NOT on the GPU hot path; it is the step before it ("next-2").
+ * Obstacles use the same convention as include/obca_hip.h: nOb convex obstacles, vOb[j] half-space rows each, A row-major (M x 2), b.
+ */
+#ifndef OBCA_PLAN_H
+#define OBCA_PLAN_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Hybrid A* from start (x, y, yaw) to goal.  ego = [front, left, rear, right] extents from the rear axle (main.jl:73), L = wheelbase,
+ * XYbounds = [xmin, xmax, ymin, ymax] of the rear-axle position.
+ * opts (NULL = defaults): {xy resolution 0.25, yaw resolution [deg] 7.5, primitive length 0.6, max steer 0.6, steer samples per side 2,
+ *   collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance [deg] 8, reverse cost 1.5, switch cost 2.0, steer cost 0.3,
+ *   max expansions 400000}.
+ * Output: path[3k..3k+2] = x, y, yaw of node k (0.2 m apart), dir[k] = +1 / -1 (motion that led to the node), at most cap nodes.
+ * Returns the number of nodes (>= 2); 0 = no path; -1 = bad arguments / cap too small; -2 = start or goal pose collides. */
+int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                           const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
+                           int *expansions /* may be NULL */);
+
+/* 1 if the car rectangle at (x, y, yaw), inflated by margin, overlaps an obstacle or leaves XYbounds (the planner's own test). */
+int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, const double *A, const double *b, const double ego[4],
+                       const double XYbounds[4], double margin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
+#include "../../include/obca_plan.h"
 
 namespace {
 

@@ -44,3 +44,12 @@ def test_path_to_warm_start_shapes_and_consistency():
     # batch helper: same result per instance, in order
     r = PL.warm_start_many(sc, np.stack([sc["x0"]] * 4), np.stack([sc["xF"]] * 4), N, workers=2)
     assert all(np.array_equal(q[1], xWS) for q in r)
+
+
+def test_planner_library_exports_every_symbol_of_its_header():
+    import ctypes as C, os, re
+    from conftest import ROOT
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
+    lib = C.CDLL(PL.build_library())
+    assert syms == ["obca_plan_collides", "obca_plan_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
