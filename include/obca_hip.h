@@ -94,10 +94,15 @@ int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double 
                                       const obca_opts *opts /* NULL: defaults */, double *xp, double *up, double *timeScale /* (N+1) x B */,
                                       int *exitflag /* B */, double *lp /* 30 x (N+1) x B */, double *slack /* 5 x (N+1) x B, may be NULL */,
                                       double *info /* 8 x B, may be NULL */);
+/* QuadcopterDist(x0,xF,N,Ts,R,ob1..ob5,xWS,uWS,timeWS) -- QuadcopterNavigation/QuadcopterDist.jl:25-282 (call site mainQuadcopter.jl:145):
+ * the collision-free sibling: no slack variable (:47,:65,:165...), x[10] in [-1.5, 3] (:88), exit flag 0/1 only. */
+int obca_quadcopter_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
+                               const double *ob, const double *xWS, const double *uWS /* ignored */, const double *timeWS, int dual_ws,
+                               const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *info);
 int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out);
 int obca_quad_batch_destroy(obca_quad_batch *bt);
 int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
-                           const double *xWS, const double *timeWS, int dual_ws);
+                           const double *xWS, const double *timeWS, int dual_ws, int dist /* 1: QuadcopterDist formulation */);
 int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts);   /* asynchronous on the context's stream */
 int obca_quad_batch_sync(obca_quad_batch *bt);
 int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms);

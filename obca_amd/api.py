@@ -73,7 +73,7 @@ EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts"
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
            "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
-           "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
+           "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
            "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
 
@@ -312,14 +312,14 @@ class QuadBatch:
         self._h = C.c_void_p()
         ctx._check(_load().obca_quad_batch_create(ctx._h, C.c_int(self.B), C.c_int(self.N), C.byref(self._h)), "obca_quad_batch_create")
 
-    def upload(self, x0, xF, Ts, R, ob, xWS, timeWS, dual_ws=True):
+    def upload(self, x0, xF, Ts, R, ob, xWS, timeWS, dual_ws=True, dist=False):
         B, N = self.B, self.N
         Tsv = np.broadcast_to(np.asarray(Ts, float), (B,)).copy(); tw = np.broadcast_to(np.asarray(timeWS, float), (B,)).copy()
         obv = np.broadcast_to(np.asarray(ob, float).reshape(-1, 30) if np.size(ob) != 30 else np.asarray(ob, float).reshape(1, 30), (B, 30)).copy()
         xw = np.ascontiguousarray(np.asarray(xWS, float)[:, :N + 1]); assert xw.shape == (B, N + 1, 12)
         keep = [_d(Tsv), _d(np.reshape(x0, (B, 12))), _d(np.reshape(xF, (B, 12))), _d(obv), _d(xw), _d(tw)]
         p = [k[1] for k in keep]
-        rc = _load().obca_quad_batch_upload(self._h, p[0], C.c_double(R), p[1], p[2], p[3], p[4], p[5], C.c_int(int(bool(dual_ws))))
+        rc = _load().obca_quad_batch_upload(self._h, p[0], C.c_double(R), p[1], p[2], p[3], p[4], p[5], C.c_int(int(bool(dual_ws))), C.c_int(int(bool(dist))))
         self.ctx._check(rc, "obca_quad_batch_upload")
 
     def solve(self, opts=None, sync=True):
@@ -368,12 +368,12 @@ class QuadBatch:
             pass
 
 
-def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, opts=None, device=0):
+def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, opts=None, device=0, dist=False):
     """Batched QuadcopterSignedDist: x0,xF (B,12); ob (5,6) shared or (B,5,6); xWS (B,N+1,12); Ts, timeWS scalar or (B,)."""
     B = np.reshape(x0, (-1, 12)).shape[0]
     bt = QuadBatch(_ctx(device), B, N)
     try:
-        bt.upload(x0, xF, Ts, R, ob, xWS, timeWS, dual_ws)
+        bt.upload(x0, xF, Ts, R, ob, xWS, timeWS, dual_ws, dist)
         t0 = time.perf_counter()
         bt.solve(opts)
         dt = time.perf_counter() - t0
@@ -393,4 +393,12 @@ def QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, ti
     ob = np.stack([np.ravel(o)[:6] for o in (ob1, ob2, ob3, ob4, ob5)])
     r = quadcopter_signed_dist_batch(np.reshape(x0, (1, 12)), np.reshape(xF, (1, 12)), N, Ts, R, ob, np.asarray(xWS, float)[None, :N + 1],
                                      timeWS, dual_ws, opts, device)
+    return r["xp"][0], r["up"][0], r["timeScale"][0], int(r["exitflag"][0]), r["time"], r["lp"][0], _QUAD_STATUS[int(r["status"][0])]
+
+
+def QuadcopterDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS, opts=None, device=0, dual_ws=True):
+    """Drop-in for QuadcopterDist.jl:25 (the collision-free sibling: no slack variable): same arguments and 7-tuple as QuadcopterSignedDist."""
+    ob = np.stack([np.ravel(o)[:6] for o in (ob1, ob2, ob3, ob4, ob5)])
+    r = quadcopter_signed_dist_batch(np.reshape(x0, (1, 12)), np.reshape(xF, (1, 12)), N, Ts, R, ob, np.asarray(xWS, float)[None, :N + 1],
+                                     timeWS, dual_ws, opts, device, dist=True)
     return r["xp"][0], r["up"][0], r["timeScale"][0], int(r["exitflag"][0]), r["time"], r["lp"][0], _QUAD_STATUS[int(r["status"][0])]

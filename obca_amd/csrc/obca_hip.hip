@@ -415,7 +415,7 @@ int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 1
 }
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
-                           const double *xWS, const double *timeWS, int dual_ws) {
+                           const double *xWS, const double *timeWS, int dual_ws, int dist) {
     if (!bt) return -1;
     obca_ctx *ctx = bt->ctx;
     if (!Ts || !x0 || !xF || !ob || !xWS || !timeWS) { ctx->err = "obca_quad_batch_upload: NULL argument"; return -1; }
@@ -423,7 +423,7 @@ int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, cons
     std::vector<double> hp((size_t)B * d.s_prob, 0.0);
     for (int i = 0; i < B; i++) {
         double *p = hp.data() + (size_t)i * d.s_prob;
-        p[QPH_TS] = Ts[i]; p[QPH_R] = R; p[QPH_TWS] = timeWS[i]; p[QPH_DWS] = dual_ws ? 1.0 : 0.0;
+        p[QPH_TS] = Ts[i]; p[QPH_R] = R; p[QPH_TWS] = timeWS[i]; p[QPH_DWS] = dual_ws ? 1.0 : 0.0; p[QPH_DIST] = dist ? 1.0 : 0.0;
         memcpy(p + QPH_X0, x0 + (size_t)QX * i, sizeof(double) * QX); memcpy(p + QPH_XF, xF + (size_t)QX * i, sizeof(double) * QX);
         memcpy(p + QPH_OB, ob + (size_t)QOB * QL * i, sizeof(double) * QOB * QL);
         memcpy(p + QPH_SIZE, xWS + (size_t)QX * N1 * i, sizeof(double) * QX * N1);
@@ -474,21 +474,32 @@ int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double
     }
     return 0;
 }
-int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
-                                      const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
-                                      const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp,
-                                      double *slp, double *info) {
+static int quadcopter_batch(obca_ctx *ctx, int dist, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
+                            const double *ob, const double *xWS, const double *timeWS, int dual_ws, const obca_opts *opts, double *xp,
+                            double *up, double *timeScale, int *exitflag, double *lp, double *slp, double *info) {
     if (!ctx) return -1;
-    (void)uWS;                                         /* the reference ignores it too: inputs start at the hover speed, :202 */
     obca_quad_batch *bt = nullptr;
     int rc = obca_quad_batch_create(ctx, B, N, &bt);
     if (rc) return rc;
-    rc = obca_quad_batch_upload(bt, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws);
+    rc = obca_quad_batch_upload(bt, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, dist);
     if (!rc) rc = obca_quad_batch_solve(bt, opts);
     if (!rc) rc = obca_quad_batch_sync(bt);
     if (!rc) rc = obca_quad_batch_download(bt, xp, up, timeScale, exitflag, lp, slp, info);
     obca_quad_batch_destroy(bt);
     return rc;
+}
+int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
+                                      const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
+                                      const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp,
+                                      double *slp, double *info) {
+    (void)uWS;                                         /* the reference ignores it too: inputs start at the hover speed, :202 */
+    return quadcopter_batch(ctx, 0, B, N, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, opts, xp, up, timeScale, exitflag, lp, slp, info);
+}
+int obca_quadcopter_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
+                               const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
+                               const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *info) {
+    (void)uWS;                                         /* QuadcopterDist.jl:196 */
+    return quadcopter_batch(ctx, 1, B, N, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, opts, xp, up, timeScale, exitflag, lp, nullptr, info);
 }
 
 }  // extern "C"

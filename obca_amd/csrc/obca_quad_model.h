@@ -35,10 +35,10 @@ namespace quad {
 
 struct QConsts {
     double Ts, R, wH, x0[QX], xF[QX], gyro[3];
-    int N;
+    int N, dist;    // dist = 1: QuadcopterDist.jl (no slack variable, x[10] in [-1.5, 3]); 0: QuadcopterSignedDist.jl
 };
-OBCA_FN double q_xlb(int i) { return i < 3 ? 0.0 : (i == 3 ? -3.0 : (i < 6 ? -0.2 : -1.0)); }             // :78-94
-OBCA_FN double q_xub(int i) { return i < 2 ? 10.0 : (i == 2 ? 5.0 : (i == 3 ? 3.0 : (i < 6 ? 0.2 : 1.0))); }
+OBCA_FN double q_xlb(int i, int dist = 0) { return i < 3 ? 0.0 : (i == 3 ? -3.0 : (i < 6 ? -0.2 : (dist && i == 9 ? -1.5 : -1.0))); }   // :78-94, QuadcopterDist.jl:88
+OBCA_FN double q_xub(int i, int dist = 0) { return i < 2 ? 10.0 : (i == 2 ? 5.0 : (i == 3 ? 3.0 : (i < 6 ? 0.2 : (dist && i == 9 ? 3.0 : 1.0)))); }
 // stage-vector index of the local derivative variables
 OBCA_FN int q_vidx(int a) { return a < 3 ? 3 + a : (a < 6 ? 6 + a : QS + (a - 6)); }
 
@@ -128,7 +128,7 @@ OBCA_FN void q_obs_rows(const QConsts &c, const QObsIn &in, double r[2], double 
 #pragma unroll
     for (int i = 0; i < QL; i++) bl += in.b[i] * in.lam[i];
     r[0] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] - 1;
-    r[1] = -bl + in.p[0] * q[0] + in.p[1] * q[1] + in.p[2] * q[2] + 0.01 * in.s - c.R - in.so;
+    r[1] = -bl + in.p[0] * q[0] + in.p[1] * q[1] + in.p[2] * q[2] + (c.dist ? 0.0 : 0.01 * in.s) - c.R - in.so;
 }
 
 struct QObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
@@ -156,14 +156,15 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     }
     const double is = 1.0 / in.s, iso = 1.0 / in.so;
     const double gs = 1e2 + 2e3 * in.s + 0.01 * y[1], gso = -y[1];
-    const double r_s = gs - mu_b * is, r_so = gso - mu_b * iso;
-    const double iDs = 1.0 / (2e3 + in.zs * is + dw), iDso = 1.0 / (in.zso * iso + dw);
+    // QuadcopterDist has no slack variable: it is frozen (1/D_s = 0, no residual), every term below then drops out and ds = 0
+    const double r_s = c.dist ? 0.0 : gs - mu_b * is, r_so = gso - mu_b * iso;
+    const double iDs = c.dist ? 0.0 : 1.0 / (2e3 + in.zs * is + dw), iDso = 1.0 / (in.zso * iso + dw);
     if (MODE == 0) {
-        double rz = fabs(gs - in.zs); if (rz > st->dmax) st->dmax = rz;
+        double rz = c.dist ? 0.0 : fabs(gs - in.zs); if (rz > st->dmax) st->dmax = rz;
         rz = fabs(gso - in.zso); if (rz > st->dmax) st->dmax = rz;
-        double cc = in.s * in.zs; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+        double cc = c.dist ? 0.0 : in.s * in.zs; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (!c.dist && fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
         cc = in.so * in.zso; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
-        st->sumz += fabs(in.zs) + fabs(in.zso);
+        st->sumz += (c.dist ? 0.0 : fabs(in.zs)) + fabs(in.zso);
         if (fabs(cr[0]) > st->pmax) st->pmax = fabs(cr[0]); if (fabs(cr[1]) > st->pmax) st->pmax = fabs(cr[1]);
         st->sumy += fabs(y[0]) + fabs(y[1]);
     }

@@ -42,6 +42,7 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R
 #define QPH_OB 26
 #define QPH_TWS 56
 #define QPH_DWS 57
+#define QPH_DIST 58
 #define QPH_SIZE 64
 
 struct QShared {
@@ -69,12 +70,12 @@ enum { QPF_INIT = 0, QPF_ASM_OBS, QPF_ASM_STAGE, QPF_RIC, QPF_BORDER, QPF_CL, QP
 
 // bounds of primal variable i
 struct QBnd { double lo, hi; int hasL, hasU; double mult; };
-OBCA_FN QBnd q_bounds(const QLay &l, int N, int i) {
+OBCA_FN QBnd q_bounds(const QLay &l, int N, int i, int dist) {
     QBnd b; b.lo = 0; b.hi = 0; b.hasL = 0; b.hasU = 0; b.mult = 1;
-    if (i < l.u) { int k = i / QX, cI = i - k * QX; if (k >= 1) { b.lo = q_xlb(cI); b.hi = q_xub(cI); b.hasL = b.hasU = 1; } }
+    if (i < l.u) { int k = i / QX, cI = i - k * QX; if (k >= 1) { b.lo = q_xlb(cI, dist); b.hi = q_xub(cI, dist); b.hasL = b.hasU = 1; } }
     else if (i < l.t) { b.lo = Q_ULO; b.hi = Q_UHI; b.hasL = b.hasU = 1; }
     else if (i == l.t) { b.lo = Q_TLO; b.hi = Q_THI; b.hasL = b.hasU = 1; b.mult = N + 1; }
-    else { b.hasL = 1; }
+    else if (!(dist && i >= l.s && i < l.so)) { b.hasL = 1; }      // lam, s, so >= 0 (QuadcopterDist: no slack variable, frozen at 0)
     return b;
 }
 
@@ -103,12 +104,12 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
 #pragma unroll
             for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
-            fsl += 1e2 * in.s + 1e3 * in.s * in.s;
+            if (!c.dist) fsl += 1e2 * in.s + 1e3 * in.s * in.s;
             double r[2], q[3]; q_obs_rows(c, in, r, q);
             th += fabs(r[0]) + fabs(r[1]);
 #pragma unroll
             for (int i = 0; i < QL; i++) { fsl += 1e-4 * in.lam[i] * in.lam[i]; bar += log(in.lam[i]); }
-            bar += log(in.s) + log(in.so);
+            bar += (c.dist ? 0.0 : log(in.s)) + log(in.so);
         }
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
@@ -141,8 +142,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 hz[i] = gx; hb[i] = gx; xd[i] = (i >= 9 ? 2e-4 : 0.0) + dw;
                 if (i >= 9) lf += 1e-4 * x[i] * x[i];
                 if (k >= 1) {
-                    B2 b = bound2(x[i], q_xlb(i), q_xub(i), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmu, lsz);
-                    xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; lbar += log(x[i] - q_xlb(i)) + log(q_xub(i) - x[i]);
+                    B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmu, lsz);
+                    xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; lbar += log(x[i] - q_xlb(i, c.dist)) + log(q_xub(i, c.dist) - x[i]);
                 }
             }
             for (int j = 0; j < QOB; j++) {
@@ -275,7 +276,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     dinf = fmax(dinf, fabs(gtz));
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
-    out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2) * QOB * (N + 1);
+    out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2 - (c.dist ? 1 : 0)) * QOB * (N + 1);
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
 }
 
@@ -628,7 +629,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 d[l.x + QX * k + i] = dx;
                 if (i >= 9) gd += 2e-4 * xv * dx;
                 if (k >= 1) {
-                    const double dL = xv - q_xlb(i), dU = q_xub(i) - xv, zL = z[l.zL + l.x + QX * k + i], zU = z[l.zU + l.x + QX * k + i];
+                    const double dL = xv - q_xlb(i, c.dist), dU = q_xub(i, c.dist) - xv, zL = z[l.zL + l.x + QX * k + i], zU = z[l.zU + l.x + QX * k + i];
                     gd += (-mu / dL + mu / dU) * dx;
                     FTBP(dL, dx); FTBP(dU, -dx);
                     FTBZ(zL, mu / dL - zL - zL / dL * dx); FTBZ(zU, mu / dU - zU + zU / dU * dx);
@@ -701,8 +702,8 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
                 FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
             }
             d[l.s + it] = st.ds; d[l.so + it] = st.dso; d[l.yo + 2 * it] = st.dy[0]; d[l.yo + 2 * it + 1] = st.dy[1];
-            lgd += (1e2 + 2e3 * in.s - mu / in.s) * st.ds - mu / in.so * st.dso;
-            FTBP(in.s, st.ds); FTBZ(in.zs, mu / in.s - in.zs - in.zs / in.s * st.ds);
+            lgd += -mu / in.so * st.dso;
+            if (!c.dist) { lgd += (1e2 + 2e3 * in.s - mu / in.s) * st.ds; FTBP(in.s, st.ds); FTBZ(in.zs, mu / in.s - in.zs - in.zs / in.s * st.ds); }
             FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
         }
         sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
@@ -736,17 +737,17 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
             QObsIn in; q_load_obs(sh, z, k, j, in);
 #pragma unroll
             for (int i = 0; i < QL; i++) { in.lam[i] += alpha * d[l.lam + QL * it + i]; lbar += log(in.lam[i]); lf += 1e-4 * in.lam[i] * in.lam[i]; }
-            in.s += alpha * d[l.s + it]; in.so += alpha * d[l.so + it]; lbar += log(in.s) + log(in.so);
+            in.s += alpha * d[l.s + it]; in.so += alpha * d[l.so + it]; lbar += (c.dist ? 0.0 : log(in.s)) + log(in.so);
 #pragma unroll
             for (int i = 0; i < 3; i++) in.p[i] += alpha * d[l.x + QX * k + i];
             double r[2], q[3]; q_obs_rows(c, in, r, q);
             lth += fabs(r[0]) + fabs(r[1]);
-            lf += 1e2 * in.s + 1e3 * in.s * in.s;
+            if (!c.dist) lf += 1e2 * in.s + 1e3 * in.s * in.s;
         }
         for (int k = lane; k <= N; k += OB_NT) {
             double x[QX];
 #pragma unroll
-            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i] + alpha * d[l.x + QX * k + i]; if (k >= 1) lbar += log(x[i] - q_xlb(i)) + log(q_xub(i) - x[i]); }
+            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i] + alpha * d[l.x + QX * k + i]; if (k >= 1) lbar += log(x[i] - q_xlb(i, c.dist)) + log(q_xub(i, c.dist) - x[i]); }
             lf += 1e-4 * (x[9] * x[9] + x[10] * x[10] + x[11] * x[11]);
             if (k == N) {
 #pragma unroll
@@ -777,7 +778,7 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
     const QLay &l = sh.l; const int N = sh.c.N; gdbl *z = sh.inst.z; const gdbl *d = sh.inst.d;
     PAR(lane) {
         for (int i = lane; i < l.n; i += OB_NT) {
-            const QBnd b = q_bounds(l, N, i);
+            const QBnd b = q_bounds(l, N, i, sh.c.dist);
             double v = z[i]; const double dv = d[i];
             if (i < QX) continue;                        // x_0 is a constant
             if (b.hasL) { double zz = zstep(z[l.zL + i], v - b.lo, dv, mu, az); z[l.zL + i] = clampz(zz, v + alpha * dv - b.lo, mu, ks); }
@@ -796,7 +797,7 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         for (int i = lane; i < QX * (N + 1); i += OB_NT) z[l.x + i] = i < QX ? c.x0[i] : sh.inst.prob[QPH_SIZE + i];   // xWS, :201
         for (int i = lane; i < QU * N; i += OB_NT) z[l.u + i] = c.wH;                       // QuadcopterSignedDist.jl:202
         if (lane == 0) z[l.t] = timeWS;                                                   // :199
-        for (int i = lane; i < QOB * (N + 1); i += OB_NT) z[l.s + i] = 1.0;                // :210
+        for (int i = lane; i < QOB * (N + 1); i += OB_NT) z[l.s + i] = c.dist ? 0.0 : 1.0; // :210
         for (int i = lane; i < l.m; i += OB_NT) z[l.n + i] = 0.0;
         for (int i = lane; i < l.n; i += OB_NT) { z[l.zL + i] = 1.0; z[l.zU + i] = 1.0; }
         // stage / Riccati records: zero once, constants of the dense layout
@@ -830,7 +831,7 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
     PAR(lane) {
         for (int i = lane; i < l.n; i += OB_NT) {
             if (i < QX) continue;
-            const QBnd b = q_bounds(l, N, i);
+            const QBnd b = q_bounds(l, N, i, sh.c.dist);
             if (b.hasL && b.hasU) z[i] = push2(z[i], b.lo, b.hi, bound_push, bound_frac);
             else if (b.hasL) z[i] = fmax(z[i], b.lo + bound_push * fmax(1.0, fabs(b.lo)));
         }
@@ -855,7 +856,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     PAR(lane) {
         if (lane == 0) {
             QConsts &c = sh.c; const gdbl *p = sh.inst.prob;
-            c.N = N; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
+            c.N = N; c.dist = (int)p[QPH_DIST]; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
             for (int i = 0; i < QX; i++) { c.x0[i] = p[QPH_X0 + i]; c.xF[i] = p[QPH_XF + i]; }
             for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];                          // single-index x[10..12] = stage 1
             for (int i = 0; i < QOB * QL; i++) sh.ob[i] = p[QPH_OB + i];
@@ -943,7 +944,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     const double ssum = red_sum(sh.red[0]);
     SYNC();
     int ef = status == ST_OPTIMAL ? 1 : 0;
-    if (ef == 1 && ssum > 1e-3) ef = 2;
+    if (!sh.c.dist && ef == 1 && ssum > 1e-3) ef = 2;
     PAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f; info[3] = pinf; info[4] = dinf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
     SYNC();
 }

@@ -82,7 +82,7 @@ def unpack_solution(z, N, nOb, M):
 
 
 # ---------------------------------------------------------------- quadcopter path (obca_amd/csrc/obca_quad_solver.h)
-QPH_TS, QPH_R, QPH_X0, QPH_XF, QPH_OB, QPH_TWS, QPH_DWS, QPH_SIZE = 0, 1, 2, 14, 26, 56, 57, 64
+QPH_TS, QPH_R, QPH_X0, QPH_XF, QPH_OB, QPH_TWS, QPH_DWS, QPH_DIST, QPH_SIZE = 0, 1, 2, 14, 26, 56, 57, 58, 64
 QUAD_NMAX = 64
 
 
@@ -103,10 +103,10 @@ def quad_problem_len(N):
     return QPH_SIZE + 12 * (N + 1)
 
 
-def pack_quad_problem(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=1):
+def pack_quad_problem(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=1, dist=0):
     """problem record of one quadcopter instance: header, then xWS stage-contiguous (N+1, 12). ob: 5 x 6 [max; -min]."""
     p = np.zeros(quad_problem_len(N))
     p[QPH_TS] = Ts; p[QPH_R] = R; p[QPH_X0:QPH_X0 + 12] = x0; p[QPH_XF:QPH_XF + 12] = xF
-    p[QPH_OB:QPH_OB + 30] = np.asarray(ob, float).reshape(30); p[QPH_TWS] = timeWS; p[QPH_DWS] = float(int(dual_ws))
+    p[QPH_OB:QPH_OB + 30] = np.asarray(ob, float).reshape(30); p[QPH_TWS] = timeWS; p[QPH_DWS] = float(int(dual_ws)); p[QPH_DIST] = float(int(dist))
     p[QPH_SIZE:] = np.asarray(xWS, float)[:N + 1].reshape(-1)
     return p

@@ -15,8 +15,9 @@ XUB = np.array([10, 10, 5, 3, 0.2, 0.2, 1, 1, 1, 1, 1, 1.0])
 
 
 class QuadNLP:
-    def __init__(self, x0, xF, N, Ts, R, ob):
+    def __init__(self, x0, xF, N, Ts, R, ob, dist=False):
         self.N, self.Ts, self.R = N, float(Ts), float(R)
+        self.sw = 0.0 if dist else 1.0           # QuadcopterDist: the slack variable does not exist (kept in the vector, weight 0, no bound)
         self.x0 = torch.tensor(np.asarray(x0, float).ravel()); self.xF = torch.tensor(np.asarray(xF, float).ravel())
         self.ob = torch.tensor(np.asarray(ob, float).reshape(5, 6))
         self.wH = float(np.sqrt(MASS * GRAV / (KF * 4)))
@@ -32,7 +33,9 @@ class QuadNLP:
         lb[self.ix] = np.tile(XLB, N); ub[self.ix] = np.tile(XUB, N)
         lb[self.iu] = 1.2; ub[self.iu] = 7.8
         lb[self.it], ub[self.it] = 0.5, 2.0
-        lb[self.il] = 0; lb[self.isl] = 0; lb[self.iso] = 0
+        lb[self.il] = 0; lb[self.isl] = -np.inf if dist else 0; lb[self.iso] = 0
+        if dist:
+            lb[self.ix][9::12] = -1.5; ub[self.ix][9::12] = 3.0
         self.lb, self.ub = lb, ub
         self.mult = np.ones(o); self.mult[self.it] = N + 1
         self.m = 12 * N + 12 + 10 * N1
@@ -45,7 +48,7 @@ class QuadNLP:
     def f(self, v):
         x, u, t, lam, s, so = self.unpack(v)
         J = 1e-3 * ((self.wH - u) ** 2).sum() + 1e-2 * ((u[:-1] - u[1:]) ** 2).sum() + 1e-4 * (x[:, 9:12] ** 2).sum()
-        J = J + (self.N + 1) * (0.25 * t + 5 * t ** 2) + (1e2 * s + 1e3 * s ** 2).sum() + 1e-4 * (lam ** 2).sum()
+        J = J + (self.N + 1) * (0.25 * t + 5 * t ** 2) + self.sw * (1e2 * s + 1e3 * s ** 2).sum() + 1e-4 * (lam ** 2).sum()
         return J
 
     def c(self, v):
@@ -69,7 +72,7 @@ class QuadNLP:
         cterm = x[-1] - self.xF
         q = lam[:, :, :3] - lam[:, :, 3:]
         c1 = (q ** 2).sum(2) - 1
-        c2 = -(lam * self.ob[None]).sum(2) + (x[:, None, :3] * q).sum(2) + 0.01 * s - self.R - so
+        c2 = -(lam * self.ob[None]).sum(2) + (x[:, None, :3] * q).sum(2) + self.sw * 0.01 * s - self.R - so
         cob = torch.stack([c1, c2], 2).reshape(-1)
         return torch.cat([cdyn, cterm, cob])
 

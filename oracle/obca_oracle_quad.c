@@ -56,6 +56,7 @@ static const double INERT[3] = {3.9e-3, 4.4e-3, 4.9e-3};
 
 typedef struct {
     int N; double Ts, R, x0[NXS], xF[NXS], ob[NOB][NL], wH, gyro[3];
+    int dist;    /* 1: QuadcopterDist.jl (no slack variable, x[10] in [-1.5, 3]); 0: QuadcopterSignedDist.jl */
 } prob_t;
 
 typedef struct { int x, u, t, lam, s, so, n, pi, nu, yo, m; } lay_t;
@@ -80,10 +81,11 @@ static void model_init(model_t *M, const prob_t *p) {
     M->lb = xcalloc(n, 8); M->ub = xcalloc(n, 8); M->mult = xcalloc(n, 8);
     for (int i = 0; i < n; i++) { M->lb[i] = -INFINITY; M->ub[i] = INFINITY; M->mult[i] = 1; }
     for (int k = 1; k <= N; k++) for (int i = 0; i < NXS; i++) { M->lb[l->x + NXS * k + i] = XLB[i]; M->ub[l->x + NXS * k + i] = XUB[i]; }
+    if (p->dist) for (int k = 1; k <= N; k++) { M->lb[l->x + NXS * k + 9] = -1.5; M->ub[l->x + NXS * k + 9] = 3.0; }   /* QuadcopterDist.jl:88 */
     for (int i = 0; i < NU * N; i++) { M->lb[l->u + i] = 1.2; M->ub[l->u + i] = 7.8; }      /* :74-77 */
     M->lb[l->t] = 0.5; M->ub[l->t] = 2.0; M->mult[l->t] = N + 1;                               /* :97 */
     for (int i = 0; i < NL * NOB * (N + 1); i++) M->lb[l->lam + i] = 0;                         /* :99-103 */
-    for (int i = 0; i < NOB * (N + 1); i++) { M->lb[l->s + i] = 0; M->lb[l->so + i] = 0; }     /* :105 */
+    for (int i = 0; i < NOB * (N + 1); i++) { M->lb[l->s + i] = p->dist ? -INFINITY : 0; M->lb[l->so + i] = 0; }     /* :105; no slack variable in QuadcopterDist: it stays frozen at 0 here */
 }
 static void model_free(model_t *M) { free(M->lb); free(M->ub); free(M->mult); }
 
@@ -154,7 +156,7 @@ static void obs_rows(const prob_t *p, int j, const double *x, const double *lam,
     for (int i = 0; i < 3; i++) q[i] = lam[i] - lam[3 + i];
     for (int i = 0; i < NL; i++) bl += p->ob[j][i] * lam[i];
     c[0] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] - 1;
-    c[1] = -bl + x[0] * q[0] + x[1] * q[1] + x[2] * q[2] + 0.01 * s - p->R - so;
+    c[1] = -bl + x[0] * q[0] + x[1] * q[1] + x[2] * q[2] + (p->dist ? 0.0 : 0.01 * s) - p->R - so;
 }
 
 static void eval_f_theta(const model_t *M, const double *v, double *f, double *th1, double *thinf) {
@@ -172,7 +174,7 @@ static void eval_f_theta(const model_t *M, const double *v, double *f, double *t
         J += 1e-4 * (x[9] * x[9] + x[10] * x[10] + x[11] * x[11]);
         for (int j = 0; j < NOB; j++) {
             int bo = k * NOB + j; const double *lam = v + l->lam + NL * bo; double s = v[l->s + bo], c[2], q[3];
-            J += 1e2 * s + 1e3 * s * s;
+            if (!p->dist) J += 1e2 * s + 1e3 * s * s;
             for (int i = 0; i < NL; i++) J += 1e-4 * lam[i] * lam[i];
             obs_rows(p, j, x, lam, s, v[l->so + bo], c, q);
             for (int i = 0; i < 2; i++) { double r = fabs(c[i]); th += r; if (r > ti) ti = r; }
@@ -315,7 +317,8 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 rl_b[i] = gl + b.gb; F->Dl[i] = 2e-4 + b.Sig + dw;
             }
             { bnd_t b = bound_terms(M, l->s + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); double gs = 1e2 + 2e3 * s + 0.01 * yv[1];
-              if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = 2e3 + b.Sig + dw; }
+              if (!p->dist && fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = 2e3 + b.Sig + dw; }
+            if (p->dist) { F->r_s = 0; F->Ds = INFINITY; }       /* frozen: every 1/Ds term below vanishes, ds = 0 */
             { bnd_t b = bound_terms(M, l->so + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); double gs = -yv[1];
               if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_so = gs + b.gb; F->Dso = b.Sig + dw; }
             /* row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2 */
@@ -598,7 +601,7 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
                 gd += gu * dv[l->u + NU * k + j]; }
             gd += (N + 1) * (0.25 + 10 * t) * dv[l->t];
             for (int k = 0; k <= N; k++) { for (int i = 9; i < 12; i++) gd += 2e-4 * v[l->x + NXS * k + i] * dv[l->x + NXS * k + i];
-                for (int j = 0; j < NOB; j++) { int bo = k * NOB + j; gd += (1e2 + 2e3 * v[l->s + bo]) * dv[l->s + bo];
+                for (int j = 0; j < NOB; j++) { int bo = k * NOB + j; if (!p->dist) gd += (1e2 + 2e3 * v[l->s + bo]) * dv[l->s + bo];
                     for (int i = 0; i < NL; i++) gd += 2e-4 * v[l->lam + NL * bo + i] * dv[l->lam + NL * bo + i]; } }
         }
         double phi = f - mu * barrier_sum(M, v), amin;
@@ -638,8 +641,8 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
 }
 
 /* -------------------------------------------------------------- C entry points (ctypes) */
-static void setup_prob(prob_t *p, int N, double Ts, double R, const double *x0, const double *xF, const double *ob /* 5 x 6 */) {
-    memset(p, 0, sizeof *p);
+static void setup_prob(prob_t *p, int N, double Ts, double R, const double *x0, const double *xF, const double *ob /* 5 x 6 */, int dist) {
+    memset(p, 0, sizeof *p); p->dist = dist;
     p->N = N; p->Ts = Ts; p->R = R;
     memcpy(p->x0, x0, sizeof p->x0); memcpy(p->xF, xF, sizeof p->xF); memcpy(p->ob, ob, sizeof p->ob);
     p->wH = sqrt((MASS * GRAV) / (KF * 4));                    /* :62 */
@@ -679,11 +682,12 @@ static void quad_dual_ws(const prob_t *p, const lay_t *l, double *v) {
  * exitflag 0/1/2 (:229-234, :285-288); info[8] = {status, iterations, objective, pinf, dinf, mu, nreg, t}.
  */
 int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double *x0, const double *xF, const double *ob,
-                                       const double *xWS, double timeWS, int dual_ws, const opts_t *opt, double *xp, double *up, double *tsp,
+                                       const double *xWS, double timeWS, int flags /* bit 0: dual warm start, bit 1: QuadcopterDist */, const opts_t *opt, double *xp, double *up, double *tsp,
                                        double *lp, double *slp, int *exitflag, double *info) {
     prob_t p; model_t M; opts_t o;
     if (opt) o = *opt; else obca_oracle_quad_default_opts(&o);
-    setup_prob(&p, N, Ts, R, x0, xF, ob); model_init(&M, &p);
+    const int dual_ws = flags & 1, dist = (flags >> 1) & 1;
+    setup_prob(&p, N, Ts, R, x0, xF, ob, dist); model_init(&M, &p);
     const lay_t *l = &M.l; int n = l->n, m = l->m;
     double *v = xcalloc(n, 8), *y = xcalloc(m, 8), *zL = xcalloc(n, 8), *zU = xcalloc(n, 8);
     memcpy(v + l->x, xWS, sizeof(double) * NXS * (N + 1));                  /* :201 */
@@ -691,11 +695,11 @@ int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double 
     v[l->t] = timeWS;                                                       /* :199 */
     for (int i = 0; i < NL * NOB * (N + 1); i++) v[l->lam + i] = 0.05;      /* :204-208 */
     if (dual_ws) quad_dual_ws(&p, l, v);
-    for (int i = 0; i < NOB * (N + 1); i++) v[l->s + i] = 1.0;              /* :210 */
+    for (int i = 0; i < NOB * (N + 1); i++) v[l->s + i] = dist ? 0.0 : 1.0; /* :210 */
     result_t r; ipm_solve(&M, &o, v, y, zL, zU, &r);
     int ef = r.status == ST_OPTIMAL ? 1 : 0;                                /* flag = 1 branch, :229-234 */
     double ssum = 0; for (int i = 0; i < NOB * (N + 1); i++) ssum += v[l->s + i];
-    if (ef == 1 && ssum > 1e-3) ef = 2;                                     /* :285-288 */
+    if (!dist && ef == 1 && ssum > 1e-3) ef = 2;                            /* :285-288 (QuadcopterDist has no such check) */
     memcpy(xp, v + l->x, sizeof(double) * NXS * (N + 1)); memcpy(up, v + l->u, sizeof(double) * NU * N);
     for (int k = 0; k <= N; k++) tsp[k] = v[l->t];
     memcpy(lp, v + l->lam, sizeof(double) * NL * NOB * (N + 1));
@@ -709,8 +713,8 @@ int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double 
 /* test hook: one regularised Newton direction at a full primal-dual point */
 int obca_oracle_quad_newton(int N, double Ts, double R, const double *x0, const double *xF, const double *ob, const double *v,
                             const double *y, const double *zL, const double *zU, double mu, double dw, double dc, double rho,
-                            double *dv, double *dy, double *errs) {
-    prob_t p; model_t M; setup_prob(&p, N, Ts, R, x0, xF, ob); model_init(&M, &p);
+                            double *dv, double *dy, double *errs, int dist) {
+    prob_t p; model_t M; setup_prob(&p, N, Ts, R, x0, xF, ob, dist); model_init(&M, &p);
     kkt_t *K = kkt_alloc(&M);
     int ok = kkt_assemble(K, v, y, zL, zU, mu, dw, dc);
     double sdi = stage_dual_inf(K, y);

@@ -53,12 +53,13 @@ def warm_start(x0, xF, N, via=None):
     return xWS
 
 
-def quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1):
-    """mirrors QuadcopterSignedDist(x0,xF,N,Ts,R,ob1..ob5,xWS,uWS,timeWS) (QuadcopterSignedDist.jl:25); xWS (N+1,12) here."""
+def quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1, dist=0):
+    """mirrors QuadcopterSignedDist(x0,xF,N,Ts,R,ob1..ob5,xWS,uWS,timeWS) (QuadcopterSignedDist.jl:25); xWS (N+1,12) here.
+    dist=1: QuadcopterDist (QuadcopterDist.jl:25): no slack variable, x[10] in [-1.5, 3], no sum-slack exit flag."""
     a = [_d(v) for v in (x0, xF, np.reshape(ob, (5, 6)), np.asarray(xWS, float)[:N + 1])]
     xp = np.zeros((N + 1, 12)); up = np.zeros((N, 4)); ts = np.zeros(N + 1); lp = np.zeros((N + 1, 30)); sl = np.zeros((N + 1, 5))
     ef = C.c_int(0); info = np.zeros(8)
-    rc = lib().obca_oracle_quadcopter_signed_dist(C.c_int(N), C.c_double(Ts), C.c_double(R), a[0][1], a[1][1], a[2][1], a[3][1], C.c_double(timeWS), C.c_int(int(dual_ws)),
+    rc = lib().obca_oracle_quadcopter_signed_dist(C.c_int(N), C.c_double(Ts), C.c_double(R), a[0][1], a[1][1], a[2][1], a[3][1], C.c_double(timeWS), C.c_int(int(bool(dual_ws)) | (int(bool(dist)) << 1)),
                                                   C.byref(opts) if opts is not None else None, xp.ctypes.data_as(_D), up.ctypes.data_as(_D),
                                                   ts.ctypes.data_as(_D), lp.ctypes.data_as(_D), sl.ctypes.data_as(_D), C.byref(ef), info.ctypes.data_as(_D))
     assert rc == 0
@@ -66,11 +67,15 @@ def quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dua
                 iters=int(info[1]), obj=info[2], pinf=info[3], dinf=info[4], mu=info[5], nreg=int(info[6]), t=info[7])
 
 
-def newton(N, Ts, R, x0, xF, ob, v, y, zL, zU, mu, dw, dc, rho=1e3):
+def quadcopter_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1):
+    return quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS, opts, dual_ws, dist=1)
+
+
+def newton(N, Ts, R, x0, xF, ob, v, y, zL, zU, mu, dw, dc, rho=1e3, dist=0):
     a = [_d(q) for q in (x0, xF, np.reshape(ob, (5, 6)), v, y, zL, zU)]
     L = layout(N)
     dv = np.zeros(L["n"]); dy = np.zeros(L["m"]); errs = np.zeros(3)
     ok = lib().obca_oracle_quad_newton(C.c_int(N), C.c_double(Ts), C.c_double(R), a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], a[5][1], a[6][1],
                                        C.c_double(mu), C.c_double(dw), C.c_double(dc), C.c_double(rho), dv.ctypes.data_as(_D), dy.ctypes.data_as(_D),
-                                       errs.ctypes.data_as(_D))
+                                       errs.ctypes.data_as(_D), C.c_int(int(dist)))
     return ok, dv, dy, errs

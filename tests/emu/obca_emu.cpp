@@ -100,7 +100,7 @@ static void q_free(QScratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); 
 static void q_setup(int N, const double *prob, QScratch &s) {
     quad::QShared &sh = quad::gq_sh; quad::QConsts &c = sh.c;
     sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
-    c.N = N; c.Ts = prob[QPH_TS]; c.R = prob[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
+    c.N = N; c.dist = (int)prob[QPH_DIST]; c.Ts = prob[QPH_TS]; c.R = prob[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
     for (int i = 0; i < QX; i++) { c.x0[i] = prob[QPH_X0 + i]; c.xF[i] = prob[QPH_XF + i]; }
     for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];
     for (int i = 0; i < QOB * QL; i++) sh.ob[i] = prob[QPH_OB + i];

@@ -66,3 +66,20 @@ def test_emu_quad_full_solve_matches_oracle(Q, emu, N):
     assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"])
     xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T; up = z[L["u"]:L["t"]].reshape(N, 4).T
     assert np.abs(xp - r["xp"]).max() < 1e-4 and np.abs(up - r["up"]).max() < 1e-5 and abs(z[L["t"]] - r["t"]) < 1e-9
+
+
+def test_emu_quadcopter_dist_variant_matches_oracle(Q, emu):
+    """QuadcopterDist.jl formulation (no slack variable, x[10] in [-1.5, 3]) through the same device source"""
+    N = 30; Ts = round(0.25 * 80 / N * 100) / 100
+    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
+    r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    oo = Q.default_opts(); eo = EOpts()
+    for f, _ in EOpts._fields_:
+        setattr(eo, f, getattr(oo, f))
+    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dist=1)
+    z = np.zeros(L["len"]); info = np.zeros(8)
+    emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
+    assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"]
+    assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"]) and np.abs(z[L["s"]:L["so"]]).max() == 0
+    xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T
+    assert np.abs(xp - r["xp"]).max() < 1e-4

@@ -60,3 +60,21 @@ def test_quad_batch_parity_and_feasibility(Q):
         assert (xp >= XLB[:, None] - 1e-6).all() and (xp <= XUB[:, None] + 1e-6).all() and up.min() >= 1.2 - 1e-6 and up.max() <= 7.8 + 1e-6
         assert _clearance(xp, bt["ob"]).min() >= bt["R"] - 2e-3
         assert out["slack"][i].sum() <= 1e-3
+
+
+def test_quadcopter_dist_variant_matches_oracle(Q):
+    """QuadcopterDist (the collision-free sibling): no slack variable, x[10] in [-1.5, 3], exit flag 0/1"""
+    import obca_amd
+    from obca_amd import scenarios as S
+    N = 60; Ts = S.quad_sample_time(N)
+    xWS = S.quad_warm_start(S.QUAD_X0, S.QUAD_XF, N)
+    xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *S.QUAD_OB, xWS, None, 1.0)
+    r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, S.QUAD_OB, xWS, 1.0)
+    assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
+    assert np.abs(xp - r["xp"]).max() < 1e-5 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(ts - r["timeScale"]).max() < 1e-8
+    assert _clearance(xp, S.QUAD_OB).min() >= S.QUAD_R - 1e-4
+    bt = S.make_quad_batch(24, 30)
+    out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], 30, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], dist=True)
+    assert (out["exitflag"] == 1).mean() >= 0.9 and np.abs(out["slack"]).max() == 0
+    for i in np.where(out["exitflag"] == 1)[0]:
+        assert _clearance(out["xp"][i], bt["ob"]).min() >= bt["R"] - 1e-4

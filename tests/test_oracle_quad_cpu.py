@@ -10,13 +10,14 @@ def Q():
     return oracle_quad
 
 
-def test_quad_newton_direction_vs_dense_autograd(Q):
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_quad_newton_direction_vs_dense_autograd(Q, dist):
     torch = pytest.importorskip("torch")
     from nlp_ref_quad import QuadNLP
     rng = np.random.default_rng(2)
     N, Ts, R, ob = 7, 0.3, 0.25, Q.OB_CLAMPED
     x0 = Q.X0.copy(); x0[9:12] = [0.1, -0.2, 0.15]       # non-zero stage-1 rates exercise the single-index quirk
-    nlp = QuadNLP(x0, Q.XF, N, Ts, R, ob); L = Q.layout(N); n, m = L["n"], L["m"]
+    nlp = QuadNLP(x0, Q.XF, N, Ts, R, ob, dist=bool(dist)); L = Q.layout(N); n, m = L["n"], L["m"]
     assert n == nlp.n + 12 and m == nlp.m
     xWS = Q.warm_start(x0, Q.XF, N)
     v = np.zeros(n)
@@ -27,8 +28,10 @@ def test_quad_newton_direction_vs_dense_autograd(Q):
         v[L[k]:L[k] + cnt * (N + 1)] = rng.uniform(0.1, 1, cnt * (N + 1))
     y = rng.standard_normal(m); zL = rng.uniform(0.1, 2, n); zU = rng.uniform(0.1, 2, n)
     mu, dw, dc = 0.1, 500.0, 1e-6
-    ok, dv, dy, errs = Q.newton(N, Ts, R, x0, Q.XF, ob, v, y, zL, zU, mu, dw, dc)
+    ok, dv, dy, errs = Q.newton(N, Ts, R, x0, Q.XF, ob, v, y, zL, zU, mu, dw, dc, dist=dist)
     assert ok == 1
+    if dist:
+        assert np.abs(dv[L["s"]:L["so"]]).max() == 0          # the frozen slack does not move
     vv = v[12:]; zLr = zL[12:].copy(); zUr = zU[12:].copy()
     f, g, c, J, H = nlp.eval_all(vv, y)
     IL = np.isfinite(nlp.lb); IU = np.isfinite(nlp.ub); zLr[~IL] = 0; zUr[~IU] = 0
@@ -84,3 +87,20 @@ def test_quad_reference_start_is_rank_deficient(Q):
     o = Q.default_opts(); o.max_iter = 60
     r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, o, dual_ws=0)
     assert r["exitflag"] == 0
+
+
+def test_quadcopter_dist_variant_solves_collision_free(Q):
+    """QuadcopterDist.jl (next-1 row): no slack variable, x[10] in [-1.5, 3], exit flag 0/1 only"""
+    N = 60; Ts = round(0.25 * 80 / N * 100) / 100
+    via = [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)]
+    xWS = Q.warm_start(Q.X0, Q.XF, N, via)
+    r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    assert r["exitflag"] == 1 and np.abs(r["slack"]).max() == 0
+    xp = r["xp"]
+    assert np.abs(xp[:, N] - Q.XF).max() < 1e-4 and xp[9].min() >= -1.5 - 1e-6 and xp[9].max() <= 3 + 1e-6
+    for k in range(N + 1):
+        for j in range(5):
+            hi = Q.OB_CLAMPED[j, :3]; lo = -Q.OB_CLAMPED[j, 3:]
+            assert np.linalg.norm(xp[:3, k] - np.clip(xp[:3, k], lo, hi)) >= Q.EGO_R - 1e-4
+    r2 = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    assert abs(r["obj"] - r2["obj"]) < 1e-2 * abs(r2["obj"])      # the signed-distance optimum has ~zero slack, so the two optima nearly coincide
