@@ -28,8 +28,9 @@ DMIN = 0.05
 
 
 class ParkingNLP:
-    def __init__(self, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, rx, ry, ryaw, fixTime=0):
+    def __init__(self, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, rx, ry, ryaw, fixTime=0, dist=0):
         self.N = N
+        self.dist = int(dist)     # 1: ParkingDist.jl -- the sl slot holds the slack (>= 0) of |A'lam|^2 <= 1, no penetration slack, 0.5 a^2
         self.Ts, self.L = float(Ts), float(L)
         self.x0 = torch.tensor(np.asarray(x0, float).ravel())
         self.xF = torch.tensor(np.asarray(xF, float).ravel())
@@ -68,6 +69,8 @@ class ParkingNLP:
         lb[self.il] = 0; lb[self.im] = 0
         lb[self.iss] = -0.6; ub[self.iss] = 0.6
         lb[self.iso] = 0
+        if self.dist:
+            lb[self.isl] = 0
         self.lb, self.ub = lb, ub
         # multiplicity of the bound barrier (t is N+1 copies in the reference)
         self.mult = np.ones(o); self.mult[self.it] = N + 1
@@ -90,7 +93,7 @@ class ParkingNLP:
     def f(self, v):
         x, t, u, lam, mu, sl, ss, so = self.unpack(v)
         N = self.N
-        wa, wpsi = (0.5, 1e-2) if self.fixTime else (0.1, 1e-4)
+        wa, wpsi = (0.5, 1e-2) if self.fixTime else (0.5 if self.dist else 0.1, 1e-4)
         w = torch.cat([torch.zeros(1, 2), u[:-1]], 0)
         q = t * self.Ts
         J = (0.01 * u[:, 0] ** 2 + wa * u[:, 1] ** 2).sum()
@@ -100,7 +103,8 @@ class ParkingNLP:
         J = J + 1e-4 * (x[:, 3] ** 2).sum()
         J = J + (1e-3 * (x[:, 0] - self.rx) ** 2 + 1e-3 * (x[:, 1] - self.ry) ** 2
                  + wpsi * (x[:, 2] - self.ryaw) ** 2).sum()
-        J = J + (1e2 * sl + 1e4 * sl ** 2).sum()
+        if not self.dist:
+            J = J + (1e2 * sl + 1e4 * sl ** 2).sum()
         return J
 
     def c(self, v):
@@ -126,11 +130,11 @@ class ParkingNLP:
             p = lj @ Aj                      # (N+1, 2)
             beta = lj @ bj
             m = mu[:, j]
-            c1 = p[:, 0] ** 2 + p[:, 1] ** 2 - 1
+            c1 = p[:, 0] ** 2 + p[:, 1] ** 2 - 1 + (sl[:, j] if self.dist else 0.0)
             c2 = m[:, 0] - m[:, 2] + cs * p[:, 0] + sn * p[:, 1]
             c3 = m[:, 1] - m[:, 3] - sn * p[:, 0] + cs * p[:, 1]
             c4 = (-(m * self.g).sum(1) + (x[:, 0] + cs * self.off) * p[:, 0]
-                  + (x[:, 1] + sn * self.off) * p[:, 1] - beta + sl[:, j] - DMIN - so[:, j])
+                  + (x[:, 1] + sn * self.off) * p[:, 1] - beta + (0.0 if self.dist else sl[:, j]) - DMIN - so[:, j])
             cob.append(torch.stack([c1, c2, c3, c4], 1))
         cob = torch.stack(cob, 1).reshape(-1)    # [k, j, 4]
         return torch.cat([cdyn, cterm, csteer, cob])

@@ -37,6 +37,7 @@
 
 typedef struct {
     int N, nOb, M, fixTime;
+    int dist;   /* 1: ParkingDist.jl (no slack sl, |A'lam|^2 <= 1 with its own slack stored in the sl slot, weight 0.5 on a^2); 0: ParkingSignedDist.jl */
     int vOb[NOBMAX], roff[NOBMAX + 1];
     double Ts, L, g[4], off, XYb[4], x0[4], xF[4];
     const double *A, *b, *rx, *ry, *ryaw; /* A: M x 2 row major */
@@ -71,7 +72,7 @@ void obca_oracle_default_opts(opts_t *o) {
 typedef struct {
     int x, u, t, lam, mu, sl, so, ss;            /* primal */
     int pi, nu, yg, yo;                           /* equality multipliers */
-    int zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU; /* bound multipliers */
+    int zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, zs1; /* bound multipliers (zs1: of the norm-row slack, ParkingDist only) */
     int nprimal, len;
 } lay_t;
 
@@ -83,7 +84,7 @@ static void make_layout(const prob_t *p, lay_t *l) {
     l->pi = o; o += 4 * N; l->nu = o; o += 4; l->yg = o; o += N; l->yo = o; o += 4 * nOb * N1;
     l->zxL = o; o += 4 * N1; l->zxU = o; o += 4 * N1; l->zuL = o; o += 2 * N; l->zuU = o; o += 2 * N;
     l->ztL = o; o += 1; l->ztU = o; o += 1; l->zlam = o; o += M * N1; l->zmu = o; o += 4 * nOb * N1;
-    l->zso = o; o += nOb * N1; l->zssL = o; o += N; l->zssU = o; o += N; l->len = o;
+    l->zso = o; o += nOb * N1; l->zssL = o; o += N; l->zssU = o; o += N; l->zs1 = o; o += nOb * N1; l->len = o;
 }
 
 static const double UL[2] = {-0.6, -0.4}, UU[2] = {0.6, 0.4}; /* ParkingSignedDist.jl:100-101 */
@@ -148,7 +149,7 @@ static void dyn_eval(const prob_t *p, const double *x, const double *u, double t
 }
 
 /* objective pieces, ParkingSignedDist.jl:78-92 */
-static double wa_of(const prob_t *p) { return p->fixTime ? 0.5 : 0.1; }
+static double wa_of(const prob_t *p) { return (p->fixTime || p->dist) ? 0.5 : 0.1; }   /* ParkingDist.jl:87 */
 static double wpsi_of(const prob_t *p) { return p->fixTime ? 1e-2 : 1e-4; }
 
 /* obstacle rows of one (stage, obstacle), ParkingSignedDist.jl:190-207 */
@@ -160,11 +161,11 @@ static void obs_rows(const prob_t *p, int j, const double *x, const double *lam,
     double p1 = 0, p2 = 0, beta = 0;
     for (int i = 0; i < v; i++) { p1 += Aj[2 * i] * lam[i]; p2 += Aj[2 * i + 1] * lam[i]; beta += bj[i] * lam[i]; }
     double cs = cos(x[2]), sn = sin(x[2]);
-    c[0] = p1 * p1 + p2 * p2 - 1;
+    c[0] = p1 * p1 + p2 * p2 - 1 + (p->dist ? sl : 0.0);          /* ParkingDist.jl:200: <= 1, slack kept in the sl slot */
     c[1] = mu[0] - mu[2] + cs * p1 + sn * p2;
     c[2] = mu[1] - mu[3] - sn * p1 + cs * p2;
     c[3] = -(p->g[0] * mu[0] + p->g[1] * mu[1] + p->g[2] * mu[2] + p->g[3] * mu[3]) + (x[0] + cs * p->off) * p1 +
-           (x[1] + sn * p->off) * p2 - beta + sl - DMIN - so;
+           (x[1] + sn * p->off) * p2 - beta + (p->dist ? 0.0 : sl) - DMIN - so;   /* ParkingDist.jl:207-208: no slack */
     if (ax) { ax->p1 = p1; ax->p2 = p2; ax->beta = beta; ax->cs = cs; ax->sn = sn; }
 }
 
@@ -190,7 +191,7 @@ static void eval_f_theta(const prob_t *p, const lay_t *l, const double *z, doubl
              wpsi * (x[2] - p->ryaw[k]) * (x[2] - p->ryaw[k]);
         for (int j = 0; j < nOb; j++) {
             double c[4], sl = z[l->sl + k * nOb + j];
-            J += 1e2 * sl + 1e4 * sl * sl;
+            if (!p->dist) J += 1e2 * sl + 1e4 * sl * sl;
             obs_rows(p, j, x, z + l->lam + k * M + p->roff[j], z + l->mu + 4 * (k * nOb + j), sl, z[l->so + k * nOb + j], c, NULL);
             for (int i = 0; i < 4; i++) { double r = fabs(c[i]); th += r; if (r > ti) ti = r; }
         }
@@ -213,6 +214,7 @@ static double barrier_terms(const prob_t *p, const lay_t *l, const double *z) {
     for (int i = 0; i < M * (N + 1); i++) s += log(z[l->lam + i]);
     for (int i = 0; i < 4 * nOb * (N + 1); i++) s += log(z[l->mu + i]);
     for (int i = 0; i < nOb * (N + 1); i++) s += log(z[l->so + i]);
+    if (p->dist) for (int i = 0; i < nOb * (N + 1); i++) s += log(z[l->sl + i]);
     return s;
 }
 
@@ -441,6 +443,11 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             double rsl = 1e2 + 2e4 * sl + y[3];
             F->Dso = lsq ? 1.0 : (zso / so + dw); F->Dsl = lsq ? 1.0 : (2e4 + dw);
             F->r_so = lsq ? rso_z : rso_b; F->r_sl = rsl;
+            if (p->dist) {   /* the sl slot holds the slack of the norm row: s1 >= 0, gradient y1, multiplier zs1 */
+                double zs1 = z[l->zs1 + k * nOb + j];
+                rsl = y[0] - zs1; F->r_sl = y[0] - mu / sl; F->Dsl = zs1 / sl + dw;
+                double c_ = fabs(sl * zs1); if (c_ > cmax) cmax = c_; sumz += fabs(zs1); nb++;
+            }
             if (fabs(rso_z) > dmax) dmax = fabs(rso_z); if (fabs(rsl) > dmax) dmax = fabs(rsl);
             { double c_ = fabs(so * zso); if (c_ > cmax) cmax = c_; sumz += fabs(zso); nb++; }
             for (int i = 0; i < 4; i++) {
@@ -478,13 +485,13 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
                 }
                 T[r * 3 + r] += lsq ? 0.0 : dc;
             }
-            T[8] += 1.0 / F->Dso + 1.0 / F->Dsl;
+            T[8] += 1.0 / F->Dso + (p->dist ? 0.0 : 1.0 / F->Dsl);
             for (int r = 0; r < 3; r++) {
                 double a_ = lsq ? 0.0 : -F->c[r + 1];
                 for (int i = 0; i < 4; i++) a_ += Jmu[r + 1][i] * F->r_mu[i] / F->Dmu[i];
                 F->r234[r] = a_;
             }
-            F->r234[2] += -F->r_so / F->Dso + F->r_sl / F->Dsl;
+            F->r234[2] += -F->r_so / F->Dso + (p->dist ? 0.0 : F->r_sl / F->Dsl);
             memcpy(F->Tf, T, sizeof T);
             if (ldl_n(3, F->Tf) != 0) { ok = 0; if (getenv("OBCA_DBG")) fprintf(stderr, "T fail k=%d j=%d\n", k, j); }
             /* (lambda,y1) block */
@@ -512,8 +519,8 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
                 for (int r = 0; r < 3; r++) a_ += F->Jl[r + 1][i] * W[r][v + 3];
                 F->rk[i] = a_;
             }
-            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = lsq ? 0.0 : -F->c[0];
-            if (!lamblock_factor(F, v, Kb, F->Jl[0], lsq ? 0.0 : dc)) {
+            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = lsq ? 0.0 : -F->c[0] + (p->dist ? F->r_sl / F->Dsl : 0.0);
+            if (!lamblock_factor(F, v, Kb, F->Jl[0], lsq ? 0.0 : dc + (p->dist ? 1.0 / F->Dsl : 0.0))) {
                 ok = 0;
                 if (getenv("OBCA_DBG")) fprintf(stderr, "lamblock fail k=%d j=%d y1=%g dw=%g\n", k, j, y[0], dw);
             }
@@ -814,7 +821,8 @@ static int kkt_solve(kkt_t *K, const double *z, double mu, double dc, double rho
                 double m_ = z[l->mu + idx], zz = z[l->zmu + idx];
                 d[l->zmu + idx] = mu / m_ - zz - zz / m_ * dm;
             }
-            d[l->sl + bo] = (-F->r_sl - dy[3]) / F->Dsl;
+            d[l->sl + bo] = (-F->r_sl - (p->dist ? dy[0] : dy[3])) / F->Dsl;
+            if (p->dist) { double s1 = z[l->sl + bo], zz1 = z[l->zs1 + bo]; d[l->zs1 + bo] = mu / s1 - zz1 - zz1 / s1 * d[l->sl + bo]; }
             double dso = (dy[3] - F->r_so) / F->Dso;
             d[l->so + bo] = dso;
             double so = z[l->so + bo], zz = z[l->zso + bo];
@@ -871,6 +879,7 @@ static void frac_to_boundary(const prob_t *p, const lay_t *l, const double *z, c
     for (int i = 0; i < M * (N + 1); i++) { PR(z[l->lam + i], d[l->lam + i]); DU(z[l->zlam + i], d[l->zlam + i]); }
     for (int i = 0; i < 4 * nOb * (N + 1); i++) { PR(z[l->mu + i], d[l->mu + i]); DU(z[l->zmu + i], d[l->zmu + i]); }
     for (int i = 0; i < nOb * (N + 1); i++) { PR(z[l->so + i], d[l->so + i]); DU(z[l->zso + i], d[l->zso + i]); }
+    if (p->dist) for (int i = 0; i < nOb * (N + 1); i++) { PR(z[l->sl + i], d[l->sl + i]); DU(z[l->zs1 + i], d[l->zs1 + i]); }
 #undef PR
 #undef DU
     *ap = a; *az = b;
@@ -886,7 +895,7 @@ static double barrier_dir(const prob_t *p, const lay_t *l, const double *z, cons
         if (k >= 1) for (int i = 0; i < 4; i++) if (i != 2) g += (-mu / (x[i] - p->xl[i]) + mu / (p->xu[i] - x[i])) * dx[i];
         for (int j = 0; j < nOb; j++) {
             int bo = k * nOb + j;
-            g += (1e2 + 2e4 * z[l->sl + bo]) * d[l->sl + bo] - mu / z[l->so + bo] * d[l->so + bo];
+            g += (p->dist ? -mu / z[l->sl + bo] : 1e2 + 2e4 * z[l->sl + bo]) * d[l->sl + bo] - mu / z[l->so + bo] * d[l->so + bo];
             for (int i = 0; i < 4; i++) g -= mu / z[l->mu + 4 * bo + i] * d[l->mu + 4 * bo + i];
         }
         for (int i = 0; i < M; i++) g -= mu / z[l->lam + k * M + i] * d[l->lam + k * M + i];
@@ -928,6 +937,7 @@ static void push_bounds(const prob_t *p, const lay_t *l, const opts_t *o, double
     for (int i = 0; i < M * (N + 1); i++) if (z[l->lam + i] < o->bound_push) z[l->lam + i] = o->bound_push;
     for (int i = 0; i < 4 * nOb * (N + 1); i++) if (z[l->mu + i] < o->bound_push) z[l->mu + i] = o->bound_push;
     for (int i = 0; i < nOb * (N + 1); i++) if (z[l->so + i] < o->bound_push) z[l->so + i] = o->bound_push;
+    if (p->dist) for (int i = 0; i < nOb * (N + 1); i++) if (z[l->sl + i] < o->bound_push) z[l->sl + i] = o->bound_push;
 #undef PUSH2
 }
 
@@ -943,6 +953,7 @@ static void reset_bound_mults(const prob_t *p, const lay_t *l, const opts_t *o, 
     for (int i = 0; i < M * (N + 1); i++) CL(z[l->zlam + i], z[l->lam + i]);
     for (int i = 0; i < 4 * nOb * (N + 1); i++) CL(z[l->zmu + i], z[l->mu + i]);
     for (int i = 0; i < nOb * (N + 1); i++) CL(z[l->zso + i], z[l->so + i]);
+    if (p->dist) for (int i = 0; i < nOb * (N + 1); i++) CL(z[l->zs1 + i], z[l->sl + i]);
 #undef CL
 }
 
@@ -963,8 +974,10 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
         for (int k = 0; k < N; k++) z[l->ss + k] = ((k ? z[l->u + 2 * (k - 1)] : 0) - z[l->u + 2 * k]) / q;
         for (int k = 0; k <= N; k++) for (int j = 0; j < nOb; j++) {
             double c[4]; int bo = k * nOb + j;
+            if (p->dist) z[l->sl + bo] = 0.0;
             obs_rows(p, j, z + l->x + 4 * k, z + l->lam + k * M + p->roff[j], z + l->mu + 4 * bo, z[l->sl + bo], 0.0, c, NULL);
             z[l->so + bo] = c[3];
+            if (p->dist) z[l->sl + bo] = -c[0];         /* slack of |A'lam|^2 <= 1 takes the row value */
         }
     }
     push_bounds(p, l, o, z);
@@ -1013,6 +1026,7 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             for (int i = 0; i < M * (N + 1); i++) CM(z[l->lam + i], z[l->zlam + i]);
             for (int i = 0; i < 4 * nOb * (N + 1); i++) CM(z[l->mu + i], z[l->zmu + i]);
             for (int i = 0; i < nOb * (N + 1); i++) CM(z[l->so + i], z[l->zso + i]);
+            if (p->dist) for (int i = 0; i < nOb * (N + 1); i++) CM(z[l->sl + i], z[l->zs1 + i]);
 #undef CM
             double Emu = fmax(dinf / sd, fmax(pinf, cm / sc));
             if (Emu <= o->kappa_eps * mu && mu > o->tol / 10) {
@@ -1215,23 +1229,63 @@ int obca_oracle_dualmult_ws(int N, int nOb, const int *vOb, const double *A, con
 }
 
 /*
+ * The reference's own acceptance test, restated with its quirks (ParkingConstraints.jl:29-149): in variable-time mode only the
+ * speed row of the dynamics survives in c3 (:76-79), the obstacle rows c6 are overwritten per obstacle so only the LAST obstacle counts
+ * (:108-130), the c6[4] row ignores the slack, the steering-rate row divides by timeScale[1] only (:88).  Returns 1 if every class is
+ * <= 5e-5 (:133-139).  sd = 1: signed-distance variant (|A'lam|^2 == 1), sd = 0: distance variant (<= 1).
+ */
+static int ref_constraints(const prob_t *p, const lay_t *l, const double *z, int sd) {
+    int N = p->N, nOb = p->nOb, M = p->M; const double tol = 5e-5;
+    double t = p->fixTime ? 1.0 : z[l->t];
+    double c0 = -1e300, c2 = 0, c3 = 0, c5 = 0, c6 = -1e300, m0 = 0, m1 = 0, lmin = 1e300, nmin = 1e300;
+    for (int k = 0; k < N; k++) { m0 = fmax(m0, fabs(z[l->u + 2 * k])); m1 = fmax(m1, fabs(z[l->u + 2 * k + 1])); }
+    for (int i = 0; i < M * (N + 1); i++) lmin = fmin(lmin, z[l->lam + i]);
+    for (int i = 0; i < 4 * nOb * (N + 1); i++) nmin = fmin(nmin, z[l->mu + i]);
+    c0 = fmax(fmax(m0 - 0.6, m1 - 0.4), fmax(fabs(t - 1) - 0.2, fmax(-lmin, -nmin)));
+    for (int i = 0; i < 4; i++) c2 = fmax(c2, fabs(z[l->x + 4 * N + i] - p->xF[i]));
+    for (int k = 0; k < N; k++) {
+        double F[4]; dyn_eval(p, z + l->x + 4 * k, z + l->u + 2 * k, t, F, NULL, NULL, NULL);
+        if (p->fixTime) { for (int i = 0; i < 4; i++) c3 = fmax(c3, fabs(z[l->x + 4 * (k + 1) + i] - F[i])); }
+        else c3 = fmax(c3, fabs(z[l->x + 4 * (k + 1) + 3] - F[3]));
+        double prev = k ? z[l->u + 2 * (k - 1)] : 0.0;
+        c5 = fmax(c5, fabs(z[l->u + 2 * k] - prev) / (t * p->Ts));
+    }
+    c5 -= 0.6;
+    int j = nOb - 1;                                                   /* only the last obstacle survives the overwrite */
+    for (int k = 0; k <= N && j >= 0; k++) {
+        double c[4]; const double *x = z + l->x + 4 * k;
+        int dist_keep = p->dist; ((prob_t *)p)->dist = 0;              /* evaluate the plain rows: no slack in either variant (:127-128) */
+        obs_rows(p, j, x, z + l->lam + k * M + p->roff[j], z + l->mu + 4 * (k * nOb + j), 0.0, 0.0, c, NULL);
+        ((prob_t *)p)->dist = dist_keep;
+        c6 = fmax(c6, sd ? fabs(c[0] + 1) - 1 : c[0]);                /* abs(|p|^2) - 1 (sd) or |p|^2 - 1 */
+        c6 = fmax(c6, fmax(fabs(c[1]), fabs(c[2])));
+        c6 = fmax(c6, -c[3]);                                          /* -(row) + dmin <= 0 ; obs_rows already subtracts DMIN */
+    }
+    return c0 <= tol && c2 <= tol && c3 <= tol && c5 <= tol && (nOb == 0 || c6 <= tol);
+}
+
+/*
  * One parking solve.  Array conventions (all fp64, "stage-contiguous" = the reference's column-major xp etc.):
  *   xWS 4 x (N+1) stage-contiguous, uWS 2 x N, lWS M x (N+1) stage-contiguous, nWS 4nOb x (N+1)
  *   outputs xp 4(N+1), up 2N, timeScale (N+1), lp M(N+1), np 4nOb(N+1), slp nOb(N+1)
  *   info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, t}
- * exitflag follows ParkingSignedDist.jl:256-290 (one retry from the last iterate on Error/UserLimit).
+ * dist = 0: ParkingSignedDist.  exitflag follows ParkingSignedDist.jl:256-290: Optimal -> 1; Error/UserLimit -> one retry from the last
+ *           iterate; if that fails too the reference's feasibility check decides (feasible -> 1).
+ * dist = 1: ParkingDist.  exitflag follows ParkingDist.jl:245-289: Optimal -> 1; otherwise the feasibility check runs first (feasible -> 1),
+ *           else one retry; after a failed retry the check is INVERTED in the reference (infeasible -> 1) -- reproduced.
  */
-int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
-                                    const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
-                                    const double *b, const double *rx, const double *ry, const double *ryaw,
-                                    const double *xWS, const double *uWS, const double *lWS, const double *nWS,
-                                    const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *np,
-                                    double *slp, int *exitflag, double *info) {
+static int parking_solve(int dist, int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
+                         const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
+                         const double *b, const double *rx, const double *ry, const double *ryaw,
+                         const double *xWS, const double *uWS, const double *lWS, const double *nWS,
+                         const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *np,
+                         double *slp, int *exitflag, double *info) {
     prob_t p; lay_t l; opts_t o;
     if (nOb > NOBMAX) return -1;
     for (int j = 0; j < nOb; j++) if (vOb[j] > VMAX || vOb[j] < 1) return -1;
     if (opt) o = *opt; else obca_oracle_default_opts(&o);
     setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw);
+    p.dist = dist;
     make_layout(&p, &l);
     double *z = xcalloc(l.len, sizeof(double));
     memcpy(z + l.x, xWS, sizeof(double) * 4 * (N + 1));
@@ -1243,7 +1297,9 @@ int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego
     ipm_solve(&p, &l, &o, z, &r);
     int ef = (r.status == ST_OPTIMAL);
     int iters = r.iters;
-    if (!ef && (r.status == ST_ERROR || r.status == ST_USERLIMIT)) {
+    int retry = !ef && (r.status == ST_ERROR || r.status == ST_USERLIMIT);
+    if (retry && dist && ref_constraints(&p, &l, z, 0)) { ef = 1; retry = 0; }       /* ParkingDist.jl:259-260, :284-285 */
+    if (retry) {
         /* second attempt from the last iterate (ParkingSignedDist.jl:259-263) */
         double *z2 = xcalloc(l.len, sizeof(double));
         memcpy(z2, z, sizeof(double) * l.nprimal);
@@ -1251,7 +1307,11 @@ int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego
         ipm_solve(&p, &l, &o, z2, &r2);
         iters += r2.iters;
         if (r2.status == ST_OPTIMAL) { ef = 1; memcpy(z, z2, sizeof(double) * l.len); r = r2; }
-        else if (r2.obj == r2.obj) { memcpy(z, z2, sizeof(double) * l.len); r = r2; }
+        else {
+            if (r2.obj == r2.obj) { memcpy(z, z2, sizeof(double) * l.len); r = r2; }
+            int feas = ref_constraints(&p, &l, z, dist ? 0 : 1);
+            ef = dist ? !feas : feas;                                   /* ParkingSignedDist.jl:278-283 / ParkingDist.jl:277-282 (inverted, Q6) */
+        }
         free(z2);
     }
     memcpy(xp, z + l.x, sizeof(double) * 4 * (N + 1));
@@ -1265,8 +1325,38 @@ int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego
     free(z);
     return 0;
 }
+int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
+                                    const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
+                                    const double *b, const double *rx, const double *ry, const double *ryaw,
+                                    const double *xWS, const double *uWS, const double *lWS, const double *nWS,
+                                    const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *np,
+                                    double *slp, int *exitflag, double *info) {
+    return parking_solve(0, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opt, xp, up, tsp, lp, np, slp, exitflag, info);
+}
+/* ParkingDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS)  (ParkingDist.jl:29); slp returns the norm-row slack */
+int obca_oracle_parking_dist(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
+                             const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
+                             const double *b, const double *rx, const double *ry, const double *ryaw,
+                             const double *xWS, const double *uWS, const double *lWS, const double *nWS,
+                             const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *np,
+                             double *slp, int *exitflag, double *info) {
+    return parking_solve(1, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opt, xp, up, tsp, lp, np, slp, exitflag, info);
+}
+/* test hook: the acceptance test on a returned solution (same argument conventions) */
+int obca_oracle_ref_constraints(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
+                                const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *xp,
+                                const double *up, double t, const double *lp, const double *np, int sd) {
+    prob_t p; lay_t l;
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, NULL, NULL, NULL);
+    make_layout(&p, &l);
+    double *z = xcalloc(l.len, sizeof(double));
+    memcpy(z + l.x, xp, sizeof(double) * 4 * (N + 1)); memcpy(z + l.u, up, sizeof(double) * 2 * N); z[l.t] = t;
+    memcpy(z + l.lam, lp, sizeof(double) * p.M * (N + 1)); memcpy(z + l.mu, np, sizeof(double) * 4 * nOb * (N + 1));
+    int r = ref_constraints(&p, &l, z, sd);
+    free(z);
+    return r;
+}
 
-/* ---- test hooks: evaluate the model pieces and one Newton step so tests can compare with autograd / dense algebra */
 int obca_oracle_eval(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
                      const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *rx,
                      const double *ry, const double *ryaw, const double *zin /* packed primal in oracle layout */,
@@ -1278,7 +1368,7 @@ int obca_oracle_eval(int N, double Ts, double L, const double ego[4], const doub
     return l.len;
 }
 
-int obca_oracle_layout(int N, int nOb, const int *vOb, int *out /* 25 ints */) {
+int obca_oracle_layout(int N, int nOb, const int *vOb, int *out /* 26 ints */) {
     prob_t p; lay_t l; memset(&p, 0, sizeof p);
     p.N = N; p.nOb = nOb; p.M = 0; for (int j = 0; j < nOb; j++) p.M += vOb[j];
     make_layout(&p, &l);
@@ -1290,9 +1380,10 @@ int obca_oracle_layout(int N, int nOb, const int *vOb, int *out /* 25 ints */) {
 int obca_oracle_newton(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
                        const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *rx,
                        const double *ry, const double *ryaw, const double *z, double mu, double dw, double dc, double rho,
-                       double *d, double *errs /* dinf,pinf,cinf */) {
+                       double *d, double *errs /* dinf,pinf,cinf */, int dist) {
     prob_t p; lay_t l;
     setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw);
+    p.dist = dist;
     make_layout(&p, &l);
     kkt_t *K = kkt_alloc(&p, &l);
     int ok = kkt_assemble(K, z, mu, dw, dc, 0);

@@ -52,7 +52,7 @@ def _i(a):
     return a, a.ctypes.data_as(_I)
 
 
-LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU nprimal len").split()
+LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU zs1 nprimal len").split()
 
 
 def layout(N, vOb):
@@ -75,7 +75,7 @@ def dualmult_ws(N, vOb, A, b, rx, ry, ryaw, ego):
 
 
 def parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
-                        opts=None):
+                        opts=None, dist=0):
     """Mirrors ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS) (ParkingSignedDist.jl:29).
     xWS (N+1,4), uWS (>=N,2) as in the reference.  Returns dict with xp (4,N+1), up (2,N), timeScale, exitflag, lp (M,N+1),
     np (4nOb,N+1), sl, info."""
@@ -88,7 +88,8 @@ def parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw
     lw, plw = _d(lWS); nw, pnw = _d(nWS)
     xp = np.zeros((N + 1, 4)); up = np.zeros((N, 2)); ts = np.zeros(N + 1); lp = np.zeros((N + 1, M)); npp = np.zeros((N + 1, 4 * nOb))
     slp = np.zeros((N + 1, nOb)); ef = C.c_int(0); info = np.zeros(8)
-    rc = lib().obca_oracle_parking_signed_dist(
+    fn = lib().obca_oracle_parking_dist if dist else lib().obca_oracle_parking_signed_dist
+    rc = fn(
         C.c_int(N), C.c_double(Ts), C.c_double(L), args[0][1], args[1][1], C.c_int(int(fixTime)), args[2][1], args[3][1],
         C.c_int(nOb), pv, pA, pb, prx, pry, pyw, pxw, puw, plw, pnw, C.byref(opts) if opts is not None else None,
         xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D), lp.ctypes.data_as(_D), npp.ctypes.data_as(_D),
@@ -98,11 +99,24 @@ def parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw
                 status=int(info[0]), iters=int(info[1]), obj=info[2], pinf=info[3], dinf=info[4], mu=info[5], nreg=int(info[6]), t=info[7])
 
 
-def newton(N, Ts, L, ego, XYbounds, fixTime, x0, xF, vOb, A, b, rx, ry, ryaw, z, mu, dw, dc, rho=1e3):
+def parking_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None, opts=None):
+    """Mirrors ParkingDist(...) (ParkingDist.jl:29): the collision-free sibling; `sl` of the result holds the slack of |A'lam|^2 <= 1."""
+    return parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS, nWS, opts, dist=1)
+
+
+def ref_constraints(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, xp, up, t, lp, np_, fixTime, sd):
+    """the C restatement of ParkingConstraints.jl used for the exit flag; xp (4,N+1), up (2,N), lp (M,N+1), np_ (4nOb,N+1)"""
+    vOb_, pv = _i(vOb)
+    a = [_d(v) for v in (ego, XYbounds, x0, xF, A, b, np.asarray(xp).T, np.asarray(up).T, np.asarray(lp).T, np.asarray(np_).T)]
+    return lib().obca_oracle_ref_constraints(C.c_int(N), C.c_double(Ts), C.c_double(L), a[0][1], a[1][1], C.c_int(int(fixTime)), a[2][1], a[3][1],
+                                             C.c_int(len(vOb_)), pv, a[4][1], a[5][1], a[6][1], a[7][1], C.c_double(t), a[8][1], a[9][1], C.c_int(int(sd)))
+
+
+def newton(N, Ts, L, ego, XYbounds, fixTime, x0, xF, vOb, A, b, rx, ry, ryaw, z, mu, dw, dc, rho=1e3, dist=0):
     vOb_, pv = _i(vOb); nOb = len(vOb_)
     a = [_d(v) for v in (ego, XYbounds, x0, xF, A, b, rx, ry, ryaw, z)]
     d = np.zeros_like(a[9][0]); errs = np.zeros(3)
     ok = lib().obca_oracle_newton(C.c_int(N), C.c_double(Ts), C.c_double(L), a[0][1], a[1][1], C.c_int(int(fixTime)), a[2][1], a[3][1],
                                   C.c_int(nOb), pv, a[4][1], a[5][1], a[6][1], a[7][1], a[8][1], a[9][1], C.c_double(mu),
-                                  C.c_double(dw), C.c_double(dc), C.c_double(rho), d.ctypes.data_as(_D), errs.ctypes.data_as(_D))
+                                  C.c_double(dw), C.c_double(dc), C.c_double(rho), d.ctypes.data_as(_D), errs.ctypes.data_as(_D), C.c_int(int(dist)))
     return ok, d, errs

@@ -103,14 +103,16 @@ def test_oracle_config3_parallel_parking_golden_and_reference_checker(oracle):
         assert r["sl"].max() < 0.02                                            # penetration below 2 cm: the bay is 1.3 m longer than the car
 
 
-def test_newton_direction_vs_dense_autograd(oracle, backwards):
-    """closed-form derivatives + condensation + Riccati + border == dense solve of the autograd KKT system"""
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_newton_direction_vs_dense_autograd(oracle, backwards, dist):
+    """closed-form derivatives + condensation + Riccati + border == dense solve of the autograd KKT system
+    (both formulations: ParkingSignedDist and the next-1 sibling ParkingDist)"""
     torch = pytest.importorskip("torch")
     from nlp_ref import ParkingNLP
     rng = np.random.default_rng(1)
     N = 4; sc = S.BACKWARDS; A, b, v = backwards["A"], backwards["b"], backwards["vOb"]; nOb = len(v); M = int(v.sum())
     x0 = np.array([-6, 9.5, 0.1, 0.]); Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); Ts = 0.6
-    nlp = ParkingNLP(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2])
+    nlp = ParkingNLP(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], dist=dist)
     L = oracle.layout(N, v)
     z = np.zeros(L["len"])
     X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 4)); X[0] = x0
@@ -120,11 +122,11 @@ def test_newton_direction_vs_dense_autograd(oracle, backwards):
     for k, lo, hi in (("lam", 0.1, 1), ("mu", 0.1, 1), ("so", 0.1, 1), ("ss", -0.3, 0.3)):
         n = L[oracle.LAYOUT_FIELDS[oracle.LAYOUT_FIELDS.index(k) + 1]] - L[k]
         z[L[k]:L[k] + n] = rng.uniform(lo, hi, n)
-    z[L["sl"]:L["so"]] = 0.01 * rng.standard_normal(L["so"] - L["sl"])
+    z[L["sl"]:L["so"]] = rng.uniform(0.1, 1, L["so"] - L["sl"]) if dist else 0.01 * rng.standard_normal(L["so"] - L["sl"])
     z[L["pi"]:L["zxL"]] = rng.standard_normal(L["zxL"] - L["pi"])
     z[L["zxL"]:] = rng.uniform(0.1, 2, L["len"] - L["zxL"])
     mu, dw, dc = 0.1, 3.0, 1e-6
-    ok, d, errs = oracle.newton(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc)
+    ok, d, errs = oracle.newton(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc, dist=dist)
     assert ok == 1
 
     def to_ref(w):
@@ -144,6 +146,7 @@ def test_newton_direction_vs_dense_autograd(oracle, backwards):
     zL[nlp.iu] = z[L["zuL"]:L["zuL"] + 2 * N]; zU[nlp.iu] = z[L["zuU"]:L["zuU"] + 2 * N]
     zL[nlp.il] = z[L["zlam"]:L["zlam"] + M * (N + 1)]; zL[nlp.im] = z[L["zmu"]:L["zmu"] + 4 * nOb * (N + 1)]
     zL[nlp.iso] = z[L["zso"]:L["zso"] + nOb * (N + 1)]
+    zL[nlp.isl] = z[L["zs1"]:L["zs1"] + nOb * (N + 1)]              # only bounded (hence used) in the ParkingDist formulation
     zL[nlp.iss] = z[L["zssL"]:L["zssL"] + N]; zU[nlp.iss] = z[L["zssU"]:L["zssU"] + N]
     IL = np.isfinite(nlp.lb); IU = np.isfinite(nlp.ub); zL[~IL] = 0; zU[~IU] = 0
     dL = np.where(IL, vv - nlp.lb, 1.0); dU = np.where(IU, nlp.ub - vv, 1.0)
