@@ -62,9 +62,19 @@ int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts
                                    int *exitflag /* B */, double *lp, double *np, double *slp /* nOb_i x (N+1) packed, may be NULL */,
                                    double *info /* 8 x B {status,iters,objective,pinf,dinf,mu,nreg,exitflag}, may be NULL */);
 
+/* ParkingDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS) -- AutonomousParking/ParkingDist.jl:29-315 (call site
+ * main.jl:258): the collision-free sibling -- no penetration slack, |A'lam|^2 <= 1, weight 0.5 on a^2 (:87), exit flag per :245-289
+ * (incl. the inverted feasibility check after a failed retry).  Same argument conventions as the signed-distance call. */
+int obca_parking_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYbounds[4],
+                            int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
+                            const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
+                            const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp, double *up,
+                            double *timeScale, int *exitflag, double *lp, double *np, double *info);
+
 /* ---- device-resident batch API (benchmarks, receding-horizon callers): upload once, solve many times ---- */
 int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out);
 int obca_batch_destroy(obca_batch *bt);
+int obca_batch_set_formulation(obca_batch *bt, int dist);   /* 0 = ParkingSignedDist (default), 1 = ParkingDist; call before obca_batch_upload */
 int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double ego[4], const double XYbounds[4], int fixTime,
                       const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A, const double *b,
                       const double *rx, const double *ry, const double *ryaw, const double *xWS, const double *uWS,

@@ -67,6 +67,23 @@ function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, 
     return xp[:, :, 1], up[:, :, 1], timeScalep, Int(ef[1]), t, lp[:, :, 1], np[:, :, 1]
 end
 
+"Drop-in for ParkingDist.jl:29 (collision-free sibling; entry point obca_parking_dist_batch has the same arguments minus the slack output)."
+function ParkingDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
+    M = sum(vOb)
+    xp = zeros(4, N + 1); up = zeros(2, N); ts = zeros(N + 1); ef = zeros(Cint, 1); lp = zeros(M, N + 1); np = zeros(4nOb, N + 1)
+    t0 = time()
+    rc = ccall((:obca_parking_dist_batch, LIB), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx().h, 1, N, [Float64(Ts)], L, f64(vec(ego)), f64(vec(XYbounds)), fixTime, f64(vec(x0)), f64(vec(xF)), Cint[nOb], Cint.(vec(vOb)),
+               vec(permutedims(f64(A))), f64(vec(b)), f64(rx)[1:N+1], f64(ry)[1:N+1], f64(ryaw)[1:N+1], vec(permutedims(f64(xWS)[1:N+1, :])),
+               vec(permutedims(f64(uWS)[1:N, :])), C_NULL, C_NULL, C_NULL, xp, up, ts, ef, lp, np, C_NULL)
+    rc == 0 || error("obca_parking_dist_batch failed: " * lasterr(ctx()))
+    timeScalep = fixTime == 1 ? ones(1, N + 1) : ts
+    return xp, up, timeScalep, Int(ef[1]), time() - t0, lp, np          # ParkingDist.jl:313
+end
+
 "Drop-in for DualMultWS.jl:29; `ego` defaults to the global the reference reads (DualMultWS.jl:39-45). Returns (lp (N+1)xM, np (N+1)x4nOb)."
 function DualMultWS(N, nOb, vOb, A, b, rx, ry, ryaw; ego=Main.ego)
     M = sum(vOb)

@@ -70,7 +70,8 @@ def _load():
 
 
 EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
-           "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_batch_create", "obca_batch_destroy",
+           "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
+           "obca_batch_set_formulation",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
            "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
            "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
@@ -162,7 +163,8 @@ class Batch:
         self._h = C.c_void_p()
         ctx._check(_load().obca_batch_create(ctx._h, C.c_int(self.B), C.c_int(self.N), C.byref(self._h)), "obca_batch_create")
 
-    def upload(self, x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None):
+    def upload(self, x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None, dist=False):
+        self.ctx._check(_load().obca_batch_set_formulation(self._h, C.c_int(int(bool(dist)))), "obca_batch_set_formulation")
         """lWS/nWS, when given, are packed per instance as (N+1, M_i) / (N+1, 4 nOb_i) row-major blocks (= the reference's
         column-major l (M x N+1) and n (4nOb x N+1))."""
         B, N = self.B, self.N
@@ -238,13 +240,13 @@ class Batch:
 
 
 def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
-                              opts=None, device=0):
+                              opts=None, device=0, dist=False):
     """Batched ParkingSignedDist: x0,xF (B,4); rx,ry,ryaw (B,N+1); xWS (B,N+1,4); uWS (B,>=N,2); Ts scalar or (B,).
     Obstacles: one shared set (vOb 1-D, A (M,2), b (M,)) or per-instance lists.  lWS/nWS=None runs DualMultWS on the GPU."""
     B = np.reshape(x0, (-1, 4)).shape[0]
     bt = Batch(_ctx(device), B, N)
     try:
-        bt.upload(x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS, nWS)
+        bt.upload(x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS, nWS, dist)
         t0 = time.perf_counter()
         bt.solve(opts)
         dt = time.perf_counter() - t0
@@ -263,6 +265,17 @@ def ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, r
                                   np.reshape(np.ravel(ryaw)[:N + 1], (1, -1)), fixTime, np.asarray(xWS, float)[None, :N + 1],
                                   np.asarray(uWS, float)[None, :N], opts=opts, device=device)
     ts = np.ones((1, N + 1)) if fixTime else r["timeScale"][0]          # ParkingSignedDist.jl:304-308
+    return r["xp"][0], r["up"][0], ts, int(r["exitflag"][0]), r["time"], r["lp"][0], r["np"][0]
+
+
+def ParkingDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, opts=None, device=0):
+    """Drop-in for ParkingDist.jl:29 (the collision-free sibling of ParkingSignedDist): same arguments, same 7-tuple."""
+    assert int(nOb) == len(np.ravel(vOb))
+    r = parking_signed_dist_batch(np.reshape(x0, (1, 4)), np.reshape(xF, (1, 4)), N, Ts, L, ego, XYbounds, vOb, A, b,
+                                  np.reshape(np.ravel(rx)[:N + 1], (1, -1)), np.reshape(np.ravel(ry)[:N + 1], (1, -1)),
+                                  np.reshape(np.ravel(ryaw)[:N + 1], (1, -1)), fixTime, np.asarray(xWS, float)[None, :N + 1],
+                                  np.asarray(uWS, float)[None, :N], opts=opts, device=device, dist=True)
+    ts = np.ones((1, N + 1)) if fixTime else r["timeScale"][0]
     return r["xp"][0], r["up"][0], ts, int(r["exitflag"][0]), r["time"], r["lp"][0], r["np"][0]
 
 

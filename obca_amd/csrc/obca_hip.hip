@@ -116,7 +116,7 @@ struct obca_ctx { int device; hipStream_t stream; std::string err; std::string n
 static std::string g_create_err;
 
 struct obca_batch {
-    obca_ctx *ctx; int B, N, nObMax, MMax, zlen, have_duals, uploaded;
+    obca_ctx *ctx; int B, N, nObMax, MMax, zlen, have_duals, uploaded, dist;
     DevBufs d;
     std::vector<int> nOb, M, obOff, rowOff;
     std::vector<double> Ts; int fixTime;
@@ -168,7 +168,7 @@ int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
     if (!ctx || !out) return -1;
     if (B < 1 || N < 0 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
-    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0;
+    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0;
     memset(&bt->d, 0, sizeof bt->d);
     hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventCreate(&bt->e0)); HIPCHK(ctx, hipEventCreate(&bt->e1)); HIPCHK(ctx, hipEventCreate(&bt->e2));
@@ -190,6 +190,7 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   
     HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
+int obca_batch_set_formulation(obca_batch *bt, int dist) { if (!bt) return -1; bt->dist = dist ? 1 : 0; return 0; }   /* before obca_batch_upload */
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 
 int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double ego[4], const double XYb[4], int fixTime,
@@ -232,7 +233,7 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
     for (int i = 0; i < B; i++) {
         double *p = hp.data() + (size_t)i * d.s_prob;
         const int n = bt->nOb[i], m = bt->M[i];
-        p[PH_TS] = Ts[i]; p[PH_L] = L;
+        p[PH_TS] = Ts[i]; p[PH_L] = L; p[PH_DIST] = bt->dist ? 1.0 : 0.0;
         p[PH_G] = L_ev / 2; p[PH_G + 1] = W_ev / 2; p[PH_G + 2] = L_ev / 2; p[PH_G + 3] = W_ev / 2;
         p[PH_OFF] = (ego[0] + ego[2]) / 2 - ego[2];
         p[PH_XL] = XYb[0]; p[PH_XL + 1] = XYb[2]; p[PH_XL + 2] = -1e300; p[PH_XL + 3] = -1.0;     /* :104-106 */
@@ -324,22 +325,39 @@ int obca_batch_download(obca_batch *bt, double *xp, double *up, double *ts, int 
     return 0;
 }
 
-int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
-                                   int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
-                                   const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
-                                   const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
-                                   double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
+static int parking_batch(obca_ctx *ctx, int dist, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
+                         int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
+                         const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
+                         const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
+                         double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
     if (!ctx) return -1;
-    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_signed_dist_batch: NULL argument"; return -1; }
+    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_(signed_)dist_batch: NULL argument"; return -1; }
     obca_batch *bt = nullptr;
     int rc = obca_batch_create(ctx, B, N, &bt);
     if (rc) return rc;
+    obca_batch_set_formulation(bt, dist);
     rc = obca_batch_upload(bt, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS);
     if (!rc) rc = obca_batch_solve(bt, opts);
     if (!rc) rc = obca_batch_sync(bt);
     if (!rc) rc = obca_batch_download(bt, xp, up, timeScale, exitflag, lp, np, slp, info);
     obca_batch_destroy(bt);
     return rc;
+}
+int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
+                                   int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
+                                   const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
+                                   const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
+                                   double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
+    return parking_batch(ctx, 0, B, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opts, xp, up,
+                         timeScale, exitflag, lp, np, slp, info);
+}
+int obca_parking_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
+                            int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
+                            const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
+                            const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
+                            double *up, double *timeScale, int *exitflag, double *lp, double *np, double *info) {
+    return parking_batch(ctx, 1, B, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opts, xp, up,
+                         timeScale, exitflag, lp, np, nullptr, info);
 }
 
 int obca_dualmult_ws_batch(obca_ctx *ctx, int B, int N, const double ego[4], const int *nOb, const int *vOb, const double *A,

@@ -23,6 +23,7 @@ namespace obca {
 struct Consts {               // uniform per instance
     double Ts, L, g[4], off, xl[4], xu[4], x0[4], xF[4];
     int fixTime, nOb, M, N;
+    int dist;                 // 1: ParkingDist.jl formulation (next-1 sibling), 0: ParkingSignedDist.jl
     double wa, wpsi;          // ParkingSignedDist.jl:78-92 (fixTime switches the weights)
 };
 
@@ -176,6 +177,7 @@ struct ObsIn {
     double a1[VM], a2[VM], b[VM];
     double lam[VM], zl[VM], mu[4], zm[4], y[4];
     double sl, so, zso, X, Y, psi;
+    double zs1;              // ParkingDist only: multiplier of the norm-row slack, which lives in `sl`
 };
 
 // the four rows c1..c4 (ParkingSignedDist.jl:198-206, c4 has the slack `so` and dmin moved to the left)
@@ -186,11 +188,11 @@ OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
     for (int i = 0; i < VM; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
     double sn, cs;
     sincos(in.psi, &sn, &cs);
-    r[0] = p1 * p1 + p2 * p2 - 1;
+    r[0] = p1 * p1 + p2 * p2 - 1 + (c.dist ? in.sl : 0.0);          // ParkingDist.jl:200: <= 1 (its slack is kept in the sl slot)
     r[1] = in.mu[0] - in.mu[2] + cs * p1 + sn * p2;
     r[2] = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
     r[3] = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * c.off) * p1 +
-           (in.Y + sn * c.off) * p2 - beta + in.sl - OB_DMIN - in.so;
+           (in.Y + sn * c.off) * p2 - beta + (c.dist ? 0.0 : in.sl) - OB_DMIN - in.so;   // ParkingDist.jl:207-208: no slack
 }
 
 struct ObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
@@ -215,11 +217,11 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     sincos(in.psi, &sn, &cs);
     const double off = c.off;
     double cr[4];
-    cr[0] = p1 * p1 + p2 * p2 - 1;
+    cr[0] = p1 * p1 + p2 * p2 - 1 + (c.dist ? in.sl : 0.0);
     cr[1] = in.mu[0] - in.mu[2] + cs * p1 + sn * p2;
     cr[2] = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
     cr[3] = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * off) * p1 +
-            (in.Y + sn * off) * p2 - beta + in.sl - OB_DMIN - in.so;
+            (in.Y + sn * off) * p2 - beta + (c.dist ? 0.0 : in.sl) - OB_DMIN - in.so;
     const double *y = in.y;
     // Jacobians
     double Jl[4][VM];
@@ -238,8 +240,12 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     const double Jmu[3][4] = {{1, 0, -1, 0}, {0, 1, 0, -1}, {-c.g[0], -c.g[1], -c.g[2], -c.g[3]}};
     // local stationarity residuals, diagonals
     const double iso = 1.0 / in.so;
-    const double iDso = 1.0 / (in.zso * iso + dw), iDsl = 1.0 / (2e4 + dw);
-    double r_so = -y[3] - mu_b * iso, r_sl = 1e2 + 2e4 * in.sl + y[3];
+    // sl: the free penetration slack of ParkingSignedDist (cost 1e2 sl + 1e4 sl^2, enters row 4) or, in the ParkingDist formulation,
+    // the slack s1 >= 0 of the norm row 1 (no cost, barrier, multiplier zs1); either way a diagonal pivot
+    const double isl = c.dist ? 1.0 / in.sl : 0.0;
+    const double iDso = 1.0 / (in.zso * iso + dw), iDsl = 1.0 / ((c.dist ? in.zs1 * isl : 2e4) + dw);
+    const double iDs4 = c.dist ? 0.0 : iDsl, iDs1 = c.dist ? iDsl : 0.0;          // where the pivot lands: row 4 or row 1
+    double r_so = -y[3] - mu_b * iso, r_sl = c.dist ? y[0] - mu_b * isl : 1e2 + 2e4 * in.sl + y[3];
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -265,7 +271,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     }
     if (MODE == 0) {
         double rz = fabs(-y[3] - in.zso); if (rz > st->dmax) st->dmax = rz;
-        if (fabs(r_sl) > st->dmax) st->dmax = fabs(r_sl);
+        { const double rzs = c.dist ? fabs(y[0] - in.zs1) : fabs(r_sl); if (rzs > st->dmax) st->dmax = rzs; }
+        if (c.dist) { const double c1 = in.sl * in.zs1; if (fabs(c1) > st->cmax0) st->cmax0 = fabs(c1); if (fabs(c1 - mu_b) > st->cmaxmu) st->cmaxmu = fabs(c1 - mu_b); st->sumz += fabs(in.zs1); }
         double cc = in.so * in.zso; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
         st->sumz += fabs(in.zso);
 #pragma unroll
@@ -282,7 +289,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
             for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * Jmu[s_][i] * iDmu[i];
             Tm[r * 3 + s_] = a_ + (r == s_ ? dc : 0.0);
         }
-    Tm[8] += iDso + iDsl;
+    Tm[8] += iDso + iDs4;
     double r234[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -291,7 +298,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] * iDmu[i];
         r234[r] = a_;
     }
-    r234[2] += -r_so * iDso + r_sl * iDsl;
+    r234[2] += -r_so * iDso + r_sl * iDs4;
     int bad = ldl_fact<3>(3, Tm);
     // W = T^{-1} [Jl234 | Jp234 | r234]
     double W[3][VM + 4];
@@ -332,7 +339,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + 3];
         rk[i] = i < v ? a_ : 0.0;
     }
-    rk[VM] = -cr[0];
+    rk[VM] = -cr[0] + r_sl * iDs1;
+    const double dc1 = dc + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
     // Householder Qh q = alpha e1
     double hw[VM], nq = 0;
 #pragma unroll
@@ -357,9 +365,9 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     }
 #pragma unroll
     for (int i = 0; i < VM; i++) hh_apply<VM>(v, hw, Kb + i * VM);
-    double a00 = Kb[0], det = a00 * (-dc) - alpha * alpha;
+    double a00 = Kb[0], det = a00 * (-dc1) - alpha * alpha;
     if (!(det < 0)) bad = 1;
-    const double idet = 1.0 / det, Mi0 = -dc * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
+    const double idet = 1.0 / det, Mi0 = -dc1 * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
     double hc[VM - 1], Hr[(VM - 1) * (VM - 1)];
 #pragma unroll
     for (int i = 0; i < VM - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * VM] : 0.0;
@@ -447,7 +455,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
             double jy = Jmu[0][i] * r3[0] + Jmu[1][i] * r3[1] + Jmu[2][i] * r3[2];
             step->dmu[i] = (-r_mu[i] - jy) * iDmu[i];
         }
-        step->dsl = (-r_sl - r3[2]) * iDsl;
+        step->dsl = (-r_sl - (c.dist ? col[VM] : r3[2])) * iDsl;
         step->dso = (r3[2] - r_so) * iDso;
     }
 }

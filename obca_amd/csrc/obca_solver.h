@@ -96,6 +96,7 @@ namespace obca {
 #define PH_NOB 24
 #define PH_M 25
 #define PH_VOB 26
+#define PH_DIST 47     // 1: ParkingDist.jl formulation
 #define PH_ROFF 36
 #define PH_A 48
 #define PH_B 128
@@ -128,7 +129,7 @@ struct Opts {
 };
 
 struct Lay {
-    int x, u, t, lam, mu, sl, so, ss, pi, nu, yg, yo, zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, nprimal, len;
+    int x, u, t, lam, mu, sl, so, ss, pi, nu, yg, yo, zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, zs1, nprimal, len;   // zs1: multiplier of the norm-row slack (ParkingDist only)
 };
 OBCA_HD void make_layout(int N, int nOb, int M, Lay &l) {
     int N1 = N + 1, o = 0;
@@ -138,7 +139,7 @@ OBCA_HD void make_layout(int N, int nOb, int M, Lay &l) {
     l.pi = o; o += 4 * N; l.nu = o; o += 4; l.yg = o; o += N; l.yo = o; o += 4 * nOb * N1;
     l.zxL = o; o += 4 * N1; l.zxU = o; o += 4 * N1; l.zuL = o; o += 2 * N; l.zuU = o; o += 2 * N;
     l.ztL = o; o += 1; l.ztU = o; o += 1; l.zlam = o; o += M * N1; l.zmu = o; o += 4 * nOb * N1;
-    l.zso = o; o += nOb * N1; l.zssL = o; o += N; l.zssU = o; o += N; l.len = o;
+    l.zso = o; o += nOb * N1; l.zssL = o; o += N; l.zssU = o; o += N; l.zs1 = o; o += nOb * N1; l.len = o;
 }
 
 struct AsmOut { int ok; double dinf, pinf, cinf0, cinfmu, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };
@@ -219,7 +220,7 @@ OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) { in.mu[i] = z[l.mu + 4 * bo + i]; in.zm[i] = z[l.zmu + 4 * bo + i]; in.y[i] = z[l.yo + 4 * bo + i]; }
-    in.sl = z[l.sl + bo]; in.so = z[l.so + bo]; in.zso = z[l.zso + bo];
+    in.sl = z[l.sl + bo]; in.so = z[l.so + bo]; in.zso = z[l.zso + bo]; in.zs1 = z[l.zs1 + bo];
     in.X = z[l.x + 4 * k]; in.Y = z[l.x + 4 * k + 1]; in.psi = z[l.x + 4 * k + 2];
 }
 
@@ -260,12 +261,12 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
 #pragma unroll
             for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
-            fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
+            if (!c.dist) fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
             double r[4]; obs_rows<VM>(c, in, r);
             th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) bar += log(in.lam[i]);
-            bar += log(in.mu[0]) + log(in.mu[1]) + log(in.mu[2]) + log(in.mu[3]) + log(in.so);
+            bar += log(in.mu[0]) + log(in.mu[1]) + log(in.mu[2]) + log(in.mu[3]) + log(in.so) + (c.dist ? log(in.sl) : 0.0);
         }
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
@@ -453,7 +454,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
     bar += red_sum(sh.red[8]);
     double Htt = red_sum(sh.red[9]), gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
     SYNC();
-    int nb = 6 * N + 4 * N + 2 * N + (M + 5 * nOb) * (N + 1);
+    int nb = 6 * N + 4 * N + 2 * N + (M + (c.dist ? 6 : 5) * nOb) * (N + 1);
     int nm = 4 * N + 4 + N + 4 * nOb * (N + 1);
     if (!c.fixTime) {
         double d0 = 0, d1 = 0, d2 = 0;
@@ -888,7 +889,8 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
                 FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], mu / in.mu[i] - in.zm[i] - in.zm[i] / in.mu[i] * st.dmu[i]);
             }
             d[l.sl + it] = st.dsl; d[l.so + it] = st.dso;
-            lgd += (1e2 + 2e4 * in.sl) * st.dsl - mu / in.so * st.dso;
+            lgd += (c.dist ? -mu / in.sl : 1e2 + 2e4 * in.sl) * st.dsl - mu / in.so * st.dso;
+            if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, mu / in.sl - in.zs1 - in.zs1 / in.sl * st.dsl); }
             FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
         }
         sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
@@ -951,11 +953,11 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
             for (int i = 0; i < VM; i++) if (i < in.v) { in.lam[i] += alpha * d[l.lam + k * M + r0 + i]; lbar += log(in.lam[i]); }
 #pragma unroll
             for (int i = 0; i < 4; i++) { in.mu[i] += alpha * d[l.mu + 4 * it + i]; lbar += log(in.mu[i]); }
-            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it]; lbar += log(in.so);
+            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it]; lbar += log(in.so) + (c.dist ? log(in.sl) : 0.0);
             in.X += alpha * d[l.x + 4 * k]; in.Y += alpha * d[l.x + 4 * k + 1]; in.psi += alpha * d[l.x + 4 * k + 2];
             double r[4]; obs_rows<VM>(c, in, r);
             lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
-            lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
+            if (!c.dist) lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
         }
         for (int k = lane; k <= N; k += OB_NT) {
             double x[4];
@@ -1017,7 +1019,11 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
             double v = z[l.so + i], dv = d[l.so + i], zz = z[l.zso + i];
             zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
             z[l.so + i] = v; z[l.zso + i] = clampz(zz, v, mu, ks);
-            z[l.sl + i] += alpha * d[l.sl + i];
+            if (c.dist) {
+                double v1 = z[l.sl + i], dv1 = d[l.sl + i], z1 = z[l.zs1 + i];
+                z1 = zstep(z1, v1, dv1, mu, az); v1 += alpha * dv1;
+                z[l.sl + i] = v1; z[l.zs1 + i] = clampz(z1, v1, mu, ks);
+            } else z[l.sl + i] += alpha * d[l.sl + i];
         }
         for (int k = lane; k <= N; k += OB_NT) {
             if (k >= 1) {
@@ -1091,9 +1097,10 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
-            in.so = 0;
+            in.so = 0; if (c.dist) in.sl = 0;
             double r[4]; obs_rows<VM>(c, in, r);
             z[l.so + it] = r[3];
+            if (c.dist) z[l.sl + it] = -r[0];          // slack of |A'lam|^2 <= 1 takes the row value
         }
     }
     SYNC();
@@ -1112,7 +1119,7 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
         if (lane == 4 && !c.fixTime) z[l.t] = push2(z[l.t], OB_TL, OB_TU, o.bound_push, o.bound_frac);
         for (int i = lane; i < M * (N + 1); i += OB_NT) z[l.lam + i] = fmax(z[l.lam + i], o.bound_push);
         for (int i = lane; i < 4 * nOb * (N + 1); i += OB_NT) z[l.mu + i] = fmax(z[l.mu + i], o.bound_push);
-        for (int i = lane; i < nOb * (N + 1); i += OB_NT) z[l.so + i] = fmax(z[l.so + i], o.bound_push);
+        for (int i = lane; i < nOb * (N + 1); i += OB_NT) { z[l.so + i] = fmax(z[l.so + i], o.bound_push); if (c.dist) z[l.sl + i] = fmax(z[l.sl + i], o.bound_push); }
     }
     SYNC();
 }
@@ -1145,6 +1152,54 @@ OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double k
 // ---------------------------------------------------------------- the interior-point driver
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
+
+// The reference's acceptance test on the current iterate, with its quirks (ParkingConstraints.jl:29-149): in variable-time
+// mode only the speed row of the dynamics is kept (:76-79), only the LAST obstacle's rows survive (:108-130), the separation row is
+// evaluated without any slack, the steering rate divides by timeScale[1].  1 = every class <= 5e-5.  Cold path (failed attempts only).
+template <int VM>
+OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M; const gdbl *z = I.z;
+    const double t = c.fixTime ? 1.0 : z[l.t];
+    PAR(lane) {
+        double w = -1e300;                                     // running max of every "should be <= 0" quantity
+        for (int i = lane; i < M * (N + 1); i += OB_NT) w = fmax(w, -z[l.lam + i]);
+        for (int i = lane; i < 4 * nOb * (N + 1); i += OB_NT) w = fmax(w, -z[l.mu + i]);
+        for (int k = lane; k < N; k += OB_NT) {
+            double x[4], u[2], F[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i];
+            u[0] = z[l.u + 2 * k]; u[1] = z[l.u + 2 * k + 1];
+            w = fmax(w, fmax(fabs(u[0]) - 0.6, fabs(u[1]) - 0.4));
+            dyn_value(c, x, u, t, F);
+            if (c.fixTime) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) w = fmax(w, fabs(z[l.x + 4 * (k + 1) + i] - F[i]));
+            } else w = fmax(w, fabs(z[l.x + 4 * (k + 1) + 3] - F[3]));
+            w = fmax(w, fabs(u[0] - (k ? z[l.u + 2 * k - 2] : 0.0)) / (t * c.Ts) - 0.6);
+        }
+        if (lane < 4) w = fmax(w, fabs(z[l.x + 4 * N + lane] - c.xF[lane]));
+        if (lane == 4) w = fmax(w, fabs(t - 1) - 0.2);
+        if (nOb > 0) for (int k = lane; k <= N; k += OB_NT) {
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, nOb - 1, in);
+            in.sl = 0; in.so = 0;
+            double p1 = 0, p2 = 0, beta = 0;
+#pragma unroll
+            for (int i = 0; i < VM; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+            double sn, cs; sincos(in.psi, &sn, &cs);
+            const double r0 = p1 * p1 + p2 * p2 - 1;
+            const double r1 = in.mu[0] - in.mu[2] + cs * p1 + sn * p2, r2 = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
+            const double r3 = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * c.off) * p1 +
+                              (in.Y + sn * c.off) * p2 - beta - OB_DMIN;
+            w = fmax(w, fmax(sd ? fabs(r0 + 1) - 1 : r0, fmax(fmax(fabs(r1), fabs(r2)), -r3)));
+        }
+        sh.red[0][lane] = w;
+    }
+    SYNC();
+    const double worst = red_max(sh.red[0]);
+    SYNC();
+    return worst <= 5e-5;
+}
+OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vm2 ? ref_constraints<2>(sh.inst, sh, sd) : ref_constraints<OB_VMAX>(sh.inst, sh, sd); }
 
 OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
     Shared &sh = g_sh;
@@ -1248,21 +1303,27 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
             c.N = N; c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
             for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
             c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
-            c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
+            c.dist = (int)sh.hdr[PH_DIST];
+            c.wa = (c.fixTime || c.dist) ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;      // ParkingDist.jl:87
             make_layout(c.N, c.nOb, c.M, sh.l);
             int vmx = 0; for (int j = 0; j < c.nOb; j++) { int v = (int)sh.hdr[PH_VOB + j]; if (v > vmx) vmx = v; }
             sh.vm2 = vmx <= 2;
         }
     }
     SYNC();
+    // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
+    // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
     Result R;
     ipm_attempt(o, R);
     int ef = (R.status == ST_OPTIMAL), iters = R.iters, nreg = R.nreg;
-    if (!ef) {
+    int retry = !ef;
+    if (retry && sh.c.dist && ph_ref_constraints(0)) { ef = 1; retry = 0; }
+    if (retry) {
         Result R2;
         ipm_attempt(o, R2);
         iters += R2.iters; nreg += R2.nreg;
         if (R2.status == ST_OPTIMAL) ef = 1;
+        else { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); ef = sh.c.dist ? !feas : feas; }
         R = R2;
     }
     PAR(lane) {

@@ -11,17 +11,17 @@ The argument conventions are those of ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbound
 import numpy as np
 
 OB_VMAX, OB_NOBMAX, OB_MMAX, OB_HDR = 4, 10, 40, 168
-PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=36, A=48, B=128)
-LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU nprimal len").split()
+PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=36, DIST=47, A=48, B=128)
+LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU zs1 nprimal len").split()
 
 
 def layout(N, nOb, M):
     N1 = N + 1
     sizes = [4 * N1, 2 * N, 1, M * N1, 4 * nOb * N1, nOb * N1, nOb * N1, N, 4 * N, 4, N, 4 * nOb * N1,
-             4 * N1, 4 * N1, 2 * N, 2 * N, 1, 1, M * N1, 4 * nOb * N1, nOb * N1, N, N]
+             4 * N1, 4 * N1, 2 * N, 2 * N, 1, 1, M * N1, 4 * nOb * N1, nOb * N1, N, N, nOb * N1]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
-    L = dict(zip(LAYOUT_FIELDS[:23], off[:23].tolist()))
-    L["nprimal"] = int(off[8]); L["len"] = int(off[23])
+    L = dict(zip(LAYOUT_FIELDS[:24], off[:24].tolist()))
+    L["nprimal"] = int(off[8]); L["len"] = int(off[24])
     return L
 
 
@@ -34,13 +34,13 @@ def check_obstacles(vOb):
     return vOb
 
 
-def pack_problem(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime):
+def pack_problem(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, dist=0):
     vOb = check_obstacles(vOb)
     nOb, M = len(vOb), int(vOb.sum())
     A = np.asarray(A, float).reshape(M, 2); b = np.asarray(b, float).ravel()
     ego = np.asarray(ego, float).ravel(); XYb = np.asarray(XYbounds, float).ravel()
     p = np.zeros(OB_HDR + 3 * (N + 1))
-    p[PH["TS"]] = Ts; p[PH["L"]] = L
+    p[PH["TS"]] = Ts; p[PH["L"]] = L; p[PH["DIST"]] = float(int(dist))      # 1: ParkingDist.jl formulation
     W_ev, L_ev = ego[1] + ego[3], ego[0] + ego[2]                      # ParkingSignedDist.jl:182-188
     p[PH["G"]:PH["G"] + 4] = [L_ev / 2, W_ev / 2, L_ev / 2, W_ev / 2]
     p[PH["OFF"]] = (ego[0] + ego[2]) / 2 - ego[2]

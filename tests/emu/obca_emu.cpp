@@ -29,7 +29,8 @@ static void setup(int N, const double *prob, Scratch &s) {
     c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
     for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
     c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
-    c.wa = c.fixTime ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
+    c.dist = (int)sh.hdr[PH_DIST];
+    c.wa = (c.fixTime || c.dist) ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
     make_layout(c.N, c.nOb, c.M, sh.l);
     int vmx = 0; for (int j = 0; j < c.nOb; j++) if (sh.vOb[j] > vmx) vmx = sh.vOb[j];
     sh.vm2 = vmx <= 2;

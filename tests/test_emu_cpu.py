@@ -20,7 +20,11 @@ def test_layouts_agree(oracle):
         assert all(a[k] == b[k] for k in a)
 
 
-def test_emu_newton_direction_matches_oracle(oracle, emu, backwards):
+import pytest
+
+
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_emu_newton_direction_matches_oracle(oracle, emu, backwards, dist):
     rng = np.random.default_rng(3)
     for N in (3, 9):
         sc = S.BACKWARDS; A, b, v = backwards["A"], backwards["b"], backwards["vOb"]; nOb = len(v); M = int(v.sum())
@@ -32,20 +36,22 @@ def test_emu_newton_direction_matches_oracle(oracle, emu, backwards):
         z[L["u"]:L["t"]] = np.clip(uWS + 0.05 * rng.standard_normal((N, 2)), -0.3, 0.3).reshape(-1)
         z[L["t"]] = 0.95
         z[L["lam"]:L["sl"]] = rng.uniform(0.1, 1, L["sl"] - L["lam"])
-        z[L["sl"]:L["so"]] = 0.01 * rng.standard_normal(L["so"] - L["sl"])
+        z[L["sl"]:L["so"]] = rng.uniform(0.1, 1, L["so"] - L["sl"]) if dist else 0.01 * rng.standard_normal(L["so"] - L["sl"])
         z[L["so"]:L["ss"]] = rng.uniform(0.1, 1, L["ss"] - L["so"])
         z[L["ss"]:L["pi"]] = rng.uniform(-0.3, 0.3, N)
         z[L["pi"]:L["zxL"]] = rng.standard_normal(L["zxL"] - L["pi"])
         z[L["zxL"]:] = rng.uniform(0.1, 2, L["len"] - L["zxL"])
         mu, dw, dc = 0.05, 5.0, 1e-7
-        ok, d, errs = oracle.newton(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc)
-        prob = P.pack_problem(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        ok, d, errs = oracle.newton(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc, dist=dist)
+        prob = P.pack_problem(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
         d2 = np.zeros_like(z); aux = np.zeros(10)
         ok2 = emu.emu_newton(C.c_int(N), dp(prob), dp(z), C.c_int(L["len"]), C.c_double(mu), C.c_double(dw), C.c_double(dc),
                              C.c_double(1e3), C.c_double(0.99), dp(d2), dp(aux))
         assert ok == 1 and ok2 == 1
         nd = L["zxL"]
         assert np.abs(d[:nd] - d2[:nd]).max() < 1e-9 * max(1.0, np.abs(d[:nd]).max())
+        if dist:
+            assert np.abs(d[L["sl"]:L["so"]]).max() > 0       # the norm-row slack moves
         assert np.allclose(aux[:3], errs, rtol=1e-10)
         # objective / constraint norm / barrier of eval_trial at alpha=0 equal the assembly's
         out = np.zeros(3)
@@ -53,7 +59,8 @@ def test_emu_newton_direction_matches_oracle(oracle, emu, backwards):
         assert np.allclose(out, aux[4:7], rtol=1e-12)
 
 
-def test_emu_full_solve_matches_oracle(oracle, emu, backwards):
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_emu_full_solve_matches_oracle(oracle, emu, backwards, dist):
     N, B = 20, 3
     bt = S.make_batch(S.BACKWARDS, B, N)
     v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
@@ -65,9 +72,9 @@ def test_emu_full_solve_matches_oracle(oracle, emu, backwards):
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
         lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
-                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS, dist=dist)
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
-                              xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+                              xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
         z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
         zo = np.zeros_like(z0); info = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
@@ -94,3 +101,36 @@ def test_emu_dualws_matches_oracle(oracle, emu, backwards):
             assert abs(d.value - do[0, j]) < 1e-10 and np.abs(lam[:vj] - lo[0, r0:r0 + vj]).max() < 1e-9
             assert np.abs(mu - no[0, 4 * j:4 * j + 4]).max() < 1e-9
             r0 += vj
+
+
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_emu_exit_flag_after_failed_attempts_follows_the_reference(oracle, emu, backwards, dist):
+    """both attempts hit the iteration limit: ParkingSignedDist then asks its acceptance test (infeasible -> 0, :278-283); ParkingDist asks it
+    before the retry and INVERTS it afterwards (infeasible -> exitflag 1, ParkingDist.jl:277-282) -- reproduced, not fixed"""
+    N = 20; bt = S.make_batch(S.BACKWARDS, 1, N)
+    v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+    oo = oracle.default_opts(); oo.max_iter = 3; eo = EOpts()
+    for n, _ in EOpts._fields_:
+        setattr(eo, n, getattr(oo, n))
+    xWS = bt["xWS"][0].copy(); xWS[0] = bt["x0"][0]
+    lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+    r = oracle.parking_signed_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                                   xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][0], lWS, nWS, opts=oo, dist=dist)
+    prob = P.pack_problem(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                          xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
+    z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][0], lWS, nWS)
+    zo = np.zeros_like(z0); info = np.zeros(8)
+    emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+    assert r["status"] == 1 and int(info[0]) == 1 and int(info[1]) == r["iters"] == 6
+    assert r["exitflag"] == int(info[7]) == (1 if dist else 0)
+    # the acceptance test itself: C restatement == the verbatim Python restatement, on an optimal and on an unfinished solution
+    import checkers as K
+    ro = oracle.parking_signed_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                                    xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][0], lWS, nWS, dist=dist)
+    for sol in (ro, r):
+        a = K.parking_constraints_ref(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], nOb, v, bt["A"], bt["b"],
+                                      sol["xp"], sol["up"], sol["lp"], sol["np"], np.full(N + 1, sol["t"]), 0, 0 if dist else 1)
+        b_ = oracle.ref_constraints(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                                    sol["xp"], sol["up"], sol["t"], sol["lp"], sol["np"], 0, 0 if dist else 1)
+        assert a == b_
+    assert ro["exitflag"] == 1

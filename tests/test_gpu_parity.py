@@ -88,6 +88,38 @@ def test_parking_matches_oracle_config3_parallel(OA, oracle):
         assert K.feasible(K.parking_constraints_full(*args, out["sl"][i]), tol=1e-4)
 
 
+def test_parking_dist_variant_matches_oracle(OA, oracle):
+    """ParkingDist: no penetration slack, |A'lam|^2 <= 1 with its own slack, 0.5 a^2, its own exit-flag logic"""
+    import checkers as K
+    N, B = 80, 48
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                       xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"], dist=True)
+    assert (out["exitflag"] == 1).all()
+    for i in range(0, B, 6):
+        r = oracle.parking_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert r["exitflag"] == 1 and out["iters"][i] == r["iters"]
+        assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and np.abs(out["up"][i] - r["up"]).max() < TOL_X
+        assert abs(out["obj"][i] - r["obj"]) < TOL_F * abs(r["obj"])
+    for i in range(B):      # collision-free: every separation row holds without any slack; the reference's own acceptance test (sd = 0) passes
+        ts = out["timeScale"][i]
+        args = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"], bt["A"], bt["b"],
+                out["xp"][i], out["up"][i], out["lp"][i], out["np"][i], ts, 0)
+        assert K.parking_constraints_ref(*args, 0) == 1
+        viol = K.parking_constraints_full(*args, np.zeros_like(out["sl"][i]))
+        assert viol["penetration"] <= 1e-6
+    # single-instance wrapper and the exit-flag quirk after two failed attempts (ParkingDist.jl:277-282, SURVEY Q6)
+    xp, up, ts, ef, t, lp, npp = OA.ParkingDist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"],
+                                               bt["A"], bt["b"], xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0])
+    assert ef == 1 and np.abs(xp - out["xp"][0]).max() < 1e-12
+    o = OA.default_opts(); o.max_iter = 3
+    bad = OA.parking_signed_dist_batch(bt["x0"][:4], bt["xF"][:4], N, bt["Ts"][:4], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[:4, :, 0], xWS[:4, :, 1], xWS[:4, :, 2], 0, xWS[:4], bt["uWS"][:4], opts=o, dist=True)
+    assert (bad["status"] == 1).all() and (bad["iters"] == 6).all() and (bad["exitflag"] == 1).all()
+
+
 def test_full_size_properties_config2(OA):
     """B=1024 (BASELINE config 2): size-independent properties -- every converged instance passes the reference's own
     acceptance test (ParkingConstraints.jl @5e-5) and the full checker; boundary conditions hold exactly; solving twice is
