@@ -249,3 +249,29 @@ def make_quad_batch(B, N=60, seed=20260925, jitter=0.3):
         x0[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3)); xF[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3))
     xWS = np.stack([quad_warm_start(x0[i], xF[i], N) for i in range(B)])
     return dict(x0=x0, xF=xF, N=N, Ts=quad_sample_time(N), R=QUAD_R, ob=QUAD_OB.copy(), xWS=xWS, timeWS=1.0)
+
+
+# ---------------------------------------------------------------- BASELINE config 5: mixed obstacle counts
+def make_mixed_batch(B, N=80, seed=20260925, max_extra=7):
+    """config-5 style batch: the backwards-parking scenario plus 0..max_extra extra convex obstacles per instance (triangles = 3 rows,
+    quadrilaterals = 4 rows, clockwise vertices through obstHrep) placed in the block left of the slot where the car never goes, so every
+    instance stays solvable while nOb runs from 3 to 10 and M from 5 to 33: irregular per-instance H-rep packing, 1-4 rows per obstacle."""
+    rng = np.random.default_rng(seed)
+    base = make_batch(BACKWARDS, B, N, seed=seed)
+    sc = BACKWARDS
+    vl, Al, bl = [], [], []
+    for i in range(B):
+        nex = int(rng.integers(0, max_extra + 1))
+        lOb = [list(map(list, o)) for o in sc["lOb"]]; vOb = list(sc["vOb"])
+        for _ in range(nex):
+            cx, cy, r = rng.uniform(-13, -4), rng.uniform(2.0, 4.0), rng.uniform(0.3, 0.8)
+            nv = int(rng.integers(3, 5))                                   # triangle or quadrilateral
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv))[::-1]             # clockwise
+            while np.min(np.diff(np.concatenate([ang[::-1], [ang[-1] + 2 * np.pi]]))) < 0.5:
+                ang = np.sort(rng.uniform(0, 2 * np.pi, nv))[::-1]
+            pts = [[cx + r * np.cos(a), cy + r * np.sin(a)] for a in ang]
+            lOb.append(pts + [pts[0]]); vOb.append(nv + 1)                 # closed polygon: nv edges = nv rows
+        A, b = obst_hrep(len(vOb), vOb, lOb)
+        vl.append(np.asarray(vOb) - 1); Al.append(A); bl.append(b)
+    base.update(vOb=vl, A=Al, b=bl)
+    return base

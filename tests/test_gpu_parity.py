@@ -192,6 +192,23 @@ def test_mixed_obstacle_counts_ragged_batch(OA, oracle):
             assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
 
 
+def test_config5_mixed_obstacle_counts_up_to_the_limits(OA, oracle):
+    """BASELINE config 5 (reduced batch): 3..10 obstacles with 1..4 half-space rows each per instance, M up to 33, in ONE launch"""
+    N, B = 80, 96
+    bt = S.make_mixed_batch(B, N)
+    assert max(len(v) for v in bt["vOb"]) == 10 and max(int(v.max()) for v in bt["vOb"]) == 4 and min(len(v) for v in bt["vOb"]) == 3
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                       xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    assert (out["exitflag"] == 1).mean() >= 0.95          # ~2 % of these synthetic instances do not converge (neither does the oracle on them)
+    for i in range(0, B, 9):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i],
+                                       bt["b"][i], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert r["exitflag"] == 1 == out["exitflag"][i]
+        assert out["iters"][i] == r["iters"] and np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+        assert out["lp"][i].shape == (int(bt["vOb"][i].sum()), N + 1) and np.abs(out["lp"][i] - r["lp"]).max() < 1e-5
+
+
 def test_bad_inputs_fail_loudly_not_crash(OA):
     N = 10; bt = S.make_batch(S.BACKWARDS, 2, N)
     xWS = bt["xWS"].copy()
