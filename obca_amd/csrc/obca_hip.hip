@@ -228,7 +228,8 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
         bt->bytes = (long long)tot;
     }
     const DevBufs &d = bt->d;
-    std::vector<double> hp((size_t)B * d.s_prob, 0.0), hz((size_t)B * d.s_z, 0.0);
+    const size_t W = (size_t)lmax.nprimal;                 // only the primal prefix (x,u,t,lam,mu,...) of the iterate travels over PCIe
+    std::vector<double> hp((size_t)B * d.s_prob, 0.0), hz((size_t)B * W, 0.0);
     const double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];     /* ParkingSignedDist.jl:182-188 */
     for (int i = 0; i < B; i++) {
         double *p = hp.data() + (size_t)i * d.s_prob;
@@ -246,7 +247,7 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
         for (int r = 0; r < m; r++) { p[PH_A + 2 * r] = A[2 * (bt->rowOff[i] + r)]; p[PH_A + 2 * r + 1] = A[2 * (bt->rowOff[i] + r) + 1]; p[PH_B + r] = b[bt->rowOff[i] + r]; }
         for (int k = 0; k < N1; k++) { p[OB_HDR + k] = rx[(size_t)i * N1 + k]; p[OB_HDR + N1 + k] = ry[(size_t)i * N1 + k]; p[OB_HDR + 2 * N1 + k] = ryaw[(size_t)i * N1 + k]; }
         Lay l; make_layout(N, n, m, l);
-        double *z = hz.data() + (size_t)i * d.s_z;
+        double *z = hz.data() + (size_t)i * W;
         if (xWS) memcpy(z + l.x, xWS + (size_t)i * 4 * N1, sizeof(double) * 4 * N1);
         if (uWS) memcpy(z + l.u, uWS + (size_t)i * 2 * N, sizeof(double) * 2 * N);
         z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
@@ -258,7 +259,8 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
     bt->have_duals = (lWS && nWS) ? 1 : 0; bt->fixTime = fixTime ? 1 : 0;
     bt->Ts.assign(Ts, Ts + B);
     HIPCHK(ctx, hipMemcpyAsync(d.prob, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d.z0, hz.data(), hz.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d.z0, 0, (size_t)B * d.s_z * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(d.z0, d.s_z * sizeof(double), hz.data(), W * sizeof(double), W * sizeof(double), B, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     bt->uploaded = 1;
     return 0;
@@ -306,13 +308,15 @@ int obca_batch_download(obca_batch *bt, double *xp, double *up, double *ts, int 
     const int B = bt->B, N = bt->N, N1 = N + 1;
     const DevBufs &d = bt->d;
     hipSetDevice(ctx->device);
-    std::vector<double> hz((size_t)B * d.s_z), hi((size_t)B * 8);
-    HIPCHK(ctx, hipMemcpyAsync(hz.data(), d.z, hz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
+    const size_t W = (size_t)lmax.so;                       // outputs are a prefix of the iterate: x, u, t, lam, mu, sl
+    std::vector<double> hz((size_t)B * W), hi((size_t)B * 8);
+    HIPCHK(ctx, hipMemcpy2DAsync(hz.data(), W * sizeof(double), d.z, d.s_z * sizeof(double), W * sizeof(double), B, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hi.data(), d.info, hi.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < B; i++) {
         Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
-        const double *z = hz.data() + (size_t)i * d.s_z;
+        const double *z = hz.data() + (size_t)i * W;
         if (xp) memcpy(xp + (size_t)i * 4 * N1, z + l.x, sizeof(double) * 4 * N1);
         if (up) memcpy(up + (size_t)i * 2 * N, z + l.u, sizeof(double) * 2 * N);
         if (ts) for (int k = 0; k < N1; k++) ts[(size_t)i * N1 + k] = bt->fixTime ? 1.0 : z[l.t];   /* ParkingSignedDist.jl:304-308 */
