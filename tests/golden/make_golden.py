@@ -6,6 +6,8 @@ Generates the fixtures under tests/golden/ (run from the repo root:  python test
   oracle_cfg2.npz   : structured C oracle on the first 8 instances of config 2 (backwards parking, N=80, seed 20260925)
   oracle_cfg3.npz   : structured C oracle on 6 instances of config 3 (parallel parking, 4 obstacles, N=80) with Hybrid A* warm starts
                       (obca_amd/planner.py); the fixture stores the warm starts too, so the test does not depend on the planner
+  slsqp_N8.npz      : the same N=8 NLP solved by a THIRD-PARTY solver (scipy.optimize SLSQP, an SQP method unrelated to the oracle's
+                      interior point) from the same warm start, autograd derivatives of oracle/nlp_ref.py (--scipy, ~40 s)
   dualws_known.npz  : poses + closed-form rectangle/half-plane distances for the DualMultWS known-answer test
 
 The reference itself (Julia 0.6 + JuMP + IPOPT) cannot run in this environment and ships no golden vectors
@@ -70,6 +72,28 @@ def oracle_cfg3(B=6, N=80):
     print("oracle_cfg3.npz", meta["exitflag"], meta["iters"])
 
 
+def slsqp_case(N=8):
+    import torch
+    from nlp_ref import ParkingNLP
+    from scipy.optimize import minimize, Bounds
+    sc = S.BACKWARDS; A, b, v = S.scenario_hrep(sc); x0 = sc["x0"].copy()
+    Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); xWS[0] = x0
+    lWS, nWS, _ = O.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
+    nlp = ParkingNLP(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2])
+    f = lambda w: nlp.f(torch.tensor(w)).item()
+    g = lambda w: torch.autograd.functional.jacobian(nlp.f, torch.tensor(w)).numpy()
+    c = lambda w: nlp.c(torch.tensor(w)).numpy()
+    J = lambda w: torch.autograd.functional.jacobian(nlp.c, torch.tensor(w)).numpy()
+    lb = np.where(np.isfinite(nlp.lb), nlp.lb, -np.inf); ub = np.where(np.isfinite(nlp.ub), nlp.ub, np.inf)
+    v0 = np.clip(nlp.pack_start(xWS, uWS, lWS, nWS), lb + 1e-3, ub - 1e-3)
+    res = minimize(f, v0, jac=g, method="SLSQP", bounds=Bounds(lb, ub), constraints=[dict(type="eq", fun=c, jac=J)],
+                   options=dict(maxiter=500, ftol=1e-12))
+    x, t, u, lam, mu, sl, ss, so = nlp.unpack(torch.tensor(res.x))
+    np.savez(os.path.join(OUT, f"slsqp_N{N}.npz"), N=N, x0=x0, xF=sc["xF"], Ts=Ts, xWS=xWS, uWS=uWS, lWS=lWS, nWS=nWS, status=res.status,
+             nit=res.nit, obj=res.fun, cviol=np.abs(c(res.x)).max(), xp=x.numpy().T, up=u.numpy().T, t=float(t))
+    print("slsqp", res.status, res.message, res.nit, res.fun)
+
+
 def dualws_known():
     # single half-plane obstacle a'p <= beta (unit a), rectangle centre c = (X+1.35 cos, Y+1.35 sin), half extents (2.35, 1):
     # d = max(0, -(a'c - beta) ... ) -- the obstacle is {p : a'p <= beta}; the car is outside it when a'c - support > beta
@@ -95,3 +119,5 @@ if __name__ == "__main__":
     oracle_cfg3()
     if "--dense" in sys.argv:
         dense_case(8)
+    if "--scipy" in sys.argv:
+        slsqp_case(8)

@@ -56,6 +56,19 @@ def test_oracle_matches_dense_ipm_fixture(oracle, backwards):
     assert abs(r["t"] - float(g["t"])) < 1e-4
 
 
+def test_oracle_optimum_matches_third_party_sqp_fixture(oracle, backwards):
+    """the same N=8 NLP solved by scipy's SLSQP (a sequential-quadratic-programming code unrelated to the oracle's interior point):
+    same optimum.  The objective is flat along the trajectory (weights 1e-3), hence the looser state tolerance."""
+    g = golden("slsqp_N8.npz"); N = int(g["N"])
+    assert int(g["status"]) == 0 and float(g["cviol"]) < 1e-10
+    r = oracle.parking_signed_dist(g["x0"], g["xF"], N, float(g["Ts"]), backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
+                                   backwards["A"], backwards["b"], g["xWS"][:, 0], g["xWS"][:, 1], g["xWS"][:, 2], 0, g["xWS"], g["uWS"],
+                                   g["lWS"], g["nWS"])
+    assert r["exitflag"] == 1
+    assert abs(r["obj"] - float(g["obj"])) < 1e-4 * abs(float(g["obj"])) and r["obj"] >= float(g["obj"]) - 1e-9   # barrier: from above
+    assert np.abs(r["xp"] - g["xp"]).max() < 1e-2 and np.abs(r["up"] - g["up"]).max() < 5e-3 and abs(r["t"] - float(g["t"])) < 1e-5
+
+
 @pytest.mark.parametrize("name,scn", [("oracle_cfg2.npz", "backwards")])
 def test_oracle_reproduces_golden(oracle, name, scn):
     g = golden(name)
