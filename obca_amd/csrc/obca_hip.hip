@@ -1,8 +1,9 @@
 // obca_hip.hip -- HIP kernels and the C ABI of libobca_hip.so (gfx950 only; see include/obca_hip.h).
 //
 // Kernels
-//   obca_parking_ipm_kernel : one 64-lane workgroup (one wavefront) per problem instance, persistent over the whole
-//                             interior-point solve (obca_solver.h).  grid = B, block = 64.
+//   obca_parking_ipm_kernel : one 128-thread workgroup (two wavefronts) per problem instance, persistent over the whole
+//                             interior-point solve (obca_solver.h).  grid = B, block = 128.
+//   obca_quad_ipm_kernel    : the same for the quadcopter NLP (obca_quad_solver.h).
 //   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
 //   prob  header+rx,ry,ryaw   [411]      z  primal-dual iterate [6554]      d  search direction [3804 used]

@@ -95,7 +95,10 @@ def warm_start(sc, x0, xF, N, **kw):
     A, b, vrows = S.scenario_hrep(sc)
     o, v_nom = SCENARIO_OPTS.get(sc["name"], (dict(), 0.5))
     o = dict(o); o.update(kw)
-    r = hybrid_astar(np.asarray(x0, float)[:3], np.asarray(xF, float)[:3], vrows, A, b, **o)
+    try:
+        r = hybrid_astar(np.asarray(x0, float)[:3], np.asarray(xF, float)[:3], vrows, A, b, **o)
+    except ValueError:          # start (or goal) pose in collision: no collision-free path exists
+        return None
     if r is None:
         return None
     return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom)
