@@ -1134,13 +1134,31 @@ OBCA_PHASE void ph_assemble_obs2(double mu, double dw, double dc) { Shared &sh =
 OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc); }
 OBCA_FN void ph_assemble_obs(double mu, double dw, double dc) { if (g_sh.vm2) ph_assemble_obs2(mu, dw, dc); else ph_assemble_obs4(mu, dw, dc); }
 OBCA_PHASE void ph_assemble_stage(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
-OBCA_FN void ph_assemble(double mu, double dw, double dc, int second) { ph_assemble_obs(mu, dw, dc); ph_assemble_stage(mu, dw, dc, second); }
+// the two assembly parts of the common (<= 2 rows per obstacle) case share ONE non-inlined function: every call of a register-hungry phase
+// saves / restores the 112 callee-saved VGPRs through scratch, so fewer calls = less HBM traffic
+OBCA_PHASE void ph_assemble2(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_obs<2>(sh.inst, sh, mu, dw, dc); assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_FN void ph_assemble(double mu, double dw, double dc, int second) { if (g_sh.vm2) ph_assemble2(mu, dw, dc, second); else { ph_assemble_obs(mu, dw, dc); ph_assemble_stage(mu, dw, dc, second); } }
 OBCA_PHASE int ph_riccati(double rho) { Shared &sh = g_sh; return riccati_backward(sh.inst, sh, rho); }
 OBCA_PHASE void ph_direction_main(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
 OBCA_PHASE void ph_direction_obs2(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
 OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
 OBCA_FN void ph_direction_obs(double mu, double dw, double dc, double tau) { if (g_sh.vm2) ph_direction_obs2(mu, dw, dc, tau); else ph_direction_obs4(mu, dw, dc, tau); }
+OBCA_PHASE void ph_direction2(double mu, double dw, double dc, double rho, double tau) {   // both parts in one call, see ph_assemble2
+    Shared &sh = g_sh;
+    direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
+    if (sh.S.ok) direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S);
+}
+// one whole Newton pass (assemble -> Riccati -> direction) of the common case in ONE call: one callee-saved-register round trip per pass
+OBCA_PHASE int ph_newton2(double mu, double dw, double dc, double rho, double tau, int do_asm) {
+    Shared &sh = g_sh;
+    if (do_asm) { assemble_obs<2>(sh.inst, sh, mu, dw, dc); assemble_stage(sh.inst, sh, mu, dw, dc, sh.A); }
+    int a_ = UNIFORM(sh.A.ok);
+    if (a_) a_ = riccati_backward(sh.inst, sh, rho);
+    if (a_) { direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); a_ = UNIFORM(sh.S.ok); if (a_) direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+    return a_;
+}
 OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double tau) {
+    if (g_sh.vm2) { ph_direction2(mu, dw, dc, rho, tau); return; }
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
@@ -1237,10 +1255,14 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
         // search direction with inertia correction (IPOPT Algorithm IC)
         double dw = 0; int ok = 0;
         for (int tr = 0; tr < 60; tr++) {
-            if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
-            int a_ = A.ok;
-            if (a_) a_ = ph_riccati(o.rho_term);
-            if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+            int a_;
+            if (sh.vm2) a_ = ph_newton2(mu, dw, dc, o.rho_term, tau, tr > 0 || mu_changed);
+            else {
+                if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
+                a_ = A.ok;
+                if (a_) a_ = ph_riccati(o.rho_term);
+                if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+            }
             if (a_) { ok = 1; break; }
             nreg++;
             if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);
