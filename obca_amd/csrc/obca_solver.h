@@ -1003,61 +1003,76 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     gdbl *z = I.z; const gdbl *d = I.d;
     PAR(lane) {
-        // one-sided (>=0) groups: lam, mu, so
-        for (int i = lane; i < M * (N + 1); i += OB_NT) {
-            double v = z[l.lam + i], dv = d[l.lam + i], zz = z[l.zlam + i];
-            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
-            z[l.lam + i] = v; z[l.zlam + i] = clampz(zz, v, mu, ks);
+        // one-sided (>= 0) groups: lam, mu (+ yo), so.  The iterate is read and written in place, so a load placed after a store cannot be
+        // hoisted by the compiler (may alias): every group is processed AP_R items per lane at a time, all loads first, then the stores --
+        // one memory round trip per chunk instead of one per item.
+#define AP_R 4
+        for (int base = 0; base < M * (N + 1); base += AP_R * OB_NT) {
+            double v[AP_R], dv[AP_R], zz[AP_R];
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < M * (N + 1) ? i : 0; v[r] = z[l.lam + ic]; dv[r] = d[l.lam + ic]; zz[r] = z[l.zlam + ic]; }
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < M * (N + 1)) {
+                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
+                z[l.lam + i] = v1; z[l.zlam + i] = clampz(z1, v1, mu, ks); } }
         }
-        for (int i = lane; i < 4 * nOb * (N + 1); i += OB_NT) {
-            double v = z[l.mu + i], dv = d[l.mu + i], zz = z[l.zmu + i];
-            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
-            z[l.mu + i] = v; z[l.zmu + i] = clampz(zz, v, mu, ks);
-            z[l.yo + i] += ay * d[l.yo + i];
+        for (int base = 0; base < 4 * nOb * (N + 1); base += AP_R * OB_NT) {
+            double v[AP_R], dv[AP_R], zz[AP_R], yv[AP_R], dyv[AP_R];
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < 4 * nOb * (N + 1) ? i : 0;
+                v[r] = z[l.mu + ic]; dv[r] = d[l.mu + ic]; zz[r] = z[l.zmu + ic]; yv[r] = z[l.yo + ic]; dyv[r] = d[l.yo + ic]; }
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < 4 * nOb * (N + 1)) {
+                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
+                z[l.mu + i] = v1; z[l.zmu + i] = clampz(z1, v1, mu, ks); z[l.yo + i] = yv[r] + ay * dyv[r]; } }
         }
-        for (int i = lane; i < nOb * (N + 1); i += OB_NT) {
-            double v = z[l.so + i], dv = d[l.so + i], zz = z[l.zso + i];
-            zz = zstep(zz, v, dv, mu, az); v += alpha * dv;
-            z[l.so + i] = v; z[l.zso + i] = clampz(zz, v, mu, ks);
-            if (c.dist) {
-                double v1 = z[l.sl + i], dv1 = d[l.sl + i], z1 = z[l.zs1 + i];
-                z1 = zstep(z1, v1, dv1, mu, az); v1 += alpha * dv1;
-                z[l.sl + i] = v1; z[l.zs1 + i] = clampz(z1, v1, mu, ks);
-            } else z[l.sl + i] += alpha * d[l.sl + i];
+        for (int base = 0; base < nOb * (N + 1); base += AP_R * OB_NT) {
+            double v[AP_R], dv[AP_R], zz[AP_R], sv[AP_R], dsv[AP_R], z1v[AP_R];
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < nOb * (N + 1) ? i : 0;
+                v[r] = z[l.so + ic]; dv[r] = d[l.so + ic]; zz[r] = z[l.zso + ic]; sv[r] = z[l.sl + ic]; dsv[r] = d[l.sl + ic]; z1v[r] = z[l.zs1 + ic]; }
+#pragma unroll
+            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < nOb * (N + 1)) {
+                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
+                z[l.so + i] = v1; z[l.zso + i] = clampz(z1, v1, mu, ks);
+                const double s1 = sv[r] + alpha * dsv[r];
+                z[l.sl + i] = s1;
+                if (c.dist) z[l.zs1 + i] = clampz(zstep(z1v[r], sv[r], dsv[r], mu, az), s1, mu, ks); } }
         }
-        for (int k = lane; k <= N; k += OB_NT) {
+        for (int k = lane; k <= N; k += OB_NT) {   // one stage per lane: all loads of the stage first (clamped indices), then the stores
+            const int ku = k < N ? k : N - 1;
+            double xv[4], dxv[4], zxl[4], zxu[4], uv[2], duv[2], zul[2], zuu[2], piv[4], dpi[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int idx = 4 * k + i; xv[i] = z[l.x + idx]; dxv[i] = d[l.x + idx]; zxl[i] = z[l.zxL + idx]; zxu[i] = z[l.zxU + idx];
+                                          piv[i] = z[l.pi + 4 * ku + i]; dpi[i] = d[l.pi + 4 * ku + i]; }
+#pragma unroll
+            for (int i = 0; i < 2; i++) { const int idx = 2 * ku + i; uv[i] = z[l.u + idx]; duv[i] = d[l.u + idx]; zul[i] = z[l.zuL + idx]; zuu[i] = z[l.zuU + idx]; }
+            const double ssv = z[l.ss + ku], dss = d[l.ss + ku], zsl = z[l.zssL + ku], zsu = z[l.zssU + ku], ygv = z[l.yg + ku], dyg = d[l.yg + ku];
             if (k >= 1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    int idx = 4 * k + i; double v = z[l.x + idx], dv = d[l.x + idx];
+                    const int idx = 4 * k + i; const double v = xv[i] + alpha * dxv[i];
                     if (i != 2) {
-                        double dL = v - c.xl[i], dU = c.xu[i] - v, zL = z[l.zxL + idx], zU = z[l.zxU + idx];
-                        zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
-                        v += alpha * dv;
+                        const double zL = zstep(zxl[i], xv[i] - c.xl[i], dxv[i], mu, az), zU = zstep(zxu[i], c.xu[i] - xv[i], -dxv[i], mu, az);
                         z[l.zxL + idx] = clampz(zL, v - c.xl[i], mu, ks); z[l.zxU + idx] = clampz(zU, c.xu[i] - v, mu, ks);
-                    } else v += alpha * dv;
+                    }
                     z[l.x + idx] = v;
                 }
             }
             if (k < N) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    int idx = 2 * k + i; double v = z[l.u + idx], dv = d[l.u + idx];
-                    const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
-                    double dL = v - lo, dU = hi - v, zL = z[l.zuL + idx], zU = z[l.zuU + idx];
-                    zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
-                    v += alpha * dv;
+                    const int idx = 2 * k + i; const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
+                    const double zL = zstep(zul[i], uv[i] - lo, duv[i], mu, az), zU = zstep(zuu[i], hi - uv[i], -duv[i], mu, az), v = uv[i] + alpha * duv[i];
                     z[l.u + idx] = v; z[l.zuL + idx] = clampz(zL, v - lo, mu, ks); z[l.zuU + idx] = clampz(zU, hi - v, mu, ks);
                 }
                 {
-                    double v = z[l.ss + k], dv = d[l.ss + k], dL = v + OB_SSB, dU = OB_SSB - v, zL = z[l.zssL + k], zU = z[l.zssU + k];
-                    zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
-                    v += alpha * dv;
+                    const double zL = zstep(zsl, ssv + OB_SSB, dss, mu, az), zU = zstep(zsu, OB_SSB - ssv, -dss, mu, az), v = ssv + alpha * dss;
                     z[l.ss + k] = v; z[l.zssL + k] = clampz(zL, v + OB_SSB, mu, ks); z[l.zssU + k] = clampz(zU, OB_SSB - v, mu, ks);
                 }
-                z[l.yg + k] += ay * d[l.yg + k];
+                z[l.yg + k] = ygv + ay * dyg;
 #pragma unroll
-                for (int i = 0; i < 4; i++) z[l.pi + 4 * k + i] += ay * d[l.pi + 4 * k + i];
+                for (int i = 0; i < 4; i++) z[l.pi + 4 * k + i] = piv[i] + ay * dpi[i];
             }
         }
         if (lane < 4) z[l.nu + lane] += ay * d[l.nu + lane];

@@ -110,7 +110,8 @@ def _ws_job(args):
 
 
 def warm_start_many(sc, x0, xF, N, workers=None):
-    """warm starts of a batch on the host cores (one search per process)."""
+    """warm starts of a batch on the host cores (one search per forked process).  Call it before a HIP context exists in this process, or
+    pass workers=1: fork() next to a live GPU runtime is not safe."""
     jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N) for a, g in zip(x0, xF)]
     workers = min(len(jobs), workers or os.cpu_count() or 1)
     if workers <= 1 or len(jobs) < 4:

@@ -68,12 +68,13 @@ def test_parking_matches_oracle_config3_parallel(OA, oracle):
     import checkers as K
     g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
     A, b, v = S.scenario_hrep(S.PARALLEL)
+    fresh = S.make_batch(S.PARALLEL, 32, N, seed=7, workers=1)      # planned in-process: no fork() next to a live HIP runtime
     bt = dict(x0=g["x0"], xF=g["xF"], Ts=g["Ts"], xWS=g["xWS"], uWS=g["uWS"], A=A, b=b, vOb=v, N=N, L=S.L_WHEELBASE, ego=S.EGO, XYbounds=S.XYBOUNDS)
     out, _ = _solve_batch(OA, bt)
     assert (out["exitflag"] == 1).all() and (out["iters"] == g["iters"]).all()
     assert np.abs(out["xp"] - g["xp"]).max() < TOL_X and np.abs(out["up"] - g["up"]).max() < TOL_X
     assert np.abs(out["obj"] - g["obj"]).max() < TOL_F * np.abs(g["obj"]).max()
-    bt = S.make_batch(S.PARALLEL, 32, N, seed=7)
+    bt = fresh
     out, xWS = _solve_batch(OA, bt)
     assert (out["exitflag"] == 1).mean() >= 0.9
     for i in range(0, 32, 5):
