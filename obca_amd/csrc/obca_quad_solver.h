@@ -505,7 +505,6 @@ OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
 // ---------------------------------------------------------------- border, forward sweep, stage-parallel back-substitution
 OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
-    so.ok = 1;
     // ---- 13x13 border in (dt, nu) from the bilinear constants: eliminate nu (S = -B(nu,nu) must be PD) then t.  Wavefront 0.
     WAVE0_BEGIN
         double *S = sh.bord, *col = sh.bord + 169, *colr = col + 13;   // S 12x12 (stride 12)
@@ -547,7 +546,10 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     WAVE0_END
     SYNC();
     QPROF(QPF_BORDER);
-    if (!sh.bord_ok) { so.ok = 0; return; }
+    {   // stored ONCE: both wavefronts write the shared slot, it must never hold an intermediate value
+        const int ok = sh.bord_ok; so.ok = ok;
+        if (!ok) return;
+    }
     const double dt = sh.coef[1];
     // ---- closed-loop maps per stage: Acl = [A + B K ; K], bcl = [B kf + d + dt Ft ; kf]
     PAR(lane) {
@@ -768,9 +770,11 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
         sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
     }
     SYNC();
-    f = red_sum(sh.red[0]); th1 = red_sum(sh.red[1]); bar = red_sum(sh.red[2]);
+    // finish the values in registers and store each shared slot exactly once (both wavefronts write them; see eval_trial in obca_solver.h)
+    double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
-    f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+    fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+    f = fr; th1 = tr; bar = br;
 }
 
 // ---------------------------------------------------------------- accept the step (generic over the primal vector)

@@ -662,7 +662,7 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
 OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
-    so.ok = 1;
+    int ok = 1;     // kept in a register and stored ONCE: both wavefronts write the shared slot, so it must never hold an intermediate value
     // ---- 5x5 border in (dt, nu): all entries are bilinear constants of the Riccati value function
     double dt, nu[4];
     {
@@ -675,18 +675,19 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             for (int b_ = 0; b_ < 4; b_++) S[a_ * 4 + b_] = -B[(2 + a_) * 6 + (2 + b_)];
             col[a_] = -B[(2 + a_) * 6 + 1]; colr[a_] = -(e[a_] - B[(2 + a_) * 6 + 0]);
         }
-        if (ldl_fact<4>(4, S)) so.ok = 0;
+        if (ldl_fact<4>(4, S)) ok = 0;
         ldl_solve<4>(4, S, col); ldl_solve<4>(4, S, colr);
         double piv = att, rr = rt;
         for (int a_ = 0; a_ < 4; a_++) { piv -= B[1 * 6 + 2 + a_] * col[a_]; rr -= B[1 * 6 + 2 + a_] * colr[a_]; }
         if (c.fixTime) { dt = 0; for (int a_ = 0; a_ < 4; a_++) nu[a_] = colr[a_]; }
         else {
-            if (!(piv > 0)) so.ok = 0;
+            if (!(piv > 0)) ok = 0;
             dt = rr / piv;
             for (int a_ = 0; a_ < 4; a_++) nu[a_] = colr[a_] - col[a_] * dt;
         }
     }
-    if (!so.ok) return;
+    so.ok = ok;
+    if (!ok) return;
     const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
     // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
     PAR(lane) {
@@ -988,9 +989,12 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
         sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
     }
     SYNC();
-    f = red_sum(sh.red[0]); th1 = red_sum(sh.red[1]); bar = red_sum(sh.red[2]);
+    // f, th1, bar live in LDS and BOTH wavefronts write them: finish the values in registers and store each exactly once (a read-modify-write
+    // of the shared slot here was a data race: the slower wavefront could add the t terms on top of the faster one's finished value)
+    double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
-    if (!c.fixTime) { f += (N + 1) * (0.5 * t + t * t); bar += (N + 1) * (log(t - OB_TL) + log(OB_TU - t)); }
+    if (!c.fixTime) { fr += (N + 1) * (0.5 * t + t * t); br += (N + 1) * (log(t - OB_TL) + log(OB_TU - t)); }
+    f = fr; th1 = tr; bar = br;
     PROF(I, PF_TRIAL);
 }
 
