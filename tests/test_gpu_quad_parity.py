@@ -42,6 +42,9 @@ def test_quad_batch_parity_and_feasibility(Q):
     out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
     ok = out["exitflag"] == 1
     assert ok.mean() >= 0.9, (ok.mean(), out["iters"])
+    for rep in range(4):        # repeated solves are bit-identical (no race between the two wavefronts of an instance)
+        o2 = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
+        assert np.array_equal(o2["iters"], out["iters"]) and np.abs(o2["xp"] - out["xp"]).max() == 0.0, rep
     n_it = 0
     for i in range(6):
         r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
