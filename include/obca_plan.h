@@ -27,6 +27,12 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
 int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, const double *A, const double *b, const double ego[4],
                        const double XYbounds[4], double margin);
 
+/* 3-D grid A* for the quadcopter warm start (stands where mainQuadcopter.jl:124-128 calls a_star.calc_astar_path, a_star_3D.jl): 26-connected
+ * grid of spacing res over the room [0,room[0]] x [0,room[1]] x [0,room[2]]; boxes nBox x 6 as [xmax,ymax,zmax,-xmin,-ymin,-zmin], inflated by
+ * `clear`.  path receives way-points start .. goal.  Returns their number, 0 = no path, -1 = bad arguments, -2 = start / goal blocked. */
+int obca_plan_astar3d(const double start[3], const double goal[3], int nBox, const double *boxes, double clear, const double room[3],
+                      double res, double *path, int cap, int *expansions /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,4 +210,61 @@ int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, 
     return collides(w, x, y, yaw) ? 1 : 0;
 }
 
+/*
+ * 3-D grid A* for the quadcopter warm start (the role of a_star_3D.jl / mainQuadcopter.jl:108-138): 26-connected grid of spacing `res`
+ * over the room [0, room[0]] x [0, room[1]] x [0, room[2]], boxes = nBox x 6 as [xmax,ymax,zmax,-xmin,-ymin,-zmin] inflated by `clear`
+ * (ball radius + margin), Euclidean heuristic.  Output: path[3k..] way-points from start to goal (grid nodes, end points exact),
+ * at most cap.  Returns the number of way-points (>= 2), 0 = no path, -1 = bad arguments, -2 = start or goal inside an inflated box.
+ */
+int obca_plan_astar3d(const double start[3], const double goal[3], int nBox, const double *boxes, double clear, const double room[3],
+                      double res, double *path, int cap, int *expansions) {
+    if (!start || !goal || nBox < 0 || (nBox && !boxes) || !room || !path || cap < 2 || !(res > 0)) return -1;
+    const int nx = (int)std::floor(room[0] / res) + 1, ny = (int)std::floor(room[1] / res) + 1, nz = (int)std::floor(room[2] / res) + 1;
+    if ((long long)nx * ny * nz > 64000000LL) return -1;
+    auto blocked = [&](double x, double y, double z) {
+        if (x < 0 || y < 0 || z < 0 || x > room[0] || y > room[1] || z > room[2]) return true;
+        for (int j = 0; j < nBox; j++) {
+            const double *b = boxes + 6 * j;
+            if (x <= b[0] + clear && y <= b[1] + clear && z <= b[2] + clear && x >= -b[3] - clear && y >= -b[4] - clear && z >= -b[5] - clear) return true;
+        }
+        return false;
+    };
+    if (blocked(start[0], start[1], start[2]) || blocked(goal[0], goal[1], goal[2])) return -2;
+    auto cell = [&](const double p[3], int c[3]) { for (int i = 0; i < 3; i++) c[i] = (int)std::lround(p[i] / res); c[0] = std::min(c[0], nx - 1); c[1] = std::min(c[1], ny - 1); c[2] = std::min(c[2], nz - 1); };
+    int cs[3], cg[3]; cell(start, cs); cell(goal, cg);
+    auto id = [&](int x, int y, int z) { return ((size_t)z * ny + y) * nx + x; };
+    const size_t ncell = (size_t)nx * ny * nz;
+    std::vector<float> g(ncell, 1e30f); std::vector<int> par(ncell, -1);
+    typedef std::pair<float, int> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> open;
+    auto h = [&](int x, int y, int z) { return (float)(res * std::sqrt((double)(x - cg[0]) * (x - cg[0]) + (double)(y - cg[1]) * (y - cg[1]) + (double)(z - cg[2]) * (z - cg[2]))); };
+    const size_t s0 = id(cs[0], cs[1], cs[2]), gid = id(cg[0], cg[1], cg[2]);
+    g[s0] = 0; open.push({h(cs[0], cs[1], cs[2]), (int)s0});
+    long nexp = 0; bool found = false;
+    while (!open.empty()) {
+        const QE e = open.top(); open.pop();
+        const size_t c = (size_t)e.second; const int cx = (int)(c % nx), cy = (int)((c / nx) % ny), cz = (int)(c / ((size_t)nx * ny));
+        if (e.first > g[c] + h(cx, cy, cz) + 1e-4f) continue;
+        if (c == gid) { found = true; break; }
+        nexp++;
+        for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            if (!dx && !dy && !dz) continue;
+            const int qx = cx + dx, qy = cy + dy, qz = cz + dz;
+            if (qx < 0 || qy < 0 || qz < 0 || qx >= nx || qy >= ny || qz >= nz) continue;
+            if (blocked(qx * res, qy * res, qz * res)) continue;
+            const size_t q = id(qx, qy, qz); const float gn = g[c] + (float)(res * std::sqrt((double)(dx * dx + dy * dy + dz * dz)));
+            if (gn < g[q]) { g[q] = gn; par[q] = (int)c; open.push({gn + h(qx, qy, qz), (int)q}); }
+        }
+    }
+    if (expansions) *expansions = (int)nexp;
+    if (!found) return 0;
+    std::vector<size_t> chain; for (long c = (long)gid; c >= 0; c = par[(size_t)c]) chain.push_back((size_t)c);
+    std::reverse(chain.begin(), chain.end());
+    const int cnt = (int)chain.size() + 2;
+    if (cnt > cap) return -1;
+    int k = 0; path[0] = start[0]; path[1] = start[1]; path[2] = start[2]; k = 1;
+    for (size_t c : chain) { path[3 * k] = (c % nx) * res; path[3 * k + 1] = ((c / nx) % ny) * res; path[3 * k + 2] = (c / ((size_t)nx * ny)) * res; k++; }
+    path[3 * k] = goal[0]; path[3 * k + 1] = goal[1]; path[3 * k + 2] = goal[2]; k++;
+    return k;
+}
+
 }  // extern "C"

@@ -120,3 +120,27 @@ def warm_start_many(sc, x0, xF, N, workers=None):
     import multiprocessing as mp
     with mp.get_context("fork").Pool(workers) as pool:
         return pool.map(_ws_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+
+
+# ---------------------------------------------------------------- quadcopter: 3-D grid A* (a_star_3D.jl, mainQuadcopter.jl:108-138)
+QUAD_ROOM = (10.0, 10.0, 5.0)
+
+
+def astar3d(start, goal, boxes=None, clear=0.4, room=QUAD_ROOM, res=0.25):
+    """way-points (K,3) from start to goal around the boxes inflated by `clear`, or None.  boxes: (nBox,6) [max; -min] (default: the scenario's)."""
+    boxes = np.ascontiguousarray(S.QUAD_OB if boxes is None else boxes, float).reshape(-1, 6)
+    s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy(); rm = np.ascontiguousarray(room, float)
+    cap = 4096; path = np.zeros((cap, 3)); nexp = C.c_int(0)
+    n = _load().obca_plan_astar3d(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(boxes)), boxes.ctypes.data_as(_D), C.c_double(clear),
+                                  rm.ctypes.data_as(_D), C.c_double(res), path.ctypes.data_as(_D), C.c_int(cap), C.byref(nexp))
+    if n == -1:
+        raise ValueError("bad arguments")
+    return None if n <= 0 else path[:n].copy()
+
+
+def quad_warm_start(x0, xF, N, boxes=None, clear=0.4, res=0.25):
+    """A* way-points resampled uniformly in arc length to N+1 stages, all other states 0 (mainQuadcopter.jl:134-138); None if no path."""
+    wp = astar3d(x0[:3], xF[:3], boxes, clear, res=res)
+    if wp is None:
+        return None
+    return S.quad_warm_start(x0, xF, N, via=[tuple(p) for p in wp[1:-1]])

@@ -241,13 +241,27 @@ def quad_warm_start(x0, xF, N, via=QUAD_VIA):
     return xWS
 
 
-def make_quad_batch(B, N=60, seed=20260925, jitter=0.3):
-    """B instances of the shipped quadcopter scenario with start and goal positions jittered uniformly by +-jitter (instance 0 exact)."""
+def make_quad_batch(B, N=60, seed=20260925, jitter=0.3, random_endpoints=False):
+    """B instances of the quadcopter scenario.  Default: the shipped start / goal jittered uniformly by +-jitter (instance 0 exact) with the
+    way-point warm start.  random_endpoints=True: start anywhere in front of the first wall, goal anywhere behind the second, warm start from
+    the 3-D grid A* of obca_amd/planner.py (the reference's a_star_3D.jl step); instance 0 stays the shipped one."""
     rng = np.random.default_rng(seed)
     x0 = np.tile(QUAD_X0, (B, 1)); xF = np.tile(QUAD_XF, (B, 1))
-    if B > 1:
-        x0[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3)); xF[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3))
-    xWS = np.stack([quad_warm_start(x0[i], xF[i], N) for i in range(B)])
+    if not random_endpoints:
+        if B > 1:
+            x0[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3)); xF[1:, :3] += rng.uniform(-jitter, jitter, (B - 1, 3))
+        xWS = np.stack([quad_warm_start(x0[i], xF[i], N) for i in range(B)])
+    else:
+        from . import planner as PL
+        xWS = np.zeros((B, N + 1, 12))
+        for i in range(B):
+            while True:
+                if i:
+                    x0[i, :3] = [rng.uniform(0.5, 1.6), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)]
+                    xF[i, :3] = [rng.uniform(8.0, 9.5), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)]
+                w = PL.quad_warm_start(x0[i], xF[i], N)
+                if w is not None:
+                    xWS[i] = w; break
     return dict(x0=x0, xF=xF, N=N, Ts=quad_sample_time(N), R=QUAD_R, ob=QUAD_OB.copy(), xWS=xWS, timeWS=1.0)
 
 

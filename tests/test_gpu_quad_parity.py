@@ -81,3 +81,21 @@ def test_quadcopter_dist_variant_matches_oracle(Q):
     assert (out["exitflag"] == 1).mean() >= 0.9 and np.abs(out["slack"]).max() == 0
     for i in np.where(out["exitflag"] == 1)[0]:
         assert _clearance(out["xp"][i], bt["ob"]).min() >= bt["R"] - 1e-4
+
+
+def test_quad_random_endpoints_with_astar_warm_starts(Q):
+    """start / goal anywhere on either side of the two walls, warm starts from the 3-D grid A* planner"""
+    import obca_amd
+    from obca_amd import scenarios as S, validate as V
+    B, N = 32, 60
+    bt = S.make_quad_batch(B, N, random_endpoints=True)
+    out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
+    assert (out["exitflag"] == 1).mean() >= 0.9
+    for i in range(0, B, 6):
+        r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
+        assert r["exitflag"] == out["exitflag"][i]
+        if r["exitflag"] == 1:
+            assert abs(out["obj"][i] - r["obj"]) < 1e-6 * abs(r["obj"]) and np.abs(out["xp"][i] - r["xp"]).max() < 1e-3
+    for i in np.where(out["exitflag"] == 1)[0]:
+        ok, w = V.validate_quadcopter(out["xp"][i], out["up"][i], out["timeScale"][i], bt["x0"][i], bt["xF"][i], bt["Ts"], out["lp"][i], bt["ob"], bt["R"])
+        assert ok, (i, w)

@@ -52,4 +52,19 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_collides", "obca_plan_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+
+
+def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
+    """3-D grid A* (the a_star_3D.jl step): way-points stay outside the inflated boxes; the oracle converges from the resampled path"""
+    import oracle_quad as Q
+    wp = PL.astar3d(S.QUAD_X0, S.QUAD_XF, clear=0.4)
+    assert np.allclose(wp[0], S.QUAD_X0[:3]) and np.allclose(wp[-1], S.QUAD_XF[:3]) and len(wp) > 10
+    hi = S.QUAD_OB[:, :3]; lo = -S.QUAD_OB[:, 3:]
+    d = np.linalg.norm(wp[:, None, :] - np.clip(wp[:, None, :], lo[None], hi[None]), axis=2)
+    assert d.min() >= 0.4 - 1e-9 and np.linalg.norm(np.diff(wp, axis=0), axis=1).max() <= 0.25 * np.sqrt(3) + 0.26
+    assert PL.astar3d([2.2, 5.0, 2.0], S.QUAD_XF) is None            # start inside the first wall
+    bt = S.make_quad_batch(4, 40, random_endpoints=True)
+    for i in range(4):
+        r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], 40, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
+        assert r["exitflag"] == 1 and r["slack"].sum() < 1e-3
