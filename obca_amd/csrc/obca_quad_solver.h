@@ -551,62 +551,60 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         if (!ok) return;
     }
     const double dt = sh.coef[1];
-    // ---- closed-loop maps per stage: Acl = [A + B K ; K], bcl = [B kf + d + dt Ft ; kf]
-    PAR(lane) {
-        for (int k = lane; k < N; k += OB_NT) {
-            const gdbl *rec = sh.inst.as + (size_t)k * QSR; gdbl *ro = sh.inst.rs + (size_t)k * QRR;
-            double kf[QU];
-#pragma unroll
-            for (int i = 0; i < QU; i++) { double s_ = 0; for (int cc = 0; cc < QC; cc++) s_ += ro[QRR_KF + i * QC + cc] * sh.coef[cc]; kf[i] = s_; }
-            for (int i = 0; i < QX; i++) {
-                double Bi[QU];
-#pragma unroll
-                for (int a = 0; a < QU; a++) Bi[a] = rec[QSR_F + i * QFC + 12 + a];
-                for (int j = 0; j < QS; j++) {
-                    double s_ = j < QX ? rec[QSR_F + i * QFC + j] : 0.0;
-#pragma unroll
-                    for (int a = 0; a < QU; a++) s_ += Bi[a] * ro[QRR_K + a * QS + j];
-                    ro[QRR_CL + i * QS + j] = s_;
-                }
-                double s_ = rec[QSR_F + i * QFC + 16] + dt * rec[QSR_F + i * QFC + 17];
-#pragma unroll
-                for (int a = 0; a < QU; a++) s_ += Bi[a] * kf[a];
-                ro[QRR_CL + QS * QS + i] = s_;
-            }
-            for (int a = 0; a < QU; a++) { for (int j = 0; j < QS; j++) ro[QRR_CL + (QX + a) * QS + j] = ro[QRR_K + a * QS + j]; ro[QRR_CL + QS * QS + QX + a] = kf[a]; }
-        }
-    }
-    SYNC();
     QPROF(QPF_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k on wavefront 0; maps staged through LDS in chunks (ring in the reduction scratch)
+    // ---- forward recursion on wavefront 0:  u_k = K_k s_k + kf_k(coef),  x_{k+1} = A_k x_k + B_k u_k + d_k + dt Ft_k,  w_{k+1} = u_k.
+    // Per stage the first 12 rows of the dense FX block (216 doubles, stage record) and the gains K | KF (120 doubles, Riccati record) are
+    // staged through LDS in chunks of QFW_CH stages (ring in the reduction scratch, gathered one chunk ahead); no closed-loop matrices are
+    // formed.  Two LDS phases per stage: partial inputs (lanes 0..3: K s, lanes 4..7: KF coef), then the 16 state rows.
 #define QFW_CH 3
-#define QFW_SZ 272
+#define QFW_F 216
+#define QFW_SZ (QFW_F + 120)
 #define QFW_PER ((QFW_CH * QFW_SZ + 63) / 64)
     WAVE0_BEGIN
         double pf[OBCA_NL][QFW_PER];
         double *ring = &sh.red[0][0];
+        double *up = sh.sB;                       // 8 partial inputs (free after the backward sweep)
         PAR64(lane) {
             if (lane < QS) sh.traj[lane] = 0.0;
 #pragma unroll
-            for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r, st = e / QFW_SZ, j = e % QFW_SZ; if (e < QFW_CH * QFW_SZ && st < N) ring[e] = (sh.inst.rs + (size_t)st * QRR)[QRR_CL + j]; }
+            for (int r = 0; r < QFW_PER; r++) {
+                const int e = lane + 64 * r, st = e / QFW_SZ, j = e % QFW_SZ;
+                if (e < QFW_CH * QFW_SZ && st < N) ring[e] = j < QFW_F ? (sh.inst.as + (size_t)st * QSR)[QSR_F + j] : (sh.inst.rs + (size_t)st * QRR)[QRR_K + (j - QFW_F)];
+            }
         }
         LDS_SYNC();
         for (int k0 = 0; k0 < N; k0 += QFW_CH) {
             const int cb = (k0 / QFW_CH) & 1;
             PAR64(lane) {
 #pragma unroll
-                for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r, st = k0 + QFW_CH + e / QFW_SZ, j = e % QFW_SZ;
-                    pf[LI(lane)][r] = (e < QFW_CH * QFW_SZ && st < N) ? (sh.inst.rs + (size_t)st * QRR)[QRR_CL + j] : 0.0; }
+                for (int r = 0; r < QFW_PER; r++) {
+                    const int e = lane + 64 * r, st = k0 + QFW_CH + e / QFW_SZ, j = e % QFW_SZ; const int sc = st < N ? st : N - 1;
+                    const double v = j < QFW_F ? (sh.inst.as + (size_t)sc * QSR)[QSR_F + j] : (sh.inst.rs + (size_t)sc * QRR)[QRR_K + (j - QFW_F)];
+                    pf[LI(lane)][r] = v;
+                }
             }
             for (int k = k0; k < k0 + QFW_CH && k < N; k++) {
+                const double *rec = ring + (size_t)(cb * QFW_CH + (k - k0)) * QFW_SZ, *s_ = sh.traj + (size_t)k * QS;
                 PAR64(lane) {
-                    if (lane < QS) {
-                        const double *cl = ring + (size_t)(cb * QFW_CH + (k - k0)) * QFW_SZ, *s_ = sh.traj + (size_t)k * QS;
-                        double v = cl[QS * QS + lane];
+                    if (lane < QU) { double v = 0;
 #pragma unroll
-                        for (int j = 0; j < QS; j++) v += cl[lane * QS + j] * s_[j];
+                        for (int j = 0; j < QS; j++) v += rec[QFW_F + lane * QS + j] * s_[j];
+                        up[lane] = v; }
+                    else if (lane < 2 * QU) { const int i = lane - QU; double v = 0;
+#pragma unroll
+                        for (int cc = 0; cc < QC; cc++) v += rec[QFW_F + 64 + i * QC + cc] * sh.coef[cc];
+                        up[lane] = v; }
+                }
+                LDS_SYNC();
+                PAR64(lane) {
+                    if (lane < QX) {
+                        double v = rec[lane * QFC + 16] + dt * rec[lane * QFC + 17];
+#pragma unroll
+                        for (int j = 0; j < QX; j++) v += rec[lane * QFC + j] * s_[j];
+#pragma unroll
+                        for (int a = 0; a < QU; a++) v += rec[lane * QFC + 12 + a] * (up[a] + up[QU + a]);
                         sh.traj[(size_t)(k + 1) * QS + lane] = v;
-                    }
+                    } else if (lane < QS) sh.traj[(size_t)(k + 1) * QS + lane] = up[lane - QX] + up[QU + lane - QX];
                 }
                 LDS_SYNC();
             }
@@ -638,10 +636,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 }
             }
             if (k < N) {
-                const gdbl *ro = sh.inst.rs + (size_t)k * QRR;
                 for (int j = 0; j < QU; j++) {
-                    double du = ro[QRR_CL + QS * QS + QX + j];
-                    for (int i = 0; i < QS; i++) du += ro[QRR_CL + (QX + j) * QS + i] * s[i];
+                    const double du = sh.traj[(size_t)(k + 1) * QS + QX + j];        // w_{k+1} = u_k
                     d[l.u + QU * k + j] = du;
                     const double uv = z[l.u + QU * k + j];
                     double gu = -2e-3 * (c.wH - uv);
