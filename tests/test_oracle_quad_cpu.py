@@ -104,3 +104,15 @@ def test_quadcopter_dist_variant_solves_collision_free(Q):
             assert np.linalg.norm(xp[:3, k] - np.clip(xp[:3, k], lo, hi)) >= Q.EGO_R - 1e-4
     r2 = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
     assert abs(r["obj"] - r2["obj"]) < 1e-2 * abs(r2["obj"])      # the signed-distance optimum has ~zero slack, so the two optima nearly coincide
+
+
+def test_quad_oracle_optimum_matches_third_party_sqp_fixture(Q):
+    """a short hop (N=8) solved by scipy SLSQP (tests/golden/make_slsqp_quad.py): same optimal value.  The cost has no term on the path itself
+    (inputs, rates, time only), so the minimiser is not unique along it: the objective and the time scale are compared, not the positions."""
+    from conftest import golden
+    g = golden("slsqp_quad_N8.npz"); N = int(g["N"])
+    assert float(g["cviol"]) < 1e-7
+    r = Q.quadcopter_signed_dist(g["x0"], g["xF"], N, float(g["Ts"]), Q.EGO_R, Q.OB_CLAMPED, g["xWS"], 1.0)
+    assert r["exitflag"] == 1
+    assert abs(r["obj"] - float(g["obj"])) < 1e-4 * abs(float(g["obj"])) and r["obj"] >= float(g["obj"]) - 1e-9
+    assert abs(r["t"] - float(g["t"])) < 1e-5 and np.abs(r["up"] - g["up"]).max() < 5e-3
