@@ -1059,8 +1059,9 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             if (th <= th_min) amin = fmin(amin, o->delta * pow(th, o->s_theta) / pow(-gd, o->s_phi));
         } else amin = o->gamma_theta;
         amin *= o->gamma_alpha;
-        double alpha = ap; int acc = 0;
+        double alpha = ap; int acc = 0, ntrial = 0;
         while (alpha >= amin) {
+            ntrial++;
             for (int i = 0; i < l->nprimal; i++) zt[i] = z[i] + alpha * d[i];
             double ft, tht, thi;
             eval_f_theta(p, l, zt, &ft, &tht, &thi);
@@ -1081,6 +1082,7 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             }
             alpha *= 0.5;
         }
+        if (o->verbose > 1) printf("   ls: alpha_max %.3e accepted %.3e trials %d\n", ap, alpha, ntrial);
         if (!acc) { status = ST_ERROR; break; } /* IPOPT would enter restoration here */
         for (int i = 0; i < l->nprimal; i++) z[i] += alpha * d[i];
         double ay = fmin(alpha, az); /* alpha_for_y = "min" (ParkingSignedDist.jl:41) */
