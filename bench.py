@@ -160,7 +160,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     out = batch.download()
-    conv = int((out["exitflag"] == 1).sum())
+    # a solve counts only if exitflag == 1 AND the returned trajectory passes the a-posteriori checker: every constraint class of
+    # the NLP with its slack at IPOPT's constr_viol_tol (obca_amd/validate.py, pure numpy, outside the timed region)
+    from obca_amd import validate as V
+    okv = np.zeros(B, bool)
+    for i in np.flatnonzero(out["exitflag"] == 1):
+        okv[i] = V.validate_parking(bt["x0"][i], bt["xF"][i], N_HORIZON, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                    out["xp"][i], out["up"][i], out["timeScale"][i], out["lp"][i], out["np"][i], out["sl"][i], tol=1e-4)[0]
+    conv = int(okv.sum())
     passes = float((out["info"][:, 1] + out["info"][:, 6]).sum())
     stats = torch.tensor([dt, float(conv), float(out["iters"].sum()), passes, float(np.mean(ipm_ms))], dtype=torch.float64)
     if dist is not None:
@@ -182,7 +189,8 @@ def main():
                                    "variable time, 1024 randomised start poses per GPU, line/arc/line warm starts, fp64 interior point",
                        "batch_per_gpu": B, "horizon": N_HORIZON, "sharding": f"independent instances, {world} rank(s), no data-path collective", "streams": nS,
                        "converged": int(conv_all), "instances": B * world, "mean_iterations": round(iters_all / (B * world), 2),
-                       "max_iterations_rank0": int(out["iters"].max())},
+                       "max_iterations_rank0": int(out["iters"].max()), "p95_iterations_rank0": float(np.percentile(out["iters"], 95)),
+                       "exitflag1_rank0": int((out["exitflag"] == 1).sum()), "validated_rank0": int(okv.sum())},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "traffic": committed_pmc_traffic(),
                          "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
