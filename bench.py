@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU for a functional test)")
     ap.add_argument("--streams", type=int, default=1, help="device-resident copies of the batch on their own HIP streams; with 2 the steps are not "
                     "synchronised one by one, so the tail of one step (a few hard instances) overlaps the bulk of the next (default 1: the contract's step)")
     a = ap.parse_args()
@@ -120,8 +121,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            local = local % max(1, torch.cuda.device_count())          # functional test: ranks may share a device
+            torch.cuda.set_device(local)
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     B = a.batch
     bt = S.make_batch(S.BACKWARDS, B, N_HORIZON, seed=SEED + rank)
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
@@ -171,7 +177,7 @@ def main():
     passes = float((out["info"][:, 1] + out["info"][:, 6]).sum())
     stats = torch.tensor([dt, float(conv), float(out["iters"].sum()), passes, float(np.mean(ipm_ms))], dtype=torch.float64)
     if dist is not None:
-        g = stats.cuda()
+        g = stats.cuda() if a.backend == "nccl" else stats.clone()
         tmax = g[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = g[1:4].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dt = float(tmax.item()); conv_all, iters_all, passes_all = [float(v) for v in sums.cpu()]
