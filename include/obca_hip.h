@@ -81,6 +81,10 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
                       const double *lWS, const double *nWS);
 int obca_batch_solve(obca_batch *bt, const obca_opts *opts);   /* asynchronous on the context's stream: warm start -> (DualMultWS) -> IPM */
 int obca_batch_sync(obca_batch *bt);
+/* receding-horizon restart (not in the reference): replace the uploaded warm start by the last solution advanced by `shift`
+ * stages (x, u, lambda, mu and the tracking reference move up, the tail repeats the goal stage; t = 1, sl = 0), entirely on the device; the new
+ * initial state is x0_new (4 x B host, measured state) or, if NULL, stage `shift` of the solution.  The next obca_batch_solve starts from it. */
+int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new);
 int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms);   /* HIP-event durations of the last solve */
 int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *np,
                         double *slp, double *info);

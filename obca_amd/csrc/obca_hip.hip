@@ -83,6 +83,28 @@ __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObM
     if (b.dws) b.dws[(size_t)inst * per + rem] = dv;
 }
 
+// receding-horizon restart (not in the reference): the warm start of the next solve is the previous solution advanced by
+// `shift` stages -- x, lambda, mu, the tracking reference (rx, ry, ryaw) and u move up, the tail repeats the terminal stage (standing at the
+// goal: acceleration 0), t = 1 and sl = 0 as in ParkingSignedDist.jl:213-222 -- entirely on the device.  One workgroup per instance.
+__global__ __launch_bounds__(128) void obca_shift_kernel(int B, int N, int shift, DevBufs b, const double *x0_new /* 4 x B or NULL */) {
+    const int inst = blockIdx.x; if (inst >= B) return;
+    double *p = b.prob + (size_t)inst * b.s_prob; const double *z = b.z + (size_t)inst * b.s_z; double *w = b.z0 + (size_t)inst * b.s_z;
+    double *tmp = b.d + (size_t)inst * b.s_z;                      // the direction buffer is free between solves
+    const int nOb = (int)p[PH_NOB], M = (int)p[PH_M], N1 = N + 1;
+    Lay l; make_layout(N, nOb, M, l);
+    for (int i = threadIdx.x; i < 3 * N1; i += blockDim.x) { const int a = i / N1, k = i % N1, ks = min(k + shift, N); tmp[i] = p[OB_HDR + a * N1 + ks]; }
+    for (int i = threadIdx.x; i < l.nprimal; i += blockDim.x) w[i] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * N1; i += blockDim.x) p[OB_HDR + i] = tmp[i];
+    for (int i = threadIdx.x; i < 4 * N1; i += blockDim.x) { const int k = i / 4, c = i % 4, ks = min(k + shift, N); w[l.x + i] = z[l.x + 4 * ks + c]; }
+    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) { const int k = i / 2, c = i % 2, ks = min(k + shift, N - 1); w[l.u + i] = (c == 1 && k + shift > N - 1) ? 0.0 : z[l.u + 2 * ks + c]; }
+    for (int i = threadIdx.x; i < M * N1; i += blockDim.x) { const int k = i / M, c = i % M, ks = min(k + shift, N); w[l.lam + i] = z[l.lam + ks * M + c]; }
+    for (int i = threadIdx.x; i < 4 * nOb * N1; i += blockDim.x) { const int k = i / (4 * nOb), c = i % (4 * nOb), ks = min(k + shift, N); w[l.mu + i] = z[l.mu + ks * 4 * nOb + c]; }
+    __syncthreads();
+    if (threadIdx.x < 4) { const double v = x0_new ? x0_new[4 * inst + threadIdx.x] : z[l.x + 4 * min(shift, N) + threadIdx.x]; p[PH_X0 + threadIdx.x] = v; w[l.x + threadIdx.x] = v; }
+    if (threadIdx.x == 4) w[l.t] = 1.0;
+}
+
 // quadcopter path: one 128-thread workgroup per instance, persistent over the interior-point solve (obca_quad_solver.h)
 struct QDevBufs {
     double *prob, *z, *d, *as, *rs, *oc, *info, *prof;
@@ -292,6 +314,24 @@ int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
     hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(bt->e2, ctx->stream));
+    return 0;
+}
+int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new) {
+    if (!bt) return -1;
+    obca_ctx *ctx = bt->ctx;
+    if (!bt->uploaded) { ctx->err = "obca_batch_shift_warm_start: nothing uploaded"; return -1; }
+    if (shift < 0 || shift > bt->N) { ctx->err = "obca_batch_shift_warm_start: shift out of range 0..N"; return -1; }
+    hipSetDevice(ctx->device);
+    double *dx0 = nullptr;
+    if (x0_new) {
+        HIPCHK(ctx, hipMalloc((void **)&dx0, (size_t)bt->B * 4 * sizeof(double)));
+        HIPCHK(ctx, hipMemcpyAsync(dx0, x0_new, (size_t)bt->B * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(obca_shift_kernel, dim3(bt->B), dim3(128), 0, ctx->stream, bt->B, bt->N, shift, bt->d, (const double *)dx0);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dx0) hipFree(dx0);
+    bt->have_duals = 1;                                 // the shifted multipliers are the dual warm start: DualMultWS is skipped
     return 0;
 }
 int obca_batch_sync(obca_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }

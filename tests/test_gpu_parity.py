@@ -211,6 +211,34 @@ def test_config5_mixed_obstacle_counts_up_to_the_limits(OA, oracle):
         assert out["lp"][i].shape == (int(bt["vOb"][i].sum()), N + 1) and np.abs(out["lp"][i] - r["lp"]).max() < 1e-5
 
 
+def test_receding_horizon_restart_on_the_device(OA, oracle):
+    """next-4: the previous solution advanced by `shift` stages becomes the warm start of the next solve without leaving the GPU;
+    the oracle started from the same (host-built) shifted warm start takes the same iterations to the same trajectory"""
+    N, B, sh = 80, 16, 8
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    b = OA.Batch(OA.Context(0), B, N)
+    b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    b.solve(); o1 = b.download()
+    assert (o1["exitflag"] == 1).all()
+    wo = OA.warm_restart_opts()                                  # small initial barrier / bound push: the standard interior-point warm start
+    b.shift_warm_start(sh); b.solve(wo); o2 = b.download()
+    assert (o2["exitflag"] == 1).all() and o2["iters"].mean() < 0.75 * o1["iters"].mean()      # a warm restart is cheaper than the cold solve
+    oo = oracle.default_opts(); oo.mu_init = wo.mu_init; oo.bound_push = wo.bound_push; oo.bound_frac = wo.bound_frac
+    idx = np.minimum(np.arange(N + 1) + sh, N); iu = np.minimum(np.arange(N) + sh, N - 1)
+    for i in range(0, B, 5):
+        xw = o1["xp"][i].T[idx]; uw = o1["up"][i].T[iu].copy(); uw[np.arange(N) + sh > N - 1, 1] = 0.0
+        r = oracle.parking_signed_dist(xw[0], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                       xWS[i, idx, 0], xWS[i, idx, 1], xWS[i, idx, 2], 0, xw, uw, o1["lp"][i].T[idx], o1["np"][i].T[idx], opts=oo)
+        assert r["exitflag"] == 1 and r["iters"] == o2["iters"][i]
+        assert np.abs(r["xp"] - o2["xp"][i]).max() < TOL_X and np.abs(o2["xp"][i][:, 0] - o1["xp"][i][:, sh]).max() == 0.0
+    # a measured state instead of the predicted one
+    x0n = o2["xp"][:, :, 4].copy(); x0n[:, 0] += 0.02
+    b.shift_warm_start(4, x0n); b.solve(wo); o3 = b.download()
+    assert (o3["exitflag"] == 1).all() and np.abs(o3["xp"][:, :, 0] - x0n).max() == 0.0
+    b.close()
+
+
 def test_bad_inputs_fail_loudly_not_crash(OA):
     N = 10; bt = S.make_batch(S.BACKWARDS, 2, N)
     xWS = bt["xWS"].copy()
