@@ -520,6 +520,13 @@ OBCA_FN void stage_unpack_store(double *sg, const UnpackPlan &p, const double v[
     sg[p.dst[0]] = p.kc[0] + p.flag[0] * v[0]; sg[p.dst[1]] = p.kc[1] + p.flag[1] * v[1];
 }
 
+// A dependent fp64 operation costs ~45 clock ticks when an instance runs alone on its CU (one wavefront per SIMD: nothing fills the pipeline;
+// tools/micro/lds_barrier_latency.hip), so the short dot products of the sequential sweeps are summed as a tree (depth 4 instead of 7).
+OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3, double a4, double b4,
+                         double a5, double b5) {
+    const double t0 = fma(a1, b1, a0 * b0), t1 = fma(a3, b3, a2 * b2), t2 = fma(a5, b5, fma(a4, b4, init));
+    return (t0 + t1) + t2;
+}
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
 // One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k).
 // A single wavefront is instruction-issue bound on this sweep (~400 dependent fp64 / LDS instructions per stage), so the work is cut
@@ -535,10 +542,8 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     PAR(lane) {   // phase A: T[a][cc], lanes 0..83;  u2[m][b] = off_m . p_b, lanes 84..95
         if (lane < 84) {
             const int a_ = lane / 14, cc = lane % 14;
-            double acc = cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)];
-#pragma unroll
-            for (int b_ = 0; b_ < 6; b_++) acc += sh.Pn[a_ * 6 + b_] * sg[SG_FA + b_ * 14 + cc];
-            T[lane] = acc;
+            const double *Pr = sh.Pn + a_ * 6, *Fc = sg + SG_FA + cc;
+            T[lane] = dot6_tree(cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)], Pr[0], Fc[0], Pr[1], Fc[14], Pr[2], Fc[28], Pr[3], Fc[42], Pr[4], Fc[56], Pr[5], Fc[70]);
         } else if (lane < 96) {
             const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; double u2 = 0;
 #pragma unroll
@@ -550,10 +555,9 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     PAR(lane) {   // phase B: Qhat[i][cc], lanes 0..111;  u1[m][b] = off_m . T[:, 8+b], lanes 112..123
         if (lane < 112) {
             const int i = lane / 14, cc = lane % 14;
-            double acc = cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)];
-#pragma unroll
-            for (int a_ = 0; a_ < 6; a_++) acc += sg[SG_FA + a_ * 14 + i] * T[a_ * 14 + cc];
-            sh.Qhat[lane] = acc;
+            const double *Fi = sg + SG_FA + i, *Tc = T + cc;
+            sh.Qhat[lane] = dot6_tree(cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)], Fi[0], Tc[0], Fi[14], Tc[14], Fi[28], Tc[28],
+                                      Fi[42], Tc[42], Fi[56], Tc[56], Fi[70], Tc[70]);
         } else if (lane < 124) {
             const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; double u1 = 0;
 #pragma unroll
@@ -563,11 +567,12 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     }
     LDS_BARRIER();
     PROF(I, PF_RIC_P1);
-    // Quu = [q00 q10; q10 q11] must be positive definite; its inverse [g00 g01; g01 g11] from the two Schur pivots (no sqrt needed)
+    // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
+    // does not need it (the adjugate products below) runs while it is in flight -- the dependent chain of this phase is ~7 operations, not ~18
     const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
-    const double iq00 = 1.0 / q00, m10 = q10 * iq00, sch = q11 - m10 * q10;
-    const int ok = UNIFORM((q00 > 0) && (sch > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
-    const double g11 = 1.0 / sch, g01 = -m10 * g11, g00 = iq00 - m10 * g01;
+    const double det = fma(q00, q11, -(q10 * q10));
+    const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
+    const double idet = 1.0 / det;
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C: lanes 0..35 P[i][cc], 36..71 p[i][cc], 72..92 bilinear constants
         if (PIPE) {
@@ -577,8 +582,9 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         }
         const int e = lane < 72 ? lane : 0, r = e / 36, i = (e % 36) / 6, cc = e % 6, qc = r ? cc + 8 : cc;
         const double q6 = sh.Qhat[6 * 14 + qc], q7 = sh.Qhat[7 * 14 + qc];
-        const double k0 = -(g00 * q6 + g01 * q7), k1 = -(g01 * q6 + g11 * q7);
-        const double v = sh.Qhat[i * 14 + qc] + sh.Qhat[i * 14 + 6] * k0 + sh.Qhat[i * 14 + 7] * k1;
+        const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
+        const double k0 = n0 * idet, k1 = n1 * idet;
+        const double v = fma(fma(sh.Qhat[i * 14 + 6], n0, sh.Qhat[i * 14 + 7] * n1), idet, sh.Qhat[i * 14 + qc]);
         if (lane < 36) sh.Pn[lane] = v; else if (lane < 72) sh.pn[lane - 36] = v;
         const bool row = lane < 72 && i < 4, gain = lane < 72 && i == 0;      // rows 0..3 of P / p go to HBM; row 0 carries the gains
         ro[row ? (r ? RS_PV : RS_PX) + i * 6 + cc : RS_PAD] = v;
@@ -587,8 +593,8 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         if (lane >= 72 && lane < 93) {
             int a_, b_; pair_of(lane - 72, a_, b_);
             const double p6 = sh.Qhat[6 * 14 + 8 + b_], p7 = sh.Qhat[7 * 14 + 8 + b_];
-            const double c0 = -(g00 * p6 + g01 * p7), c1 = -(g01 * p6 + g11 * p7);
-            double w = sh.Qhat[6 * 14 + 8 + a_] * c0 + sh.Qhat[7 * 14 + 8 + a_] * c1;
+            const double m0 = fma(q10, p7, -(q11 * p6)), m1 = fma(q10, p6, -(q00 * p7));
+            double w = fma(sh.Qhat[6 * 14 + 8 + a_], m0, sh.Qhat[7 * 14 + 8 + a_] * m1) * idet;
             // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the columns 0 (main) and 1 (t) only
             if (a_ < 2) w += sh.sB[a_ * 6 + b_];
             if (b_ < 2) w += sh.sB[12 + b_ * 6 + a_];
@@ -749,10 +755,8 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 PAR64(lane) {
                     if (lane < 6) {
                         const double *cl = ring + (size_t)(cb * FW_CH + (k - k0)) * 42, *s_ = sh.traj + (size_t)k * 6;
-                        double v = cl[36 + lane];
-#pragma unroll
-                        for (int j = 0; j < 6; j++) v += cl[lane * 6 + j] * s_[j];
-                        sh.traj[(size_t)(k + 1) * 6 + lane] = v;
+                        const double *cr = cl + lane * 6;
+                        sh.traj[(size_t)(k + 1) * 6 + lane] = dot6_tree(cl[36 + lane], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
                     }
                 }
                 LDS_SYNC();
