@@ -157,6 +157,7 @@ struct Shared {
     double stg[2][200];        // double-buffered unpacked stage data (+ pad slot for lanes without an item) of the Riccati backward sweep (SG_* offsets)
     double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
+    double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
     double filt[OB_FILT][2];
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
     Consts c; Lay l;
@@ -177,6 +178,11 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
 #define PROF(I, id) do { long long now_ = clock64(); if (LANE0) sh.prof[id] += (double)(now_ - (I).tlast); (I).tlast = now_; } while (0)
 #else
 #define PROF(I, id) ((void)0)
+#endif
+#ifdef OBCA_PROFILE_FINE          // per-stage counters inside the Riccati sweep: they cost ~20 % of a stage, off by default even in profile builds
+#define PROF_FINE(I, id) PROF(I, id)
+#else
+#define PROF_FINE(I, id) ((void)0)
 #endif
 
 // ---------------------------------------------------------------- reductions (64-lane butterfly; same order in the emulation)
@@ -528,81 +534,91 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
     return (t0 + t1) + t2;
 }
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
-// One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k).
-// A single wavefront is instruction-issue bound on this sweep (~400 dependent fp64 / LDS instructions per stage), so the work is cut
-// into one small item per lane and spread over both wavefronts, with LDS-only workgroup barriers in between.
+// One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), one small
+// item per lane, LDS-only workgroup barriers in between.
+// Every lane runs the SAME straight-line code in every phase: what differs between the item kinds of a phase (a T entry or one of the
+// partial sums of the bilinear update; a P / p entry or a bilinear constant) is only where the operands live, and that is a per-lane table
+// of LDS offsets built once per sweep (RicPlan).  A divergent `if (lane < ..) .. else if ..` made the second wavefront execute both sides
+// one after the other, which doubled the length of every phase.
 // PIPE = 1: steady state of the software pipeline -- the last phase first retires the gather of stage k-1 (issued RIC_D stages ago into
 // nv[..][slot]) into the LDS buffer and re-issues the slot for stage k-1-RIC_D.  Every global load / store is issued unconditionally
 // (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
 // memory operation the compiler's in-order vmcnt bookkeeping stays exact and old gathers retire without draining the younger ones.
+struct RicPlan {      // offsets in doubles from the start of Shared
+    int a_a, a_as, a_b, a_bs, a_i, a_d, a_sg;      // phase A: operand A (offset, stride), operand B, initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
+    int b_a, b_as, b_b, b_bs, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
+    int c_x6, c_x7, c_col, c_base, c_s1, c_s2, c_d1, c_d2, c_rv, c_rk0, c_rk1;   // phase C: see riccati_stage
+};
+OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
+    const double *L = (const double *)&sh;
+    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.cl[0] - L),
+              oSG = (int)(sh.stg[0] - L), oZ = (int)(&sh.zero - L), oD = (int)(&sh.dump - L);
+    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + sum_b P[a][b] FA[b][cc]   (lanes 0..83);  u2[m][b] = sum_i FA[i][8+m] p[i][b]   (lanes 84..95; rows 4, 5 of the off columns are 0)
+    p.a_a = oZ; p.a_as = 0; p.a_b = oZ; p.a_bs = 0; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
+    if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_as = 1; p.a_b = oSG + SG_FA + cc; p.a_bs = 14; p.a_sg = 2;
+                     p.a_i = cc < 8 ? oZ : opn + a_ * OB_NC + (cc - 8); p.a_d = oT + lane; }
+    else if (lane < 96) { const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; p.a_a = oSG + SG_FA + 8 + m; p.a_as = 14; p.a_sg = 1; p.a_b = opn + b_; p.a_bs = OB_NC; p.a_d = osB + 12 + m * 6 + b_; }
+    // B: Qhat[i][cc] = [H | hc][i][cc] + sum_a FA[a][i] T[a][cc]   (lanes 0..111);  u1[m][b] = sum_i FA[i][8+m] T[i][8+b]   (lanes 112..123)
+    p.b_a = oZ; p.b_as = 0; p.b_b = oZ; p.b_bs = 0; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
+    if (lane < 112) { const int i = lane / 14, cc = lane % 14; p.b_a = oSG + SG_FA + i; p.b_as = 14; p.b_b = oT + cc; p.b_bs = 14; p.b_sg = 1 | 4;
+                      p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + lane; }
+    else if (lane < 124) { const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; p.b_a = oSG + SG_FA + 8 + m; p.b_as = 14; p.b_sg = 1; p.b_b = oT + 8 + b_; p.b_bs = 14; p.b_d = osB + m * 6 + b_; }
+    // C: value = base + (X6 n0 + X7 n1) / det + s1 + s2 with (n0, n1) = adj(Quu) applied to column c_col of rows 6, 7 of Qhat
+    //    lanes 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry);  lanes 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
+    p.c_x6 = oZ; p.c_x7 = oZ; p.c_col = 0; p.c_base = oZ; p.c_s1 = oZ; p.c_s2 = oZ; p.c_d1 = oD; p.c_d2 = oD; p.c_rv = RS_PAD; p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
+    if (lane < 72) {
+        const int r = lane / 36, i = (lane % 36) / 6, cc = lane % 6, qc = r ? cc + 8 : cc;
+        p.c_x6 = oQ + i * 14 + 6; p.c_x7 = oQ + i * 14 + 7; p.c_col = qc; p.c_base = oQ + i * 14 + qc; p.c_d1 = r ? opn + (lane - 36) : oPn + lane;
+        if (i < 4) p.c_rv = (r ? RS_PV : RS_PX) + i * 6 + cc;                 // rows 0..3 of P / p go to HBM; row 0 carries the gains
+        if (i == 0) { p.c_rk0 = (r ? RS_KF : RS_K) + cc; p.c_rk1 = (r ? RS_KF + OB_NC : RS_K + 6) + cc; }
+    } else if (lane < 93) {
+        int a_, b_; pair_of(lane - 72, a_, b_);
+        p.c_x6 = oQ + 6 * 14 + 8 + a_; p.c_x7 = oQ + 7 * 14 + 8 + a_; p.c_col = 8 + b_; p.c_base = oBm + a_ * 6 + b_; p.c_d1 = oBm + a_ * 6 + b_;
+        if (a_ != b_) p.c_d2 = oBm + b_ * 6 + a_;
+        if (a_ < 2) p.c_s1 = osB + a_ * 6 + b_;                               // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the
+        if (b_ < 2) p.c_s2 = osB + 12 + b_ * 6 + a_;                          // columns 0 (main) and 1 (t) only
+    }
+}
 template <int PIPE>
-OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
-    const double *sg = sh.stg[k & 1];
-    double *T = sh.cl[0];                                          // 6 x 14 scratch (the closed-loop buffers are free during this sweep)
-    PAR(lane) {   // phase A: T[a][cc], lanes 0..83;  u2[m][b] = off_m . p_b, lanes 84..95
-        if (lane < 84) {
-            const int a_ = lane / 14, cc = lane % 14;
-            const double *Pr = sh.Pn + a_ * 6, *Fc = sg + SG_FA + cc;
-            T[lane] = dot6_tree(cc < 8 ? 0.0 : sh.pn[a_ * OB_NC + (cc - 8)], Pr[0], Fc[0], Pr[1], Fc[14], Pr[2], Fc[28], Pr[3], Fc[42], Pr[4], Fc[56], Pr[5], Fc[70]);
-        } else if (lane < 96) {
-            const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; double u2 = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) u2 += sg[SG_FA + i * 14 + 8 + m] * sh.pn[i * OB_NC + b_];
-            sh.sB[12 + m * 6 + b_] = u2;
-        }
+OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicPlan (&rp)[OBCA_NLT],
+                          double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
+    double *L = (double *)&sh;
+    const int sgo = (k & 1) * (int)(sh.stg[1] - sh.stg[0]);         // which of the two stage buffers holds stage k
+    PAR(lane) {   // phase A
+        const RicPlan &p = rp[LI(lane)];
+        const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
+        L[p.a_d] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
     }
     LDS_BARRIER();
-    PAR(lane) {   // phase B: Qhat[i][cc], lanes 0..111;  u1[m][b] = off_m . T[:, 8+b], lanes 112..123
-        if (lane < 112) {
-            const int i = lane / 14, cc = lane % 14;
-            const double *Fi = sg + SG_FA + i, *Tc = T + cc;
-            sh.Qhat[lane] = dot6_tree(cc < 8 ? sg[SG_H + i * 8 + cc] : sg[SG_HC + i * OB_NC + (cc - 8)], Fi[0], Tc[0], Fi[14], Tc[14], Fi[28], Tc[28],
-                                      Fi[42], Tc[42], Fi[56], Tc[56], Fi[70], Tc[70]);
-        } else if (lane < 124) {
-            const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; double u1 = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) u1 += sg[SG_FA + i * 14 + 8 + m] * T[i * 14 + 8 + b_];
-            sh.sB[m * 6 + b_] = u1;
-        }
+    PAR(lane) {   // phase B
+        const RicPlan &p = rp[LI(lane)];
+        const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
+        L[p.b_d] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
     }
     LDS_BARRIER();
-    PROF(I, PF_RIC_P1);
+    PROF_FINE(I, PF_RIC_P1);
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
-    // does not need it (the adjugate products below) runs while it is in flight -- the dependent chain of this phase is ~7 operations, not ~18
+    // does not need it (the adjugate products below) runs while it is in flight
     const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
     const double det = fma(q00, q11, -(q10 * q10));
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
     const double idet = 1.0 / det;
     gdbl *ro = I.rs + (size_t)k * OB_RS;
-    PAR(lane) {   // phase C: lanes 0..35 P[i][cc], 36..71 p[i][cc], 72..92 bilinear constants
+    PAR(lane) {   // phase C
+        const RicPlan &p = rp[LI(lane)];
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
             stage_unpack_store(sh.stg[kp & 1], plan[LI(lane)], nv[LI(lane)][slot]);
             stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
-        const int e = lane < 72 ? lane : 0, r = e / 36, i = (e % 36) / 6, cc = e % 6, qc = r ? cc + 8 : cc;
-        const double q6 = sh.Qhat[6 * 14 + qc], q7 = sh.Qhat[7 * 14 + qc];
+        const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
         const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
-        const double k0 = n0 * idet, k1 = n1 * idet;
-        const double v = fma(fma(sh.Qhat[i * 14 + 6], n0, sh.Qhat[i * 14 + 7] * n1), idet, sh.Qhat[i * 14 + qc]);
-        if (lane < 36) sh.Pn[lane] = v; else if (lane < 72) sh.pn[lane - 36] = v;
-        const bool row = lane < 72 && i < 4, gain = lane < 72 && i == 0;      // rows 0..3 of P / p go to HBM; row 0 carries the gains
-        ro[row ? (r ? RS_PV : RS_PX) + i * 6 + cc : RS_PAD] = v;
-        ro[gain ? (r ? RS_KF : RS_K) + cc : RS_PAD] = k0;
-        ro[gain ? (r ? RS_KF + OB_NC : RS_K + 6) + cc : RS_PAD] = k1;
-        if (lane >= 72 && lane < 93) {
-            int a_, b_; pair_of(lane - 72, a_, b_);
-            const double p6 = sh.Qhat[6 * 14 + 8 + b_], p7 = sh.Qhat[7 * 14 + 8 + b_];
-            const double m0 = fma(q10, p7, -(q11 * p6)), m1 = fma(q10, p6, -(q00 * p7));
-            double w = fma(sh.Qhat[6 * 14 + 8 + a_], m0, sh.Qhat[7 * 14 + 8 + a_] * m1) * idet;
-            // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the columns 0 (main) and 1 (t) only
-            if (a_ < 2) w += sh.sB[a_ * 6 + b_];
-            if (b_ < 2) w += sh.sB[12 + b_ * 6 + a_];
-            sh.Bm[a_ * 6 + b_] += w; if (a_ != b_) sh.Bm[b_ * 6 + a_] += w;
-        }
+        const double v = fma(fma(L[p.c_x6], n0, L[p.c_x7] * n1), idet, L[p.c_base]) + (L[p.c_s1] + L[p.c_s2]);
+        L[p.c_d1] = v; L[p.c_d2] = v;
+        ro[p.c_rv] = v; ro[p.c_rk0] = n0 * idet; ro[p.c_rk1] = n1 * idet;
     }
     LDS_BARRIER();
-    PROF(I, PF_RIC_P2);
+    PROF_FINE(I, PF_RIC_P2);
     return ok;
 }
 
@@ -610,9 +626,10 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
     double nv[OBCA_NLT][RIC_D][2];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
-    UnpackPlan plan[OBCA_NLT];
+    UnpackPlan plan[OBCA_NLT]; RicPlan rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
-        stage_unpack_plan(lane, plan[LI(lane)]);
+        stage_unpack_plan(lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
+        if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
@@ -632,7 +649,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
         PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sh.stg[k & 1], plan[LI(lane)], v); }
         LDS_BARRIER();
-        if (!riccati_stage<0>(I, sh, k, plan, nv, 0)) { PROF(I, PF_RIC_BWD); return 0; }
+        if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0)) { PROF(I, PF_RIC_BWD); return 0; }
     }
     if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
     PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
@@ -649,7 +666,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     int ok = 1;
     for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, nv, (ju + 1) % RIC_D);
+        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D);
     }
     PROF(I, PF_RIC_BWD);
     return ok;
