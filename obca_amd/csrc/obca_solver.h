@@ -175,7 +175,7 @@ __shared__ Shared g_sh;     // the one LDS block of the workgroup (= one wavefro
 // phase ids of the diagnostic cycle counters
 enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_SEQ, PF_BS_STAGE, PF_BS_OBS, PF_TRIAL, PF_APPLY, PF_OTHER, PF_RIC_P1, PF_RIC_P2, PF_N };
 #if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
-#define PROF(I, id) do { long long now_ = clock64(); if (LANE0) sh.prof[id] += (double)(now_ - (I).tlast); (I).tlast = now_; } while (0)
+#define PROF(I, id) do { if (LANE0) { long long now_ = clock64(); sh.prof[id] += (double)(now_ - (I).tlast); (I).tlast = now_; } } while (0)   /* one writer: lane 0 */
 #else
 #define PROF(I, id) ((void)0)
 #endif
