@@ -344,10 +344,10 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
             unsigned wa = p.a[r]; OPAQUE(wa);
             const int a = wa & 31, tc = (wa >> 5) & 31, pc = (int)((wa >> 10) & 31) - 1;
             if (a < QS) {
-                double acc = pc >= 0 ? sh.pn[a * QC + pc] : 0.0;
+                double ac[4] = {pc >= 0 ? sh.pn[a * QC + pc] : 0.0, 0.0, 0.0, 0.0};   // four chains: a dependent fp64 FMA costs ~45 clocks
 #pragma unroll
-                for (int b_ = 0; b_ < QS; b_++) acc += sh.Pn[a * QS + b_] * sg[QSR_F + b_ * QFC + tc];
-                QTH(a, tc) = acc;
+                for (int b_ = 0; b_ < QS; b_++) ac[b_ & 3] += sh.Pn[a * QS + b_] * sg[QSR_F + b_ * QFC + tc];
+                QTH(a, tc) = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             }
         }
     }
@@ -361,22 +361,22 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
             if (it < QZ * QQC) {
                 unsigned w = p.b[r]; OPAQUE(w);
                 const int h = w & 1023, t = (w >> 10) & 4095, fx = (int)((w >> 22) & 31) - 1, id = (int)(w >> 27) - 1;
-                double acc = sg[h];
+                double ac[4] = {sg[h], 0.0, 0.0, 0.0};
                 if (fx >= 0) {
                     const double *tp = L + t; const int ts = t >= off_pn ? QC : QTC, fo = QSR_F + fx;
 #pragma unroll
-                    for (int a = 0; a < QX; a++) acc += sg[fo + a * QFC] * tp[a * ts];
-                    if (id >= 0) acc += tp[id * ts];
+                    for (int a = 0; a < QX; a++) ac[a & 3] += sg[fo + a * QFC] * tp[a * ts];
+                    if (id >= 0) ac[0] += tp[id * ts];
                 }
-                Qhat[it] = acc;
+                Qhat[it] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             }
         }
         if (lane < 2 * QC) {   // sB[m][b] = off_m . That[:, rhs b] ; sB[2+m][b] = off_m . pn[:, b]   (m = 0: d, 1: Ft)
-            const int m = lane / QC, b_ = lane % QC; double u1 = 0, u2 = 0;
+            const int m = lane / QC, b_ = lane % QC; double u1[2] = {0, 0}, u2[2] = {0, 0};
             const double *tp = b_ < 2 ? That + 16 + b_ : sh.pn + b_; const int ts = b_ < 2 ? QTC : QC;
 #pragma unroll
-            for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1 += o * tp[i * ts]; u2 += o * sh.pn[i * QC + b_]; }
-            sh.sB[m * QC + b_] = u1; sh.sB[(2 + m) * QC + b_] = u2;
+            for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1[i & 1] += o * tp[i * ts]; u2[i & 1] += o * sh.pn[i * QC + b_]; }
+            sh.sB[m * QC + b_] = u1[0] + u1[1]; sh.sB[(2 + m) * QC + b_] = u2[0] + u2[1];
         }
     }
     LDS_BARRIER();
@@ -585,25 +585,26 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
             }
             for (int k = k0; k < k0 + QFW_CH && k < N; k++) {
                 const double *rec = ring + (size_t)(cb * QFW_CH + (k - k0)) * QFW_SZ, *s_ = sh.traj + (size_t)k * QS;
-                PAR64(lane) {
-                    if (lane < QU) { double v = 0;
+                PAR64(lane) {   // one branch-free 16-term product for both kinds of lane (a divergent if / else would run both sides in turn)
+                    const bool fb = lane < QU; const int ln = lane < 2 * QU ? lane : 0;
+                    const double *ap = rec + QFW_F + (fb ? ln * QS : 64 + (ln - QU) * QC), *bp = fb ? s_ : sh.coef;
+                    double ac[4] = {0, 0, 0, 0};
 #pragma unroll
-                        for (int j = 0; j < QS; j++) v += rec[QFW_F + lane * QS + j] * s_[j];
-                        up[lane] = v; }
-                    else if (lane < 2 * QU) { const int i = lane - QU; double v = 0;
-#pragma unroll
-                        for (int cc = 0; cc < QC; cc++) v += rec[QFW_F + 64 + i * QC + cc] * sh.coef[cc];
-                        up[lane] = v; }
+                    for (int j = 0; j < QS; j++) {
+                        const bool on = j < QC || fb; const int jj = on ? j : 0;
+                        const double bv = bp[jj]; ac[j & 3] += ap[jj] * (on ? bv : 0.0);
+                    }
+                    if (lane < 2 * QU) up[lane] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
                 }
                 LDS_SYNC();
                 PAR64(lane) {
                     if (lane < QX) {
-                        double v = rec[lane * QFC + 16] + dt * rec[lane * QFC + 17];
+                        double ac[4] = {rec[lane * QFC + 16] + dt * rec[lane * QFC + 17], 0, 0, 0};
 #pragma unroll
-                        for (int j = 0; j < QX; j++) v += rec[lane * QFC + j] * s_[j];
+                        for (int j = 0; j < QX; j++) ac[j & 3] += rec[lane * QFC + j] * s_[j];
 #pragma unroll
-                        for (int a = 0; a < QU; a++) v += rec[lane * QFC + 12 + a] * (up[a] + up[QU + a]);
-                        sh.traj[(size_t)(k + 1) * QS + lane] = v;
+                        for (int a = 0; a < QU; a++) ac[a] += rec[lane * QFC + 12 + a] * (up[a] + up[QU + a]);
+                        sh.traj[(size_t)(k + 1) * QS + lane] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
                     } else if (lane < QS) sh.traj[(size_t)(k + 1) * QS + lane] = up[lane - QX] + up[QU + lane - QX];
                 }
                 LDS_SYNC();
