@@ -108,8 +108,14 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
             double r[2], q[3]; q_obs_rows(c, in, r, q);
             th += fabs(r[0]) + fabs(r[1]);
 #pragma unroll
-            for (int i = 0; i < QL; i++) { fsl += 1e-4 * in.lam[i] * in.lam[i]; bar += log(in.lam[i]); }
-            bar += (c.dist ? 0.0 : log(in.s)) + log(in.so);
+            for (int i = 0; i < QL; i++) fsl += 1e-4 * in.lam[i] * in.lam[i];
+            {   // barrier of the item as one log of the product of its eight distances (log_prod, obca_solver.h)
+                double dd[QL + 2];
+#pragma unroll
+                for (int i = 0; i < QL; i++) dd[i] = in.lam[i];
+                dd[QL] = c.dist ? 1.0 : in.s; dd[QL + 1] = in.so;
+                bar += log_prod(dd);
+            }
         }
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
@@ -135,6 +141,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
         for (int k = lane; k <= N; k += OB_NT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSR;
             double x[QX], hz[QX], hb[QX], xd[QX], Hpos[6] = {0, 0, 0, 0, 0, 0};
+            BarAcc ba, bb, bu; bar_init(ba); bar_init(bb); bar_init(bu);      // barrier distances: states 0..5, states 6..11, inputs
 #pragma unroll
             for (int i = 0; i < QX; i++) {
                 x[i] = z[l.x + QX * k + i];
@@ -143,7 +150,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 if (i >= 9) lf += 1e-4 * x[i] * x[i];
                 if (k >= 1) {
                     B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmu, lsz);
-                    xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; lbar += log(x[i] - q_xlb(i, c.dist)) + log(q_xub(i, c.dist) - x[i]);
+                    xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; bar_mul(i < 6 ? ba : bb, x[i] - q_xlb(i, c.dist), q_xub(i, c.dist) - x[i]);
                 }
             }
             for (int j = 0; j < QOB; j++) {
@@ -165,6 +172,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 }
                 rec[QSR_H + 0 * QZ + 1] = Hpos[1]; rec[QSR_H + 1 * QZ + 0] = Hpos[1]; rec[QSR_H + 0 * QZ + 2] = Hpos[2]; rec[QSR_H + 2 * QZ + 0] = Hpos[2];
                 rec[QSR_H + 1 * QZ + 2] = Hpos[4]; rec[QSR_H + 2 * QZ + 1] = Hpos[4];
+                lbar += bar_log(ba) + bar_log(bb);
                 continue;
             }
             double u[QU], pi[QX], g[QX], dg[9][QV], HG[55];
@@ -222,7 +230,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #pragma unroll
             for (int j = 0; j < QU; j++) {
                 B2 b = bound2(u[j], Q_ULO, Q_UHI, z[l.zL + l.u + QU * k + j], z[l.zU + l.u + QU * k + j], mu, 1, lc0, lcmu, lsz);
-                lbar += log(u[j] - Q_ULO) + log(Q_UHI - u[j]);
+                bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
                 double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
                 lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
                 if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
@@ -257,6 +265,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 rec[QSR_HC + 2 * (QX + j)] = hzw[j]; rec[QSR_HC + 2 * (QX + j) + 1] = 0.0;
                 rec[QSR_HC + 2 * (QS + j)] = hbu[j]; rec[QSR_HC + 2 * (QS + j) + 1] = Ht[QS + j];
             }
+            lbar += bar_log(ba) + bar_log(bb) + bar_log(bu);
         }
         sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmu;
         sh.red[4][lane] = lsz; sh.red[5][lane] = lsy; sh.red[6][lane] = lf; sh.red[7][lane] = lth;
@@ -272,7 +281,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     c0 = fmax(c0, d0); cmu = fmax(cmu, d1); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
     const double gf = (N + 1) * (0.25 + 10 * t);
     gtb += gf + b.gb; gtz += gf + b.gz;
-    f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+    f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     dinf = fmax(dinf, fabs(gtz));
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
@@ -735,8 +744,15 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
 #pragma unroll
-            for (int i = 0; i < QL; i++) { in.lam[i] += alpha * d[l.lam + QL * it + i]; lbar += log(in.lam[i]); lf += 1e-4 * in.lam[i] * in.lam[i]; }
-            in.s += alpha * d[l.s + it]; in.so += alpha * d[l.so + it]; lbar += (c.dist ? 0.0 : log(in.s)) + log(in.so);
+            for (int i = 0; i < QL; i++) { in.lam[i] += alpha * d[l.lam + QL * it + i]; lf += 1e-4 * in.lam[i] * in.lam[i]; }
+            in.s += alpha * d[l.s + it]; in.so += alpha * d[l.so + it];
+            {
+                double dd[QL + 2];
+#pragma unroll
+                for (int i = 0; i < QL; i++) dd[i] = in.lam[i];
+                dd[QL] = c.dist ? 1.0 : in.s; dd[QL + 1] = in.so;
+                lbar += log_prod(dd);
+            }
 #pragma unroll
             for (int i = 0; i < 3; i++) in.p[i] += alpha * d[l.x + QX * k + i];
             double r[2], q[3]; q_obs_rows(c, in, r, q);
@@ -745,8 +761,9 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
         }
         for (int k = lane; k <= N; k += OB_NT) {
             double x[QX];
+            BarAcc ba, bb, bu; bar_init(ba); bar_init(bb); bar_init(bu);
 #pragma unroll
-            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i] + alpha * d[l.x + QX * k + i]; if (k >= 1) lbar += log(x[i] - q_xlb(i, c.dist)) + log(q_xub(i, c.dist) - x[i]); }
+            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i] + alpha * d[l.x + QX * k + i]; if (k >= 1) bar_mul(i < 6 ? ba : bb, x[i] - q_xlb(i, c.dist), q_xub(i, c.dist) - x[i]); }
             lf += 1e-4 * (x[9] * x[9] + x[10] * x[10] + x[11] * x[11]);
             if (k == N) {
 #pragma unroll
@@ -756,13 +773,14 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
 #pragma unroll
                 for (int j = 0; j < QU; j++) {
                     u[j] = z[l.u + QU * k + j] + alpha * d[l.u + QU * k + j];
-                    lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]); lbar += log(u[j] - Q_ULO) + log(Q_UHI - u[j]);
+                    lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]); bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
                     if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] + alpha * d[l.u + QU * (k - 1) + j] - u[j]; lf += 1e-2 * e * e; }
                 }
                 dyn_g_value(c, x, u, g);
 #pragma unroll
                 for (int i = 0; i < QX; i++) lth += fabs(z[l.x + QX * (k + 1) + i] + alpha * d[l.x + QX * (k + 1) + i] - x[i] - tau * g[i]);
             }
+            lbar += bar_log(ba) + bar_log(bb) + bar_log(bu);
         }
         sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
     }
@@ -770,7 +788,7 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
     // finish the values in registers and store each shared slot exactly once (both wavefronts write them; see eval_trial in obca_solver.h)
     double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
-    fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * (log(t - Q_TLO) + log(Q_THI - t));
+    fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     f = fr; th1 = tr; bar = br;
 }
 

@@ -185,26 +185,41 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
 #define PROF_FINE(I, id) ((void)0)
 #endif
 
-// ---------------------------------------------------------------- reductions (64-lane butterfly; same order in the emulation)
-// reductions over the OB_NT lanes of the instance: fold the second wavefront's slots onto the first, then a 64-lane butterfly
-// (same association order in the emulation, so results are bit-identical)
+// ---------------------------------------------------------------- reductions over the OB_NT lanes of the instance
+// Fold the second wavefront's slots onto the first, then a 64-lane butterfly in ASCENDING distance (1, 2, 4, 8, 16, 32).  The first
+// four exchanges stay inside a row of 16 lanes and run as DPP moves on the vector ALU (quad permutes, then half-row and row mirrors:
+// once every lane of a quad / half-row holds the same partial result, the mirrored partner carries exactly what the xor partner
+// would); only distances 16 and 32 cross rows and go through ds_bpermute.  An LDS exchange costs a ~100-clock round trip that the
+// compiler serialises per reduction, and a pass holds some thirty reductions.  The emulation pairs lanes i and i^o in the same
+// order, so its results are bit-identical (sum and max are commutative).
 #ifdef OBCA_EMU
 #define RED_IMPL(NAME, COMB)                                                                                     \
     OBCA_FN double NAME(const double *r) {                                                                       \
         double a[64], b[64];                                                                                     \
         for (int i = 0; i < 64; i++) { a[i] = r[i]; if (OB_NT > 64) { double w = r[i + 64 * (OB_NT > 64)], v = a[i]; a[i] = COMB; } } \
-        for (int o = 32; o > 0; o >>= 1) {                                                                       \
+        for (int o = 1; o < 64; o <<= 1) {                                                                       \
             for (int i = 0; i < 64; i++) { double v = a[i], w = a[i ^ o]; b[i] = COMB; }                         \
             for (int i = 0; i < 64; i++) a[i] = b[i];                                                            \
         }                                                                                                        \
         return a[0];                                                                                             \
     }
 #else
+template <int CTRL>
+OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are called from uniform control flow)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 #define RED_IMPL(NAME, COMB)                                                                                     \
     OBCA_FN double NAME(const double *r) {                                                                       \
-        double v = r[threadIdx.x & 63];                                                                          \
-        if (OB_NT > 64) { double w = r[(threadIdx.x & 63) + 64 * (OB_NT > 64)]; v = COMB; }                      \
-        for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = COMB; }                          \
+        double v = r[threadIdx.x & 63], w;                                                                       \
+        if (OB_NT > 64) { w = r[(threadIdx.x & 63) + 64 * (OB_NT > 64)]; v = COMB; }                             \
+        w = dpp_f64<0xB1>(v); v = COMB;          /* quad_perm [1,0,3,2]  : i ^ 1 */                               \
+        w = dpp_f64<0x4E>(v); v = COMB;          /* quad_perm [2,3,0,1]  : i ^ 2 */                               \
+        w = dpp_f64<0x141>(v); v = COMB;         /* row_half_mirror      : stands in for i ^ 4 */                 \
+        w = dpp_f64<0x140>(v); v = COMB;         /* row_mirror           : stands in for i ^ 8 */                 \
+        w = __shfl_xor(v, 16, 64); v = COMB;                                                                     \
+        w = __shfl_xor(v, 32, 64); v = COMB;                                                                     \
         return v;                                                                                                \
     }
 #endif
@@ -242,6 +257,28 @@ OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double m
     sumz += fabs(zL) + fabs(zU);
     return r;
 }
+// Barrier sums.  sum_i log(d_i) is evaluated as log(prod_i d_i) over groups of at most G distances: a double-precision log is a ~2k-clock
+// dependent chain for a lone wavefront and there are a dozen per stage / obstacle item, while the product of twelve distances in
+// [1e-25, 1e25] stays inside the double range.  A non-positive distance poisons its group (NaN), as its own log would.  The assembly and
+// the trial evaluation use the same groups in the same order, so the same point gives the same bits in both.
+template <int NN, int G = 12>
+OBCA_FN double log_prod(const double (&dd)[NN]) {
+    double s_ = 0;
+#pragma unroll
+    for (int g = 0; g < NN; g += G) {
+        double p0 = 1, p1 = 1, mn = 1;
+#pragma unroll
+        for (int i = g; i < g + G && i < NN; i++) { if (i & 1) p1 *= dd[i]; else p0 *= dd[i]; mn = fmin(mn, dd[i]); }
+        const double lg = log(p0 * p1);
+        s_ += mn > 0 ? lg : NAN;
+    }
+    return s_;
+}
+// the same with running accumulators (two product chains, lower / upper distances) for code that meets its bounds one at a time
+struct BarAcc { double p0, p1, mn; };
+OBCA_FN void bar_init(BarAcc &a) { a.p0 = a.p1 = a.mn = 1.0; }
+OBCA_FN void bar_mul(BarAcc &a, double dlo, double dhi) { a.p0 *= dlo; a.p1 *= dhi; a.mn = fmin(a.mn, fmin(dlo, dhi)); }
+OBCA_FN double bar_log(const BarAcc &a) { const double lg = log(a.p0 * a.p1); return a.mn > 0 ? lg : NAN; }
 OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; return a_ * 8 - a_ * (a_ - 1) / 2 + (b_ - a_); }
 
 
@@ -270,9 +307,15 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
             if (!c.dist) fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
             double r[4]; obs_rows<VM>(c, in, r);
             th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
+            {
+                double dd[VM + 6];
 #pragma unroll
-            for (int i = 0; i < VM; i++) if (i < in.v) bar += log(in.lam[i]);
-            bar += log(in.mu[0]) + log(in.mu[1]) + log(in.mu[2]) + log(in.mu[3]) + log(in.so) + (c.dist ? log(in.sl) : 0.0);
+                for (int i = 0; i < VM; i++) dd[i] = i < in.v ? in.lam[i] : 1.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) dd[VM + i] = in.mu[i];
+                dd[VM + 4] = in.so; dd[VM + 5] = c.dist ? in.sl : 1.0;
+                bar += log_prod(dd);
+            }
         }
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
@@ -301,6 +344,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
     PAR(lane) {
         double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
         for (int k = lane; k <= N; k += OB_NT) {
+            BarAcc ba; bar_init(ba);                  // barrier distances of the stage: x (3 pairs), u (2), steering rate (1)
             double Hp[36], hz[8], hb[8], Ht[8];     // Hp: packed upper triangle of the symmetric 8x8 stage Hessian (HH(i,j), i<=j)
 #define HH(i, j) Hp[hidx((i), (j))]
 #pragma unroll
@@ -331,7 +375,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 if (i != 2 && k >= 1) {
                     B2 b = bound2(x[i], c.xl[i], c.xu[i], z[l.zxL + 4 * k + i], z[l.zxU + 4 * k + i], mu, 1, lc0, lcmu, lsz);
                     Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb;
-                    lbar += log(x[i] - c.xl[i]) + log(c.xu[i] - x[i]);
+                    bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
                 }
                 HH(i, i) = hx[i] + Sig + dw;
             }
@@ -363,7 +407,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
                     B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmu, lsz);
                     hz[6 + i] += b.gz; hb[6 + i] += b.gb;
-                    lbar += log(u[i] - lo) + log(hi - u[i]);
+                    bar_mul(ba, u[i] - lo, hi - u[i]);
                     HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
                     HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr;
                     if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei / t; Ht[4 + i] += 4 * rr * ei / t; }
@@ -373,7 +417,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double g = (w[0] - u[0]) / q;
                     const double gg[3] = {1 / q, -1 / q, c.fixTime ? 0.0 : -g / t};
                     B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmu, lsz);
-                    lbar += log(ss + OB_SSB) + log(OB_SSB - ss);
+                    bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
                     if (fabs(rz) > dmax) dmax = fabs(rz);
@@ -444,6 +488,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; if (fabs(tot) > dmax) dmax = fabs(tot); }
                 }
             }
+            lbar += bar_log(ba);
 #pragma unroll
             for (int i = 0; i < 36; i++) rec[AS_H + i] = Hp[i];
 #undef HH
@@ -471,7 +516,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
         Htt += 2.0 * (N + 1) + b.Sig + dw;
         gtb += gf + b.gb; gtz += gf + b.gz;
         f += (N + 1) * (0.5 * t + t * t);
-        bar += (N + 1) * (log(t - OB_TL) + log(OB_TU - t));
+        bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));
         dinf = fmax(dinf, fabs(gtz));
     } else { Htt = 1.0; gtb = 0; }
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
@@ -972,10 +1017,19 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             const int r0 = sh.roff[j];
 #pragma unroll
-            for (int i = 0; i < VM; i++) if (i < in.v) { in.lam[i] += alpha * d[l.lam + k * M + r0 + i]; lbar += log(in.lam[i]); }
+            for (int i = 0; i < VM; i++) if (i < in.v) in.lam[i] += alpha * d[l.lam + k * M + r0 + i];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { in.mu[i] += alpha * d[l.mu + 4 * it + i]; lbar += log(in.mu[i]); }
-            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it]; lbar += log(in.so) + (c.dist ? log(in.sl) : 0.0);
+            for (int i = 0; i < 4; i++) in.mu[i] += alpha * d[l.mu + 4 * it + i];
+            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it];
+            {
+                double dd[VM + 6];
+#pragma unroll
+                for (int i = 0; i < VM; i++) dd[i] = i < in.v ? in.lam[i] : 1.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) dd[VM + i] = in.mu[i];
+                dd[VM + 4] = in.so; dd[VM + 5] = c.dist ? in.sl : 1.0;
+                lbar += log_prod(dd);
+            }
             in.X += alpha * d[l.x + 4 * k]; in.Y += alpha * d[l.x + 4 * k + 1]; in.psi += alpha * d[l.x + 4 * k + 2];
             double r[4]; obs_rows<VM>(c, in, r);
             lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
@@ -987,9 +1041,10 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
             for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i] + alpha * d[l.x + 4 * k + i];
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
             lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
+            BarAcc ba; bar_init(ba);                  // same order of the products as in assemble_stage
             if (k >= 1) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) if (i != 2) lbar += log(x[i] - c.xl[i]) + log(c.xu[i] - x[i]);
+                for (int i = 0; i < 4; i++) if (i != 2) bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
             }
             if (k == N) {
 #pragma unroll
@@ -998,14 +1053,15 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
                 const double u[2] = {z[l.u + 2 * k] + alpha * d[l.u + 2 * k], z[l.u + 2 * k + 1] + alpha * d[l.u + 2 * k + 1]};
                 const double w[2] = {k ? z[l.u + 2 * k - 2] + alpha * d[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] + alpha * d[l.u + 2 * k - 1] : 0.0};
                 lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + 0.1 * ((u[0] - w[0]) * (u[0] - w[0]) + (u[1] - w[1]) * (u[1] - w[1])) / (q * q);
-                lbar += log(u[0] - OB_UL0) + log(OB_UU0 - u[0]) + log(u[1] - OB_UL1) + log(OB_UU1 - u[1]);
+                bar_mul(ba, u[0] - OB_UL0, OB_UU0 - u[0]); bar_mul(ba, u[1] - OB_UL1, OB_UU1 - u[1]);
                 const double ss = z[l.ss + k] + alpha * d[l.ss + k];
-                lbar += log(ss + OB_SSB) + log(OB_SSB - ss);
+                bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                 lth += fabs((w[0] - u[0]) / q - ss);
                 double F[4]; dyn_value(c, x, u, t, F);
 #pragma unroll
                 for (int i = 0; i < 4; i++) lth += fabs(z[l.x + 4 * (k + 1) + i] + alpha * d[l.x + 4 * (k + 1) + i] - F[i]);
             }
+            lbar += bar_log(ba);
         }
         sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
     }
@@ -1014,7 +1070,7 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
     // of the shared slot here was a data race: the slower wavefront could add the t terms on top of the faster one's finished value)
     double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
-    if (!c.fixTime) { fr += (N + 1) * (0.5 * t + t * t); br += (N + 1) * (log(t - OB_TL) + log(OB_TU - t)); }
+    if (!c.fixTime) { fr += (N + 1) * (0.5 * t + t * t); br += (N + 1) * log((t - OB_TL) * (OB_TU - t)); }
     f = fr; th1 = tr; bar = br;
     PROF(I, PF_TRIAL);
 }
