@@ -20,6 +20,21 @@
 
 namespace obca {
 
+// Reciprocal for the latency-critical pivots: v_rcp_f64 refined by two Newton steps (5 dependent instructions; the IEEE division
+// sequence with its scaling and fix-up is 11, and a dependent fp64 instruction costs a lone wavefront some 45 clocks).  The result is
+// within an ulp or two of 1/d for the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN, and those
+// are rejected by the positivity tests next to every use.  The host emulation divides.
+OBCA_FN double rcp_nr(double d) {
+#ifdef OBCA_EMU
+    return 1.0 / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+#endif
+}
+
 struct Consts {               // uniform per instance
     double Ts, L, g[4], off, xl[4], xu[4], x0[4], xF[4];
     int fixTime, nOb, M, N;
@@ -116,7 +131,7 @@ OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower tr
             for (int k = 0; k < NMAX; k++) if (k < j) d -= A[j * NMAX + k] * A[j * NMAX + k] * D[k];
             if (!(d > 0)) bad = 1;
             D[j] = d;
-            const double id = 1.0 / d;
+            const double id = rcp_nr(d);
             A[j * NMAX + j] = id;
 #pragma unroll
             for (int i = 0; i < NMAX; i++) if (i > j && i < n) {

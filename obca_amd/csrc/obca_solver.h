@@ -247,7 +247,7 @@ OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int
 
 struct B2 { double Sig, gz, gb; };
 OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmu, double &sumz) {
-    const double dL = v - lo, dU = hi - v, iL = 1.0 / dL, iU = 1.0 / dU;
+    const double dL = v - lo, dU = hi - v, iL = rcp_nr(dL), iU = rcp_nr(dU);
     B2 r; r.Sig = mult * (zL * iL + zU * iU); r.gz = mult * (-zL + zU); r.gb = mult * mu * (iU - iL);
     double c1 = dL * zL, c2 = dU * zU;
     if (fabs(c1) > c0) c0 = fabs(c1);
@@ -647,7 +647,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
     const double det = fma(q00, q11, -(q10 * q10));
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
-    const double idet = 1.0 / det;
+    const double idet = rcp_nr(det);
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C
         const RicPlan &p = rp[LI(lane)];
@@ -1078,7 +1078,7 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
 // ---------------------------------------------------------------- accept the step
 OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu / dist, lo = q / ks, hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
 // bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
-OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = 1.0 / dist; return zz + az * (mu * id - zz - zz * id * dv); }
+OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr(dist); return zz + az * (mu * id - zz - zz * id * dv); }
 
 OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, double az, double mu, double ks) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
