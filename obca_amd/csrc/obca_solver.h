@@ -40,7 +40,11 @@
 #define OBCA_HD __host__ __device__ inline
 // Phase entry points are real (non-inlined) device functions: each gets its own register allocation, so the unrolled
 // per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
+#ifdef OBCA_PHASE_INLINE
+#define OBCA_PHASE static __device__ __forceinline__
+#else
 #define OBCA_PHASE static __device__ __noinline__
+#endif
 #define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
