@@ -44,7 +44,7 @@ B_PASS = (56500 + 29550) * 8.0
 
 
 def committed_pmc_traffic():
-    """HBM bytes per launch of obca_parking_ipm_kernel from the committed rocprofv3 --pmc passes of this same command
+    """HBM bytes per step (all launches of obca_parking_ipm_kernel in the one-step trace) from the committed rocprofv3 --pmc passes of this same command
     (profiles/r01_pmc_*.csv; FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md, checked on the D2D copy in the
     same trace).  Not collected live: bench.py cannot run under rocprofv3 by itself."""
     import csv
@@ -53,7 +53,7 @@ def committed_pmc_traffic():
         for name, fn in (("FETCH_SIZE", "r01_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_pmc_write_size.csv")):
             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
                 if r["Kernel_Name"].startswith("obca_parking_ipm_kernel") and r["Counter_Name"] == name:
-                    vals[name] = float(r["Counter_Value"]) * 1024.0
+                    vals[name] = vals.get(name, 0.0) + float(r["Counter_Value"]) * 1024.0       # one step = all IPM launches of the trace
         return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
     except Exception:
         return None
@@ -199,13 +199,14 @@ def main():
                        "exitflag1_rank0": int((out["exitflag"] == 1).sum()), "validated_rank0": int(okv.sum())},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "traffic": committed_pmc_traffic(),
-                         "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
+                         "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "ipm_launches_per_step": batch.last_schedule()[0], "slice_passes": batch.last_schedule()[1], "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
                          "fp64_tflops": round(tflops, 3), "fp64_frac": round(tflops / FP64_PEAK_TFLOPS, 5),
                          "model": "per factorisation pass of one instance: B_PASS=%.3g algorithmic HBM bytes and F_PASS=%.3g executed fp64 flops "
                                   "(SURVEY 8d Model B), x %d passes (iterations + inertia retries, read back from the kernel). The larger of the "
-                                  "two fractions is reported as the bound; neither is tight: the kernel is latency-bound (one or two waves per "
-                                  "SIMD, 81 dependent stages per pass) and ends with the slowest instance of the batch. traffic = PMC bytes of "
-                                  "one launch from profiles/r01_pmc_*.csv (committed, not live)" % (B_PASS, F_PASS, int(passes))},
+                                  "two fractions is reported as the bound; neither is tight: the kernel is latency-bound (one wave per SIMD, 81 dependent "
+                                  "stages per pass) and ends with the slowest instance of the batch. kernel_ms = HIP-event time of all IPM launches of "
+                                  "a step (two-launch schedule: slice + hardest-first completion); traffic = PMC bytes of one step from "
+                                  "profiles/r01_pmc_*.csv (committed, not live)" % (B_PASS, F_PASS, int(passes))},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -86,6 +86,10 @@ int obca_batch_sync(obca_batch *bt);
  * initial state is x0_new (4 x B host, measured state) or, if NULL, stage `shift` of the solution.  The next obca_batch_solve starts from it. */
 int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new);
 int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms);   /* HIP-event durations of the last solve */
+/* how the last obca_batch_solve ran the interior-point kernel: 1 launch, or the two-launch schedule (a slice of `slice_passes` factorisation
+ * passes for every instance, then the parked solves hardest-first; used when the batch exceeds the resident capacity of the GPU, results are
+ * bit-identical either way; environment OBCA_SLICE_PASSES=0 disables it).  ipm_ms of obca_batch_kernel_ms covers all launches. */
+int obca_batch_last_schedule(const obca_batch *bt, int *ipm_launches, int *slice_passes);
 int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *np,
                         double *slp, double *info);
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes);

@@ -72,7 +72,7 @@ def _load():
 EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
-           "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_download",
+           "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
            "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
            "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
@@ -208,6 +208,12 @@ class Batch:
         """(ipm_ms, dualws_ms) of the last solve, measured with HIP events on the launch stream."""
         a, b = C.c_float(0), C.c_float(0)
         self.ctx._check(_load().obca_batch_kernel_ms(self._h, C.byref(a), C.byref(b)), "obca_batch_kernel_ms")
+        return a.value, b.value
+
+    def last_schedule(self):
+        """(ipm launches, slice passes) of the last solve: (1, 0) single launch, (2, q) the two-launch schedule with a q-pass first slice"""
+        a, b = C.c_int(0), C.c_int(0)
+        self.ctx._check(_load().obca_batch_last_schedule(self._h, C.byref(a), C.byref(b)), "obca_batch_last_schedule")
         return a.value, b.value
 
     def phase_cycles(self):

@@ -27,6 +27,8 @@ static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == O
 
 struct DevBufs {
     double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;
+    double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
+    int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
     size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
 };
 
@@ -37,9 +39,11 @@ struct DevBufs {
 #ifndef OBCA_IPM_WAVES_PER_EU
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
-__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o) {
-    const int inst = blockIdx.x;
-    if (inst >= B) return;
+__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget) {
+    // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
+    // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
+    const int inst = mode ? b.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst < 0 || inst >= B) return;
     if (threadIdx.x == 0) {
         Inst &I = g_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
@@ -51,14 +55,52 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
 #endif
     }
 #ifdef OBCA_PROFILE
-    if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = 0;
+    if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = mode ? b.prof[(size_t)inst * 16 + threadIdx.x] : 0.0;   // counters add up over the slices
 #endif
     __syncthreads();
-    solve_instance(N, o, b.info + (size_t)inst * 8);
+    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
 #endif
+}
+
+// difficulty class of a parked instance (0..63, higher = dispatched earlier)
+__device__ inline int obca_slice_class(const double *st) {
+    const int nreg = (int)st[SL_NREG] + (int)st[SL_NREGPREV];
+    const double pinf = st[SL_PINF];
+    int c = 8 * (nreg < 7 ? nreg : 7);
+    // within the same retry count: the constraint violation that is left, one class per decade from 1e-6 up
+    int e = pinf > 0 ? (int)floor(log10(pinf)) + 7 : 0;
+    e = e < 0 ? 0 : (e > 7 ? 7 : e);
+    return c + e;
+}
+
+// Dispatch order of the second launch: parked instances sorted by a difficulty class (descending), finished ones dropped.  The class is what
+// the first slice revealed about the instance: every inertia retry so far counts, then the constraint violation still left -- the instances
+// that go on to need two or three times the median number of passes are almost all among those that already needed retries (DESIGN.md
+// section 3 has the measured ranking quality).  One workgroup, counting sort on 64 classes; the order inside a class is whatever the LDS
+// atomics give, which changes timing only, never results.
+__global__ __launch_bounds__(1024) void obca_order_kernel(int B, const double *info, const double *slice, int *order) {
+    __shared__ int cnt[64], base[64];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        if ((int)info[(size_t)i * 8] != ST_SUSPENDED) continue;
+        const double *st = slice + (size_t)i * SL_SIZE;
+        atomicAdd(&cnt[obca_slice_class(st)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int c = 63; c >= 0; c--) { base[c] = acc; acc += cnt[c]; cnt[c] = 0; } base[0] = base[0]; order[B] = acc; }
+    __syncthreads();
+    const int total = order[B];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        if ((int)info[(size_t)i * 8] != ST_SUSPENDED) continue;
+        const double *st = slice + (size_t)i * SL_SIZE;
+        const int c = obca_slice_class(st);
+        order[base[c] + atomicAdd(&cnt[c], 1)] = i;
+    }
+    for (int i = total + threadIdx.x; i < B; i += blockDim.x) order[i] = -1;
 }
 
 // one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
@@ -145,7 +187,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_k
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct obca_ctx { int device; hipStream_t stream; std::string err; std::string name; };
+struct obca_ctx { int device; hipStream_t stream; std::string err; std::string name; int cus; };
 static std::string g_create_err;
 
 struct obca_batch {
@@ -155,6 +197,7 @@ struct obca_batch {
     std::vector<double> Ts; int fixTime;
     hipEvent_t e0, e1, e2;
     long long bytes;
+    int sliced;          // slice length (passes) of the last solve if it used the two-launch schedule, else 0
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
@@ -188,7 +231,7 @@ int obca_create(obca_ctx **out, int device) {
         g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; return -2;
     }
     obca_ctx *c = new obca_ctx();
-    c->device = device; c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")";
+    c->device = device; c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return -2; }
     *out = c;
     return 0;
@@ -201,7 +244,7 @@ int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
     if (!ctx || !out) return -1;
     if (B < 1 || N < 0 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
-    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0;
+    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0;
     memset(&bt->d, 0, sizeof bt->d);
     hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventCreate(&bt->e0)); HIPCHK(ctx, hipEventCreate(&bt->e1)); HIPCHK(ctx, hipEventCreate(&bt->e2));
@@ -209,8 +252,9 @@ int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+    if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
 }
 int obca_batch_destroy(obca_batch *bt) {
     if (!bt) return -1;
@@ -257,6 +301,8 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
         ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
         ALLOC(d.info, (size_t)B * 8); ALLOC(d.dws, (size_t)B * N1 * nObMax); ALLOC(d.prof, (size_t)B * 16);
+        ALLOC(d.slice, (size_t)B * SL_SIZE);
+        HIPCHK(ctx, hipMalloc((void **)&d.order, ((size_t)B + 1) * sizeof(int))); tot += ((size_t)B + 1) * sizeof(int);
 #undef ALLOC
         bt->bytes = (long long)tot;
     }
@@ -321,8 +367,30 @@ int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
     HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
     if (!bt->have_duals) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
-    hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
-    HIPCHK(ctx, hipGetLastError());
+    // Two-launch schedule.  The kernel keeps two instances per CU resident; a larger batch is dispatched in blockIdx
+    // order as workgroups retire, so an instance that needs three times the median number of passes and happens to sit late in the batch
+    // would start late and finish alone.  Instead every instance first runs a short slice (OBCA_SLICE_PASSES factorisation passes, default
+    // 6), the parked solves are ranked by what the slice revealed, and a second launch finishes them hardest-first.  No work is repeated
+    // and every instance walks through the same iterates as in a single launch.  OBCA_SLICE_PASSES=0 turns it off; OBCA_SLICE_ONLY=1
+    // (diagnostic) stops after the first slice.
+    int budget = 6;
+    if (const char *e = getenv("OBCA_SLICE_PASSES")) budget = atoi(e);
+    const bool slice_only = getenv("OBCA_SLICE_ONLY") && atoi(getenv("OBCA_SLICE_ONLY"));
+    const int slots = 2 * (ctx->cus > 0 ? ctx->cus : 256);
+    bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
+    if (!bt->sliced) {
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 0, 0);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 0, budget);
+        HIPCHK(ctx, hipGetLastError());
+        if (!slice_only) {
+            hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
+            HIPCHK(ctx, hipGetLastError());
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 1, 0);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
     HIPCHK(ctx, hipEventRecord(bt->e2, ctx->stream));
     return 0;
 }
@@ -345,6 +413,12 @@ int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new)
     return 0;
 }
 int obca_batch_sync(obca_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }
+int obca_batch_last_schedule(const obca_batch *bt, int *ipm_launches, int *slice_passes) {
+    if (!bt) return -1;
+    if (ipm_launches) *ipm_launches = bt->sliced ? 2 : 1;
+    if (slice_passes) *slice_passes = bt->sliced;
+    return 0;
+}
 int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms) {
     if (!bt) return -1;
     float a = 0, b = 0;

@@ -1259,7 +1259,19 @@ OBCA_FN void ph_trial(double alpha) { if (g_sh.vm2) ph_trial2(alpha); else ph_tr
 OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double ks) { Shared &sh = g_sh; apply_step(sh.inst, sh, alpha, ay, az, mu, ks); }
 
 // ---------------------------------------------------------------- the interior-point driver
-enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
+enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2, ST_SUSPENDED = 3 };
+
+// Time slicing ("two-launch schedule").  A solve may be cut at the top of an interior-point iteration and continued by
+// a later launch: everything the iteration loop carries across iterations besides the iterate itself (which lives in HBM anyway) is a
+// handful of scalars and the filter, saved in the instance's slice record.  A resumed solve recomputes the assembly at the same point, so
+// the sequence of iterates is bit-identical to an uninterrupted solve.  Record layout (doubles):
+enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_FILT = 16, SL_SIZE = SL_FILT + 2 * OB_FILT };
+struct Slice {
+    gdbl *st;        // slice record of this instance (may be null when budget == 0 and resume == 0)
+    int resume;      // 1: the next ipm_attempt continues from the record instead of starting at the warm start
+    int budget;      // factorisation passes (iterations + inertia retries) this launch may spend; 0 = no limit
+    int used;        // passes spent so far in this launch
+};
 struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
 
 // The reference's acceptance test on the current iterate, with its quirks (ParkingConstraints.jl:29-149): in variable-time
@@ -1310,14 +1322,31 @@ OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
 }
 OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vm2 ? ref_constraints<2>(sh.inst, sh, sd) : ref_constraints<OB_VMAX>(sh.inst, sh, sd); }
 
-OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
+OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh;
-    ph_init(o.bound_push, o.bound_frac);
-    double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
+    double mu = o.mu_init, dw_last = 0;
     int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
-    const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
+    if (sl.resume) {
+        const gdbl *st = sl.st;
+        it = (int)st[SL_IT]; nf = (int)st[SL_NF]; nreg = (int)st[SL_NREG]; mu = st[SL_MU]; dw_last = st[SL_DWLAST]; th_min = st[SL_THMIN]; th_max = st[SL_THMAX];
+        pinf = st[SL_PINF];
+        PAR(lane) { for (int i = lane; i < 2 * nf; i += OB_NT) (&sh.filt[0][0])[i] = st[SL_FILT + i]; }
+        SYNC();
+        sl.resume = 0;
+    } else ph_init(o.bound_push, o.bound_frac);
+    double tau = fmax(o.tau_min, 1 - mu);
+    const int p_start = it + nreg;
+    const AsmOut &A = sh.A;
     for (;;) {
+        if (sl.budget > 0 && sl.used + (it + nreg - p_start) >= sl.budget) {   // out of budget: park the loop state, a later launch continues
+            gdbl *st = sl.st;
+            PAR(lane) {
+                if (lane == 0) { st[SL_IT] = it; st[SL_NF] = nf; st[SL_NREG] = nreg; st[SL_MU] = mu; st[SL_DWLAST] = dw_last; st[SL_THMIN] = th_min; st[SL_THMAX] = th_max; st[SL_PINF] = pinf; }
+                for (int i = lane; i < 2 * nf; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
+            }
+            status = ST_SUSPENDED; break;
+        }
         double dc = o.dc_bar * pow(mu, o.kappa_c);
         ph_assemble(mu, 0.0, dc, 0);
         if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
@@ -1395,12 +1424,15 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R) {
         ph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
         it++;
     }
+    sl.used += it + nreg - p_start;
     R.status = status; R.iters = it; R.nreg = nreg; R.obj = f; R.pinf = pinf; R.dinf = dinf; R.mu = mu;
 }
 
 // Full solve of one instance (pointers already in g_sh.inst): first attempt, and on Error/UserLimit one re-solve from the last
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
-OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
+// Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
+// solve was parked; the iterate buffer then holds the point to continue from).
+OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
@@ -1424,18 +1456,31 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info) {
     SYNC();
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
-    Result R;
-    ipm_attempt(o, R);
-    int ef = (R.status == ST_OPTIMAL), iters = R.iters, nreg = R.nreg;
-    int retry = !ef;
-    if (retry && sh.c.dist && ph_ref_constraints(0)) { ef = 1; retry = 0; }
-    if (retry) {
+    Slice sl = {st, mode == 1, st ? budget : 0, 0};
+    int att = 0, it_prev = 0, nreg_prev = 0;
+    if (mode == 1) { att = (int)st[SL_ATT]; it_prev = (int)st[SL_ITPREV]; nreg_prev = (int)st[SL_NREGPREV]; }
+    Result R; R.status = ST_ERROR; R.iters = 0; R.nreg = 0; R.obj = R.pinf = R.dinf = R.mu = 0;
+    int ef = 0, iters = 0, nreg = 0, retry = att;
+    if (att == 0) {
+        ipm_attempt(o, R, sl);
+        iters = R.iters; nreg = R.nreg;
+        if (R.status != ST_SUSPENDED) {
+            ef = (R.status == ST_OPTIMAL); retry = !ef;
+            if (retry && sh.c.dist && ph_ref_constraints(0)) { ef = 1; retry = 0; }
+            if (retry) { att = 1; it_prev = R.iters; nreg_prev = R.nreg; }
+        }
+    }
+    if (retry && R.status != ST_SUSPENDED) {
         Result R2;
-        ipm_attempt(o, R2);
-        iters += R2.iters; nreg += R2.nreg;
+        ipm_attempt(o, R2, sl);
+        iters = it_prev + R2.iters; nreg = nreg_prev + R2.nreg;
         if (R2.status == ST_OPTIMAL) ef = 1;
-        else { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); ef = sh.c.dist ? !feas : feas; }
+        else if (R2.status != ST_SUSPENDED) { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); ef = sh.c.dist ? !feas : feas; }
         R = R2;
+    }
+    if (R.status == ST_SUSPENDED) {
+        PAR(lane) { if (lane == 0) { st[SL_ATT] = att; st[SL_ITPREV] = it_prev; st[SL_NREGPREV] = nreg_prev; } }
+        ef = 0;
     }
     PAR(lane) {
         if (lane == 0) { info[0] = R.status; info[1] = iters; info[2] = R.obj; info[3] = R.pinf; info[4] = R.dinf; info[5] = R.mu; info[6] = nreg; info[7] = ef; }

@@ -80,6 +80,24 @@ int emu_solve(int N, const double *prob, const double *zinit, int len, const voi
     return 0;
 }
 
+// the same solve cut into launches of `budget` factorisation passes each (time slicing, obca_solver.h): returns the number of launches
+int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, const void *opts, int budget, double *zout, double *info) {
+    Scratch s; alloc_scratch(N, len, s);
+    memcpy(s.z, zinit, sizeof(double) * len);
+    double *st = (double *)calloc(SL_SIZE, 8);
+    int launches = 0;
+    for (int mode = 0;; mode = 1) {
+        memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
+        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+        solve_instance(N, *(const Opts *)opts, info, st, mode, budget);
+        launches++;
+        if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
+    }
+    memcpy(zout, s.z, sizeof(double) * len);
+    free(st); free_scratch(s);
+    return launches;
+}
+
 int emu_dualws(int v, const double *a1, const double *a2, const double *b, const double *g, double ex, double ey, double cs, double sn,
                double *lam, double *mu, double *d) {
     double l4[OB_VMAX], m4[4];

@@ -134,3 +134,26 @@ def test_emu_exit_flag_after_failed_attempts_follows_the_reference(oracle, emu, 
                                     sol["xp"], sol["up"], sol["t"], sol["lp"], sol["np"], 0, 0 if dist else 1)
         assert a == b_
     assert ro["exitflag"] == 1
+
+
+@pytest.mark.parametrize("budget,max_iter", [(1, 3000), (5, 3000), (4, 7)], ids=["every_pass", "five_passes", "retry_attempt"])
+def test_emu_sliced_solve_is_bit_identical(oracle, emu, backwards, budget, max_iter):
+    """time slicing (two-launch schedule): a solve parked every `budget` factorisation passes and resumed from its slice record walks through
+    exactly the same iterates as an uninterrupted solve -- also when the cut falls into the second attempt (max_iter small forces the retry)"""
+    N = 20; bt = S.make_batch(S.BACKWARDS, 2, N)
+    v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+    oo = oracle.default_opts(); oo.max_iter = max_iter; eo = EOpts()
+    for n, _ in EOpts._fields_:
+        setattr(eo, n, getattr(oo, n))
+    for i in range(2):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
+                              xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        za = np.zeros_like(z0); ia = np.zeros(8); zb = np.zeros_like(z0); ib = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(za), dp(ia))
+        launches = emu.emu_solve_sliced(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), C.c_int(budget), dp(zb), dp(ib))
+        passes = int(ia[1] + ia[6])
+        assert launches > 1 and launches >= int(ia[1]) // budget          # the cut falls between iterations
+        assert np.array_equal(ia, ib) and np.array_equal(za, zb)

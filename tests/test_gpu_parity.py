@@ -145,6 +145,25 @@ def test_full_size_properties_config2(OA):
         assert np.array_equal(out["iters"], out2["iters"]) and np.abs(out["xp"] - out2["xp"]).max() == 0.0, rep
 
 
+def test_two_launch_schedule_is_bit_identical_to_a_single_launch(OA, monkeypatch):
+    """B=1024 exceeds the resident capacity (2 instances per CU), so obca_batch_solve uses the two-launch schedule (slice, rank, finish
+    hardest-first).  Parking a solve and resuming it must not change a single bit of any output; an odd slice length also cuts solves inside
+    their inertia-retry sequence and right before convergence."""
+    N, B = 80, 1024
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    ctx = OA.Context(0); b = OA.Batch(ctx, B, N)
+    b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    monkeypatch.setenv("OBCA_SLICE_PASSES", "0")
+    b.solve(); ref = b.download(); assert b.last_schedule() == (1, 0)
+    for q in (6, 1, 27):
+        monkeypatch.setenv("OBCA_SLICE_PASSES", str(q))
+        b.solve(); out = b.download(); assert b.last_schedule() == (2, q)
+        for k in ("xp", "up", "timeScale", "lp", "np", "sl", "info", "exitflag"):
+            assert np.array_equal(ref[k], out[k]), (q, k)
+    b.close(); ctx.close()
+
+
 def test_single_instance_wrapper_and_shapes(OA, oracle, backwards):
     N = 40; sc = S.BACKWARDS; x0 = sc["x0"]
     Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); xWS[0] = x0
