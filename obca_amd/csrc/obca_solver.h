@@ -168,6 +168,8 @@ struct Shared {
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2;   // phase inputs/outputs (wave-uniform, exchanged through LDS)
     double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
+    double clm[(OB_NMAX + 1) * 42];   // closed-loop maps of all stages (Acl 6x6 row-major, then bcl): written stage-parallel, read by the forward
+                                      // sweep and the back-substitution without leaving LDS (two instances per CU leave 80 KB per workgroup)
 };
 
 #ifdef OBCA_EMU
@@ -208,6 +210,10 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
         return a[0];                                                                                             \
     }
 #else
+OBCA_FN double readlane_f64(double v, const int l) {   // value of lane l (a constant) as a wave-uniform scalar
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL>
 OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are called from uniform control flow)
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -764,7 +770,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
     PAR(lane) {
         for (int k = lane; k < N; k += OB_NT) {
-            const gdbl *rec = I.as + (size_t)k * OB_AS; gdbl *ro = I.rs + (size_t)k * OB_RS;
+            const gdbl *rec = I.as + (size_t)k * OB_AS; const gdbl *ro = I.rs + (size_t)k * OB_RS; double *cm = sh.clm + (size_t)k * 42;
             double K0[6], K1[6], kf0 = 0, kf1 = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
@@ -778,61 +784,60 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                     double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
                     if (j == 2) a_ += rec[AS_DF + 5 * i + 0];
                     if (j == 3) a_ += rec[AS_DF + 5 * i + 1];
-                    ro[RS_CL + i * 6 + j] = a_ + b0 * K0[j] + b1 * K1[j];
+                    cm[i * 6 + j] = a_ + b0 * K0[j] + b1 * K1[j];
                 }
-                ro[RS_CL + 36 + i] = rec[AS_DD + i] + dt * rec[AS_DF + 5 * i + 4] + b0 * kf0 + b1 * kf1;
+                cm[36 + i] = rec[AS_DD + i] + dt * rec[AS_DF + 5 * i + 4] + b0 * kf0 + b1 * kf1;
             }
 #pragma unroll
-            for (int j = 0; j < 6; j++) { ro[RS_CL + 24 + j] = K0[j]; ro[RS_CL + 30 + j] = K1[j]; }
-            ro[RS_CL + 40] = kf0; ro[RS_CL + 41] = kf1;
+            for (int j = 0; j < 6; j++) { cm[24 + j] = K0[j]; cm[30 + j] = K1[j]; }
+            cm[40] = kf0; cm[41] = kf1;
         }
         if (lane < 8) { sh.s[0][lane] = 0; sh.s[1][lane] = 0; }
     }
     SYNC();
     PROF(I, PF_BORDER_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential, wavefront 0).  The closed-loop maps are staged through LDS in
-    // chunks of FW_CH stages (ring of two chunks in the reduction scratch, which is idle here): the 64 lanes gather the NEXT chunk
-    // from HBM into registers at the start of a chunk and park it in LDS at its end, so the per-step loop only touches LDS and the
-    // HBM latency is paid once per chunk, overlapped with FW_CH steps of work.  The trajectory stays in LDS.
-#define FW_CH 16
-#define FW_PER ((FW_CH * 42 + 63) / 64)
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential, wavefront 0), maps and trajectory in LDS.
     WAVE0_BEGIN
-        double pf[OBCA_NL][FW_PER];
-        double *ring = &sh.red[0][0];                      // 2 * FW_CH * 42 doubles <= 16 * OB_NT
-        PAR64(lane) {
-            if (lane < 6) sh.traj[lane] = 0.0;
-#pragma unroll
-            for (int r = 0; r < FW_PER; r++) {             // chunk 0 straight into the ring
-                int e = lane + 64 * r, st = e / 42, j = e % 42;
-                if (e < FW_CH * 42 && st < N) ring[e] = (I.rs + (size_t)st * OB_RS)[RS_CL + j];
-            }
-        }
+#ifdef OBCA_EMU
+        PAR64(lane) { if (lane < 6) sh.traj[lane] = 0.0; }
         LDS_SYNC();
-        for (int k0 = 0; k0 < N; k0 += FW_CH) {
-            const int cb = (k0 / FW_CH) & 1;
-            PAR64(lane) {                                   // issue the gathers of the next chunk
-#pragma unroll
-                for (int r = 0; r < FW_PER; r++) {
-                    int e = lane + 64 * r, st = k0 + FW_CH + e / 42, j = e % 42;
-                    pf[LI(lane)][r] = (e < FW_CH * 42 && st < N) ? (I.rs + (size_t)st * OB_RS)[RS_CL + j] : 0.0;
+        for (int k = 0; k < N; k++) {
+            PAR64(lane) {
+                if (lane < 6) {
+                    const double *cl = sh.clm + (size_t)k * 42, *s_ = sh.traj + (size_t)k * 6;
+                    const double *cr = cl + lane * 6;
+                    sh.traj[(size_t)(k + 1) * 6 + lane] = dot6_tree(cl[36 + lane], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
                 }
-            }
-            for (int k = k0; k < k0 + FW_CH && k < N; k++) {
-                PAR64(lane) {
-                    if (lane < 6) {
-                        const double *cl = ring + (size_t)(cb * FW_CH + (k - k0)) * 42, *s_ = sh.traj + (size_t)k * 6;
-                        const double *cr = cl + lane * 6;
-                        sh.traj[(size_t)(k + 1) * 6 + lane] = dot6_tree(cl[36 + lane], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
-                    }
-                }
-                LDS_SYNC();
-            }
-            PAR64(lane) {                                   // park the next chunk in the other half of the ring
-#pragma unroll
-                for (int r = 0; r < FW_PER; r++) { int e = lane + 64 * r; if (e < FW_CH * 42) ring[(size_t)(1 - cb) * FW_CH * 42 + e] = pf[LI(lane)][r]; }
             }
             LDS_SYNC();
         }
+#else
+        // The state never goes through LDS on its way to the next stage: lane i (< 6) computes s_{k+1}[i], v_readlane broadcasts the six
+        // values into scalar registers, and they enter the next stage's products as scalar operands -- no LDS round trip (~170 clocks) on the
+        // dependent path; the rows of the next stage's map are fetched while this one is computed.  The trajectory is still written to LDS
+        // for the stage-parallel phases that follow (fire and forget).  Same operation order as the emulation above: bit-identical results.
+        {
+            const int ln = (int)threadIdx.x < 6 ? (int)threadIdx.x : 0, Nn = UNIFORM(N);
+            double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_k, wave-uniform (scalar registers); s_0 = 0
+            if (threadIdx.x < 6) sh.traj[threadIdx.x] = 0.0;
+            double cr[6], cb_;
+#pragma unroll
+            for (int j = 0; j < 6; j++) cr[j] = sh.clm[ln * 6 + j];
+            cb_ = sh.clm[36 + ln];
+            for (int k = 0; k < Nn; k++) {
+                const double *cn = sh.clm + (size_t)(k + 1 < Nn ? k + 1 : k) * 42;
+                double nr[6], nb_;
+#pragma unroll
+                for (int j = 0; j < 6; j++) nr[j] = cn[ln * 6 + j];
+                nb_ = cn[36 + ln];
+                const double v = dot6_tree(cb_, cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                if (threadIdx.x < 6) sh.traj[(size_t)(k + 1) * 6 + threadIdx.x] = v;
+#pragma unroll
+                for (int j = 0; j < 6; j++) { fw_s[j] = readlane_f64(v, j); cr[j] = nr[j]; }
+                cb_ = nb_;
+            }
+        }
+#endif
     WAVE0_END
     SYNC();
     PROF(I, PF_FWD_SEQ);
@@ -864,9 +869,10 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             if (k < N) {
                 const gdbl *ro = I.rs + (size_t)k * OB_RS;
                 double du[2];
-                du[0] = ro[RS_CL + 40]; du[1] = ro[RS_CL + 41];
+                const double *cm = sh.clm + (size_t)k * 42;
+                du[0] = cm[40]; du[1] = cm[41];
 #pragma unroll
-                for (int j = 0; j < 6; j++) { du[0] += ro[RS_CL + 24 + j] * s[j]; du[1] += ro[RS_CL + 30 + j] * s[j]; }
+                for (int j = 0; j < 6; j++) { du[0] += cm[24 + j] * s[j]; du[1] += cm[30 + j] * s[j]; }
                 d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
                 const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
                 const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
