@@ -796,12 +796,41 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     }
     SYNC();
     PROF(I, PF_BORDER_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k (sequential, wavefront 0), maps and trajectory in LDS.
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k, maps and trajectory in LDS.  The recursion is a chain of N dependent steps
+    // (~280 clocks each: a 4-deep fp64 dependency plus the broadcast), so it is run TWO stages per step: the maps of stages 2j and 2j+1 are
+    // composed first (stage-parallel, all lanes: Pm_j = Acl_{2j+1} Acl_{2j}, pb_j = Acl_{2j+1} bcl_{2j} + bcl_{2j+1}; the reduction scratch,
+    // idle here, holds up to FW_PMAX of them), then every sequential step produces s_{2j+2} (lanes 0..5, composed map) and s_{2j+1} (lanes
+    // 6..11, plain map) from s_{2j}.  Stages beyond the composed pairs (odd N, N > 2 FW_PMAX) are stepped one at a time.
+#define FW_PMAX 48
+    const int NP = UNIFORM(N / 2 < FW_PMAX ? N / 2 : FW_PMAX);
+    double *pairbuf = &sh.red[0][0];                      // FW_PMAX * 42 doubles <= 16 * OB_NT
+    PAR(lane) {
+        for (int it = lane; it < NP * 6; it += OB_NT) {
+            const int j = it / 6, r = it % 6;
+            const double *M0 = sh.clm + (size_t)(2 * j) * 42, *M1 = M0 + 42, *m1 = M1 + r * 6; double *pm = pairbuf + (size_t)j * 42;
+#pragma unroll
+            for (int cI = 0; cI < 6; cI++)
+                pm[r * 6 + cI] = dot6_tree(0.0, m1[0], M0[cI], m1[1], M0[6 + cI], m1[2], M0[12 + cI], m1[3], M0[18 + cI], m1[4], M0[24 + cI], m1[5], M0[30 + cI]);
+            pm[36 + r] = dot6_tree(M1[36 + r], m1[0], M0[36], m1[1], M0[37], m1[2], M0[38], m1[3], M0[39], m1[4], M0[40], m1[5], M0[41]);
+        }
+    }
+    SYNC();
     WAVE0_BEGIN
 #ifdef OBCA_EMU
         PAR64(lane) { if (lane < 6) sh.traj[lane] = 0.0; }
         LDS_SYNC();
-        for (int k = 0; k < N; k++) {
+        for (int j = 0; j < NP; j++) {
+            PAR64(lane) {
+                if (lane < 12) {
+                    const int r = lane < 6 ? lane : lane - 6;
+                    const double *cl = lane < 6 ? pairbuf + (size_t)j * 42 : sh.clm + (size_t)(2 * j) * 42, *s_ = sh.traj + (size_t)(2 * j) * 6;
+                    const double *cr = cl + r * 6;
+                    sh.traj[(size_t)(2 * j + (lane < 6 ? 2 : 1)) * 6 + r] = dot6_tree(cl[36 + r], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
+                }
+            }
+            LDS_SYNC();
+        }
+        for (int k = 2 * NP; k < N; k++) {
             PAR64(lane) {
                 if (lane < 6) {
                     const double *cl = sh.clm + (size_t)k * 42, *s_ = sh.traj + (size_t)k * 6;
@@ -812,29 +841,52 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             LDS_SYNC();
         }
 #else
-        // The state never goes through LDS on its way to the next stage: lane i (< 6) computes s_{k+1}[i], v_readlane broadcasts the six
-        // values into scalar registers, and they enter the next stage's products as scalar operands -- no LDS round trip (~170 clocks) on the
-        // dependent path; the rows of the next stage's map are fetched while this one is computed.  The trajectory is still written to LDS
-        // for the stage-parallel phases that follow (fire and forget).  Same operation order as the emulation above: bit-identical results.
+        // The state never goes through LDS on its way to the next step: v_readlane broadcasts the six values of lanes 0..5 into scalar registers
+        // and they enter the next step's products as scalar operands -- no LDS round trip (~170 clocks) on the dependent path; the map rows of
+        // the next step are fetched while this one is computed.  The trajectory is written to LDS for the stage-parallel phases that follow
+        // (fire and forget).  Same operation order as the emulation above: bit-identical results.
         {
-            const int ln = (int)threadIdx.x < 6 ? (int)threadIdx.x : 0, Nn = UNIFORM(N);
+            const int tx = (int)threadIdx.x, r = tx < 6 ? tx : (tx < 12 ? tx - 6 : 0), Nn = UNIFORM(N);
+            const bool pr = tx < 6 || tx >= 12;                 // this lane works on the composed map
             double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_k, wave-uniform (scalar registers); s_0 = 0
-            if (threadIdx.x < 6) sh.traj[threadIdx.x] = 0.0;
+            if (tx < 6) sh.traj[tx] = 0.0;
             double cr[6], cb_;
+            {
+                const double *c0 = pr ? pairbuf : sh.clm;
 #pragma unroll
-            for (int j = 0; j < 6; j++) cr[j] = sh.clm[ln * 6 + j];
-            cb_ = sh.clm[36 + ln];
-            for (int k = 0; k < Nn; k++) {
-                const double *cn = sh.clm + (size_t)(k + 1 < Nn ? k + 1 : k) * 42;
+                for (int q = 0; q < 6; q++) cr[q] = c0[r * 6 + q];
+                cb_ = c0[36 + r];
+            }
+            for (int j = 0; j < NP; j++) {
+                const int jn = j + 1 < NP ? j + 1 : j;
+                const double *cn = pr ? pairbuf + (size_t)jn * 42 : sh.clm + (size_t)(2 * jn) * 42;
                 double nr[6], nb_;
 #pragma unroll
-                for (int j = 0; j < 6; j++) nr[j] = cn[ln * 6 + j];
-                nb_ = cn[36 + ln];
+                for (int q = 0; q < 6; q++) nr[q] = cn[r * 6 + q];
+                nb_ = cn[36 + r];
                 const double v = dot6_tree(cb_, cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                if (threadIdx.x < 6) sh.traj[(size_t)(k + 1) * 6 + threadIdx.x] = v;
+                if (tx < 12) sh.traj[(size_t)(2 * j + (tx < 6 ? 2 : 1)) * 6 + r] = v;
 #pragma unroll
-                for (int j = 0; j < 6; j++) { fw_s[j] = readlane_f64(v, j); cr[j] = nr[j]; }
+                for (int q = 0; q < 6; q++) { fw_s[q] = readlane_f64(v, q); cr[q] = nr[q]; }
                 cb_ = nb_;
+            }
+            if (2 * NP < Nn) {                                   // leftover stages, one at a time
+                const int k0 = 2 * NP;
+#pragma unroll
+                for (int q = 0; q < 6; q++) cr[q] = sh.clm[(size_t)k0 * 42 + r * 6 + q];
+                cb_ = sh.clm[(size_t)k0 * 42 + 36 + r];
+                for (int k = k0; k < Nn; k++) {
+                    const double *cn = sh.clm + (size_t)(k + 1 < Nn ? k + 1 : k) * 42;
+                    double nr[6], nb_;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) nr[q] = cn[r * 6 + q];
+                    nb_ = cn[36 + r];
+                    const double v = dot6_tree(cb_, cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                    if (tx < 6) sh.traj[(size_t)(k + 1) * 6 + tx] = v;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { fw_s[q] = readlane_f64(v, q); cr[q] = nr[q]; }
+                    cb_ = nb_;
+                }
             }
         }
 #endif
