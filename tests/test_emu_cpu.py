@@ -59,9 +59,9 @@ def test_emu_newton_direction_matches_oracle(oracle, emu, backwards, dist):
         assert np.allclose(out, aux[4:7], rtol=1e-12)
 
 
-@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
-def test_emu_full_solve_matches_oracle(oracle, emu, backwards, dist):
-    N, B = 20, 3
+@pytest.mark.parametrize("dist,N", [(0, 20), (1, 20), (0, 21), (0, 99)], ids=["signed_dist", "dist", "odd_horizon", "beyond_the_composed_pairs"])
+def test_emu_full_solve_matches_oracle(oracle, emu, backwards, dist, N):
+    B = 3 if N <= 21 else 1
     bt = S.make_batch(S.BACKWARDS, B, N)
     v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
     oo = oracle.default_opts(); eo = EOpts()

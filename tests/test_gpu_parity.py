@@ -53,6 +53,21 @@ def test_parking_matches_oracle_config2(OA, oracle):
         assert np.abs(out["lp"][i] - r["lp"]).max() < 1e-5 and np.abs(out["np"][i] - r["np"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("N", [33, 101, 128], ids=["odd_horizon", "beyond_the_composed_pairs", "longest_horizon"])
+def test_parking_matches_oracle_other_horizons(OA, oracle, N):
+    """horizons that exercise the tails of the sweeps: odd N (one leftover stage after the two-stage steps of the forward sweep), N > 96 (more
+    stage pairs than the composed-map buffer holds) and OBCA_NMAX itself (every LDS array at its limit)"""
+    B = 3
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    out, xWS = _solve_batch(OA, bt)
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert out["exitflag"][i] == r["exitflag"] == 1 and out["iters"][i] == r["iters"]
+        assert abs(out["obj"][i] - r["obj"]) <= TOL_F * max(1, abs(r["obj"]))
+        assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and np.abs(out["up"][i] - r["up"]).max() < TOL_X
+
+
 def test_parking_matches_golden_fixture(OA):
     g = golden("oracle_cfg2.npz")
     B, N = int(g["B"]), int(g["N"])
