@@ -8,6 +8,8 @@ Generates the fixtures under tests/golden/ (run from the repo root:  python test
                       (obca_amd/planner.py); the fixture stores the warm starts too, so the test does not depend on the planner
   slsqp_N8.npz      : the same N=8 NLP solved by a THIRD-PARTY solver (scipy.optimize SLSQP, an SQP method unrelated to the oracle's
                       interior point) from the same warm start, autograd derivatives of oracle/nlp_ref.py (--scipy, ~40 s)
+  oracle_quad_cfg4.npz : quadcopter oracle (oracle/obca_oracle_quad.c) on config 4: the shipped scenario and three jittered start / goal pairs
+                      of scenarios.make_quad_batch at N=60 (--quad)
   dualws_known.npz  : poses + closed-form rectangle/half-plane distances for the DualMultWS known-answer test
 
 The reference itself (Julia 0.6 + JuMP + IPOPT) cannot run in this environment and ships no golden vectors
@@ -113,7 +115,22 @@ def dualws_known():
     np.savez(os.path.join(OUT, "dualws_known.npz"), poses=poses, a=a, beta=beta, d=d)
 
 
+def oracle_quad_cfg4(B=4, N=60):
+    import oracle_quad as Q
+    bt = S.make_quad_batch(B, N)
+    keys = ("xp", "up", "lp"); res = {k: [] for k in keys}; meta = dict(exitflag=[], iters=[], obj=[], t=[])
+    for i in range(B):
+        r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
+        for k in keys: res[k].append(r[k])
+        for k in meta: meta[k].append(r[k])
+    np.savez(os.path.join(OUT, "oracle_quad_cfg4.npz"), B=B, N=N, x0=bt["x0"], xF=bt["xF"], Ts=bt["Ts"], R=bt["R"], ob=bt["ob"], xWS=bt["xWS"],
+             **{k: np.array(v) for k, v in res.items()}, **{k: np.array(v) for k, v in meta.items()})
+    print("oracle_quad_cfg4.npz", meta["exitflag"], meta["iters"])
+
+
 if __name__ == "__main__":
+    if "--quad" in sys.argv:
+        oracle_quad_cfg4(); sys.exit(0)
     dualws_known()
     oracle_cases(S.BACKWARDS, 8, "oracle_cfg2.npz")
     oracle_cfg3()

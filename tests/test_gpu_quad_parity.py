@@ -99,3 +99,17 @@ def test_quad_random_endpoints_with_astar_warm_starts(Q):
     for i in np.where(out["exitflag"] == 1)[0]:
         ok, w = V.validate_quadcopter(out["xp"][i], out["up"][i], out["timeScale"][i], bt["x0"][i], bt["xF"][i], bt["Ts"], out["lp"][i], bt["ob"], bt["R"])
         assert ok, (i, w)
+
+
+def test_quad_matches_golden_fixture_config4():
+    """tests/golden/oracle_quad_cfg4.npz (the quadcopter oracle on config 4 at N=60, generated by tests/golden/make_golden.py --quad): the HIP
+    path reproduces the stored trajectories without the oracle at run time"""
+    import obca_amd
+    from conftest import golden
+    g = golden("oracle_quad_cfg4.npz"); B, N = int(g["B"]), int(g["N"])
+    out = obca_amd.quadcopter_signed_dist_batch(g["x0"], g["xF"], N, float(g["Ts"]), float(g["R"]), g["ob"], g["xWS"], np.ones(B))
+    assert (out["exitflag"] == 1).all() and (g["exitflag"] == 1).all()
+    assert np.abs(out["obj"] - g["obj"]).max() < 1e-6 * np.abs(g["obj"]).max()
+    assert np.abs(out["xp"] - g["xp"]).max() < 1e-3 and np.abs(out["up"] - g["up"]).max() < 1e-3
+    assert np.abs(out["timeScale"][:, 0] - g["t"]).max() < 1e-6
+    assert (out["iters"] == g["iters"]).sum() >= B - 1        # round-off may flip one inertia test (DESIGN.md section 9)

@@ -116,3 +116,13 @@ def test_quad_oracle_optimum_matches_third_party_sqp_fixture(Q):
     assert r["exitflag"] == 1
     assert abs(r["obj"] - float(g["obj"])) < 1e-4 * abs(float(g["obj"])) and r["obj"] >= float(g["obj"]) - 1e-9
     assert abs(r["t"] - float(g["t"])) < 1e-5 and np.abs(r["up"] - g["up"]).max() < 5e-3
+
+
+def test_quad_oracle_reproduces_golden_config4(Q):
+    """the committed config-4 fixture is what the current oracle produces (guards the fixture the GPU test relies on)"""
+    from conftest import golden
+    g = golden("oracle_quad_cfg4.npz"); B, N = int(g["B"]), int(g["N"])
+    for i in range(B):
+        r = Q.quadcopter_signed_dist(g["x0"][i], g["xF"][i], N, float(g["Ts"]), float(g["R"]), g["ob"], g["xWS"][i], 1.0)
+        assert r["exitflag"] == g["exitflag"][i] == 1 and r["iters"] == g["iters"][i]
+        assert np.array_equal(r["xp"], g["xp"][i]) and np.array_equal(r["up"], g["up"][i]) and r["t"] == g["t"][i]
