@@ -888,8 +888,10 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
     const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
+    double dc_mu = -1.0, dc_val = 0;
     for (;;) {
-        double dc = o.dc_bar * pow(mu, o.kappa_c);
+        if (mu != dc_mu) { dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
+        double dc = dc_val;
         qph_assemble(mu, 0.0, dc, 0);
         if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
@@ -906,12 +908,13 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
                 if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
                     mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
                     tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
-                    qph_assemble(mu, 0.0, o.dc_bar * pow(mu, o.kappa_c), 1);
+                    dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu;
+                    qph_assemble(mu, 0.0, dc_val, 1);
                     cm = sh.A2.cinfmu;
                 } else break;
             }
         }
-        dc = o.dc_bar * pow(mu, o.kappa_c);
+        dc = dc_val;
         double dw = 0; int ok = 0;
         for (int tr = 0; tr < 60; tr++) {
             if (tr > 0 || mu_changed) qph_assemble(mu, dw, dc, 0);
@@ -926,8 +929,8 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         if (!ok) { status = ST_ERROR; break; }
         if (dw > 0) dw_last = dw;
         const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
-        double amin;
-        if (gd < 0) { amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd)); if (th <= th_min) amin = fmin(amin, o.delta * pow(th, o.s_theta) / pow(-gd, o.s_phi)); }
+        double amin, pw_th = 0, pw_gd = 0;
+        if (gd < 0) { amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd)); pw_th = pow(th, o.s_theta); pw_gd = pow(-gd, o.s_phi); if (th <= th_min) amin = fmin(amin, o.delta * pw_th / pw_gd); }
         else amin = o.gamma_theta;
         amin *= o.gamma_alpha;
         double alpha = sh.S.ap; int acc = 0;
@@ -938,7 +941,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
                 int okf = 1;
                 for (int i = 0; i < nf && okf; i++) if (!(tht < sh.filt[i][0] || pht < sh.filt[i][1])) okf = 0;
                 if (okf) {
-                    const int sw = gd < 0 && alpha * pow(-gd, o.s_phi) > o.delta * pow(th, o.s_theta), armijo = pht <= phi + o.eta_phi * alpha * gd;
+                    const int sw = gd < 0 && alpha * pw_gd > o.delta * pw_th, armijo = pht <= phi + o.eta_phi * alpha * gd;
                     if (th <= th_min && sw) { if (armijo) { acc = 1; break; } }
                     else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
                         acc = 1;
