@@ -1408,7 +1408,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         }
         if (mu != dc_mu) { dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
         double dc = dc_val;
-        ph_assemble(mu, 0.0, dc, 0);
+        PROF(sh.inst, PF_OTHER); ph_assemble(mu, 0.0, dc, 0);
         if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
@@ -1427,7 +1427,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
                     mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
                     tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
                     dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu;
-                    ph_assemble(mu, 0.0, dc_val, 1);   // complementarity error w.r.t. the new mu
+                    PROF(sh.inst, PF_OTHER); ph_assemble(mu, 0.0, dc_val, 1);   // complementarity error w.r.t. the new mu
                     cm = sh.A2.cinfmu;
                 } else break;
             }
@@ -1438,10 +1438,10 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         for (int tr = 0; tr < 60; tr++) {
             // (a single call for the whole Newton pass saves one more callee-saved-register round trip but costs more in-body spills in the
             // stage assembly: measured 1.3 % slower, so assembly and direction stay separate calls)
-            if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
+            PROF(sh.inst, PF_OTHER); if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
             int a_ = A.ok;
-            if (a_) a_ = ph_riccati(o.rho_term);
-            if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+            PROF(sh.inst, PF_OTHER); if (a_) a_ = ph_riccati(o.rho_term);
+            PROF(sh.inst, PF_OTHER); if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
             if (a_) { ok = 1; break; }
             nreg++;
             if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);
@@ -1460,7 +1460,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         amin *= o.gamma_alpha;
         double alpha = sh.S.ap; int acc = 0;
         while (alpha >= amin) {
-            ph_trial(alpha);
+            PROF(sh.inst, PF_OTHER); ph_trial(alpha);
             const double ft = sh.trial[0], tht = sh.trial[1], pht = ft - mu * sh.trial[2];
             if (ft == ft && tht == tht && pht == pht && tht < th_max) {
                 int okf = 1;
@@ -1483,7 +1483,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             alpha *= 0.5;
         }
         if (!acc) { status = ST_ERROR; break; }   // IPOPT would enter restoration here
-        ph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
+        PROF(sh.inst, PF_OTHER); ph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
         it++;
     }
     sl.used += it + nreg - p_start;
