@@ -175,12 +175,13 @@ OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
     b1 /= Lc[2]; b0 = (b0 - Lc[1] * b1) / Lc[0];
 }
 template <int VM>
-OBCA_FN void hh_apply(int v, const double *w, double *x) {
-    double s = 0;
+OBCA_FN void hh_apply(int v, const double *w, double beta, double *x) {   // x <- (I - beta w w') x, beta = 2 / (w'w): w is NOT normalised
+    double s = 0;                                                         // (a square root and a division less on the dependent chain)
 #pragma unroll
     for (int i = 0; i < VM; i++) if (i < v) s += w[i] * x[i];
+    s *= beta;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < v) x[i] -= 2 * s * w[i];
+    for (int i = 0; i < VM; i++) if (i < v) x[i] -= s * w[i];
 }
 
 // ---------------------------------------------------------------- one (stage, obstacle) block
@@ -364,25 +365,22 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double alpha = Jl[0][0] > 0 ? -nq : nq, nw = 0;
 #pragma unroll
     for (int i = 0; i < VM; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
-    nw = sqrt(nw);
-    { const double inw = nw > 0 ? 1.0 / nw : 0.0;
-#pragma unroll
-      for (int i = 0; i < VM; i++) hw[i] *= inw; }
+    const double hb = nw > 0 ? 2.0 * rcp_nr(nw) : 0.0;
     // Ht = Qh Kb Qh
 #pragma unroll
     for (int j = 0; j < VM; j++) {
         double col[VM];
 #pragma unroll
         for (int i = 0; i < VM; i++) col[i] = Kb[i * VM + j];
-        hh_apply<VM>(v, hw, col);
+        hh_apply<VM>(v, hw, hb, col);
 #pragma unroll
         for (int i = 0; i < VM; i++) Kb[i * VM + j] = col[i];
     }
 #pragma unroll
-    for (int i = 0; i < VM; i++) hh_apply<VM>(v, hw, Kb + i * VM);
+    for (int i = 0; i < VM; i++) hh_apply<VM>(v, hw, hb, Kb + i * VM);
     double a00 = Kb[0], det = a00 * (-dc1) - alpha * alpha;
     if (!(det < 0)) bad = 1;
-    const double idet = 1.0 / det, Mi0 = -dc1 * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
+    const double idet = rcp_nr(det), Mi0 = -dc1 * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
     double hc[VM - 1], Hr[(VM - 1) * (VM - 1)];
 #pragma unroll
     for (int i = 0; i < VM - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * VM] : 0.0;
@@ -393,7 +391,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     if (v > 1) bad |= ldl_fact<(VM > 1 ? VM - 1 : 1)>(v - 1, Hr);
     // solve K^{-1} col  for col = [r_lam(v); r_y]
     auto ksolve = [&](double *col /* VM+1 */) {
-        hh_apply<VM>(v, hw, col);
+        hh_apply<VM>(v, hw, hb, col);
         double g0 = col[0], gy = col[VM];
         double t0 = Mi0 * g0 + Mi1 * gy;
         double rr[VM - 1];
@@ -408,7 +406,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         col[VM] = Mi1 * g0 + Mi2 * gy;
 #pragma unroll
         for (int i = 0; i < VM - 1; i++) col[i + 1] = (i + 1 < v) ? rr[i] : 0.0;
-        hh_apply<VM>(v, hw, col);
+        hh_apply<VM>(v, hw, hb, col);
     };
     if (MODE == 0) {
         st->bad |= bad;

@@ -196,24 +196,21 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     double nw = 0;
 #pragma unroll
     for (int i = 0; i < QL; i++) { hw[i] = g1[i] - (i == 0 ? alpha : 0.0); nw += hw[i] * hw[i]; }
-    nw = sqrt(nw);
-    { const double inw = nw > 0 ? 1.0 / nw : 0.0;
-#pragma unroll
-      for (int i = 0; i < QL; i++) hw[i] *= inw; }
+    const double hb = nw > 0 ? 2.0 * rcp_nr(nw) : 0.0;       // unnormalised Householder vector, see hh_apply
 #pragma unroll
     for (int j = 0; j < QL; j++) {
         double col[QL];
 #pragma unroll
         for (int i = 0; i < QL; i++) col[i] = Hb[i * QL + j];
-        hh_apply<QL>(QL, hw, col);
+        hh_apply<QL>(QL, hw, hb, col);
 #pragma unroll
         for (int i = 0; i < QL; i++) Hb[i * QL + j] = col[i];
     }
 #pragma unroll
-    for (int i = 0; i < QL; i++) hh_apply<QL>(QL, hw, Hb + i * QL);
+    for (int i = 0; i < QL; i++) hh_apply<QL>(QL, hw, hb, Hb + i * QL);
     const double a00 = Hb[0], det = a00 * (-dc) - alpha * alpha;
     int bad = !(det < 0);
-    const double idet = 1.0 / det, Mi0 = -dc * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
+    const double idet = rcp_nr(det), Mi0 = -dc * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
     double hc[QL - 1], Hr[(QL - 1) * (QL - 1)];
 #pragma unroll
     for (int i = 0; i < QL - 1; i++) hc[i] = Hb[(i + 1) * QL];
@@ -223,7 +220,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         for (int j = 0; j < QL - 1; j++) Hr[i * (QL - 1) + j] = Hb[(i + 1) * QL + (j + 1)] - Mi0 * hc[i] * hc[j];
     bad |= ldl_fact<QL - 1>(QL - 1, Hr);
     auto ksolve = [&](double *col /* QL+1 */) {
-        hh_apply<QL>(QL, hw, col);
+        hh_apply<QL>(QL, hw, hb, col);
         double g0 = col[0], gy = col[QL];
         const double t0 = Mi0 * g0 + Mi1 * gy;
         double rr[QL - 1];
@@ -237,7 +234,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         col[0] = Mi0 * g0 + Mi1 * gy; col[QL] = Mi1 * g0 + Mi2 * gy;
 #pragma unroll
         for (int i = 0; i < QL - 1; i++) col[i + 1] = rr[i];
-        hh_apply<QL>(QL, hw, col);
+        hh_apply<QL>(QL, hw, hb, col);
     };
     if (MODE == 0) {
         st->bad |= bad;
