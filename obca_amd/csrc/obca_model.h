@@ -35,6 +35,8 @@ OBCA_FN double rcp_nr(double d) {
 #endif
 }
 
+OBCA_FN double rdiv(double a, double b) { return a * rcp_nr(b); }   // a / b to an ulp or two, 6 instructions instead of 12
+
 struct Consts {               // uniform per instance
     double Ts, L, g[4], off, xl[4], xu[4], x0[4], xF[4];
     int fixTime, nOb, M, N;

@@ -630,8 +630,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     // ---- stage-parallel: steps of x, u; costate increments; step-length / descent partials of x, u
     PAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
-#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < ap) ap = cc_; }
-#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < az) az = cc_; }
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
         for (int k = lane; k <= N; k += OB_NT) {
             const double *s = sh.traj + (size_t)k * QS;
             for (int i = 0; i < QX; i++) {
@@ -640,9 +640,9 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 if (i >= 9) gd += 2e-4 * xv * dx;
                 if (k >= 1) {
                     const double dL = xv - q_xlb(i, c.dist), dU = q_xub(i, c.dist) - xv, zL = z[l.zL + l.x + QX * k + i], zU = z[l.zU + l.x + QX * k + i];
-                    gd += (-mu / dL + mu / dU) * dx;
+                    gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dx;
                     FTBP(dL, dx); FTBP(dU, -dx);
-                    FTBZ(zL, mu / dL - zL - zL / dL * dx); FTBZ(zU, mu / dU - zU + zU / dU * dx);
+                    FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * dx); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * dx);
                 }
             }
             if (k < N) {
@@ -653,9 +653,9 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                     double gu = -2e-3 * (c.wH - uv);
                     if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - uv; gu -= 2e-2 * e; gd += 2e-2 * e * s[QX + j]; }
                     const double dL = uv - Q_ULO, dU = Q_UHI - uv, zL = z[l.zL + l.u + QU * k + j], zU = z[l.zU + l.u + QU * k + j];
-                    gd += (gu - mu / dL + mu / dU) * du;
+                    gd += (gu - rdiv(mu, dL) + rdiv(mu, dU)) * du;
                     FTBP(dL, du); FTBP(dU, -du);
-                    FTBZ(zL, mu / dL - zL - zL / dL * du); FTBZ(zU, mu / dU - zU + zU / dU * du);
+                    FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * du); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * du);
                 }
                 const double *sn = sh.traj + (size_t)(k + 1) * QS;
                 if (k + 1 < N) {
@@ -695,8 +695,8 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
     const double dt = sh.coef[1];
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
-#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < lap) lap = cc_; }
-#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < laz) laz = cc_; }
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < laz) laz = cc_; }
         for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
@@ -706,13 +706,13 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
 #pragma unroll
             for (int i = 0; i < QL; i++) {
                 d[l.lam + QL * it + i] = st.dlam[i];
-                lgd += (2e-4 * in.lam[i] - mu / in.lam[i]) * st.dlam[i];
-                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
+                lgd += (2e-4 * in.lam[i] - rdiv(mu, in.lam[i])) * st.dlam[i];
+                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv(mu, in.lam[i]) - in.zl[i] - rdiv(in.zl[i], in.lam[i]) * st.dlam[i]);
             }
             d[l.s + it] = st.ds; d[l.so + it] = st.dso; d[l.yo + 2 * it] = st.dy[0]; d[l.yo + 2 * it + 1] = st.dy[1];
-            lgd += -mu / in.so * st.dso;
-            if (!c.dist) { lgd += (1e2 + 2e3 * in.s - mu / in.s) * st.ds; FTBP(in.s, st.ds); FTBZ(in.zs, mu / in.s - in.zs - in.zs / in.s * st.ds); }
-            FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
+            lgd += -rdiv(mu, in.so) * st.dso;
+            if (!c.dist) { lgd += (1e2 + 2e3 * in.s - rdiv(mu, in.s)) * st.ds; FTBP(in.s, st.ds); FTBZ(in.zs, rdiv(mu, in.s) - in.zs - rdiv(in.zs, in.s) * st.ds); }
+            FTBP(in.so, st.dso); FTBZ(in.zso, rdiv(mu, in.so) - in.zso - rdiv(in.zso, in.so) * st.dso);
         }
         sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
 #undef FTBP
@@ -726,10 +726,10 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
         double cc_;
         cc_ = dt < 0 ? -tau * dL / dt : 1e300; if (cc_ < ap) ap = cc_;
         cc_ = -dt < 0 ? -tau * dU / (-dt) : 1e300; if (cc_ < ap) ap = cc_;
-        const double dzL = mu / dL - zL - zL / dL * dt, dzU = mu / dU - zU + zU / dU * dt;
+        const double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
         cc_ = dzL < 0 ? -tau * zL / dzL : 1e300; if (cc_ < az) az = cc_;
         cc_ = dzU < 0 ? -tau * zU / dzU : 1e300; if (cc_ < az) az = cc_;
-        gd += ((N + 1) * (0.25 + 10 * t) + (N + 1) * (-mu / dL + mu / dU)) * dt;
+        gd += ((N + 1) * (0.25 + 10 * t) + (N + 1) * (-rdiv(mu, dL) + rdiv(mu, dU))) * dt;
     }
     so.ap = ap; so.az = az; so.gd = gd;
 }

@@ -896,8 +896,8 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     // ---- stage-parallel: primal steps of x,u; costates; bound terms of x,u ; steering rows
     PAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
-#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < ap) ap = cc_; }
-#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < az) az = cc_; }
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
         const double t = z[l.t], q = t * c.Ts;
         for (int k = lane; k <= N; k += OB_NT) {
             double s[6];
@@ -912,9 +912,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #pragma unroll
                 for (int i = 0; i < 4; i++) if (i != 2) {
                     double dL = x[i] - c.xl[i], dU = c.xu[i] - x[i], zL = z[l.zxL + 4 * k + i], zU = z[l.zxU + 4 * k + i];
-                    gd += (-mu / dL + mu / dU) * s[i];
+                    gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * s[i];
                     FTBP(dL, s[i]); FTBP(dU, -s[i]);
-                    FTBZ(zL, mu / dL - zL - zL / dL * s[i]); FTBZ(zU, mu / dU - zU + zU / dU * s[i]);
+                    FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * s[i]); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * s[i]);
                 }
                 // costate increment of the row x_k - F_{k-1}: -(Px_k s_k + pv_k . coef)   (for k=N, rs[N] is not written: use terminal data)
             }
@@ -933,9 +933,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 for (int i = 0; i < 2; i++) {
                     const double ei = u[i] - w[i], lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     const double dL = u[i] - lo, dU = hi - u[i], zL = z[l.zuL + 2 * k + i], zU = z[l.zuU + 2 * k + i];
-                    gd += (2 * cu[i] * u[i] + 2 * rr * ei) * du[i] - 2 * rr * ei * s[4 + i] + (-mu / dL + mu / dU) * du[i];
+                    gd += (2 * cu[i] * u[i] + 2 * rr * ei) * du[i] - 2 * rr * ei * s[4 + i] + (-rdiv(mu, dL) + rdiv(mu, dU)) * du[i];
                     FTBP(dL, du[i]); FTBP(dU, -du[i]);
-                    FTBZ(zL, mu / dL - zL - zL / dL * du[i]); FTBZ(zU, mu / dU - zU + zU / dU * du[i]);
+                    FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * du[i]); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * du[i]);
                 }
                 // steering row back-substitution
                 const gdbl *rec = I.as + (size_t)k * OB_AS;
@@ -944,9 +944,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 const double dss = (dyg - rec[AS_RSS]) / rec[AS_DSS];
                 d[l.yg + k] = dyg; d[l.ss + k] = dss;
                 const double ss = z[l.ss + k], zL = z[l.zssL + k], zU = z[l.zssU + k], dL = ss + OB_SSB, dU = OB_SSB - ss;
-                gd += (-mu / dL + mu / dU) * dss;
+                gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dss;
                 FTBP(dL, dss); FTBP(dU, -dss);
-                FTBZ(zL, mu / dL - zL - zL / dL * dss); FTBZ(zU, mu / dU - zU + zU / dU * dss);
+                FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * dss); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * dss);
                 // costate of x_{k+1} - F_k
                 double sn[6];
 #pragma unroll
@@ -996,8 +996,8 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
     // ---- obstacle blocks: back-substitution (the block is re-factorised instead of being stored)
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
-#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < lap) lap = cc_; }
-#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) / (dv) : 1e300; if (cc_ < laz) laz = cc_; }
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < laz) laz = cc_; }
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
@@ -1008,19 +1008,19 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
                 d[l.lam + k * M + r0 + i] = st.dlam[i];
-                lgd -= mu / in.lam[i] * st.dlam[i];
-                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], mu / in.lam[i] - in.zl[i] - in.zl[i] / in.lam[i] * st.dlam[i]);
+                lgd -= rdiv(mu, in.lam[i]) * st.dlam[i];
+                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv(mu, in.lam[i]) - in.zl[i] - rdiv(in.zl[i], in.lam[i]) * st.dlam[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 d[l.mu + 4 * it + i] = st.dmu[i]; d[l.yo + 4 * it + i] = st.dy[i];
-                lgd -= mu / in.mu[i] * st.dmu[i];
-                FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], mu / in.mu[i] - in.zm[i] - in.zm[i] / in.mu[i] * st.dmu[i]);
+                lgd -= rdiv(mu, in.mu[i]) * st.dmu[i];
+                FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], rdiv(mu, in.mu[i]) - in.zm[i] - rdiv(in.zm[i], in.mu[i]) * st.dmu[i]);
             }
             d[l.sl + it] = st.dsl; d[l.so + it] = st.dso;
-            lgd += (c.dist ? -mu / in.sl : 1e2 + 2e4 * in.sl) * st.dsl - mu / in.so * st.dso;
-            if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, mu / in.sl - in.zs1 - in.zs1 / in.sl * st.dsl); }
-            FTBP(in.so, st.dso); FTBZ(in.zso, mu / in.so - in.zso - in.zso / in.so * st.dso);
+            lgd += (c.dist ? -rdiv(mu, in.sl) : 1e2 + 2e4 * in.sl) * st.dsl - rdiv(mu, in.so) * st.dso;
+            if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, rdiv(mu, in.sl) - in.zs1 - rdiv(in.zs1, in.sl) * st.dsl); }
+            FTBP(in.so, st.dso); FTBZ(in.zso, rdiv(mu, in.so) - in.zso - rdiv(in.zso, in.so) * st.dso);
         }
         sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
 #undef FTBP
@@ -1036,11 +1036,11 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
         // The barrier-function gradient (no constraint terms) is formed separately below.
         (void)q;
         double cc_;
-        cc_ = dt < 0 ? -tau * dL / dt : 1e300; if (cc_ < ap) ap = cc_;
-        cc_ = -dt < 0 ? -tau * dU / (-dt) : 1e300; if (cc_ < ap) ap = cc_;
-        double dzL = mu / dL - zL - zL / dL * dt, dzU = mu / dU - zU + zU / dU * dt;
-        cc_ = dzL < 0 ? -tau * zL / dzL : 1e300; if (cc_ < az) az = cc_;
-        cc_ = dzU < 0 ? -tau * zU / dzU : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dt < 0 ? -tau * dL * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = -dt < 0 ? tau * dU * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
+        double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
+        cc_ = dzL < 0 ? -tau * zL * rcp_nr(dzL) : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzU < 0 ? -tau * zU * rcp_nr(dzU) : 1e300; if (cc_ < az) az = cc_;
     }
     PAR(lane) {   // rate-cost part of d phi / d t
         double g = 0;
@@ -1138,7 +1138,7 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
 }
 
 // ---------------------------------------------------------------- accept the step
-OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu / dist, lo = q / ks, hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
+OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu * rcp_nr(dist), lo = q * rcp_nr(ks), hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
 // bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
 OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr(dist); return zz + az * (mu * id - zz - zz * id * dv); }
 
