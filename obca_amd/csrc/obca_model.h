@@ -38,7 +38,7 @@ OBCA_FN double rcp_nr(double d) {
 OBCA_FN double rdiv(double a, double b) { return a * rcp_nr(b); }   // a / b to an ulp or two, 6 instructions instead of 12
 
 struct Consts {               // uniform per instance
-    double Ts, L, g[4], off, xl[4], xu[4], x0[4], xF[4];
+    double Ts, L, iL, g[4], off, xl[4], xu[4], x0[4], xF[4];   // iL = 1 / L (the wheelbase divides a dozen terms per stage)
     int fixTime, nOb, M, N;
     int dist;                 // 1: ParkingDist.jl formulation (next-1 sibling), 0: ParkingSignedDist.jl
     double wa, wpsi;          // ParkingSignedDist.jl:78-92 (fixTime switches the weights)
@@ -61,26 +61,26 @@ struct DynOut {
 
 OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], double t, double F[4]) {
     double tau = c.Ts * t, s = x[3] + 0.5 * tau * u[1], T = tan(u[0]);
-    double phi = x[2] + tau * x[3] * T / (2 * c.L), sn, cs;
+    double phi = x[2] + tau * x[3] * T * (0.5 * c.iL), sn, cs;
     sincos(phi, &sn, &cs);
-    F[0] = x[0] + tau * s * cs; F[1] = x[1] + tau * s * sn; F[2] = x[2] + tau * s * T / c.L; F[3] = x[3] + tau * u[1];
+    F[0] = x[0] + tau * s * cs; F[1] = x[1] + tau * s * sn; F[2] = x[2] + tau * s * T * c.iL; F[3] = x[3] + tau * u[1];
 }
 
 // first derivatives and  HL = sum_i w_i Hess(F_i)  (5x5, symmetric, full storage)
 OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], double t, const double w[4], DynOut &o,
                         double HL[5][5]) {
-    double Ts = c.Ts, L = c.L, v = x[3], a = u[1];
+    double Ts = c.Ts, iL = c.iL, i2L = 0.5 * c.iL, v = x[3], a = u[1];
     double tau = Ts * t, s = v + 0.5 * tau * a, T = tan(u[0]), Tp = 1 + T * T;
-    double phi = x[2] + tau * v * T / (2 * L), sn, cs;
+    double phi = x[2] + tau * v * T * i2L, sn, cs;
     sincos(phi, &sn, &cs);
-    o.F[0] = x[0] + tau * s * cs; o.F[1] = x[1] + tau * s * sn; o.F[2] = x[2] + tau * s * T / L; o.F[3] = v + tau * a;
+    o.F[0] = x[0] + tau * s * cs; o.F[1] = x[1] + tau * s * sn; o.F[2] = x[2] + tau * s * T * iL; o.F[3] = v + tau * a;
     const double dtau[5] = {0, 0, 0, 0, Ts};
     const double ds[5] = {0, 1, 0, 0.5 * tau, 0.5 * Ts * a};
-    const double dphi[5] = {1, tau * T / (2 * L), tau * v * Tp / (2 * L), 0, Ts * v * T / (2 * L)};
+    const double dphi[5] = {1, tau * T * i2L, tau * v * Tp * i2L, 0, Ts * v * T * i2L};
     const double dT[5] = {0, 0, Tp, 0, 0};
     const double g1[3] = {s * cs, tau * cs, -tau * s * sn};
     const double g2[3] = {s * sn, tau * sn, tau * s * cs};
-    const double g3[3] = {s * T / L, tau * T / L, tau * s / L};
+    const double g3[3] = {s * T * iL, tau * T * iL, tau * s * iL};
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         o.dF[0][i] = g1[0] * dtau[i] + g1[1] * ds[i] + g1[2] * dphi[i];
@@ -94,7 +94,7 @@ OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], d
     const double G12[3][3] = {{0, w[0] * cs + w[1] * sn, w[0] * (-s * sn) + w[1] * (s * cs)},
                               {w[0] * cs + w[1] * sn, 0, w[0] * (-tau * sn) + w[1] * (tau * cs)},
                               {w[0] * (-s * sn) + w[1] * (s * cs), w[0] * (-tau * sn) + w[1] * (tau * cs), w[0] * (-tau * s * cs) + w[1] * (-tau * s * sn)}};
-    const double G3w[3][3] = {{0, w[2] * T / L, w[2] * s / L}, {w[2] * T / L, 0, w[2] * tau / L}, {w[2] * s / L, w[2] * tau / L, 0}};
+    const double G3w[3][3] = {{0, w[2] * T * iL, w[2] * s * iL}, {w[2] * T * iL, 0, w[2] * tau * iL}, {w[2] * s * iL, w[2] * tau * iL, 0}};
     const double gs = w[0] * g1[1] + w[1] * g2[1] + w[2] * g3[1];      // weight of Hess(s)
     const double gp = w[0] * g1[2] + w[1] * g2[2];                      // weight of Hess(phi)
     const double gT = w[2] * g3[2];                                     // weight of Hess(T)
@@ -114,9 +114,9 @@ OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], d
     // Hess(s): (a,t)=Ts/2 ; Hess(phi): (v,d)=tau Tp/2L, (v,t)=Ts T/2L, (d,d)=tau v T Tp/L, (d,t)=Ts v Tp/2L ; Hess(T): (d,d)=2 T Tp ; Hess(F_v): (a,t)=Ts
     const double hat = gs * 0.5 * Ts + w[3] * Ts;
     HL[3][4] += hat; HL[4][3] += hat;
-    const double hvd = gp * tau * Tp / (2 * L), hvt = gp * Ts * T / (2 * L), hdt = gp * Ts * v * Tp / (2 * L);
+    const double hvd = gp * tau * Tp * i2L, hvt = gp * Ts * T * i2L, hdt = gp * Ts * v * Tp * i2L;
     HL[1][2] += hvd; HL[2][1] += hvd; HL[1][4] += hvt; HL[4][1] += hvt; HL[2][4] += hdt; HL[4][2] += hdt;
-    HL[2][2] += gp * tau * v * T * Tp / L + gT * 2 * T * Tp;
+    HL[2][2] += gp * tau * v * T * Tp * iL + gT * 2 * T * Tp;
 }
 
 // ---------------------------------------------------------------- small dense helpers (compile-time sizes)
@@ -257,18 +257,18 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     // d rows 2..4 / d mu
     const double Jmu[3][4] = {{1, 0, -1, 0}, {0, 1, 0, -1}, {-c.g[0], -c.g[1], -c.g[2], -c.g[3]}};
     // local stationarity residuals, diagonals
-    const double iso = 1.0 / in.so;
+    const double iso = rcp_nr(in.so);
     // sl: the free penetration slack of ParkingSignedDist (cost 1e2 sl + 1e4 sl^2, enters row 4) or, in the ParkingDist formulation,
     // the slack s1 >= 0 of the norm row 1 (no cost, barrier, multiplier zs1); either way a diagonal pivot
-    const double isl = c.dist ? 1.0 / in.sl : 0.0;
-    const double iDso = 1.0 / (in.zso * iso + dw), iDsl = 1.0 / ((c.dist ? in.zs1 * isl : 2e4) + dw);
+    const double isl = c.dist ? rcp_nr(in.sl) : 0.0;
+    const double iDso = rcp_nr(in.zso * iso + dw), iDsl = rcp_nr((c.dist ? in.zs1 * isl : 2e4) + dw);
     const double iDs4 = c.dist ? 0.0 : iDsl, iDs1 = c.dist ? iDsl : 0.0;          // where the pivot lands: row 4 or row 1
     double r_so = -y[3] - mu_b * iso, r_sl = c.dist ? y[0] - mu_b * isl : 1e2 + 2e4 * in.sl + y[3];
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
-        { const double im = 1.0 / in.mu[i]; r_mu[i] = jy - mu_b * im; iDmu[i] = 1.0 / (in.zm[i] * im + dw); }
+        { const double im = rcp_nr(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr(in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); if (rz > st->dmax) st->dmax = rz;
             double cc = in.mu[i] * in.zm[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
@@ -279,7 +279,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     for (int i = 0; i < VM; i++) {
         if (i < v) {
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
-            { const double il = 1.0 / in.lam[i]; r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
+            { const double il = rcp_nr(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
                 double cc = in.lam[i] * in.zl[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);

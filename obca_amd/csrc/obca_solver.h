@@ -347,6 +347,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
     const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z;
     const double t = z[l.t], q = t * c.Ts;
+    const double iq = 1.0 / q, it_ = 1.0 / t;          // uniform: one division each, the stage code multiplies
     double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
@@ -408,7 +409,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
             } else {
                 const double w[2] = {k ? um[0] : 0.0, k ? um[1] : 0.0};
                 const double cu[2] = {0.01, c.wa};
-                const double rr = 0.1 / (q * q), e1 = u[0] - w[0], e2 = u[1] - w[1], rv = rr * (e1 * e1 + e2 * e2);
+                const double rr = 0.1 * (iq * iq), e1 = u[0] - w[0], e2 = u[1] - w[1], rv = rr * (e1 * e1 + e2 * e2);
                 lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rv;
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
@@ -420,19 +421,19 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     bar_mul(ba, u[i] - lo, hi - u[i]);
                     HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
                     HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr;
-                    if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei / t; Ht[4 + i] += 4 * rr * ei / t; }
+                    if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei * it_; Ht[4 + i] += 4 * rr * ei * it_; }
                 }
-                if (!c.fixTime) { lgtz += -2 * rv / t; lgtb += -2 * rv / t; lHtt += 6 * rv / (t * t); }
+                if (!c.fixTime) { lgtz += -2 * rv * it_; lgtb += -2 * rv * it_; lHtt += 6 * rv * (it_ * it_); }
                 {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
-                    const double g = (w[0] - u[0]) / q;
-                    const double gg[3] = {1 / q, -1 / q, c.fixTime ? 0.0 : -g / t};
+                    const double g = (w[0] - u[0]) * iq;
+                    const double gg[3] = {iq, -iq, c.fixTime ? 0.0 : -g * it_};
                     B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmu, lsz);
                     bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
                     if (fabs(rz) > dmax) dmax = fabs(rz);
                     const double res = g - ss; if (fabs(res) > pmax) pmax = fabs(res); lth += fabs(res);
-                    const double Dss = b.Sig + dw, sig = 1.0 / (1.0 / Dss + dc), rg = res + rb / Dss;
+                    const double Dss = b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = res + rb * iDss;
                     rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
                     rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
                     const int id[2] = {4, 6};
@@ -441,9 +442,9 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                         hz[id[a_]] += gg[a_] * yg; hb[id[a_]] += gg[a_] * (yg + sig * rg);
 #pragma unroll
                         for (int b_ = 0; b_ < 2; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += sig * gg[a_] * gg[b_];
-                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + yg * (a_ == 0 ? -1 / (q * t) : 1 / (q * t));
+                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + yg * (a_ == 0 ? -(iq * it_) : iq * it_);
                     }
-                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g / (t * t); }
+                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g * (it_ * it_); }
                 }
                 {   // dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
                     DynOut dy; double HL[5][5];
@@ -491,7 +492,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 {   // dual infeasibility of u_k: own part + copy part living in stage k+1
                     double wn[2] = {0, 0};
                     if (k + 1 < N) {
-                        wn[0] = -2 * rr * (un[0] - u[0]) + (1 / q) * ygn;
+                        wn[0] = -2 * rr * (un[0] - u[0]) + iq * ygn;
                         wn[1] = -2 * rr * (un[1] - u[1]);
                     }
 #pragma unroll
@@ -928,7 +929,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
                 const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
                 const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
-                const double cu[2] = {0.01, c.wa}, rr = 0.1 / (q * q);
+                const double cu[2] = {0.01, c.wa}, iq = 1.0 / q, rr = 0.1 * (iq * iq);
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const double ei = u[i] - w[i], lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
@@ -941,7 +942,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 const gdbl *rec = I.as + (size_t)k * OB_AS;
                 const double lin = rec[AS_GG] * s[4] + rec[AS_GG + 1] * du[0] + rec[AS_GG + 2] * dt;
                 const double dyg = rec[AS_SIG] * (lin + rec[AS_RG]);
-                const double dss = (dyg - rec[AS_RSS]) / rec[AS_DSS];
+                const double dss = rdiv(dyg - rec[AS_RSS], rec[AS_DSS]);
                 d[l.yg + k] = dyg; d[l.ss + k] = dss;
                 const double ss = z[l.ss + k], zL = z[l.zssL + k], zU = z[l.zssU + k], dL = ss + OB_SSB, dU = OB_SSB - ss;
                 gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dss;
@@ -1071,7 +1072,7 @@ template <int VM>
 OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, double &th1, double &bar) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z, *d = I.d;
-    const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts;
+    const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts, iq = 1.0 / q, rr = 0.1 * (iq * iq);
     PAR(lane) {
         double lf = 0, lth = 0, lbar = 0;
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
@@ -1114,11 +1115,11 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
             } else {
                 const double u[2] = {z[l.u + 2 * k] + alpha * d[l.u + 2 * k], z[l.u + 2 * k + 1] + alpha * d[l.u + 2 * k + 1]};
                 const double w[2] = {k ? z[l.u + 2 * k - 2] + alpha * d[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] + alpha * d[l.u + 2 * k - 1] : 0.0};
-                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + 0.1 * ((u[0] - w[0]) * (u[0] - w[0]) + (u[1] - w[1]) * (u[1] - w[1])) / (q * q);
+                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rr * ((u[0] - w[0]) * (u[0] - w[0]) + (u[1] - w[1]) * (u[1] - w[1]));   // same form as assemble_stage
                 bar_mul(ba, u[0] - OB_UL0, OB_UU0 - u[0]); bar_mul(ba, u[1] - OB_UL1, OB_UU1 - u[1]);
                 const double ss = z[l.ss + k] + alpha * d[l.ss + k];
                 bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
-                lth += fabs((w[0] - u[0]) / q - ss);
+                lth += fabs((w[0] - u[0]) * iq - ss);
                 double F[4]; dyn_value(c, x, u, t, F);
 #pragma unroll
                 for (int i = 0; i < 4; i++) lth += fabs(z[l.x + 4 * (k + 1) + i] + alpha * d[l.x + 4 * (k + 1) + i] - F[i]);
@@ -1505,7 +1506,7 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullp
         if (lane < OB_NOBMAX) sh.vOb[lane] = (int)sh.hdr[PH_VOB + lane];
         if (lane == 0) {
             Consts &c = sh.c;
-            c.N = N; c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
+            c.N = N; c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.iL = 1.0 / c.L; c.off = sh.hdr[PH_OFF];
             for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
             c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
             c.dist = (int)sh.hdr[PH_DIST];

@@ -26,7 +26,7 @@ static void setup(int N, const double *prob, Scratch &s) {
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
     Consts &c = sh.c; c.N = N;
-    c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.off = sh.hdr[PH_OFF];
+    c.Ts = sh.hdr[PH_TS]; c.L = sh.hdr[PH_L]; c.iL = 1.0 / c.L; c.off = sh.hdr[PH_OFF];
     for (int i = 0; i < 4; i++) { c.g[i] = sh.hdr[PH_G + i]; c.xl[i] = sh.hdr[PH_XL + i]; c.xu[i] = sh.hdr[PH_XU + i]; c.x0[i] = sh.hdr[PH_X0 + i]; c.xF[i] = sh.hdr[PH_XF + i]; }
     c.fixTime = (int)sh.hdr[PH_FIX]; c.nOb = (int)sh.hdr[PH_NOB]; c.M = (int)sh.hdr[PH_M];
     c.dist = (int)sh.hdr[PH_DIST];
