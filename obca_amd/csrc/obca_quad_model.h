@@ -46,14 +46,14 @@ OBCA_FN int q_vidx(int a) { return a < 3 ? 3 + a : (a < 6 ? 6 + a : QS + (a - 6)
 OBCA_FN void dyn_g_value(const QConsts &c, const double *x, const double *u, double g[QX]) {
     double s4, c4, s5, c5, s6, c6;
     sincos(x[3], &s4, &c4); sincos(x[4], &s5, &c5); sincos(x[5], &s6, &c6);
-    const double T4 = s4 / c4, S4 = 1 / c4, r10 = x[9], r11 = x[10], r12 = x[11];
+    const double S4 = rcp_nr(c4), T4 = s4 * S4, r10 = x[9], r11 = x[10], r12 = x[11];
     const double U = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3], kap = Q_KF / Q_MASS, h = s5 * r10 - c5 * r12;
     g[0] = x[6]; g[1] = x[7]; g[2] = x[8];
     g[3] = c5 * r10 + s5 * r12; g[4] = T4 * h + r11; g[5] = -S4 * h;
     g[6] = kap * U * (s4 * c5 * s6 + s5 * c6); g[7] = kap * U * (-s4 * c5 * c6 + s5 * s6); g[8] = kap * U * c4 * c5 - Q_GRAV;
-    g[9] = (Q_ARM * Q_KF * (u[1] * u[1] - u[3] * u[3]) - (Q_I3 - Q_I2) * c.gyro[1] * c.gyro[2]) / Q_I1;
-    g[10] = (Q_ARM * Q_KF * (u[2] * u[2] - u[0] * u[0]) - (Q_I1 - Q_I3) * c.gyro[0] * c.gyro[2]) / Q_I2;
-    g[11] = (Q_KM * (u[0] * u[0] - u[1] * u[1] + u[2] * u[2] - u[3] * u[3]) - (Q_I2 - Q_I1) * c.gyro[0] * c.gyro[1]) / Q_I3;
+    g[9] = (Q_ARM * Q_KF * (u[1] * u[1] - u[3] * u[3]) - (Q_I3 - Q_I2) * c.gyro[1] * c.gyro[2]) * (1.0 / Q_I1);
+    g[10] = (Q_ARM * Q_KF * (u[2] * u[2] - u[0] * u[0]) - (Q_I1 - Q_I3) * c.gyro[0] * c.gyro[2]) * (1.0 / Q_I2);
+    g[11] = (Q_KM * (u[0] * u[0] - u[1] * u[1] + u[2] * u[2] - u[3] * u[3]) - (Q_I2 - Q_I1) * c.gyro[0] * c.gyro[1]) * (1.0 / Q_I3);
 }
 
 // value, Jacobian rows 3..11 w.r.t. the QV local variables (dg[i-3][a]) and HG = sum_i w_i Hess g_i (upper triangle, packed 55)
@@ -61,16 +61,16 @@ OBCA_FN int q_pidx(int a, int b) { int i = a < b ? a : b, j = a < b ? b : a; ret
 OBCA_FN void dyn_g_derivs(const QConsts &c, const double *x, const double *u, const double *w, double g[QX], double dg[9][QV], double HG[55]) {
     double s4, c4, s5, c5, s6, c6;
     sincos(x[3], &s4, &c4); sincos(x[4], &s5, &c5); sincos(x[5], &s6, &c6);
-    const double T4 = s4 / c4, S4 = 1 / c4, r10 = x[9], r11 = x[10], r12 = x[11];
+    const double S4 = rcp_nr(c4), T4 = s4 * S4, r10 = x[9], r11 = x[10], r12 = x[11];
     const double U = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3], kap = Q_KF / Q_MASS;
     const double g4 = c5 * r10 + s5 * r12, h = s5 * r10 - c5 * r12;
     const double E7 = s4 * c5 * s6 + s5 * c6, E8 = -s4 * c5 * c6 + s5 * s6, E9 = c4 * c5;
     g[0] = x[6]; g[1] = x[7]; g[2] = x[8];
     g[3] = g4; g[4] = T4 * h + r11; g[5] = -S4 * h;
     g[6] = kap * U * E7; g[7] = kap * U * E8; g[8] = kap * U * E9 - Q_GRAV;
-    g[9] = (Q_ARM * Q_KF * (u[1] * u[1] - u[3] * u[3]) - (Q_I3 - Q_I2) * c.gyro[1] * c.gyro[2]) / Q_I1;
-    g[10] = (Q_ARM * Q_KF * (u[2] * u[2] - u[0] * u[0]) - (Q_I1 - Q_I3) * c.gyro[0] * c.gyro[2]) / Q_I2;
-    g[11] = (Q_KM * (u[0] * u[0] - u[1] * u[1] + u[2] * u[2] - u[3] * u[3]) - (Q_I2 - Q_I1) * c.gyro[0] * c.gyro[1]) / Q_I3;
+    g[9] = (Q_ARM * Q_KF * (u[1] * u[1] - u[3] * u[3]) - (Q_I3 - Q_I2) * c.gyro[1] * c.gyro[2]) * (1.0 / Q_I1);
+    g[10] = (Q_ARM * Q_KF * (u[2] * u[2] - u[0] * u[0]) - (Q_I1 - Q_I3) * c.gyro[0] * c.gyro[2]) * (1.0 / Q_I2);
+    g[11] = (Q_KM * (u[0] * u[0] - u[1] * u[1] + u[2] * u[2] - u[3] * u[3]) - (Q_I2 - Q_I1) * c.gyro[0] * c.gyro[1]) * (1.0 / Q_I3);
 #pragma unroll
     for (int i = 0; i < 9; i++)
 #pragma unroll
@@ -86,9 +86,9 @@ OBCA_FN void dyn_g_derivs(const QConsts &c, const double *x, const double *u, co
     for (int a = 0; a < 3; a++) { dg[3][a] = kap * U * E7d[a]; dg[4][a] = kap * U * E8d[a]; dg[5][a] = kap * U * E9d[a]; }
 #pragma unroll
     for (int j = 0; j < 4; j++) { dg[3][6 + j] = 2 * kap * u[j] * E7; dg[4][6 + j] = 2 * kap * u[j] * E8; dg[5][6 + j] = 2 * kap * u[j] * E9; }
-    dg[6][6 + 1] = 2 * Q_ARM * Q_KF * u[1] / Q_I1; dg[6][6 + 3] = -2 * Q_ARM * Q_KF * u[3] / Q_I1;
-    dg[7][6 + 2] = 2 * Q_ARM * Q_KF * u[2] / Q_I2; dg[7][6 + 0] = -2 * Q_ARM * Q_KF * u[0] / Q_I2;
-    dg[8][6 + 0] = 2 * Q_KM * u[0] / Q_I3; dg[8][6 + 1] = -2 * Q_KM * u[1] / Q_I3; dg[8][6 + 2] = 2 * Q_KM * u[2] / Q_I3; dg[8][6 + 3] = -2 * Q_KM * u[3] / Q_I3;
+    dg[6][6 + 1] = 2 * Q_ARM * Q_KF * u[1] * (1.0 / Q_I1); dg[6][6 + 3] = -2 * Q_ARM * Q_KF * u[3] * (1.0 / Q_I1);
+    dg[7][6 + 2] = 2 * Q_ARM * Q_KF * u[2] * (1.0 / Q_I2); dg[7][6 + 0] = -2 * Q_ARM * Q_KF * u[0] * (1.0 / Q_I2);
+    dg[8][6 + 0] = 2 * Q_KM * u[0] * (1.0 / Q_I3); dg[8][6 + 1] = -2 * Q_KM * u[1] * (1.0 / Q_I3); dg[8][6 + 2] = 2 * Q_KM * u[2] * (1.0 / Q_I3); dg[8][6 + 3] = -2 * Q_KM * u[3] * (1.0 / Q_I3);
 #pragma unroll
     for (int i = 0; i < 55; i++) HG[i] = 0;
 #define QSYM(i, j, v) HG[q_pidx((i), (j))] += (v)
@@ -111,10 +111,10 @@ OBCA_FN void dyn_g_derivs(const QConsts &c, const double *x, const double *u, co
 #pragma unroll
         for (int a = 0; a < 3; a++) QSYM(a, 6 + j, 2 * kap * u[j] * (w[6] * E7d[a] + w[7] * E8d[a] + w[8] * E9d[a]));
     }
-    QSYM(6 + 1, 6 + 1, w[9] * 2 * Q_ARM * Q_KF / Q_I1); QSYM(6 + 3, 6 + 3, -w[9] * 2 * Q_ARM * Q_KF / Q_I1);
-    QSYM(6 + 2, 6 + 2, w[10] * 2 * Q_ARM * Q_KF / Q_I2); QSYM(6 + 0, 6 + 0, -w[10] * 2 * Q_ARM * Q_KF / Q_I2);
-    QSYM(6 + 0, 6 + 0, w[11] * 2 * Q_KM / Q_I3); QSYM(6 + 1, 6 + 1, -w[11] * 2 * Q_KM / Q_I3);
-    QSYM(6 + 2, 6 + 2, w[11] * 2 * Q_KM / Q_I3); QSYM(6 + 3, 6 + 3, -w[11] * 2 * Q_KM / Q_I3);
+    QSYM(6 + 1, 6 + 1, w[9] * 2 * Q_ARM * Q_KF * (1.0 / Q_I1)); QSYM(6 + 3, 6 + 3, -w[9] * 2 * Q_ARM * Q_KF * (1.0 / Q_I1));
+    QSYM(6 + 2, 6 + 2, w[10] * 2 * Q_ARM * Q_KF * (1.0 / Q_I2)); QSYM(6 + 0, 6 + 0, -w[10] * 2 * Q_ARM * Q_KF * (1.0 / Q_I2));
+    QSYM(6 + 0, 6 + 0, w[11] * 2 * Q_KM * (1.0 / Q_I3)); QSYM(6 + 1, 6 + 1, -w[11] * 2 * Q_KM * (1.0 / Q_I3));
+    QSYM(6 + 2, 6 + 2, w[11] * 2 * Q_KM * (1.0 / Q_I3)); QSYM(6 + 3, 6 + 3, -w[11] * 2 * Q_KM * (1.0 / Q_I3));
 #undef QSYM
 }
 
@@ -146,7 +146,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     for (int i = 0; i < QL; i++) {
         const double sg = i < 3 ? 1.0 : -1.0; const int a = i % 3;
         g1[i] = 2 * sg * q[a]; g2[i] = -in.b[i] + sg * in.p[a];
-        const double il = 1.0 / in.lam[i], gl = 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
+        const double il = rcp_nr(in.lam[i]), gl = 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
         rl[i] = gl - mu_b * il; Dl[i] = 2e-4 + in.zl[i] * il + dw;
         if (MODE == 0) {
             double rz = fabs(gl - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
@@ -154,11 +154,11 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
             st->sumz += fabs(in.zl[i]);
         }
     }
-    const double is = 1.0 / in.s, iso = 1.0 / in.so;
+    const double is = rcp_nr(in.s), iso = rcp_nr(in.so);
     const double gs = 1e2 + 2e3 * in.s + 0.01 * y[1], gso = -y[1];
     // QuadcopterDist has no slack variable: it is frozen (1/D_s = 0, no residual), every term below then drops out and ds = 0
     const double r_s = c.dist ? 0.0 : gs - mu_b * is, r_so = gso - mu_b * iso;
-    const double iDs = c.dist ? 0.0 : 1.0 / (2e3 + in.zs * is + dw), iDso = 1.0 / (in.zso * iso + dw);
+    const double iDs = c.dist ? 0.0 : rcp_nr(2e3 + in.zs * is + dw), iDso = rcp_nr(in.zso * iso + dw);
     if (MODE == 0) {
         double rz = c.dist ? 0.0 : fabs(gs - in.zs); if (rz > st->dmax) st->dmax = rz;
         rz = fabs(gso - in.zso); if (rz > st->dmax) st->dmax = rz;
@@ -169,7 +169,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         st->sumy += fabs(y[0]) + fabs(y[1]);
     }
     // row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2
-    const double iT2 = 1.0 / (1e-4 * iDs + iDso + dc);
+    const double iT2 = rcp_nr(1e-4 * iDs + iDso + dc);
     const double r2 = -cr[1] + 0.01 * r_s * iDs - r_so * iDso;
     // (lambda, y1) block: Hb = diag(Dl) + 2 y1 D'D + g2 g2'/T2 ; coupling Cp = y2 D' + g2 q'/T2 ; rk
     double Hb[QL * QL], Cp[QL][3], rk[QL + 1];

@@ -724,11 +724,11 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
     {
         const double t = z[l.t], dL = t - Q_TLO, dU = Q_THI - t, zL = z[l.zL + l.t], zU = z[l.zU + l.t];
         double cc_;
-        cc_ = dt < 0 ? -tau * dL / dt : 1e300; if (cc_ < ap) ap = cc_;
-        cc_ = -dt < 0 ? -tau * dU / (-dt) : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = dt < 0 ? -tau * dL * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = -dt < 0 ? tau * dU * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
         const double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
-        cc_ = dzL < 0 ? -tau * zL / dzL : 1e300; if (cc_ < az) az = cc_;
-        cc_ = dzU < 0 ? -tau * zU / dzU : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzL < 0 ? -tau * zL * rcp_nr(dzL) : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzU < 0 ? -tau * zU * rcp_nr(dzU) : 1e300; if (cc_ < az) az = cc_;
         gd += ((N + 1) * (0.25 + 10 * t) + (N + 1) * (-rdiv(mu, dL) + rdiv(mu, dU))) * dt;
     }
     so.ap = ap; so.az = az; so.gd = gd;
