@@ -298,6 +298,11 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 // All index arithmetic of the item -> (row, column) maps is done once per sweep (QRicPlan, registers); the inner loops are
 // branch-free strided LDS reads + fp64 FMAs.  Stage records are gathered QRIC_D stages ahead (same vmcnt discipline as the
 // parking sweep: unconditional loads / stores, single-exit loop).
+#ifdef OBCA_QUAD_NO_OPAQUE
+#define QOPAQUE(x) ((void)0)
+#else
+#define QOPAQUE(x) OPAQUE(x)
+#endif
 #define QTC 18                       // columns of That: x (12), u (4), d, Ft
 #define QTH(a, tc) That[(a) * QTC + (tc)]
 #define QQH(i, cI) Qhat[(i) * QQC + (cI)]
@@ -350,7 +355,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         const QRicPlan &p = plan[LI(lane)];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            unsigned wa = p.a[r]; OPAQUE(wa);
+            unsigned wa = p.a[r]; QOPAQUE(wa);
             const int a = wa & 31, tc = (wa >> 5) & 31, pc = (int)((wa >> 10) & 31) - 1;
             if (a < QS) {
                 double ac[4] = {pc >= 0 ? sh.pn[a * QC + pc] : 0.0, 0.0, 0.0, 0.0};   // four chains: a dependent fp64 FMA costs ~45 clocks
@@ -368,7 +373,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         for (int r = 0; r < 6; r++) {
             const int it = lane + OB_NT * r;
             if (it < QZ * QQC) {
-                unsigned w = p.b[r]; OPAQUE(w);
+                unsigned w = p.b[r]; QOPAQUE(w);
                 const int h = w & 1023, t = (w >> 10) & 4095, fx = (int)((w >> 22) & 31) - 1, id = (int)(w >> 27) - 1;
                 double ac[4] = {sg[h], 0.0, 0.0, 0.0};
                 if (fx >= 0) {
@@ -423,7 +428,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         double pv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            unsigned w = p.d[r]; OPAQUE(w);
+            unsigned w = p.d[r]; QOPAQUE(w);
             const int i = (w & 31) < QS ? (int)(w & 31) : 0, cc = (w >> 5) & 31, qc = (w >> 10) & 63, rs = w >> 16;
             double v = QQH(i, qc);
 #pragma unroll
@@ -438,7 +443,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
             ro[rs] = v;
         }
         double bm = 0;
-        int pa_ = p.pa, pb_ = p.pb; OPAQUE(pa_); OPAQUE(pb_);
+        int pa_ = p.pa, pb_ = p.pb; QOPAQUE(pa_); QOPAQUE(pb_);
         if (pa_ >= 0) {
             const int a_ = pa_, b_ = pb_;
 #pragma unroll
@@ -449,7 +454,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            unsigned w = p.d[r]; OPAQUE(w); const int i = w & 31, cc = (w >> 5) & 31;
+            unsigned w = p.d[r]; QOPAQUE(w); const int i = w & 31, cc = (w >> 5) & 31;
             if (i < QS) { if (cc < QS) sh.Pn[i * QS + cc] = pv[r]; else sh.pn[i * QC + (cc - QS)] = pv[r]; }
         }
     }
