@@ -640,6 +640,8 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
                           double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
     double *L = (double *)&sh;
     const int sgo = (k & 1) * (int)(sh.stg[1] - sh.stg[0]);         // which of the two stage buffers holds stage k
+    // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
+    // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
         const RicPlan &p = rp[LI(lane)];
         const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
@@ -662,14 +664,15 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C
         const RicPlan &p = rp[LI(lane)];
+        const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
+        const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
+        const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
+        const double v = fma(fma(x6, n0, x7 * n1), idet, ba) + s12;
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
             stage_unpack_store(sh.stg[kp & 1], plan[LI(lane)], nv[LI(lane)][slot]);
             stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
-        const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
-        const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
-        const double v = fma(fma(L[p.c_x6], n0, L[p.c_x7] * n1), idet, L[p.c_base]) + (L[p.c_s1] + L[p.c_s2]);
         L[p.c_d1] = v; L[p.c_d2] = v;
         ro[p.c_rv] = v; ro[p.c_rk0] = n0 * idet; ro[p.c_rk1] = n1 * idet;
     }
