@@ -26,7 +26,7 @@ import pytest
 @pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
 def test_emu_newton_direction_matches_oracle(oracle, emu, backwards, dist):
     rng = np.random.default_rng(3)
-    for N in (3, 9):
+    for N in (2, 3, 9):
         sc = S.BACKWARDS; A, b, v = backwards["A"], backwards["b"], backwards["vOb"]; nOb = len(v); M = int(v.sum())
         x0 = np.array([-5, 9.0, -0.1, 0.]); Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); Ts = 0.7
         L = P.layout(N, nOb, M)
