@@ -1,18 +1,20 @@
-// obca_solver.h -- one OBCA parking NLP instance solved by ONE 64-lane wavefront (gfx950).
+// obca_solver.h -- one OBCA parking NLP instance solved by ONE workgroup of OB_NT = 128 threads (two wavefronts, gfx950), persistent over
+// the whole interior-point solve; the kernel runs one wavefront per SIMD (256 VGPRs + 256 AGPRs per wave), two instances per CU.
 //
-// Programming model: the whole solve runs inside one workgroup of exactly 64 threads (one wave).  Code outside a
-// PAR(lane){...} region is wave-uniform (every lane computes the same scalars); PAR regions distribute work items
-// (stages, (stage,obstacle) blocks, matrix entries) over the 64 lanes; data crosses lanes only through LDS (`Shared`) or
-// the per-instance global scratch, never through registers held across a SYNC().
+// Programming model: code outside a PAR(lane){...} region is workgroup-uniform (every lane computes the same scalars); PAR regions
+// distribute work items over the 128 lanes; data crosses lanes only through LDS (`Shared`), the per-instance records in HBM, or -- inside
+// wavefront 0 -- DPP / v_readlane; never through registers held across a SYNC().
 //   * (stage, obstacle) blocks  -> one lane per block        (condensation / back-substitution, obca_model.h)
 //   * stages                    -> one lane per stage        (bicycle model derivatives, costs, bounds)
-//   * Riccati recursion         -> sequential in the stage index, the 8x(8+6) extended stage matrices spread over the lanes
-//   * reductions (norms, step lengths, objective) -> 64-lane butterfly
-// The algorithm is the primal-dual interior-point method stated in DESIGN.md (IPOPT's Algorithm A with the option
-// values of ParkingSignedDist.jl:41-43).
+//   * Riccati backward sweep    -> sequential in the stage index; per stage three short LDS phases, one matrix entry per lane on both waves
+//   * forward sweep             -> wavefront 0, two stages per dependent step, state broadcast with v_readlane
+//   * reductions (norms, step lengths, objective) -> LDS fold of the second wave + 64-lane butterfly (DPP for the in-row exchanges)
+// Phases are non-inlined device functions (ph_*) with all uniform state in LDS; a solve can be parked at the top of an iteration and
+// resumed by a later launch (Slice, two-launch schedule).  The algorithm is the primal-dual interior-point method stated in DESIGN.md
+// (IPOPT's Algorithm A with the option values of ParkingSignedDist.jl:41-43).
 //
-// The same source is compiled by tests/emu (g++, -DOBCA_EMU) where PAR is a plain loop over 64 lanes: that build exists
-// only so that the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
+// The same source is compiled by tests/emu (g++, -DOBCA_EMU) where PAR is a plain loop over the lanes: that build exists only so that
+// the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
 #pragma once
 #ifndef OB_NT
 #define OB_NT 128    // threads per problem instance (1 or 2 wavefronts): lane-parallel phases use all of them, sequential sweeps wave 0
@@ -175,7 +177,7 @@ struct Shared {
 #ifdef OBCA_EMU
 static Shared g_sh;
 #else
-__shared__ Shared g_sh;     // the one LDS block of the workgroup (= one wavefront = one problem instance)
+__shared__ Shared g_sh;     // the one LDS block of the workgroup (= two wavefronts = one problem instance)
 #endif
 
 // phase ids of the diagnostic cycle counters

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY.  Host emulation of the wave-per-instance HIP solver: the device source
+// TEST INFRASTRUCTURE ONLY.  Host emulation of the workgroup-per-instance HIP solver: the device source
 // obca_amd/csrc/obca_solver.h is compiled with -DOBCA_EMU, which turns every PAR(lane) region into a plain
 // loop over 64 lanes.  It lets the CPU test-suite check the kernel logic (Newton direction, full solves) against
 // the oracle on a machine without a GPU.  It is never linked into libobca_hip.so.
