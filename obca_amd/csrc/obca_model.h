@@ -164,17 +164,17 @@ OBCA_FN void ldl_solve(int n, const double *A, double *b) {
         }
     }
 }
-OBCA_FN int chol2(double q00, double q10, double q11, double Lc[3]) {
+OBCA_FN int chol2(double q00, double q10, double q11, double Lc[3]) {   // 2x2 LDL' (no square roots): Lc = {1/d0, l, 1/d1}; 0 unless positive definite
     if (!(q00 > 0)) return 0;
-    Lc[0] = sqrt(q00); Lc[1] = q10 / Lc[0];
-    double d = q11 - Lc[1] * Lc[1];
+    Lc[0] = rcp_nr(q00); Lc[1] = q10 * Lc[0];
+    const double d = q11 - Lc[1] * q10;
     if (!(d > 0)) return 0;
-    Lc[2] = sqrt(d);
+    Lc[2] = rcp_nr(d);
     return 1;
 }
 OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
-    b0 /= Lc[0]; b1 = (b1 - Lc[1] * b0) / Lc[2];
-    b1 /= Lc[2]; b0 = (b0 - Lc[1] * b1) / Lc[0];
+    b1 = (b1 - Lc[1] * b0) * Lc[2];
+    b0 = b0 * Lc[0] - Lc[1] * b1;
 }
 template <int VM>
 OBCA_FN void hh_apply(int v, const double *w, double beta, double *x) {   // x <- (I - beta w w') x, beta = 2 / (w'w): w is NOT normalised
@@ -500,6 +500,7 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         for (int i = 0; i < 4; i++) zm[i] = 1;
     }
     const double Em0[4] = {1, 0, -1, 0}, Em1[4] = {0, 1, 0, -1};
+    const double iv5 = 1.0 / (v + 5);
     for (int it = 0; it < 60; it++) {
         double p1 = 0, p2 = 0;
 #pragma unroll
@@ -510,7 +511,7 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         for (int i = 0; i < OB_VMAX; i++) if (i < v) gap += lam[i] * zl[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) gap += mu[i] * zm[i];
-        double mbar = gap / (v + 5);
+        double mbar = gap * iv5;
         double gh[OB_VMAX], rl[OB_VMAX], rm[4], rmax = 0;
 #pragma unroll
         for (int i = 0; i < OB_VMAX; i++) {
@@ -524,17 +525,25 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         for (int i = 0; i < 4; i++) { rm[i] = g[i] + Em0[i] * eta0 + Em1[i] * eta1 - zm[i]; if (fabs(rm[i]) > rmax) rmax = fabs(rm[i]); }
         if (mbar < 1e-9 && rmax < 1e-9) break;
         double mt = 0.1 * mbar;
-        double Hl[OB_VMAX * OB_VMAX], bl[OB_VMAX], Dm[4], bm[4];
+        // reciprocals of the barrier variables, once per iteration (reciprocal + Newton, obca_model.h: rcp_nr); the subproblem is a chain of
+        // dependent scalar operations per lane, and an IEEE division is 11 of them
+        const double ih = rcp_nr(h);
+        double il[OB_VMAX], im[4];
+#pragma unroll
+        for (int i = 0; i < OB_VMAX; i++) il[i] = i < v ? rcp_nr(lam[i]) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) im[i] = rcp_nr(mu[i]);
+        double Hl[OB_VMAX * OB_VMAX], bl[OB_VMAX], Dm[4], iDm[4], bm[4];
 #pragma unroll
         for (int i = 0; i < OB_VMAX; i++) {
 #pragma unroll
             for (int j = 0; j < OB_VMAX; j++)
-                Hl[i * OB_VMAX + j] = (i < v && j < v) ? zh * 2 * (a1[i] * a1[j] + a2[i] * a2[j]) + (zh / h) * gh[i] * gh[j] : 0.0;
-            if (i < v) { Hl[i * OB_VMAX + i] += zl[i] / lam[i]; bl[i] = -(rl[i] + zl[i] - mt / lam[i] + (zh - mt / h) * gh[i]); }
+                Hl[i * OB_VMAX + j] = (i < v && j < v) ? zh * 2 * (a1[i] * a1[j] + a2[i] * a2[j]) + (zh * ih) * gh[i] * gh[j] : 0.0;
+            if (i < v) { Hl[i * OB_VMAX + i] += zl[i] * il[i]; bl[i] = -(rl[i] + zl[i] - mt * il[i] + (zh - mt * ih) * gh[i]); }
             else bl[i] = 0;
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) { Dm[i] = zm[i] / mu[i]; bm[i] = -(rm[i] + zm[i] - mt / mu[i]); }
+        for (int i = 0; i < 4; i++) { Dm[i] = zm[i] * im[i]; iDm[i] = rcp_nr(Dm[i]); bm[i] = -(rm[i] + zm[i] - mt * im[i]); }
         if (ldl_fact<OB_VMAX>(v, Hl)) break;
         double HiQ0[OB_VMAX], HiQ1[OB_VMAX], Hib[OB_VMAX];
 #pragma unroll
@@ -548,8 +557,8 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            S00 += Em0[i] * Em0[i] / Dm[i]; S01 += Em0[i] * Em1[i] / Dm[i]; S11 += Em1[i] * Em1[i] / Dm[i];
-            rs0 += Em0[i] * bm[i] / Dm[i]; rs1 += Em1[i] * bm[i] / Dm[i];
+            S00 += Em0[i] * Em0[i] * iDm[i]; S01 += Em0[i] * Em1[i] * iDm[i]; S11 += Em1[i] * Em1[i] * iDm[i];
+            rs0 += Em0[i] * bm[i] * iDm[i]; rs1 += Em1[i] * bm[i] * iDm[i];
         }
         double Lc[3];
         if (!chol2(S00, S01, S11, Lc)) break;
@@ -559,17 +568,17 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
 #pragma unroll
         for (int i = 0; i < OB_VMAX; i++) {
             dl[i] = i < v ? Hib[i] - HiQ0[i] * de0 - HiQ1[i] * de1 : 0.0;
-            dzl[i] = i < v ? mt / lam[i] - zl[i] - zl[i] / lam[i] * dl[i] : 0.0;
+            dzl[i] = i < v ? mt * il[i] - zl[i] - zl[i] * il[i] * dl[i] : 0.0;
             ghd += gh[i] * dl[i];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            dm[i] = (bm[i] - Em0[i] * de0 - Em1[i] * de1) / Dm[i];
-            dzm[i] = mt / mu[i] - zm[i] - zm[i] / mu[i] * dm[i];
+            dm[i] = (bm[i] - Em0[i] * de0 - Em1[i] * de1) * iDm[i];
+            dzm[i] = mt * im[i] - zm[i] - zm[i] * im[i] * dm[i];
         }
-        double dzh = mt / h - zh - zh / h * ghd;
+        double dzh = mt * ih - zh - zh * ih * ghd;
         double a = 1, tb = 0.995, cc;
-#define OB_FTB(val, dv) { cc = (dv) < 0 ? -tb * (val) / (dv) : 1e300; if (cc < a) a = cc; }
+#define OB_FTB(val, dv) { cc = (dv) < 0 ? -tb * (val) * rcp_nr(dv) : 1e300; if (cc < a) a = cc; }
 #pragma unroll
         for (int i = 0; i < OB_VMAX; i++) if (i < v) { OB_FTB(lam[i], dl[i]); OB_FTB(zl[i], dzl[i]); }
 #pragma unroll
