@@ -6,15 +6,26 @@ A "step" is one pass of the hot path over one batch of synthetic input: BASELINE
 (ParkingSignedDist, N=80, 3 obstacles / 5 half-space rows, variable time, fp64) for 1 024 randomised start poses PER GPU
 (weak scaling: rank r solves its own 1 024 instances, seed 20260925+r; no collective touches the solve).  Inputs (problem data
 and warm starts) are resident in HBM before the timed region; a step = device-side reset of the iterates + DualMultWS kernel +
-interior-point kernel + stream sync.  `value` counts CONVERGED solves (exitflag 1) of all ranks per second.
+interior-point kernel(s).  `value` counts CONVERGED solves (exitflag 1) of all ranks per second.
 
-  python bench.py --gpus 1 --steps 5 --warmup 1
+Steps are PIPELINED: every rank keeps --streams (default 4) device-resident copies of its batch, each on its own HIP stream, and step k runs
+on copy k mod streams without a host synchronisation between steps (the K timed steps are bracketed by barrier + synchronize as the
+contract says).  The solve times of a batch are heavy-tailed -- the median instance needs 27 factorisation passes, the slowest of a batch
+100-300 depending on the seed (tools/rank_tails.py) -- so a step that waits for its last instance leaves the GPU idle for half of its
+duration; with several batches in flight the tail of one step overlaps the bulk of the next ones.  `--streams 1` gives the synchronous step
+(one launch alone on the GPU; 87.5 k instead of ~128 k solves/s, and an 8-GPU run is then held back by the rank with the unluckiest batch).
+
+  python bench.py --gpus 1 --steps 20 --warmup 4
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
 Extra objects in the JSON line:
   roofline     : dominant kernel = obca_parking_ipm_kernel: "achieved" = algorithmic HBM bytes (B_PASS per
-                 factorisation pass x passes actually taken, read back from the kernel's iteration/regularisation counters) /
-                 HIP-event duration of that kernel; the executed-algorithm fp64 flop rate is reported next to it.
+                 factorisation pass x passes actually taken, read back from the kernel's iteration/regularisation counters) of the
+                 launches in the timed region / the time they take: with --streams 1 the HIP-event duration of the kernel, with
+                 pipelined steps (launches of several streams overlap, so a single launch's duration says nothing about the rate the
+                 device sustains) the wall time of the region; kernel_ms is the HIP-event duration of one step's launches either way
+                 (overlapped if pipelined -- the figure the rocprofv3 trace of the same command shows).  The executed-algorithm fp64
+                 flop rate is reported next to it.
   cpu_baseline : the CPU oracle (C restatement, NOT IPOPT) on a bounded sample of the same instances, on the box's host cores.
 """
 import argparse
@@ -101,13 +112,15 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU for a functional test)")
-    ap.add_argument("--streams", type=int, default=1, help="device-resident copies of the batch on their own HIP streams; with 2 the steps are not "
-                    "synchronised one by one, so the tail of one step (a few hard instances) overlaps the bulk of the next (default 1: the contract's step)")
+    ap.add_argument("--streams", type=int, default=4, help="device-resident copies of the batch, each on its own HIP stream: step k runs on copy k mod "
+                    "streams and steps are not synchronised one by one, so the tail of one step (a few hard instances) overlaps the bulk of the "
+                    "next ones; 1 = synchronous steps (one launch alone on the GPU)")
+    ap.add_argument("--seed-offset", type=int, default=None, help="diagnostic: use the batch of this rank (seed 20260925 + offset) instead of the rank's own")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -129,7 +142,7 @@ def main():
             torch.cuda.set_device(local)
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     B = a.batch
-    bt = S.make_batch(S.BACKWARDS, B, N_HORIZON, seed=SEED + rank)
+    bt = S.make_batch(S.BACKWARDS, B, N_HORIZON, seed=SEED + (rank if a.seed_offset is None else a.seed_offset))
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
     batches = []
     for si in range(max(1, a.streams)):
@@ -146,7 +159,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(max(a.warmup, nS if nS > 1 else 0)):
+    for w in range(a.warmup):
         batches[w % nS].solve()
     fence()
     t0 = time.perf_counter()
@@ -185,8 +198,18 @@ def main():
         conv_all, iters_all, passes_all = float(conv), float(out["iters"].sum()), passes
     if rank == 0:
         k_ms = float(np.mean(ipm_ms))
-        tflops = passes * F_PASS / (k_ms * 1e-3) / 1e12        # rank 0's kernel: flops of the passes it took / its duration
-        gbs = passes * B_PASS / (k_ms * 1e-3) / 1e9            # algorithmic HBM bytes of those passes / its duration
+        t_eff = k_ms * 1e-3 if nS == 1 else dt / a.steps       # time per step's worth of passes: the launch alone, or the pipelined region / K
+        tflops = passes * F_PASS / t_eff / 1e12                # rank 0: flops of the passes of one step / that time
+        gbs = passes * B_PASS / t_eff / 1e9                    # algorithmic HBM bytes of those passes / that time
+        how = ("the HIP-event time of the step's IPM launches" if nS == 1 else
+               "(timed wall time / steps): %d steps are in flight on their own streams, so the rate the device sustains is the region's, not one "
+               "overlapped launch's" % nS)
+        model_txt = ("per factorisation pass of one instance: B_PASS=%.3g algorithmic HBM bytes and F_PASS=%.3g executed fp64 flops (SURVEY 8d Model B), "
+                     "x %d passes per step (iterations + inertia retries, read back from the kernel). The larger of the two fractions is reported as the "
+                     "bound; neither is tight: the kernel is latency / issue bound (one wave per SIMD, 81 dependent stages per pass) and a batch ends "
+                     "with its slowest instance. achieved = those bytes / %s. kernel_ms = HIP-event time of all IPM launches of one step (two-launch "
+                     "schedule: slice + hardest-first completion)%s; traffic = PMC bytes of one step from profiles/r01_pmc_*.csv (committed, not live)"
+                     % (B_PASS, F_PASS, int(passes), how, "" if nS == 1 else ", overlapped with the other steps in flight"))
         line = {
             "metric": "OBCA NLP solves/sec (N=80, 3 obs, batch)", "value": round(conv_all * a.steps / dt, 2), "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -199,14 +222,9 @@ def main():
                        "exitflag1_rank0": int((out["exitflag"] == 1).sum()), "validated_rank0": int(okv.sum())},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "traffic": committed_pmc_traffic(),
-                         "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "ipm_launches_per_step": batch.last_schedule()[0], "slice_passes": batch.last_schedule()[1], "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
+                         "kernel": "obca_parking_ipm_kernel", "kernel_ms": round(k_ms, 3), "steps_in_flight": nS, "ipm_launches_per_step": batch.last_schedule()[0], "slice_passes": batch.last_schedule()[1], "dualws_kernel_ms": round(float(np.mean(dws_ms)), 3),
                          "fp64_tflops": round(tflops, 3), "fp64_frac": round(tflops / FP64_PEAK_TFLOPS, 5),
-                         "model": "per factorisation pass of one instance: B_PASS=%.3g algorithmic HBM bytes and F_PASS=%.3g executed fp64 flops "
-                                  "(SURVEY 8d Model B), x %d passes (iterations + inertia retries, read back from the kernel). The larger of the "
-                                  "two fractions is reported as the bound; neither is tight: the kernel is latency-bound (one wave per SIMD, 81 dependent "
-                                  "stages per pass) and ends with the slowest instance of the batch. kernel_ms = HIP-event time of all IPM launches of "
-                                  "a step (two-launch schedule: slice + hardest-first completion); traffic = PMC bytes of one step from "
-                                  "profiles/r01_pmc_*.csv (committed, not live)" % (B_PASS, F_PASS, int(passes))},
+                         "model": model_txt},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

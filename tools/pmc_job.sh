@@ -3,7 +3,7 @@
 R=$(pwd); export TMPDIR=/tmp; cd /tmp
 rm -rf $R/gpurun_out/pmcq; mkdir -p $R/gpurun_out/pmcq
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcq -o $C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmcq/$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcq -o $C -- python $R/bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmcq/$C.err
 done
 cd $R; python - <<'PY'
 import csv
