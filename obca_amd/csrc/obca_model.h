@@ -270,8 +270,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
         { const double im = rcp_nr(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr(in.zm[i] * im + dw); }
         if (MODE == 0) {
-            double rz = fabs(jy - in.zm[i]); if (rz > st->dmax) st->dmax = rz;
-            double cc = in.mu[i] * in.zm[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+            double rz = fabs(jy - in.zm[i]); st->dmax = fmax(st->dmax, rz);
+            double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
             st->sumz += fabs(in.zm[i]);
         }
     }
@@ -281,20 +281,20 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
             { const double il = rcp_nr(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
-                double rz = fabs(jy - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
-                double cc = in.lam[i] * in.zl[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+                double rz = fabs(jy - in.zl[i]); st->dmax = fmax(st->dmax, rz);
+                double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
                 st->sumz += fabs(in.zl[i]);
             }
         } else { r_lam[i] = 0; Dlam[i] = 1; }
     }
     if (MODE == 0) {
-        double rz = fabs(-y[3] - in.zso); if (rz > st->dmax) st->dmax = rz;
-        { const double rzs = c.dist ? fabs(y[0] - in.zs1) : fabs(r_sl); if (rzs > st->dmax) st->dmax = rzs; }
-        if (c.dist) { const double c1 = in.sl * in.zs1; if (fabs(c1) > st->cmax0) st->cmax0 = fabs(c1); if (fabs(c1 - mu_b) > st->cmaxmu) st->cmaxmu = fabs(c1 - mu_b); st->sumz += fabs(in.zs1); }
-        double cc = in.so * in.zso; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+        double rz = fabs(-y[3] - in.zso); st->dmax = fmax(st->dmax, rz);
+        { const double rzs = c.dist ? fabs(y[0] - in.zs1) : fabs(r_sl); st->dmax = fmax(st->dmax, rzs); }
+        if (c.dist) { const double c1 = in.sl * in.zs1; st->cmax0 = fmax(st->cmax0, fabs(c1)); st->cmaxmu = fmax(st->cmaxmu, fabs(c1 - mu_b)); st->sumz += fabs(in.zs1); }
+        double cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
         st->sumz += fabs(in.zso);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { if (fabs(cr[r]) > st->pmax) st->pmax = fabs(cr[r]); st->sumy += fabs(y[r]); }
+        for (int r = 0; r < 4; r++) { st->pmax = fmax(st->pmax, fabs(cr[r])); st->sumy += fabs(y[r]); }
     }
     // rows 2..4 after eliminating so, sl, mu:   Jl dlam + Jp dpose - T dy = r234
     double Tm[9];
@@ -486,7 +486,7 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         double x1 = i < v ? a1[i] : 0.0, x2 = i < v ? a2[i] : 0.0;
         Q0[i] = cs * x1 + sn * x2; Q1[i] = -sn * x1 + cs * x2;
         cl[i] = x1 * ex + x2 * ey - (i < v ? bj[i] : 0.0);
-        double nr = sqrt(x1 * x1 + x2 * x2); if (nr > amax) amax = nr;
+        double nr = sqrt(x1 * x1 + x2 * x2); amax = fmax(amax, nr);
     }
     double zl[OB_VMAX], zm[4], zh = 1, eta0 = 0, eta1 = 0;
 #pragma unroll
@@ -518,11 +518,11 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
             if (i < v) {
                 gh[i] = -2 * (p1 * a1[i] + p2 * a2[i]);
                 rl[i] = -cl[i] + Q0[i] * eta0 + Q1[i] * eta1 - zl[i] - zh * gh[i];
-                if (fabs(rl[i]) > rmax) rmax = fabs(rl[i]);
+                rmax = fmax(rmax, fabs(rl[i]));
             } else { gh[i] = 0; rl[i] = 0; }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) { rm[i] = g[i] + Em0[i] * eta0 + Em1[i] * eta1 - zm[i]; if (fabs(rm[i]) > rmax) rmax = fabs(rm[i]); }
+        for (int i = 0; i < 4; i++) { rm[i] = g[i] + Em0[i] * eta0 + Em1[i] * eta1 - zm[i]; rmax = fmax(rmax, fabs(rm[i])); }
         if (mbar < 1e-9 && rmax < 1e-9) break;
         double mt = 0.1 * mbar;
         // reciprocals of the barrier variables, once per iteration (reciprocal + Newton, obca_model.h: rcp_nr); the subproblem is a chain of

@@ -149,8 +149,8 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         const double il = rcp_nr(in.lam[i]), gl = 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
         rl[i] = gl - mu_b * il; Dl[i] = 2e-4 + in.zl[i] * il + dw;
         if (MODE == 0) {
-            double rz = fabs(gl - in.zl[i]); if (rz > st->dmax) st->dmax = rz;
-            double cc = in.lam[i] * in.zl[i]; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+            double rz = fabs(gl - in.zl[i]); st->dmax = fmax(st->dmax, rz);
+            double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
             st->sumz += fabs(in.zl[i]);
         }
     }
@@ -160,12 +160,12 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     const double r_s = c.dist ? 0.0 : gs - mu_b * is, r_so = gso - mu_b * iso;
     const double iDs = c.dist ? 0.0 : rcp_nr(2e3 + in.zs * is + dw), iDso = rcp_nr(in.zso * iso + dw);
     if (MODE == 0) {
-        double rz = c.dist ? 0.0 : fabs(gs - in.zs); if (rz > st->dmax) st->dmax = rz;
-        rz = fabs(gso - in.zso); if (rz > st->dmax) st->dmax = rz;
-        double cc = c.dist ? 0.0 : in.s * in.zs; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (!c.dist && fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
-        cc = in.so * in.zso; if (fabs(cc) > st->cmax0) st->cmax0 = fabs(cc); if (fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+        double rz = c.dist ? 0.0 : fabs(gs - in.zs); st->dmax = fmax(st->dmax, rz);
+        rz = fabs(gso - in.zso); st->dmax = fmax(st->dmax, rz);
+        double cc = c.dist ? 0.0 : in.s * in.zs; st->cmax0 = fmax(st->cmax0, fabs(cc)); if (!c.dist && fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
+        cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
         st->sumz += (c.dist ? 0.0 : fabs(in.zs)) + fabs(in.zso);
-        if (fabs(cr[0]) > st->pmax) st->pmax = fabs(cr[0]); if (fabs(cr[1]) > st->pmax) st->pmax = fabs(cr[1]);
+        st->pmax = fmax(st->pmax, fabs(cr[0])); st->pmax = fmax(st->pmax, fabs(cr[1]));
         st->sumy += fabs(y[0]) + fabs(y[1]);
     }
     // row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2

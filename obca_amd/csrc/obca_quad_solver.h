@@ -163,9 +163,9 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             if (k == N) {
 #pragma unroll
                 for (int i = 0; i < QX; i++) {
-                    const double e = fabs(x[i] - c.xF[i]); if (e > pmax) pmax = e; lth += e;
+                    const double e = fabs(x[i] - c.xF[i]); pmax = fmax(pmax, e); lth += e;
                     const double r = z[l.pi + QX * (N - 1) + i] + z[l.nu + i];
-                    hz[i] += r; hb[i] += r; if (fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                    hz[i] += r; hb[i] += r; dmax = fmax(dmax, fabs(hz[i]));
                     lsy += fabs(z[l.nu + i]);
                     rec[QSR_H + i * QZ + i] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
                     rec[QSR_HC + 2 * i] = hb[i]; rec[QSR_HC + 2 * i + 1] = 0.0;
@@ -185,7 +185,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #pragma unroll
             for (int i = 0; i < QX; i++) {
                 const double r = z[l.x + QX * (k + 1) + i] - x[i] - tau * g[i];
-                if (fabs(r) > pmax) pmax = fabs(r); lth += fabs(r);
+                pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                 rec[QSR_F + i * QFC + 16] = -r; rec[QSR_F + i * QFC + 17] = c.Ts * g[i];
             }
 #pragma unroll
@@ -236,7 +236,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
                 hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = hu + b.Sig + dw;
                 wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - z[l.u + QU * (k + 1) + j]) : 0.0;     // copy part living in stage k+1
-                const double tot = hzu[j] + wn[j]; if (fabs(tot) > dmax) dmax = fabs(tot);
+                const double tot = hzu[j] + wn[j]; dmax = fmax(dmax, fabs(tot));
             }
             // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
 #pragma unroll

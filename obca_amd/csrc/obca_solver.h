@@ -262,10 +262,10 @@ OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double m
     const double dL = v - lo, dU = hi - v, iL = rcp_nr(dL), iU = rcp_nr(dU);
     B2 r; r.Sig = mult * (zL * iL + zU * iU); r.gz = mult * (-zL + zU); r.gb = mult * mu * (iU - iL);
     double c1 = dL * zL, c2 = dU * zU;
-    if (fabs(c1) > c0) c0 = fabs(c1);
-    if (fabs(c2) > c0) c0 = fabs(c2);
-    if (fabs(c1 - mu) > cmu) cmu = fabs(c1 - mu);
-    if (fabs(c2 - mu) > cmu) cmu = fabs(c2 - mu);
+    c0 = fmax(c0, fabs(c1));
+    c0 = fmax(c0, fabs(c2));
+    cmu = fmax(cmu, fabs(c1 - mu));
+    cmu = fmax(cmu, fabs(c2 - mu));
     sumz += fabs(zL) + fabs(zU);
     return r;
 }
@@ -402,10 +402,10 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
             if (k == N) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    double e = fabs(x[i] - c.xF[i]); if (e > pmax) pmax = e; lth += e;
+                    double e = fabs(x[i] - c.xF[i]); pmax = fmax(pmax, e); lth += e;
                     double r = pi[i] + nu4[i];
                     hz[i] += r; hb[i] += r;
-                    if (fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                    dmax = fmax(dmax, fabs(hz[i]));
                     lsy += fabs(nu4[i]);
                 }
             } else {
@@ -433,8 +433,8 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
-                    if (fabs(rz) > dmax) dmax = fabs(rz);
-                    const double res = g - ss; if (fabs(res) > pmax) pmax = fabs(res); lth += fabs(res);
+                    dmax = fmax(dmax, fabs(rz));
+                    const double res = g - ss; pmax = fmax(pmax, fabs(res)); lth += fabs(res);
                     const double Dss = b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = res + rb * iDss;
                     rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
                     rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
@@ -456,7 +456,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
                         for (int j = 0; j < 5; j++) rec[AS_DF + 5 * i + j] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
                         double r = xn[i] - dy.F[i];
-                        rec[AS_DD + i] = -r; if (fabs(r) > pmax) pmax = fabs(r); lth += fabs(r);
+                        rec[AS_DD + i] = -r; pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                         lsy += fabs(pi[i]);
                     }
                     const int id[4] = {2, 3, 6, 7};
@@ -498,7 +498,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                         wn[1] = -2 * rr * (un[1] - u[1]);
                     }
 #pragma unroll
-                    for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; if (fabs(tot) > dmax) dmax = fabs(tot); }
+                    for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; dmax = fmax(dmax, fabs(tot)); }
                 }
             }
             lbar += bar_log(ba);
