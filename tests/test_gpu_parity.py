@@ -179,6 +179,36 @@ def test_two_launch_schedule_is_bit_identical_to_a_single_launch(OA, monkeypatch
     b.close(); ctx.close()
 
 
+def test_batches_in_flight_on_several_contexts_do_not_interfere(OA):
+    """the deployment pattern of INTEGRATION.md / bench.py: several contexts (one HIP stream each), each with its own batch, solves submitted
+    round-robin without synchronising in between.  Every batch must come out exactly as when it is solved alone."""
+    N, B = 80, 640                      # > 512: the two-launch schedule is active, its ordering kernel and slice records are per batch
+    bts = [S.make_batch(S.BACKWARDS, B, N, seed=100 + i) for i in range(3)]
+    ctxs = [OA.Context(0) for _ in bts]; bs = []
+    for ctx, bt in zip(ctxs, bts):
+        xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+        b = OA.Batch(ctx, B, N)
+        b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+        bs.append(b)
+    alone = []
+    for b in bs:
+        b.solve(); alone.append(b.download())
+    for rep in range(3):
+        for b in bs:
+            b.solve(sync=False)
+    for b in bs:
+        b.sync()
+    for i, b in enumerate(bs):
+        out = b.download()
+        for k in ("xp", "up", "timeScale", "lp", "np", "sl", "info", "exitflag"):
+            assert np.array_equal(alone[i][k], out[k]), (i, k)
+        assert (out["exitflag"] == 1).mean() > 0.97
+    for b in bs:
+        b.close()
+    for c in ctxs:
+        c.close()
+
+
 def test_single_instance_wrapper_and_shapes(OA, oracle, backwards):
     N = 40; sc = S.BACKWARDS; x0 = sc["x0"]
     Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); xWS[0] = x0
