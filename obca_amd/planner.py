@@ -84,6 +84,45 @@ def path_to_warm_start(path, dr, N, xF=None, v_nom=0.5, L=S.L_WHEELBASE):
     return Ts, np.stack([X, Y, yaw, v], 1), np.stack([delta, a], 1)
 
 
+def velo_smooth(v, amax, Ts):
+    """Velocity smoother of the warm-start pipeline (behaviour of AutonomousParking/veloSmooth.jl:29-109, used at main.jl:230-231): the planner's
+    speed profile is piecewise constant at +-v_nom (0 at the end); every jump of the profile is replaced by a ramp of slope amax --
+    0 <-> +-v_nom jumps by a ramp of round(v_nom / amax / Ts) samples that ends (starts) at the jump, +-v_nom <-> -+v_nom jumps by a ramp of
+    twice that length centred on it -- and at every sample the candidate with the smallest speed is kept.  Returns (v_smooth (n,), a (n-1,))
+    with a = diff(v_smooth) / Ts.  v[0] sets the nominal speed (veloSmooth.jl:44-47), so the profile must start in motion."""
+    v = np.asarray(v, float).ravel(); n = len(v); v1 = abs(v[0])
+    pad = 19                                                    # veloSmooth.jl:31-41: 19 leading / 21 trailing zeros around the profile
+    vex = np.zeros(n + 41); vex[pad + 1:pad + 1 + n] = v        # 1-based like the reference: vex[k], k = 1 .. n+40
+    bar = np.zeros((4, n + 41)); bar[:, pad + 1:pad + 1 + n] = v
+    acc = int(round(v1 / amax / Ts))
+    dv = np.zeros(n + 41); dv[1:n + 40] = np.diff(vex[1:n + 41])  # dv[k] = vex[k+1] - vex[k]
+    ks = np.arange(1, n + 40)
+    cut1, cut2 = 0.25 * v1, 1.25 * v1
+    up1 = [k for k in ks if cut1 < dv[k] < cut2]; up2 = [k for k in ks if dv[k] > cut2]
+    dn1 = [k for k in ks if -cut2 < dv[k] < -cut1]; dn2 = [k for k in ks if dv[k] < -cut2]
+    if up1 and up1[0] == pad: up1[0] += 1                       # a jump on the very first sample starts its ramp on it (:55-60)
+    if dn1 and dn1[0] == pad: dn1[0] += 1
+    ramp = np.linspace(0.0, v1, acc + 1)
+
+    def put(row, lo, vals):                                     # bar[row, lo : lo+len-1] = vals, clipped to the padded array
+        for i, x in enumerate(vals):
+            if 1 <= lo + i <= n + 40: bar[row, lo + i] = x
+    for k in up1:                                               # rise by v_nom: start from rest, or come to rest from reverse (:63-69)
+        if vex[k] > cut1 or vex[k + 1] > cut1: put(0, k, ramp)
+        elif vex[k] < -cut1 or vex[k + 1] < -cut1: put(0, k - acc + 1, ramp - v1)
+    for k in dn1:                                               # fall by v_nom: come to rest, or start in reverse (:71-77)
+        if vex[k] > cut1 or vex[k + 1] > cut1: put(1, k - acc + 1, v1 - ramp)
+        elif vex[k] < -cut1 or vex[k + 1] < -cut1: put(1, k, -ramp)
+    full = np.linspace(-v1, v1, 2 * acc + 1)
+    for k in up2: put(2, k - acc, full)                         # reverse -> forward (:79-81)
+    for k in dn2: put(3, k - acc, -full)                        # forward -> reverse (:83-85)
+    out = np.zeros(n)
+    for i in range(pad + 1, pad + 1 + n):                       # (:87-104): a candidate of the wrong sign falls back to the raw profile
+        c = np.where(bar[:, i] == 0, 0.0, np.where(np.sign(vex[i]) != np.sign(bar[:, i]), vex[i], bar[:, i]))
+        out[i - pad - 1] = c.min() if vex[i] > 0 else c.max()
+    return out, np.diff(out) / Ts
+
+
 # search settings per scenario: the 6 m bay of the parallel scenario leaves 0.65 m at either end of the car, which needs a fine grid;
 # nominal speeds follow the reference's sampling times (0.6 s and 0.9 s per 0.3 m of path, main.jl:46-50,66 and the scenario tables)
 SCENARIO_OPTS = {"backwards": (dict(), 0.5),

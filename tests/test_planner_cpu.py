@@ -68,3 +68,25 @@ def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
     for i in range(4):
         r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], 40, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
         assert r["exitflag"] == 1 and r["slack"].sum() < 1e-3
+
+
+def test_velo_smooth_ramps_the_planner_speed_profile():
+    """veloSmooth.jl restated (planner.velo_smooth): jumps of the piecewise-constant +-v_nom profile become ramps of slope amax; the middle of
+    a long constant segment is untouched; signs are kept; the profile starts from rest and ends at rest"""
+    from obca_amd.planner import velo_smooth
+    vn, amax, Ts = 0.5, 0.3, 0.12
+    acc = int(round(vn / amax / Ts))
+    v = np.r_[np.full(40, vn), np.full(35, -vn), np.full(30, vn), 0.0]
+    vs, a = velo_smooth(v, amax, Ts)
+    assert vs.shape == v.shape and a.shape == (len(v) - 1,)
+    assert np.abs(a).max() <= amax * 1.02 and np.allclose(a, np.diff(vs) / Ts)
+    assert vs[0] == 0.0 and vs[-1] == 0.0
+    assert np.all(vs[:40] >= 0) and np.all(vs[40:75] <= 0) and np.all(vs[75:] >= 0)          # never against the planner's direction
+    assert np.all(np.abs(vs) <= vn + 1e-12)
+    assert np.allclose(vs[acc:40 - acc], vn) and np.allclose(vs[40 + acc:75 - acc], -vn)      # plateaus between the ramps
+    assert np.allclose(vs[:acc + 1], np.linspace(0, vn, acc + 1))                              # start ramp
+    k = int(np.argmin(np.abs(vs[30:50]))) + 30
+    assert abs(k - 40) <= 1                                                                    # the reversal ramp is centred on the switch
+    # a profile that only drives backwards (the reverse-parking scenario)
+    vs2, a2 = velo_smooth(np.r_[np.full(50, -vn), 0.0], amax, Ts)
+    assert vs2[0] == 0.0 and vs2[-1] == 0.0 and np.all(vs2 <= 0) and np.abs(a2).max() <= amax * 1.02
