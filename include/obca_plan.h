@@ -16,12 +16,19 @@ extern "C" {
  * XYbounds = [xmin, xmax, ymin, ymax] of the rear-axle position.
  * opts (NULL = defaults): {xy resolution 0.25, yaw resolution [deg] 7.5, primitive length 0.6, max steer 0.6, steer samples per side 2,
  *   collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance [deg] 8, reverse cost 1.5, switch cost 2.0, steer cost 0.3,
- *   max expansions 400000}.
+ *   max expansions 400000, analytic expansion (1: try the shortest Reeds-Shepp curve to the goal from expanded nodes, as the reference does) 1}.
  * Output: path[3k..3k+2] = x, y, yaw of node k (0.2 m apart), dir[k] = +1 / -1 (motion that led to the node), at most cap nodes.
  * Returns the number of nodes (>= 2); 0 = no path; -1 = bad arguments / cap too small; -2 = start or goal pose collides. */
 int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
                            const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
                            int *expansions /* may be NULL */);
+
+/* Shortest Reeds-Shepp path (forward and reverse arcs of radius R and straight lines; stands where hybrid_a_star.jl:262-300 calls
+ * reeds_shepp.calc_shortest_path, reeds_shepp.jl) from start to goal (x, y, yaw), sampled every `step` metres: path[3k..3k+2] = pose k,
+ * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5 doubles, may be NULL) their
+ * signed lengths in metres, total (may be NULL) the path length.  Returns the number of samples, -1 on bad arguments / cap too small. */
+int obca_plan_reeds_shepp(const double start[3], const double goal[3], double R, double step, double *path, int *dir, int cap, char *word,
+                          double *seglen, double *total);
 
 /* 1 if the car rectangle at (x, y, yaw), inflated by margin, overlaps an obstacle or leaves XYbounds (the planner's own test). */
 int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, const double *A, const double *b, const double ego[4],

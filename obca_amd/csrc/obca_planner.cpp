@@ -81,6 +81,109 @@ static inline double wrap(double a) { while (a > M_PI) a -= 2 * M_PI; while (a <
 
 }  // namespace
 
+// ---------------------------------------------------------------- Reeds-Shepp curves (the planner's analytic expansion)
+// Shortest path of a car that drives forwards and backwards with a bounded turning radius (Reeds & Shepp 1990), in the normalised problem
+// (unit radius, start at the origin with heading 0): the 48 candidate words are generated from the closed-form families CSC, CCC, CCCC, CCSC,
+// CCSCC and the time-flip / reflection / backwards symmetries, the shortest is kept.  Stands where hybrid_a_star.jl:262-300 calls
+// reeds_shepp.calc_shortest_path (reeds_shepp.jl).  A path is at most five segments: type 'L' / 'R' (arc, signed angle) or 'S' (signed length).
+namespace rs {
+struct Path { char type[5]; double len[5]; int n; double total; };
+static const double PI = M_PI, ZERO = 1e-12;
+static inline double mod2pi(double x) { double v = std::fmod(x, 2 * PI); if (v < -PI) v += 2 * PI; else if (v > PI) v -= 2 * PI; return v; }
+static inline void polar(double x, double y, double &r, double &th) { r = std::hypot(x, y); th = std::atan2(y, x); }
+static inline void tau_omega(double u, double v, double xi, double eta, double phi, double &tau, double &omega) {
+    const double delta = mod2pi(u - v), A = std::sin(u) - std::sin(delta), B = std::cos(u) - std::cos(delta) - 1.0;
+    const double t1 = std::atan2(eta * A - xi * B, xi * A + eta * B), t2 = 2.0 * (std::cos(delta) - std::cos(v) - std::cos(u)) + 3.0;
+    tau = t2 < 0 ? mod2pi(t1 + PI) : mod2pi(t1);
+    omega = mod2pi(tau - u + v - phi);
+}
+static bool LpSpLp(double x, double y, double phi, double &t, double &u, double &v) {
+    polar(x - std::sin(phi), y - 1.0 + std::cos(phi), u, t);
+    if (t >= -ZERO) { v = mod2pi(phi - t); if (v >= -ZERO) return true; }
+    return false;
+}
+static bool LpSpRp(double x, double y, double phi, double &t, double &u, double &v) {
+    double t1, u1; polar(x + std::sin(phi), y - 1.0 - std::cos(phi), u1, t1);
+    u1 *= u1;
+    if (u1 >= 4.0) { u = std::sqrt(u1 - 4.0); const double th = std::atan2(2.0, u); t = mod2pi(t1 + th); v = mod2pi(t - phi); return t >= -ZERO && v >= -ZERO; }
+    return false;
+}
+static bool LpRmL(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x - std::sin(phi), eta = y - 1.0 + std::cos(phi); double u1, th; polar(xi, eta, u1, th);
+    if (u1 <= 4.0) { u = -2.0 * std::asin(0.25 * u1); t = mod2pi(th + 0.5 * u + PI); v = mod2pi(phi - t + u); return t >= -ZERO && u <= ZERO; }
+    return false;
+}
+static bool LpRupLumRm(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi), rho = 0.25 * (2.0 + std::hypot(xi, eta));
+    if (rho <= 1.0) { u = std::acos(rho); tau_omega(u, -u, xi, eta, phi, t, v); return t >= -ZERO && v <= ZERO; }
+    return false;
+}
+static bool LpRumLumRp(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi), rho = (20.0 - xi * xi - eta * eta) / 16.0;
+    if (rho >= 0 && rho <= 1) { u = -std::acos(rho); if (u >= -0.5 * PI) { tau_omega(u, u, xi, eta, phi, t, v); return t >= -ZERO && v >= -ZERO; } }
+    return false;
+}
+static bool LpRmSmLm(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x - std::sin(phi), eta = y - 1.0 + std::cos(phi); double rho, th; polar(xi, eta, rho, th);
+    if (rho >= 2.0) { const double r = std::sqrt(rho * rho - 4.0); u = 2.0 - r; t = mod2pi(th + std::atan2(r, -2.0)); v = mod2pi(phi - 0.5 * PI - t); return t >= -ZERO && u <= ZERO && v <= ZERO; }
+    return false;
+}
+static bool LpRmSmRm(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi); double rho, th; polar(-eta, xi, rho, th);
+    if (rho >= 2.0) { t = th; u = 2.0 - rho; v = mod2pi(t + 0.5 * PI - phi); return t >= -ZERO && u <= ZERO && v <= ZERO; }
+    return false;
+}
+static bool LpRmSLmRp(double x, double y, double phi, double &t, double &u, double &v) {
+    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi); double rho, th; polar(xi, eta, rho, th);
+    if (rho >= 2.0) {
+        u = 4.0 - std::sqrt(rho * rho - 4.0);
+        if (u <= ZERO) { t = mod2pi(std::atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta)); v = mod2pi(t - phi); return t >= -ZERO && v >= -ZERO; }
+    }
+    return false;
+}
+static void offer(Path &best, const char *ty, int n, const double *len) {
+    double tot = 0; for (int i = 0; i < n; i++) tot += std::fabs(len[i]);
+    if (tot < best.total) { best.n = n; best.total = tot; for (int i = 0; i < n; i++) { best.type[i] = ty[i]; best.len[i] = len[i]; } }
+}
+// every family is tried on (x, y, phi), its time flip (-x, y, -phi: all lengths negated), its reflection (x, -y, -phi: L <-> R) and both
+template <class F> static void four(Path &best, F f, double x, double y, double phi, const char *ty, const char *tyr, int n,
+                                    void (*fill)(double, double, double, double *)) {
+    double t, u, v, len[5];
+    if (f(x, y, phi, t, u, v)) { fill(t, u, v, len); offer(best, ty, n, len); }
+    if (f(-x, y, -phi, t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, ty, n, len); }
+    if (f(x, -y, -phi, t, u, v)) { fill(t, u, v, len); offer(best, tyr, n, len); }
+    if (f(-x, -y, phi, t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, tyr, n, len); }
+}
+static void f_tuv(double t, double u, double v, double *l) { l[0] = t; l[1] = u; l[2] = v; }
+static void f_vut(double t, double u, double v, double *l) { l[0] = v; l[1] = u; l[2] = t; }
+static void f_tuuv_m(double t, double u, double v, double *l) { l[0] = t; l[1] = u; l[2] = -u; l[3] = v; }
+static void f_tuuv_p(double t, double u, double v, double *l) { l[0] = t; l[1] = u; l[2] = u; l[3] = v; }
+static void f_t_q_u_v(double t, double u, double v, double *l) { l[0] = t; l[1] = -0.5 * PI; l[2] = u; l[3] = v; }
+static void f_v_u_q_t(double t, double u, double v, double *l) { l[0] = v; l[1] = u; l[2] = -0.5 * PI; l[3] = t; }
+static void f_t_q_u_q_v(double t, double u, double v, double *l) { l[0] = t; l[1] = -0.5 * PI; l[2] = u; l[3] = -0.5 * PI; l[4] = v; }
+static Path shortest(double x, double y, double phi) {
+    Path best; best.n = 0; best.total = 1e300;
+    four(best, LpSpLp, x, y, phi, "LSL", "RSR", 3, f_tuv);
+    four(best, LpSpRp, x, y, phi, "LSR", "RSL", 3, f_tuv);
+    four(best, LpRmL, x, y, phi, "LRL", "RLR", 3, f_tuv);
+    const double xb = x * std::cos(phi) + y * std::sin(phi), yb = x * std::sin(phi) - y * std::cos(phi);       // the same word driven backwards
+    four(best, LpRmL, xb, yb, phi, "LRL", "RLR", 3, f_vut);
+    four(best, LpRupLumRm, x, y, phi, "LRLR", "RLRL", 4, f_tuuv_m);
+    four(best, LpRumLumRp, x, y, phi, "LRLR", "RLRL", 4, f_tuuv_p);
+    four(best, LpRmSmLm, x, y, phi, "LRSL", "RLSR", 4, f_t_q_u_v);
+    four(best, LpRmSmRm, x, y, phi, "LRSR", "RLSL", 4, f_t_q_u_v);
+    four(best, LpRmSmLm, xb, yb, phi, "LSRL", "RSLR", 4, f_v_u_q_t);
+    four(best, LpRmSmRm, xb, yb, phi, "RSRL", "LSLR", 4, f_v_u_q_t);
+    four(best, LpRmSLmRp, x, y, phi, "LRSLR", "RLSRL", 5, f_t_q_u_q_v);
+    return best;
+}
+// advance a pose along one segment by the signed amount s (unit radius)
+static inline void advance(char ty, double s, double &x, double &y, double &yaw) {
+    if (ty == 'S') { x += s * std::cos(yaw); y += s * std::sin(yaw); }
+    else { const double k = ty == 'L' ? 1.0 : -1.0, y1 = yaw + k * s; x += k * (std::sin(y1) - std::sin(yaw)); y += -k * (std::cos(y1) - std::cos(yaw)); yaw = y1; }
+}
+}  // namespace rs
+
 extern "C" {
 
 /*
@@ -88,7 +191,7 @@ extern "C" {
  * (M x 2), b).  ego = [front, left, rear, right] extents from the rear axle (main.jl:73), L = wheelbase, XYbounds = [xmin,xmax,ymin,ymax].
  * opts (may be NULL) = {xy resolution 0.25, yaw resolution deg 7.5, primitive length 0.6, max steer 0.6, #steer samples per side 2,
  *                       collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance deg 8, reverse cost 1.5, switch cost 2.0,
- *                       steer cost 0.3, max expansions 400000}.
+ *                       steer cost 0.3, max expansions 400000, analytic (Reeds-Shepp) expansion 1}.
  * Output: path[3 * k] = x, y, yaw of the k-th node and dir[k] = +1 / -1 (motion that led to the node), up to cap nodes.
  * Returns the number of nodes (>= 2), 0 if no path was found, -1 on bad arguments, -2 if the start or the goal collides.
  */
@@ -99,6 +202,8 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
     const double res = opts ? opts[0] : 0.25, yres = (opts ? opts[1] : 7.5) * M_PI / 180, step = opts ? opts[2] : 0.6, smax = opts ? opts[3] : 0.6;
     const int nst = opts ? (int)opts[4] : 2; const double margin = opts ? opts[5] : 0.1, gtol = opts ? opts[6] : 0.3, ytol = (opts ? opts[7] : 8.0) * M_PI / 180;
     const double crev = opts ? opts[8] : 1.5, csw = opts ? opts[9] : 2.0, cst = opts ? opts[10] : 0.3; const long maxexp = opts ? (long)opts[11] : 400000;
+    const double analytic = opts ? opts[12] : 1.0;       // analytic (Reeds-Shepp) expansion towards the goal, hybrid_a_star.jl:193-214: 0 = off,
+                                                         // else the fraction of the steering lock its arcs use (1 = the reference's full lock)
     World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
     for (int j = 0; j < nOb; j++) { if (vOb[j] < 1) return -1; w.off[j + 1] = w.off[j] + vOb[j]; }
     w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
@@ -148,12 +253,35 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
     open.push({heur(start[0], start[1], start[2]), 0}); best[key(start[0], start[1], start[2])] = 0.0;
     long nexp = 0; int found = -1;
     const int sub = std::max(1, (int)std::ceil(step / 0.2));
+    const double Rmin = L / std::tan(smax * (analytic > 0 ? std::min(1.0, analytic) : 1.0));
+    std::vector<double> tail; std::vector<int> taild;     // collision-free Reeds-Shepp connection of node `found` to the exact goal pose
     while (!open.empty() && nexp < maxexp) {
         const QE e = open.top(); open.pop();
         const Node cur = nodes[e.second];
         { auto it = best.find(key(cur.x, cur.y, cur.yaw)); if (it != best.end() && it->second < cur.g - 1e-9) continue; }
         if (std::hypot(cur.x - goal[0], cur.y - goal[1]) <= gtol && std::fabs(wrap(cur.yaw - goal[2])) <= ytol) { found = e.second; break; }
         nexp++;
+        if (analytic > 0 && (std::hypot(cur.x - goal[0], cur.y - goal[1]) < 6.0 * Rmin || nexp % 16 == 0)) {
+            // shortest Reeds-Shepp curve from this node to the goal: if the car can follow it without touching anything, the search is over
+            const double dx = goal[0] - cur.x, dy = goal[1] - cur.y, c = std::cos(cur.yaw), s_ = std::sin(cur.yaw);
+            const rs::Path p = rs::shortest((c * dx + s_ * dy) / Rmin, (-s_ * dx + c * dy) / Rmin, wrap(goal[2] - cur.yaw));
+            if (p.n > 0) {
+                tail.clear(); taild.clear();
+                double x = 0, y = 0, yaw = 0; bool ok = true;
+                for (int i = 0; i < p.n && ok; i++) {
+                    const double L_ = std::fabs(p.len[i]); if (L_ < 1e-12) continue;
+                    const int d = p.len[i] >= 0 ? 1 : -1, m = std::max(1, (int)std::ceil(L_ * Rmin / 0.2));
+                    for (int q = 0; q < m && ok; q++) {
+                        rs::advance(p.type[i], p.len[i] / m, x, y, yaw);
+                        const double wx = cur.x + Rmin * (c * x - s_ * y), wy = cur.y + Rmin * (s_ * x + c * y), wyaw = wrap(cur.yaw + yaw);
+                        ok = !collides(w, wx, wy, wyaw);
+                        tail.insert(tail.end(), {wx, wy, wyaw}); taild.push_back(d);
+                    }
+                }
+                if (ok) { found = e.second; break; }
+                tail.clear(); taild.clear();
+            }
+        }
         for (int d = 1; d >= -1; d -= 2)
             for (int si = -nst; si <= nst; si++) {
                 const double steer = smax * si / nst, kap = std::tan(steer) / L;
@@ -193,9 +321,39 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
             px.insert(px.end(), {x, y, yaw}); pd.push_back(n.dir);
         }
     }
+    px.insert(px.end(), tail.begin(), tail.end()); pd.insert(pd.end(), taild.begin(), taild.end());
+    if (chain.size() == 1 && !taild.empty()) pd[0] = taild[0];
     const int cnt = (int)pd.size();
     if (cnt > cap) return -1;
     std::memcpy(path, px.data(), sizeof(double) * 3 * cnt); std::memcpy(dir, pd.data(), sizeof(int) * cnt);
+    return cnt;
+}
+
+/* Shortest Reeds-Shepp path from start to goal (x, y, yaw) for turning radius R, sampled every `step` metres: path[3k..] = pose k,
+ * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5, may be NULL) their signed
+ * lengths in metres.  Returns the number of samples (start and goal included), -1 on bad arguments / cap too small. */
+int obca_plan_reeds_shepp(const double start[3], const double goal[3], double R, double step, double *path, int *dir, int cap, char *word,
+                          double *seglen, double *total) {
+    if (!start || !goal || !(R > 0) || !(step > 0) || !path || !dir || cap < 2) return -1;
+    const double dx = goal[0] - start[0], dy = goal[1] - start[1], c = std::cos(start[2]), s_ = std::sin(start[2]);
+    const rs::Path p = rs::shortest((c * dx + s_ * dy) / R, (-s_ * dx + c * dy) / R, wrap(goal[2] - start[2]));
+    if (p.n == 0) return -1;
+    if (word) { for (int i = 0; i < p.n; i++) word[i] = p.type[i]; word[p.n] = 0; }
+    if (seglen) for (int i = 0; i < 5; i++) seglen[i] = i < p.n ? p.len[i] * R : 0.0;
+    if (total) *total = p.total * R;
+    int cnt = 0;
+    double x = 0, y = 0, yaw = 0;                                    // normalised frame
+    auto emit = [&](int d) -> bool {
+        if (cnt >= cap) return false;
+        path[3 * cnt] = start[0] + R * (c * x - s_ * y); path[3 * cnt + 1] = start[1] + R * (s_ * x + c * y); path[3 * cnt + 2] = wrap(start[2] + yaw);
+        dir[cnt++] = d; return true;
+    };
+    if (!emit(p.len[0] >= 0 ? 1 : -1)) return -1;
+    for (int i = 0; i < p.n; i++) {
+        const double L_ = std::fabs(p.len[i]); if (L_ < 1e-12) continue;
+        const int d = p.len[i] >= 0 ? 1 : -1, m = std::max(1, (int)std::ceil(L_ * R / step));
+        for (int q = 0; q < m; q++) { rs::advance(p.type[i], p.len[i] / m, x, y, yaw); if (!emit(d)) return -1; }
+    }
     return cnt;
 }
 

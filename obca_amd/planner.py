@@ -32,7 +32,10 @@ def _load():
 
 
 DEFAULT_OPTS = dict(xy_res=0.25, yaw_res_deg=7.5, step=0.6, max_steer=0.6, steer_samples=2, margin=0.1, goal_xy_tol=0.3,
-                    goal_yaw_tol_deg=8.0, reverse_cost=1.5, switch_cost=2.0, steer_cost=0.3, max_expansions=400000)
+                    goal_yaw_tol_deg=8.0, reverse_cost=1.5, switch_cost=2.0, steer_cost=0.3, max_expansions=400000, analytic=0.85)
+# analytic: Reeds-Shepp expansion towards the goal (0 = off), the value is the fraction of the steering lock its arcs use.  The reference uses
+# the full lock (1.0); a warm start that rides the steering bound costs the interior point iterations (config 3, 96 instances on the oracle:
+# mean 43.4 / worst 400 iterations at 1.0, 37.4 / 71 at 0.85, 40.6 / 90 without the expansion), hence 0.85.
 
 
 def hybrid_astar(start, goal, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.XYBOUNDS, **kw):
@@ -51,6 +54,18 @@ def hybrid_astar(start, goal, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.
     if n == 0:
         return None
     return path[:n].copy(), dr[:n].copy(), nexp.value
+
+
+def reeds_shepp(start, goal, R, step=0.2):
+    """shortest Reeds-Shepp path between two poses (x, y, yaw) for turning radius R: returns (path (K,3), dir (K,), word, segment lengths, total)"""
+    s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()
+    cap = 20000; path = np.zeros((cap, 3)); dr = np.zeros(cap, np.int32); word = C.create_string_buffer(8); seg = np.zeros(5); tot = C.c_double(0)
+    n = _load().obca_plan_reeds_shepp(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_double(R), C.c_double(step), path.ctypes.data_as(_D),
+                                      dr.ctypes.data_as(_I), C.c_int(cap), word, seg.ctypes.data_as(_D), C.byref(tot))
+    if n < 0:
+        raise ValueError("bad arguments")
+    w = word.value.decode()
+    return path[:n].copy(), dr[:n].copy(), w, seg[:len(w)].copy(), tot.value
 
 
 def collides(pose, vOb, A, b, ego=S.EGO, XYbounds=S.XYBOUNDS, margin=0.0):

@@ -52,7 +52,7 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_reeds_shepp"] and all(hasattr(lib, s) for s in syms)
 
 
 def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
@@ -90,3 +90,45 @@ def test_velo_smooth_ramps_the_planner_speed_profile():
     # a profile that only drives backwards (the reverse-parking scenario)
     vs2, a2 = velo_smooth(np.r_[np.full(50, -vn), 0.0], amax, Ts)
     assert vs2[0] == 0.0 and vs2[-1] == 0.0 and np.all(vs2 <= 0) and np.abs(a2).max() <= amax * 1.02
+
+
+def test_reeds_shepp_paths_reach_the_goal_and_respect_the_symmetries():
+    """obca_plan_reeds_shepp (the planner's analytic expansion, reeds_shepp.jl in the reference): every path ends exactly on the goal pose, never
+    turns tighter than R, is no shorter than the straight line, and its length is invariant under the time-flip and reflection symmetries of
+    the problem (a missing family would break one of them); known closed-form cases"""
+    rng = np.random.default_rng(11); words = set()
+    for t in range(1500):
+        R = rng.uniform(0.5, 5.0)
+        s = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)])
+        g = np.array([s[0] + rng.uniform(-12, 12), s[1] + rng.uniform(-12, 12), rng.uniform(-np.pi, np.pi)])
+        if t % 4 == 0: g[:2] = s[:2] + rng.uniform(-1, 1, 2) * R                 # near goals: the CCC / CCCC words
+        path, dr, word, seg, tot = PL.reeds_shepp(s, g, R, step=0.05)
+        words.add(word)
+        assert np.hypot(*(path[-1, :2] - g[:2])) < 1e-9 and abs((path[-1, 2] - g[2] + np.pi) % (2 * np.pi) - np.pi) < 1e-9
+        assert np.allclose(path[0], [s[0], s[1], (s[2] + np.pi) % (2 * np.pi) - np.pi]) and abs(np.abs(seg).sum() - tot) < 1e-9
+        assert tot >= np.hypot(*(g[:2] - s[:2])) - 1e-9
+        d = np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1])); dyaw = np.abs((np.diff(path[:, 2]) + np.pi) % (2 * np.pi) - np.pi)
+        assert np.all(dyaw <= d / R * (1 + 1e-3) + 1e-9) and abs(d.sum() - tot) < 5e-3 * max(1.0, tot)      # curvature <= 1/R, samples follow the path
+    assert len(words) >= 16                                                       # all families of words occur
+    for t in range(300):                                                          # symmetries, normalised problem
+        x, y = rng.uniform(-4, 4, 2) if t % 2 else rng.uniform(-1.5, 1.5, 2); phi = rng.uniform(-np.pi, np.pi)
+        L0 = PL.reeds_shepp([0, 0, 0], [x, y, phi], 1.0)[4]
+        for q in ([x, -y, -phi], [-x, y, -phi], [-x, -y, phi]):
+            assert abs(PL.reeds_shepp([0, 0, 0], q, 1.0)[4] - L0) < 1e-9
+    assert abs(PL.reeds_shepp([0, 0, 0], [3, 0, 0], 1.0)[4] - 3.0) < 1e-12 and abs(PL.reeds_shepp([0, 0, 0], [-3, 0, 0], 1.0)[4] - 3.0) < 1e-12
+    assert abs(PL.reeds_shepp([0, 0, 0], [1, 1, np.pi / 2], 1.0)[4] - np.pi / 2) < 1e-12       # a quarter turn to the left
+    assert PL.reeds_shepp([0, 0, 0], [0, 0.5, 0], 1.0)[4] < 2.5                                 # a sideways shift needs cusps, not a full circle
+
+
+def test_hybrid_astar_finishes_on_the_exact_goal_with_the_analytic_expansion(backwards):
+    """with the Reeds-Shepp expansion the planner's path ends ON the goal pose (without it: within the goal tolerance), is collision-free
+    pose by pose, and needs fewer expansions"""
+    A, b, v = backwards["A"], backwards["b"], backwards["vOb"]
+    x0 = np.array([-6.0, 9.5, 0.0]); xF = S.BACKWARDS["xF"][:3]
+    p1, d1, n1 = PL.hybrid_astar(x0, xF, v, A, b)
+    p0, d0, n0 = PL.hybrid_astar(x0, xF, v, A, b, analytic=0)
+    assert np.hypot(*(p1[-1, :2] - xF[:2])) < 1e-9 and abs((p1[-1, 2] - xF[2] + np.pi) % (2 * np.pi) - np.pi) < 1e-9
+    assert np.hypot(*(p0[-1, :2] - xF[:2])) <= 0.3 + 1e-9 and n1 <= n0
+    for q in p1:
+        assert not PL.collides(q, v, A, b, margin=0.1 - 1e-9)
+    assert np.all(np.hypot(np.diff(p1[:, 0]), np.diff(p1[:, 1])) <= 0.2 + 1e-6)
