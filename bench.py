@@ -211,7 +211,7 @@ def main():
                      "schedule: slice + hardest-first completion)%s; traffic = PMC bytes of one step from profiles/r01_pmc_*.csv (committed, not live)"
                      % (B_PASS, F_PASS, int(passes), how, "" if nS == 1 else ", overlapped with the other steps in flight"))
         line = {
-            "metric": "OBCA NLP solves/sec (N=80, 3 obs, batch)", "value": round(conv_all * a.steps / dt, 2), "unit": "solves/s",
+            "metric": "OBCA NLP solves/sec (N=80, 3 obs, batch) at 1/2/4/8 MI355X vs IPOPT-CPU", "value": round(conv_all * a.steps / dt, 2), "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: reverse-parking ParkingSignedDist NLP, N=80, 3 obstacles (5 half-space rows), "
