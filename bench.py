@@ -173,11 +173,16 @@ def main():
             bq.solve(sync=False)            # queued behind the previous step of the same stream; overlaps the other streams
     for bq in batches:
         bq.sync()
-    if nS > 1:
-        for bq in batches:
-            m = bq.kernel_ms(); ipm_ms.append(m[0]); dws_ms.append(m[1])     # last launch of every stream (overlapped durations)
     fence()
     dt = time.perf_counter() - t0
+    if nS > 1:
+        used = sorted({k % nS for k in range(a.steps)} | {w % nS for w in range(a.warmup)})
+        for si in used:
+            m = batches[si].kernel_ms(); ipm_ms.append(m[0]); dws_ms.append(m[1])     # last launch of every stream that ran (overlapped durations)
+    if a.steps + a.warmup == 0 or (a.steps == 0):
+        raise SystemExit("bench.py: --steps must be >= 1")
+    if not any(k % nS == 0 for k in range(a.steps)) and not any(w % nS == 0 for w in range(a.warmup)):
+        batch.solve()                                   # (never with steps >= 1: step 0 runs on copy 0)
     out = batch.download()
     # a solve counts only if exitflag == 1 AND the returned trajectory passes the a-posteriori checker: every constraint class of
     # the NLP with its slack at IPOPT's constr_viol_tol (obca_amd/validate.py, pure numpy, outside the timed region)

@@ -232,7 +232,9 @@ int obca_create(obca_ctx **out, int device) {
     }
     obca_ctx *c = new obca_ctx();
     c->device = device; c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return -2; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return -2; }
+    // (non-blocking: the context's stream never synchronises implicitly with the legacy default stream, which other libraries in the process may use;
+    //  several contexts are meant to run side by side, see INTEGRATION.md "several batches in flight")
     *out = c;
     return 0;
 }
@@ -264,6 +266,7 @@ int obca_batch_destroy(obca_batch *bt) {
 }
 int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
+    HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream));
     HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -557,6 +560,7 @@ int obca_quad_batch_destroy(obca_quad_batch *bt) {
 }
 int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
+    HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream));
     HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
