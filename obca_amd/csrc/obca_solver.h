@@ -591,7 +591,9 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
     const double t0 = fma(a1, b1, a0 * b0), t1 = fma(a3, b3, a2 * b2), t2 = fma(a5, b5, fma(a4, b4, init));
     return (t0 + t1) + t2;
 }
+#ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
+#endif
 // One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), one small
 // item per lane, LDS-only workgroup barriers in between.
 // Every lane runs the SAME straight-line code in every phase: what differs between the item kinds of a phase (a T entry or one of the
