@@ -71,7 +71,7 @@ __device__ inline int obca_slice_class(const double *st) {
     const double pinf = st[SL_PINF];
     int c = 8 * (nreg < 7 ? nreg : 7);
     // within the same retry count: the constraint violation that is left, one class per decade from 1e-6 up
-    int e = pinf > 0 ? (int)floor(log10(pinf)) + 7 : 0;
+    int e = (pinf > 1e-30 && pinf < 1e30) ? (int)floor(log10(pinf)) + 7 : (pinf >= 1e30 ? 7 : 0);
     e = e < 0 ? 0 : (e > 7 ? 7 : e);
     return c + e;
 }
