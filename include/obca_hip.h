@@ -43,6 +43,16 @@ typedef struct obca_opts {
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);
+/* A context over several GPUs of the node ("the context owns devices and streams"): devices = NULL or ndev <= 0 takes every
+ * visible device.  The host-pointer entry points below cut their batch into chunks and hand them to the devices through a work queue
+ * (solve times are heavy-tailed: a static slice per device would wait for the unluckiest one); every device runs OBCA_SLOTS (default 4)
+ * chunks at a time on streams of their own, so that the PCIe transfers and the host-side packing of one chunk overlap the solves of the
+ * others.  Instances are independent: no collective touches the data path.  Results do not depend on the device count, the chunk size
+ * (OBCA_CHUNK, default = twice the instances resident on one GPU) or the slot count: every instance is solved by one workgroup either way.
+ * The device-resident obca_batch_* / obca_quad_batch_* calls of a multi-device context run on its first device. */
+int obca_create_multi(obca_ctx **out, const int *devices, int ndev);
+int obca_device_count(const obca_ctx *ctx);          /* devices this context drives */
+int obca_visible_device_count(void);                 /* HIP devices visible to the process */
 int obca_destroy(obca_ctx *ctx);
 const char *obca_last_error(const obca_ctx *ctx);   /* ctx may be NULL: error of the last failed obca_create */
 int obca_default_opts(obca_opts *o);

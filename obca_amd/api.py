@@ -69,7 +69,7 @@ def _load():
     return lib
 
 
-EXPORTS = ["obca_create", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
+EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visible_device_count", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
@@ -105,13 +105,28 @@ def _i(a):
 
 
 class Context:
-    def __init__(self, device=0):
+    """One device (`device=k`), an explicit list (`devices=[...]`) or every visible device (`devices="all"`): the host-pointer entry points
+    of a multi-device context shard their batch over the devices through a work queue (include/obca_hip.h, obca_create_multi)."""
+
+    def __init__(self, device=0, devices=None):
         lib = _load()
         self._h = C.c_void_p()
-        rc = lib.obca_create(C.byref(self._h), C.c_int(int(device)))
+        if devices is None:
+            rc = lib.obca_create(C.byref(self._h), C.c_int(int(device)))
+            self.devices = [int(device)]
+        else:
+            lst = [] if isinstance(devices, str) else [int(d) for d in devices]
+            arr = (C.c_int * max(1, len(lst)))(*lst)
+            rc = lib.obca_create_multi(C.byref(self._h), arr if lst else None, C.c_int(len(lst)))
+            self.devices = lst
         if rc != 0:
             raise ObcaError("obca_create failed: " + (lib.obca_last_error(None) or b"").decode())
-        self.device = int(device)
+        if devices is not None:
+            self.devices = list(range(lib.obca_device_count(self._h))) if not self.devices else self.devices
+        self.device = self.devices[0]
+
+    def device_count(self):
+        return int(_load().obca_device_count(self._h))
 
     def _check(self, rc, what):
         if rc != 0:
@@ -138,9 +153,13 @@ _default_ctx = {}
 
 
 def _ctx(device=0):
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    """cached context of one device index, of a tuple of indices, or of "all" visible devices"""
+    if isinstance(device, Context):
+        return device
+    key = device if isinstance(device, (int, str)) else tuple(device)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(device) if isinstance(key, int) else Context(devices=device)
+    return _default_ctx[key]
 
 
 def _norm_obstacles(B, vOb, A, b):
@@ -236,15 +255,7 @@ class Batch:
                                          ef.ctypes.data_as(_I), lp.ctypes.data_as(_D), npp.ctypes.data_as(_D), sl.ctypes.data_as(_D),
                                          info.ctypes.data_as(_D))
         self.ctx._check(rc, "obca_batch_download")
-        lps, nps, sls = [], [], []          # per instance, reference shapes (M,N+1) / (4nOb,N+1) / (nOb,N+1)
-        ro = oo = 0
-        for m, n in zip(self.Ms, self.nObs):
-            lps.append(lp[ro * (N + 1):(ro + m) * (N + 1)].reshape(N + 1, m).T.copy())
-            nps.append(npp[4 * oo * (N + 1):4 * (oo + n) * (N + 1)].reshape(N + 1, 4 * n).T.copy())
-            sls.append(sl[oo * (N + 1):(oo + n) * (N + 1)].reshape(N + 1, n).T.copy())
-            ro += m; oo += n
-        return dict(xp=np.transpose(xp, (0, 2, 1)).copy(), up=np.transpose(up, (0, 2, 1)).copy(), timeScale=ts, exitflag=ef,
-                    lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
+        return _unpack_parking(B, N, self.nObs, self.Ms, xp, up, ts, ef, lp, npp, sl, info)
 
     def close(self):
         if self._h:
@@ -260,20 +271,60 @@ class Batch:
 
 def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
                               opts=None, device=0, dist=False):
-    """Batched ParkingSignedDist: x0,xF (B,4); rx,ry,ryaw (B,N+1); xWS (B,N+1,4); uWS (B,>=N,2); Ts scalar or (B,).
-    Obstacles: one shared set (vOb 1-D, A (M,2), b (M,)) or per-instance lists.  lWS/nWS=None runs DualMultWS on the GPU."""
-    B = np.reshape(x0, (-1, 4)).shape[0]
-    bt = Batch(_ctx(device), B, N)
-    try:
-        bt.upload(x0, xF, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS, nWS, dist)
-        t0 = time.perf_counter()
-        bt.solve(opts)
-        dt = time.perf_counter() - t0
-        out = bt.download()
-        out["time"] = dt
-        return out
-    finally:
-        bt.close()
+    """Batched ParkingSignedDist through the host-pointer entry point obca_parking_(signed_)dist_batch (what the Julia shim calls):
+    x0,xF (B,4); rx,ry,ryaw (B,N+1); xWS (B,N+1,4); uWS (B,>=N,2); Ts scalar or (B,).
+    Obstacles: one shared set (vOb 1-D, A (M,2), b (M,)) or per-instance lists.  lWS/nWS=None runs DualMultWS on the GPU.
+    `device`: an index, a list of indices or "all" (the batch is then sharded over the devices, obca_create_multi), or a Context."""
+    x0 = np.ascontiguousarray(np.reshape(x0, (-1, 4)), float); B = x0.shape[0]
+    ctx = _ctx(device)
+    nObs, vflat, Aflat, bflat = _norm_obstacles(B, vOb, A, b)
+    Ms = _row_counts(nObs, vflat)
+    Mt, nt = int(Ms.sum()), int(nObs.sum())
+    Tsv = np.ascontiguousarray(np.broadcast_to(np.asarray(Ts, float), (B,)))
+    if lWS is not None and not isinstance(lWS, np.ndarray):
+        lWS = np.concatenate([np.ravel(x) for x in lWS]); nWS = np.concatenate([np.ravel(x) for x in nWS])
+    keep = [_d(Tsv), _d(ego), _d(XYbounds), _d(x0), _d(np.reshape(xF, (B, 4))), _i(nObs), _i(vflat), _d(Aflat), _d(bflat),
+            _d(np.reshape(rx, (B, N + 1))), _d(np.reshape(ry, (B, N + 1))), _d(np.reshape(ryaw, (B, N + 1))),
+            _d(np.asarray(xWS, float).reshape(B, -1, 4)[:, :N + 1]), _d(np.asarray(uWS, float).reshape(B, -1, 2)[:, :N]), _d(lWS), _d(nWS)]
+    p = [k[1] for k in keep]
+    xp = np.empty((B, N + 1, 4)); up = np.empty((B, N, 2)); ts = np.empty((B, N + 1)); ef = np.zeros(B, np.int32)
+    lp = np.empty(Mt * (N + 1)); npp = np.empty(4 * nt * (N + 1)); sl = np.zeros(nt * (N + 1)); info = np.zeros((B, 8))
+    lib = _load()
+    t0 = time.perf_counter()
+    if dist:
+        rc = lib.obca_parking_dist_batch(ctx._h, C.c_int(B), C.c_int(int(N)), p[0], C.c_double(float(L)), p[1], p[2], C.c_int(int(fixTime)), p[3], p[4],
+                                         p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15], C.byref(opts) if opts is not None else None,
+                                         xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D), ef.ctypes.data_as(_I), lp.ctypes.data_as(_D),
+                                         npp.ctypes.data_as(_D), info.ctypes.data_as(_D))
+    else:
+        rc = lib.obca_parking_signed_dist_batch(ctx._h, C.c_int(B), C.c_int(int(N)), p[0], C.c_double(float(L)), p[1], p[2], C.c_int(int(fixTime)), p[3], p[4],
+                                                p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15],
+                                                C.byref(opts) if opts is not None else None, xp.ctypes.data_as(_D), up.ctypes.data_as(_D),
+                                                ts.ctypes.data_as(_D), ef.ctypes.data_as(_I), lp.ctypes.data_as(_D), npp.ctypes.data_as(_D),
+                                                sl.ctypes.data_as(_D), info.ctypes.data_as(_D))
+    dt = time.perf_counter() - t0
+    ctx._check(rc, "obca_parking_dist_batch" if dist else "obca_parking_signed_dist_batch")
+    out = _unpack_parking(B, N, nObs, Ms, xp, up, ts, ef, lp, npp, sl, info)
+    out["time"] = dt
+    return out
+
+
+def _unpack_parking(B, N, nObs, Ms, xp, up, ts, ef, lp, npp, sl, info):
+    """C-ABI output arrays -> the reference's shapes: xp (B,4,N+1), up (B,2,N), per-instance lp (M,N+1) / np (4nOb,N+1) / sl (nOb,N+1)"""
+    if len(set(Ms.tolist())) == 1 and len(set(nObs.tolist())) == 1:          # uniform obstacle sets: one reshape, views per instance
+        m, n = int(Ms[0]), int(nObs[0])
+        L3 = lp.reshape(B, N + 1, m).transpose(0, 2, 1); N3 = npp.reshape(B, N + 1, 4 * n).transpose(0, 2, 1); S3 = sl.reshape(B, N + 1, n).transpose(0, 2, 1)
+        lps, nps, sls = list(L3), list(N3), list(S3)
+    else:
+        lps, nps, sls = [], [], []
+        ro = oo = 0
+        for m, n in zip(Ms, nObs):
+            lps.append(lp[ro * (N + 1):(ro + m) * (N + 1)].reshape(N + 1, m).T)
+            nps.append(npp[4 * oo * (N + 1):4 * (oo + n) * (N + 1)].reshape(N + 1, 4 * n).T)
+            sls.append(sl[oo * (N + 1):(oo + n) * (N + 1)].reshape(N + 1, n).T)
+            ro += m; oo += n
+    return dict(xp=np.transpose(xp, (0, 2, 1)), up=np.transpose(up, (0, 2, 1)), timeScale=ts, exitflag=ef,
+                lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
 
 
 def ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, opts=None, device=0):
@@ -401,19 +452,32 @@ class QuadBatch:
 
 
 def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, opts=None, device=0, dist=False):
-    """Batched QuadcopterSignedDist: x0,xF (B,12); ob (5,6) shared or (B,5,6); xWS (B,N+1,12); Ts, timeWS scalar or (B,)."""
-    B = np.reshape(x0, (-1, 12)).shape[0]
-    bt = QuadBatch(_ctx(device), B, N)
-    try:
-        bt.upload(x0, xF, Ts, R, ob, xWS, timeWS, dual_ws, dist)
-        t0 = time.perf_counter()
-        bt.solve(opts)
-        dt = time.perf_counter() - t0
-        out = bt.download()
-        out["time"] = dt
-        return out
-    finally:
-        bt.close()
+    """Batched QuadcopterSignedDist / QuadcopterDist through the host-pointer entry points (what the Julia shim calls):
+    x0,xF (B,12); ob (5,6) shared or (B,5,6); xWS (B,N+1,12); Ts, timeWS scalar or (B,).  `device` as in parking_signed_dist_batch."""
+    x0 = np.ascontiguousarray(np.reshape(x0, (-1, 12)), float); B = x0.shape[0]
+    ctx = _ctx(device)
+    Tsv = np.broadcast_to(np.asarray(Ts, float), (B,)).copy(); tw = np.broadcast_to(np.asarray(timeWS, float), (B,)).copy()
+    obv = np.broadcast_to(np.asarray(ob, float).reshape(-1, 30) if np.size(ob) != 30 else np.asarray(ob, float).reshape(1, 30), (B, 30)).copy()
+    xw = np.ascontiguousarray(np.asarray(xWS, float)[:, :N + 1]); assert xw.shape == (B, N + 1, 12)
+    keep = [_d(Tsv), _d(x0), _d(np.reshape(xF, (B, 12))), _d(obv), _d(xw), _d(tw)]
+    p = [k[1] for k in keep]
+    xp = np.empty((B, N + 1, 12)); up = np.empty((B, N, 4)); ts = np.empty((B, N + 1)); ef = np.zeros(B, np.int32)
+    lp = np.empty((B, N + 1, 30)); sl = np.zeros((B, N + 1, 5)); info = np.zeros((B, 8))
+    lib = _load(); o = C.byref(opts) if opts is not None else None
+    t0 = time.perf_counter()
+    if dist:
+        rc = lib.obca_quadcopter_dist_batch(ctx._h, C.c_int(B), C.c_int(int(N)), p[0], C.c_double(float(R)), p[1], p[2], p[3], p[4], None, p[5],
+                                            C.c_int(int(bool(dual_ws))), o, xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D),
+                                            ef.ctypes.data_as(_I), lp.ctypes.data_as(_D), info.ctypes.data_as(_D))
+    else:
+        rc = lib.obca_quadcopter_signed_dist_batch(ctx._h, C.c_int(B), C.c_int(int(N)), p[0], C.c_double(float(R)), p[1], p[2], p[3], p[4], None, p[5],
+                                                   C.c_int(int(bool(dual_ws))), o, xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D),
+                                                   ef.ctypes.data_as(_I), lp.ctypes.data_as(_D), sl.ctypes.data_as(_D), info.ctypes.data_as(_D))
+    dt = time.perf_counter() - t0
+    ctx._check(rc, "obca_quadcopter_dist_batch" if dist else "obca_quadcopter_signed_dist_batch")
+    T = lambda a: np.transpose(a, (0, 2, 1))
+    return dict(xp=T(xp), up=T(up), timeScale=ts, exitflag=ef, lp=T(lp), slack=T(sl), info=info, iters=info[:, 1].astype(int),
+                obj=info[:, 2], status=info[:, 0].astype(int), time=dt)
 
 
 _QUAD_STATUS = {0: "Optimal", 1: "UserLimit", 2: "Error"}

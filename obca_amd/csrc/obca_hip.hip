@@ -15,6 +15,9 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <algorithm>
 #include "obca_solver.h"
 #include "obca_quad_solver.h"
 #include "../../include/obca_hip.h"
@@ -39,6 +42,7 @@ struct DevBufs {
 #ifndef OBCA_IPM_WAVES_PER_EU
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
+#define OBCA_RESIDENT_PER_CU (2 * OBCA_IPM_WAVES_PER_EU)   // instances (workgroups of two wavefronts) resident per CU
 __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
@@ -186,21 +190,60 @@ __global__ __launch_bounds__(OB_NT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_k
 #endif
 }
 
+// rows of a strided device array <-> a dense staging array (one contiguous PCIe transfer per direction instead of a 2-D copy):
+//   scatter: dst[i * ds + j] = j < W ? src[i * W + j] : 0   for j < zero_to   (upload: primal prefix of the iterate, rest of the row cleared)
+//   gather : dst[i * W + j] = src[i * ss + j]                                   (download: the output prefix of the iterate)
+__global__ __launch_bounds__(256) void obca_scatter_rows_kernel(double *dst, size_t ds, const double *src, size_t W, size_t zero_to) {
+    const size_t i = blockIdx.y;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < zero_to; j += (size_t)gridDim.x * blockDim.x)
+        dst[i * ds + j] = j < W ? src[i * W + j] : 0.0;
+}
+__global__ __launch_bounds__(256) void obca_gather_rows_kernel(double *dst, size_t W, const double *src, size_t ss) {
+    const size_t i = blockIdx.y;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < W; j += (size_t)gridDim.x * blockDim.x)
+        dst[i * W + j] = src[i * ss + j];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
-struct obca_ctx { int device; hipStream_t stream; std::string err; std::string name; int cus; };
+// A context drives one or several devices.  Every device has OBCA_SLOTS worker lanes ("slots": a HIP stream, a cached chunk-sized batch
+// with pinned staging buffers); the host-pointer entry points cut a call's batch into chunks and a host thread per slot pulls chunks from a
+// shared counter (work queue, SURVEY 8e: solve times are heavy-tailed, a static slice per device would wait for the unluckiest one):
+// pack into pinned memory -> H2D -> DualMultWS + interior point -> D2H of the outputs only -> unpack into the caller's arrays.  With several
+// slots per device the transfers and the host-side (un)packing of one chunk overlap the solves of the others, and the few hard instances
+// at the end of one chunk overlap the bulk of the next.  Instances are independent: no collective touches the data path.
+struct obca_batch;
+struct obca_quad_batch;
+struct Slot { int device; hipStream_t stream; obca_batch *pb; obca_quad_batch *qb; int cus; };
+struct obca_ctx {
+    int device; hipStream_t stream;         // primary device / stream (= slots[0]): the device-resident obca_batch_* API runs here
+    std::vector<int> devices; std::vector<Slot> slots;
+    std::string err; std::string name; int cus;
+};
 static std::string g_create_err;
 
 struct obca_batch {
-    obca_ctx *ctx; int B, N, nObMax, MMax, zlen, have_duals, uploaded, dist;
-    DevBufs d;
-    std::vector<int> nOb, M, obOff, rowOff;
-    std::vector<double> Ts; int fixTime;
+    obca_ctx *ctx; int device; hipStream_t stream; std::string err;
+    int B, cap, N, nObMax, MMax, zlen, have_duals, uploaded, dist;
+    DevBufs d; double *stage;                               // stage: dense device staging of the PCIe transfers
+    double *h_prob, *h_zin, *h_zout, *h_info; size_t hcap_prob, hcap_zin, hcap_zout, hcap_info, dcap_stage;   // pinned host staging
+    std::vector<int> nOb, M, obOff, rowOff;                 // per instance; offsets into the caller's packed obstacle arrays
+    int fixTime;
     hipEvent_t e0, e1, e2;
     long long bytes;
     int sliced;          // slice length (passes) of the last solve if it used the two-launch schedule, else 0
 };
 
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+#define HIPCHK(bt, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (bt)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+static inline int fin(obca_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
+
+static int pinned_reserve(std::string &err, double **p, size_t *cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*p) hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipHostMalloc((void **)p, need * sizeof(double), hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return -2; }
+    *cap = need;
+    return 0;
+}
 
 extern "C" {
 
@@ -219,55 +262,359 @@ int obca_default_opts(obca_opts *o) {
     return 0;
 }
 
-int obca_create(obca_ctx **out, int device) {
+int obca_visible_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+/* devices == NULL or ndev <= 0: every visible device */
+int obca_create_multi(obca_ctx **out, const int *devices, int ndev) {
     if (!out) return -1;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { g_create_err = "no HIP device available (libobca_hip has no CPU fallback)"; return -2; }
-    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return -1; }
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; return -2; }
-    if (std::string(pr.gcnArchName).find("gfx950") == std::string::npos) {
-        g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; return -2;
-    }
+    std::vector<int> devs;
+    if (!devices || ndev <= 0) { for (int i = 0; i < n; i++) devs.push_back(i); }
+    else devs.assign(devices, devices + ndev);
+    int nslot = 4;                                       // worker lanes per device (OBCA_SLOTS)
+    if (const char *ev = getenv("OBCA_SLOTS")) { nslot = atoi(ev); if (nslot < 1) nslot = 1; if (nslot > 8) nslot = 8; }
     obca_ctx *c = new obca_ctx();
-    c->device = device; c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return -2; }
-    // (non-blocking: the context's stream never synchronises implicitly with the legacy default stream, which other libraries in the process may use;
-    //  several contexts are meant to run side by side, see INTEGRATION.md "several batches in flight")
+    c->devices = devs;
+    std::vector<hipStream_t> made;
+    for (int s = 0; s < nslot; s++) for (size_t di = 0; di < devs.size(); di++) {       // slot order interleaves the devices
+        const int dv = devs[di];
+        if (dv < 0 || dv >= n) { g_create_err = "device index out of range"; delete c; return -1; }
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dv) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; delete c; return -2; }
+        if (std::string(pr.gcnArchName).find("gfx950") == std::string::npos) {
+            g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; delete c; return -2;
+        }
+        if (s == 0 && di == 0) { c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount; }
+        Slot sl; sl.device = dv; sl.pb = nullptr; sl.qb = nullptr; sl.cus = pr.multiProcessorCount;
+        // non-blocking: the streams never synchronise implicitly with the legacy default stream, which other libraries in the process may use
+        if (hipSetDevice(dv) != hipSuccess || hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
+            g_create_err = "hipStreamCreate failed"; for (auto &q : c->slots) { hipSetDevice(q.device); hipStreamDestroy(q.stream); } delete c; return -2;
+        }
+        c->slots.push_back(sl);
+    }
+    c->device = c->slots[0].device; c->stream = c->slots[0].stream;
+    hipSetDevice(c->device);
     *out = c;
     return 0;
 }
-int obca_destroy(obca_ctx *c) { if (!c) return -1; hipSetDevice(c->device); hipStreamDestroy(c->stream); delete c; return 0; }
+int obca_create(obca_ctx **out, int device) { return obca_create_multi(out, &device, 1); }
+int obca_device_count(const obca_ctx *c) { return c ? (int)c->devices.size() : -1; }
+int obca_batch_destroy(obca_batch *bt);
+int obca_quad_batch_destroy(obca_quad_batch *bt);
+int obca_destroy(obca_ctx *c) {
+    if (!c) return -1;
+    for (auto &s : c->slots) {
+        if (s.pb) obca_batch_destroy(s.pb);
+        if (s.qb) obca_quad_batch_destroy(s.qb);
+        hipSetDevice(s.device); hipStreamDestroy(s.stream);
+    }
+    delete c; return 0;
+}
 const char *obca_last_error(const obca_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 int obca_device_name(const obca_ctx *c, char *buf, int n) { if (!c || !buf || n <= 0) return -1; snprintf(buf, n, "%s", c->name.c_str()); return 0; }
 
-int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
-    if (!ctx || !out) return -1;
-    if (B < 1 || N < 0 || N > OBCA_NMAX) { ctx->err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
+}  // extern "C"
+
+static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B, int N, obca_batch **out, std::string &err) {
+    if (B < 1 || N < 0 || N > OBCA_NMAX) { err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
-    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0;
-    memset(&bt->d, 0, sizeof bt->d);
-    hipSetDevice(ctx->device);
-    HIPCHK(ctx, hipEventCreate(&bt->e0)); HIPCHK(ctx, hipEventCreate(&bt->e1)); HIPCHK(ctx, hipEventCreate(&bt->e2));
+    bt->ctx = ctx; bt->device = device; bt->stream = stream;
+    bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0; bt->zlen = 0; bt->fixTime = 0;
+    memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr; bt->dcap_stage = 0;
+    bt->h_prob = bt->h_zin = bt->h_zout = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_zin = bt->hcap_zout = bt->hcap_info = 0;
+    hipSetDevice(device);
+    if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess || hipEventCreate(&bt->e2) != hipSuccess) { err = "hipEventCreate failed"; delete bt; return -2; }
     *out = bt;
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
     if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
+    bt->dcap_stage = 0;
+}
+
+// everything a parking call hands over (host pointers of the whole call; a chunk is instances lo .. lo+n-1 of it)
+struct ParkIn {
+    const double *Ts; double L; const double *ego, *XYb; int fixTime;
+    const double *x0, *xF; const int *nOb, *vOb; const double *A, *b, *rx, *ry, *ryaw, *xWS, *uWS, *lWS, *nWS;
+    std::vector<int> obOff, rowOff;                    // running sums over the call's instances
+};
+struct ParkOut { double *xp, *up, *ts; int *exitflag; double *lp, *np, *slp, *info; double *lWS, *nWS, *dd; };
+
+static int park_prefix(std::string &err, int B, const int *nOb, const int *vOb, ParkIn &in) {
+    in.obOff.assign(B + 1, 0); in.rowOff.assign(B + 1, 0);
+    for (int i = 0; i < B; i++) {
+        const int n = nOb[i];
+        if (n < 1 || n > OBCA_NOBMAX) { err = "nOb out of range 1..OBCA_NOBMAX"; return -1; }
+        int m = 0;
+        for (int j = 0; j < n; j++) { const int v = vOb[in.obOff[i] + j]; if (v < 1 || v > OBCA_VMAX) { err = "vOb out of range 1..OBCA_VMAX"; return -1; } m += v; }
+        in.obOff[i + 1] = in.obOff[i] + n; in.rowOff[i + 1] = in.rowOff[i] + m;
+    }
+    return 0;
+}
+
+// instances lo .. lo+n-1 of the call become instances 0 .. n-1 of the batch (n <= capacity)
+static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
+    const int N = bt->N, N1 = N + 1;
+    if (n < 1 || n > bt->cap) { bt->err = "obca_batch_upload: more instances than the batch was created for"; return -1; }
+    bt->B = n;
+    bt->nOb.assign(n, 0); bt->M.assign(n, 0); bt->obOff.assign(n + 1, 0); bt->rowOff.assign(n + 1, 0);
+    int nObMax = 0, MMax = 0;
+    for (int i = 0; i < n; i++) {
+        const int g = lo + i;
+        bt->nOb[i] = in.obOff[g + 1] - in.obOff[g]; bt->M[i] = in.rowOff[g + 1] - in.rowOff[g];
+        bt->obOff[i] = in.obOff[g]; bt->rowOff[i] = in.rowOff[g];
+        nObMax = std::max(nObMax, bt->nOb[i]); MMax = std::max(MMax, bt->M[i]);
+    }
+    bt->obOff[n] = in.obOff[lo + n]; bt->rowOff[n] = in.rowOff[lo + n];
+    hipSetDevice(bt->device);
+    const size_t B = bt->cap;
+    if (!bt->uploaded || nObMax > bt->nObMax || MMax > bt->MMax) {       // (a cached batch keeps the largest shape it has seen)
+        free_dev(bt);
+        bt->nObMax = std::max(nObMax, bt->nObMax); bt->MMax = std::max(MMax, bt->MMax);
+        Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
+        bt->zlen = lmax.len;
+        DevBufs &d = bt->d;
+        d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
+        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_traj = (size_t)(N + 2) * 6;
+        size_t tot = 0;
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(bt, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
+        ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
+        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
+        ALLOC(d.info, B * 8); ALLOC(d.dws, B * N1 * bt->nObMax); ALLOC(d.prof, B * 16);
+        ALLOC(d.slice, B * SL_SIZE);
+        bt->dcap_stage = B * (size_t)lmax.nprimal;                       // nprimal >= the output prefix
+        ALLOC(bt->stage, bt->dcap_stage);
+        HIPCHK(bt, hipMalloc((void **)&d.order, (B + 1) * sizeof(int))); tot += (B + 1) * sizeof(int);
+#undef ALLOC
+        bt->bytes = (long long)tot;
+    }
+    const DevBufs &d = bt->d;
+    Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
+    const size_t W = (size_t)lmax.nprimal;                 // only the primal prefix (x,u,t,lam,mu,...) of the iterate travels over PCIe
+    if (pinned_reserve(bt->err, &bt->h_prob, &bt->hcap_prob, B * d.s_prob) || pinned_reserve(bt->err, &bt->h_zin, &bt->hcap_zin, B * W)) return -2;
+    const double *ego = in.ego, *XYb = in.XYb;
+    const double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];     /* ParkingSignedDist.jl:182-188 */
+    const bool duals = in.lWS && in.nWS;
+    for (int i = 0; i < n; i++) {
+        const int g = lo + i;
+        double *p = bt->h_prob + (size_t)i * d.s_prob;
+        memset(p, 0, sizeof(double) * OB_HDR);
+        const int no = bt->nOb[i], m = bt->M[i];
+        p[PH_TS] = in.Ts[g]; p[PH_L] = in.L; p[PH_DIST] = bt->dist ? 1.0 : 0.0;
+        p[PH_G] = L_ev / 2; p[PH_G + 1] = W_ev / 2; p[PH_G + 2] = L_ev / 2; p[PH_G + 3] = W_ev / 2;
+        p[PH_OFF] = (ego[0] + ego[2]) / 2 - ego[2];
+        p[PH_XL] = XYb[0]; p[PH_XL + 1] = XYb[2]; p[PH_XL + 2] = -1e300; p[PH_XL + 3] = -1.0;     /* :104-106 */
+        p[PH_XU] = XYb[1]; p[PH_XU + 1] = XYb[3]; p[PH_XU + 2] = 1e300; p[PH_XU + 3] = 2.0;
+        for (int q = 0; q < 4; q++) { p[PH_X0 + q] = in.x0 ? in.x0[4 * (size_t)g + q] : 0.0; p[PH_XF + q] = in.xF ? in.xF[4 * (size_t)g + q] : 0.0; }
+        p[PH_FIX] = in.fixTime ? 1 : 0; p[PH_NOB] = no; p[PH_M] = m;
+        int ro = 0;
+        for (int j = 0; j < no; j++) { const int v = in.vOb[bt->obOff[i] + j]; p[PH_VOB + j] = v; p[PH_ROFF + j] = ro; ro += v; }
+        p[PH_ROFF + no] = ro;
+        const size_t r0 = bt->rowOff[i];
+        for (int r = 0; r < m; r++) { p[PH_A + 2 * r] = in.A[2 * (r0 + r)]; p[PH_A + 2 * r + 1] = in.A[2 * (r0 + r) + 1]; p[PH_B + r] = in.b[r0 + r]; }
+        memcpy(p + OB_HDR, in.rx + (size_t)g * N1, sizeof(double) * N1);
+        memcpy(p + OB_HDR + N1, in.ry + (size_t)g * N1, sizeof(double) * N1);
+        memcpy(p + OB_HDR + 2 * N1, in.ryaw + (size_t)g * N1, sizeof(double) * N1);
+        Lay l; make_layout(N, no, m, l);
+        double *z = bt->h_zin + (size_t)i * W;
+        if (in.xWS) memcpy(z + l.x, in.xWS + (size_t)g * 4 * N1, sizeof(double) * 4 * N1); else memset(z + l.x, 0, sizeof(double) * 4 * N1);
+        if (in.uWS) memcpy(z + l.u, in.uWS + (size_t)g * 2 * N, sizeof(double) * 2 * N); else memset(z + l.u, 0, sizeof(double) * 2 * N);
+        z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
+        if (duals) {
+            memcpy(z + l.lam, in.lWS + r0 * N1, sizeof(double) * m * N1);
+            memcpy(z + l.mu, in.nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * no * N1);
+            memset(z + l.sl, 0, sizeof(double) * (W - l.sl));
+        } else memset(z + l.lam, 0, sizeof(double) * (W - l.lam));
+    }
+    bt->have_duals = duals ? 1 : 0; bt->fixTime = in.fixTime ? 1 : 0;
+    HIPCHK(bt, hipMemcpyAsync(d.prob, bt->h_prob, (size_t)n * d.s_prob * sizeof(double), hipMemcpyHostToDevice, bt->stream));
+    HIPCHK(bt, hipMemcpyAsync(bt->stage, bt->h_zin, (size_t)n * W * sizeof(double), hipMemcpyHostToDevice, bt->stream));
+    hipLaunchKernelGGL(obca_scatter_rows_kernel, dim3((unsigned)((d.s_z + 1023) / 1024), n), dim3(256), 0, bt->stream, d.z0, d.s_z, (const double *)bt->stage, W, d.s_z);
+    HIPCHK(bt, hipGetLastError());
+    bt->uploaded = 1;
+    return 0;
+}
+
+static int launch_dualws(obca_batch *bt, double *zdst) {
+    long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
+    int blocks = (int)((tot + 255) / 256);
+    hipLaunchKernelGGL(obca_dualws_kernel, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
+    HIPCHK(bt, hipGetLastError());
+    return 0;
+}
+
+// asynchronous on the batch's stream: warm start -> (DualMultWS) -> interior point; dualws_only: stop after DualMultWS
+static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
+    if (!bt->uploaded) { bt->err = "obca_batch_solve: nothing uploaded"; return -1; }
+    if (!dualws_only && bt->N < 2) { bt->err = "obca_batch_solve: the NLP needs a horizon N>=2"; return -1; }
+    obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
+    Opts ko; memcpy(&ko, &o, sizeof ko);
+    hipSetDevice(bt->device);
+    const DevBufs &d = bt->d;
+    HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
+    HIPCHK(bt, hipEventRecord(bt->e0, bt->stream));
+    if (!bt->have_duals || dualws_only) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
+    HIPCHK(bt, hipEventRecord(bt->e1, bt->stream));
+    if (dualws_only) { HIPCHK(bt, hipEventRecord(bt->e2, bt->stream)); return 0; }
+    // Two-launch schedule.  The kernel keeps a fixed number of instances resident; a larger batch is dispatched in blockIdx
+    // order as workgroups retire, so an instance that needs three times the median number of passes and happens to sit late in the batch
+    // would start late and finish alone.  Instead every instance first runs a short slice (OBCA_SLICE_PASSES factorisation passes, default
+    // 6), the parked solves are ranked by what the slice revealed, and a second launch finishes them hardest-first.  No work is repeated
+    // and every instance walks through the same iterates as in a single launch.  OBCA_SLICE_PASSES=0 turns it off; OBCA_SLICE_ONLY=1
+    // (diagnostic) stops after the first slice.
+    int budget = 6;
+    if (const char *e = getenv("OBCA_SLICE_PASSES")) budget = atoi(e);
+    const bool slice_only = getenv("OBCA_SLICE_ONLY") && atoi(getenv("OBCA_SLICE_ONLY"));
+    const int slots = OBCA_RESIDENT_PER_CU * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
+    bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
+    if (!bt->sliced) {
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0);
+        HIPCHK(bt, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget);
+        HIPCHK(bt, hipGetLastError());
+        if (!slice_only) {
+            hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
+            HIPCHK(bt, hipGetLastError());
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0);
+            HIPCHK(bt, hipGetLastError());
+        }
+    }
+    HIPCHK(bt, hipEventRecord(bt->e2, bt->stream));
+    return 0;
+}
+
+// outputs of the batch's instances into the caller's arrays (instance i of the batch = instance lo + i of the call; packed obstacle outputs
+// go to the offsets recorded at upload).  Synchronises the batch's stream.
+static int batch_download_range(obca_batch *bt, const ParkOut &o, int lo) {
+    const int B = bt->B, N = bt->N, N1 = N + 1;
+    const DevBufs &d = bt->d;
+    hipSetDevice(bt->device);
+    Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
+    const size_t W = (size_t)lmax.so;                       // outputs are a prefix of the iterate: x, u, t, lam, mu, sl
+    const bool want_z = o.xp || o.up || o.ts || o.lp || o.np || o.slp || o.lWS || o.nWS;
+    if (pinned_reserve(bt->err, &bt->h_zout, &bt->hcap_zout, (size_t)bt->cap * std::max(W, (size_t)N1 * bt->nObMax)) ||
+        pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return -2;
+    if (want_z) {
+        hipLaunchKernelGGL(obca_gather_rows_kernel, dim3((unsigned)((W + 1023) / 1024), B), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
+        HIPCHK(bt, hipGetLastError());
+        HIPCHK(bt, hipMemcpyAsync(bt->h_zout, bt->stage, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
+    }
+    HIPCHK(bt, hipMemcpyAsync(bt->h_info, d.info, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
+    HIPCHK(bt, hipStreamSynchronize(bt->stream));
+    for (int i = 0; i < B; i++) {
+        const size_t g = (size_t)lo + i;
+        Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
+        const double *z = bt->h_zout + (size_t)i * W;
+        if (o.xp) memcpy(o.xp + g * 4 * N1, z + l.x, sizeof(double) * 4 * N1);
+        if (o.up) memcpy(o.up + g * 2 * N, z + l.u, sizeof(double) * 2 * N);
+        if (o.ts) for (int k = 0; k < N1; k++) o.ts[g * N1 + k] = bt->fixTime ? 1.0 : z[l.t];   /* ParkingSignedDist.jl:304-308 */
+        if (o.lp) memcpy(o.lp + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+        if (o.np) memcpy(o.np + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
+        if (o.slp) memcpy(o.slp + (size_t)bt->obOff[i] * N1, z + l.sl, sizeof(double) * bt->nOb[i] * N1);
+        if (o.lWS) memcpy(o.lWS + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+        if (o.nWS) memcpy(o.nWS + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
+        if (o.exitflag) o.exitflag[g] = (int)bt->h_info[(size_t)i * 8 + 7];
+        if (o.info) memcpy(o.info + g * 8, bt->h_info + (size_t)i * 8, sizeof(double) * 8);
+    }
+    if (o.dd) {   // DualMultWS distances: nOb_i x (N+1) packed
+        HIPCHK(bt, hipMemcpyAsync(bt->h_zout, d.dws, (size_t)B * N1 * bt->nObMax * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
+        HIPCHK(bt, hipStreamSynchronize(bt->stream));
+        for (int i = 0; i < B; i++) for (int k = 0; k < N1; k++) for (int j = 0; j < bt->nOb[i]; j++)
+            o.dd[(size_t)bt->obOff[i] * N1 + (size_t)k * bt->nOb[i] + j] = bt->h_zout[(size_t)i * N1 * bt->nObMax + (size_t)k * bt->nObMax + j];
+    }
+    return 0;
+}
+
+// ---- chunked execution of a host-pointer call over the slots of the context (work queue)
+template <typename F>
+static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int lo, int n, std::string &err) */) {
+    const int nchunks = (B + chunk - 1) / chunk;
+    const int nw = std::min<int>(nchunks, (int)ctx->slots.size());
+    std::atomic<int> next(0);
+    std::vector<int> rcs(nw, 0); std::vector<std::string> errs(nw);
+    auto work = [&](int w) {
+        Slot &s = ctx->slots[w];
+        hipSetDevice(s.device);
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= nchunks) break;
+            const int lo = c * chunk, n = std::min(chunk, B - lo);
+            const int rc = fn(s, lo, n, errs[w]);
+            if (rc) { rcs[w] = rc; next.store(nchunks); break; }
+        }
+    };
+    if (nw <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 1; w < nw; w++) th.emplace_back(work, w);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    hipSetDevice(ctx->device);
+    for (int w = 0; w < nw; w++) if (rcs[w]) { ctx->err = errs[w]; return rcs[w]; }
+    return 0;
+}
+static int pick_chunk(const obca_ctx *ctx, int B) {
+    // twice the instances resident on one GPU per chunk: measured best on config-2 batches (PCIe-inclusive, 4 lanes: 92-98 k solves/s against 75 k
+    // with 256-instance chunks) -- what counts is the number of instances in flight (lanes x chunk), which must cover the heavy tail of the
+    // solve times several times over; chunks beyond the resident capacity use the two-launch schedule of batch_solve
+    int chunk = 2 * OBCA_RESIDENT_PER_CU * (ctx->cus > 0 ? ctx->cus : 256);
+    if (const char *e = getenv("OBCA_CHUNK")) { const int v = atoi(e); if (v > 0) chunk = v; }
+    // small calls: still give every slot something to do once there is enough work to hide a transfer behind
+    const int ns = (int)ctx->slots.size();
+    if (B < chunk * ns && B >= 64 * ns) chunk = (B + ns - 1) / ns;
+    return std::max(1, std::min(chunk, B));
+}
+static int slot_parking_batch(obca_ctx *ctx, Slot &s, int n, int N, int dist, std::string &err) {
+    if (s.pb && (s.pb->cap < n || s.pb->N != N)) { obca_batch_destroy(s.pb); s.pb = nullptr; }
+    if (!s.pb) { int rc = batch_create_on(ctx, s.device, s.stream, n, N, &s.pb, err); if (rc) return rc; }
+    if (s.pb->dist != (dist ? 1 : 0)) { s.pb->dist = dist ? 1 : 0; }
+    return 0;
+}
+
+static int parking_call(obca_ctx *ctx, int dist, int dualws_only, int B, int N, ParkIn &in, const obca_opts *opts, const ParkOut &out) {
+    if (!ctx) return -1;
+    if (B < 1 || N < 0 || N > OBCA_NMAX) { ctx->err = "need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
+    if (!in.Ts || !in.ego || !in.XYb || !in.nOb || !in.vOb || !in.A || !in.b || !in.rx || !in.ry || !in.ryaw) { ctx->err = "NULL argument"; return -1; }
+    if (!dualws_only && N < 2) { ctx->err = "the NLP needs a horizon N>=2"; return -1; }
+    if (int rc = park_prefix(ctx->err, B, in.nOb, in.vOb, in)) return rc;
+    const int chunk = pick_chunk(ctx, B);
+    return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
+        int rc = slot_parking_batch(ctx, s, std::min(chunk, B), N, dist, err);
+        if (rc) return rc;
+        obca_batch *bt = s.pb;
+        rc = batch_upload_range(bt, in, lo, n);
+        if (!rc) rc = batch_solve(bt, opts, dualws_only);
+        if (!rc) rc = batch_download_range(bt, out, lo);
+        if (rc) err = bt->err;
+        return rc;
+    });
+}
+
+extern "C" {
+
+int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
+    if (!ctx || !out) return -1;
+    return batch_create_on(ctx, ctx->device, ctx->stream, B, N, out, ctx->err);
 }
 int obca_batch_destroy(obca_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->ctx->device);
+    hipSetDevice(bt->device);
     free_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); hipEventDestroy(bt->e2);
+    double **hs[] = {&bt->h_prob, &bt->h_zin, &bt->h_zout, &bt->h_info};
+    for (auto p : hs) if (*p) hipHostFree(*p);
     delete bt; return 0;
 }
 int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
-    HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream));
-    HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    hipSetDevice(bt->device);
+    if (hipStreamSynchronize(bt->stream) != hipSuccess ||
+        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_batch_debug_phase_cycles: copy failed"; return -2; }
     return 0;
 }
 int obca_batch_set_formulation(obca_batch *bt, int dist) { if (!bt) return -1; bt->dist = dist ? 1 : 0; return 0; }   /* before obca_batch_upload */
@@ -278,144 +625,38 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
                       const double *rx, const double *ry, const double *ryaw, const double *xWS, const double *uWS,
                       const double *lWS, const double *nWS) {
     if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx;
-    const int B = bt->B, N = bt->N, N1 = N + 1;
-    if (!Ts || !ego || !XYb || !nOb || !vOb || !A || !b || !rx || !ry || !ryaw) { ctx->err = "obca_batch_upload: NULL argument"; return -1; }
-    bt->nOb.assign(B, 0); bt->M.assign(B, 0); bt->obOff.assign(B + 1, 0); bt->rowOff.assign(B + 1, 0);
-    int nObMax = 0, MMax = 0;
-    for (int i = 0; i < B; i++) {
-        int n = nOb[i];
-        if (n < 1 || n > OBCA_NOBMAX) { ctx->err = "obca_batch_upload: nOb out of range 1..OBCA_NOBMAX"; return -1; }
-        int m = 0;
-        for (int j = 0; j < n; j++) { int v = vOb[bt->obOff[i] + j]; if (v < 1 || v > OBCA_VMAX) { ctx->err = "obca_batch_upload: vOb out of range 1..OBCA_VMAX"; return -1; } m += v; }
-        bt->nOb[i] = n; bt->M[i] = m; bt->obOff[i + 1] = bt->obOff[i] + n; bt->rowOff[i + 1] = bt->rowOff[i] + m;
-        if (n > nObMax) nObMax = n; if (m > MMax) MMax = m;
-    }
-    Lay lmax; make_layout(N, nObMax, MMax, lmax);
-    hipSetDevice(ctx->device);
-    if (!bt->uploaded || nObMax != bt->nObMax || MMax != bt->MMax) {
-        free_dev(bt);
-        bt->nObMax = nObMax; bt->MMax = MMax; bt->zlen = lmax.len;
-        DevBufs &d = bt->d;
-        d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
-        d.s_oc = (size_t)N1 * nObMax * OB_OC; d.s_traj = (size_t)(N + 2) * 6;
-        size_t tot = 0;
-#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(ctx, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
-        ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
-        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
-        ALLOC(d.info, (size_t)B * 8); ALLOC(d.dws, (size_t)B * N1 * nObMax); ALLOC(d.prof, (size_t)B * 16);
-        ALLOC(d.slice, (size_t)B * SL_SIZE);
-        HIPCHK(ctx, hipMalloc((void **)&d.order, ((size_t)B + 1) * sizeof(int))); tot += ((size_t)B + 1) * sizeof(int);
-#undef ALLOC
-        bt->bytes = (long long)tot;
-    }
-    const DevBufs &d = bt->d;
-    const size_t W = (size_t)lmax.nprimal;                 // only the primal prefix (x,u,t,lam,mu,...) of the iterate travels over PCIe
-    std::vector<double> hp((size_t)B * d.s_prob, 0.0), hz((size_t)B * W, 0.0);
-    const double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];     /* ParkingSignedDist.jl:182-188 */
-    for (int i = 0; i < B; i++) {
-        double *p = hp.data() + (size_t)i * d.s_prob;
-        const int n = bt->nOb[i], m = bt->M[i];
-        p[PH_TS] = Ts[i]; p[PH_L] = L; p[PH_DIST] = bt->dist ? 1.0 : 0.0;
-        p[PH_G] = L_ev / 2; p[PH_G + 1] = W_ev / 2; p[PH_G + 2] = L_ev / 2; p[PH_G + 3] = W_ev / 2;
-        p[PH_OFF] = (ego[0] + ego[2]) / 2 - ego[2];
-        p[PH_XL] = XYb[0]; p[PH_XL + 1] = XYb[2]; p[PH_XL + 2] = -1e300; p[PH_XL + 3] = -1.0;     /* :104-106 */
-        p[PH_XU] = XYb[1]; p[PH_XU + 1] = XYb[3]; p[PH_XU + 2] = 1e300; p[PH_XU + 3] = 2.0;
-        for (int q = 0; q < 4; q++) { p[PH_X0 + q] = x0 ? x0[4 * i + q] : 0.0; p[PH_XF + q] = xF ? xF[4 * i + q] : 0.0; }
-        p[PH_FIX] = fixTime ? 1 : 0; p[PH_NOB] = n; p[PH_M] = m;
-        int ro = 0;
-        for (int j = 0; j < n; j++) { int v = vOb[bt->obOff[i] + j]; p[PH_VOB + j] = v; p[PH_ROFF + j] = ro; ro += v; }
-        p[PH_ROFF + n] = ro;
-        for (int r = 0; r < m; r++) { p[PH_A + 2 * r] = A[2 * (bt->rowOff[i] + r)]; p[PH_A + 2 * r + 1] = A[2 * (bt->rowOff[i] + r) + 1]; p[PH_B + r] = b[bt->rowOff[i] + r]; }
-        for (int k = 0; k < N1; k++) { p[OB_HDR + k] = rx[(size_t)i * N1 + k]; p[OB_HDR + N1 + k] = ry[(size_t)i * N1 + k]; p[OB_HDR + 2 * N1 + k] = ryaw[(size_t)i * N1 + k]; }
-        Lay l; make_layout(N, n, m, l);
-        double *z = hz.data() + (size_t)i * W;
-        if (xWS) memcpy(z + l.x, xWS + (size_t)i * 4 * N1, sizeof(double) * 4 * N1);
-        if (uWS) memcpy(z + l.u, uWS + (size_t)i * 2 * N, sizeof(double) * 2 * N);
-        z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
-        if (lWS && nWS) {
-            memcpy(z + l.lam, lWS + (size_t)bt->rowOff[i] * N1, sizeof(double) * m * N1);
-            memcpy(z + l.mu, nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * n * N1);
-        }
-    }
-    bt->have_duals = (lWS && nWS) ? 1 : 0; bt->fixTime = fixTime ? 1 : 0;
-    bt->Ts.assign(Ts, Ts + B);
-    HIPCHK(ctx, hipMemcpyAsync(d.prob, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d.z0, 0, (size_t)B * d.s_z * sizeof(double), ctx->stream));
-    HIPCHK(ctx, hipMemcpy2DAsync(d.z0, d.s_z * sizeof(double), hz.data(), W * sizeof(double), W * sizeof(double), B, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    bt->uploaded = 1;
-    return 0;
+    if (!Ts || !ego || !XYb || !nOb || !vOb || !A || !b || !rx || !ry || !ryaw) { bt->ctx->err = "obca_batch_upload: NULL argument"; return -1; }
+    ParkIn in = {Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, {}, {}};
+    if (int rc = park_prefix(bt->err, bt->cap, nOb, vOb, in)) { bt->ctx->err = "obca_batch_upload: " + bt->err; return rc; }
+    int rc = batch_upload_range(bt, in, 0, bt->cap);
+    if (!rc && hipStreamSynchronize(bt->stream) != hipSuccess) { bt->err = "obca_batch_upload: stream sync failed"; rc = -2; }
+    return fin(bt, rc);
 }
-
-static int launch_dualws(obca_batch *bt, double *zdst) {
-    obca_ctx *ctx = bt->ctx;
-    long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
-    int blocks = (int)((tot + 255) / 256);
-    hipLaunchKernelGGL(obca_dualws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int obca_batch_solve(obca_batch *bt, const obca_opts *opts) {
-    if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx;
-    if (!bt->uploaded) { ctx->err = "obca_batch_solve: nothing uploaded"; return -1; }
-    if (bt->N < 2) { ctx->err = "obca_batch_solve: the NLP needs a horizon N>=2"; return -1; }
-    obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
-    Opts ko; memcpy(&ko, &o, sizeof ko);
-    hipSetDevice(ctx->device);
-    const DevBufs &d = bt->d;
-    HIPCHK(ctx, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
-    if (!bt->have_duals) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
-    HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
-    // Two-launch schedule.  The kernel keeps two instances per CU resident; a larger batch is dispatched in blockIdx
-    // order as workgroups retire, so an instance that needs three times the median number of passes and happens to sit late in the batch
-    // would start late and finish alone.  Instead every instance first runs a short slice (OBCA_SLICE_PASSES factorisation passes, default
-    // 6), the parked solves are ranked by what the slice revealed, and a second launch finishes them hardest-first.  No work is repeated
-    // and every instance walks through the same iterates as in a single launch.  OBCA_SLICE_PASSES=0 turns it off; OBCA_SLICE_ONLY=1
-    // (diagnostic) stops after the first slice.
-    int budget = 6;
-    if (const char *e = getenv("OBCA_SLICE_PASSES")) budget = atoi(e);
-    const bool slice_only = getenv("OBCA_SLICE_ONLY") && atoi(getenv("OBCA_SLICE_ONLY"));
-    const int slots = 2 * (ctx->cus > 0 ? ctx->cus : 256);
-    bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
-    if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 0, 0);
-        HIPCHK(ctx, hipGetLastError());
-    } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 0, budget);
-        HIPCHK(ctx, hipGetLastError());
-        if (!slice_only) {
-            hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
-            HIPCHK(ctx, hipGetLastError());
-            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko, 1, 0);
-            HIPCHK(ctx, hipGetLastError());
-        }
-    }
-    HIPCHK(ctx, hipEventRecord(bt->e2, ctx->stream));
-    return 0;
-}
+int obca_batch_solve(obca_batch *bt, const obca_opts *opts) { if (!bt) return -1; return fin(bt, batch_solve(bt, opts, 0)); }
 int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new) {
     if (!bt) return -1;
     obca_ctx *ctx = bt->ctx;
     if (!bt->uploaded) { ctx->err = "obca_batch_shift_warm_start: nothing uploaded"; return -1; }
     if (shift < 0 || shift > bt->N) { ctx->err = "obca_batch_shift_warm_start: shift out of range 0..N"; return -1; }
-    hipSetDevice(ctx->device);
+    hipSetDevice(bt->device);
     double *dx0 = nullptr;
-    if (x0_new) {
-        HIPCHK(ctx, hipMalloc((void **)&dx0, (size_t)bt->B * 4 * sizeof(double)));
-        HIPCHK(ctx, hipMemcpyAsync(dx0, x0_new, (size_t)bt->B * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (x0_new) {   // staged through the (idle) device staging buffer of the batch: nothing to free on the error paths
+        if (pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return fin(bt, -2);
+        memcpy(bt->h_info, x0_new, (size_t)bt->B * 4 * sizeof(double));
+        dx0 = bt->stage;
+        if (hipMemcpyAsync(dx0, bt->h_info, (size_t)bt->B * 4 * sizeof(double), hipMemcpyHostToDevice, bt->stream) != hipSuccess) { ctx->err = "obca_batch_shift_warm_start: H2D failed"; return -2; }
     }
-    hipLaunchKernelGGL(obca_shift_kernel, dim3(bt->B), dim3(128), 0, ctx->stream, bt->B, bt->N, shift, bt->d, (const double *)dx0);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (dx0) hipFree(dx0);
+    hipLaunchKernelGGL(obca_shift_kernel, dim3(bt->B), dim3(128), 0, bt->stream, bt->B, bt->N, shift, bt->d, (const double *)dx0);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(bt->stream) != hipSuccess) { ctx->err = "obca_batch_shift_warm_start: kernel failed"; return -2; }
     bt->have_duals = 1;                                 // the shifted multipliers are the dual warm start: DualMultWS is skipped
     return 0;
 }
-int obca_batch_sync(obca_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }
+int obca_batch_sync(obca_batch *bt) {
+    if (!bt) return -1;
+    hipSetDevice(bt->device);
+    if (hipStreamSynchronize(bt->stream) != hipSuccess) { bt->ctx->err = "obca_batch_sync: hipStreamSynchronize failed"; return -2; }
+    return 0;
+}
 int obca_batch_last_schedule(const obca_batch *bt, int *ipm_launches, int *slice_passes) {
     if (!bt) return -1;
     if (ipm_launches) *ipm_launches = bt->sliced ? 2 : 1;
@@ -425,111 +666,135 @@ int obca_batch_last_schedule(const obca_batch *bt, int *ipm_launches, int *slice
 int obca_batch_kernel_ms(obca_batch *bt, float *ipm_ms, float *dualws_ms) {
     if (!bt) return -1;
     float a = 0, b = 0;
-    HIPCHK(bt->ctx, hipEventElapsedTime(&a, bt->e0, bt->e1)); HIPCHK(bt->ctx, hipEventElapsedTime(&b, bt->e1, bt->e2));
+    if (hipEventElapsedTime(&a, bt->e0, bt->e1) != hipSuccess || hipEventElapsedTime(&b, bt->e1, bt->e2) != hipSuccess) { bt->ctx->err = "obca_batch_kernel_ms: events not ready"; return -2; }
     if (dualws_ms) *dualws_ms = a; if (ipm_ms) *ipm_ms = b;
     return 0;
 }
-
 int obca_batch_download(obca_batch *bt, double *xp, double *up, double *ts, int *exitflag, double *lp, double *np, double *slp, double *info) {
     if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx;
-    const int B = bt->B, N = bt->N, N1 = N + 1;
-    const DevBufs &d = bt->d;
-    hipSetDevice(ctx->device);
-    Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
-    const size_t W = (size_t)lmax.so;                       // outputs are a prefix of the iterate: x, u, t, lam, mu, sl
-    std::vector<double> hz((size_t)B * W), hi((size_t)B * 8);
-    HIPCHK(ctx, hipMemcpy2DAsync(hz.data(), W * sizeof(double), d.z, d.s_z * sizeof(double), W * sizeof(double), B, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hi.data(), d.info, hi.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < B; i++) {
-        Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
-        const double *z = hz.data() + (size_t)i * W;
-        if (xp) memcpy(xp + (size_t)i * 4 * N1, z + l.x, sizeof(double) * 4 * N1);
-        if (up) memcpy(up + (size_t)i * 2 * N, z + l.u, sizeof(double) * 2 * N);
-        if (ts) for (int k = 0; k < N1; k++) ts[(size_t)i * N1 + k] = bt->fixTime ? 1.0 : z[l.t];   /* ParkingSignedDist.jl:304-308 */
-        if (lp) memcpy(lp + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
-        if (np) memcpy(np + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
-        if (slp) memcpy(slp + (size_t)bt->obOff[i] * N1, z + l.sl, sizeof(double) * bt->nOb[i] * N1);
-        if (exitflag) exitflag[i] = (int)hi[(size_t)i * 8 + 7];
-        if (info) memcpy(info + (size_t)i * 8, hi.data() + (size_t)i * 8, sizeof(double) * 8);
-    }
-    return 0;
+    if (!bt->uploaded) { bt->ctx->err = "obca_batch_download: nothing uploaded"; return -1; }
+    ParkOut o = {xp, up, ts, exitflag, lp, np, slp, info, nullptr, nullptr, nullptr};
+    return fin(bt, batch_download_range(bt, o, 0));
 }
 
-static int parking_batch(obca_ctx *ctx, int dist, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
-                         int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
-                         const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
-                         const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
-                         double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
-    if (!ctx) return -1;
-    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_(signed_)dist_batch: NULL argument"; return -1; }
-    obca_batch *bt = nullptr;
-    int rc = obca_batch_create(ctx, B, N, &bt);
-    if (rc) return rc;
-    obca_batch_set_formulation(bt, dist);
-    rc = obca_batch_upload(bt, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS);
-    if (!rc) rc = obca_batch_solve(bt, opts);
-    if (!rc) rc = obca_batch_sync(bt);
-    if (!rc) rc = obca_batch_download(bt, xp, up, timeScale, exitflag, lp, np, slp, info);
-    obca_batch_destroy(bt);
-    return rc;
-}
 int obca_parking_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
                                    int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
                                    const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
                                    const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
                                    double *up, double *timeScale, int *exitflag, double *lp, double *np, double *slp, double *info) {
-    return parking_batch(ctx, 0, B, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opts, xp, up,
-                         timeScale, exitflag, lp, np, slp, info);
+    if (!ctx) return -1;
+    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_signed_dist_batch: NULL argument"; return -1; }
+    ParkIn in = {Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, {}, {}};
+    ParkOut o = {xp, up, timeScale, exitflag, lp, np, slp, info, nullptr, nullptr, nullptr};
+    return parking_call(ctx, 0, 0, B, N, in, opts, o);
 }
 int obca_parking_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double L, const double ego[4], const double XYb[4],
                             int fixTime, const double *x0, const double *xF, const int *nOb, const int *vOb, const double *A,
                             const double *b, const double *rx, const double *ry, const double *ryaw, const double *xWS,
                             const double *uWS, const double *lWS, const double *nWS, const obca_opts *opts, double *xp,
                             double *up, double *timeScale, int *exitflag, double *lp, double *np, double *info) {
-    return parking_batch(ctx, 1, B, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opts, xp, up,
-                         timeScale, exitflag, lp, np, nullptr, info);
+    if (!ctx) return -1;
+    if (!x0 || !xF || !xWS || !uWS) { ctx->err = "obca_parking_dist_batch: NULL argument"; return -1; }
+    ParkIn in = {Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, {}, {}};
+    ParkOut o = {xp, up, timeScale, exitflag, lp, np, nullptr, info, nullptr, nullptr, nullptr};
+    return parking_call(ctx, 1, 0, B, N, in, opts, o);
 }
 
 int obca_dualmult_ws_batch(obca_ctx *ctx, int B, int N, const double ego[4], const int *nOb, const int *vOb, const double *A,
                            const double *b, const double *rx, const double *ry, const double *ryaw, double *lWS, double *nWS, double *dd) {
     if (!ctx) return -1;
     if (!lWS || !nWS) { ctx->err = "obca_dualmult_ws_batch: NULL output"; return -1; }
-    obca_batch *bt = nullptr;
-    int rc = obca_batch_create(ctx, B, N, &bt);
-    if (rc) return rc;
+    if (B < 1) { ctx->err = "obca_dualmult_ws_batch: need B>=1"; return -1; }
     std::vector<double> Ts(B, 1.0); const double XYb[4] = {0, 0, 0, 0};
-    rc = obca_batch_upload(bt, Ts.data(), 1.0, ego, XYb, 0, nullptr, nullptr, nOb, vOb, A, b, rx, ry, ryaw, nullptr, nullptr, nullptr, nullptr);
-    if (!rc) rc = launch_dualws(bt, bt->d.z);
-    if (!rc) rc = obca_batch_sync(bt);
-    if (!rc) {
-        const int N1 = N + 1;
-        std::vector<double> hz((size_t)B * bt->d.s_z), hd((size_t)B * N1 * bt->nObMax);
-        if (hipMemcpy(hz.data(), bt->d.z, hz.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(hd.data(), bt->d.dws, hd.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "obca_dualmult_ws_batch: copy back failed"; rc = -2; }
-        for (int i = 0; i < B && !rc; i++) {
-            Lay l; make_layout(N, bt->nOb[i], bt->M[i], l);
-            const double *z = hz.data() + (size_t)i * bt->d.s_z;
-            memcpy(lWS + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
-            memcpy(nWS + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
-            if (dd) for (int k = 0; k < N1; k++) for (int j = 0; j < bt->nOb[i]; j++)
-                dd[(size_t)bt->obOff[i] * N1 + (size_t)k * bt->nOb[i] + j] = hd[(size_t)i * N1 * bt->nObMax + (size_t)k * bt->nObMax + j];
-        }
-    }
-    obca_batch_destroy(bt);
-    return rc;
+    ParkIn in = {Ts.data(), 1.0, ego, XYb, 0, nullptr, nullptr, nOb, vOb, A, b, rx, ry, ryaw, nullptr, nullptr, nullptr, nullptr, {}, {}};
+    ParkOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lWS, nWS, dd};
+    return parking_call(ctx, 0, 1, B, N, in, nullptr, o);
 }
+
+}  // extern "C"
 
 /* ---------------------------------------------------------------- quadcopter path */
 struct obca_quad_batch {
-    obca_ctx *ctx; int B, N, uploaded;
-    QDevBufs d; hipEvent_t e0, e1; long long bytes;
+    obca_ctx *ctx; int device; hipStream_t stream; std::string err;
+    int B, cap, N, uploaded;
+    QDevBufs d; double *stage; hipEvent_t e0, e1; long long bytes;
+    double *h_prob, *h_z, *h_info; size_t hcap_prob, hcap_z, hcap_info;       // pinned host staging
 };
+#define QCHK(bt, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (bt)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+static inline int qfin(obca_quad_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
 static void qfree_dev(obca_quad_batch *bt) {
     double **ps[] = {&bt->d.prob, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.prof};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+    if (bt->stage) hipFree(bt->stage); bt->stage = nullptr;
 }
+static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B, int N, obca_quad_batch **out, std::string &err) {
+    if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { err = "obca_quad_batch_create: need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
+    obca_quad_batch *bt = new obca_quad_batch();
+    bt->ctx = ctx; bt->device = device; bt->stream = stream; bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0; memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr;
+    bt->h_prob = bt->h_z = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_z = bt->hcap_info = 0;
+    hipSetDevice(device);
+    quad::QLay l; quad::q_make_layout(N, l);
+    QDevBufs &d = bt->d; const size_t N1 = N + 1;
+    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSR; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
+    size_t tot = 0;
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
+    ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
+    ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8); ALLOC(d.prof, (size_t)B * 16); ALLOC(bt->stage, (size_t)B * l.so);
+#undef ALLOC
+    bt->bytes = (long long)tot;
+    if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess) { err = "hipEventCreate failed"; qfree_dev(bt); delete bt; return -2; }
+    *out = bt;
+    return 0;
+}
+struct QuadIn { const double *Ts; double R; const double *x0, *xF, *ob, *xWS, *timeWS; int dual_ws, dist; };
+struct QuadOut { double *xp, *up, *ts; int *exitflag; double *lp, *slp, *info; };
+static int quad_upload_range(obca_quad_batch *bt, const QuadIn &in, int lo, int n) {
+    if (n < 1 || n > bt->cap) { bt->err = "obca_quad_batch_upload: more instances than the batch was created for"; return -1; }
+    bt->B = n;
+    const int N1 = bt->N + 1; const QDevBufs &d = bt->d;
+    if (pinned_reserve(bt->err, &bt->h_prob, &bt->hcap_prob, (size_t)bt->cap * d.s_prob)) return -2;
+    for (int i = 0; i < n; i++) {
+        const size_t g = (size_t)lo + i;
+        double *p = bt->h_prob + (size_t)i * d.s_prob;
+        memset(p, 0, sizeof(double) * QPH_SIZE);
+        p[QPH_TS] = in.Ts[g]; p[QPH_R] = in.R; p[QPH_TWS] = in.timeWS[g]; p[QPH_DWS] = in.dual_ws ? 1.0 : 0.0; p[QPH_DIST] = in.dist ? 1.0 : 0.0;
+        memcpy(p + QPH_X0, in.x0 + QX * g, sizeof(double) * QX); memcpy(p + QPH_XF, in.xF + QX * g, sizeof(double) * QX);
+        memcpy(p + QPH_OB, in.ob + (size_t)QOB * QL * g, sizeof(double) * QOB * QL);
+        memcpy(p + QPH_SIZE, in.xWS + (size_t)QX * N1 * g, sizeof(double) * QX * N1);
+    }
+    hipSetDevice(bt->device);
+    QCHK(bt, hipMemcpyAsync(d.prob, bt->h_prob, (size_t)n * d.s_prob * sizeof(double), hipMemcpyHostToDevice, bt->stream));
+    bt->uploaded = 1;
+    return 0;
+}
+static int quad_solve(obca_quad_batch *bt, const obca_opts *opts);
+static int quad_download_range(obca_quad_batch *bt, const QuadOut &o, int lo) {
+    const int B = bt->B, N = bt->N, N1 = N + 1; const QDevBufs &d = bt->d;
+    quad::QLay l; quad::q_make_layout(N, l);
+    hipSetDevice(bt->device);
+    const size_t W = (size_t)l.so;                          // outputs are a prefix of the iterate: x, u, t, lam, s
+    if (pinned_reserve(bt->err, &bt->h_z, &bt->hcap_z, (size_t)bt->cap * W) || pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return -2;
+    hipLaunchKernelGGL(obca_gather_rows_kernel, dim3((unsigned)((W + 1023) / 1024), B), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
+    QCHK(bt, hipGetLastError());
+    QCHK(bt, hipMemcpyAsync(bt->h_z, bt->stage, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
+    QCHK(bt, hipMemcpyAsync(bt->h_info, d.info, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
+    QCHK(bt, hipStreamSynchronize(bt->stream));
+    for (int i = 0; i < B; i++) {
+        const size_t g = (size_t)lo + i;
+        const double *z = bt->h_z + (size_t)i * W;
+        if (o.xp) memcpy(o.xp + g * QX * N1, z + l.x, sizeof(double) * QX * N1);
+        if (o.up) memcpy(o.up + g * QU * N, z + l.u, sizeof(double) * QU * N);
+        if (o.ts) for (int k = 0; k < N1; k++) o.ts[g * N1 + k] = z[l.t];                                 /* QuadcopterSignedDist.jl:293 */
+        if (o.lp) memcpy(o.lp + g * QL * QOB * N1, z + l.lam, sizeof(double) * QL * QOB * N1);            /* [l1;..;l5] stacked, :295 */
+        if (o.slp) memcpy(o.slp + g * QOB * N1, z + l.s, sizeof(double) * QOB * N1);
+        if (o.exitflag) o.exitflag[g] = (int)bt->h_info[(size_t)i * 8 + 7];
+        if (o.info) memcpy(o.info + g * 8, bt->h_info + (size_t)i * 8, sizeof(double) * 8);
+    }
+    return 0;
+}
+
+extern "C" {
+
 int obca_quadcopter_default_opts(obca_opts *o) {
     if (obca_default_opts(o)) return -1;
     o->max_iter = 3000; o->dw_min = 1e-10;            /* QuadcopterSignedDist.jl:28-31: no max_iter (IPOPT default), min_hessian_perturbation 1e-10 */
@@ -537,120 +802,94 @@ int obca_quadcopter_default_opts(obca_opts *o) {
 }
 int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
     if (!ctx || !out) return -1;
-    if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { ctx->err = "obca_quad_batch_create: need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
-    obca_quad_batch *bt = new obca_quad_batch();
-    bt->ctx = ctx; bt->B = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0; memset(&bt->d, 0, sizeof bt->d);
-    hipSetDevice(ctx->device);
-    quad::QLay l; quad::q_make_layout(N, l);
-    QDevBufs &d = bt->d; const size_t N1 = N + 1;
-    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSR; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
-    size_t tot = 0;
-#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { ctx->err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
-    ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
-    ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8); ALLOC(d.prof, (size_t)B * 16);
-#undef ALLOC
-    bt->bytes = (long long)tot;
-    if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess) { ctx->err = "hipEventCreate failed"; qfree_dev(bt); delete bt; return -2; }
-    *out = bt;
-    return 0;
+    return quad_batch_create_on(ctx, ctx->device, ctx->stream, B, N, out, ctx->err);
 }
 int obca_quad_batch_destroy(obca_quad_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->ctx->device); qfree_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); delete bt; return 0;
+    hipSetDevice(bt->device); qfree_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1);
+    double **hs[] = {&bt->h_prob, &bt->h_z, &bt->h_info};
+    for (auto p : hs) if (*p) hipHostFree(*p);
+    delete bt; return 0;
 }
 int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
-    HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream));
-    HIPCHK(bt->ctx, hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    hipSetDevice(bt->device);
+    if (hipStreamSynchronize(bt->stream) != hipSuccess ||
+        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_quad_batch_debug_phase_cycles: copy failed"; return -2; }
     return 0;
 }
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
                            const double *xWS, const double *timeWS, int dual_ws, int dist) {
     if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx;
-    if (!Ts || !x0 || !xF || !ob || !xWS || !timeWS) { ctx->err = "obca_quad_batch_upload: NULL argument"; return -1; }
-    const int B = bt->B, N1 = bt->N + 1; const QDevBufs &d = bt->d;
-    std::vector<double> hp((size_t)B * d.s_prob, 0.0);
-    for (int i = 0; i < B; i++) {
-        double *p = hp.data() + (size_t)i * d.s_prob;
-        p[QPH_TS] = Ts[i]; p[QPH_R] = R; p[QPH_TWS] = timeWS[i]; p[QPH_DWS] = dual_ws ? 1.0 : 0.0; p[QPH_DIST] = dist ? 1.0 : 0.0;
-        memcpy(p + QPH_X0, x0 + (size_t)QX * i, sizeof(double) * QX); memcpy(p + QPH_XF, xF + (size_t)QX * i, sizeof(double) * QX);
-        memcpy(p + QPH_OB, ob + (size_t)QOB * QL * i, sizeof(double) * QOB * QL);
-        memcpy(p + QPH_SIZE, xWS + (size_t)QX * N1 * i, sizeof(double) * QX * N1);
-    }
-    hipSetDevice(ctx->device);
-    HIPCHK(ctx, hipMemcpyAsync(d.prob, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    bt->uploaded = 1;
-    return 0;
+    if (!Ts || !x0 || !xF || !ob || !xWS || !timeWS) { bt->ctx->err = "obca_quad_batch_upload: NULL argument"; return -1; }
+    QuadIn in = {Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, dist};
+    int rc = quad_upload_range(bt, in, 0, bt->cap);
+    if (!rc && hipStreamSynchronize(bt->stream) != hipSuccess) { bt->err = "obca_quad_batch_upload: stream sync failed"; rc = -2; }
+    return qfin(bt, rc);
 }
-int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts) {
-    if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx;
-    if (!bt->uploaded) { ctx->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
+}  // extern "C"
+static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
+    if (!bt->uploaded) { bt->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
     Opts ko; memcpy(&ko, &o, sizeof ko);
-    hipSetDevice(ctx->device);
-    HIPCHK(ctx, hipEventRecord(bt->e0, ctx->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, ctx->stream, bt->B, bt->N, bt->d, ko);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(bt->e1, ctx->stream));
+    hipSetDevice(bt->device);
+    QCHK(bt, hipEventRecord(bt->e0, bt->stream));
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko);
+    QCHK(bt, hipGetLastError());
+    QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;
 }
-int obca_quad_batch_sync(obca_quad_batch *bt) { if (!bt) return -1; hipSetDevice(bt->ctx->device); HIPCHK(bt->ctx, hipStreamSynchronize(bt->ctx->stream)); return 0; }
+static int quadcopter_call(obca_ctx *ctx, int B, int N, const QuadIn &in, const obca_opts *opts, const QuadOut &out) {
+    if (!ctx) return -1;
+    if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { ctx->err = "need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
+    if (!in.Ts || !in.x0 || !in.xF || !in.ob || !in.xWS || !in.timeWS) { ctx->err = "NULL argument"; return -1; }
+    const int chunk = pick_chunk(ctx, B);
+    return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
+        if (s.qb && (s.qb->cap < n || s.qb->N != N)) { obca_quad_batch_destroy(s.qb); s.qb = nullptr; }
+        if (!s.qb) { int rc = quad_batch_create_on(ctx, s.device, s.stream, std::min(chunk, B), N, &s.qb, err); if (rc) return rc; }
+        obca_quad_batch *bt = s.qb;
+        int rc = quad_upload_range(bt, in, lo, n);
+        if (!rc) rc = quad_solve(bt, opts);
+        if (!rc) rc = quad_download_range(bt, out, lo);
+        if (rc) err = bt->err;
+        return rc;
+    });
+}
+extern "C" {
+int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts) { if (!bt) return -1; return qfin(bt, quad_solve(bt, opts)); }
+int obca_quad_batch_sync(obca_quad_batch *bt) {
+    if (!bt) return -1;
+    hipSetDevice(bt->device);
+    if (hipStreamSynchronize(bt->stream) != hipSuccess) { bt->ctx->err = "obca_quad_batch_sync: hipStreamSynchronize failed"; return -2; }
+    return 0;
+}
 int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms) {
     if (!bt || !ipm_ms) return -1;
-    HIPCHK(bt->ctx, hipEventElapsedTime(ipm_ms, bt->e0, bt->e1));
+    if (hipEventElapsedTime(ipm_ms, bt->e0, bt->e1) != hipSuccess) { bt->ctx->err = "obca_quad_batch_kernel_ms: events not ready"; return -2; }
     return 0;
 }
 int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double *ts, int *exitflag, double *lp, double *slp, double *info) {
     if (!bt) return -1;
-    obca_ctx *ctx = bt->ctx; const int B = bt->B, N = bt->N, N1 = N + 1; const QDevBufs &d = bt->d;
-    quad::QLay l; quad::q_make_layout(N, l);
-    hipSetDevice(ctx->device);
-    std::vector<double> hz((size_t)B * d.s_z), hi((size_t)B * 8);
-    HIPCHK(ctx, hipMemcpyAsync(hz.data(), d.z, hz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hi.data(), d.info, hi.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < B; i++) {
-        const double *z = hz.data() + (size_t)i * d.s_z;
-        if (xp) memcpy(xp + (size_t)i * QX * N1, z + l.x, sizeof(double) * QX * N1);
-        if (up) memcpy(up + (size_t)i * QU * N, z + l.u, sizeof(double) * QU * N);
-        if (ts) for (int k = 0; k < N1; k++) ts[(size_t)i * N1 + k] = z[l.t];                       /* QuadcopterSignedDist.jl:293 */
-        if (lp) memcpy(lp + (size_t)i * QL * QOB * N1, z + l.lam, sizeof(double) * QL * QOB * N1);    /* [l1;..;l5] stacked, :295 */
-        if (slp) memcpy(slp + (size_t)i * QOB * N1, z + l.s, sizeof(double) * QOB * N1);
-        if (exitflag) exitflag[i] = (int)hi[(size_t)i * 8 + 7];
-        if (info) memcpy(info + (size_t)i * 8, hi.data() + (size_t)i * 8, sizeof(double) * 8);
-    }
-    return 0;
-}
-static int quadcopter_batch(obca_ctx *ctx, int dist, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
-                            const double *ob, const double *xWS, const double *timeWS, int dual_ws, const obca_opts *opts, double *xp,
-                            double *up, double *timeScale, int *exitflag, double *lp, double *slp, double *info) {
-    if (!ctx) return -1;
-    obca_quad_batch *bt = nullptr;
-    int rc = obca_quad_batch_create(ctx, B, N, &bt);
-    if (rc) return rc;
-    rc = obca_quad_batch_upload(bt, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, dist);
-    if (!rc) rc = obca_quad_batch_solve(bt, opts);
-    if (!rc) rc = obca_quad_batch_sync(bt);
-    if (!rc) rc = obca_quad_batch_download(bt, xp, up, timeScale, exitflag, lp, slp, info);
-    obca_quad_batch_destroy(bt);
-    return rc;
+    QuadOut o = {xp, up, ts, exitflag, lp, slp, info};
+    return qfin(bt, quad_download_range(bt, o, 0));
 }
 int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
                                       const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
                                       const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp,
                                       double *slp, double *info) {
     (void)uWS;                                         /* the reference ignores it too: inputs start at the hover speed, :202 */
-    return quadcopter_batch(ctx, 0, B, N, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, opts, xp, up, timeScale, exitflag, lp, slp, info);
+    QuadIn in = {Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, 0};
+    QuadOut o = {xp, up, timeScale, exitflag, lp, slp, info};
+    return quadcopter_call(ctx, B, N, in, opts, o);
 }
 int obca_quadcopter_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts, double R, const double *x0, const double *xF,
                                const double *ob, const double *xWS, const double *uWS, const double *timeWS, int dual_ws,
                                const obca_opts *opts, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *info) {
     (void)uWS;                                         /* QuadcopterDist.jl:196 */
-    return quadcopter_batch(ctx, 1, B, N, Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, opts, xp, up, timeScale, exitflag, lp, nullptr, info);
+    QuadIn in = {Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, 1};
+    QuadOut o = {xp, up, timeScale, exitflag, lp, nullptr, info};
+    return quadcopter_call(ctx, B, N, in, opts, o);
 }
 
 }  // extern "C"

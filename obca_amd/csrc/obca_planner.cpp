@@ -24,6 +24,7 @@ struct World {
     int nOb; std::vector<int> v, off; std::vector<double> A, b;   // obstacle j: rows off[j] .. off[j]+v[j]
     double xmin, xmax, ymin, ymax;                               // XYbounds of the rear-axle position
     double ego[4], margin;                                        // front, left, rear, right extents from the rear axle; inflation
+    mutable std::vector<P2> bufA, bufB;                           // clip scratch of collides(), sized for the obstacle with the most rows
 };
 
 // convex polygon clipped by the half-plane a.p <= bb (Sutherland-Hodgman); returns the number of vertices left
@@ -44,10 +45,12 @@ static bool collides(const World &w, double x, double y, double yaw) {
     const double f = w.ego[0] + m, l = w.ego[1] + m, r = w.ego[2] + m, rt = w.ego[3] + m;
     const P2 car[4] = {{x + f * c - l * s, y + f * s + l * c}, {x - r * c - l * s, y - r * s + l * c},
                        {x - r * c + rt * s, y - r * s - rt * c}, {x + f * c + rt * s, y + f * s - rt * c}};
-    P2 bufA[16], bufB[16];
+    int vmax = 0; for (int j = 0; j < w.nOb; j++) vmax = std::max(vmax, w.v[j]);
+    std::vector<P2> &bufA = w.bufA, &bufB = w.bufB;              // every half-plane adds at most one vertex to a convex polygon
+    if ((int)bufA.size() < 4 + vmax + 1) { bufA.resize(4 + vmax + 1); bufB.resize(4 + vmax + 1); }
     for (int j = 0; j < w.nOb; j++) {
-        int n = 4; std::memcpy(bufA, car, sizeof car);
-        P2 *cur = bufA, *nxt = bufB;
+        int n = 4; std::memcpy(bufA.data(), car, sizeof car);
+        P2 *cur = bufA.data(), *nxt = bufB.data();
         for (int i = 0; i < w.v[j] && n > 0; i++) {
             const int rix = w.off[j] + i;
             n = clip(cur, n, w.A[2 * rix], w.A[2 * rix + 1], w.b[rix], nxt);
@@ -360,6 +363,8 @@ int obca_plan_reeds_shepp(const double start[3], const double goal[3], double R,
 /* 1 if the car pose collides with an obstacle (inflated by margin) or leaves XYbounds -- the planner's own test, exported for the tests */
 int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, const double *A, const double *b, const double ego[4],
                        const double XYbounds[4], double margin) {
+    if (nOb < 0 || (nOb > 0 && (!vOb || !A || !b)) || !ego || !XYbounds) return -1;
+    for (int j = 0; j < nOb; j++) if (vOb[j] < 1) return -1;
     World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
     for (int j = 0; j < nOb; j++) w.off[j + 1] = w.off[j] + vOb[j];
     w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
