@@ -3,7 +3,10 @@
 # Drop-in replacements, with the reference's positional signatures and return tuples, for
 #   ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS)   (AutonomousParking/ParkingSignedDist.jl:29)
 #   DualMultWS(N,nOb,vOb,A,b,rx,ry,ryaw)                                                   (AutonomousParking/DualMultWS.jl:29)
-# plus batched variants.  Julia arrays are column-major, which is exactly the "stage-contiguous" layout of the C ABI
+#   ParkingDist(...)                                                                       (AutonomousParking/ParkingDist.jl:29)
+#   QuadcopterSignedDist(x0,xF,N,Ts,R,ob1,ob2,ob3,ob4,ob5,xWS,uWS,timeWS)                  (QuadcopterNavigation/QuadcopterSignedDist.jl:25)
+#   QuadcopterDist(...)                                                                    (QuadcopterNavigation/QuadcopterDist.jl:25)
+# plus batched variants and multi-GPU contexts.  Julia arrays are column-major, which is exactly the "stage-contiguous" layout of the C ABI
 # (include/obca_hip.h), so every array is passed with zero copies.
 #
 # NOTE: Julia is not installed in the build environment of this repository, so this file has not been executed there; the
@@ -24,6 +27,19 @@ function Context(device::Integer=0)
     finalizer(x -> ccall((:obca_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), c)
     return c
 end
+
+"Context over several GPUs of the node (all visible ones by default): the batched calls shard their batch over them (obca_create_multi)."
+function MultiContext(devices::Vector{<:Integer}=Int[])
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:obca_create_multi, LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cint}, Cint), r, isempty(devices) ? C_NULL : Cint.(devices), length(devices))
+    rc == 0 || error("obca_create_multi failed: " * unsafe_string(ccall((:obca_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    c = Context(r[])
+    finalizer(x -> ccall((:obca_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), c)
+    return c
+end
+device_count(c::Context) = Int(ccall((:obca_device_count, LIB), Cint, (Ptr{Cvoid},), c.h))
+"make every later call of this module use context `c` (e.g. `use!(MultiContext())` for all GPUs of the node)"
+use!(c::Context) = (_ctx[] = c)
 
 const _ctx = Ref{Union{Nothing,Context}}(nothing)
 ctx() = (_ctx[] === nothing && (_ctx[] = Context(0)); _ctx[])
@@ -98,19 +114,51 @@ function DualMultWS(N, nOb, vOb, A, b, rx, ry, ryaw; ego=Main.ego)
 end
 
 
-"Drop-in for QuadcopterSignedDist.jl:25 (one instance): same arguments, same 7-tuple (xp, up, timeScalep, exitflag, time, lp, status)."
-function QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true)
-    xp = zeros(12, N + 1); up = zeros(4, N); ts = zeros(N + 1); ef = zeros(Cint, 1); lp = zeros(30, N + 1); info = zeros(8)
-    ob = f64(vcat(vec(ob1), vec(ob2), vec(ob3), vec(ob4), vec(ob5)))     # 6 x 5: [xmax,ymax,zmax,-xmin,-ymin,-zmin] per box (:162-166)
+"""
+    QuadcopterSignedDist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS; dual_ws=true, dist=false)
+
+Batched form: x0, xF 12xB; Ts, timeWS vectors of length B; ob 6x5xB (ob1..ob5 of every instance back to back, each
+[xmax,ymax,zmax,-xmin,-ymin,-zmin]); xWS 12x(N+1)xB.  Returns (xp 12x(N+1)xB, up 4xNxB, timeScale (N+1)xB, exitflag B, time, lp 30x(N+1)xB,
+status codes B).  dist=true solves the QuadcopterDist formulation (obca_quadcopter_dist_batch).
+"""
+function QuadcopterSignedDist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS; dual_ws::Bool=true, dist::Bool=false)
+    B = size(x0, 2)
+    xp = zeros(12, N + 1, B); up = zeros(4, N, B); ts = zeros(N + 1, B); ef = zeros(Cint, B); lp = zeros(30, N + 1, B); info = zeros(8, B)
     t0 = time()
-    rc = ccall((:obca_quadcopter_signed_dist_batch, LIB), Cint,
-               (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-                Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-               ctx().h, 1, N, [Float64(Ts)], Float64(R), f64(vec(x0)), f64(vec(xF)), ob, vec(permutedims(f64(xWS)[1:N+1, :])), C_NULL,
-               [Float64(timeWS)], dual_ws ? 1 : 0, C_NULL, xp, up, ts, ef, lp, C_NULL, info)
-    rc == 0 || error("obca_quadcopter_signed_dist_batch failed: " * lasterr(ctx()))
-    status = info[1] == 0 ? "Optimal" : (info[1] == 1 ? "UserLimit" : "Error")
-    return xp, up, ts, Int(ef[1]), time() - t0, lp, status            # QuadcopterSignedDist.jl:298
+    if dist
+        rc = ccall((:obca_quadcopter_dist_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, C_NULL,
+                   xp, up, ts, ef, lp, info)
+    else
+        rc = ccall((:obca_quadcopter_signed_dist_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, C_NULL,
+                   xp, up, ts, ef, lp, C_NULL, info)
+    end
+    rc == 0 || error("obca_quadcopter_(signed_)dist_batch failed: " * lasterr(ctx()))
+    return xp, up, ts, ef, time() - t0, lp, info[1, :]
 end
+
+_quad_status(c) = c == 0 ? "Optimal" : (c == 1 ? "UserLimit" : "Error")
+
+# xWS is 12 x (N+1) in the reference (mainQuadcopter.jl:136 builds [rx'; ry'; rz'; zeros...], QuadcopterSignedDist.jl:201 does setvalue(x, xWS)
+# without a transpose): column-major, that is already the stage-contiguous layout of the C ABI.
+function _quad_one(x0, xF, N, Ts, R, obs, xWS, timeWS, dual_ws, dist)
+    ob = reshape(f64(vcat(map(vec, obs)...)), 6, 5, 1)               # [xmax,ymax,zmax,-xmin,-ymin,-zmin] per box (:162-166)
+    xp, up, ts, ef, t, lp, st = QuadcopterSignedDist_batch(reshape(f64(vec(x0)), 12, 1), reshape(f64(vec(xF)), 12, 1), N, [Float64(Ts)], R, ob,
+        reshape(f64(xWS)[:, 1:N+1], 12, N + 1, 1), [Float64(timeWS)]; dual_ws=dual_ws, dist=dist)
+    return xp[:, :, 1], up[:, :, 1], ts[:, 1], Int(ef[1]), t, lp[:, :, 1], _quad_status(st[1])
+end
+
+"Drop-in for QuadcopterSignedDist.jl:25 (one instance): same arguments, same 7-tuple (xp, up, timeScalep, exitflag, time, lp, status), :298."
+QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true) =
+    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, false)
+
+"Drop-in for QuadcopterDist.jl:25 (call site mainQuadcopter.jl:145): the collision-free sibling, same arguments and 7-tuple (:282)."
+QuadcopterDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true) =
+    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, true)
 
 end # module
