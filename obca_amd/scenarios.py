@@ -266,17 +266,22 @@ def make_quad_batch(B, N=60, seed=20260925, jitter=0.3, random_endpoints=False):
 
 
 # ---------------------------------------------------------------- BASELINE config 5: mixed obstacle counts
-def make_mixed_batch(B, N=80, seed=20260925, max_extra=7):
+def make_mixed_batch(B, N=80, seed=20260925, max_extra=7, min_obstacles=3):
     """config-5 style batch: the backwards-parking scenario plus 0..max_extra extra convex obstacles per instance (triangles = 3 rows,
     quadrilaterals = 4 rows, clockwise vertices through obstHrep) placed in the block left of the slot where the car never goes, so every
-    instance stays solvable while nOb runs from 3 to 10 and M from 5 to 33: irregular per-instance H-rep packing, 1-4 rows per obstacle."""
+    instance stays solvable while nOb runs from 3 to 10 and M from 5 to 33: irregular per-instance H-rep packing, 1-4 rows per obstacle.
+    min_obstacles=1 (BASELINE.json configs[4] as written: "1-10 obstacles per instance"): the obstacle count is drawn from U{1..10}; counts
+    below three keep only the first one / two obstacles of the scenario (left block; both blocks of the slot, no wall above the road)."""
     rng = np.random.default_rng(seed)
     base = make_batch(BACKWARDS, B, N, seed=seed)
     sc = BACKWARDS
     vl, Al, bl = [], [], []
     for i in range(B):
-        nex = int(rng.integers(0, max_extra + 1))
-        lOb = [list(map(list, o)) for o in sc["lOb"]]; vOb = list(sc["vOb"])
+        if min_obstacles < 3:
+            ntot = int(rng.integers(max(1, min_obstacles), 3 + max_extra + 1)); nbase = min(3, ntot); nex = ntot - nbase
+        else:
+            nbase = 3; nex = int(rng.integers(0, max_extra + 1))
+        lOb = [list(map(list, o)) for o in sc["lOb"][:nbase]]; vOb = list(sc["vOb"][:nbase])
         for _ in range(nex):
             cx, cy, r = rng.uniform(-13, -4), rng.uniform(2.0, 4.0), rng.uniform(0.3, 0.8)
             nv = int(rng.integers(3, 5))                                   # triangle or quadrilateral
