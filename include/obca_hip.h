@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define OBCA_VMAX 4      /* max half-space rows per obstacle */
+#define OBCA_VMAX 8      /* max half-space rows per obstacle (obstHrep.jl:31-102: one row per polygon edge) */
+#define OBCA_MMAX 40     /* max half-space rows per instance (all obstacles together) */
 #define OBCA_NOBMAX 10   /* max obstacles per instance */
 #define OBCA_NMAX 128    /* max horizon (the reference's planners give N ~ 50-90) */
 
@@ -113,7 +114,7 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-pha
  * dual_ws != 0 starts the multipliers at the closed-form point-to-box dual solution (recommended; the reference's lambda = 0.05
  * start has a rank-deficient Jacobian and relies on IPOPT's restoration phase, which this solver does not have -- DESIGN.md).
  * exitflag: 1 = solved, 2 = solved but sum(slack) > 1e-3 (:285-288), 0 = failed.  max_iter default 3000, see obca_quadcopter_default_opts. */
-#define OBCA_QUAD_NMAX 64
+#define OBCA_QUAD_NMAX 128   /* mainQuadcopter.jl:116-131: the A* path on the 1.0 grid from x = 10 to 90 gives N_as >= 80 */
 typedef struct obca_quad_batch obca_quad_batch;
 int obca_quadcopter_default_opts(obca_opts *o);
 int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts /* B */, double R, const double *x0 /* 12 x B */,

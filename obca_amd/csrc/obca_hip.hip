@@ -26,7 +26,7 @@ using namespace obca;
 
 static_assert(sizeof(obca_opts) == sizeof(Opts), "obca_opts must mirror obca::Opts");
 static_assert(OBCA_QUAD_NMAX == QNMAX, "ABI limits must match the kernels");
-static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX, "ABI limits must match the kernels");
+static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX && OBCA_MMAX == OB_MMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
     double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(1024) void obca_order_kernel(int B, const double *i
 }
 
 // one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
+template <int VM>
 __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObMax, DevBufs b, double *zdst, size_t s_zdst) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)(N + 1) * nObMax;
@@ -118,19 +119,19 @@ __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObM
     const int nOb = (int)p[PH_NOB], M = (int)p[PH_M];
     if (j >= nOb) return;
     const int v = (int)p[PH_VOB + j], r0 = (int)p[PH_ROFF + j];
-    double a1[OB_VMAX], a2[OB_VMAX], bj[OB_VMAX], g[4];
+    double a1[VM], a2[VM], bj[VM], g[4];
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) { bool on = i < v; a1[i] = on ? p[PH_A + 2 * (r0 + i)] : 0.0; a2[i] = on ? p[PH_A + 2 * (r0 + i) + 1] : 0.0; bj[i] = on ? p[PH_B + r0 + i] : 0.0; }
+    for (int i = 0; i < VM; i++) { bool on = i < v; a1[i] = on ? p[PH_A + 2 * (r0 + i)] : 0.0; a2[i] = on ? p[PH_A + 2 * (r0 + i) + 1] : 0.0; bj[i] = on ? p[PH_B + r0 + i] : 0.0; }
 #pragma unroll
     for (int i = 0; i < 4; i++) g[i] = p[PH_G + i];
     const double rx = p[OB_HDR + k], ry = p[OB_HDR + (N + 1) + k], ryaw = p[OB_HDR + 2 * (N + 1) + k], off = p[PH_OFF];
     double sn, cs; sincos(ryaw, &sn, &cs);
-    double lam[OB_VMAX], mu[4], dv;
-    dualws_one(v, a1, a2, bj, g, rx + cs * off, ry + sn * off, cs, sn, lam, mu, &dv);
+    double lam[VM], mu[4], dv;
+    dualws_one<VM>(v, a1, a2, bj, g, rx + cs * off, ry + sn * off, cs, sn, lam, mu, &dv);
     Lay l; make_layout(N, nOb, M, l);
     double *z = zdst + (size_t)inst * s_zdst;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) z[l.lam + k * M + r0 + i] = lam[i];
+    for (int i = 0; i < VM; i++) if (i < v) z[l.lam + k * M + r0 + i] = lam[i];
 #pragma unroll
     for (int i = 0; i < 4; i++) z[l.mu + 4 * (k * nOb + j) + i] = mu[i];
     if (b.dws) b.dws[(size_t)inst * per + rem] = dv;
@@ -223,7 +224,7 @@ static std::string g_create_err;
 
 struct obca_batch {
     obca_ctx *ctx; int device; hipStream_t stream; std::string err;
-    int B, cap, N, nObMax, MMax, zlen, have_duals, uploaded, dist;
+    int B, cap, N, nObMax, MMax, zlen, have_duals, uploaded, dist, vmax;   // vmax: most rows of one obstacle in the uploaded instances
     DevBufs d; double *stage;                               // stage: dense device staging of the PCIe transfers
     double *h_prob, *h_zin, *h_zout, *h_info; size_t hcap_prob, hcap_zin, hcap_zout, hcap_info, dcap_stage;   // pinned host staging
     std::vector<int> nOb, M, obOff, rowOff;                 // per instance; offsets into the caller's packed obstacle arrays
@@ -287,10 +288,13 @@ int obca_create_multi(obca_ctx **out, const int *devices, int ndev) {
             g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; delete c; return -2;
         }
         if (s == 0 && di == 0) { c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount; }
-        Slot sl; sl.device = dv; sl.pb = nullptr; sl.qb = nullptr; sl.cus = pr.multiProcessorCount;
-        // non-blocking: the streams never synchronise implicitly with the legacy default stream, which other libraries in the process may use
-        if (hipSetDevice(dv) != hipSuccess || hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
-            g_create_err = "hipStreamCreate failed"; for (auto &q : c->slots) { hipSetDevice(q.device); hipStreamDestroy(q.stream); } delete c; return -2;
+        Slot sl; sl.device = dv; sl.pb = nullptr; sl.qb = nullptr; sl.cus = pr.multiProcessorCount; sl.stream = nullptr;
+        // Non-blocking: the streams never synchronise implicitly with the legacy default stream, which other libraries in the process may use.
+        // Only the primary lane gets its stream now; the others are created when a call first needs them: HIP spreads streams over a handful of
+        // hardware queues in creation order, and a process that keeps several single-lane contexts busy at once (bench.py) would otherwise find
+        // its four primary streams on ONE queue, serialised (measured: 103 k instead of 132 k solves/s).
+        if (s == 0 && di == 0 && (hipSetDevice(dv) != hipSuccess || hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess)) {
+            g_create_err = "hipStreamCreate failed"; delete c; return -2;
         }
         c->slots.push_back(sl);
     }
@@ -308,7 +312,7 @@ int obca_destroy(obca_ctx *c) {
     for (auto &s : c->slots) {
         if (s.pb) obca_batch_destroy(s.pb);
         if (s.qb) obca_quad_batch_destroy(s.qb);
-        hipSetDevice(s.device); hipStreamDestroy(s.stream);
+        if (s.stream) { hipSetDevice(s.device); hipStreamDestroy(s.stream); }
     }
     delete c; return 0;
 }
@@ -321,7 +325,7 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     if (B < 1 || N < 0 || N > OBCA_NMAX) { err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
     bt->ctx = ctx; bt->device = device; bt->stream = stream;
-    bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0; bt->zlen = 0; bt->fixTime = 0;
+    bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0; bt->zlen = 0; bt->fixTime = 0; bt->vmax = 0;
     memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr; bt->dcap_stage = 0;
     bt->h_prob = bt->h_zin = bt->h_zout = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_zin = bt->hcap_zout = bt->hcap_info = 0;
     hipSetDevice(device);
@@ -351,6 +355,7 @@ static int park_prefix(std::string &err, int B, const int *nOb, const int *vOb, 
         if (n < 1 || n > OBCA_NOBMAX) { err = "nOb out of range 1..OBCA_NOBMAX"; return -1; }
         int m = 0;
         for (int j = 0; j < n; j++) { const int v = vOb[in.obOff[i] + j]; if (v < 1 || v > OBCA_VMAX) { err = "vOb out of range 1..OBCA_VMAX"; return -1; } m += v; }
+        if (m > OBCA_MMAX) { err = "more than OBCA_MMAX half-space rows in one instance"; return -1; }
         in.obOff[i + 1] = in.obOff[i] + n; in.rowOff[i + 1] = in.rowOff[i] + m;
     }
     return 0;
@@ -362,9 +367,10 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
     if (n < 1 || n > bt->cap) { bt->err = "obca_batch_upload: more instances than the batch was created for"; return -1; }
     bt->B = n;
     bt->nOb.assign(n, 0); bt->M.assign(n, 0); bt->obOff.assign(n + 1, 0); bt->rowOff.assign(n + 1, 0);
-    int nObMax = 0, MMax = 0;
+    int nObMax = 0, MMax = 0; bt->vmax = 0;
     for (int i = 0; i < n; i++) {
         const int g = lo + i;
+        for (int j = in.obOff[g]; j < in.obOff[g + 1]; j++) bt->vmax = std::max(bt->vmax, in.vOb[j]);
         bt->nOb[i] = in.obOff[g + 1] - in.obOff[g]; bt->M[i] = in.rowOff[g + 1] - in.rowOff[g];
         bt->obOff[i] = in.obOff[g]; bt->rowOff[i] = in.rowOff[g];
         nObMax = std::max(nObMax, bt->nOb[i]); MMax = std::max(MMax, bt->M[i]);
@@ -442,7 +448,8 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
 static int launch_dualws(obca_batch *bt, double *zdst) {
     long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
     int blocks = (int)((tot + 255) / 256);
-    hipLaunchKernelGGL(obca_dualws_kernel, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
+    if (bt->vmax <= OB_VMID) hipLaunchKernelGGL(obca_dualws_kernel<OB_VMID>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
+    else hipLaunchKernelGGL(obca_dualws_kernel<OB_VMAX>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     HIPCHK(bt, hipGetLastError());
     return 0;
 }
@@ -537,6 +544,10 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
     const int nw = std::min<int>(nchunks, (int)ctx->slots.size());
     std::atomic<int> next(0);
     std::vector<int> rcs(nw, 0); std::vector<std::string> errs(nw);
+    for (int w = 0; w < nw; w++) {      // lanes get their stream on first use (see obca_create_multi)
+        Slot &s = ctx->slots[w];
+        if (!s.stream && (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)) { ctx->err = "hipStreamCreate failed"; return -2; }
+    }
     auto work = [&](int w) {
         Slot &s = ctx->slots[w];
         hipSetDevice(s.device);

@@ -14,7 +14,8 @@
 #define OBCA_FN static inline
 #endif
 
-#define OB_VMAX 4
+#define OB_VMAX 8      // max half-space rows per obstacle (polygons with up to 8 edges; obstHrep.jl:31-102 emits one row per edge)
+#define OB_VMID 4      // the code of a (stage, obstacle) block is instantiated for <= 2, <= OB_VMID and <= OB_VMAX rows
 #define OB_NOBMAX 10
 #define OB_MMAX 40
 
@@ -187,7 +188,7 @@ OBCA_FN void hh_apply(int v, const double *w, double beta, double *x) {   // x <
 }
 
 // ---------------------------------------------------------------- one (stage, obstacle) block
-// VM = compile-time bound on the half-space rows per obstacle (2 for the shipped parking scenarios, 4 in general): all small
+// VM = compile-time bound on the half-space rows per obstacle (2 for the shipped parking scenarios, 4 or 8 in general): all small
 // matrices of a block are sized by it, which decides whether the block fits the register file without spilling.
 template <int VM>
 struct ObsIn {
@@ -478,23 +479,24 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
 // ---------------------------------------------------------------- DualMultWS: one (pose, obstacle) convex problem
 // max d = -g'mu + (A e - b)'lam  s.t. |A'lam|^2<=1, G'mu + R'A'lam = 0, lam,mu>=0   (DualMultWS.jl:52-73)
 // feasible-start primal-dual path following (sigma = 0.1) down to an average complementarity of 1e-9.
+template <int VM>
 OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double *bj, const double g[4], double ex, double ey,
                         double cs, double sn, double *lam, double *mu, double *dout) {
-    double Q0[OB_VMAX], Q1[OB_VMAX], cl[OB_VMAX], amax = 0;
+    double Q0[VM], Q1[VM], cl[VM], amax = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) {
+    for (int i = 0; i < VM; i++) {
         double x1 = i < v ? a1[i] : 0.0, x2 = i < v ? a2[i] : 0.0;
         Q0[i] = cs * x1 + sn * x2; Q1[i] = -sn * x1 + cs * x2;
         cl[i] = x1 * ex + x2 * ey - (i < v ? bj[i] : 0.0);
         double nr = sqrt(x1 * x1 + x2 * x2); amax = fmax(amax, nr);
     }
-    double zl[OB_VMAX], zm[4], zh = 1, eta0 = 0, eta1 = 0;
+    double zl[VM], zm[4], zh = 1, eta0 = 0, eta1 = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) { lam[i] = i < v ? 0.5 / (v * fmax(amax, 1e-12)) : 0.0; zl[i] = 1; }
+    for (int i = 0; i < VM; i++) { lam[i] = i < v ? 0.5 / (v * fmax(amax, 1e-12)) : 0.0; zl[i] = 1; }
     {
         double q0 = 0, q1 = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) { q0 += Q0[i] * lam[i]; q1 += Q1[i] * lam[i]; }
+        for (int i = 0; i < VM; i++) { q0 += Q0[i] * lam[i]; q1 += Q1[i] * lam[i]; }
         mu[0] = 1 + fmax(0.0, -q0); mu[2] = mu[0] + q0; mu[1] = 1 + fmax(0.0, -q1); mu[3] = mu[1] + q1;
 #pragma unroll
         for (int i = 0; i < 4; i++) zm[i] = 1;
@@ -504,17 +506,17 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
     for (int it = 0; it < 60; it++) {
         double p1 = 0, p2 = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) if (i < v) { p1 += a1[i] * lam[i]; p2 += a2[i] * lam[i]; }
+        for (int i = 0; i < VM; i++) if (i < v) { p1 += a1[i] * lam[i]; p2 += a2[i] * lam[i]; }
         double h = 1 - p1 * p1 - p2 * p2;
         double gap = h * zh;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) if (i < v) gap += lam[i] * zl[i];
+        for (int i = 0; i < VM; i++) if (i < v) gap += lam[i] * zl[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) gap += mu[i] * zm[i];
         double mbar = gap * iv5;
-        double gh[OB_VMAX], rl[OB_VMAX], rm[4], rmax = 0;
+        double gh[VM], rl[VM], rm[4], rmax = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) {
+        for (int i = 0; i < VM; i++) {
             if (i < v) {
                 gh[i] = -2 * (p1 * a1[i] + p2 * a2[i]);
                 rl[i] = -cl[i] + Q0[i] * eta0 + Q1[i] * eta1 - zl[i] - zh * gh[i];
@@ -528,30 +530,30 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         // reciprocals of the barrier variables, once per iteration (reciprocal + Newton, obca_model.h: rcp_nr); the subproblem is a chain of
         // dependent scalar operations per lane, and an IEEE division is 11 of them
         const double ih = rcp_nr(h);
-        double il[OB_VMAX], im[4];
+        double il[VM], im[4];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) il[i] = i < v ? rcp_nr(lam[i]) : 0.0;
+        for (int i = 0; i < VM; i++) il[i] = i < v ? rcp_nr(lam[i]) : 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) im[i] = rcp_nr(mu[i]);
-        double Hl[OB_VMAX * OB_VMAX], bl[OB_VMAX], Dm[4], iDm[4], bm[4];
+        double Hl[VM * VM], bl[VM], Dm[4], iDm[4], bm[4];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) {
+        for (int i = 0; i < VM; i++) {
 #pragma unroll
-            for (int j = 0; j < OB_VMAX; j++)
-                Hl[i * OB_VMAX + j] = (i < v && j < v) ? zh * 2 * (a1[i] * a1[j] + a2[i] * a2[j]) + (zh * ih) * gh[i] * gh[j] : 0.0;
-            if (i < v) { Hl[i * OB_VMAX + i] += zl[i] * il[i]; bl[i] = -(rl[i] + zl[i] - mt * il[i] + (zh - mt * ih) * gh[i]); }
+            for (int j = 0; j < VM; j++)
+                Hl[i * VM + j] = (i < v && j < v) ? zh * 2 * (a1[i] * a1[j] + a2[i] * a2[j]) + (zh * ih) * gh[i] * gh[j] : 0.0;
+            if (i < v) { Hl[i * VM + i] += zl[i] * il[i]; bl[i] = -(rl[i] + zl[i] - mt * il[i] + (zh - mt * ih) * gh[i]); }
             else bl[i] = 0;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) { Dm[i] = zm[i] * im[i]; iDm[i] = rcp_nr(Dm[i]); bm[i] = -(rm[i] + zm[i] - mt * im[i]); }
-        if (ldl_fact<OB_VMAX>(v, Hl)) break;
-        double HiQ0[OB_VMAX], HiQ1[OB_VMAX], Hib[OB_VMAX];
+        if (ldl_fact<VM>(v, Hl)) break;
+        double HiQ0[VM], HiQ1[VM], Hib[VM];
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) { HiQ0[i] = Q0[i]; HiQ1[i] = Q1[i]; Hib[i] = bl[i]; }
-        ldl_solve<OB_VMAX>(v, Hl, HiQ0); ldl_solve<OB_VMAX>(v, Hl, HiQ1); ldl_solve<OB_VMAX>(v, Hl, Hib);
+        for (int i = 0; i < VM; i++) { HiQ0[i] = Q0[i]; HiQ1[i] = Q1[i]; Hib[i] = bl[i]; }
+        ldl_solve<VM>(v, Hl, HiQ0); ldl_solve<VM>(v, Hl, HiQ1); ldl_solve<VM>(v, Hl, Hib);
         double S00 = 0, S01 = 0, S11 = 0, rs0 = 0, rs1 = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) if (i < v) {
+        for (int i = 0; i < VM; i++) if (i < v) {
             S00 += Q0[i] * HiQ0[i]; S01 += Q0[i] * HiQ1[i]; S11 += Q1[i] * HiQ1[i];
             rs0 += Q0[i] * Hib[i]; rs1 += Q1[i] * Hib[i];
         }
@@ -564,9 +566,9 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         if (!chol2(S00, S01, S11, Lc)) break;
         double de0 = rs0, de1 = rs1;
         chol2_solve(Lc, de0, de1);
-        double dl[OB_VMAX], dm[4], dzl[OB_VMAX], dzm[4], ghd = 0;
+        double dl[VM], dm[4], dzl[VM], dzm[4], ghd = 0;
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) {
+        for (int i = 0; i < VM; i++) {
             dl[i] = i < v ? Hib[i] - HiQ0[i] * de0 - HiQ1[i] * de1 : 0.0;
             dzl[i] = i < v ? mt * il[i] - zl[i] - zl[i] * il[i] * dl[i] : 0.0;
             ghd += gh[i] * dl[i];
@@ -580,7 +582,7 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         double a = 1, tb = 0.995, cc;
 #define OB_FTB(val, dv) { cc = (dv) < 0 ? -tb * (val) * rcp_nr(dv) : 1e300; if (cc < a) a = cc; }
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) if (i < v) { OB_FTB(lam[i], dl[i]); OB_FTB(zl[i], dzl[i]); }
+        for (int i = 0; i < VM; i++) if (i < v) { OB_FTB(lam[i], dl[i]); OB_FTB(zl[i], dzl[i]); }
 #pragma unroll
         for (int i = 0; i < 4; i++) { OB_FTB(mu[i], dm[i]); OB_FTB(zm[i], dzm[i]); }
         OB_FTB(zh, dzh);
@@ -588,19 +590,19 @@ OBCA_FN void dualws_one(int v, const double *a1, const double *a2, const double 
         for (int bt = 0; bt < 60; bt++) {
             double q1 = 0, q2 = 0;
 #pragma unroll
-            for (int i = 0; i < OB_VMAX; i++) if (i < v) { q1 += a1[i] * (lam[i] + a * dl[i]); q2 += a2[i] * (lam[i] + a * dl[i]); }
+            for (int i = 0; i < VM; i++) if (i < v) { q1 += a1[i] * (lam[i] + a * dl[i]); q2 += a2[i] * (lam[i] + a * dl[i]); }
             if (1 - q1 * q1 - q2 * q2 >= (1 - tb) * h) break;
             a *= 0.7;
         }
 #pragma unroll
-        for (int i = 0; i < OB_VMAX; i++) if (i < v) { lam[i] += a * dl[i]; zl[i] += a * dzl[i]; }
+        for (int i = 0; i < VM; i++) if (i < v) { lam[i] += a * dl[i]; zl[i] += a * dzl[i]; }
 #pragma unroll
         for (int i = 0; i < 4; i++) { mu[i] += a * dm[i]; zm[i] += a * dzm[i]; }
         zh += a * dzh; eta0 += a * de0; eta1 += a * de1;
     }
     double dv = 0;
 #pragma unroll
-    for (int i = 0; i < OB_VMAX; i++) if (i < v) dv += cl[i] * lam[i];
+    for (int i = 0; i < VM; i++) if (i < v) dv += cl[i] * lam[i];
 #pragma unroll
     for (int i = 0; i < 4; i++) dv -= g[i] * mu[i];
     *dout = dv;

@@ -10,7 +10,7 @@
 namespace obca {
 namespace quad {
 
-#define QNMAX 64                     // longest horizon (the forward-sweep trajectory lives in LDS)
+#define QNMAX 128                    // longest horizon (the forward-sweep trajectory lives in LDS: (QNMAX + 2) x 16 doubles)
 #define QSR 736                      // doubles per stage record: H 20x20 | Fh 16x18 | hc 20x2
 #define QSR_H 0
 #define QSR_F 400                    // Fh[a][c]: c<12 x columns (A), 12..15 u columns (B / identity), 16 = d, 17 = Ft
@@ -863,8 +863,57 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
     SYNC();
 }
 
+// ---------------------------------------------------------------- block feasibility restoration
+// The reference starts every lambda at 0.05 (QuadcopterSignedDist.jl:204-208) where A'lambda = 0: the gradient of |A'lambda|^2 == 1 vanishes, the
+// Jacobian is rank deficient and IPOPT leaves the point through its restoration phase (the authors mention its messages, mainQuadcopter.jl:140).
+// For fixed positions the violation of the two rows of a (stage, box) block is minimised in closed form (point-to-box dual, q_dual_ws): the
+// restoration resets lambda / row slack / row multipliers / their bound multipliers of every block at the current positions and keeps
+// everything else; the driver then restarts the barrier parameter and clears the filter.  Same steps, same order as oracle/obca_oracle_quad.c.
+#define Q_MAX_RESTORE 3
+OBCA_FN double q_min_norm2(QShared &sh) {
+    const QLay &l = sh.l; const int N = sh.c.N; const gdbl *z = sh.inst.z;
+    PAR(lane) {
+        double mn = 1e300;
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            double n2 = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const double q = z[l.lam + QL * it + i] - z[l.lam + QL * it + 3 + i]; n2 += q * q; }
+            mn = fmin(mn, n2);
+        }
+        sh.red[0][lane] = mn;
+    }
+    SYNC();
+    const double r = red_min(sh.red[0]);
+    SYNC();
+    return r;
+}
+OBCA_FN void q_restore_blocks(QShared &sh, double bound_push) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; gdbl *z = sh.inst.z;
+    PAR(lane) {
+        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+            const int k = it / QOB, j = it - k * QOB;
+            double lam[QL]; const double p[3] = {z[l.x + QX * k], z[l.x + QX * k + 1], z[l.x + QX * k + 2]};
+            q_dual_ws(&sh.ob[j * QL], p, lam);
+            QObsIn in;
+#pragma unroll
+            for (int i = 0; i < QL; i++) { in.b[i] = sh.ob[j * QL + i]; in.lam[i] = lam[i]; }
+            in.s = z[l.s + it]; in.so = 0; in.p[0] = p[0]; in.p[1] = p[1]; in.p[2] = p[2];
+            double r[2], q[3]; q_obs_rows(c, in, r, q);
+            z[l.so + it] = r[1] < bound_push ? bound_push : r[1];
+#pragma unroll
+            for (int i = 0; i < QL; i++) { z[l.lam + QL * it + i] = lam[i] < bound_push ? bound_push : lam[i]; z[l.zL + l.lam + QL * it + i] = 1.0; }
+            if (!c.dist) { if (in.s < bound_push) z[l.s + it] = bound_push; z[l.zL + l.s + it] = 1.0; }
+            z[l.zL + l.so + it] = 1.0;
+            z[l.yo + 2 * it] = 0.0; z[l.yo + 2 * it + 1] = 0.0;
+        }
+    }
+    SYNC();
+}
+
 // ---------------------------------------------------------------- phase entry points and driver
 OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); QPROF(QPF_INIT); }
+OBCA_PHASE double qph_min_norm2() { return q_min_norm2(gq_sh); }
+OBCA_PHASE void qph_restore(double bp) { q_restore_blocks(gq_sh, bp); }
 OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
 OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
 OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
@@ -890,15 +939,18 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     SYNC();
     qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS]);
     double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
-    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
+    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1;
     const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
     double dc_mu = -1.0, dc_val = 0;
+    if (qph_min_norm2() < 1e-12) { qph_restore(o.bound_push); nrest++; }      // rank-deficient start (the reference's lambda = 0.05): restoration first
+    // where IPOPT would enter its restoration phase (line search or inertia correction failed): block restoration, barrier restart, empty filter
+#define Q_RESTORE_AND_CONTINUE { qph_restore(o.bound_push); nrest++; mu = o.mu_init; tau = fmax(o.tau_min, 1 - mu); nf = 0; dw_last = 0; reset_th = 1; continue; }
     for (;;) {
         if (mu != dc_mu) { dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
         double dc = dc_val;
         qph_assemble(mu, 0.0, dc, 0);
-        if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
+        if (reset_th) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); reset_th = 0; }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
         const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
@@ -931,7 +983,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
             if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last); else dw *= (dw_last == 0 ? o.kw_inc0 : o.kw_inc);
             if (dw > o.dw_max) break;
         }
-        if (!ok) { status = ST_ERROR; break; }
+        if (!ok) { if (nrest < Q_MAX_RESTORE) Q_RESTORE_AND_CONTINUE; status = ST_ERROR; break; }
         if (dw > 0) dw_last = dw;
         const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
         double amin, pw_th = 0, pw_gd = 0;
@@ -961,10 +1013,11 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
             }
             alpha *= 0.5;
         }
-        if (!acc) { status = ST_ERROR; break; }
+        if (!acc) { if (nrest < Q_MAX_RESTORE) Q_RESTORE_AND_CONTINUE; status = ST_ERROR; break; }
         qph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
         it++;
     }
+#undef Q_RESTORE_AND_CONTINUE
     // exit flag: 1 = Optimal, 2 = Optimal but sum(slack) > 1e-3, 0 otherwise
     PAR(lane) { double s_ = 0; for (int i = lane; i < QOB * (N + 1); i += OB_NT) s_ += sh.inst.z[sh.l.s + i]; sh.red[0][lane] = s_; }
     SYNC();

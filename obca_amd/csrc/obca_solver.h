@@ -168,7 +168,7 @@ struct Shared {
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
-    Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2;   // phase inputs/outputs (wave-uniform, exchanged through LDS)
+    Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
     double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
     double clm[(OB_NMAX + 1) * 42];   // closed-loop maps of all stages (Acl 6x6 row-major, then bcl): written stage-parallel, read by the forward
                                       // sweep and the back-substitution without leaving LDS (two instances per CU leave 80 KB per workgroup)
@@ -1291,14 +1291,17 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
 }
 
 // ---------------------------------------------------------------- phase entry points (non-inlined; state lives in g_sh)
+// the per-lane (stage, obstacle) code exists in three sizes (VM = 2, OB_VMID, OB_VMAX rows); an instance uses the smallest that holds its widest obstacle
+#define VM_CALL(F, ...) do { if (g_sh.vmc == 0) F<2>(__VA_ARGS__); else if (g_sh.vmc == 1) F<OB_VMID>(__VA_ARGS__); else F<OB_VMAX>(__VA_ARGS__); } while (0)
 OBCA_PHASE void ph_init(double bound_push, double bound_frac) {
     Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac}; PROF(sh.inst, PF_OTHER);
-    if (sh.vm2) init_point<2>(sh.inst, sh, po); else init_point<OB_VMAX>(sh.inst, sh, po);
+    VM_CALL(init_point, sh.inst, sh, po);
     PROF(sh.inst, PF_INIT);
 }
 OBCA_PHASE void ph_assemble_obs2(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<2>(sh.inst, sh, mu, dw, dc); }
-OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc); }
-OBCA_FN void ph_assemble_obs(double mu, double dw, double dc) { if (g_sh.vm2) ph_assemble_obs2(mu, dw, dc); else ph_assemble_obs4(mu, dw, dc); }
+OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMID>(sh.inst, sh, mu, dw, dc); }
+OBCA_PHASE void ph_assemble_obs8(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc); }
+OBCA_FN void ph_assemble_obs(double mu, double dw, double dc) { if (g_sh.vmc == 0) ph_assemble_obs2(mu, dw, dc); else if (g_sh.vmc == 1) ph_assemble_obs4(mu, dw, dc); else ph_assemble_obs8(mu, dw, dc); }
 OBCA_PHASE void ph_assemble_stage(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
 // the two assembly parts of the common (<= 2 rows per obstacle) case share ONE non-inlined function: every call of a register-hungry phase
 // saves / restores the 112 callee-saved VGPRs through scratch, so fewer calls = less HBM traffic
@@ -1307,8 +1310,9 @@ OBCA_FN void ph_assemble(double mu, double dw, double dc, int second) { if (g_sh
 OBCA_PHASE int ph_riccati(double rho) { Shared &sh = g_sh; return riccati_backward(sh.inst, sh, rho); }
 OBCA_PHASE void ph_direction_main(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
 OBCA_PHASE void ph_direction_obs2(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
-OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
-OBCA_FN void ph_direction_obs(double mu, double dw, double dc, double tau) { if (g_sh.vm2) ph_direction_obs2(mu, dw, dc, tau); else ph_direction_obs4(mu, dw, dc, tau); }
+OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMID>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs8(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_FN void ph_direction_obs(double mu, double dw, double dc, double tau) { if (g_sh.vmc == 0) ph_direction_obs2(mu, dw, dc, tau); else if (g_sh.vmc == 1) ph_direction_obs4(mu, dw, dc, tau); else ph_direction_obs8(mu, dw, dc, tau); }
 OBCA_PHASE void ph_direction2(double mu, double dw, double dc, double rho, double tau) {   // both parts in one call, see ph_assemble2
     Shared &sh = g_sh;
     direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
@@ -1320,8 +1324,9 @@ OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double ta
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
 OBCA_PHASE void ph_trial2(double alpha) { Shared &sh = g_sh; eval_trial<2>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_FN void ph_trial(double alpha) { if (g_sh.vm2) ph_trial2(alpha); else ph_trial4(alpha); }
+OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMID>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_PHASE void ph_trial8(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
+OBCA_FN void ph_trial(double alpha) { if (g_sh.vmc == 0) ph_trial2(alpha); else if (g_sh.vmc == 1) ph_trial4(alpha); else ph_trial8(alpha); }
 OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double ks) { Shared &sh = g_sh; apply_step(sh.inst, sh, alpha, ay, az, mu, ks); }
 
 // ---------------------------------------------------------------- the interior-point driver
@@ -1386,7 +1391,7 @@ OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
     SYNC();
     return worst <= 5e-5;
 }
-OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vm2 ? ref_constraints<2>(sh.inst, sh, sd) : ref_constraints<OB_VMAX>(sh.inst, sh, sd); }
+OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 0 ? ref_constraints<2>(sh.inst, sh, sd) : (sh.vmc == 1 ? ref_constraints<OB_VMID>(sh.inst, sh, sd) : ref_constraints<OB_VMAX>(sh.inst, sh, sd)); }
 
 OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh;
@@ -1520,7 +1525,7 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullp
             c.wa = (c.fixTime || c.dist) ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;      // ParkingDist.jl:87
             make_layout(c.N, c.nOb, c.M, sh.l);
             int vmx = 0; for (int j = 0; j < c.nOb; j++) { int v = (int)sh.hdr[PH_VOB + j]; if (v > vmx) vmx = v; }
-            sh.vm2 = vmx <= 2;
+            sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
         }
     }
     SYNC();

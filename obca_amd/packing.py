@@ -10,7 +10,7 @@ The argument conventions are those of ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbound
 """
 import numpy as np
 
-OB_VMAX, OB_NOBMAX, OB_MMAX, OB_HDR = 4, 10, 40, 168
+OB_VMAX, OB_NOBMAX, OB_MMAX, OB_HDR = 8, 10, 40, 168
 PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=36, DIST=47, A=48, B=128)
 LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU zs1 nprimal len").split()
 
@@ -31,6 +31,8 @@ def check_obstacles(vOb):
         raise ValueError(f"nOb must be in 1..{OB_NOBMAX}")
     if vOb.min() < 1 or vOb.max() > OB_VMAX:
         raise ValueError(f"rows per obstacle must be in 1..{OB_VMAX}")
+    if vOb.sum() > OB_MMAX:
+        raise ValueError(f"at most {OB_MMAX} half-space rows per instance")
     return vOb
 
 
@@ -83,7 +85,7 @@ def unpack_solution(z, N, nOb, M):
 
 # ---------------------------------------------------------------- quadcopter path (obca_amd/csrc/obca_quad_solver.h)
 QPH_TS, QPH_R, QPH_X0, QPH_XF, QPH_OB, QPH_TWS, QPH_DWS, QPH_DIST, QPH_SIZE = 0, 1, 2, 14, 26, 56, 57, 58, 64
-QUAD_NMAX = 64
+QUAD_NMAX = 128
 
 
 def quad_layout(N):

@@ -31,7 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define VMAX 4
+#define VMAX 8
 #define NOBMAX 10
 #define NCOL 6 /* right-hand sides through the Riccati: main, t, nu1..nu4 */
 

@@ -520,11 +520,56 @@ static int kkt_solve(kkt_t *K, const double *v, double dc, double rho, double *d
     return 1;
 }
 
+
+/*
+ * Block feasibility restoration (stands in for the part of IPOPT's restoration phase this path needs).  The reference starts every lambda at
+ * 0.05 (QuadcopterSignedDist.jl:204-208) where A'lambda = 0: the gradient of |A'lambda|^2 == 1 vanishes, the constraint Jacobian is rank
+ * deficient and IPOPT leaves the point through its restoration phase (minimise the constraint violation; the authors mention its messages,
+ * mainQuadcopter.jl:140).  For FIXED positions the violation of the two rows of a (stage, box) block is minimised in closed form: lambda =
+ * the dual solution of the point-to-box distance (|A'lambda| = 1 exactly), row slack = row value.  The restoration step therefore resets the
+ * multipliers lambda / row slacks / row multipliers of every block at the current positions, keeps x, u, timeScale and their multipliers,
+ * restarts the barrier parameter and clears the filter.  It runs (a) at the start if some block has A'lambda = 0 and (b) where IPOPT would
+ * enter restoration (line search or inertia correction failed), at most MAX_RESTORE times.  The HIP solver does exactly the same.
+ */
+#define MAX_RESTORE 3
+static void dual_ws_block(const prob_t *p, int j, const double *x, double *lam) {
+    double d[3], n2 = 0, q[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) { double hi = p->ob[j][i], lo = -p->ob[j][3 + i], c = x[i] < lo ? lo : (x[i] > hi ? hi : x[i]); d[i] = x[i] - c; n2 += d[i] * d[i]; }
+    if (n2 > 1e-16) { double in = 1 / sqrt(n2); for (int i = 0; i < 3; i++) q[i] = d[i] * in; }
+    else {   /* inside the box: normal of the nearest face */
+        int best = 0; double bd = 1e300, sg = 1;
+        for (int i = 0; i < 3; i++) { double hi = p->ob[j][i] - x[i], lo = x[i] + p->ob[j][3 + i]; if (hi < bd) { bd = hi; best = i; sg = 1; } if (lo < bd) { bd = lo; best = i; sg = -1; } }
+        q[best] = sg;
+    }
+    for (int i = 0; i < 3; i++) { lam[i] = q[i] > 0 ? q[i] : 0; lam[3 + i] = q[i] < 0 ? -q[i] : 0; }
+}
+static double min_norm2(const model_t *M, const double *v) {
+    const prob_t *p = M->p; const lay_t *l = &M->l; double mn = 1e300;
+    for (int k = 0; k <= p->N; k++) for (int j = 0; j < NOB; j++) { const double *lam = v + l->lam + NL * (k * NOB + j); double n2 = 0;
+        for (int i = 0; i < 3; i++) n2 += (lam[i] - lam[3 + i]) * (lam[i] - lam[3 + i]); if (n2 < mn) mn = n2; }
+    return mn;
+}
+static void restore_blocks(const model_t *M, const opts_t *o, double *v, double *y, double *zL) {
+    const prob_t *p = M->p; const lay_t *l = &M->l; const double pl = o->bound_push;
+    for (int k = 0; k <= p->N; k++) for (int j = 0; j < NOB; j++) {
+        const int bo = k * NOB + j; double *lam = v + l->lam + NL * bo, c[2], q[3];
+        dual_ws_block(p, j, v + l->x + NXS * k, lam);
+        obs_rows(p, j, v + l->x + NXS * k, lam, v[l->s + bo], 0.0, c, q);
+        v[l->so + bo] = c[1] < pl ? pl : c[1];
+        for (int i = 0; i < NL; i++) { if (lam[i] < pl) lam[i] = pl; zL[l->lam + NL * bo + i] = 1.0; }
+        if (!p->dist) { if (v[l->s + bo] < pl) v[l->s + bo] = pl; zL[l->s + bo] = 1.0; }
+        zL[l->so + bo] = 1.0;
+        y[l->yo + 2 * bo] = 0.0; y[l->yo + 2 * bo + 1] = 0.0;
+    }
+}
+
 /* -------------------------------------------------------------- interior-point driver */
 typedef struct { int status, iters, nreg; double obj, pinf, dinf, mu, t; } result_t;
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 #define FILT_MAX 4096
 
+#define RESTORE_AND_CONTINUE do { restore_blocks(M, o, v, y, zL); nrest++; mu = o->mu_init; tau = fmax(o->tau_min, 1 - mu); nf = 0; dw_last = 0; \
+        eval_f_theta(M, v, &f, &th, &thinf); th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th); goto next_iter; } while (0)
 static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, double *zL, double *zU, result_t *res) {
     const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, n = l->n, m = l->m;
     kkt_t *K = kkt_alloc(M);
@@ -549,7 +594,11 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
     double f, th, thinf;
     eval_f_theta(M, v, &f, &th, &thinf);
     double th_min = 1e-4 * fmax(1, th), th_max = 1e4 * fmax(1, th);
-    int it = 0, status = ST_USERLIMIT, nreg = 0; double last_pinf = 0, last_dinf = 0;
+    int it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0; double last_pinf = 0, last_dinf = 0;
+    if (min_norm2(M, v) < 1e-12) {      /* rank-deficient start (the reference's lambda = 0.05): restoration before the first iteration */
+        restore_blocks(M, o, v, y, zL); nrest++;
+        eval_f_theta(M, v, &f, &th, &thinf); th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th);
+    }
     for (;;) {
         kkt_assemble(K, v, y, zL, zU, mu, 0, 0);
         double dinf = fmax(K->dinf, stage_dual_inf(K, y)), pinf = K->pinf, cinf0 = K->cinf0;
@@ -582,7 +631,10 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
             if (dw == 0) dw = dw_last == 0 ? o->dw0 : fmax(o->dw_min, o->kw_dec * dw_last); else dw *= (dw_last == 0 ? o->kw_inc0 : o->kw_inc);
             if (dw > o->dw_max) break;
         }
-        if (!ok) { status = ST_ERROR; break; }
+        if (!ok) {
+            if (nrest < MAX_RESTORE) { RESTORE_AND_CONTINUE; }
+            status = ST_ERROR; break;
+        }
         if (dw > 0) dw_last = dw;
         double ap = 1, az = 1, gd = 0;
         {   /* bound multiplier steps, fraction to the boundary, directional derivative of the barrier function */
@@ -624,7 +676,10 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
             }
             alpha *= 0.5;
         }
-        if (!acc) { status = ST_ERROR; break; }
+        if (!acc) {
+            if (nrest < MAX_RESTORE) { RESTORE_AND_CONTINUE; }
+            status = ST_ERROR; break;
+        }
         double ay = fmin(alpha, az);
         for (int i = 0; i < n; i++) v[i] += alpha * dv[i];
         for (int i = 0; i < m; i++) y[i] += ay * dy[i];
@@ -634,6 +689,7 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
             if (isfinite(M->ub[i])) { double d = M->ub[i] - v[i], z = zU[i] + az * dzU[i], lo = mu / (o->kappa_sigma * d), hi = o->kappa_sigma * mu / d; zU[i] = z < lo ? lo : (z > hi ? hi : z); }
         }
         it++;
+        next_iter:;
     }
     eval_f_theta(M, v, &f, &th, &thinf);
     res->status = status; res->iters = it; res->nreg = nreg; res->obj = f; res->pinf = last_pinf; res->dinf = last_dinf; res->mu = mu; res->t = v[l->t];
@@ -654,25 +710,14 @@ int obca_oracle_quad_layout(int N, int *out /* 11 ints */) { lay_t l; make_layou
 /*
  * Dual warm start (the quadcopter analogue of DualMultWS.jl): the reference starts every lambda at 0.05 (:204-208), where
  * A'lambda = 0, so the gradient of the row |A'lambda|^2 == 1 vanishes and the constraint Jacobian is rank deficient; IPOPT gets
- * away from that point through its restoration phase (the authors mention its messages, mainQuadcopter.jl:140), which this
- * solver does not have.  With dual_ws != 0 the lambdas start at the closed-form dual solution of the point-to-box distance at
+ * away from that point through its restoration phase (the authors mention its messages, mainQuadcopter.jl:140); here the block
+ * restoration above plays that part.  With dual_ws != 0 the lambdas start at the closed-form dual solution of the point-to-box distance at
  * the warm-start position: q = unit vector from the box to the point (or the least-penetration face normal inside the box),
  * lambda = [max(q,0); max(-q,0)], so that |A'lambda| = 1 and the separation row equals the (signed) distance.
  */
 static void quad_dual_ws(const prob_t *p, const lay_t *l, double *v) {
     for (int k = 0; k <= p->N; k++)
-        for (int j = 0; j < NOB; j++) {
-            const double *x = v + l->x + NXS * k; double *lam = v + l->lam + NL * (k * NOB + j);
-            double d[3], n2 = 0, q[3] = {0, 0, 0};
-            for (int i = 0; i < 3; i++) { double hi = p->ob[j][i], lo = -p->ob[j][3 + i], c = x[i] < lo ? lo : (x[i] > hi ? hi : x[i]); d[i] = x[i] - c; n2 += d[i] * d[i]; }
-            if (n2 > 1e-16) { double in = 1 / sqrt(n2); for (int i = 0; i < 3; i++) q[i] = d[i] * in; }
-            else {   /* inside the box: normal of the nearest face */
-                int best = 0; double bd = 1e300, sg = 1;
-                for (int i = 0; i < 3; i++) { double hi = p->ob[j][i] - x[i], lo = x[i] + p->ob[j][3 + i]; if (hi < bd) { bd = hi; best = i; sg = 1; } if (lo < bd) { bd = lo; best = i; sg = -1; } }
-                q[best] = sg;
-            }
-            for (int i = 0; i < 3; i++) { lam[i] = q[i] > 0 ? q[i] : 0; lam[3 + i] = q[i] < 0 ? -q[i] : 0; }
-        }
+        for (int j = 0; j < NOB; j++) dual_ws_block(p, j, v + l->x + NXS * k, v + l->lam + NL * (k * NOB + j));
 }
 
 /*

@@ -33,7 +33,7 @@ static void setup(int N, const double *prob, Scratch &s) {
     c.wa = (c.fixTime || c.dist) ? 0.5 : 0.1; c.wpsi = c.fixTime ? 1e-2 : 1e-4;
     make_layout(c.N, c.nOb, c.M, sh.l);
     int vmx = 0; for (int j = 0; j < c.nOb; j++) if (sh.vOb[j] > vmx) vmx = sh.vOb[j];
-    sh.vm2 = vmx <= 2;
+    sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
 }
 
 extern "C" {
@@ -46,13 +46,13 @@ int emu_newton(int N, const double *prob, const double *zin, int len, double mu,
     memcpy(s.z, zin, sizeof(double) * len);
     setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
     AsmOut A;
-    if (sh.vm2) assemble_obs<2>(I, sh, mu, dw, dc); else assemble_obs<OB_VMAX>(I, sh, mu, dw, dc);
+    if (sh.vmc == 0) assemble_obs<2>(I, sh, mu, dw, dc); else if (sh.vmc == 1) assemble_obs<OB_VMID>(I, sh, mu, dw, dc); else assemble_obs<OB_VMAX>(I, sh, mu, dw, dc);
     assemble_stage(I, sh, mu, dw, dc, A);
     int ok = A.ok;
     StepOut S; S.ap = S.az = S.gd = 0;
     if (ok) ok = riccati_backward(I, sh, rho);
     if (ok) { direction_main(I, sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; }
-    if (ok) { if (sh.vm2) direction_obs<2>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX>(I, sh, mu, dw, dc, tau, S); }
+    if (ok) { if (sh.vmc == 0) direction_obs<2>(I, sh, mu, dw, dc, tau, S); else if (sh.vmc == 1) direction_obs<OB_VMID>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX>(I, sh, mu, dw, dc, tau, S); }
     memcpy(dout, s.d, sizeof(double) * len);
     aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = A.cinfmu; aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
     aux[7] = S.ap; aux[8] = S.az; aux[9] = S.gd;
@@ -64,7 +64,7 @@ int emu_eval_trial(int N, const double *prob, const double *zin, const double *d
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len); memcpy(s.d, din, sizeof(double) * len);
     setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
-    if (sh.vm2) eval_trial<2>(I, sh, alpha, out3[0], out3[1], out3[2]); else eval_trial<OB_VMAX>(I, sh, alpha, out3[0], out3[1], out3[2]);
+    if (sh.vmc == 0) eval_trial<2>(I, sh, alpha, out3[0], out3[1], out3[2]); else if (sh.vmc == 1) eval_trial<OB_VMID>(I, sh, alpha, out3[0], out3[1], out3[2]); else eval_trial<OB_VMAX>(I, sh, alpha, out3[0], out3[1], out3[2]);
     free_scratch(s);
     return 0;
 }
@@ -101,7 +101,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
 int emu_dualws(int v, const double *a1, const double *a2, const double *b, const double *g, double ex, double ey, double cs, double sn,
                double *lam, double *mu, double *d) {
     double l4[OB_VMAX], m4[4];
-    dualws_one(v, a1, a2, b, g, ex, ey, cs, sn, l4, m4, d);
+    dualws_one<OB_VMAX>(v, a1, a2, b, g, ex, ey, cs, sn, l4, m4, d);
     for (int i = 0; i < v; i++) lam[i] = l4[i];
     for (int i = 0; i < 4; i++) mu[i] = m4[i];
     return 0;

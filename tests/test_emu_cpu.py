@@ -157,3 +157,40 @@ def test_emu_sliced_solve_is_bit_identical(oracle, emu, backwards, budget, max_i
         passes = int(ia[1] + ia[6])
         assert launches > 1 and launches >= int(ia[1]) // budget          # the cut falls between iterations
         assert np.array_equal(ia, ib) and np.array_equal(za, zb)
+
+
+def test_emu_wide_obstacles_match_oracle(oracle, emu):
+    """obstacles with 5..8 half-space rows (obstHrep.jl emits one row per polygon edge for any vertex count): the OB_VMAX = 8 instantiation of the
+    (stage, obstacle) block code against the oracle -- Newton direction sizes, DualMultWS and the full solve"""
+    N = 16
+    bt = S.make_mixed_batch(6, N, seed=11, rows=(5, 8), max_extra=4)
+    oo = oracle.default_opts(); eo = EOpts()
+    for n, _ in EOpts._fields_:
+        setattr(eo, n, getattr(oo, n))
+    done = 0
+    for i in range(6):
+        v = np.asarray(bt["vOb"][i]); A = bt["A"][i]; b = bt["b"][i]
+        if v.max() <= 4:
+            continue
+        nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, dWS = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        # DualMultWS sub-problem of the widest obstacle through the emulated kernel code
+        j = int(np.argmax(v)); r0 = int(v[:j].sum()); vj = int(v[j]); k = 3
+        a1 = np.ascontiguousarray(A[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(A[r0:r0 + vj, 1]); bj = np.ascontiguousarray(b[r0:r0 + vj])
+        lam = np.zeros(8); mu = np.zeros(4); d = C.c_double(0); cs, sn = np.cos(xWS[k, 2]), np.sin(xWS[k, 2]); g = np.array([2.35, 1.0, 2.35, 1.0])
+        emu.emu_dualws(C.c_int(vj), dp(a1), dp(a2), dp(bj), dp(g), C.c_double(xWS[k, 0] + 1.35 * cs), C.c_double(xWS[k, 1] + 1.35 * sn), C.c_double(cs), C.c_double(sn),
+                       dp(lam), dp(mu), C.byref(d))
+        assert abs(d.value - dWS[k, j]) < 1e-9 and np.abs(lam[:vj] - lWS[k, r0:r0 + vj]).max() < 1e-8
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b,
+                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        zo = np.zeros_like(z0); info = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+        assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"]
+        assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
+        assert np.abs(lp - r["lp"]).max() < 1e-5
+        done += 1
+    assert done >= 2

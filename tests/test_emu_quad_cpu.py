@@ -50,20 +50,22 @@ def test_emu_quad_newton_direction_matches_oracle(Q, emu):
     assert np.allclose(aux[:3], errs, rtol=1e-10)
 
 
-@pytest.mark.parametrize("N", [16, 30])
-def test_emu_quad_full_solve_matches_oracle(Q, emu, N):
+@pytest.mark.parametrize("N,dws", [(16, 1), (30, 1), (16, 0), (100, 0)], ids=["N16", "N30", "reference_start", "reference_start_N100_beyond_64"])
+def test_emu_quad_full_solve_matches_oracle(Q, emu, N, dws):
+    """dws = 0: the reference's own start (lambda = 0.05, block restoration before the first iteration); N = 100: a horizon of the size
+    mainQuadcopter.jl's A* path produces (N_as >= 80), beyond the former limit of 64"""
     Ts = round(0.25 * 80 / N * 100) / 100
-    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
-    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA if N < 60 else [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)])
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=dws)
     oo = Q.default_opts(); eo = EOpts()
     for f, _ in EOpts._fields_:
         setattr(eo, f, getattr(oo, f))
-    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=dws)
     z = np.zeros(L["len"]); info = np.zeros(8)
     emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
     assert r["exitflag"] == 1 and info[0] == 0 and info[7] == 1
-    assert int(info[1]) == r["iters"]
-    assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"])
+    assert int(info[1]) == r["iters"] and int(info[6]) == r["nreg"]
+    assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"])
     xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T; up = z[L["u"]:L["t"]].reshape(N, 4).T
     assert np.abs(xp - r["xp"]).max() < 1e-4 and np.abs(up - r["up"]).max() < 1e-5 and abs(z[L["t"]] - r["t"]) < 1e-9
 

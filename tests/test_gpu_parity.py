@@ -306,8 +306,11 @@ def test_receding_horizon_restart_on_the_device(OA, oracle):
 def test_bad_inputs_fail_loudly_not_crash(OA):
     N = 10; bt = S.make_batch(S.BACKWARDS, 2, N)
     xWS = bt["xWS"].copy()
-    with pytest.raises(OA.ObcaError):      # 5 rows in one obstacle > OBCA_VMAX
-        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [5], np.zeros((5, 2)), np.zeros(5),
+    with pytest.raises(OA.ObcaError):      # 9 rows in one obstacle > OBCA_VMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [9], np.zeros((9, 2)), np.zeros(9),
+                                     xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    with pytest.raises(OA.ObcaError):      # 6 x 7 = 42 rows in one instance > OBCA_MMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [7] * 6, np.ones((42, 2)), np.zeros(42),
                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
     with pytest.raises(OA.ObcaError):      # 11 obstacles > OBCA_NOBMAX
         OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [1] * 11, np.ones((11, 2)), np.zeros(11),
@@ -324,3 +327,27 @@ def test_iteration_limit_and_retry_exitflag(OA, oracle):
     o = OA.default_opts(); o.max_iter = 3
     out, _ = _solve_batch(OA, bt, opts=o)
     assert np.all(out["exitflag"] == 0) and np.all(out["iters"] == 6) and np.all(out["status"] == 1)   # two attempts (:256-290)
+
+
+def test_wide_obstacles_up_to_eight_rows(OA, oracle):
+    """polygons with 5..8 edges (OBCA_VMAX = 8; obstHrep.jl:31-102 emits one row per edge): the widest instantiation of the block code and of
+    the DualMultWS kernel through the C ABI against the oracle, in one batch with narrow instances (per-instance dispatch of the block size)"""
+    N, B = 40, 24
+    bt = S.make_mixed_batch(B, N, seed=11, rows=(5, 8), max_extra=4)
+    assert max(int(np.max(v)) for v in bt["vOb"]) >= 7 and min(int(np.max(v)) for v in bt["vOb"]) == 2
+    out, xWS = _solve_batch(OA, dict(bt, N=N))
+    ls, ns, ds = OA.dualmult_ws_batch(N, bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], bt["ego"])
+    assert (out["exitflag"] == 1).mean() >= 0.9
+    n = 0
+    for i in range(B):
+        if np.max(bt["vOb"][i]) <= 4 and i % 4:
+            continue
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i],
+                                       bt["b"][i], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        lo, no, do = oracle.dualmult_ws(N, bt["vOb"][i], bt["A"][i], bt["b"][i], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], bt["ego"])
+        assert np.abs(ds[i] - do).max() < 1e-9 and np.abs(ls[i] - lo).max() < 1e-7
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"]
+        if r["exitflag"] == 1:
+            assert abs(out["obj"][i] - r["obj"]) <= TOL_F * max(1, abs(r["obj"])) and np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+        n += 1
+    assert n >= 8

@@ -29,7 +29,7 @@ def test_quad_shipped_scenario_matches_oracle(Q):
     r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, ob, xWS, 1.0)
     assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
     assert xp.shape == (12, N + 1) and up.shape == (4, N) and lp.shape == (30, N + 1) and ts.shape == (N + 1,)
-    assert np.abs(xp - r["xp"]).max() < 1e-5 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(ts - r["timeScale"]).max() < 1e-8
+    assert np.abs(xp - r["xp"]).max() < 1e-6 and np.abs(up - r["up"]).max() < 1e-6 and np.abs(ts - r["timeScale"]).max() < 1e-9
     assert np.abs(lp - r["lp"]).max() < 1e-4
     assert _clearance(xp, ob).min() >= S.QUAD_R - 2e-3
 
@@ -45,15 +45,21 @@ def test_quad_batch_parity_and_feasibility(Q):
     for rep in range(4):        # repeated solves are bit-identical (no race between the two wavefronts of an instance)
         o2 = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
         assert np.array_equal(o2["iters"], out["iters"]) and np.abs(o2["xp"] - out["xp"]).max() == 0.0, rep
-    n_it = 0
-    for i in range(6):
+    # Two fp64 implementations of the same iteration: iteration counts, regularisation counts, objective, time scale and inputs agree tightly.
+    # Positions and multipliers agree only to ~1e-4 / 1e-2: the cost has no term on the path (QuadcopterSignedDist.jl:110-128), so the minimiser is
+    # not unique along flat directions and round-off decides where on the optimal face the iteration stops (measured between the oracle and the
+    # host emulation of this very kernel source at identical iteration counts: 4e-5 in x, 1.6e-2 in lambda, 5e-11 in the objective).
+    flips = []
+    for i in range(12):
         r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0)
         assert r["exitflag"] == out["exitflag"][i]
         if r["exitflag"] == 1:
-            assert abs(out["obj"][i] - r["obj"]) < 1e-6 * abs(r["obj"])
-            assert np.abs(out["xp"][i] - r["xp"]).max() < 1e-3 and abs(out["timeScale"][i, 0] - r["t"]) < 1e-6
-            n_it += int(out["iters"][i] == r["iters"])
-    assert n_it >= 4          # identical iteration counts except where round-off flips an inertia test
+            assert abs(out["obj"][i] - r["obj"]) < 1e-8 * abs(r["obj"])
+            assert abs(out["timeScale"][i, 0] - r["t"]) < 1e-8 and np.abs(out["up"][i] - r["up"]).max() < 1e-5
+            assert np.abs(out["xp"][i] - r["xp"]).max() < 1e-3
+            if out["iters"][i] != r["iters"] or out["info"][i, 6] != r["nreg"]:
+                flips.append((i, int(out["iters"][i]), r["iters"]))
+    assert len(flips) <= 1, flips          # an inertia test decided by round-off (Quu pivot ~ 0) may take a different branch: at most one in twelve
     # size-independent properties on every converged instance: bounds, terminal state, dynamics residual, clearance >= R
     from nlp_ref_quad import XLB, XUB
     import oracle_quad
@@ -81,6 +87,28 @@ def test_quadcopter_dist_variant_matches_oracle(Q):
     assert (out["exitflag"] == 1).mean() >= 0.9 and np.abs(out["slack"]).max() == 0
     for i in np.where(out["exitflag"] == 1)[0]:
         assert _clearance(out["xp"][i], bt["ob"]).min() >= bt["R"] - 1e-4
+
+
+def test_reference_main_call_runs_as_is(Q):
+    """mainQuadcopter.jl's own call sequence: the 3-D A* path on the 1.0 grid from x = 10 to x = 90 gives N_as >= 80 way-points (:116-129), Ts_as is
+    rounded to two decimals (:131), the warm start stacks the path positions with zeros (:134-136), the boxes are the ones clamped by the plot call
+    (SURVEY Q3), and BOTH functions are called with the reference's start lambda = 0.05 (QuadcopterDist :145, QuadcopterSignedDist :152)"""
+    import obca_amd
+    from obca_amd import scenarios as S, planner as PL, validate as V
+    path = PL.astar3d(S.QUAD_X0[:3], S.QUAD_XF[:3], res=0.1)              # grid resolution 1.0 in the reference's x10 scaled units
+    assert path is not None
+    N_as = len(path) - 1
+    assert 80 <= N_as <= 128, N_as
+    Ts_as = round((0.25 * 80 / N_as) * 100) / 100                        # :131 with Ts = 0.25
+    xWS = np.zeros((N_as + 1, 12)); xWS[:, :3] = path                     # = the reference's 12 x (N_as+1) array, column-major
+    for fn, orc in ((obca_amd.QuadcopterDist, Q.quadcopter_dist), (obca_amd.QuadcopterSignedDist, Q.quadcopter_signed_dist)):
+        xp, up, ts, ef, t, lp, status = fn(S.QUAD_X0, S.QUAD_XF, N_as, Ts_as, S.QUAD_R, *S.QUAD_OB, xWS, 0.5 * np.ones((N_as, 4)), 1, dual_ws=False)
+        r = orc(Q.X0, Q.XF, N_as, Ts_as, Q.EGO_R, S.QUAD_OB, xWS, 1.0, dual_ws=0)
+        assert ef == 1 and r["exitflag"] == 1 and status == "Optimal", (fn.__name__, ef, status)
+        assert xp.shape == (12, N_as + 1) and up.shape == (4, N_as) and lp.shape == (30, N_as + 1)
+        assert abs(ts[0] - r["t"]) < 1e-8 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(xp - r["xp"]).max() < 1e-3
+        ok, w = V.validate_quadcopter(xp, up, ts, S.QUAD_X0, S.QUAD_XF, Ts_as, lp, S.QUAD_OB, S.QUAD_R)
+        assert ok, (fn.__name__, w)
 
 
 def test_quad_random_endpoints_with_astar_warm_starts(Q):
@@ -112,4 +140,5 @@ def test_quad_matches_golden_fixture_config4():
     assert np.abs(out["obj"] - g["obj"]).max() < 1e-6 * np.abs(g["obj"]).max()
     assert np.abs(out["xp"] - g["xp"]).max() < 1e-3 and np.abs(out["up"] - g["up"]).max() < 1e-3
     assert np.abs(out["timeScale"][:, 0] - g["t"]).max() < 1e-6
+    assert np.abs(out["up"] - g["up"]).max() < 1e-5
     assert (out["iters"] == g["iters"]).sum() >= B - 1        # round-off may flip one inertia test

@@ -79,14 +79,16 @@ def test_quad_shipped_scenario_solves_and_is_feasible(Q):
             assert d >= Q.EGO_R - 2e-3, (k, j, d)
 
 
-def test_quad_reference_start_is_rank_deficient(Q):
-    """documents why the dual warm start exists: at lambda = 0.05 (QuadcopterSignedDist.jl:204-208) A'lambda = 0 and the row
-    |A'lambda|^2 == 1 has a zero gradient; without IPOPT's restoration phase the solve stalls"""
-    N = 20; Ts = 1.0
-    xWS = Q.warm_start(Q.X0, Q.XF, N, [(2.25, 1.5, 0.3), (7.25, 4.5, 2.5)])
-    o = Q.default_opts(); o.max_iter = 60
-    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, o, dual_ws=0)
-    assert r["exitflag"] == 0
+def test_quad_reference_start_converges_through_block_restoration(Q):
+    """the reference's start lambda = 0.05 (QuadcopterSignedDist.jl:204-208) has A'lambda = 0: the row |A'lambda|^2 == 1 has a zero gradient
+    there (rank-deficient Jacobian; IPOPT leaves it through its restoration phase).  The block restoration (closed-form minimiser of the block's
+    constraint violation at fixed positions) runs before the first iteration and the solve converges to the optimum of the dual-warm-start run"""
+    for N, Ts, via in ((20, 1.0, [(2.25, 1.5, 0.3), (7.25, 4.5, 2.5)]), (60, 0.33, [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)])):
+        xWS = Q.warm_start(Q.X0, Q.XF, N, via)
+        r0 = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=0)
+        r1 = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=1)
+        assert r0["exitflag"] == 1 and r1["exitflag"] == 1
+        assert abs(r0["obj"] - r1["obj"]) < 1e-9 * abs(r1["obj"]) and abs(r0["t"] - r1["t"]) < 1e-9
 
 
 def test_quadcopter_dist_variant_solves_collision_free(Q):
