@@ -1,8 +1,8 @@
 // obca_hip.hip -- HIP kernels and the C ABI of libobca_hip.so (gfx950 only; see include/obca_hip.h).
 //
 // Kernels
-//   obca_parking_ipm_kernel : one 128-thread workgroup (two wavefronts) per problem instance, persistent over the whole
-//                             interior-point solve (obca_solver.h).  grid = B, block = 128.
+//   obca_parking_ipm_kernel : one wavefront (64-thread workgroup) per problem instance, persistent over the whole
+//                             interior-point solve (obca_solver.h).  grid = B, block = 64; four instances per CU.
 //   obca_quad_ipm_kernel    : the same for the quadcopter NLP (obca_quad_solver.h).
 //   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
@@ -35,14 +35,14 @@ struct DevBufs {
     size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
 };
 
-// One wavefront per SIMD (two instances per CU): each wave may then use 256 VGPRs + 256 AGPRs, and the register-hungry per-lane phases
+// One wavefront per SIMD (four one-wavefront instances per CU): each wave may then use 256 VGPRs + 256 AGPRs, and the register-hungry per-lane phases
 // keep their spills (and most callee-saved registers) in AGPRs instead of scratch.  Against two waves per SIMD with 256 registers each this
 // is faster at every batch size measured: a lone instance is ~10 % quicker per pass, and a full machine no longer streams the scratch
 // save areas through HBM.
 #ifndef OBCA_IPM_WAVES_PER_EU
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
-#define OBCA_RESIDENT_PER_CU (2 * OBCA_IPM_WAVES_PER_EU)   // instances (workgroups of two wavefronts) resident per CU
+#define OBCA_RESIDENT_PER_CU (4 * OBCA_IPM_WAVES_PER_EU)   // parking instances (one wavefront each) resident per CU
 __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
@@ -167,7 +167,7 @@ struct QDevBufs {
 #ifndef OBCA_QUAD_WAVES_PER_EU
 #define OBCA_QUAD_WAVES_PER_EU 1      // as for the parking kernel
 #endif
-__global__ __launch_bounds__(OB_NT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
+__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
     if (threadIdx.x == 0) {
@@ -385,7 +385,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         bt->zlen = lmax.len;
         DevBufs &d = bt->d;
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
-        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_traj = (size_t)(N + 2) * 6;
+        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_traj = std::max((size_t)(N + 2) * 6, (size_t)(N / 2) * 42);   // traj: composed stage-pair maps of the forward sweep
         size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(bt, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
@@ -570,11 +570,11 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
     for (int w = 0; w < nw; w++) if (rcs[w]) { ctx->err = errs[w]; return rcs[w]; }
     return 0;
 }
-static int pick_chunk(const obca_ctx *ctx, int B) {
+static int pick_chunk(const obca_ctx *ctx, int B, int resident_per_cu) {
     // twice the instances resident on one GPU per chunk: measured best on config-2 batches (PCIe-inclusive, 4 lanes: 92-98 k solves/s against 75 k
     // with 256-instance chunks) -- what counts is the number of instances in flight (lanes x chunk), which must cover the heavy tail of the
     // solve times several times over; chunks beyond the resident capacity use the two-launch schedule of batch_solve
-    int chunk = 2 * OBCA_RESIDENT_PER_CU * (ctx->cus > 0 ? ctx->cus : 256);
+    int chunk = (resident_per_cu >= 4 ? 1 : 2) * resident_per_cu * (ctx->cus > 0 ? ctx->cus : 256);      // 1024 on a 256-CU part for both paths
     if (const char *e = getenv("OBCA_CHUNK")) { const int v = atoi(e); if (v > 0) chunk = v; }
     // small calls: still give every slot something to do once there is enough work to hide a transfer behind
     const int ns = (int)ctx->slots.size();
@@ -594,7 +594,7 @@ static int parking_call(obca_ctx *ctx, int dist, int dualws_only, int B, int N, 
     if (!in.Ts || !in.ego || !in.XYb || !in.nOb || !in.vOb || !in.A || !in.b || !in.rx || !in.ry || !in.ryaw) { ctx->err = "NULL argument"; return -1; }
     if (!dualws_only && N < 2) { ctx->err = "the NLP needs a horizon N>=2"; return -1; }
     if (int rc = park_prefix(ctx->err, B, in.nOb, in.vOb, in)) return rc;
-    const int chunk = pick_chunk(ctx, B);
+    const int chunk = pick_chunk(ctx, B, OBCA_RESIDENT_PER_CU);
     return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
         int rc = slot_parking_batch(ctx, s, std::min(chunk, B), N, dist, err);
         if (rc) return rc;
@@ -846,7 +846,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), 0, bt->stream, bt->B, bt->N, bt->d, ko);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;
@@ -855,7 +855,7 @@ static int quadcopter_call(obca_ctx *ctx, int B, int N, const QuadIn &in, const 
     if (!ctx) return -1;
     if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { ctx->err = "need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
     if (!in.Ts || !in.x0 || !in.xF || !in.ob || !in.xWS || !in.timeWS) { ctx->err = "NULL argument"; return -1; }
-    const int chunk = pick_chunk(ctx, B);
+    const int chunk = pick_chunk(ctx, B, 2 * OBCA_QUAD_WAVES_PER_EU);
     return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
         if (s.qb && (s.qb->cap < n || s.qb->N != N)) { obca_quad_batch_destroy(s.qb); s.qb = nullptr; }
         if (!s.qb) { int rc = quad_batch_create_on(ctx, s.device, s.stream, std::min(chunk, B), N, &s.qb, err); if (rc) return rc; }

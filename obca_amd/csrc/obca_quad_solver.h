@@ -10,6 +10,7 @@
 namespace obca {
 namespace quad {
 
+#define QNT 128                      // threads per instance: two wavefronts (the 16-state sweep has 288..680 items per phase)
 #define QNMAX 128                    // longest horizon (the forward-sweep trajectory lives in LDS: (QNMAX + 2) x 16 doubles)
 #define QSR 736                      // doubles per stage record: H 20x20 | Fh 16x18 | hc 20x2
 #define QSR_H 0
@@ -24,6 +25,17 @@ namespace quad {
 #define QFILT 224
 #define QFC 18                       // columns of Fh
 #define QQC (QZ + QC)                // columns of the extended matrix (34)
+
+#ifdef OBCA_EMU
+#define QPAR(lane) for (int lane = 0; lane < QNT; ++lane)
+#define QNLT QNT
+#else
+#define QPAR(lane) PAR(lane)
+#define QNLT 1
+#endif
+OBCA_FN double red_sum(const double *r) { return red_sum_t<QNT>(r); }      // (hide the one-wavefront reductions of the parking solver)
+OBCA_FN double red_max(const double *r) { return red_max_t<QNT>(r); }
+OBCA_FN double red_min(const double *r) { return red_min_t<QNT>(r); }
 
 struct QLay { int x, u, t, lam, s, so, n, pi, nu, yo, m, zL, zU, len; };   // iterate buffer: v[n] | y[m] | zL[n] | zU[n]
 OBCA_HD void q_make_layout(int N, QLay &l) {
@@ -48,7 +60,7 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R
 struct QShared {
     QConsts c; QLay l; QInst inst; AsmOut A, A2, Ap; StepOut S; double trial[4];
     double ob[QOB * QL];
-    double red[16][OB_NT];               // reductions; during the sweeps the same memory holds That|Qhat or the forward-sweep ring
+    double red[16][QNT];               // reductions; during the sweeps the same memory holds That|Qhat or the forward-sweep ring
     double Pn[QS * QS], pn[QS * QC], sg[QSR], Khat[QU * 30], Bm[QC * QC], sB[4 * QC], Lq[QU * QU];
     double bord[13 * 13 + 3 * 13], coef[QC];
     double traj[(QNMAX + 2) * QS];
@@ -91,10 +103,10 @@ OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &
 // ---------------------------------------------------------------- assemble, part (a): box blocks
 OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z;
-    PAR(lane) {
+    QPAR(lane) {
         QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
         double fsl = 0, th = 0, bar = 0;
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
             ObsCond cd;
@@ -136,9 +148,9 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
-    PAR(lane) {
+    QPAR(lane) {
         double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lgtb = 0, lgtz = 0;
-        for (int k = lane; k <= N; k += OB_NT) {
+        for (int k = lane; k <= N; k += QNT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSR;
             double x[QX], hz[QX], hb[QX], xd[QX], Hpos[6] = {0, 0, 0, 0, 0, 0};
             BarAcc ba, bb, bu; bar_init(ba); bar_init(bb); bar_init(bu);      // barrier distances: states 0..5, states 6..11, inputs
@@ -307,7 +319,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #define QTH(a, tc) That[(a) * QTC + (tc)]
 #define QQH(i, cI) Qhat[(i) * QQC + (cI)]
 #define QRIC_D 2
-#define QREC_PER ((QSR + OB_NT - 1) / OB_NT)     // doubles of one stage record per lane (6)
+#define QREC_PER ((QSR + QNT - 1) / QNT)     // doubles of one stage record per lane (6)
 OBCA_FN void q_pair(int p, int &a_, int &b_) { a_ = 0; int rem = p; while (rem >= QC - a_) { rem -= QC - a_; a_++; } b_ = a_ + rem; }
 
 // item maps, bit-packed so that the whole plan lives in 15 registers:
@@ -320,12 +332,12 @@ struct QRicPlan { unsigned a[3], b[6], d[4]; int pa, pb; };
 OBCA_FN void q_ric_plan(int lane, int off_That, int off_pn, QRicPlan &p) {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const int it = lane + OB_NT * r; const bool on = it < QS * QTC; const int tc = it % QTC;
+        const int it = lane + QNT * r; const bool on = it < QS * QTC; const int tc = it % QTC;
         p.a[r] = on ? (unsigned)(it / QTC) | (unsigned)tc << 5 | (unsigned)(tc >= 16 ? tc - 16 + 1 : 0) << 10 : 31u;
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        const int it = lane + OB_NT * r; const bool on = it < QZ * QQC;
+        const int it = lane + QNT * r; const bool on = it < QZ * QQC;
         const int i = on ? it / QQC : 0, cI = on ? it % QQC : 0;
         const bool wrow = i >= QX && i < QS, wcol = cI >= QX && cI < QS;
         const int h = cI < QZ ? QSR_H + i * QZ + cI : (cI < QZ + 2 ? QSR_HC + 2 * i + (cI - QZ) : QSR - 1);   // QSR-1: a zero of the record padding
@@ -338,7 +350,7 @@ OBCA_FN void q_ric_plan(int lane, int off_That, int off_pn, QRicPlan &p) {
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int it = lane + OB_NT * r; const bool on = it < QS * 30;
+        const int it = lane + QNT * r; const bool on = it < QS * 30;
         const int i = on ? it / 30 : 0, cc = on ? it % 30 : 0, qc = cc < QS ? cc : QZ + (cc - QS);
         const int rs = (on && i < QX) ? (cc < QS ? QRR_PX + i * QS + cc : QRR_PV + i * QC + (cc - QS)) : QRR_PAD;
         p.d[r] = (unsigned)(on ? i : 31) | (unsigned)cc << 5 | (unsigned)qc << 10 | (unsigned)rs << 16;
@@ -347,11 +359,11 @@ OBCA_FN void q_ric_plan(int lane, int off_That, int off_pn, QRicPlan &p) {
 }
 
 template <int PIPE>
-OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBCA_NLT], double (&nv)[OBCA_NLT][QRIC_D][QREC_PER], const int slot) {
-    double *That = &sh.red[0][0], *Qhat = That + QS * QTC;      // 288 + 680 doubles <= 16 * OB_NT
+OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[QNLT], double (&nv)[QNLT][QRIC_D][QREC_PER], const int slot) {
+    double *That = &sh.red[0][0], *Qhat = That + QS * QTC;      // 288 + 680 doubles <= 16 * QNT
     double *L = &sh.red[0][0];                                   // base of the plan's LDS offsets
     const double *sg = sh.sg;
-    PAR(lane) {   // A
+    QPAR(lane) {   // A
         const QRicPlan &p = plan[LI(lane)];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -367,11 +379,11 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
     }
     LDS_BARRIER();
     const int off_pn = (int)(sh.pn - L);
-    PAR(lane) {   // B
+    QPAR(lane) {   // B
         const QRicPlan &p = plan[LI(lane)];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const int it = lane + OB_NT * r;
+            const int it = lane + QNT * r;
             if (it < QZ * QQC) {
                 unsigned w = p.b[r]; QOPAQUE(w);
                 const int h = w & 1023, t = (w >> 10) & 4095, fx = (int)((w >> 22) & 31) - 1, id = (int)(w >> 27) - 1;
@@ -402,7 +414,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         for (int j = 0; j < QU; j++) Lq[i * QU + j] = QQH(QS + i, QS + j);
     const int ok = UNIFORM(ldl_fact<QU>(QU, Lq) ? 0 : 1);        // (no early exit, see the parking sweep)
     gdbl *ro = sh.inst.rs + (size_t)k * QRR;
-    PAR(lane) {
+    QPAR(lane) {
         const int cc = lane < 30 ? lane : 0, qc = cc < QS ? cc : QZ + (cc - QS);
         double b[QU];
 #pragma unroll
@@ -415,15 +427,15 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
         }
     }
     LDS_BARRIER();
-    PAR(lane) {   // D
+    QPAR(lane) {   // D
         const QRicPlan &p = plan[LI(lane)];
         if (PIPE) {   // park the record of stage k-1 (gathered QRIC_D stages ago) and re-issue the slot
             const int kl = k - 1 - QRIC_D > 0 ? k - 1 - QRIC_D : 0;
             const gdbl *rn = sh.inst.as + (size_t)kl * QSR;
 #pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; sh.sg[e < QSR ? e : QSR - 1] = e < QSR ? nv[LI(lane)][slot][r] : 0.0; }
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; sh.sg[e < QSR ? e : QSR - 1] = e < QSR ? nv[LI(lane)][slot][r] : 0.0; }
 #pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; nv[LI(lane)][slot][r] = rn[e < QSR ? e : QSR - 1]; }
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; nv[LI(lane)][slot][r] = rn[e < QSR ? e : QSR - 1]; }
         }
         double pv[4];
 #pragma unroll
@@ -464,35 +476,35 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[OBC
 
 OBCA_FN int q_riccati_body(QShared &sh, double rho) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = UNIFORM(c.N); const gdbl *z = sh.inst.z;
-    double nv[OBCA_NLT][QRIC_D][QREC_PER];
-    QRicPlan plan[OBCA_NLT];
-    PAR(lane) {
+    double nv[QNLT][QRIC_D][QREC_PER];
+    QRicPlan plan[QNLT];
+    QPAR(lane) {
         q_ric_plan(lane, 0, (int)(sh.pn - &sh.red[0][0]), plan[LI(lane)]);
         const gdbl *rec = sh.inst.as + (size_t)N * QSR;
-        for (int it = lane; it < QS * QS; it += OB_NT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
-        for (int it = lane; it < QS * QC; it += OB_NT) {
+        for (int it = lane; it < QS * QS; it += QNT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
+        for (int it = lane; it < QS * QC; it += QNT) {
             int i = it / QC, cc = it % QC; double v = 0;
             if (i < QX) { if (cc == 0) v = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
             sh.pn[it] = v;
         }
-        for (int it = lane; it < QC * QC; it += OB_NT) sh.Bm[it] = 0;
+        for (int it = lane; it < QC * QC; it += QNT) sh.Bm[it] = 0;
     }
     // head: synchronous gathers until the remaining stage count is a multiple of QRIC_D
     int k = N - 1;
     for (; k >= 0 && (k + 1) % QRIC_D != 0; k--) {
-        PAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSR; for (int i = lane; i < QSR; i += OB_NT) sh.sg[i] = r1[i]; }
+        QPAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSR; for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i]; }
         LDS_BARRIER();
         if (!q_riccati_stage<0>(sh, k, plan, nv, 0)) return 0;
     }
     if (k < 0) return 1;
-    PAR(lane) {
+    QPAR(lane) {
         const gdbl *r1 = sh.inst.as + (size_t)k * QSR;
-        for (int i = lane; i < QSR; i += OB_NT) sh.sg[i] = r1[i];
+        for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i];
 #pragma unroll
         for (int j = 0; j < QRIC_D; j++) {
             const int st = k - 1 - j > 0 ? k - 1 - j : 0; const gdbl *rn = sh.inst.as + (size_t)st * QSR;
 #pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + OB_NT * r; nv[LI(lane)][(j + 1) % QRIC_D][r] = rn[e < QSR ? e : QSR - 1]; }
+            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; nv[LI(lane)][(j + 1) % QRIC_D][r] = rn[e < QSR ? e : QSR - 1]; }
         }
 #ifndef OBCA_EMU
 #pragma unroll
@@ -511,7 +523,7 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
 }
 OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
     const int ok = q_riccati_body(sh, rho);
-    PAR(lane) { if (lane == 0) sh.ric_ok = ok; }
+    QPAR(lane) { if (lane == 0) sh.ric_ok = ok; }
     SYNC();
     return sh.ric_ok;
 }
@@ -633,11 +645,11 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     SYNC();
     QPROF(QPF_FWD);
     // ---- stage-parallel: steps of x, u; costate increments; step-length / descent partials of x, u
-    PAR(lane) {
+    QPAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
-        for (int k = lane; k <= N; k += OB_NT) {
+        for (int k = lane; k <= N; k += QNT) {
             const double *s = sh.traj + (size_t)k * QS;
             for (int i = 0; i < QX; i++) {
                 const double xv = z[l.x + QX * k + i], dx = s[i];
@@ -698,11 +710,11 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
     double ap = so.ap, az = so.az, gd = so.gd;
     const double dt = sh.coef[1];
-    PAR(lane) {
+    QPAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < laz) laz = cc_; }
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
             const double dp[3] = {d[l.x + QX * k], d[l.x + QX * k + 1], d[l.x + QX * k + 2]};
@@ -743,9 +755,9 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
 OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, double &bar) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z, *d = sh.inst.d;
     const double t = z[l.t] + alpha * d[l.t], tau = t * c.Ts;
-    PAR(lane) {
+    QPAR(lane) {
         double lf = 0, lth = 0, lbar = 0;
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
 #pragma unroll
@@ -764,7 +776,7 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
             lth += fabs(r[0]) + fabs(r[1]);
             if (!c.dist) lf += 1e2 * in.s + 1e3 * in.s * in.s;
         }
-        for (int k = lane; k <= N; k += OB_NT) {
+        for (int k = lane; k <= N; k += QNT) {
             double x[QX];
             BarAcc ba, bb, bu; bar_init(ba); bar_init(bb); bar_init(bu);
 #pragma unroll
@@ -800,8 +812,8 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
 // ---------------------------------------------------------------- accept the step (generic over the primal vector)
 OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, double mu, double ks) {
     const QLay &l = sh.l; const int N = sh.c.N; gdbl *z = sh.inst.z; const gdbl *d = sh.inst.d;
-    PAR(lane) {
-        for (int i = lane; i < l.n; i += OB_NT) {
+    QPAR(lane) {
+        for (int i = lane; i < l.n; i += QNT) {
             const QBnd b = q_bounds(l, N, i, sh.c.dist);
             double v = z[i]; const double dv = d[i];
             if (i < QX) continue;                        // x_0 is a constant
@@ -809,7 +821,7 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
             if (b.hasU) { double zz = zstep(z[l.zU + i], b.hi - v, -dv, mu, az); z[l.zU + i] = clampz(zz, b.hi - (v + alpha * dv), mu, ks); }
             z[i] = v + alpha * dv;
         }
-        for (int i = lane; i < l.m; i += OB_NT) z[l.n + i] += ay * d[l.n + i];
+        for (int i = lane; i < l.m; i += QNT) z[l.n + i] += ay * d[l.n + i];
     }
     SYNC();
 }
@@ -817,24 +829,24 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
 // ---------------------------------------------------------------- starting point
 OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, double timeWS, int dual_ws) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; gdbl *z = sh.inst.z;
-    PAR(lane) {
-        for (int i = lane; i < QX * (N + 1); i += OB_NT) z[l.x + i] = i < QX ? c.x0[i] : sh.inst.prob[QPH_SIZE + i];   // xWS, :201
-        for (int i = lane; i < QU * N; i += OB_NT) z[l.u + i] = c.wH;                       // QuadcopterSignedDist.jl:202
+    QPAR(lane) {
+        for (int i = lane; i < QX * (N + 1); i += QNT) z[l.x + i] = i < QX ? c.x0[i] : sh.inst.prob[QPH_SIZE + i];   // xWS, :201
+        for (int i = lane; i < QU * N; i += QNT) z[l.u + i] = c.wH;                       // QuadcopterSignedDist.jl:202
         if (lane == 0) z[l.t] = timeWS;                                                   // :199
-        for (int i = lane; i < QOB * (N + 1); i += OB_NT) z[l.s + i] = c.dist ? 0.0 : 1.0; // :210
-        for (int i = lane; i < l.m; i += OB_NT) z[l.n + i] = 0.0;
-        for (int i = lane; i < l.n; i += OB_NT) { z[l.zL + i] = 1.0; z[l.zU + i] = 1.0; }
+        for (int i = lane; i < QOB * (N + 1); i += QNT) z[l.s + i] = c.dist ? 0.0 : 1.0; // :210
+        for (int i = lane; i < l.m; i += QNT) z[l.n + i] = 0.0;
+        for (int i = lane; i < l.n; i += QNT) { z[l.zL + i] = 1.0; z[l.zU + i] = 1.0; }
         // stage / Riccati records: zero once, constants of the dense layout
-        for (int i = lane; i < (N + 1) * QSR; i += OB_NT) sh.inst.as[i] = 0.0;
+        for (int i = lane; i < (N + 1) * QSR; i += QNT) sh.inst.as[i] = 0.0;
     }
     SYNC();
-    PAR(lane) {
-        for (int k = lane; k <= N; k += OB_NT) {
+    QPAR(lane) {
+        for (int k = lane; k <= N; k += QNT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSR;
             for (int i = 0; i < 3; i++) { rec[QSR_F + i * QFC + i] = 1.0; rec[QSR_F + (6 + i) * QFC + (6 + i)] = 1.0; }
             for (int j = 0; j < QU; j++) rec[QSR_F + (QX + j) * QFC + QX + j] = 1.0;          // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
         }
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             double lam[QL], p[3] = {z[l.x + QX * k], z[l.x + QX * k + 1], z[l.x + QX * k + 2]};
             if (dual_ws) q_dual_ws(&sh.ob[j * QL], p, lam);
@@ -843,8 +855,8 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         }
     }
     SYNC();
-    PAR(lane) {   // row slack = row value at the start, then everything is pushed inside its bounds
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+    QPAR(lane) {   // row slack = row value at the start, then everything is pushed inside its bounds
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in); in.so = 0;
             double r[2], q[3]; q_obs_rows(c, in, r, q);
@@ -852,8 +864,8 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         }
     }
     SYNC();
-    PAR(lane) {
-        for (int i = lane; i < l.n; i += OB_NT) {
+    QPAR(lane) {
+        for (int i = lane; i < l.n; i += QNT) {
             if (i < QX) continue;
             const QBnd b = q_bounds(l, N, i, sh.c.dist);
             if (b.hasL && b.hasU) z[i] = push2(z[i], b.lo, b.hi, bound_push, bound_frac);
@@ -868,13 +880,13 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
 // Jacobian is rank deficient and IPOPT leaves the point through its restoration phase (the authors mention its messages, mainQuadcopter.jl:140).
 // For fixed positions the violation of the two rows of a (stage, box) block is minimised in closed form (point-to-box dual, q_dual_ws): the
 // restoration resets lambda / row slack / row multipliers / their bound multipliers of every block at the current positions and keeps
-// everything else; the driver then restarts the barrier parameter and clears the filter.  Same steps, same order as oracle/obca_oracle_quad.c.
+// everything else; the driver then restarts the barrier parameter and clears the filter.  Same steps, same order as the CPU checker of the tests.
 #define Q_MAX_RESTORE 3
 OBCA_FN double q_min_norm2(QShared &sh) {
     const QLay &l = sh.l; const int N = sh.c.N; const gdbl *z = sh.inst.z;
-    PAR(lane) {
+    QPAR(lane) {
         double mn = 1e300;
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             double n2 = 0;
 #pragma unroll
             for (int i = 0; i < 3; i++) { const double q = z[l.lam + QL * it + i] - z[l.lam + QL * it + 3 + i]; n2 += q * q; }
@@ -889,8 +901,8 @@ OBCA_FN double q_min_norm2(QShared &sh) {
 }
 OBCA_FN void q_restore_blocks(QShared &sh, double bound_push) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; gdbl *z = sh.inst.z;
-    PAR(lane) {
-        for (int it = lane; it < (N + 1) * QOB; it += OB_NT) {
+    QPAR(lane) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             double lam[QL]; const double p[3] = {z[l.x + QX * k], z[l.x + QX * k + 1], z[l.x + QX * k + 2]};
             q_dual_ws(&sh.ob[j * QL], p, lam);
@@ -926,7 +938,7 @@ OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double 
 // info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
 OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     QShared &sh = gq_sh;
-    PAR(lane) {
+    QPAR(lane) {
         if (lane == 0) {
             QConsts &c = sh.c; const gdbl *p = sh.inst.prob;
             c.N = N; c.dist = (int)p[QPH_DIST]; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
@@ -1003,7 +1015,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
                     else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
                         acc = 1;
                         if (!(sw && armijo) && nf < QFILT) {
-                            PAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
+                            QPAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
                             SYNC();
                             nf++;
                         }
@@ -1019,13 +1031,13 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     }
 #undef Q_RESTORE_AND_CONTINUE
     // exit flag: 1 = Optimal, 2 = Optimal but sum(slack) > 1e-3, 0 otherwise
-    PAR(lane) { double s_ = 0; for (int i = lane; i < QOB * (N + 1); i += OB_NT) s_ += sh.inst.z[sh.l.s + i]; sh.red[0][lane] = s_; }
+    QPAR(lane) { double s_ = 0; for (int i = lane; i < QOB * (N + 1); i += QNT) s_ += sh.inst.z[sh.l.s + i]; sh.red[0][lane] = s_; }
     SYNC();
     const double ssum = red_sum(sh.red[0]);
     SYNC();
     int ef = status == ST_OPTIMAL ? 1 : 0;
     if (!sh.c.dist && ef == 1 && ssum > 1e-3) ef = 2;
-    PAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f; info[3] = pinf; info[4] = dinf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
+    QPAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f; info[3] = pinf; info[4] = dinf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
     SYNC();
 }
 

@@ -1,5 +1,7 @@
-// obca_solver.h -- one OBCA parking NLP instance solved by ONE workgroup of OB_NT = 128 threads (two wavefronts, gfx950), persistent over
-// the whole interior-point solve; the kernel runs one wavefront per SIMD (256 VGPRs + 256 AGPRs per wave), two instances per CU.
+// obca_solver.h -- one OBCA parking NLP instance solved by ONE wavefront (workgroup of OB_NT = 64 threads, gfx950), persistent over the whole
+// interior-point solve; the kernel runs one wavefront per SIMD (256 VGPRs + 256 AGPRs per wave), FOUR instances per CU (25 KB of LDS each).
+// (Round 1 used two wavefronts per instance and two instances per CU: while wavefront 0 ran a sequential sweep the other one idled on its SIMD, and
+// every exchange between the two cost a workgroup barrier.  With the instance inside one wavefront all cross-lane traffic is wave-local.)
 //
 // Programming model: code outside a PAR(lane){...} region is workgroup-uniform (every lane computes the same scalars); PAR regions
 // distribute work items over the 128 lanes; data crosses lanes only through LDS (`Shared`), the per-instance records in HBM, or -- inside
@@ -17,7 +19,7 @@
 // the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
 #pragma once
 #ifndef OB_NT
-#define OB_NT 128    // threads per problem instance (1 or 2 wavefronts): lane-parallel phases use all of them, sequential sweeps wave 0
+#define OB_NT 64     // threads per problem instance: one wavefront
 #endif
 #ifdef OBCA_EMU
 #define OBCA_FN static inline
@@ -159,7 +161,7 @@ struct Inst {              // uniform: pointers of this instance
 
 struct Shared {
     double hdr[OB_HDR];
-    double red[16][OB_NT];
+    double red[12][OB_NT];
     double stg[2][200];        // double-buffered unpacked stage data (+ pad slot for lanes without an item) of the Riccati backward sweep (SG_* offsets)
     double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
@@ -170,8 +172,8 @@ struct Shared {
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
     double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
-    double clm[(OB_NMAX + 1) * 42];   // closed-loop maps of all stages (Acl 6x6 row-major, then bcl): written stage-parallel, read by the forward
-                                      // sweep and the back-substitution without leaving LDS (two instances per CU leave 80 KB per workgroup)
+    // (the closed-loop maps of the stages, 42 doubles each, live in the Riccati records in HBM / L2 -- RS_CL -- and the composed stage-pair maps
+    //  in the instance's `traj` buffer: with them in LDS an instance needed 78 KB and only two fitted a CU; the forward sweep prefetches them)
 };
 
 #ifdef OBCA_EMU
@@ -193,8 +195,8 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
 #define PROF_FINE(I, id) ((void)0)
 #endif
 
-// ---------------------------------------------------------------- reductions over the OB_NT lanes of the instance
-// Fold the second wavefront's slots onto the first, then a 64-lane butterfly in ASCENDING distance (1, 2, 4, 8, 16, 32).  The first
+// ---------------------------------------------------------------- reductions over the lanes of the instance
+// (Two-wavefront instances -- the quadcopter kernel, NT = 128 -- first fold the second wavefront's slots onto the first.)  A 64-lane butterfly in ASCENDING distance (1, 2, 4, 8, 16, 32).  The first
 // four exchanges stay inside a row of 16 lanes and run as DPP moves on the vector ALU (quad permutes, then half-row and row mirrors:
 // once every lane of a quad / half-row holds the same partial result, the mirrored partner carries exactly what the xor partner
 // would); only distances 16 and 32 cross rows and go through ds_bpermute.  An LDS exchange costs a ~100-clock round trip that the
@@ -202,9 +204,9 @@ enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_S
 // order, so its results are bit-identical (sum and max are commutative).
 #ifdef OBCA_EMU
 #define RED_IMPL(NAME, COMB)                                                                                     \
-    OBCA_FN double NAME(const double *r) {                                                                       \
+    template <int NT> OBCA_FN double NAME(const double *r) {                                                     \
         double a[64], b[64];                                                                                     \
-        for (int i = 0; i < 64; i++) { a[i] = r[i]; if (OB_NT > 64) { double w = r[i + 64 * (OB_NT > 64)], v = a[i]; a[i] = COMB; } } \
+        for (int i = 0; i < 64; i++) { a[i] = r[i]; if (NT > 64) { double w = r[i + 64 * (NT > 64)], v = a[i]; a[i] = COMB; } } \
         for (int o = 1; o < 64; o <<= 1) {                                                                       \
             for (int i = 0; i < 64; i++) { double v = a[i], w = a[i ^ o]; b[i] = COMB; }                         \
             for (int i = 0; i < 64; i++) a[i] = b[i];                                                            \
@@ -223,9 +225,9 @@ OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are ca
     return __hiloint2double(hi, lo);
 }
 #define RED_IMPL(NAME, COMB)                                                                                     \
-    OBCA_FN double NAME(const double *r) {                                                                       \
+    template <int NT> OBCA_FN double NAME(const double *r) {                                                     \
         double v = r[threadIdx.x & 63], w;                                                                       \
-        if (OB_NT > 64) { w = r[(threadIdx.x & 63) + 64 * (OB_NT > 64)]; v = COMB; }                             \
+        if (NT > 64) { w = r[(threadIdx.x & 63) + 64 * (NT > 64)]; v = COMB; }                                   \
         w = dpp_f64<0xB1>(v); v = COMB;          /* quad_perm [1,0,3,2]  : i ^ 1 */                               \
         w = dpp_f64<0x4E>(v); v = COMB;          /* quad_perm [2,3,0,1]  : i ^ 2 */                               \
         w = dpp_f64<0x141>(v); v = COMB;         /* row_half_mirror      : stands in for i ^ 4 */                 \
@@ -235,9 +237,12 @@ OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are ca
         return v;                                                                                                \
     }
 #endif
-RED_IMPL(red_sum, (v + w))
-RED_IMPL(red_max, ((w > v || w != w) ? w : v))      // NaN-propagating max
-RED_IMPL(red_min, ((w < v) ? w : v))
+RED_IMPL(red_sum_t, (v + w))
+RED_IMPL(red_max_t, ((w > v || w != w) ? w : v))      // NaN-propagating max
+RED_IMPL(red_min_t, ((w < v) ? w : v))
+OBCA_FN double red_sum(const double *r) { return red_sum_t<OB_NT>(r); }
+OBCA_FN double red_max(const double *r) { return red_max_t<OB_NT>(r); }
+OBCA_FN double red_min(const double *r) { return red_min_t<OB_NT>(r); }
 
 template <int VM>
 OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int j, ObsIn<VM> &in) {
@@ -551,9 +556,12 @@ OBCA_FN void pair_of(int p, int &a_, int &b_) {   // p-th pair (a<=b) of the 6 c
 #define SG_FA 64
 #define SG_HC 148
 #define SG_SIZE 196
-// gather plan of one lane (128 lanes, 196 staged values -> items lane and lane+128): value = kc + flag * rec[idx], stored at sg[dst]
-struct UnpackPlan { int idx[2], dst[2]; double flag[2], kc[2]; };
-OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &kc) {
+// Staged values of a stage: 196, of which 92 are constants of the layout (identity / zero pattern of FA, unused right-hand-side columns of hc):
+// those are written ONCE per sweep into both buffers (stage_unpack_constants); the 104 that change with the stage -- H (64, the symmetric entries
+// twice), the 24 bicycle-model entries of FA, the 16 gradient / time columns of hc -- are gathered per stage, two per lane (value = kc + rec[idx]).
+#define SG_NVAR 104
+struct UnpackPlan { int idx[2], dst[2]; double kc[2]; };
+OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &kc) {     // all 196 positions: what is stored where (fl = 0: the constant kc)
     idx = AS_DD; fl = 0.0; kc = 0.0; dst = SG_SIZE;              // default: harmless gather, store to the pad slot behind the buffer
     if (it < 64) { idx = AS_H + hidx(it >> 3, it & 7); fl = 1.0; dst = SG_H + it; }
     else if (it < 64 + 84) {
@@ -573,15 +581,27 @@ OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &k
         if (cc == 1) { idx = AS_HT + i; fl = 1.0; }
     }
 }
+OBCA_FN int stage_var_position(int v) {     // v-th stage-dependent value -> its position among the 196
+    if (v < 64) return v;
+    if (v < 88) { const int a_ = (v - 64) / 6, q = (v - 64) % 6; const int cc = q < 2 ? 2 + q : (q < 4 ? 4 + q : 4 + q); return 64 + a_ * 14 + cc; }     // columns 2, 3, 6, 7, 8, 9
+    if (v < SG_NVAR) { const int i = (v - 88) / 2, cc = (v - 88) % 2; return 148 + i * OB_NC + cc; }
+    return SG_SIZE;
+}
 OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
 #pragma unroll
-    for (int r = 0; r < 2; r++) stage_unpack_item(lane + OB_NT * r, p.idx[r], p.dst[r], p.flag[r], p.kc[r]);
+    for (int r = 0; r < 2; r++) { double fl; stage_unpack_item(stage_var_position(lane + OB_NT * r), p.idx[r], p.dst[r], fl, p.kc[r]); }
+}
+OBCA_FN void stage_unpack_constants(Shared &sh, int lane) {     // once per sweep, both buffers (+ the pad slot)
+    for (int it = lane; it <= SG_SIZE; it += OB_NT) {
+        int idx, dst; double fl, kc; stage_unpack_item(it, idx, dst, fl, kc);
+        if (fl == 0.0) { sh.stg[0][dst] = kc; sh.stg[1][dst] = kc; }
+    }
 }
 OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[2]) {   // independent, branch-free gathers;
     v[0] = rec[p.idx[0]]; v[1] = rec[p.idx[1]];                                         // the raw values are only touched at store time
 }
 OBCA_FN void stage_unpack_store(double *sg, const UnpackPlan &p, const double v[2]) {
-    sg[p.dst[0]] = p.kc[0] + p.flag[0] * v[0]; sg[p.dst[1]] = p.kc[1] + p.flag[1] * v[1];
+    sg[p.dst[0]] = p.kc[0] + v[0]; sg[p.dst[1]] = p.kc[1] + v[1];
 }
 
 // A dependent fp64 operation costs ~45 clock ticks when an instance runs alone on its CU (one wavefront per SIMD: nothing fills the pipeline;
@@ -594,37 +614,38 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
 #ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
 #endif
-// One stage of the sweep on all 128 lanes, three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), one small
-// item per lane, LDS-only workgroup barriers in between.
+// One stage of the sweep on the 64 lanes of the wavefront: three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), up to
+// two small items per lane and phase, wave-local LDS barriers in between (no cross-wavefront synchronisation: the instance IS one wavefront).
 // Every lane runs the SAME straight-line code in every phase: what differs between the item kinds of a phase (a T entry or one of the
 // partial sums of the bilinear update; a P / p entry or a bilinear constant) is only where the operands live, and that is a per-lane table
-// of LDS offsets built once per sweep (RicPlan).  A divergent `if (lane < ..) .. else if ..` made the second wavefront execute both sides
-// one after the other, which doubled the length of every phase.
+// of LDS offsets built once per sweep (RicPlan).
 // PIPE = 1: steady state of the software pipeline -- the last phase first retires the gather of stage k-1 (issued RIC_D stages ago into
 // nv[..][slot]) into the LDS buffer and re-issues the slot for stage k-1-RIC_D.  Every global load / store is issued unconditionally
 // (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
 // memory operation the compiler's in-order vmcnt bookkeeping stays exact and old gathers retire without draining the younger ones.
-struct RicPlan {      // offsets in doubles from the start of Shared
+struct RicItem {      // offsets in doubles from the start of Shared
     int a_a, a_as, a_b, a_bs, a_i, a_d, a_sg;      // phase A: operand A (offset, stride), operand B, initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
     int b_a, b_as, b_b, b_bs, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
     int c_x6, c_x7, c_col, c_base, c_s1, c_s2, c_d1, c_d2, c_rv, c_rk0, c_rk1;   // phase C: see riccati_stage
 };
-OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
+#define RIC_IPL 2       // items per lane and phase: 96 / 124 / 93 items over 64 lanes
+struct RicPlan { RicItem it[RIC_IPL]; };
+OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {     // `lane` = item number 0..127
     const double *L = (const double *)&sh;
     const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.cl[0] - L),
               oSG = (int)(sh.stg[0] - L), oZ = (int)(&sh.zero - L), oD = (int)(&sh.dump - L);
-    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + sum_b P[a][b] FA[b][cc]   (lanes 0..83);  u2[m][b] = sum_i FA[i][8+m] p[i][b]   (lanes 84..95; rows 4, 5 of the off columns are 0)
+    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + sum_b P[a][b] FA[b][cc]   (items 0..83);  u2[m][b] = sum_i FA[i][8+m] p[i][b]   (items 84..95; rows 4, 5 of the off columns are 0)
     p.a_a = oZ; p.a_as = 0; p.a_b = oZ; p.a_bs = 0; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
     if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_as = 1; p.a_b = oSG + SG_FA + cc; p.a_bs = 14; p.a_sg = 2;
                      p.a_i = cc < 8 ? oZ : opn + a_ * OB_NC + (cc - 8); p.a_d = oT + lane; }
     else if (lane < 96) { const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; p.a_a = oSG + SG_FA + 8 + m; p.a_as = 14; p.a_sg = 1; p.a_b = opn + b_; p.a_bs = OB_NC; p.a_d = osB + 12 + m * 6 + b_; }
-    // B: Qhat[i][cc] = [H | hc][i][cc] + sum_a FA[a][i] T[a][cc]   (lanes 0..111);  u1[m][b] = sum_i FA[i][8+m] T[i][8+b]   (lanes 112..123)
+    // B: Qhat[i][cc] = [H | hc][i][cc] + sum_a FA[a][i] T[a][cc]   (items 0..111);  u1[m][b] = sum_i FA[i][8+m] T[i][8+b]   (items 112..123)
     p.b_a = oZ; p.b_as = 0; p.b_b = oZ; p.b_bs = 0; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
     if (lane < 112) { const int i = lane / 14, cc = lane % 14; p.b_a = oSG + SG_FA + i; p.b_as = 14; p.b_b = oT + cc; p.b_bs = 14; p.b_sg = 1 | 4;
                       p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + lane; }
     else if (lane < 124) { const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; p.b_a = oSG + SG_FA + 8 + m; p.b_as = 14; p.b_sg = 1; p.b_b = oT + 8 + b_; p.b_bs = 14; p.b_d = osB + m * 6 + b_; }
     // C: value = base + (X6 n0 + X7 n1) / det + s1 + s2 with (n0, n1) = adj(Quu) applied to column c_col of rows 6, 7 of Qhat
-    //    lanes 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry);  lanes 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
+    //    items 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry);  items 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
     p.c_x6 = oZ; p.c_x7 = oZ; p.c_col = 0; p.c_base = oZ; p.c_s1 = oZ; p.c_s2 = oZ; p.c_d1 = oD; p.c_d2 = oD; p.c_rv = RS_PAD; p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
     if (lane < 72) {
         const int r = lane / 36, i = (lane % 36) / 6, cc = lane % 6, qc = r ? cc + 8 : cc;
@@ -639,6 +660,10 @@ OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
         if (b_ < 2) p.c_s2 = osB + 12 + b_ * 6 + a_;                          // columns 0 (main) and 1 (t) only
     }
 }
+OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
+#pragma unroll
+    for (int r = 0; r < RIC_IPL; r++) ric_item(sh, lane + OB_NT * r, p.it[r]);
+}
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicPlan (&rp)[OBCA_NLT],
                           double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
@@ -647,15 +672,27 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
     // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
-        const RicPlan &p = rp[LI(lane)];
-        const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
-        L[p.a_d] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+        double v[RIC_IPL];
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) {
+            const RicItem &p = rp[LI(lane)].it[r];
+            const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
+            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+        }
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].a_d] = v[r];
     }
     LDS_BARRIER();
     PAR(lane) {   // phase B
-        const RicPlan &p = rp[LI(lane)];
-        const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
-        L[p.b_d] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+        double v[RIC_IPL];
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) {
+            const RicItem &p = rp[LI(lane)].it[r];
+            const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
+            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+        }
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].b_d] = v[r];
     }
     LDS_BARRIER();
     PROF_FINE(I, PF_RIC_P1);
@@ -667,18 +704,26 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     const double idet = rcp_nr(det);
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C
-        const RicPlan &p = rp[LI(lane)];
-        const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
-        const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
-        const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
-        const double v = fma(fma(x6, n0, x7 * n1), idet, ba) + s12;
+        double v[RIC_IPL], n0[RIC_IPL], n1[RIC_IPL];
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) {
+            const RicItem &p = rp[LI(lane)].it[r];
+            const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
+            const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
+            n0[r] = fma(q10, q7, -(q11 * q6)); n1[r] = fma(q10, q6, -(q00 * q7));       // det * gains of this column
+            v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, ba) + s12;
+        }
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
             stage_unpack_store(sh.stg[kp & 1], plan[LI(lane)], nv[LI(lane)][slot]);
             stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
-        L[p.c_d1] = v; L[p.c_d2] = v;
-        ro[p.c_rv] = v; ro[p.c_rk0] = n0 * idet; ro[p.c_rk1] = n1 * idet;
+#pragma unroll
+        for (int r = 0; r < RIC_IPL; r++) {
+            const RicItem &p = rp[LI(lane)].it[r];
+            L[p.c_d1] = v[r]; L[p.c_d2] = v[r];
+            ro[p.c_rv] = v[r]; ro[p.c_rk0] = n0[r] * idet; ro[p.c_rk1] = n1[r] * idet;
+        }
     }
     LDS_BARRIER();
     PROF_FINE(I, PF_RIC_P2);
@@ -692,6 +737,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     UnpackPlan plan[OBCA_NLT]; RicPlan rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
         stage_unpack_plan(lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
+        stage_unpack_constants(sh, lane);
         if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
@@ -707,6 +753,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
             for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
         }
     }
+    LDS_BARRIER();
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
@@ -775,26 +822,29 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     so.ok = ok;
     if (!ok) return;
     const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
-    // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]
+    // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]; written into the Riccati record (RS_CL)
     PAR(lane) {
         for (int k = lane; k < N; k += OB_NT) {
-            const gdbl *rec = I.as + (size_t)k * OB_AS; const gdbl *ro = I.rs + (size_t)k * OB_RS; double *cm = sh.clm + (size_t)k * 42;
+            const gdbl *rec = I.as + (size_t)k * OB_AS; gdbl *ro = I.rs + (size_t)k * OB_RS; gdbl *cm = ro + RS_CL;
             double K0[6], K1[6], kf0 = 0, kf1 = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
 #pragma unroll
             for (int cc = 0; cc < OB_NC; cc++) { kf0 += ro[RS_KF + cc] * coef[cc]; kf1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
+            double b0[4], b1[4], a2[4], a3[4], dd[4], ft[4];      // every load before the first store (the record may alias as far as the compiler knows)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { b0[i] = rec[AS_DF + 5 * i + 2]; b1[i] = rec[AS_DF + 5 * i + 3]; a2[i] = rec[AS_DF + 5 * i + 0]; a3[i] = rec[AS_DF + 5 * i + 1];
+                                          dd[i] = rec[AS_DD + i]; ft[i] = rec[AS_DF + 5 * i + 4]; }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                double b0 = rec[AS_DF + 5 * i + 2], b1 = rec[AS_DF + 5 * i + 3];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
                     double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
-                    if (j == 2) a_ += rec[AS_DF + 5 * i + 0];
-                    if (j == 3) a_ += rec[AS_DF + 5 * i + 1];
-                    cm[i * 6 + j] = a_ + b0 * K0[j] + b1 * K1[j];
+                    if (j == 2) a_ += a2[i];
+                    if (j == 3) a_ += a3[i];
+                    cm[i * 6 + j] = a_ + b0[i] * K0[j] + b1[i] * K1[j];
                 }
-                cm[36 + i] = rec[AS_DD + i] + dt * rec[AS_DF + 5 * i + 4] + b0 * kf0 + b1 * kf1;
+                cm[36 + i] = dd[i] + dt * ft[i] + b0[i] * kf0 + b1[i] * kf1;
             }
 #pragma unroll
             for (int j = 0; j < 6; j++) { cm[24 + j] = K0[j]; cm[30 + j] = K1[j]; }
@@ -804,22 +854,30 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     }
     SYNC();
     PROF(I, PF_BORDER_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k, maps and trajectory in LDS.  The recursion is a chain of N dependent steps
-    // (~280 clocks each: a 4-deep fp64 dependency plus the broadcast), so it is run TWO stages per step: the maps of stages 2j and 2j+1 are
-    // composed first (stage-parallel, all lanes: Pm_j = Acl_{2j+1} Acl_{2j}, pb_j = Acl_{2j+1} bcl_{2j} + bcl_{2j+1}; the reduction scratch,
-    // idle here, holds up to FW_PMAX of them), then every sequential step produces s_{2j+2} (lanes 0..5, composed map) and s_{2j+1} (lanes
-    // 6..11, plain map) from s_{2j}.  Stages beyond the composed pairs (odd N, N > 2 FW_PMAX) are stepped one at a time.
-#define FW_PMAX 48
-    const int NP = UNIFORM(N / 2 < FW_PMAX ? N / 2 : FW_PMAX);
-    double *pairbuf = &sh.red[0][0];                      // FW_PMAX * 42 doubles <= 16 * OB_NT
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k.  The recursion is a chain of N dependent steps (~280 clocks each: a 4-deep fp64
+    // dependency plus the broadcast), so it is run TWO stages per step: the maps of stages 2j and 2j+1 are composed first (stage-parallel:
+    // Pm_j = Acl_{2j+1} Acl_{2j}, pb_j = Acl_{2j+1} bcl_{2j} + bcl_{2j+1}, into the instance's `traj` buffer in HBM / L2), then every
+    // sequential step produces s_{2j+2} (lanes 0..5, composed map) and s_{2j+1} (lanes 6..11, plain map) from s_{2j}.  A last odd stage is
+    // stepped on its own.  The maps are read from memory FW_D steps ahead into a rotating register set (7 doubles per lane and step), the
+    // state itself never leaves the wavefront's scalar registers; the trajectory goes to LDS for the stage-parallel phases that follow.
+#ifndef FW_D
+#define FW_D 4
+#endif
+    const int NP = UNIFORM(N / 2);
+    gdbl *pairbuf = I.traj;                                   // NP * 42 doubles
     PAR(lane) {
         for (int it = lane; it < NP * 6; it += OB_NT) {
             const int j = it / 6, r = it % 6;
-            const double *M0 = sh.clm + (size_t)(2 * j) * 42, *M1 = M0 + 42, *m1 = M1 + r * 6; double *pm = pairbuf + (size_t)j * 42;
+            const gdbl *M0 = I.rs + (size_t)(2 * j) * OB_RS + RS_CL, *M1 = I.rs + (size_t)(2 * j + 1) * OB_RS + RS_CL, *m1 = M1 + r * 6; gdbl *pm = pairbuf + (size_t)j * 42;
+            double m1r[6], m0[42], b1r = M1[36 + r];
+#pragma unroll
+            for (int q = 0; q < 6; q++) m1r[q] = m1[q];
+#pragma unroll
+            for (int q = 0; q < 42; q++) m0[q] = M0[q];
 #pragma unroll
             for (int cI = 0; cI < 6; cI++)
-                pm[r * 6 + cI] = dot6_tree(0.0, m1[0], M0[cI], m1[1], M0[6 + cI], m1[2], M0[12 + cI], m1[3], M0[18 + cI], m1[4], M0[24 + cI], m1[5], M0[30 + cI]);
-            pm[36 + r] = dot6_tree(M1[36 + r], m1[0], M0[36], m1[1], M0[37], m1[2], M0[38], m1[3], M0[39], m1[4], M0[40], m1[5], M0[41]);
+                pm[r * 6 + cI] = dot6_tree(0.0, m1r[0], m0[cI], m1r[1], m0[6 + cI], m1r[2], m0[12 + cI], m1r[3], m0[18 + cI], m1r[4], m0[24 + cI], m1r[5], m0[30 + cI]);
+            pm[36 + r] = dot6_tree(b1r, m1r[0], m0[36], m1r[1], m0[37], m1r[2], m0[38], m1r[3], m0[39], m1r[4], m0[40], m1r[5], m0[41]);
         }
     }
     SYNC();
@@ -831,8 +889,8 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             PAR64(lane) {
                 if (lane < 12) {
                     const int r = lane < 6 ? lane : lane - 6;
-                    const double *cl = lane < 6 ? pairbuf + (size_t)j * 42 : sh.clm + (size_t)(2 * j) * 42, *s_ = sh.traj + (size_t)(2 * j) * 6;
-                    const double *cr = cl + r * 6;
+                    const gdbl *cl = lane < 6 ? pairbuf + (size_t)j * 42 : I.rs + (size_t)(2 * j) * OB_RS + RS_CL; const double *s_ = sh.traj + (size_t)(2 * j) * 6;
+                    const gdbl *cr = cl + r * 6;
                     sh.traj[(size_t)(2 * j + (lane < 6 ? 2 : 1)) * 6 + r] = dot6_tree(cl[36 + r], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
                 }
             }
@@ -841,60 +899,61 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
         for (int k = 2 * NP; k < N; k++) {
             PAR64(lane) {
                 if (lane < 6) {
-                    const double *cl = sh.clm + (size_t)k * 42, *s_ = sh.traj + (size_t)k * 6;
-                    const double *cr = cl + lane * 6;
+                    const gdbl *cl = I.rs + (size_t)k * OB_RS + RS_CL; const double *s_ = sh.traj + (size_t)k * 6;
+                    const gdbl *cr = cl + lane * 6;
                     sh.traj[(size_t)(k + 1) * 6 + lane] = dot6_tree(cl[36 + lane], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
                 }
             }
             LDS_SYNC();
         }
 #else
-        // The state never goes through LDS on its way to the next step: v_readlane broadcasts the six values of lanes 0..5 into scalar registers
-        // and they enter the next step's products as scalar operands -- no LDS round trip (~170 clocks) on the dependent path; the map rows of
-        // the next step are fetched while this one is computed.  The trajectory is written to LDS for the stage-parallel phases that follow
-        // (fire and forget).  Same operation order as the emulation above: bit-identical results.
+        // v_readlane broadcasts the six values of lanes 0..5 into scalar registers and they enter the next step's products as scalar operands.
+        // Same operation order as the emulation above: bit-identical results.
         {
             const int tx = (int)threadIdx.x, r = tx < 6 ? tx : (tx < 12 ? tx - 6 : 0), Nn = UNIFORM(N);
             const bool pr = tx < 6 || tx >= 12;                 // this lane works on the composed map
             double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_k, wave-uniform (scalar registers); s_0 = 0
             if (tx < 6) sh.traj[tx] = 0.0;
-            double cr[6], cb_;
-            {
-                const double *c0 = pr ? pairbuf : sh.clm;
+            // per-lane base and stride (in doubles) of the map rows: composed maps are 42 apart, plain maps of the even stages 2 * OB_RS apart
+            const gdbl *mb = pr ? pairbuf + r * 6 : I.rs + RS_CL + r * 6; const size_t ms = pr ? 42 : 2 * (size_t)OB_RS; const int bo = 36 - 5 * r;   // bias = row base + bo
+            double ring[FW_D][7];
+            const int NPc = NP > 0 ? NP - 1 : 0;
 #pragma unroll
-                for (int q = 0; q < 6; q++) cr[q] = c0[r * 6 + q];
-                cb_ = c0[36 + r];
+            for (int q = 0; q < FW_D; q++) {                    // prologue: steps 0 .. FW_D-1 (clamped: unconditional loads keep the vmcnt bookkeeping exact)
+                const gdbl *cn = mb + (size_t)(q < NPc ? q : NPc) * ms;
+#pragma unroll
+                for (int e = 0; e < 6; e++) ring[q][e] = cn[e];
+                ring[q][6] = cn[bo];
             }
-            for (int j = 0; j < NP; j++) {
-                const int jn = j + 1 < NP ? j + 1 : j;
-                const double *cn = pr ? pairbuf + (size_t)jn * 42 : sh.clm + (size_t)(2 * jn) * 42;
-                double nr[6], nb_;
+            for (int j0 = 0; j0 < NP; j0 += FW_D) {
 #pragma unroll
-                for (int q = 0; q < 6; q++) nr[q] = cn[r * 6 + q];
-                nb_ = cn[36 + r];
-                const double v = dot6_tree(cb_, cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                if (tx < 12) sh.traj[(size_t)(2 * j + (tx < 6 ? 2 : 1)) * 6 + r] = v;
+                for (int q = 0; q < FW_D; q++) {
+                    const int j = j0 + q;
+                    double cr[7];
 #pragma unroll
-                for (int q = 0; q < 6; q++) { fw_s[q] = readlane_f64(v, q); cr[q] = nr[q]; }
-                cb_ = nb_;
-            }
-            if (2 * NP < Nn) {                                   // leftover stages, one at a time
-                const int k0 = 2 * NP;
+                    for (int e = 0; e < 7; e++) cr[e] = ring[q][e];
+                    {   // re-issue the slot for step j + FW_D
+                        const int jn = j + FW_D < NPc ? j + FW_D : NPc; const gdbl *cn = mb + (size_t)jn * ms;
 #pragma unroll
-                for (int q = 0; q < 6; q++) cr[q] = sh.clm[(size_t)k0 * 42 + r * 6 + q];
-                cb_ = sh.clm[(size_t)k0 * 42 + 36 + r];
-                for (int k = k0; k < Nn; k++) {
-                    const double *cn = sh.clm + (size_t)(k + 1 < Nn ? k + 1 : k) * 42;
-                    double nr[6], nb_;
+                        for (int e = 0; e < 6; e++) ring[q][e] = cn[e];
+                        ring[q][6] = cn[bo];
+                    }
+                    if (j < NP) {
+                        const double v = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                        if (tx < 12) sh.traj[(size_t)(2 * j + (tx < 6 ? 2 : 1)) * 6 + r] = v;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) nr[q] = cn[r * 6 + q];
-                    nb_ = cn[36 + r];
-                    const double v = dot6_tree(cb_, cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                    if (tx < 6) sh.traj[(size_t)(k + 1) * 6 + tx] = v;
-#pragma unroll
-                    for (int q = 0; q < 6; q++) { fw_s[q] = readlane_f64(v, q); cr[q] = nr[q]; }
-                    cb_ = nb_;
+                        for (int e = 0; e < 6; e++) fw_s[e] = readlane_f64(v, e);
+                    }
                 }
+            }
+            if (2 * NP < Nn) {                                   // odd horizon: the last stage on its own
+                const int k = 2 * NP; const gdbl *cn = I.rs + (size_t)k * OB_RS + RS_CL + r * 6;
+                double cr[7];
+#pragma unroll
+                for (int e = 0; e < 6; e++) cr[e] = cn[e];
+                cr[6] = cn[bo];
+                const double v = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                if (tx < 6) sh.traj[(size_t)(k + 1) * 6 + tx] = v;
             }
         }
 #endif
@@ -929,7 +988,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             if (k < N) {
                 const gdbl *ro = I.rs + (size_t)k * OB_RS;
                 double du[2];
-                const double *cm = sh.clm + (size_t)k * 42;
+                const gdbl *cm = ro + RS_CL;
                 du[0] = cm[40]; du[1] = cm[41];
 #pragma unroll
                 for (int j = 0; j < 6; j++) { du[0] += cm[24 + j] * s[j]; du[1] += cm[30 + j] * s[j]; }
@@ -1323,6 +1382,19 @@ OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double ta
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
+// one factorisation pass of the common (<= 2 rows per obstacle) case in ONE non-inlined function: every call of a register-hungry phase saves /
+// restores the callee-saved registers it uses through scratch (112 VGPRs + the AGPRs beyond a31: ~1-2 KB per lane and call), and that traffic
+// is a fifth of what the kernel moves.  -DOBCA_FUSE_NEWTON (A/B switch)
+OBCA_PHASE int ph_newton2(double mu, double dw, double dc, double rho, double tau, int assemble) {
+    Shared &sh = g_sh;
+    if (assemble) { assemble_obs<2>(sh.inst, sh, mu, dw, dc); assemble_stage(sh.inst, sh, mu, dw, dc, sh.A); }
+    if (!sh.A.ok) return 0;
+    if (!riccati_backward(sh.inst, sh, rho)) return 0;
+    direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
+    if (!sh.S.ok) return 0;
+    direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S);
+    return 1;
+}
 OBCA_PHASE void ph_trial2(double alpha) { Shared &sh = g_sh; eval_trial<2>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
 OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMID>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
 OBCA_PHASE void ph_trial8(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
@@ -1451,10 +1523,20 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         for (int tr = 0; tr < 60; tr++) {
             // (a single call for the whole Newton pass saves one more callee-saved-register round trip but costs more in-body spills in the
             // stage assembly: measured 1.3 % slower, so assembly and direction stay separate calls)
+#ifndef OBCA_FUSE_NEWTON
+            int a_;
+#endif
+#ifdef OBCA_FUSE_NEWTON
+            int a_;
+            if (sh.vm2) { PROF(sh.inst, PF_OTHER); a_ = ph_newton2(mu, dw, dc, o.rho_term, tau, tr > 0 || mu_changed); }
+            else
+#endif
+            {
             PROF(sh.inst, PF_OTHER); if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
-            int a_ = A.ok;
+            a_ = A.ok;
             PROF(sh.inst, PF_OTHER); if (a_) a_ = ph_riccati(o.rho_term);
             PROF(sh.inst, PF_OTHER); if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+            }
             if (a_) { ok = 1; break; }
             nreg++;
             if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);

@@ -1276,6 +1276,7 @@ static int ref_constraints(const prob_t *p, const lay_t *l, const double *z, int
  * dist = 1: ParkingDist.  exitflag follows ParkingDist.jl:245-289: Optimal -> 1; otherwise the feasibility check runs first (feasible -> 1),
  *           else one retry; after a failed retry the check is INVERTED in the reference (infeasible -> 1) -- reproduced.
  */
+static double *g_zfull = NULL;      /* test hook: when set, the full primal-dual iterate (layout of make_layout) is copied out after the solve */
 static int parking_solve(int dist, int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
                          const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
                          const double *b, const double *rx, const double *ry, const double *ryaw,
@@ -1324,8 +1325,22 @@ static int parking_solve(int dist, int N, double Ts, double L, const double ego[
     if (slp) memcpy(slp, z + l.sl, sizeof(double) * nOb * (N + 1));
     *exitflag = ef;
     if (info) { info[0] = r.status; info[1] = iters; info[2] = r.obj; info[3] = r.pinf; info[4] = r.dinf; info[5] = r.mu; info[6] = r.nreg; info[7] = r.t; }
+    if (g_zfull) memcpy(g_zfull, z, sizeof(double) * l.len);
     free(z);
     return 0;
+}
+/* the same solve, additionally returning the full primal-dual iterate x,u,t,lam,mu,sl,so,ss | pi,nu,yg,yo | bound multipliers (for the independent
+ * optimality certificate of tests/golden/make_kkt_pin.py: multipliers of the oracle, derivatives of oracle/nlp_ref.py) */
+int obca_oracle_parking_signed_dist_full(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
+                                         const double *x0, const double *xF, int nOb, const int *vOb, const double *A,
+                                         const double *b, const double *rx, const double *ry, const double *ryaw,
+                                         const double *xWS, const double *uWS, const double *lWS, const double *nWS,
+                                         const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *np,
+                                         double *slp, int *exitflag, double *info, double *zfull) {
+    g_zfull = zfull;
+    int rc = parking_solve(0, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, opt, xp, up, tsp, lp, np, slp, exitflag, info);
+    g_zfull = NULL;
+    return rc;
 }
 int obca_oracle_parking_signed_dist(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
                                     const double *x0, const double *xF, int nOb, const int *vOb, const double *A,

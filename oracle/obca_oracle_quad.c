@@ -726,6 +726,7 @@ static void quad_dual_ws(const prob_t *p, const lay_t *l, double *v) {
  * outputs xp 12(N+1), up 4N, tsp (N+1), lp 30 x (N+1) stage-contiguous (rows l1..l5 stacked, :295), slack 5(N+1);
  * exitflag 0/1/2 (:229-234, :285-288); info[8] = {status, iterations, objective, pinf, dinf, mu, nreg, t}.
  */
+static double *g_qfull = NULL;      /* test hook: v[n] | y[m] | zL[n] | zU[n] of the final iterate */
 int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double *x0, const double *xF, const double *ob,
                                        const double *xWS, double timeWS, int flags /* bit 0: dual warm start, bit 1: QuadcopterDist */, const opts_t *opt, double *xp, double *up, double *tsp,
                                        double *lp, double *slp, int *exitflag, double *info) {
@@ -751,8 +752,17 @@ int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double 
     if (slp) memcpy(slp, v + l->s, sizeof(double) * NOB * (N + 1));
     *exitflag = ef;
     if (info) { info[0] = r.status; info[1] = r.iters; info[2] = r.obj; info[3] = r.pinf; info[4] = r.dinf; info[5] = r.mu; info[6] = r.nreg; info[7] = r.t; }
+    if (g_qfull) { memcpy(g_qfull, v, 8 * n); memcpy(g_qfull + n, y, 8 * m); memcpy(g_qfull + n + m, zL, 8 * n); memcpy(g_qfull + 2 * n + m, zU, 8 * n); }
     free(v); free(y); free(zL); free(zU); model_free(&M);
     return 0;
+}
+/* the same solve, additionally returning the full primal-dual iterate (independent optimality certificate, tests/golden/make_kkt_pin.py) */
+int obca_oracle_quadcopter_signed_dist_full(int N, double Ts, double R, const double *x0, const double *xF, const double *ob, const double *xWS, double timeWS, int flags,
+                                            const opts_t *opt, double *xp, double *up, double *tsp, double *lp, double *slp, int *exitflag, double *info, double *full) {
+    g_qfull = full;
+    int rc = obca_oracle_quadcopter_signed_dist(N, Ts, R, x0, xF, ob, xWS, timeWS, flags, opt, xp, up, tsp, lp, slp, exitflag, info);
+    g_qfull = NULL;
+    return rc;
 }
 
 /* test hook: one regularised Newton direction at a full primal-dual point */

@@ -75,7 +75,7 @@ def dualmult_ws(N, vOb, A, b, rx, ry, ryaw, ego):
 
 
 def parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
-                        opts=None, dist=0):
+                        opts=None, dist=0, full=False):
     """Mirrors ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbounds,nOb,vOb,A,b,rx,ry,ryaw,fixTime,xWS,uWS) (ParkingSignedDist.jl:29).
     xWS (N+1,4), uWS (>=N,2) as in the reference.  Returns dict with xp (4,N+1), up (2,N), timeScale, exitflag, lp (M,N+1),
     np (4nOb,N+1), sl, info."""
@@ -89,12 +89,19 @@ def parking_signed_dist(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw
     xp = np.zeros((N + 1, 4)); up = np.zeros((N, 2)); ts = np.zeros(N + 1); lp = np.zeros((N + 1, M)); npp = np.zeros((N + 1, 4 * nOb))
     slp = np.zeros((N + 1, nOb)); ef = C.c_int(0); info = np.zeros(8)
     fn = lib().obca_oracle_parking_dist if dist else lib().obca_oracle_parking_signed_dist
+    extra = []
+    if full:        # full primal-dual iterate (signed-distance formulation only): layout(N, vOb)
+        assert not dist
+        zfull = np.zeros(layout(N, vOb_)["len"]); fn = lib().obca_oracle_parking_signed_dist_full; extra = [zfull.ctypes.data_as(_D)]
     rc = fn(
         C.c_int(N), C.c_double(Ts), C.c_double(L), args[0][1], args[1][1], C.c_int(int(fixTime)), args[2][1], args[3][1],
         C.c_int(nOb), pv, pA, pb, prx, pry, pyw, pxw, puw, plw, pnw, C.byref(opts) if opts is not None else None,
         xp.ctypes.data_as(_D), up.ctypes.data_as(_D), ts.ctypes.data_as(_D), lp.ctypes.data_as(_D), npp.ctypes.data_as(_D),
-        slp.ctypes.data_as(_D), C.byref(ef), info.ctypes.data_as(_D))
+        slp.ctypes.data_as(_D), C.byref(ef), info.ctypes.data_as(_D), *extra)
     assert rc == 0
+    if full:
+        return dict(zfull=zfull, exitflag=ef.value, iters=int(info[1]), obj=info[2], mu=info[5], xp=xp.T.copy(), up=up.T.copy(), t=info[7],
+                    lp=lp.T.copy(), np=npp.T.copy(), sl=slp.T.copy())
     return dict(xp=xp.T.copy(), up=up.T.copy(), timeScale=ts, exitflag=ef.value, lp=lp.T.copy(), np=npp.T.copy(), sl=slp.T.copy(),
                 status=int(info[0]), iters=int(info[1]), obj=info[2], pinf=info[3], dinf=info[4], mu=info[5], nreg=int(info[6]), t=info[7])
 

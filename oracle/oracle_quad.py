@@ -67,6 +67,20 @@ def quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dua
                 iters=int(info[1]), obj=info[2], pinf=info[3], dinf=info[4], mu=info[5], nreg=int(info[6]), t=info[7])
 
 
+def quadcopter_signed_dist_full(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1):
+    """the same solve + the full primal-dual iterate (v, y, zL, zU) in the oracle's layout (layout(N)): for the optimality certificate"""
+    a = [_d(v) for v in (x0, xF, np.reshape(ob, (5, 6)), np.asarray(xWS, float)[:N + 1])]
+    xp = np.zeros((N + 1, 12)); up = np.zeros((N, 4)); ts = np.zeros(N + 1); lp = np.zeros((N + 1, 30)); sl = np.zeros((N + 1, 5))
+    ef = C.c_int(0); info = np.zeros(8); L = layout(N); full = np.zeros(3 * L["n"] + L["m"])
+    rc = lib().obca_oracle_quadcopter_signed_dist_full(C.c_int(N), C.c_double(Ts), C.c_double(R), a[0][1], a[1][1], a[2][1], a[3][1], C.c_double(timeWS), C.c_int(int(bool(dual_ws))),
+                                                       C.byref(opts) if opts is not None else None, xp.ctypes.data_as(_D), up.ctypes.data_as(_D),
+                                                       ts.ctypes.data_as(_D), lp.ctypes.data_as(_D), sl.ctypes.data_as(_D), C.byref(ef), info.ctypes.data_as(_D), full.ctypes.data_as(_D))
+    assert rc == 0
+    n, m = L["n"], L["m"]
+    return dict(xp=xp.T.copy(), up=up.T.copy(), exitflag=ef.value, lp=lp.T.copy(), slack=sl.T.copy(), iters=int(info[1]), obj=info[2], mu=info[5], t=info[7],
+                v=full[:n], y=full[n:n + m], zL=full[n + m:2 * n + m], zU=full[2 * n + m:])
+
+
 def quadcopter_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1):
     return quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS, opts, dual_ws, dist=1)
 

@@ -15,7 +15,7 @@ struct Scratch { double *z, *d, *as, *rs, *oc, *traj; };
 static void alloc_scratch(int N, int len, Scratch &s) {
     s.z = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
     s.as = (double *)calloc((size_t)(N + 1) * OB_AS, 8); s.rs = (double *)calloc((size_t)(N + 1) * OB_RS, 8);
-    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.traj = (double *)calloc((size_t)(N + 2) * 6, 8);
+    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.traj = (double *)calloc((size_t)(N + 2) * 42, 8);
 }
 static void free_scratch(Scratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.traj); }
 

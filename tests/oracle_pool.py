@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE: the CPU oracle on many instances in parallel (spawned workers: safe next to a live HIP runtime)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _init():
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _parking_chunk(args):
+    _init()
+    import numpy as np
+    import oracle as O
+    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS) = args
+    out = []
+    for i in range(len(x0)):
+        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb, A, b, xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i])
+        out.append((lo + i, r["exitflag"], r["iters"], r["obj"], r["xp"], r["up"], r["t"]))
+    return out
+
+
+def parking_oracle_all(bt, xWS, workers=None, chunk=8):
+    """oracle solution of every instance of a shared-obstacle batch: list of (index, exitflag, iters, obj, xp, up, t)"""
+    import multiprocessing as mp
+    import oracle as O
+    O.build()
+    B = len(bt["x0"]); N = xWS.shape[1] - 1
+    jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"][lo:lo + chunk], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+             xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk]) for lo in range(0, B, chunk)]
+    workers = workers or min(os.cpu_count() or 1, 64)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_parking_chunk, jobs)
+    return sorted([r for ch in res for r in ch], key=lambda r: r[0])

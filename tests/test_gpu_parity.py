@@ -53,6 +53,25 @@ def test_parking_matches_oracle_config2(OA, oracle):
         assert np.abs(out["lp"][i] - r["lp"]).max() < 1e-5 and np.abs(out["np"][i] - r["np"]).max() < 1e-5
 
 
+def test_every_instance_of_the_benchmark_batch_matches_oracle(OA):
+    """ALL 1 024 instances of BASELINE config 2 (the batch bench.py times, including the 103-pass straggler, instance 768): exit flag, iteration
+    count, regularisation count, objective and trajectory against the oracle (run on all host cores in spawned workers)"""
+    import oracle_pool
+    N, B = 80, 1024
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    out, xWS = _solve_batch(OA, bt)
+    ref = oracle_pool.parking_oracle_all(bt, xWS)
+    assert len(ref) == B and (out["exitflag"] == 1).all()
+    worst_x = worst_u = worst_f = 0.0
+    for (i, ef, it, obj, xp, up, t) in ref:
+        assert out["exitflag"][i] == ef and out["iters"][i] == it, (i, out["iters"][i], it)
+        worst_f = max(worst_f, abs(out["obj"][i] - obj) / max(1, abs(obj)))
+        worst_x = max(worst_x, np.abs(out["xp"][i] - xp).max()); worst_u = max(worst_u, np.abs(out["up"][i] - up).max())
+        assert abs(out["timeScale"][i, 0] - t) < 1e-9
+    assert worst_x < TOL_X and worst_u < TOL_X and worst_f < TOL_F, (worst_x, worst_u, worst_f)
+    assert out["iters"][768] + out["info"][768, 6] >= 100          # the straggler that ends the synchronous step is among the compared
+
+
 @pytest.mark.parametrize("N", [33, 101, 128], ids=["odd_horizon", "beyond_the_composed_pairs", "longest_horizon"])
 def test_parking_matches_oracle_other_horizons(OA, oracle, N):
     """horizons that exercise the tails of the sweeps: odd N (one leftover stage after the two-stage steps of the forward sweep), N > 96 (more
@@ -161,10 +180,10 @@ def test_full_size_properties_config2(OA):
 
 
 def test_two_launch_schedule_is_bit_identical_to_a_single_launch(OA, monkeypatch):
-    """B=1024 exceeds the resident capacity (2 instances per CU), so obca_batch_solve uses the two-launch schedule (slice, rank, finish
+    """B=1536 exceeds the resident capacity (4 one-wavefront instances per CU = 1024), so obca_batch_solve uses the two-launch schedule (slice, rank, finish
     hardest-first).  Parking a solve and resuming it must not change a single bit of any output; an odd slice length also cuts solves inside
     their inertia-retry sequence and right before convergence."""
-    N, B = 80, 1024
+    N, B = 80, 1536
     bt = S.make_batch(S.BACKWARDS, B, N)
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
     ctx = OA.Context(0); b = OA.Batch(ctx, B, N)
@@ -351,3 +370,24 @@ def test_wide_obstacles_up_to_eight_rows(OA, oracle):
             assert abs(out["obj"][i] - r["obj"]) <= TOL_F * max(1, abs(r["obj"])) and np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
         n += 1
     assert n >= 8
+
+
+def test_hip_reproduces_the_independently_certified_solutions(OA):
+    """tests/golden/kkt_pin.npz: solutions whose optimality is certified with independent (autograd) derivatives at the benchmark size (test_pin_cpu.py):
+    the HIP path must return the same arrays -- config 2 and config 3 at N = 80, quadcopter at N = 60 -- without the oracle at run time"""
+    recs = list(golden("kkt_pin.npz")["records"])
+    for tag, sc in (("cfg2", S.BACKWARDS), ("cfg3", S.PARALLEL)):
+        rs = [r for r in recs if r["tag"] == tag]; A, b, v = S.scenario_hrep(sc); N = rs[0]["xp"].shape[1] - 1
+        bt = dict(x0=np.stack([r["x0"] for r in rs]), xF=np.stack([r["xF"] for r in rs]), Ts=np.array([float(r["Ts"]) for r in rs]), xWS=np.stack([r["xWS"] for r in rs]),
+                  uWS=np.stack([r["uWS"] for r in rs]), A=A, b=b, vOb=v, N=N, L=S.L_WHEELBASE, ego=S.EGO, XYbounds=S.XYBOUNDS)
+        out, _ = _solve_batch(OA, bt)
+        for i, r in enumerate(rs):
+            assert out["exitflag"][i] == 1 and out["iters"][i] == r["iters"], (tag, i)
+            assert abs(out["obj"][i] - r["oracle_obj"]) <= TOL_F * max(1, abs(r["oracle_obj"]))
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and np.abs(out["up"][i] - r["up"]).max() < TOL_X and abs(out["timeScale"][i, 0] - r["t"]) < 1e-9
+    rs = [r for r in recs if r["tag"] == "quad"]; N = rs[0]["xp"].shape[1] - 1
+    out = OA.quadcopter_signed_dist_batch(np.stack([r["x0"] for r in rs]), np.stack([r["xF"] for r in rs]), N, float(rs[0]["Ts"]), float(rs[0]["R"]), rs[0]["ob"],
+                                          np.stack([r["xWS"] for r in rs]), np.ones(len(rs)))
+    for i, r in enumerate(rs):
+        assert out["exitflag"][i] == 1 and abs(out["obj"][i] - r["oracle_obj"]) <= 1e-8 * abs(r["oracle_obj"])
+        assert np.abs(out["up"][i] - r["up"]).max() < 1e-5 and abs(out["timeScale"][i, 0] - r["t"]) < 1e-8 and np.abs(out["xp"][i] - r["xp"]).max() < 1e-3
