@@ -74,21 +74,22 @@ def b_pass_parking(N, nOb, M):
 F_PASS_QUAD = 60 * 33000 + 305 * 2400 + 61 * 2500 + 1.0e5   # Riccati 16-state sweep + 305 box blocks + stage derivatives + trial evaluations
 
 
-def committed_pmc_traffic(kernel):
-    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes of `bench.py --streams 1 --steps 1` (profiles/r02_pmc_*.csv; FETCH_SIZE doubled
-    per the gfx950 calibration in MI355X_MICROARCH.md).  NOT collected in this run: bench.py cannot wrap itself in rocprofv3."""
+def committed_pmc_traffic(kernel, tag=""):
+    """HBM bytes PER LAUNCH of `kernel` from the committed rocprofv3 --pmc passes of `bench.py --streams 1 --steps 1 --sync-steps 1` (profiles/r02_pmc_*.csv,
+    FETCH_SIZE and WRITE_SIZE in separate passes): 2 x FETCH_SIZE + WRITE_SIZE, KiB units, averaged over the launches in the trace.  The factor 2 and what the
+    counters see were calibrated this round (tools/micro/fetch_calib.hip, profiles/r02_pmc_calib_*.csv): FETCH_SIZE reports half the bytes of wide, of coalesced
+    8-byte and of one-double-per-128-byte-line loads alike (i.e. whole 128-byte lines), does NOT count re-reads served by the Infinity Cache (a 64 MiB buffer read
+    8 times counts once), WRITE_SIZE is exact for streaming stores and counts 32 bytes per isolated 8-byte store.  NOT collected in this run."""
     import csv
-    for rnd in ("r02", "r01"):
-        try:
-            vals = {}
-            for name, fn in (("FETCH_SIZE", f"{rnd}_pmc_fetch_size.csv"), ("WRITE_SIZE", f"{rnd}_pmc_write_size.csv")):
-                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
-                    if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == name:
-                        vals[name] = vals.get(name, 0.0) + float(r["Counter_Value"]) * 1024.0
-            return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], f"profiles/{rnd}_pmc_fetch_size.csv + {rnd}_pmc_write_size.csv (committed, not this run)"
-        except Exception:
-            continue
-    return None, None
+    try:
+        vals = {}; cnt = {}
+        for name, fn in (("FETCH_SIZE", f"r02_pmc_{tag}fetch_size.csv"), ("WRITE_SIZE", f"r02_pmc_{tag}write_size.csv")):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+                if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == name:
+                    vals[name] = vals.get(name, 0.0) + float(r["Counter_Value"]) * 1024.0; cnt[name] = cnt.get(name, 0) + 1
+        return 2.0 * vals["FETCH_SIZE"] / cnt["FETCH_SIZE"] + vals["WRITE_SIZE"] / cnt["WRITE_SIZE"], f"profiles/r02_pmc_{tag}fetch_size.csv + r02_pmc_{tag}write_size.csv (committed rocprofv3 --pmc passes of this command, not this run)"
+    except Exception:
+        return None, None
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle = test infrastructure, used here only as the timed CPU leg)
@@ -340,7 +341,7 @@ def main():
                 f_pass = f_pass_parking(N, len(np.ravel(vOb))); b_pass = b_pass_parking(N, len(np.ravel(vOb)), int(np.sum(vOb)))
             kernel = "obca_parking_ipm_kernel"
         tflops = passes0 * f_pass / (k_ms * 1e-3) / 1e12
-        traffic, tsrc = committed_pmc_traffic(kernel) if cfg == 2 and B == 1024 else (None, None)
+        traffic, tsrc = committed_pmc_traffic(kernel, "" if cfg == 2 else "quad_") if (cfg in (2, 4) and B == 1024) else (None, None)
         roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5),
                 "traffic": traffic, "traffic_source": tsrc,
                 "bound_detail": "fp64 arithmetic of the executed algorithm (SURVEY 8d Model B: the condensed KKT solve is compute / latency bound, HBM carries I/O only); "
@@ -351,6 +352,11 @@ def main():
                 "passes_per_launch": int(passes0), "flops_per_pass_model": f_pass,
                 "pipelined_tflops": round(passes0 * f_pass / (dt / a.steps) / 1e12, 3), "pipelined_frac": round(passes0 * f_pass / (dt / a.steps) / 1e12 / FP64_PEAK_TFLOPS, 5),
                 "pipelined_note": "the same work / (timed wall time / steps) with %d steps in flight: device utilisation of the timed region, not a kernel roofline" % nS}
+        if traffic is not None:     # measured HBM bytes (committed PMC passes) over the kernel time / the pipelined step time of THIS run
+            roof.update(hbm_measured_gbs_one_launch=round(traffic / (k_ms * 1e-3) / 1e9, 1), hbm_measured_frac_one_launch=round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        hbm_measured_gbs_pipelined=round(traffic / (dt / a.steps) / 1e9, 1), hbm_measured_frac_pipelined=round(traffic / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                        hbm_measured_note="PMC bytes per launch / kernel time, and / wall time per pipelined step: the kernels stream their per-instance state through HBM "
+                                          "(it does not fit LDS), so this -- not the fp64 fraction -- is the roof the pipelined rate runs into (DESIGN.md section 5)")
         if b_pass is not None:
             roof.update(streamed_model_gbs=round(passes0 * b_pass / (k_ms * 1e-3) / 1e9, 1), streamed_model_frac_of_hbm=round(passes0 * b_pass / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         streamed_model_note="per-pass streaming model of DESIGN.md section 5 (%.3g bytes per pass), NOT a SURVEY 8d quantity and not measured" % b_pass)
