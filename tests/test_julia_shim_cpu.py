@@ -9,7 +9,7 @@ JL = {"Cint": "int", "Cdouble": "double", "Clonglong": "longlong"}
 
 
 def c_prototypes():
-    txt = open(os.path.join(ROOT, "include", "obca_hip.h")).read()
+    txt = open(os.path.join(ROOT, "include", "obca_hip.h")).read() + open(os.path.join(ROOT, "include", "obca_plan.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
     for m in re.finditer(r"\b(?:int|const char \*)\s*(obca_[a-z_0-9]+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
@@ -31,7 +31,7 @@ def c_prototypes():
 def jl_ccalls(path):
     src = open(path).read()
     out = []
-    for m in re.finditer(r"ccall\(\(:(obca_[a-z_0-9]+), LIB\),\s*(\w+),\s*\(", src):
+    for m in re.finditer(r"ccall\(\(:(obca_[a-z_0-9]+), (?:LIB|PLAN)\),\s*(\w+),\s*\(", src):
         i = m.end(); depth = 1; j = i
         while depth:
             depth += {"(": 1, ")": -1}.get(src[j], 0); j += 1
@@ -51,7 +51,7 @@ def test_every_ccall_matches_the_header():
             assert name in protos, (fn, name)
             assert kinds == protos[name], (fn, name, kinds, protos[name])
             n += 1
-    assert n >= 8
+    assert n >= 12
 
 
 def test_quadcopter_warm_start_orientation():
