@@ -611,6 +611,25 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
     const double t0 = fma(a1, b1, a0 * b0), t1 = fma(a3, b3, a2 * b2), t2 = fma(a5, b5, fma(a4, b4, init));
     return (t0 + t1) + t2;
 }
+// Build variant -DOBCA_RICCATI_FP32 (BASELINE config 5: "fp32 with fp64 KKT refinement"): the factorisation half of a pass -- the three phases of
+// the Riccati recursion, i.e. value function, gains, border constants -- runs in fp32 arithmetic, everything that forms residuals (assembly, termination
+// test, line search) stays fp64.  The interior-point iteration is then an inexact Newton method on fp64 residuals: every outer iteration IS a refinement
+// step, the termination test sees fp64 quantities, so a converged solve meets the same tolerances.  A/B in DESIGN.md section 8.
+#ifdef OBCA_RICCATI_FP32
+typedef float ric_t;
+#else
+typedef double ric_t;
+#endif
+OBCA_FN double dot6_ric(double init, double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3, double a4, double b4,
+                        double a5, double b5) {
+#ifdef OBCA_RICCATI_FP32
+    const float t0 = fmaf((float)a1, (float)b1, (float)a0 * (float)b0), t1 = fmaf((float)a3, (float)b3, (float)a2 * (float)b2),
+                t2 = fmaf((float)a5, (float)b5, fmaf((float)a4, (float)b4, (float)init));
+    return (double)((t0 + t1) + t2);
+#else
+    return dot6_tree(init, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5);
+#endif
+}
 #ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
 #endif
@@ -677,7 +696,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
-            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            v[r] = dot6_ric(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].a_d] = v[r];
@@ -689,7 +708,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
-            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            v[r] = dot6_ric(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].b_d] = v[r];
@@ -698,20 +717,29 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     PROF_FINE(I, PF_RIC_P1);
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
     // does not need it (the adjugate products below) runs while it is in flight
-    const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
-    const double det = fma(q00, q11, -(q10 * q10));
+    const ric_t q00 = (ric_t)sh.Qhat[6 * 14 + 6], q10 = (ric_t)sh.Qhat[7 * 14 + 6], q11 = (ric_t)sh.Qhat[7 * 14 + 7];
+    const ric_t det = q00 * q11 - q10 * q10;
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
+#ifdef OBCA_RICCATI_FP32
+    const ric_t idet = 1.0f / det;
+#else
     const double idet = rcp_nr(det);
+#endif
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C
         double v[RIC_IPL], n0[RIC_IPL], n1[RIC_IPL];
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
-            const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
-            const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
+            const ric_t q6 = (ric_t)sh.Qhat[6 * 14 + p.c_col], q7 = (ric_t)sh.Qhat[7 * 14 + p.c_col];
+            const ric_t x6 = (ric_t)L[p.c_x6], x7 = (ric_t)L[p.c_x7], ba = (ric_t)L[p.c_base], s12 = (ric_t)L[p.c_s1] + (ric_t)L[p.c_s2];
+#ifdef OBCA_RICCATI_FP32
+            const ric_t m0 = q10 * q7 - q11 * q6, m1 = q10 * q6 - q00 * q7;
+            n0[r] = m0; n1[r] = m1; v[r] = (double)((x6 * m0 + x7 * m1) * idet + ba + s12);
+#else
             n0[r] = fma(q10, q7, -(q11 * q6)); n1[r] = fma(q10, q6, -(q00 * q7));       // det * gains of this column
             v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, ba) + s12;
+#endif
         }
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
@@ -722,7 +750,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             L[p.c_d1] = v[r]; L[p.c_d2] = v[r];
-            ro[p.c_rv] = v[r]; ro[p.c_rk0] = n0[r] * idet; ro[p.c_rk1] = n1[r] * idet;
+            ro[p.c_rv] = v[r]; ro[p.c_rk0] = (double)((ric_t)n0[r] * idet); ro[p.c_rk1] = (double)((ric_t)n1[r] * idet);
         }
     }
     LDS_BARRIER();

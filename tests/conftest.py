@@ -47,6 +47,18 @@ def emu_mfma():
 
 
 @pytest.fixture(scope="session")
+def emu_fp32():
+    """the emulation with the Riccati factorisation in fp32 arithmetic (build variant -DOBCA_RICCATI_FP32: BASELINE config 5's "fp32 with fp64 KKT refinement")"""
+    import ctypes as C
+    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
+    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_fp32.so")
+    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_RICCATI_FP32", "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="session")
 def backwards():
     from obca_amd import scenarios as S
     A, b, v = S.scenario_hrep(S.BACKWARDS)
