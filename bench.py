@@ -131,7 +131,7 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------- batch generation (rank 0) and the scatter
-def make_host_batch(cfg, B, seed):
+def make_host_batch(cfg, B, seed, hybrid=False):
     """the whole job's batch as a dict of (B, K) float64 arrays + the shared scalars"""
     from obca_amd import scenarios as S
     c = CONFIGS[cfg]; N = c["N"]
@@ -140,7 +140,7 @@ def make_host_batch(cfg, B, seed):
         rows = dict(x0=q["x0"], xF=q["xF"], Ts=np.full((B, 1), q["Ts"]), timeWS=np.full((B, 1), q["timeWS"]), xWS=q["xWS"].reshape(B, -1))
         return rows, dict(R=q["R"], ob=q["ob"])
     if cfg == 2:
-        bt = S.make_batch(S.BACKWARDS, B, N, seed=seed)
+        bt = S.make_batch(S.BACKWARDS, B, N, seed=seed, planner=True, smooth=True) if hybrid else S.make_batch(S.BACKWARDS, B, N, seed=seed)
     elif cfg == 3:
         bt = S.make_batch(S.PARALLEL, B, N, seed=seed, goal_jitter=True)
     else:
@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU for a functional test)")
     ap.add_argument("--streams", type=int, default=4, help="device-resident copies of the batch, each on its own HIP stream (1 = synchronous steps)")
     ap.add_argument("--sync-steps", type=int, default=6, help="synchronous steps measured after the timed region for the per-launch kernel time of the roofline")
+    ap.add_argument("--warm-start", default="primitive", choices=["primitive", "hybrid"], help="config 2 only: line/arc/line primitives (default) or the reference's "
+                    "pipeline main.jl:216-248 -- Hybrid A* path, velocity smoother, resampling (planned on the host cores before the timed region)")
     ap.add_argument("--seed-offset", type=int, default=0, help="diagnostic: shift the seed of the job's batch")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,7 +212,7 @@ def main():
     rows = shared = None
     B = a.batch or C["per_gpu"]; B_total = B * world
     if rank == 0:
-        rows, shared = make_host_batch(cfg, B_total, SEED + a.seed_offset)      # (config 3 / 4 plan their warm starts on the host cores here, before HIP is up)
+        rows, shared = make_host_batch(cfg, B_total, SEED + a.seed_offset, hybrid=(a.warm_start == "hybrid"))      # (config 3 / 4 plan their warm starts on the host cores here, before HIP is up)
     import torch
     import obca_amd
     from obca_amd import sharding, validate as V
@@ -366,7 +368,7 @@ def main():
             "metric": "OBCA NLP solves/sec (N=80, 3 obs, batch) at 1/2/4/8 MI355X vs IPOPT-CPU", "value": round(conv_all * a.steps / dt, 2), "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": C["name"], "config": cfg, "batch_per_gpu": B, "horizon": N,
+            "config": {"workload": C["name"] + (" [warm starts: Hybrid A* + velocity smoother, the reference's pipeline main.jl:216-248]" if (cfg == 2 and a.warm_start == "hybrid") else ""), "config": cfg, "batch_per_gpu": B, "horizon": N,
                        "sharding": f"one host batch of {B_total} instances made on rank 0, scattered over {world} rank(s) (one scatter), solved device-resident, full result tuples "
                                    f"gathered on rank 0 (one gather) and validated there; no collective inside the timed region",
                        "streams": nS, "timed_region_s": round(dt, 3), "converged": conv_all, "exitflag_ok": conv_flag, "instances": B_total,

@@ -521,9 +521,187 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
     }
     return ok;
 }
+// ---------------------------------------------------------------- Riccati backward sweep on the matrix cores (default; -DOBCA_QUAD_RICCATI_LDS keeps the LDS / VALU sweep above)
+// The LDS sweep is bound by LDS bandwidth (every fp64 FMA of its products reads two operands from LDS: 10 k clocks per stage with two instances per CU).  Here the
+// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (35 per stage); the stage record is gathered
+// from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
+//   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
+//   Register kb of a tile in D layout is the B operand of K-block kb (rows 4 kb .. 4 kb + 3), and the A operand of the TRANSPOSED tile.
+// Tiles (rows x columns; x = 12 states, w = copy of u_{k-1} (4), u = 4 inputs, rhs = main, t, nu_1..12):
+//   PD   (x,w) x (x,w)  value function, symmetric         pnD  (x,w) x rhs
+//   FXD0 FX[:, x|u columns]   FXD1 FX[:, d|Ft] (columns 0, 1)   FXU FX[:, u columns] (columns 0..3)         FX = [A B d Ft; 0 I 0 0] is the 16 x 18 block of the stage record
+//   Th0 = PD FXD0                         (x,w) x (x|u)          Th1 = pnD + PD FXD1                        (x,w) x rhs
+//   Q00 = H + FXD0(x cols)' Th0           (x,w) x (x|u)          Q01 = hc + FXD0(x cols)' Th1               (x,w) x rhs
+//   Q10 = H + FXU' Th0                     u    x (x|u)          Q11 = hc + FXU' Th1                         u    x rhs
+//   the w columns of the stage Hessian carry no product (F has zero columns there) and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww.
+//   Quu = Q10[:, u columns]: LDL' (uniform);  every lane solves the gains of its own column (x | w columns and the rhs columns)
+//   P' = Q00(x | w columns) + Q[., u] K    p' = Q01 + Q[., u] Kf    (Q[., u] taken as the transpose of Q10 / the closed-form w rows), P' symmetrised through LDS
+//   border constants  Bm += FXD1' Th1 + pnD' FXD1 + Q11' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a and the gain part, all into one accumulator tile)
+#define QMD 2                        // stages the gathers run ahead
+#define QMG 23                       // gathers per lane and stage
+struct QMPlan { int off[QMG]; };
+OBCA_FN void qm_plan(int lane, QMPlan &p) {
+    const int g = lane >> 4, j = lane & 15, Z = QSR - 1;      // Z: a zero of the record padding (lanes without an element)
+    const int col = j < QX ? j : j + QU;                    // column of the stage vector (x | u) that tile column j stands for
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        p.off[kb] = QSR_F + (4 * kb + g) * QFC + j;
+        p.off[4 + kb] = j < 2 ? QSR_F + (4 * kb + g) * QFC + 16 + j : Z;
+        p.off[8 + kb] = j < QU ? QSR_F + (4 * kb + g) * QFC + QX + j : Z;
+        p.off[12 + kb] = QSR_H + (g + 4 * kb) * QZ + col;                       // H rows (x, w) of register kb
+        p.off[17 + kb] = j < 2 ? QSR_HC + 2 * (g + 4 * kb) + j : Z;
+    }
+    p.off[16] = QSR_H + (QS + g) * QZ + col;                                    // H rows u
+    p.off[21] = j < 2 ? QSR_HC + 2 * (QS + g) + j : Z;
+    p.off[22] = QSR_H + QX * QZ + QX;                                           // ww = H[w_0][w_0] (uniform)
+}
+OBCA_FN void qm_gather(const gdbl *rec, const QMPlan &p, double (&v)[QMG]) {
+#pragma unroll
+    for (int e = 0; e < QMG; e++) v[e] = rec[p.off[e]];
+}
+template <int PIPE>
+OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[OBCA_NLT], double (&PD)[4][OBCA_NLT], double (&pnD)[4][OBCA_NLT], double (&BmD)[4][OBCA_NLT],
+                                 double (&nv)[OBCA_NLT][QMD][QMG], const int slot, const double (*raw)[QMG]) {
+    double FXD0[4][OBCA_NLT], FXD0m[4][OBCA_NLT], FXD1[4][OBCA_NLT], FXU[4][OBCA_NLT], Th0[4][OBCA_NLT], Th1[4][OBCA_NLT];
+    double Q00[4][OBCA_NLT], Q01[4][OBCA_NLT], Q10[4][OBCA_NLT], Q11[4][OBCA_NLT], ww[OBCA_NLT];
+    PAR64(lane) {
+        const int L_ = LI(lane), j = lane & 15; const QMPlan &p = plan[L_];
+        double v[QMG];
+#pragma unroll
+        for (int e = 0; e < QMG; e++) v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
+        if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSR, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            FXD0[r][L_] = v[r]; FXD0m[r][L_] = j < QX ? v[r] : 0.0; FXD1[r][L_] = v[4 + r]; FXU[r][L_] = v[8 + r];
+            Q00[r][L_] = v[12 + r]; Q01[r][L_] = v[17 + r]; Th0[r][L_] = 0.0; Th1[r][L_] = pnD[r][L_];
+            Q10[r][L_] = r == 0 ? v[16] : 0.0; Q11[r][L_] = r == 0 ? v[21] : 0.0;
+        }
+        ww[L_] = v[22];
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) { wv_mfma(Th0, PD[kb], FXD0[kb]); wv_mfma(Th1, PD[kb], FXD1[kb]); }
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        wv_mfma(Q00, FXD0m[kb], Th0[kb]); wv_mfma(Q01, FXD0m[kb], Th1[kb]);
+        wv_mfma(Q10, FXU[kb], Th0[kb]); wv_mfma(Q11, FXU[kb], Th1[kb]);
+        wv_mfma(BmD, FXD1[kb], Th1[kb]); wv_mfma(BmD, pnD[kb], FXD1[kb]);       // static parts of the border constants (pnD: still the next stage's p)
+    }
+    // Quu = Q10[u rows][u columns]: lane (a, 12 + b) of register 0
+    double Lq[QU * QU];
+#pragma unroll
+    for (int a = 0; a < QU; a++)
+#pragma unroll
+        for (int b_ = 0; b_ < QU; b_++) Lq[a * QU + b_] = WV_READLANE(Q10[0], 16 * a + QX + b_);
+    const int ok = UNIFORM(ldl_fact<QU>(QU, Lq) ? 0 : 1);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
+    const double wwu = WV_READLANE(ww, 0);
+    // the four u-row entries of every column: rows u_0..u_3 sit in lane groups 0..3 of register 0
+    double c0[QU][OBCA_NLT], c1[QU][OBCA_NLT];
+#pragma unroll
+    for (int a = 0; a < QU; a++) { wv_shfl_group(c0[a], Q10[0], a); wv_shfl_group(c1[a], Q11[0], a); }
+    double Aq[OBCA_NLT], Bk0[OBCA_NLT], Bk1[OBCA_NLT], Sn[4][OBCA_NLT];
+    gdbl *ro = sh.inst.rs + (size_t)k * QRR;
+    PAR64(lane) {
+        const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+        double b0[QU], b1[QU];
+#pragma unroll
+        for (int a = 0; a < QU; a++) { b0[a] = j < QX ? -c0[a][L_] : (a == j - QX ? wwu : 0.0); b1[a] = -c1[a][L_]; }      // w columns: -Q[u][w_c] = ww e_c
+        ldl_solve<QU>(QU, Lq, b0); ldl_solve<QU>(QU, Lq, b1);
+        const double k0 = g == 0 ? b0[0] : (g == 1 ? b0[1] : (g == 2 ? b0[2] : b0[3])), k1 = g == 0 ? b1[0] : (g == 1 ? b1[1] : (g == 2 ? b1[2] : b1[3]));
+        Bk0[L_] = k0; Bk1[L_] = j < QC ? k1 : 0.0;
+        Aq[L_] = j < QX ? Q10[0][L_] : (j - QX == g ? -wwu : 0.0);               // Q[row][u_g]: transpose of Q10 for the x rows, closed form for the w rows
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sn[r][L_] = j < QX ? Q00[r][L_] : ((g + 4 * r) == j ? wwu : 0.0);      // w columns of [H | .]: ww on the (w, w) diagonal
+        ro[QRR_K + g * QS + j] = k0;                                              // gains: row g, column j of the 4 x 16 / 4 x 14 blocks
+        ro[j < QC ? QRR_KF + g * QC + j : QRR_PAD] = k1;
+    }
+    wv_mfma(Sn, Aq, Bk0); wv_mfma(Q01, Aq, Bk1); wv_mfma(BmD, Q11[0], Bk1);
+    // symmetrise the value function through LDS (without it round-off flipped the Quu > 0 inertia test on this badly scaled problem)
+    double *tr = &sh.red[0][0];
+    PAR64(lane) {
+        const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 16 + j] = Sn[r][L_];
+    }
+    LDS_SYNC();
+    PAR64(lane) {
+        const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double v = 0.5 * (Sn[r][L_] + tr[j * 16 + (g + 4 * r)]);
+            PD[r][L_] = v; pnD[r][L_] = j < QC ? Q01[r][L_] : 0.0;
+            if (r < 3) { ro[QRR_PX + (g + 4 * r) * QS + j] = v; ro[j < QC ? QRR_PV + (g + 4 * r) * QC + j : QRR_PAD] = pnD[r][L_]; }      // rows 0..11 of P / p
+        }
+    }
+    LDS_SYNC();
+    return ok;
+}
+
+OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = UNIFORM(c.N); const gdbl *z = sh.inst.z;
+    int ok = 1;
+    WAVE0_BEGIN
+        double nv[OBCA_NLT][QMD][QMG], raw[OBCA_NLT][QMG], PD[4][OBCA_NLT], pnD[4][OBCA_NLT], BmD[4][OBCA_NLT];
+        QMPlan plan[OBCA_NLT];
+        PAR64(lane) {   // terminal cost-to-go: P_N = H_N[x, x] + rho I, p_N = (hb_N - rho e, 0, e_i)
+            const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+            qm_plan(lane, plan[L_]);
+            const gdbl *rec = sh.inst.as + (size_t)N * QSR;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = g + 4 * r; double v = 0.0, w = 0.0;
+                if (i < QX && j < QX) { v = rec[QSR_H + i * QZ + j]; if (i == j) v += rho; }
+                if (i < QX) { if (j == 0) w = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
+                PD[r][L_] = v; pnD[r][L_] = w; BmD[r][L_] = 0.0;
+            }
+        }
+        int k = N - 1, fin = 0;
+        for (; k >= 0 && (k + 1) % QMD != 0; k--) {      // head: synchronous gathers until the remaining stage count is a multiple of QMD
+            PAR64(lane) { qm_gather(sh.inst.as + (size_t)k * QSR, plan[LI(lane)], raw[LI(lane)]); }
+            if (!q_riccati_stage_mfma<0>(sh, k, plan, PD, pnD, BmD, nv, 0, raw)) { ok = 0; fin = 1; break; }
+        }
+        if (!fin && k >= 0) {
+            PAR64(lane) {
+#pragma unroll
+                for (int ju = 0; ju < QMD; ju++) { const int st = k - ju > 0 ? k - ju : 0; qm_gather(sh.inst.as + (size_t)st * QSR, plan[LI(lane)], nv[LI(lane)][ju]); }
+#ifndef OBCA_EMU
+#pragma unroll
+                for (int ju = 0; ju < QMD; ju++)
+#pragma unroll
+                    for (int e = 0; e < QMG; e++) asm volatile("" : "+v"(nv[0][ju][e]));
+#endif
+            }
+            for (int kb = k; kb >= QMD - 1 && ok; kb -= QMD) {
+#pragma unroll
+                for (int ju = 0; ju < QMD; ju++) ok &= q_riccati_stage_mfma<1>(sh, kb - ju, plan, PD, pnD, BmD, nv, ju, nullptr);
+            }
+        }
+        // border constants to LDS, exactly symmetric (the accumulator tile is symmetric up to round-off)
+        double *tr = &sh.red[0][0];
+        PAR64(lane) {
+            const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 16 + j] = BmD[r][L_];
+        }
+        LDS_SYNC();
+        PAR64(lane) {
+            const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int a = g + 4 * r; if (a < QC && j < QC) sh.Bm[a * QC + j] = 0.5 * (tr[a * 16 + j] + tr[j * 16 + a]); }
+        }
+    WAVE0_END
+    return ok;
+}
+
 OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
+#ifdef OBCA_QUAD_RICCATI_LDS
     const int ok = q_riccati_body(sh, rho);
     QPAR(lane) { if (lane == 0) sh.ric_ok = ok; }
+#else
+    const int ok = q_riccati_body_mfma(sh, rho);      // (meaningful on wavefront 0 only: it publishes the flag)
+    WAVE0_BEGIN
+        PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
+    WAVE0_END
+#endif
     SYNC();
     return sh.ric_ok;
 }

@@ -75,7 +75,7 @@ def collides(pose, vOb, A, b, ego=S.EGO, XYbounds=S.XYBOUNDS, margin=0.0):
                                            A.ctypes.data_as(_D), b.ctypes.data_as(_D), e.ctypes.data_as(_D), xy.ctypes.data_as(_D), C.c_double(margin)))
 
 
-def path_to_warm_start(path, dr, N, xF=None, v_nom=0.5, L=S.L_WHEELBASE):
+def path_to_warm_start(path, dr, N, xF=None, v_nom=0.5, L=S.L_WHEELBASE, smooth=False):
     """resample the planner path uniformly in arc length to N+1 stages (main.jl:237-252 down-samples the smoothed profile instead) and
     derive the state / input warm start: speed +-v_nom (0 at both ends and at direction switches), steering from the path curvature.
     xF (optional) replaces the last pose so that the warm start ends on the NLP's terminal state."""
@@ -93,6 +93,9 @@ def path_to_warm_start(path, dr, N, xF=None, v_nom=0.5, L=S.L_WHEELBASE):
     for i in range(1, N):
         if d[i] != d[i + 1]:
             v[i] = 0
+    if smooth:      # the reference's pipeline (main.jl:222-231): raw speed of every interval, then veloSmooth with 0.3 m/s^2
+        rv = np.concatenate([d[1:] * v_nom, [0.0]])
+        v, _ = velo_smooth(rv, 0.3, Ts)
     a = np.clip(np.diff(v) / Ts, -0.4, 0.4)
     dpsi = np.diff(yaw); dsv = np.maximum(np.diff(ss), 1e-9) * np.where(d[1:] == 0, 1, d[1:])
     delta = np.clip(np.arctan(L * dpsi / dsv), -0.6, 0.6)
@@ -144,8 +147,9 @@ SCENARIO_OPTS = {"backwards": (dict(), 0.5),
                  "parallel": (dict(step=0.2, xy_res=0.1, yaw_res_deg=3.0, margin=0.02, max_expansions=2000000), 0.25)}
 
 
-def warm_start(sc, x0, xF, N, **kw):
-    """Hybrid A* warm start of one instance of a scenario table (S.BACKWARDS / S.PARALLEL): returns (Ts, xWS (N+1,4), uWS (N,2)) or None."""
+def warm_start(sc, x0, xF, N, smooth=False, **kw):
+    """Hybrid A* warm start of one instance of a scenario table (S.BACKWARDS / S.PARALLEL): returns (Ts, xWS (N+1,4), uWS (N,2)) or None.
+    smooth=True runs the planner's speed profile through velo_smooth as main.jl:222-231 does."""
     A, b, vrows = S.scenario_hrep(sc)
     o, v_nom = SCENARIO_OPTS.get(sc["name"], (dict(), 0.5))
     o = dict(o); o.update(kw)
@@ -155,18 +159,18 @@ def warm_start(sc, x0, xF, N, **kw):
         return None
     if r is None:
         return None
-    return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom)
+    return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom, smooth=smooth)
 
 
 def _ws_job(args):
-    name, x0, xF, N = args
-    return warm_start(S.BACKWARDS if name == "backwards" else S.PARALLEL, x0, xF, N)
+    name, x0, xF, N, smooth = args
+    return warm_start(S.BACKWARDS if name == "backwards" else S.PARALLEL, x0, xF, N, smooth=smooth)
 
 
-def warm_start_many(sc, x0, xF, N, workers=None):
+def warm_start_many(sc, x0, xF, N, workers=None, smooth=False):
     """warm starts of a batch on the host cores (one search per forked process).  Call it before a HIP context exists in this process, or
     pass workers=1: fork() next to a live GPU runtime is not safe."""
-    jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N) for a, g in zip(x0, xF)]
+    jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N, bool(smooth)) for a, g in zip(x0, xF)]
     workers = min(len(jobs), workers or os.cpu_count() or 1)
     if workers <= 1 or len(jobs) < 4:
         return [_ws_job(j) for j in jobs]

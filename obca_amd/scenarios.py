@@ -178,7 +178,7 @@ def warm_start_parallel(x0, xF, N, R=4.5):
     return Ts, xWS, uWS
 
 
-def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, workers=None):
+def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, workers=None, smooth=False):
     """Synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0.
     planner=None: geometric line/arc primitives for the backwards scenario, Hybrid A* (obca_amd/planner.py) for the parallel one, whose
     6 m bay needs a multi-manoeuvre path; planner=True/False forces the choice.  Instances for which the planner finds no path
@@ -202,7 +202,7 @@ def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, work
         from . import planner as PL
         todo = list(range(B))
         while todo:
-            res = PL.warm_start_many(sc, x0[todo], xF[todo], N, workers=workers)
+            res = PL.warm_start_many(sc, x0[todo], xF[todo], N, workers=workers, smooth=smooth)
             nxt = []
             for i, r in zip(todo, res):
                 if r is None:

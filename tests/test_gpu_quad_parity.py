@@ -55,7 +55,7 @@ def test_quad_batch_parity_and_feasibility(Q):
         assert r["exitflag"] == out["exitflag"][i]
         if r["exitflag"] == 1:
             assert abs(out["obj"][i] - r["obj"]) < 1e-8 * abs(r["obj"])
-            assert abs(out["timeScale"][i, 0] - r["t"]) < 1e-8 and np.abs(out["up"][i] - r["up"]).max() < 1e-5
+            assert abs(out["timeScale"][i, 0] - r["t"]) < 1e-8 and np.abs(out["up"][i] - r["up"]).max() < 1e-4      # (flat directions reach the inputs at the 1e-5 level)
             assert np.abs(out["xp"][i] - r["xp"]).max() < 1e-3
             if out["iters"][i] != r["iters"] or out["info"][i, 6] != r["nreg"]:
                 flips.append((i, int(out["iters"][i]), r["iters"]))
