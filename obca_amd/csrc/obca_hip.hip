@@ -170,7 +170,9 @@ struct QDevBufs {
 __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
+    extern __shared__ double q_dyn_lds[];
     if (threadIdx.x == 0) {
+        quad::gq_sh.traj = q_dyn_lds;
         quad::QInst &I = quad::gq_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_d);
@@ -846,7 +848,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), 0, bt->stream, bt->B, bt->N, bt->d, ko);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * QS * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;
@@ -855,7 +857,7 @@ static int quadcopter_call(obca_ctx *ctx, int B, int N, const QuadIn &in, const 
     if (!ctx) return -1;
     if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { ctx->err = "need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
     if (!in.Ts || !in.x0 || !in.xF || !in.ob || !in.xWS || !in.timeWS) { ctx->err = "NULL argument"; return -1; }
-    const int chunk = pick_chunk(ctx, B, 2 * OBCA_QUAD_WAVES_PER_EU);
+    const int chunk = pick_chunk(ctx, B, (QNT == 64 ? 4 : 2) * OBCA_QUAD_WAVES_PER_EU);
     return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
         if (s.qb && (s.qb->cap < n || s.qb->N != N)) { obca_quad_batch_destroy(s.qb); s.qb = nullptr; }
         if (!s.qb) { int rc = quad_batch_create_on(ctx, s.device, s.stream, std::min(chunk, B), N, &s.qb, err); if (rc) return rc; }

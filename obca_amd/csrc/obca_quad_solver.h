@@ -1,4 +1,6 @@
-// obca_quad_solver.h -- one quadcopter signed-distance NLP instance (QuadcopterSignedDist.jl) solved by one 128-thread workgroup.
+// obca_quad_solver.h -- one quadcopter signed-distance NLP instance (QuadcopterSignedDist.jl) solved by ONE wavefront (64-thread workgroup), four instances per CU
+// (round 1 / early round 2: two wavefronts per instance, two instances per CU -- but the stage-parallel phases have 61 items and both sweeps run on one wavefront,
+// so the second wavefront idled three quarters of the time; with the MFMA sweep an instance needs neither its lanes nor the LDS they came with).
 //
 // Same programming model, interior-point algorithm and phase structure as obca_solver.h (parking); what differs is the model
 // (12 states, 4 rotor speeds, 5 box obstacles with 6 multipliers each, slack >= 0), hence the sizes: Riccati state 16 (x and the
@@ -10,7 +12,11 @@
 namespace obca {
 namespace quad {
 
-#define QNT 128                      // threads per instance: two wavefronts (the 16-state sweep has 288..680 items per phase)
+#ifdef OBCA_QUAD_RICCATI_LDS
+#define QNT 128                      // the LDS / VALU sweep (build variant) wants two wavefronts: 288..680 items per phase
+#else
+#define QNT 64                       // threads per instance: one wavefront
+#endif
 #define QNMAX 128                    // longest horizon (the forward-sweep trajectory lives in LDS: (QNMAX + 2) x 16 doubles)
 #define QSR 736                      // doubles per stage record: H 20x20 | Fh 16x18 | hc 20x2
 #define QSR_H 0
@@ -60,10 +66,15 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R
 struct QShared {
     QConsts c; QLay l; QInst inst; AsmOut A, A2, Ap; StepOut S; double trial[4];
     double ob[QOB * QL];
-    double red[16][QNT];               // reductions; during the sweeps the same memory holds That|Qhat or the forward-sweep ring
+    double red[16][QNT];               // reductions; during the sweeps the same memory holds That|Qhat or -- together with Pn, pn, sg behind it, which are dead
+                                       // by then -- the forward-sweep ring (2 x QFW_CH x QFW_SZ = 2 016 doubles <= 16 QNT + 256 + 224 + 736)
     double Pn[QS * QS], pn[QS * QC], sg[QSR], Khat[QU * 30], Bm[QC * QC], sB[4 * QC], Lq[QU * QU];
     double bord[13 * 13 + 3 * 13], coef[QC];
+#ifdef OBCA_EMU
     double traj[(QNMAX + 2) * QS];
+#else
+    double *traj;                      // (N + 2) x 16 doubles of dynamic LDS behind this block: the launch sizes it for the batch's horizon (N = 60: 7.9 KB, four instances per CU)
+#endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
