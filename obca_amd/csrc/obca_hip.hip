@@ -748,7 +748,7 @@ static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, i
     hipSetDevice(device);
     quad::QLay l; quad::q_make_layout(N, l);
     QDevBufs &d = bt->d; const size_t N1 = N + 1;
-    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSR; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
+    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
     size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
     ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);

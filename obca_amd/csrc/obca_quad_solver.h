@@ -32,6 +32,48 @@ namespace quad {
 #define QFC 18                       // columns of Fh
 #define QQC (QZ + QC)                // columns of the extended matrix (34)
 
+// ---------------------------------------------------------------- physical layout of the stage record
+// The logical stage record is dense (QSR = 736 doubles: H 20x20 | Fh 16x18 | hc 20x2) but only 291 of its entries are ever non-zero.  In HBM it is stored PACKED
+// (QSP = 288 doubles): QR(o) maps a logical offset o to its slot (structural zeros share one slot that holds 0, the constant 1 of the identity entries another).
+// The kernels are limited by HBM traffic: the dense record cost 5.9 KB per stage and pass to read and -- written 8 bytes at a time into a
+// sparse pattern -- 32 bytes per non-zero to write.  The -DOBCA_QUAD_RICCATI_LDS variant keeps the dense record (its sweep copies records into LDS wholesale).
+#ifdef OBCA_QUAD_RICCATI_LDS
+#define QSP QSR
+OBCA_FN int QR(int o) { return o; }
+#define QR_ZERO (QSR - 1)
+#else
+#define QP_LOC 0        // H[v][v'] over the 10 local variables (angles, rates, inputs)
+#define QP_POS 100      // H[0..2][0..2]
+#define QP_VEL 109      // H[6..8] diagonal
+#define QP_W 112        // H[w_j][w_j], then H[w_j][u_j], then H[u_j][w_j]
+#define QP_FD 124       // d (12), Ft (12)
+#define QP_TAU 148      // F[i][6 + i], i < 3
+#define QP_ONE 151      // the 1 of every identity entry of F
+#define QP_FLOC 152     // F[3..11][local columns]
+#define QP_HC 242       // hc 20 x 2
+#define QR_ZERO 282
+#define QSP 288
+OBCA_FN int q_vpos(int i) { return (i >= 3 && i < 6) ? i - 3 : ((i >= 9 && i < 12) ? i - 6 : ((i >= QS && i < QZ) ? i - 10 : -1)); }   // inverse of q_vidx
+OBCA_FN int QR(int o) {
+    if (o >= QSR_HC) return o < QSR_HC + 2 * QZ ? QP_HC + (o - QSR_HC) : QR_ZERO;
+    if (o >= QSR_F) {
+        const int i = (o - QSR_F) / QFC, cI = (o - QSR_F) % QFC;
+        if (cI >= 16) return i < QX ? QP_FD + (cI - 16) * QX + i : QR_ZERO;
+        const int id = cI < QX ? cI : cI + QU;                       // stage-vector index of the column
+        if (i < 3) return cI == i ? QP_ONE : (cI == 6 + i ? QP_TAU + i : QR_ZERO);
+        if (i < QX) { const int vp = q_vpos(id); return vp >= 0 ? QP_FLOC + (i - 3) * QV + vp : ((cI == i && i >= 6 && i < 9) ? QP_ONE : QR_ZERO); }
+        return cI == i ? QP_ONE : QR_ZERO;
+    }
+    const int i = o / QZ, j = o % QZ, vi = q_vpos(i), vj = q_vpos(j);
+    if (vi >= 0 && vj >= 0) return QP_LOC + vi * QV + vj;
+    if (i < 3 && j < 3) return QP_POS + i * 3 + j;
+    if (i == j && i >= 6 && i < 9) return QP_VEL + (i - 6);
+    if (i >= QX && i < QS) return j == i ? QP_W + (i - QX) : (j == i + QU ? QP_W + 4 + (i - QX) : QR_ZERO);
+    if (i >= QS && j == i - QU) return QP_W + 8 + (i - QS);
+    return QR_ZERO;
+}
+#endif
+
 #ifdef OBCA_EMU
 #define QPAR(lane) for (int lane = 0; lane < QNT; ++lane)
 #define QNLT QNT
@@ -162,7 +204,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     QPAR(lane) {
         double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lgtb = 0, lgtz = 0;
         for (int k = lane; k <= N; k += QNT) {
-            gdbl *rec = sh.inst.as + (size_t)k * QSR;
+            gdbl *rec = sh.inst.as + (size_t)k * QSP;
             double x[QX], hz[QX], hb[QX], xd[QX], Hpos[6] = {0, 0, 0, 0, 0, 0};
             BarAcc ba, bb, bu; bar_init(ba); bar_init(bb); bar_init(bu);      // barrier distances: states 0..5, states 6..11, inputs
 #pragma unroll
@@ -190,11 +232,11 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                     const double r = z[l.pi + QX * (N - 1) + i] + z[l.nu + i];
                     hz[i] += r; hb[i] += r; dmax = fmax(dmax, fabs(hz[i]));
                     lsy += fabs(z[l.nu + i]);
-                    rec[QSR_H + i * QZ + i] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
-                    rec[QSR_HC + 2 * i] = hb[i]; rec[QSR_HC + 2 * i + 1] = 0.0;
+                    rec[QR(QSR_H + i * QZ + i)] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
+                    rec[QR(QSR_HC + 2 * i)] = hb[i]; rec[QR(QSR_HC + 2 * i + 1)] = 0.0;
                 }
-                rec[QSR_H + 0 * QZ + 1] = Hpos[1]; rec[QSR_H + 1 * QZ + 0] = Hpos[1]; rec[QSR_H + 0 * QZ + 2] = Hpos[2]; rec[QSR_H + 2 * QZ + 0] = Hpos[2];
-                rec[QSR_H + 1 * QZ + 2] = Hpos[4]; rec[QSR_H + 2 * QZ + 1] = Hpos[4];
+                rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2]; rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
+                rec[QR(QSR_H + 1 * QZ + 2)] = Hpos[4]; rec[QR(QSR_H + 2 * QZ + 1)] = Hpos[4];
                 lbar += bar_log(ba) + bar_log(bb);
                 continue;
             }
@@ -209,17 +251,17 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int i = 0; i < QX; i++) {
                 const double r = z[l.x + QX * (k + 1) + i] - x[i] - tau * g[i];
                 pmax = fmax(pmax, fabs(r)); lth += fabs(r);
-                rec[QSR_F + i * QFC + 16] = -r; rec[QSR_F + i * QFC + 17] = c.Ts * g[i];
+                rec[QR(QSR_F + i * QFC + 16)] = -r; rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
             }
 #pragma unroll
-            for (int i = 0; i < 3; i++) rec[QSR_F + i * QFC + 6 + i] = tau;
+            for (int i = 0; i < 3; i++) rec[QR(QSR_F + i * QFC + 6 + i)] = tau;
 #pragma unroll
             for (int i = 3; i < QX; i++)
 #pragma unroll
                 for (int a = 0; a < QV; a++) {
                     const int id = q_vidx(a);
-                    if (id < QX) rec[QSR_F + i * QFC + id] = (id == i ? 1.0 : 0.0) + tau * dg[i - 3][a];
-                    else rec[QSR_F + i * QFC + 12 + (id - QS)] = tau * dg[i - 3][a];
+                    if (id < QX) rec[QR(QSR_F + i * QFC + id)] = (id == i ? 1.0 : 0.0) + tau * dg[i - 3][a];
+                    else rec[QR(QSR_F + i * QFC + 12 + (id - QS))] = tau * dg[i - 3][a];
                 }
             // J^T pi for x_k, u_k, t ; Hessian cross terms with t
             double Ht[QZ];
@@ -263,9 +305,9 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             }
             // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
 #pragma unroll
-            for (int i = 0; i < QX; i++) rec[QSR_H + i * QZ + i] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
-            rec[QSR_H + 0 * QZ + 1] = Hpos[1]; rec[QSR_H + 1 * QZ + 0] = Hpos[1]; rec[QSR_H + 0 * QZ + 2] = Hpos[2]; rec[QSR_H + 2 * QZ + 0] = Hpos[2];
-            rec[QSR_H + 1 * QZ + 2] = Hpos[4]; rec[QSR_H + 2 * QZ + 1] = Hpos[4];
+            for (int i = 0; i < QX; i++) rec[QR(QSR_H + i * QZ + i)] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
+            rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2]; rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
+            rec[QR(QSR_H + 1 * QZ + 2)] = Hpos[4]; rec[QR(QSR_H + 2 * QZ + 1)] = Hpos[4];
 #pragma unroll
             for (int a = 0; a < QV; a++)
 #pragma unroll
@@ -273,20 +315,20 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                     const int ia = q_vidx(a), ib = q_vidx(b_);
                     double v = -tau * HG[q_pidx(a, b_)];
                     if (a == b_) v += (ia < QX) ? xd[ia] : ud[ia - QS];
-                    rec[QSR_H + ia * QZ + ib] = v;
+                    rec[QR(QSR_H + ia * QZ + ib)] = v;
                 }
 #pragma unroll
             for (int j = 0; j < QU; j++) {
                 const double ww = k >= 1 ? 2e-2 : 0.0;
-                rec[QSR_H + (QX + j) * QZ + (QX + j)] = ww; rec[QSR_H + (QX + j) * QZ + (QS + j)] = -ww; rec[QSR_H + (QS + j) * QZ + (QX + j)] = -ww;
+                rec[QR(QSR_H + (QX + j) * QZ + (QX + j))] = ww; rec[QR(QSR_H + (QX + j) * QZ + (QS + j))] = -ww; rec[QR(QSR_H + (QS + j) * QZ + (QX + j))] = -ww;
             }
             // gradients / t-columns
 #pragma unroll
-            for (int i = 0; i < QX; i++) { rec[QSR_HC + 2 * i] = hb[i]; rec[QSR_HC + 2 * i + 1] = Ht[i]; }
+            for (int i = 0; i < QX; i++) { rec[QR(QSR_HC + 2 * i)] = hb[i]; rec[QR(QSR_HC + 2 * i + 1)] = Ht[i]; }
 #pragma unroll
             for (int j = 0; j < QU; j++) {
-                rec[QSR_HC + 2 * (QX + j)] = hzw[j]; rec[QSR_HC + 2 * (QX + j) + 1] = 0.0;
-                rec[QSR_HC + 2 * (QS + j)] = hbu[j]; rec[QSR_HC + 2 * (QS + j) + 1] = Ht[QS + j];
+                rec[QR(QSR_HC + 2 * (QX + j))] = hzw[j]; rec[QR(QSR_HC + 2 * (QX + j) + 1)] = 0.0;
+                rec[QR(QSR_HC + 2 * (QS + j))] = hbu[j]; rec[QR(QSR_HC + 2 * (QS + j) + 1)] = Ht[QS + j];
             }
             lbar += bar_log(ba) + bar_log(bb) + bar_log(bu);
         }
@@ -442,7 +484,7 @@ OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[QNL
         const QRicPlan &p = plan[LI(lane)];
         if (PIPE) {   // park the record of stage k-1 (gathered QRIC_D stages ago) and re-issue the slot
             const int kl = k - 1 - QRIC_D > 0 ? k - 1 - QRIC_D : 0;
-            const gdbl *rn = sh.inst.as + (size_t)kl * QSR;
+            const gdbl *rn = sh.inst.as + (size_t)kl * QSP;
 #pragma unroll
             for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; sh.sg[e < QSR ? e : QSR - 1] = e < QSR ? nv[LI(lane)][slot][r] : 0.0; }
 #pragma unroll
@@ -491,11 +533,11 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
     QRicPlan plan[QNLT];
     QPAR(lane) {
         q_ric_plan(lane, 0, (int)(sh.pn - &sh.red[0][0]), plan[LI(lane)]);
-        const gdbl *rec = sh.inst.as + (size_t)N * QSR;
-        for (int it = lane; it < QS * QS; it += QNT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QSR_H + i * QZ + j] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
+        const gdbl *rec = sh.inst.as + (size_t)N * QSP;
+        for (int it = lane; it < QS * QS; it += QNT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QR(QSR_H + i * QZ + j)] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
         for (int it = lane; it < QS * QC; it += QNT) {
             int i = it / QC, cc = it % QC; double v = 0;
-            if (i < QX) { if (cc == 0) v = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
+            if (i < QX) { if (cc == 0) v = rec[QR(QSR_HC + 2 * i)] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
             sh.pn[it] = v;
         }
         for (int it = lane; it < QC * QC; it += QNT) sh.Bm[it] = 0;
@@ -503,17 +545,17 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
     // head: synchronous gathers until the remaining stage count is a multiple of QRIC_D
     int k = N - 1;
     for (; k >= 0 && (k + 1) % QRIC_D != 0; k--) {
-        QPAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSR; for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i]; }
+        QPAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSP; for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i]; }
         LDS_BARRIER();
         if (!q_riccati_stage<0>(sh, k, plan, nv, 0)) return 0;
     }
     if (k < 0) return 1;
     QPAR(lane) {
-        const gdbl *r1 = sh.inst.as + (size_t)k * QSR;
+        const gdbl *r1 = sh.inst.as + (size_t)k * QSP;
         for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i];
 #pragma unroll
         for (int j = 0; j < QRIC_D; j++) {
-            const int st = k - 1 - j > 0 ? k - 1 - j : 0; const gdbl *rn = sh.inst.as + (size_t)st * QSR;
+            const int st = k - 1 - j > 0 ? k - 1 - j : 0; const gdbl *rn = sh.inst.as + (size_t)st * QSP;
 #pragma unroll
             for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; nv[LI(lane)][(j + 1) % QRIC_D][r] = rn[e < QSR ? e : QSR - 1]; }
         }
@@ -552,19 +594,19 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
 #define QMG 23                       // gathers per lane and stage
 struct QMPlan { int off[QMG]; };
 OBCA_FN void qm_plan(int lane, QMPlan &p) {
-    const int g = lane >> 4, j = lane & 15, Z = QSR - 1;      // Z: a zero of the record padding (lanes without an element)
+    const int g = lane >> 4, j = lane & 15, Z = QR_ZERO;          // Z: the slot of the structural zeros (lanes without an element)
     const int col = j < QX ? j : j + QU;                    // column of the stage vector (x | u) that tile column j stands for
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
-        p.off[kb] = QSR_F + (4 * kb + g) * QFC + j;
-        p.off[4 + kb] = j < 2 ? QSR_F + (4 * kb + g) * QFC + 16 + j : Z;
-        p.off[8 + kb] = j < QU ? QSR_F + (4 * kb + g) * QFC + QX + j : Z;
-        p.off[12 + kb] = QSR_H + (g + 4 * kb) * QZ + col;                       // H rows (x, w) of register kb
-        p.off[17 + kb] = j < 2 ? QSR_HC + 2 * (g + 4 * kb) + j : Z;
+        p.off[kb] = QR(QSR_F + (4 * kb + g) * QFC + j);
+        p.off[4 + kb] = j < 2 ? QR(QSR_F + (4 * kb + g) * QFC + 16 + j) : Z;
+        p.off[8 + kb] = j < QU ? QR(QSR_F + (4 * kb + g) * QFC + QX + j) : Z;
+        p.off[12 + kb] = QR(QSR_H + (g + 4 * kb) * QZ + col);                       // H rows (x, w) of register kb
+        p.off[17 + kb] = j < 2 ? QR(QSR_HC + 2 * (g + 4 * kb) + j) : Z;
     }
-    p.off[16] = QSR_H + (QS + g) * QZ + col;                                    // H rows u
-    p.off[21] = j < 2 ? QSR_HC + 2 * (QS + g) + j : Z;
-    p.off[22] = QSR_H + QX * QZ + QX;                                           // ww = H[w_0][w_0] (uniform)
+    p.off[16] = QR(QSR_H + (QS + g) * QZ + col);                                    // H rows u
+    p.off[21] = j < 2 ? QR(QSR_HC + 2 * (QS + g) + j) : Z;
+    p.off[22] = QR(QSR_H + QX * QZ + QX);                                           // ww = H[w_0][w_0] (uniform)
 }
 OBCA_FN void qm_gather(const gdbl *rec, const QMPlan &p, double (&v)[QMG]) {
 #pragma unroll
@@ -580,7 +622,7 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
         double v[QMG];
 #pragma unroll
         for (int e = 0; e < QMG; e++) v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
-        if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSR, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
+        if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSP, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             FXD0[r][L_] = v[r]; FXD0m[r][L_] = j < QX ? v[r] : 0.0; FXD1[r][L_] = v[4 + r]; FXU[r][L_] = v[8 + r];
@@ -656,24 +698,24 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
         PAR64(lane) {   // terminal cost-to-go: P_N = H_N[x, x] + rho I, p_N = (hb_N - rho e, 0, e_i)
             const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
             qm_plan(lane, plan[L_]);
-            const gdbl *rec = sh.inst.as + (size_t)N * QSR;
+            const gdbl *rec = sh.inst.as + (size_t)N * QSP;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = g + 4 * r; double v = 0.0, w = 0.0;
-                if (i < QX && j < QX) { v = rec[QSR_H + i * QZ + j]; if (i == j) v += rho; }
-                if (i < QX) { if (j == 0) w = rec[QSR_HC + 2 * i] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
+                if (i < QX && j < QX) { v = rec[QR(QSR_H + i * QZ + j)]; if (i == j) v += rho; }
+                if (i < QX) { if (j == 0) w = rec[QR(QSR_HC + 2 * i)] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
                 PD[r][L_] = v; pnD[r][L_] = w; BmD[r][L_] = 0.0;
             }
         }
         int k = N - 1, fin = 0;
         for (; k >= 0 && (k + 1) % QMD != 0; k--) {      // head: synchronous gathers until the remaining stage count is a multiple of QMD
-            PAR64(lane) { qm_gather(sh.inst.as + (size_t)k * QSR, plan[LI(lane)], raw[LI(lane)]); }
+            PAR64(lane) { qm_gather(sh.inst.as + (size_t)k * QSP, plan[LI(lane)], raw[LI(lane)]); }
             if (!q_riccati_stage_mfma<0>(sh, k, plan, PD, pnD, BmD, nv, 0, raw)) { ok = 0; fin = 1; break; }
         }
         if (!fin && k >= 0) {
             PAR64(lane) {
 #pragma unroll
-                for (int ju = 0; ju < QMD; ju++) { const int st = k - ju > 0 ? k - ju : 0; qm_gather(sh.inst.as + (size_t)st * QSR, plan[LI(lane)], nv[LI(lane)][ju]); }
+                for (int ju = 0; ju < QMD; ju++) { const int st = k - ju > 0 ? k - ju : 0; qm_gather(sh.inst.as + (size_t)st * QSP, plan[LI(lane)], nv[LI(lane)][ju]); }
 #ifndef OBCA_EMU
 #pragma unroll
                 for (int ju = 0; ju < QMD; ju++)
@@ -784,7 +826,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
 #pragma unroll
             for (int r = 0; r < QFW_PER; r++) {
                 const int e = lane + 64 * r, st = e / QFW_SZ, j = e % QFW_SZ;
-                if (e < QFW_CH * QFW_SZ && st < N) ring[e] = j < QFW_F ? (sh.inst.as + (size_t)st * QSR)[QSR_F + j] : (sh.inst.rs + (size_t)st * QRR)[QRR_K + (j - QFW_F)];
+                if (e < QFW_CH * QFW_SZ && st < N) ring[e] = j < QFW_F ? (sh.inst.as + (size_t)st * QSP)[QR(QSR_F + j)] : (sh.inst.rs + (size_t)st * QRR)[QRR_K + (j - QFW_F)];
             }
         }
         LDS_SYNC();
@@ -794,7 +836,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
 #pragma unroll
                 for (int r = 0; r < QFW_PER; r++) {
                     const int e = lane + 64 * r, st = k0 + QFW_CH + e / QFW_SZ, j = e % QFW_SZ; const int sc = st < N ? st : N - 1;
-                    const double v = j < QFW_F ? (sh.inst.as + (size_t)sc * QSR)[QSR_F + j] : (sh.inst.rs + (size_t)sc * QRR)[QRR_K + (j - QFW_F)];
+                    const double v = j < QFW_F ? (sh.inst.as + (size_t)sc * QSP)[QR(QSR_F + j)] : (sh.inst.rs + (size_t)sc * QRR)[QRR_K + (j - QFW_F)];
                     pf[LI(lane)][r] = v;
                 }
             }
@@ -873,11 +915,11 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                         d[l.pi + QX * k + i] = -a_;
                     }
                 } else {
-                    const gdbl *rN = sh.inst.as + (size_t)N * QSR;
+                    const gdbl *rN = sh.inst.as + (size_t)N * QSP;
                     for (int i = 0; i < QX; i++) {
                         const double e = -(z[l.x + QX * N + i] - c.xF[i]);
-                        double a_ = (rN[QSR_HC + 2 * i] - rho * e) + sh.coef[2 + i];
-                        for (int j = 0; j < QX; j++) a_ += (rN[QSR_H + i * QZ + j] + (i == j ? rho : 0.0)) * sn[j];
+                        double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
+                        for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
                         d[l.pi + QX * k + i] = -a_;
                     }
                 }
@@ -1026,14 +1068,14 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         for (int i = lane; i < l.m; i += QNT) z[l.n + i] = 0.0;
         for (int i = lane; i < l.n; i += QNT) { z[l.zL + i] = 1.0; z[l.zU + i] = 1.0; }
         // stage / Riccati records: zero once, constants of the dense layout
-        for (int i = lane; i < (N + 1) * QSR; i += QNT) sh.inst.as[i] = 0.0;
+        for (int i = lane; i < (N + 1) * QSP; i += QNT) sh.inst.as[i] = 0.0;
     }
     SYNC();
     QPAR(lane) {
         for (int k = lane; k <= N; k += QNT) {
-            gdbl *rec = sh.inst.as + (size_t)k * QSR;
-            for (int i = 0; i < 3; i++) { rec[QSR_F + i * QFC + i] = 1.0; rec[QSR_F + (6 + i) * QFC + (6 + i)] = 1.0; }
-            for (int j = 0; j < QU; j++) rec[QSR_F + (QX + j) * QFC + QX + j] = 1.0;          // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
+            gdbl *rec = sh.inst.as + (size_t)k * QSP;
+            for (int i = 0; i < 3; i++) { rec[QR(QSR_F + i * QFC + i)] = 1.0; rec[QR(QSR_F + (6 + i) * QFC + (6 + i))] = 1.0; }
+            for (int j = 0; j < QU; j++) rec[QR(QSR_F + (QX + j) * QFC + QX + j)] = 1.0;          // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
         }
         for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;

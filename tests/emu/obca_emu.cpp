@@ -112,7 +112,7 @@ struct QScratch { double *z, *d, *as, *rs, *oc; };
 static void q_alloc(int N, QScratch &s, quad::QLay &l) {
     quad::q_make_layout(N, l);
     s.z = (double *)calloc(l.len, 8); s.d = (double *)calloc(l.n + l.m, 8);
-    s.as = (double *)calloc((size_t)(N + 1) * QSR, 8); s.rs = (double *)calloc((size_t)(N + 1) * QRR, 8);
+    s.as = (double *)calloc((size_t)(N + 1) * QSP, 8); s.rs = (double *)calloc((size_t)(N + 1) * QRR, 8);
     s.oc = (double *)calloc((size_t)(N + 1) * QOB * OB_OC, 8);
 }
 static void q_free(QScratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); free(s.oc); }
@@ -134,8 +134,8 @@ int emu_quad_newton(int N, const double *prob, const double *zin, double mu, dou
     q_setup(N, prob, s); quad::QShared &sh = quad::gq_sh;
     // constants of the dense stage record (the solver writes them in its init phase)
     for (int k = 0; k <= N; k++) {
-        for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSR + QSR_F + i * QFC + i] = 1.0; s.as[(size_t)k * QSR + QSR_F + (6 + i) * QFC + 6 + i] = 1.0; }
-        for (int j = 0; j < QU; j++) s.as[(size_t)k * QSR + QSR_F + (QX + j) * QFC + QX + j] = 1.0;
+        for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSP + quad::QR(QSR_F + i * QFC + i)] = 1.0; s.as[(size_t)k * QSP + quad::QR(QSR_F + (6 + i) * QFC + 6 + i)] = 1.0; }
+        for (int j = 0; j < QU; j++) s.as[(size_t)k * QSP + quad::QR(QSR_F + (QX + j) * QFC + QX + j)] = 1.0;
     }
     quad::q_assemble_obs(sh, mu, dw, dc);
     AsmOut A; quad::q_assemble_stage(sh, mu, dw, dc, A);
