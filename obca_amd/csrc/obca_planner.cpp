@@ -205,7 +205,8 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
     const double res = opts ? opts[0] : 0.25, yres = (opts ? opts[1] : 7.5) * M_PI / 180, step = opts ? opts[2] : 0.6, smax = opts ? opts[3] : 0.6;
     const int nst = opts ? (int)opts[4] : 2; const double margin = opts ? opts[5] : 0.1, gtol = opts ? opts[6] : 0.3, ytol = (opts ? opts[7] : 8.0) * M_PI / 180;
     const double crev = opts ? opts[8] : 1.5, csw = opts ? opts[9] : 2.0, cst = opts ? opts[10] : 0.3; const long maxexp = opts ? (long)opts[11] : 400000;
-    const double analytic = opts ? opts[12] : 1.0;       // analytic (Reeds-Shepp) expansion towards the goal, hybrid_a_star.jl:193-214: 0 = off,
+    const double analytic = opts ? opts[12] : 1.0;
+    const double cchg = opts ? opts[13] : 0.2;          // steer-change cost per radian (hybrid_a_star.jl:63 STEER_CHANGE_COST)       // analytic (Reeds-Shepp) expansion towards the goal, hybrid_a_star.jl:193-214: 0 = off,
                                                          // else the fraction of the steering lock its arcs use (1 = the reference's full lock)
     World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
     for (int j = 0; j < nOb; j++) { if (vOb[j] < 1) return -1; w.off[j + 1] = w.off[j] + vOb[j]; }
@@ -296,7 +297,7 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
                     ok = !collides(w, x, y, yaw);
                 }
                 if (!ok) continue;
-                double g = cur.g + step * (d > 0 ? 1.0 : crev) + cst * std::fabs(steer) * step + 0.2 * std::fabs(steer - smax * cur.steer / nst);
+                double g = cur.g + step * (d > 0 ? 1.0 : crev) + cst * std::fabs(steer) * step + cchg * std::fabs(steer - smax * cur.steer / nst);
                 if (cur.dir != 0 && cur.dir != d) g += csw;
                 const long long k = key(x, y, yaw);
                 auto it = best.find(k);

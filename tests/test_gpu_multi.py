@@ -131,3 +131,31 @@ def test_two_ranks_on_one_gpu_scatter_solve_gather(OA):
     ref, _ = _resident(OA, sc, N)
     _same(out, ref, B)
     assert (out["exitflag"] == 1).all() and out["xp"].shape == (B, 4, N + 1) and out["np"][0].shape == (12, N + 1)
+
+
+def _nccl_rank(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from obca_amd import sharding
+    rng = np.random.default_rng(1); full = rng.standard_normal((7, 5))
+    loc = sharding.scatter_rows(full if rank == 0 else None, 7, 5, rank, world, 0)
+    back = sharding.gather_rows(loc * 2.0, 7, rank, world, 0)
+    summ = sharding.gather_summaries(loc[:, :2], 7, rank, world)
+    meta = [("hello", 3)] if rank == 0 else [None]
+    dist.broadcast_object_list(meta, src=0)
+    dist.barrier()
+    ret[rank] = (np.array_equal(loc, full), np.array_equal(back, 2.0 * full), np.array_equal(summ, full[:, :2]), meta[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharding_collectives_on_rccl(OA):
+    """the collectives bench.py uses under torchrun (scatter, gather, all_gather, object broadcast) on the `nccl` = RCCL backend with device tensors: one rank on the
+    one GPU of this box (two RCCL ranks cannot share a device); the 8-GPU runs are the driver's"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_nccl_rank, args=(1, 29711 + os.getpid() % 200, ret), nprocs=1, join=True)
+    assert ret[0] == (True, True, True, ("hello", 3))
