@@ -35,3 +35,52 @@ def parking_oracle_all(bt, xWS, workers=None, chunk=8):
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_parking_chunk, jobs)
     return sorted([r for ch in res for r in ch], key=lambda r: r[0])
+
+
+def _quad_chunk(args):
+    _init()
+    import oracle_quad as Q
+    (lo, x0, xF, N, Ts, R, ob, xWS) = args
+    out = []
+    for i in range(len(x0)):
+        r = Q.quadcopter_signed_dist(x0[i], xF[i], N, Ts, R, ob, xWS[i], 1.0)
+        out.append((lo + i, r["exitflag"], r["iters"], r["nreg"], r["obj"], r["up"], r["t"]))
+    return out
+
+
+def quad_oracle_all(bt, workers=None, chunk=8):
+    """quadcopter oracle on every instance of a batch of scenarios.make_quad_batch: list of (index, exitflag, iters, nreg, obj, up, t)"""
+    import multiprocessing as mp
+    import oracle_quad as Q
+    Q.lib()
+    B = len(bt["x0"]); N = bt["xWS"].shape[1] - 1
+    jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][lo:lo + chunk]) for lo in range(0, B, chunk)]
+    workers = workers or min(os.cpu_count() or 1, 64)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_quad_chunk, jobs)
+    return sorted([r for ch in res for r in ch], key=lambda r: r[0])
+
+
+def _mixed_chunk(args):
+    _init()
+    import oracle as O
+    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS) = args
+    out = []
+    for i in range(len(x0)):
+        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb[i], A[i], b[i], xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i])
+        out.append((lo + i, r["exitflag"], r["iters"], r["obj"], r["xp"]))
+    return out
+
+
+def mixed_oracle_all(bt, xWS, workers=None, chunk=8):
+    """parking oracle on every instance of a batch with per-instance obstacle sets (scenarios.make_mixed_batch)"""
+    import multiprocessing as mp
+    import oracle as O
+    O.build()
+    B = len(bt["x0"]); N = xWS.shape[1] - 1
+    jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"][lo:lo + chunk], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][lo:lo + chunk],
+             bt["A"][lo:lo + chunk], bt["b"][lo:lo + chunk], xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk]) for lo in range(0, B, chunk)]
+    workers = workers or min(os.cpu_count() or 1, 64)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_mixed_chunk, jobs)
+    return sorted([r for ch in res for r in ch], key=lambda r: r[0])

@@ -85,3 +85,19 @@ def test_emu_quadcopter_dist_variant_matches_oracle(Q, emu):
     assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"]) and np.abs(z[L["s"]:L["so"]]).max() == 0
     xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T
     assert np.abs(xp - r["xp"]).max() < 1e-4
+
+
+def test_emu_quad_lds_sweep_variant_matches_oracle(Q, emu_qlds):
+    """build variant -DOBCA_QUAD_RICCATI_LDS: the round-1 LDS / VALU sweep on two wavefronts with dense stage records, kept for A/B; the default is the MFMA sweep
+    (one wavefront, packed records), which the other tests of this file run"""
+    N = 30; Ts = round(0.25 * 80 / N * 100) / 100
+    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    oo = Q.default_opts(); eo = EOpts()
+    for f, _ in EOpts._fields_:
+        setattr(eo, f, getattr(oo, f))
+    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    z = np.zeros(L["len"]); info = np.zeros(8)
+    emu_qlds.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
+    assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"] and int(info[6]) == r["nreg"]
+    assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"])

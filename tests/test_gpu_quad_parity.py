@@ -142,3 +142,34 @@ def test_quad_matches_golden_fixture_config4():
     assert np.abs(out["timeScale"][:, 0] - g["t"]).max() < 1e-6
     assert np.abs(out["up"] - g["up"]).max() < 1e-5
     assert (out["iters"] == g["iters"]).sum() >= B - 1        # round-off may flip one inertia test
+
+
+@pytest.mark.timeout(900)
+def test_all_1024_quadcopter_bench_instances_match_oracle(Q):
+    """every instance of the config-4 bench batch (N = 60, random end points, A* warm starts) against the oracle run on all host cores: exit flags equal everywhere;
+    objective, time scale and inputs agree tightly on every instance whose iteration took the same branches (same iteration and regularisation counts: two fp64
+    implementations of one algorithm); the few instances where an inertia test decided by round-off takes the other branch must still reach the same optimum"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import obca_amd, oracle_pool
+    from obca_amd import scenarios as S
+    B, N = 1024, 60
+    bt = S.make_quad_batch(B, N, random_endpoints=True)
+    out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
+    ref = oracle_pool.quad_oracle_all(bt)
+    assert len(ref) == B
+    flips = 0; worst_f = worst_u = worst_t = 0.0
+    for (i, ef, it, nreg, obj, up, t) in ref:
+        assert out["exitflag"][i] == ef, (i, out["exitflag"][i], ef)
+        if ef != 1:
+            continue
+        same = out["iters"][i] == it and out["info"][i, 6] == nreg
+        flips += int(not same)
+        df = abs(out["obj"][i] - obj) / abs(obj)
+        if same:
+            worst_f = max(worst_f, df); worst_u = max(worst_u, np.abs(out["up"][i] - up).max()); worst_t = max(worst_t, abs(out["timeScale"][i, 0] - t))
+        else:
+            assert df < 1e-6, (i, df)            # another path through the iteration, the same optimum
+    assert (out["exitflag"] == 1).mean() > 0.99
+    assert flips <= 0.03 * B, flips
+    assert worst_f < 1e-8 and worst_t < 1e-7 and worst_u < 1e-3, (worst_f, worst_t, worst_u)
