@@ -52,6 +52,8 @@ typedef struct {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
     int lsq_init, verbose;
+    int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc = 4); 0 = off, the default: see DESIGN.md section 2 for the measured A/B */
+    int recalc_y;     /* recalc_y = "yes" (ParkingSignedDist.jl:41): least-squares multipliers once the constraint violation is below 1e-6; 0 = off (default) */
 } opts_t;
 
 void obca_oracle_default_opts(opts_t *o) {
@@ -66,6 +68,7 @@ void obca_oracle_default_opts(opts_t *o) {
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4;
     o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
+    o->max_soc = getenv("OBCA_SOC") ? atoi(getenv("OBCA_SOC")) : 0; o->recalc_y = getenv("OBCA_RECALC_Y") ? atoi(getenv("OBCA_RECALC_Y")) : 0;   /* environment: tools/soc_probe.py */
 }
 
 /* ------------------------------------------------------------------ iterate layout (one flat vector) */
@@ -291,6 +294,7 @@ typedef struct {
     double (*ds)[NCOL][6], (*du)[NCOL][2], (*pic)[NCOL][4];
     /* errors */
     double dinf, cinf_mu0, pinf, sumy, sumz; int nb, nm;
+    const double *csoc;  /* second-order correction: constraint values that replace c(z) on the right-hand side (layout pi | nu | yg | yo), or NULL */
 } kkt_t;
 
 static void *xcalloc(size_t n, size_t s) { void *q = calloc(n ? n : 1, s); if (!q) { fprintf(stderr, "oom\n"); exit(1); } return q; }
@@ -422,6 +426,8 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             obs_aux ax;
             obs_rows(p, j, x, lam, mu_, sl, so, F->c, &ax);
             for (int r = 0; r < 4; r++) { double a_ = fabs(F->c[r]); if (a_ > pmax) pmax = a_; sumy += fabs(y[r]); }
+            double cr[4];
+            for (int r = 0; r < 4; r++) cr[r] = K->csoc ? K->csoc[(l->yo - l->pi) + 4 * (k * nOb + j) + r] : F->c[r];
             nm += 4;
             double cs = ax.cs, sn = ax.sn, p1 = ax.p1, p2 = ax.p2, off = p->off;
             /* Jacobians */
@@ -487,7 +493,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             }
             T[8] += 1.0 / F->Dso + (p->dist ? 0.0 : 1.0 / F->Dsl);
             for (int r = 0; r < 3; r++) {
-                double a_ = lsq ? 0.0 : -F->c[r + 1];
+                double a_ = lsq ? 0.0 : -cr[r + 1];
                 for (int i = 0; i < 4; i++) a_ += Jmu[r + 1][i] * F->r_mu[i] / F->Dmu[i];
                 F->r234[r] = a_;
             }
@@ -519,7 +525,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
                 for (int r = 0; r < 3; r++) a_ += F->Jl[r + 1][i] * W[r][v + 3];
                 F->rk[i] = a_;
             }
-            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = lsq ? 0.0 : -F->c[0] + (p->dist ? F->r_sl / F->Dsl : 0.0);
+            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = lsq ? 0.0 : -cr[0] + (p->dist ? F->r_sl / F->Dsl : 0.0);
             if (!lamblock_factor(F, v, Kb, F->Jl[0], lsq ? 0.0 : dc + (p->dist ? 1.0 / F->Dsl : 0.0))) {
                 ok = 0;
                 if (getenv("OBCA_DBG")) fprintf(stderr, "lamblock fail k=%d j=%d y1=%g dw=%g\n", k, j, y[0], dw);
@@ -585,7 +591,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             double res = g - ss; if (fabs(res) > pmax) pmax = fabs(res);
             K->Dss[k] = lsq ? 1.0 : (Sig + dw); K->r_ss[k] = lsq ? rz : rb;
             double sig = 1.0 / (1.0 / K->Dss[k] + (lsq ? 0 : dc));
-            K->sig_g[k] = sig; K->rg[k] = (lsq ? 0.0 : res) + K->r_ss[k] / K->Dss[k];
+            K->sig_g[k] = sig; K->rg[k] = (lsq ? 0.0 : (K->csoc ? K->csoc[(l->yg - l->pi) + k] : res)) + K->r_ss[k] / K->Dss[k];
             /* indices of (w0, delta) inside the stage vector */
             int id[2] = {4, 6};
             for (int a_ = 0; a_ < 2; a_++) {
@@ -609,7 +615,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
                 A[i][2] += dF[i][0]; A[i][3] += dF[i][1]; B[i][0] = dF[i][2]; B[i][1] = dF[i][3];
                 K->Ftd[k][i] = p->fixTime ? 0 : dF[i][4];
                 double r = z[l->x + 4 * (k + 1) + i] - F[i];
-                K->dd[k][i] = lsq ? 0.0 : -r; if (fabs(r) > pmax) pmax = fabs(r);
+                K->dd[k][i] = lsq ? 0.0 : -(K->csoc ? K->csoc[4 * k + i] : r); if (fabs(r) > pmax) pmax = fabs(r);
                 sumy += fabs(pi[i]);
             }
             nm += 4;
@@ -670,7 +676,7 @@ static int kkt_solve(kkt_t *K, const double *z, double mu, double dc, double rho
     double Pn[6][6] = {{0}}, pn[NCOL][6] = {{0}};
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Pn[i][j] = K->Hs[N][i][j];
     double e[4];
-    for (int i = 0; i < 4; i++) { e[i] = lsq ? 0.0 : -(z[l->x + 4 * N + i] - p->xF[i]); Pn[i][i] += rho; }
+    for (int i = 0; i < 4; i++) { e[i] = lsq ? 0.0 : -(K->csoc ? K->csoc[(l->nu - l->pi) + i] : z[l->x + 4 * N + i] - p->xF[i]); Pn[i][i] += rho; }
     for (int i = 0; i < 6; i++) { pn[0][i] = K->hb[N][i]; pn[1][i] = K->Ht[N][i]; }
     for (int i = 0; i < 4; i++) { pn[0][i] -= rho * e[i]; pn[2 + i][i] = 1.0; }
     memcpy(K->P[N], Pn, sizeof Pn); memcpy(K->pv[N], pn, sizeof pn);
@@ -922,6 +928,23 @@ static double barrier_dir(const prob_t *p, const lay_t *l, const double *z, cons
     return g;
 }
 
+/* values of all equality rows at z (layout pi | nu | yg | yo, signs as the Newton system uses them) */
+static void constraint_values(const prob_t *p, const lay_t *l, const double *z, double *c) {
+    int N = p->N, nOb = p->nOb, M = p->M;
+    double t = z[l->t], q = t * p->Ts;
+    for (int k = 0; k < N; k++) {
+        double F[4]; const double *u = z + l->u + 2 * k;
+        dyn_eval(p, z + l->x + 4 * k, u, t, F, NULL, NULL, NULL);
+        for (int i = 0; i < 4; i++) c[4 * k + i] = z[l->x + 4 * (k + 1) + i] - F[i];
+        c[(l->yg - l->pi) + k] = ((k ? u[-2] : 0) - u[0]) / q - z[l->ss + k];
+    }
+    for (int i = 0; i < 4; i++) c[(l->nu - l->pi) + i] = z[l->x + 4 * N + i] - p->xF[i];
+    for (int k = 0; k <= N; k++) for (int j = 0; j < nOb; j++) {
+        int bo = k * nOb + j;
+        obs_rows(p, j, z + l->x + 4 * k, z + l->lam + k * M + p->roff[j], z + l->mu + 4 * bo, z[l->sl + bo], z[l->so + bo], c + (l->yo - l->pi) + 4 * bo, NULL);
+    }
+}
+
 /* ------------------------------------------------------------------ the interior-point driver */
 typedef struct { int status; int iters; int nreg; double obj, pinf, dinf, cinf, mu, t; } result_t;
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2, ST_INFEASIBLE = 3 };
@@ -962,7 +985,9 @@ static void reset_bound_mults(const prob_t *p, const lay_t *l, const opts_t *o, 
 static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *z, result_t *res) {
     int N = p->N, nOb = p->nOb, M = p->M;
     kkt_t *K = kkt_alloc(p, l);
-    double *d = xcalloc(l->len, sizeof(double)), *zt = xcalloc(l->len, sizeof(double));
+    double *d = xcalloc(l->len, sizeof(double)), *zt = xcalloc(l->len, sizeof(double)), *dsoc = xcalloc(l->len, sizeof(double));
+    double *csoc = xcalloc(l->zxL - l->pi, sizeof(double)), *ctr = xcalloc(l->zxL - l->pi, sizeof(double));
+    int max_soc = o->max_soc, nsoc = 0, nsoc_acc = 0, recalc_y = o->recalc_y, nrecalc = 0;
     double mu = o->mu_init, tau = fmax(o->tau_min, 1 - mu), dw_last = 0;
     double filt[FILT_MAX][2]; int nf = 0;
     /* initial point: x_0 = x0, x_N stays at the warm start (pulled to xF by the Newton step), bounds pushed */
@@ -1080,6 +1105,44 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
                     }
                 }
             }
+            /* second-order correction (IPOPT A-5.5..A-5.9, max_soc = 4, kappa_soc = 0.99): only for the first trial step and only if it did not reduce theta */
+            if (max_soc > 0 && ntrial == 1 && ft == ft && tht == tht && tht >= th) {
+                int nc = l->zxL - l->pi; double th_old = 0, th_tr = tht, asoc = alpha;
+                constraint_values(p, l, z, csoc);
+                for (int ps = 0; ps < max_soc && !acc && (ps == 0 || th_tr <= 0.99 * th_old); ps++) {
+                    th_old = th_tr;
+                    constraint_values(p, l, zt, ctr);
+                    for (int i = 0; i < nc; i++) csoc[i] = asoc * csoc[i] + ctr[i];
+                    K->csoc = csoc;
+                    int a = kkt_assemble(K, z, mu, dw, dc, 0);
+                    stage_dual_inf(K, z);
+                    if (a) a = kkt_solve(K, z, mu, dc, o->rho_term, 0, dsoc);
+                    K->csoc = NULL;
+                    if (!a) break;
+                    double azs; frac_to_boundary(p, l, z, dsoc, tau, &asoc, &azs);
+                    for (int i = 0; i < l->nprimal; i++) zt[i] = z[i] + asoc * dsoc[i];
+                    eval_f_theta(p, l, zt, &ft, &tht, &thi);
+                    nsoc++;
+                    if (!(ft == ft && tht == tht)) break;
+                    th_tr = tht;
+                    if (tht < th_max) {
+                        double pht = ft - mu * barrier_terms(p, l, zt);
+                        int okf = (pht == pht);
+                        for (int i = 0; i < nf && okf; i++) if (!(tht < filt[i][0] || pht < filt[i][1])) okf = 0;
+                        if (okf) {
+                            int sw = gd < 0 && alpha * pow(-gd, o->s_phi) > o->delta * pow(th, o->s_theta);
+                            int armijo = pht <= phi + o->eta_phi * alpha * gd;
+                            if (th <= th_min && sw) { if (armijo) acc = 1; }
+                            else if (tht <= (1 - o->gamma_theta) * th || pht <= phi - o->gamma_phi * th) {
+                                acc = 1;
+                                if (!(sw && armijo) && nf < FILT_MAX) { filt[nf][0] = (1 - o->gamma_theta) * th; filt[nf][1] = phi - o->gamma_phi * th; nf++; }
+                            }
+                        }
+                    }
+                    if (acc) { memcpy(d, dsoc, sizeof(double) * l->len); alpha = asoc; az = azs; nsoc_acc++; }
+                }
+                if (acc) break;
+            }
             alpha *= 0.5;
         }
         if (o->verbose > 1) printf("   ls: alpha_max %.3e accepted %.3e trials %d\n", ap, alpha, ntrial);
@@ -1089,12 +1152,28 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
         for (int i = l->pi; i < l->zxL; i++) z[i] += ay * d[i];
         for (int i = l->zxL; i < l->len; i++) z[i] += az * d[i];
         reset_bound_mults(p, l, o, z, mu);
+        if (recalc_y) {   /* recalc_y = "yes" (ParkingSignedDist.jl:41), recalc_y_feas_tol = 1e-6: least-squares equality multipliers once the point is (nearly) feasible */
+            double f2, th2, thi2;
+            eval_f_theta(p, l, z, &f2, &th2, &thi2);
+            if (thi2 < 1e-6) {
+                kkt_assemble(K, z, 0.0, 0, 0, 1);
+                stage_dual_inf(K, z);
+                for (int k = 0; k <= N; k++) memcpy(K->hb[k], K->hz[k], sizeof K->hb[k]);
+                K->gt_b = K->gt_z;
+                if (kkt_solve(K, z, 0.0, 0, 0.0, 1, dsoc)) {
+                    int fin = 1;
+                    for (int i = l->pi; i < l->zxL; i++) if (!(dsoc[i] == dsoc[i]) || fabs(dsoc[i]) > 1e300) fin = 0;
+                    if (fin) { for (int i = l->pi; i < l->zxL; i++) z[i] += dsoc[i]; nrecalc++; }
+                }
+            }
+        }
         it++;
     }
     eval_f_theta(p, l, z, &f, &th, &thinf);
     res->status = status; res->iters = it; res->nreg = nreg; res->obj = f; res->pinf = Emu_pinf; res->dinf = Emu_dinf;
     res->mu = mu; res->t = z[l->t]; res->cinf = K->cinf_mu0;
-    free(d); free(zt); kkt_free(K);
+    if (getenv("OBCA_SOC_STAT")) fprintf(stderr, "soc %d accepted %d recalc_y %d iters %d status %d\n", nsoc, nsoc_acc, nrecalc, it, status);
+    free(d); free(zt); free(dsoc); free(csoc); free(ctr); kkt_free(K);
 }
 
 /* ------------------------------------------------------------------ DualMultWS (DualMultWS.jl:29-86) */

@@ -187,3 +187,23 @@ def test_oracle_fixtime_and_retry_paths(oracle, backwards):
     r = oracle.parking_signed_dist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
                                    backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS, opts=o)
     assert r["exitflag"] == 0 and r["status"] == 1 and r["iters"] == 6
+
+
+def test_second_order_correction_and_recalc_y_options(oracle):
+    """IPOPT's second-order correction (max_soc = 4, A-5.5 of Waechter & Biegler) and recalc_y = "yes" (ParkingSignedDist.jl:41) exist as oracle options, off by
+    default (tools/soc_probe.py is the A/B behind that default: config 5, 512 instances: 506 -> 507 solved, +1.5 % iterations; config 3: -0.7 % iterations;
+    recalc_y changes 6 of 768 instances by one iteration).  Here: the options take a different path on some instance of the config-3 distribution and arrive at the
+    same optimum."""
+    bt = S.make_batch(S.PARALLEL, 16, 80, seed=20260925, goal_jitter=True)
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    base, soc = oracle.default_opts(), oracle.default_opts()
+    assert base.max_soc == 0 and base.recalc_y == 0
+    soc.max_soc = 4; soc.recalc_y = 1
+    changed = 0
+    for i in range(16):
+        xWS = bt["xWS"][i]; a = (bt["x0"][i], bt["xF"][i], 80, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r0 = oracle.parking_signed_dist(*a, opts=base); r1 = oracle.parking_signed_dist(*a, opts=soc)
+        assert r0["exitflag"] == 1 and r1["exitflag"] == 1
+        changed += r0["iters"] != r1["iters"]
+        assert abs(r0["obj"] - r1["obj"]) <= 1e-5 * abs(r0["obj"]) and np.abs(r0["xp"] - r1["xp"]).max() < 2e-3 and abs(r0["t"] - r1["t"]) < 1e-4
+    assert changed >= 1
