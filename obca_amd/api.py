@@ -273,11 +273,13 @@ class Batch:
 
 
 def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, lWS=None, nWS=None,
-                              opts=None, device=0, dist=False):
+                              opts=None, device=0, dist=False, buffers=None):
     """Batched ParkingSignedDist through the host-pointer entry point obca_parking_(signed_)dist_batch (what the Julia shim calls):
     x0,xF (B,4); rx,ry,ryaw (B,N+1); xWS (B,N+1,4); uWS (B,>=N,2); Ts scalar or (B,).
     Obstacles: one shared set (vOb 1-D, A (M,2), b (M,)) or per-instance lists.  lWS/nWS=None runs DualMultWS on the GPU.
-    `device`: an index, a list of indices or "all" (the batch is then sharded over the devices, obca_create_multi), or a Context."""
+    `device`: an index, a list of indices or "all" (the batch is then sharded over the devices, obca_create_multi), or a Context.
+    `buffers`: a dict the caller keeps between calls; the output arrays live in it and are written again by the next call of the same shape (a
+    16 384-instance call returns 280 MB: fresh arrays cost a page fault per 4 KB inside the C call, tools/pcie_rate.py measures both)."""
     x0 = np.ascontiguousarray(np.reshape(x0, (-1, 4)), float); B = x0.shape[0]
     ctx = _ctx(device)
     nObs, vflat, Aflat, bflat = _norm_obstacles(B, vOb, A, b)
@@ -290,8 +292,14 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
             _d(np.reshape(rx, (B, N + 1))), _d(np.reshape(ry, (B, N + 1))), _d(np.reshape(ryaw, (B, N + 1))),
             _d(np.asarray(xWS, float).reshape(B, -1, 4)[:, :N + 1]), _d(np.asarray(uWS, float).reshape(B, -1, 2)[:, :N]), _d(lWS), _d(nWS)]
     p = [k[1] for k in keep]
-    xp = np.empty((B, N + 1, 4)); up = np.empty((B, N, 2)); ts = np.empty((B, N + 1)); ef = np.zeros(B, np.int32)
-    lp = np.empty(Mt * (N + 1)); npp = np.empty(4 * nt * (N + 1)); sl = np.zeros(nt * (N + 1)); info = np.zeros((B, 8))
+    shapes = dict(xp=(B, N + 1, 4), up=(B, N, 2), ts=(B, N + 1), lp=(Mt * (N + 1),), npp=(4 * nt * (N + 1),), sl=(nt * (N + 1),), info=(B, 8))
+    bufs = buffers if buffers is not None else {}
+    for k, shp in shapes.items():
+        if k not in bufs or bufs[k].shape != shp:
+            bufs[k] = np.zeros(shp) if k in ("sl", "info") else np.empty(shp)
+    if "ef" not in bufs or bufs["ef"].shape != (B,):
+        bufs["ef"] = np.zeros(B, np.int32)
+    xp, up, ts, ef, lp, npp, sl, info = (bufs[k] for k in ("xp", "up", "ts", "ef", "lp", "npp", "sl", "info"))
     lib = _load()
     t0 = time.perf_counter()
     if dist:

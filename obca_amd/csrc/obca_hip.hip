@@ -402,11 +402,13 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
     }
     const DevBufs &d = bt->d;
     Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
-    const size_t W = (size_t)lmax.nprimal;                 // only the primal prefix (x,u,t,lam,mu,...) of the iterate travels over PCIe
+    const bool duals = in.lWS && in.nWS;
+    // only what the caller provides travels over PCIe: x, u, t (the same offsets in every instance's layout) and, with a dual warm start, lam and mu;
+    // the scatter kernel clears the rest of each row
+    const size_t W = duals ? (size_t)lmax.sl : (size_t)lmax.lam;
     if (pinned_reserve(bt->err, &bt->h_prob, &bt->hcap_prob, B * d.s_prob) || pinned_reserve(bt->err, &bt->h_zin, &bt->hcap_zin, B * W)) return -2;
     const double *ego = in.ego, *XYb = in.XYb;
     const double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];     /* ParkingSignedDist.jl:182-188 */
-    const bool duals = in.lWS && in.nWS;
     for (int i = 0; i < n; i++) {
         const int g = lo + i;
         double *p = bt->h_prob + (size_t)i * d.s_prob;
@@ -435,8 +437,8 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         if (duals) {
             memcpy(z + l.lam, in.lWS + r0 * N1, sizeof(double) * m * N1);
             memcpy(z + l.mu, in.nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * no * N1);
-            memset(z + l.sl, 0, sizeof(double) * (W - l.sl));
-        } else memset(z + l.lam, 0, sizeof(double) * (W - l.lam));
+            if ((size_t)l.sl < W) memset(z + l.sl, 0, sizeof(double) * (W - l.sl));      // a smaller instance's layout ends before the widest one's
+        }
     }
     bt->have_duals = duals ? 1 : 0; bt->fixTime = in.fixTime ? 1 : 0;
     HIPCHK(bt, hipMemcpyAsync(d.prob, bt->h_prob, (size_t)n * d.s_prob * sizeof(double), hipMemcpyHostToDevice, bt->stream));
