@@ -134,7 +134,8 @@ OBCA_FN void q_obs_rows(const QConsts &c, const QObsIn &in, double r[2], double 
 struct QObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
 struct QObsStep { double dlam[QL], ds, dso, dy[2]; };
 
-// MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp
+// MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp;
+// MODE 2: inertia of the block only (st->bad)
 template <int MODE>
 OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, QObsStats *st,
                          const double dp[3], QObsStep *step) {
@@ -219,6 +220,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
 #pragma unroll
         for (int j = 0; j < QL - 1; j++) Hr[i * (QL - 1) + j] = Hb[(i + 1) * QL + (j + 1)] - Mi0 * hc[i] * hc[j];
     bad |= ldl_fact<QL - 1>(QL - 1, Hr);
+    if (MODE == 2) { st->bad |= bad; return; }
     auto ksolve = [&](double *col /* QL+1 */) {
         hh_apply<QL>(QL, hw, hb, col);
         double g0 = col[0], gy = col[QL];

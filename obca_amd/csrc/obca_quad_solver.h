@@ -119,6 +119,7 @@ struct QShared {
 #endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
+    int hintl[QNT];                    // per lane: a box block whose inertia was wrong in an earlier assembly (-1: none), see q_block_bad
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
 #ifdef OBCA_EMU
@@ -158,12 +159,14 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z;
     QPAR(lane) {
         QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
-        double fsl = 0, th = 0, bar = 0;
+        double fsl = 0, th = 0, bar = 0; int badit = -1;
         for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
             ObsCond cd;
+            const int bad0 = st.bad;
             q_obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            if (st.bad && !bad0) badit = it;
             gdbl *o = sh.inst.oc + (size_t)it * OB_OC;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
@@ -185,13 +188,37 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
         sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
         sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
+        if (st.bad) sh.hintl[lane] = badit;
     }
     SYNC();
     AsmOut &P = sh.Ap;
     P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cinfmu = red_max(sh.red[3]);
     P.sumz = red_sum(sh.red[4]); P.sumy = red_sum(sh.red[5]); P.f = red_sum(sh.red[6]); P.th1 = red_sum(sh.red[7]);
-    P.bar = red_sum(sh.red[8]); P.ok = !(red_max(sh.red[9]) > 0.5);
+    P.bar = red_sum(sh.red[8]);
+    P.ok = !(red_max(sh.red[9]) > 0.5);
     SYNC();
+}
+
+// Inertia of remembered box blocks at a given delta_w.  IPOPT tries delta_w = 0 in every iteration and climbs a ladder of regularisations until the inertia is right;
+// on this problem most iterations fail the first rung(s) at the block level (the norm row |A'lam|^2 == 1 makes a lambda block indefinite whenever its multiplier is
+// negative), and mostly in blocks that failed an iteration earlier.  Every lane remembers the block it last saw fail (hintl) and re-tests just that block: if any of
+// them still fails, the rung is known to fail without being assembled, and the solve moves up the ladder exactly as it would have.
+OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
+    const QConsts &c = sh.c; const gdbl *z = sh.inst.z;
+    QPAR(lane) {
+        const int it = sh.hintl[lane];
+        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        if (it >= 0) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in);
+            q_obs_block<2>(c, in, mu, dw, dc, nullptr, &st, nullptr, nullptr);
+        }
+        sh.red[9][lane] = st.bad ? 1.0 : 0.0;
+    }
+    SYNC();
+    const int bad = red_max(sh.red[9]) > 0.5;
+    SYNC();
+    return bad;
 }
 
 // ---------------------------------------------------------------- assemble, part (b): stages (writes the non-zeros of the dense record)
@@ -245,11 +272,18 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int j = 0; j < QU; j++) u[j] = z[l.u + QU * k + j];
 #pragma unroll
             for (int i = 0; i < QX; i++) { pi[i] = z[l.pi + QX * k + i]; lsy += fabs(pi[i]); }
+            // everything else the stage reads from the iterate, before the first store into the record (a load behind a store that may alias waits for its own round trip)
+            double xn[QX], pim[QX], um[QU], un[QU], zLu[QU], zUu[QU];
+            const int km = k >= 1 ? k - 1 : 0, kn = k + 1 < N ? k + 1 : k;
+#pragma unroll
+            for (int i = 0; i < QX; i++) { xn[i] = z[l.x + QX * (k + 1) + i]; pim[i] = z[l.pi + QX * km + i]; }
+#pragma unroll
+            for (int j = 0; j < QU; j++) { um[j] = z[l.u + QU * km + j]; un[j] = z[l.u + QU * kn + j]; zLu[j] = z[l.zL + l.u + QU * k + j]; zUu[j] = z[l.zU + l.u + QU * k + j]; }
             dyn_g_derivs(c, x, u, pi, g, dg, HG);
             // residual, F columns d / Ft, A, B
 #pragma unroll
             for (int i = 0; i < QX; i++) {
-                const double r = z[l.x + QX * (k + 1) + i] - x[i] - tau * g[i];
+                const double r = xn[i] - x[i] - tau * g[i];
                 pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                 rec[QR(QSR_F + i * QFC + 16)] = -r; rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
             }
@@ -287,20 +321,20 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             lgtz -= gtl; lgtb -= gtl;
 #pragma unroll
             for (int i = 0; i < QX; i++) {
-                const double r = (k >= 1 ? z[l.pi + QX * (k - 1) + i] : 0.0) - ATpi[i];
+                const double r = (k >= 1 ? pim[i] : 0.0) - ATpi[i];
                 hz[i] += r; hb[i] += r; if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
             }
             // inputs: costs, bounds, copy terms
             double hzu[QU], hbu[QU], hzw[QU], ud[QU], wn[QU];
 #pragma unroll
             for (int j = 0; j < QU; j++) {
-                B2 b = bound2(u[j], Q_ULO, Q_UHI, z[l.zL + l.u + QU * k + j], z[l.zU + l.u + QU * k + j], mu, 1, lc0, lcmu, lsz);
+                B2 b = bound2(u[j], Q_ULO, Q_UHI, zLu[j], zUu[j], mu, 1, lc0, lcmu, lsz);
                 bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
                 double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
                 lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
-                if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
+                if (k >= 1) { const double e = um[j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
                 hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = hu + b.Sig + dw;
-                wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - z[l.u + QU * (k + 1) + j]) : 0.0;     // copy part living in stage k+1
+                wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - un[j]) : 0.0;     // copy part living in stage k+1
                 const double tot = hzu[j] + wn[j]; dmax = fmax(dmax, fabs(tot));
             }
             // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
@@ -576,37 +610,45 @@ OBCA_FN int q_riccati_body(QShared &sh, double rho) {
 }
 // ---------------------------------------------------------------- Riccati backward sweep on the matrix cores (default; -DOBCA_QUAD_RICCATI_LDS keeps the LDS / VALU sweep above)
 // The LDS sweep is bound by LDS bandwidth (every fp64 FMA of its products reads two operands from LDS: 10 k clocks per stage with two instances per CU).  Here the
-// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (35 per stage); the stage record is gathered
+// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (27 per stage); the stage record is gathered
 // from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
 //   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
 //   Register kb of a tile in D layout is the B operand of K-block kb (rows 4 kb .. 4 kb + 3), and the A operand of the TRANSPOSED tile.
 // Tiles (rows x columns; x = 12 states, w = copy of u_{k-1} (4), u = 4 inputs, rhs = main, t, nu_1..12):
 //   PD   (x,w) x (x,w)  value function, symmetric         pnD  (x,w) x rhs
-//   FXD0 FX[:, x|u columns]   FXD1 FX[:, d|Ft] (columns 0, 1)   FXU FX[:, u columns] (columns 0..3)         FX = [A B d Ft; 0 I 0 0] is the 16 x 18 block of the stage record
+//   FXD0 FX[:, x|u columns]   FXD1 FX[:, d|Ft] (columns 0, 1)         FX = [A B d Ft; 0 I 0 0] is the 16 x 18 block of the stage record
 //   Th0 = PD FXD0                         (x,w) x (x|u)          Th1 = pnD + PD FXD1                        (x,w) x rhs
-//   Q00 = H + FXD0(x cols)' Th0           (x,w) x (x|u)          Q01 = hc + FXD0(x cols)' Th1               (x,w) x rhs
-//   Q10 = H + FXU' Th0                     u    x (x|u)          Q11 = hc + FXU' Th1                         u    x rhs
-//   the w columns of the stage Hessian carry no product (F has zero columns there) and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww.
-//   Quu = Q10[:, u columns]: LDL' (uniform);  every lane solves the gains of its own column (x | w columns and the rhs columns)
-//   P' = Q00(x | w columns) + Q[., u] K    p' = Q01 + Q[., u] Kf    (Q[., u] taken as the transpose of Q10 / the closed-form w rows), P' symmetrised through LDS
-//   border constants  Bm += FXD1' Th1 + pnD' FXD1 + Q11' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a and the gain part, all into one accumulator tile)
+//   Q0  = H + FXD0' Th0                   (x,u) x (x|u)          Q1  = hc + FXD0' Th1                       (x,u) x rhs
+//   (the rows of a tile follow the columns of FXD0: x in registers 0..2, u in register 3.  The rows / columns of the input copy w carry no product -- F has zero
+//   columns there -- and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww, gradient hc[w]; they are written over register 3 once the u rows are used up.)
+//   Quu = Q0[u rows][u columns]: LDL' (uniform);  every lane solves the gains of its own column (x | w columns and the rhs columns)
+//   P' = Q0(x rows | closed-form w rows) + Q[., u] K    p' = Q1 + Q[., u] Kf    (Q[., u] = transpose of the u rows / the closed-form w rows), P' symmetrised through LDS
+//   border constants  Bm += FXD1' Th1 + pnD' FXD1 + Q1[u rows]' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a and the gain part, all into one accumulator tile)
+//   27 MFMAs per stage (a v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 clocks on gfx950: fp64 matrix rate = fp64 vector rate).
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
+#define QSEG(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); seg[i] += (double)(t_ - segt); segt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)      // diagnostic: where a stage of the sweep spends its clocks (prof[12..15])
+#else
+#define QSEG(i) ((void)0)
+#endif
 #define QMD 2                        // stages the gathers run ahead
-#define QMG 23                       // gathers per lane and stage
+#define QMG 18                       // gathers per lane and stage
 struct QMPlan { int off[QMG]; };
 OBCA_FN void qm_plan(int lane, QMPlan &p) {
     const int g = lane >> 4, j = lane & 15, Z = QR_ZERO;          // Z: the slot of the structural zeros (lanes without an element)
     const int col = j < QX ? j : j + QU;                    // column of the stage vector (x | u) that tile column j stands for
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
-        p.off[kb] = QR(QSR_F + (4 * kb + g) * QFC + j);
-        p.off[4 + kb] = j < 2 ? QR(QSR_F + (4 * kb + g) * QFC + 16 + j) : Z;
-        p.off[8 + kb] = j < QU ? QR(QSR_F + (4 * kb + g) * QFC + QX + j) : Z;
-        p.off[12 + kb] = QR(QSR_H + (g + 4 * kb) * QZ + col);                       // H rows (x, w) of register kb
-        p.off[17 + kb] = j < 2 ? QR(QSR_HC + 2 * (g + 4 * kb) + j) : Z;
+        p.off[kb] = QR(QSR_F + (4 * kb + g) * QFC + j);                             // [A B; 0 I]: rows 4 kb + g, columns x (12) and u (4)
+        p.off[4 + kb] = j < 2 ? QR(QSR_F + (4 * kb + g) * QFC + 16 + j) : Z;       // d, Ft
+        if (kb < 3) {
+            p.off[8 + kb] = QR(QSR_H + (g + 4 * kb) * QZ + col);                    // H rows x of register kb
+            p.off[12 + kb] = j < 2 ? QR(QSR_HC + 2 * (g + 4 * kb) + j) : Z;
+        }
     }
-    p.off[16] = QR(QSR_H + (QS + g) * QZ + col);                                    // H rows u
-    p.off[21] = j < 2 ? QR(QSR_HC + 2 * (QS + g) + j) : Z;
-    p.off[22] = QR(QSR_H + QX * QZ + QX);                                           // ww = H[w_0][w_0] (uniform)
+    p.off[11] = QR(QSR_H + (QS + g) * QZ + col);                                    // H rows u: register 3 of the tile (its w rows are known in closed form)
+    p.off[15] = j < 2 ? QR(QSR_HC + 2 * (QS + g) + j) : Z;                          // hc rows u
+    p.off[16] = j < 2 ? QR(QSR_HC + 2 * (QX + g) + j) : Z;                          // hc rows w
+    p.off[17] = QR(QSR_H + QX * QZ + QX);                                           // ww = H[w_0][w_0] (uniform)
 }
 OBCA_FN void qm_gather(const gdbl *rec, const QMPlan &p, double (&v)[QMG]) {
 #pragma unroll
@@ -614,44 +656,56 @@ OBCA_FN void qm_gather(const gdbl *rec, const QMPlan &p, double (&v)[QMG]) {
 }
 template <int PIPE>
 OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[OBCA_NLT], double (&PD)[4][OBCA_NLT], double (&pnD)[4][OBCA_NLT], double (&BmD)[4][OBCA_NLT],
-                                 double (&nv)[OBCA_NLT][QMD][QMG], const int slot, const double (*raw)[QMG]) {
-    double FXD0[4][OBCA_NLT], FXD0m[4][OBCA_NLT], FXD1[4][OBCA_NLT], FXU[4][OBCA_NLT], Th0[4][OBCA_NLT], Th1[4][OBCA_NLT];
-    double Q00[4][OBCA_NLT], Q01[4][OBCA_NLT], Q10[4][OBCA_NLT], Q11[4][OBCA_NLT], ww[OBCA_NLT];
+                                 double (&nv)[OBCA_NLT][QMD][QMG], const int slot, const double (*raw)[QMG], double (&seg)[4], long long &segt) {
+    // Tiles (row = lane group + 4 register, column = lane & 15): Q0 = [H | .] + [A B; 0 I]' Th0 and Q1 = hc + [A B; 0 I]' Th1 have the x rows in registers 0..2 and
+    // the u rows in register 3; the rows of the input copy w carry no product (F has zero columns there) and are filled in closed form below.
+    double FXD0[4][OBCA_NLT], FXD1[4][OBCA_NLT], Th0[4][OBCA_NLT], Th1[4][OBCA_NLT];
+    double Q0[4][OBCA_NLT], Q1[4][OBCA_NLT], ww[OBCA_NLT], hw[OBCA_NLT];
     PAR64(lane) {
-        const int L_ = LI(lane), j = lane & 15; const QMPlan &p = plan[L_];
+        const int L_ = LI(lane); const QMPlan &p = plan[L_];
         double v[QMG];
+        // The prefetched operands are MOVED out of the slot's registers (a real v_mov: a plain assignment is only a rename, the old values would stay live in the
+        // slot's registers for the whole stage, the re-issued gathers would land elsewhere and the copy back at the loop edge would wait for them -- vmcnt(3)
+        // after every pair of stages, measured) so that the gathers of the stage QMD ahead return straight into the registers they are consumed from.
 #pragma unroll
-        for (int e = 0; e < QMG; e++) v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
+        for (int e = 0; e < QMG; e++) {
+#ifndef OBCA_EMU
+            if (PIPE) asm volatile("v_mov_b64 %0, %1" : "=v"(v[e]) : "v"(nv[L_][slot][e]));
+            else v[e] = raw[L_][e];
+#else
+            v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
+#endif
+        }
         if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSP, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            FXD0[r][L_] = v[r]; FXD0m[r][L_] = j < QX ? v[r] : 0.0; FXD1[r][L_] = v[4 + r]; FXU[r][L_] = v[8 + r];
-            Q00[r][L_] = v[12 + r]; Q01[r][L_] = v[17 + r]; Th0[r][L_] = 0.0; Th1[r][L_] = pnD[r][L_];
-            Q10[r][L_] = r == 0 ? v[16] : 0.0; Q11[r][L_] = r == 0 ? v[21] : 0.0;
+            FXD0[r][L_] = v[r]; FXD1[r][L_] = v[4 + r];
+            Q0[r][L_] = v[8 + r]; Q1[r][L_] = v[12 + r]; Th0[r][L_] = 0.0; Th1[r][L_] = pnD[r][L_];
         }
-        ww[L_] = v[22];
+        hw[L_] = v[16]; ww[L_] = v[17];
     }
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) { wv_mfma(Th0, PD[kb], FXD0[kb]); wv_mfma(Th1, PD[kb], FXD1[kb]); }
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
-        wv_mfma(Q00, FXD0m[kb], Th0[kb]); wv_mfma(Q01, FXD0m[kb], Th1[kb]);
-        wv_mfma(Q10, FXU[kb], Th0[kb]); wv_mfma(Q11, FXU[kb], Th1[kb]);
+        wv_mfma(Q0, FXD0[kb], Th0[kb]); wv_mfma(Q1, FXD0[kb], Th1[kb]);
         wv_mfma(BmD, FXD1[kb], Th1[kb]); wv_mfma(BmD, pnD[kb], FXD1[kb]);       // static parts of the border constants (pnD: still the next stage's p)
     }
-    // Quu = Q10[u rows][u columns]: lane (a, 12 + b) of register 0
+    QSEG(0);
+    // Quu = Q0[u rows][u columns]: lane (a, 12 + b) of register 3
     double Lq[QU * QU];
 #pragma unroll
     for (int a = 0; a < QU; a++)
 #pragma unroll
-        for (int b_ = 0; b_ < QU; b_++) Lq[a * QU + b_] = WV_READLANE(Q10[0], 16 * a + QX + b_);
+        for (int b_ = 0; b_ < QU; b_++) Lq[a * QU + b_] = WV_READLANE(Q0[3], 16 * a + QX + b_);
     const int ok = UNIFORM(ldl_fact<QU>(QU, Lq) ? 0 : 1);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
     const double wwu = WV_READLANE(ww, 0);
-    // the four u-row entries of every column: rows u_0..u_3 sit in lane groups 0..3 of register 0
+    // the four u-row entries of every column: rows u_0..u_3 sit in lane groups 0..3 of register 3
     double c0[QU][OBCA_NLT], c1[QU][OBCA_NLT];
 #pragma unroll
-    for (int a = 0; a < QU; a++) { wv_shfl_group(c0[a], Q10[0], a); wv_shfl_group(c1[a], Q11[0], a); }
-    double Aq[OBCA_NLT], Bk0[OBCA_NLT], Bk1[OBCA_NLT], Sn[4][OBCA_NLT];
+    for (int a = 0; a < QU; a++) { wv_shfl_group(c0[a], Q0[3], a); wv_shfl_group(c1[a], Q1[3], a); }
+    QSEG(1);
+    double Aq[OBCA_NLT], Bk0[OBCA_NLT], Bk1[OBCA_NLT], Sn[4][OBCA_NLT], Qu1[OBCA_NLT];
     gdbl *ro = sh.inst.rs + (size_t)k * QRR;
     PAR64(lane) {
         const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
@@ -661,31 +715,34 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
         ldl_solve<QU>(QU, Lq, b0); ldl_solve<QU>(QU, Lq, b1);
         const double k0 = g == 0 ? b0[0] : (g == 1 ? b0[1] : (g == 2 ? b0[2] : b0[3])), k1 = g == 0 ? b1[0] : (g == 1 ? b1[1] : (g == 2 ? b1[2] : b1[3]));
         Bk0[L_] = k0; Bk1[L_] = j < QC ? k1 : 0.0;
-        Aq[L_] = j < QX ? Q10[0][L_] : (j - QX == g ? -wwu : 0.0);               // Q[row][u_g]: transpose of Q10 for the x rows, closed form for the w rows
+        Aq[L_] = j < QX ? Q0[3][L_] : (j - QX == g ? -wwu : 0.0);                // Q[row][u_g]: transpose of the u rows for the x rows, closed form for the w rows
 #pragma unroll
-        for (int r = 0; r < 4; r++) Sn[r][L_] = j < QX ? Q00[r][L_] : ((g + 4 * r) == j ? wwu : 0.0);      // w columns of [H | .]: ww on the (w, w) diagonal
+        for (int r = 0; r < 4; r++) Sn[r][L_] = j < QX ? (r < 3 ? Q0[r][L_] : 0.0) : ((g + 4 * r) == j ? wwu : 0.0);      // w rows / columns of [H | .]: ww on the (w, w) diagonal, nothing else
+        Qu1[L_] = Q1[3][L_]; Q1[3][L_] = hw[L_];                                  // u rows of the right-hand sides go to the border constants, register 3 becomes the w rows (hc only)
         ro[QRR_K + g * QS + j] = k0;                                              // gains: row g, column j of the 4 x 16 / 4 x 14 blocks
         ro[j < QC ? QRR_KF + g * QC + j : QRR_PAD] = k1;
     }
-    wv_mfma(Sn, Aq, Bk0); wv_mfma(Q01, Aq, Bk1); wv_mfma(BmD, Q11[0], Bk1);
+    QSEG(2);
+    wv_mfma(Sn, Aq, Bk0); wv_mfma(Q1, Aq, Bk1); wv_mfma(BmD, Qu1, Bk1);
     // symmetrise the value function through LDS (without it round-off flipped the Quu > 0 inertia test on this badly scaled problem)
     double *tr = &sh.red[0][0];
     PAR64(lane) {
         const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 16 + j] = Sn[r][L_];
+        for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 17 + j] = Sn[r][L_];       // row stride 17: the transposed read below would hit one LDS bank 16 times with stride 16
     }
     LDS_SYNC();
     PAR64(lane) {
         const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const double v = 0.5 * (Sn[r][L_] + tr[j * 16 + (g + 4 * r)]);
-            PD[r][L_] = v; pnD[r][L_] = j < QC ? Q01[r][L_] : 0.0;
+            const double v = 0.5 * (Sn[r][L_] + tr[j * 17 + (g + 4 * r)]);
+            PD[r][L_] = v; pnD[r][L_] = j < QC ? Q1[r][L_] : 0.0;
             if (r < 3) { ro[QRR_PX + (g + 4 * r) * QS + j] = v; ro[j < QC ? QRR_PV + (g + 4 * r) * QC + j : QRR_PAD] = pnD[r][L_]; }      // rows 0..11 of P / p
         }
     }
     LDS_SYNC();
+    QSEG(3);
     return ok;
 }
 
@@ -695,6 +752,7 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
     WAVE0_BEGIN
         double nv[OBCA_NLT][QMD][QMG], raw[OBCA_NLT][QMG], PD[4][OBCA_NLT], pnD[4][OBCA_NLT], BmD[4][OBCA_NLT];
         QMPlan plan[OBCA_NLT];
+        double seg[4] = {0, 0, 0, 0}; long long segt = 0;
         PAR64(lane) {   // terminal cost-to-go: P_N = H_N[x, x] + rho I, p_N = (hb_N - rho e, 0, e_i)
             const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
             qm_plan(lane, plan[L_]);
@@ -710,7 +768,7 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
         int k = N - 1, fin = 0;
         for (; k >= 0 && (k + 1) % QMD != 0; k--) {      // head: synchronous gathers until the remaining stage count is a multiple of QMD
             PAR64(lane) { qm_gather(sh.inst.as + (size_t)k * QSP, plan[LI(lane)], raw[LI(lane)]); }
-            if (!q_riccati_stage_mfma<0>(sh, k, plan, PD, pnD, BmD, nv, 0, raw)) { ok = 0; fin = 1; break; }
+            if (!q_riccati_stage_mfma<0>(sh, k, plan, PD, pnD, BmD, nv, 0, raw, seg, segt)) { ok = 0; fin = 1; break; }
         }
         if (!fin && k >= 0) {
             PAR64(lane) {
@@ -723,11 +781,17 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
                     for (int e = 0; e < QMG; e++) asm volatile("" : "+v"(nv[0][ju][e]));
 #endif
             }
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
+            segt = clock64();
+#endif
             for (int kb = k; kb >= QMD - 1 && ok; kb -= QMD) {
 #pragma unroll
-                for (int ju = 0; ju < QMD; ju++) ok &= q_riccati_stage_mfma<1>(sh, kb - ju, plan, PD, pnD, BmD, nv, ju, nullptr);
+                for (int ju = 0; ju < QMD; ju++) ok &= q_riccati_stage_mfma<1>(sh, kb - ju, plan, PD, pnD, BmD, nv, ju, nullptr, seg, segt);
             }
         }
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
+        if (LANE0) { for (int i = 0; i < 4; i++) sh.prof[12 + i] += seg[i]; }
+#endif
         // border constants to LDS, exactly symmetric (the accumulator tile is symmetric up to round-off)
         double *tr = &sh.red[0][0];
         PAR64(lane) {
@@ -881,48 +945,62 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
         for (int k = lane; k <= N; k += QNT) {
-            const double *s = sh.traj + (size_t)k * QS;
+            // All loads of the stage come first and all stores last: d and z may alias as far as the compiler knows, so a load after a store would wait for its
+            // own round trip (the stage used to take one round trip per state and per costate row).
+            const double *s = sh.traj + (size_t)k * QS, *sn = sh.traj + (size_t)(k + 1 <= N ? k + 1 : N) * QS;
+            const int ku = k < N ? k : N - 1, km = ku >= 1 ? ku - 1 : 0;
+            double xv[QX], zLx[QX], zUx[QX], uv[QU], um[QU], zLu[QU], zUu[QU], dpi[QX];
+#pragma unroll
+            for (int i = 0; i < QX; i++) { xv[i] = z[l.x + QX * k + i]; zLx[i] = z[l.zL + l.x + QX * k + i]; zUx[i] = z[l.zU + l.x + QX * k + i]; }
+#pragma unroll
+            for (int j = 0; j < QU; j++) { uv[j] = z[l.u + QU * ku + j]; um[j] = z[l.u + QU * km + j]; zLu[j] = z[l.zL + l.u + QU * ku + j]; zUu[j] = z[l.zU + l.u + QU * ku + j]; }
+            if (k + 1 < N) {
+                const gdbl *r1 = sh.inst.rs + (size_t)(k + 1) * QRR;
+#pragma unroll
+                for (int i = 0; i < QX; i++) {
+                    double a_ = 0;
+#pragma unroll
+                    for (int cc = 0; cc < QC; cc++) a_ += r1[QRR_PV + i * QC + cc] * sh.coef[cc];
+#pragma unroll
+                    for (int j = 0; j < QS; j++) a_ += r1[QRR_PX + i * QS + j] * sn[j];
+                    dpi[i] = -a_;
+                }
+            } else if (k < N) {
+                const gdbl *rN = sh.inst.as + (size_t)N * QSP;
+#pragma unroll
+                for (int i = 0; i < QX; i++) {
+                    const double e = -(z[l.x + QX * N + i] - c.xF[i]);
+                    double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
+                    for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
+                    dpi[i] = -a_;
+                }
+            }
+#pragma unroll
             for (int i = 0; i < QX; i++) {
-                const double xv = z[l.x + QX * k + i], dx = s[i];
+                const double dx = s[i];
                 d[l.x + QX * k + i] = dx;
-                if (i >= 9) gd += 2e-4 * xv * dx;
+                if (i >= 9) gd += 2e-4 * xv[i] * dx;
                 if (k >= 1) {
-                    const double dL = xv - q_xlb(i, c.dist), dU = q_xub(i, c.dist) - xv, zL = z[l.zL + l.x + QX * k + i], zU = z[l.zU + l.x + QX * k + i];
+                    const double dL = xv[i] - q_xlb(i, c.dist), dU = q_xub(i, c.dist) - xv[i], zL = zLx[i], zU = zUx[i];
                     gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dx;
                     FTBP(dL, dx); FTBP(dU, -dx);
                     FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * dx); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * dx);
                 }
             }
             if (k < N) {
+#pragma unroll
                 for (int j = 0; j < QU; j++) {
-                    const double du = sh.traj[(size_t)(k + 1) * QS + QX + j];        // w_{k+1} = u_k
+                    const double du = sn[QX + j];        // w_{k+1} = u_k
                     d[l.u + QU * k + j] = du;
-                    const double uv = z[l.u + QU * k + j];
-                    double gu = -2e-3 * (c.wH - uv);
-                    if (k >= 1) { const double e = z[l.u + QU * (k - 1) + j] - uv; gu -= 2e-2 * e; gd += 2e-2 * e * s[QX + j]; }
-                    const double dL = uv - Q_ULO, dU = Q_UHI - uv, zL = z[l.zL + l.u + QU * k + j], zU = z[l.zU + l.u + QU * k + j];
+                    double gu = -2e-3 * (c.wH - uv[j]);
+                    if (k >= 1) { const double e = um[j] - uv[j]; gu -= 2e-2 * e; gd += 2e-2 * e * s[QX + j]; }
+                    const double dL = uv[j] - Q_ULO, dU = Q_UHI - uv[j], zL = zLu[j], zU = zUu[j];
                     gd += (gu - rdiv(mu, dL) + rdiv(mu, dU)) * du;
                     FTBP(dL, du); FTBP(dU, -du);
                     FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * du); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * du);
                 }
-                const double *sn = sh.traj + (size_t)(k + 1) * QS;
-                if (k + 1 < N) {
-                    const gdbl *r1 = sh.inst.rs + (size_t)(k + 1) * QRR;
-                    for (int i = 0; i < QX; i++) {
-                        double a_ = 0;
-                        for (int cc = 0; cc < QC; cc++) a_ += r1[QRR_PV + i * QC + cc] * sh.coef[cc];
-                        for (int j = 0; j < QS; j++) a_ += r1[QRR_PX + i * QS + j] * sn[j];
-                        d[l.pi + QX * k + i] = -a_;
-                    }
-                } else {
-                    const gdbl *rN = sh.inst.as + (size_t)N * QSP;
-                    for (int i = 0; i < QX; i++) {
-                        const double e = -(z[l.x + QX * N + i] - c.xF[i]);
-                        double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
-                        for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
-                        d[l.pi + QX * k + i] = -a_;
-                    }
-                }
+#pragma unroll
+                for (int i = 0; i < QX; i++) d[l.pi + QX * k + i] = dpi[i];
             }
         }
         sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;
@@ -1043,17 +1121,36 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
 // ---------------------------------------------------------------- accept the step (generic over the primal vector)
 OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, double mu, double ks) {
     const QLay &l = sh.l; const int N = sh.c.N; gdbl *z = sh.inst.z; const gdbl *d = sh.inst.d;
+    // The iterate is updated in place, so the compiler cannot hoist a load over an earlier store (may alias): QAP_R items per lane are processed at a time,
+    // all their loads first (indices clamped, the multiplier arrays cover every primal variable), then the arithmetic and the stores -- one memory round trip
+    // per chunk instead of one per item (a lone wavefront per SIMD has nothing else to hide the latency with).
+#define QAP_R 6
     QPAR(lane) {
-        for (int i = lane; i < l.n; i += QNT) {
-            const QBnd b = q_bounds(l, N, i, sh.c.dist);
-            double v = z[i]; const double dv = d[i];
-            if (i < QX) continue;                        // x_0 is a constant
-            if (b.hasL) { double zz = zstep(z[l.zL + i], v - b.lo, dv, mu, az); z[l.zL + i] = clampz(zz, v + alpha * dv - b.lo, mu, ks); }
-            if (b.hasU) { double zz = zstep(z[l.zU + i], b.hi - v, -dv, mu, az); z[l.zU + i] = clampz(zz, b.hi - (v + alpha * dv), mu, ks); }
-            z[i] = v + alpha * dv;
+        for (int base = 0; base < l.n; base += QAP_R * QNT) {
+            double v[QAP_R], dv[QAP_R], zl[QAP_R], zu[QAP_R];
+#pragma unroll
+            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.n ? i : 0; v[r] = z[ic]; dv[r] = d[ic]; zl[r] = z[l.zL + ic]; zu[r] = z[l.zU + ic]; }
+#pragma unroll
+            for (int r = 0; r < QAP_R; r++) {
+                const int i = base + lane + QNT * r;
+                if (i >= QX && i < l.n) {                  // x_0 is a constant
+                    const QBnd b = q_bounds(l, N, i, sh.c.dist);
+                    const double v1 = v[r] + alpha * dv[r];
+                    if (b.hasL) z[l.zL + i] = clampz(zstep(zl[r], v[r] - b.lo, dv[r], mu, az), v1 - b.lo, mu, ks);
+                    if (b.hasU) z[l.zU + i] = clampz(zstep(zu[r], b.hi - v[r], -dv[r], mu, az), b.hi - v1, mu, ks);
+                    z[i] = v1;
+                }
+            }
         }
-        for (int i = lane; i < l.m; i += QNT) z[l.n + i] += ay * d[l.n + i];
+        for (int base = 0; base < l.m; base += QAP_R * QNT) {
+            double yv[QAP_R], dy[QAP_R];
+#pragma unroll
+            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.m ? i : 0; yv[r] = z[l.n + ic]; dy[r] = d[l.n + ic]; }
+#pragma unroll
+            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r; if (i < l.m) z[l.n + i] = yv[r] + ay * dy[r]; }
+        }
     }
+#undef QAP_R
     SYNC();
 }
 
@@ -1157,6 +1254,7 @@ OBCA_FN void q_restore_blocks(QShared &sh, double bound_push) {
 OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); QPROF(QPF_INIT); }
 OBCA_PHASE double qph_min_norm2() { return q_min_norm2(gq_sh); }
 OBCA_PHASE void qph_restore(double bp) { q_restore_blocks(gq_sh, bp); }
+OBCA_PHASE int qph_block_bad(double mu, double dw, double dc) { const int b = q_block_bad(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); return b; }
 OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
 OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
 OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
@@ -1182,17 +1280,29 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     SYNC();
     qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS]);
     double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
-    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1;
+    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1, have_hint = 0;
     const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
     double dc_mu = -1.0, dc_val = 0;
+    QPAR(lane) { sh.hintl[lane] = -1; }
+    SYNC();
     if (qph_min_norm2() < 1e-12) { qph_restore(o.bound_push); nrest++; }      // rank-deficient start (the reference's lambda = 0.05): restoration first
     // where IPOPT would enter its restoration phase (line search or inertia correction failed): block restoration, barrier restart, empty filter
+#define Q_NEXT_RUNG(dw_) ((dw_) == 0 ? (dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last)) : (dw_) * (dw_last == 0 ? o.kw_inc0 : o.kw_inc))
 #define Q_RESTORE_AND_CONTINUE { qph_restore(o.bound_push); nrest++; mu = o.mu_init; tau = fmax(o.tau_min, 1 - mu); nf = 0; dw_last = 0; reset_th = 1; continue; }
     for (;;) {
         if (mu != dc_mu) { dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
         double dc = dc_val;
-        qph_assemble(mu, 0.0, dc, 0);
+        // rungs of the inertia ladder (IPOPT Algorithm IC) that a remembered block is known to fail are counted and skipped, see q_block_bad
+        int nskip = 0; double dw_first = 0;
+        if (have_hint) { while (dw_first <= o.dw_max && qph_block_bad(mu, dw_first, dc)) { nskip++; dw_first = Q_NEXT_RUNG(dw_first); } }
+        if (dw_first > o.dw_max) { nskip = 0; dw_first = 0; }
+        double dw_have = dw_first;                      // the regularisation of the system the records hold
+        qph_assemble(mu, dw_have, dc, 0);
+        if (!A.ok) have_hint = 1;
+#ifdef OBCA_SPEC_DEBUG
+        fprintf(stderr, "it %d skip %d ok %d\n", it, nskip, A.ok);
+#endif
         if (reset_th) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); reset_th = 0; }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
@@ -1215,15 +1325,21 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
             }
         }
         dc = dc_val;
-        double dw = 0; int ok = 0;
+        if (mu_changed) {      // delta_c moved with mu, and the records hold the system of the error test
+            nskip = 0; dw_first = 0; dw_have = -1.0;
+            if (have_hint) { while (dw_first <= o.dw_max && qph_block_bad(mu, dw_first, dc)) { nskip++; dw_first = Q_NEXT_RUNG(dw_first); } }
+            if (dw_first > o.dw_max) { nskip = 0; dw_first = 0; }
+        }
+        double dw = dw_first; int ok = 0;
+        nreg += nskip;
         for (int tr = 0; tr < 60; tr++) {
-            if (tr > 0 || mu_changed) qph_assemble(mu, dw, dc, 0);
+            if (dw != dw_have) { qph_assemble(mu, dw, dc, 0); dw_have = dw; if (!A.ok) have_hint = 1; }
             int a_ = A.ok;
             if (a_) a_ = qph_riccati(o.rho_term);
             if (a_) { qph_direction_main(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
             if (a_) { qph_direction_obs(mu, dw, dc, tau); ok = 1; break; }
             nreg++;
-            if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last); else dw *= (dw_last == 0 ? o.kw_inc0 : o.kw_inc);
+            dw = Q_NEXT_RUNG(dw);
             if (dw > o.dw_max) break;
         }
         if (!ok) { if (nrest < Q_MAX_RESTORE) Q_RESTORE_AND_CONTINUE; status = ST_ERROR; break; }
@@ -1261,6 +1377,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         it++;
     }
 #undef Q_RESTORE_AND_CONTINUE
+#undef Q_NEXT_RUNG
     // exit flag: 1 = Optimal, 2 = Optimal but sum(slack) > 1e-3, 0 otherwise
     QPAR(lane) { double s_ = 0; for (int i = lane; i < QOB * (N + 1); i += QNT) s_ += sh.inst.z[sh.l.s + i]; sh.red[0][lane] = s_; }
     SYNC();
