@@ -1205,79 +1205,87 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
         const double t = z[l.t], q = t * c.Ts;
         for (int k = lane; k <= N; k += OB_NT) {
-            double s[6];
+            // Every load of the stage first, every store last: d, z and the records may alias as far as the compiler knows, so a load behind a store waits for
+            // its own round trip (the stage used to take seven of them; a lone wavefront per SIMD has nothing to hide them with).
+            double s[6], sn[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) s[i] = sh.traj[(size_t)k * 6 + i];
+            for (int i = 0; i < 6; i++) { s[i] = sh.traj[(size_t)k * 6 + i]; sn[i] = sh.traj[(size_t)(k < N ? k + 1 : N) * 6 + i]; }
+            const int ku = k < N ? k : N - 1;                                    // (clamped: the loads of the last stage's absent input part are unused)
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
-            double x[4];
+            double x[4], zxL[4], zxU[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; d[l.x + 4 * k + i] = s[i]; }
+            for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i]; }
+            const gdbl *ro = I.rs + (size_t)ku * OB_RS, *cm = ro + RS_CL, *rec = I.as + (size_t)ku * OB_AS;
+            double cmK[12], cmk0 = cm[40], cmk1 = cm[41];
+#pragma unroll
+            for (int j = 0; j < 12; j++) cmK[j] = cm[24 + j];
+            const double u[2] = {z[l.u + 2 * ku], z[l.u + 2 * ku + 1]};
+            const double w[2] = {ku ? z[l.u + 2 * ku - 2] : 0.0, ku ? z[l.u + 2 * ku - 1] : 0.0};
+            const double zuL[2] = {z[l.zuL + 2 * ku], z[l.zuL + 2 * ku + 1]}, zuU[2] = {z[l.zuU + 2 * ku], z[l.zuU + 2 * ku + 1]};
+            const double gg0 = rec[AS_GG], gg1 = rec[AS_GG + 1], gg2 = rec[AS_GG + 2], sig = rec[AS_SIG], rg = rec[AS_RG], rss = rec[AS_RSS], dssd = rec[AS_DSS];
+            const double ss = z[l.ss + ku], zsL = z[l.zssL + ku], zsU = z[l.zssU + ku];
+            double dpi[4] = {0, 0, 0, 0};
+            if (k + 1 < N) {   // costate of x_{k+1} - F_k: -(Px_{k+1} s_{k+1} + pv_{k+1} . coef)
+                const gdbl *r1 = I.rs + (size_t)(k + 1) * OB_RS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double a_ = 0;
+#pragma unroll
+                    for (int cc = 0; cc < OB_NC; cc++) a_ += r1[RS_PV + i * OB_NC + cc] * coef[cc];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a_ += r1[RS_PX + i * 6 + j] * sn[j];
+                    dpi[i] = -a_;
+                }
+            } else if (k < N) {   // terminal cost-to-go: P_N = H_N(+rho), p_N = (hb_N - rho e, Ht_N, e_i)   (rs[N] is not written)
+                const gdbl *rN = I.as + (size_t)N * OB_AS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double e = -(z[l.x + 4 * N + i] - c.xF[i]);
+                    double a_ = (rN[AS_HB + i] - rho * e) + rN[AS_HT + i] * dt + nu[i];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a_ += (rN[AS_H + hidx(i, j)] + ((i == j) ? rho : 0.0)) * sn[j];
+                    dpi[i] = -a_;
+                }
+            }
+            // ---- arithmetic and stores
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[l.x + 4 * k + i] = s[i];
             gd += 2e-3 * (x[0] - rx) * s[0] + 2e-3 * (x[1] - ry) * s[1] + 2 * c.wpsi * (x[2] - ryaw) * s[2] + 2e-4 * x[3] * s[3];
             if (k >= 1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) if (i != 2) {
-                    double dL = x[i] - c.xl[i], dU = c.xu[i] - x[i], zL = z[l.zxL + 4 * k + i], zU = z[l.zxU + 4 * k + i];
+                    double dL = x[i] - c.xl[i], dU = c.xu[i] - x[i], zL = zxL[i], zU = zxU[i];
                     gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * s[i];
                     FTBP(dL, s[i]); FTBP(dU, -s[i]);
                     FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * s[i]); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * s[i]);
                 }
-                // costate increment of the row x_k - F_{k-1}: -(Px_k s_k + pv_k . coef)   (for k=N, rs[N] is not written: use terminal data)
             }
             if (k < N) {
-                const gdbl *ro = I.rs + (size_t)k * OB_RS;
                 double du[2];
-                const gdbl *cm = ro + RS_CL;
-                du[0] = cm[40]; du[1] = cm[41];
+                du[0] = cmk0; du[1] = cmk1;
 #pragma unroll
-                for (int j = 0; j < 6; j++) { du[0] += cm[24 + j] * s[j]; du[1] += cm[30 + j] * s[j]; }
+                for (int j = 0; j < 6; j++) { du[0] += cmK[j] * s[j]; du[1] += cmK[6 + j] * s[j]; }
                 d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
-                const double u[2] = {z[l.u + 2 * k], z[l.u + 2 * k + 1]};
-                const double w[2] = {k ? z[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] : 0.0};
                 const double cu[2] = {0.01, c.wa}, iq = 1.0 / q, rr = 0.1 * (iq * iq);
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const double ei = u[i] - w[i], lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
-                    const double dL = u[i] - lo, dU = hi - u[i], zL = z[l.zuL + 2 * k + i], zU = z[l.zuU + 2 * k + i];
+                    const double dL = u[i] - lo, dU = hi - u[i], zL = zuL[i], zU = zuU[i];
                     gd += (2 * cu[i] * u[i] + 2 * rr * ei) * du[i] - 2 * rr * ei * s[4 + i] + (-rdiv(mu, dL) + rdiv(mu, dU)) * du[i];
                     FTBP(dL, du[i]); FTBP(dU, -du[i]);
                     FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * du[i]); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * du[i]);
                 }
                 // steering row back-substitution
-                const gdbl *rec = I.as + (size_t)k * OB_AS;
-                const double lin = rec[AS_GG] * s[4] + rec[AS_GG + 1] * du[0] + rec[AS_GG + 2] * dt;
-                const double dyg = rec[AS_SIG] * (lin + rec[AS_RG]);
-                const double dss = rdiv(dyg - rec[AS_RSS], rec[AS_DSS]);
+                const double lin = gg0 * s[4] + gg1 * du[0] + gg2 * dt;
+                const double dyg = sig * (lin + rg);
+                const double dss = rdiv(dyg - rss, dssd);
                 d[l.yg + k] = dyg; d[l.ss + k] = dss;
-                const double ss = z[l.ss + k], zL = z[l.zssL + k], zU = z[l.zssU + k], dL = ss + OB_SSB, dU = OB_SSB - ss;
+                const double zL = zsL, zU = zsU, dL = ss + OB_SSB, dU = OB_SSB - ss;
                 gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dss;
                 FTBP(dL, dss); FTBP(dU, -dss);
                 FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * dss); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * dss);
-                // costate of x_{k+1} - F_k
-                double sn[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) sn[i] = sh.traj[(size_t)(k + 1) * 6 + i];
-                if (k + 1 < N) {
-                    const gdbl *r1 = I.rs + (size_t)(k + 1) * OB_RS;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        double a_ = 0;
-#pragma unroll
-                        for (int cc = 0; cc < OB_NC; cc++) a_ += r1[RS_PV + i * OB_NC + cc] * coef[cc];
-#pragma unroll
-                        for (int j = 0; j < 6; j++) a_ += r1[RS_PX + i * 6 + j] * sn[j];
-                        d[l.pi + 4 * k + i] = -a_;
-                    }
-                } else {   // terminal cost-to-go: P_N = H_N(+rho), p_N = (hb_N - rho e, Ht_N, e_i)
-                    const gdbl *rN = I.as + (size_t)N * OB_AS;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        double e = -(z[l.x + 4 * N + i] - c.xF[i]);
-                        double a_ = (rN[AS_HB + i] - rho * e) + rN[AS_HT + i] * dt + nu[i];
-#pragma unroll
-                        for (int j = 0; j < 6; j++) a_ += (rN[AS_H + hidx(i, j)] + ((i == j) ? rho : 0.0)) * sn[j];
-                        d[l.pi + 4 * k + i] = -a_;
-                    }
-                }
+                for (int i = 0; i < 4; i++) d[l.pi + 4 * k + i] = dpi[i];
             }
         }
         sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;
@@ -1379,15 +1387,29 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
     const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts, iq = 1.0 / q, rr = 0.1 * (iq * iq);
     PAR(lane) {
         double lf = 0, lth = 0, lbar = 0;
-        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
-            int k = it / nOb, j = it - k * nOb;
-            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
-            const int r0 = sh.roff[j];
+#define OBS_PREFETCH(VM_) ((VM_) <= 2)      /* classes whose blocks fit the register file twice (VM = 4: measured 14 % slower, the second block spills) */
+        // two blocks in flight per lane: the next block's iterate and step are loaded before this block's arithmetic (nothing is stored in this phase, but the
+        // compiler does not move loads across the loop edge on its own, and a lone wavefront per SIMD has nothing else to hide a round trip with)
+        struct TrialStep { double lam[VM], mu[4], sl, so, X, Y, psi; };
+        auto load_step = [&](int it_, ObsIn<VM> &in_, TrialStep &ts_) {
+            const int k_ = it_ / nOb, j_ = it_ - k_ * nOb, r0_ = sh.roff[j_];
+            load_obs<VM>(I, sh, z, k_, j_, in_);
 #pragma unroll
-            for (int i = 0; i < VM; i++) if (i < in.v) in.lam[i] += alpha * d[l.lam + k * M + r0 + i];
+            for (int i = 0; i < VM; i++) ts_.lam[i] = i < in_.v ? d[l.lam + k_ * M + r0_ + i] : 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) in.mu[i] += alpha * d[l.mu + 4 * it + i];
-            in.sl += alpha * d[l.sl + it]; in.so += alpha * d[l.so + it];
+            for (int i = 0; i < 4; i++) ts_.mu[i] = d[l.mu + 4 * it_ + i];
+            ts_.sl = d[l.sl + it_]; ts_.so = d[l.so + it_]; ts_.X = d[l.x + 4 * k_]; ts_.Y = d[l.x + 4 * k_ + 1]; ts_.psi = d[l.x + 4 * k_ + 2];
+        };
+        const int cnt = (N + 1) * nOb;
+        ObsIn<VM> in, nx; TrialStep ts, tn;
+        if (OBS_PREFETCH(VM) && lane < cnt) load_step(lane, in, ts);
+        for (int it = lane; it < cnt; it += OB_NT) {
+            if (OBS_PREFETCH(VM)) load_step(it + OB_NT < cnt ? it + OB_NT : it, nx, tn); else load_step(it, in, ts);
+#pragma unroll
+            for (int i = 0; i < VM; i++) if (i < in.v) in.lam[i] += alpha * ts.lam[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) in.mu[i] += alpha * ts.mu[i];
+            in.sl += alpha * ts.sl; in.so += alpha * ts.so;
             {
                 double dd[VM + 6];
 #pragma unroll
@@ -1397,10 +1419,11 @@ OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, doub
                 dd[VM + 4] = in.so; dd[VM + 5] = c.dist ? in.sl : 1.0;
                 lbar += log_prod(dd);
             }
-            in.X += alpha * d[l.x + 4 * k]; in.Y += alpha * d[l.x + 4 * k + 1]; in.psi += alpha * d[l.x + 4 * k + 2];
+            in.X += alpha * ts.X; in.Y += alpha * ts.Y; in.psi += alpha * ts.psi;
             double r[4]; obs_rows<VM>(c, in, r);
             lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
             if (!c.dist) lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
+            if (OBS_PREFETCH(VM)) { in = nx; ts = tn; }
         }
         for (int k = lane; k <= N; k += OB_NT) {
             double x[4];
