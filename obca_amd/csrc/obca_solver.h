@@ -1062,31 +1062,42 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
     // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]; written into the Riccati record (RS_CL)
     PAR(lane) {
-        for (int k = lane; k < N; k += OB_NT) {
-            const gdbl *rec = I.as + (size_t)k * OB_AS; gdbl *ro = I.rs + (size_t)k * OB_RS; gdbl *cm = ro + RS_CL;
-            double K0[6], K1[6], kf0 = 0, kf1 = 0;
+        // a lane takes stages k and k + OB_NT (N <= 2 OB_NT) together: both stages' loads before the first store, one memory round trip instead of two
+        for (int k0 = lane; k0 < N; k0 += 2 * OB_NT) {
+            double K0[2][6], K1[2][6], kf0[2] = {0, 0}, kf1[2] = {0, 0}, b0[2][4], b1[2][4], a2[2][4], a3[2][4], dd[2][4], ft[2][4];
 #pragma unroll
-            for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
+            for (int h = 0; h < 2; h++) {
+                const int k = k0 + h * OB_NT < N ? k0 + h * OB_NT : k0;      // (clamped: the second half may not exist)
+                const gdbl *rec = I.as + (size_t)k * OB_AS, *ro = I.rs + (size_t)k * OB_RS;
 #pragma unroll
-            for (int cc = 0; cc < OB_NC; cc++) { kf0 += ro[RS_KF + cc] * coef[cc]; kf1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
-            double b0[4], b1[4], a2[4], a3[4], dd[4], ft[4];      // every load before the first store (the record may alias as far as the compiler knows)
+                for (int j = 0; j < 6; j++) { K0[h][j] = ro[RS_K + j]; K1[h][j] = ro[RS_K + 6 + j]; }
 #pragma unroll
-            for (int i = 0; i < 4; i++) { b0[i] = rec[AS_DF + 5 * i + 2]; b1[i] = rec[AS_DF + 5 * i + 3]; a2[i] = rec[AS_DF + 5 * i + 0]; a3[i] = rec[AS_DF + 5 * i + 1];
-                                          dd[i] = rec[AS_DD + i]; ft[i] = rec[AS_DF + 5 * i + 4]; }
+                for (int cc = 0; cc < OB_NC; cc++) { kf0[h] += ro[RS_KF + cc] * coef[cc]; kf1[h] += ro[RS_KF + OB_NC + cc] * coef[cc]; }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
-                    if (j == 2) a_ += a2[i];
-                    if (j == 3) a_ += a3[i];
-                    cm[i * 6 + j] = a_ + b0[i] * K0[j] + b1[i] * K1[j];
-                }
-                cm[36 + i] = dd[i] + dt * ft[i] + b0[i] * kf0 + b1[i] * kf1;
+                for (int i = 0; i < 4; i++) { b0[h][i] = rec[AS_DF + 5 * i + 2]; b1[h][i] = rec[AS_DF + 5 * i + 3]; a2[h][i] = rec[AS_DF + 5 * i + 0]; a3[h][i] = rec[AS_DF + 5 * i + 1];
+                                              dd[h][i] = rec[AS_DD + i]; ft[h][i] = rec[AS_DF + 5 * i + 4]; }
             }
 #pragma unroll
-            for (int j = 0; j < 6; j++) { cm[24 + j] = K0[j]; cm[30 + j] = K1[j]; }
-            cm[40] = kf0; cm[41] = kf1;
+            for (int h = 0; h < 2; h++) {
+                const int k = k0 + h * OB_NT;
+                if (k < N) {
+                    gdbl *cm = I.rs + (size_t)k * OB_RS + RS_CL;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
+                            if (j == 2) a_ += a2[h][i];
+                            if (j == 3) a_ += a3[h][i];
+                            cm[i * 6 + j] = a_ + b0[h][i] * K0[h][j] + b1[h][i] * K1[h][j];
+                        }
+                        cm[36 + i] = dd[h][i] + dt * ft[h][i] + b0[h][i] * kf0[h] + b1[h][i] * kf1[h];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { cm[24 + j] = K0[h][j]; cm[30 + j] = K1[h][j]; }
+                    cm[40] = kf0[h]; cm[41] = kf1[h];
+                }
+            }
         }
         if (lane < 8) { sh.s[0][lane] = 0; sh.s[1][lane] = 0; }
     }
@@ -1104,18 +1115,30 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     const int NP = UNIFORM(N / 2);
     gdbl *pairbuf = I.traj;                                   // NP * 42 doubles
     PAR(lane) {
-        for (int it = lane; it < NP * 6; it += OB_NT) {
-            const int j = it / 6, r = it % 6;
-            const gdbl *M0 = I.rs + (size_t)(2 * j) * OB_RS + RS_CL, *M1 = I.rs + (size_t)(2 * j + 1) * OB_RS + RS_CL, *m1 = M1 + r * 6; gdbl *pm = pairbuf + (size_t)j * 42;
-            double m1r[6], m0[42], b1r = M1[36 + r];
+        // two (pair, row) items per lane and round, both items' loads before the first store (NP * 6 = 240 items at N = 80: two rounds instead of four)
+        for (int it0 = lane; it0 < NP * 6; it0 += 2 * OB_NT) {
+            double m1r[2][6], m0[2][42], b1r[2];
 #pragma unroll
-            for (int q = 0; q < 6; q++) m1r[q] = m1[q];
+            for (int h = 0; h < 2; h++) {
+                const int it = it0 + h * OB_NT < NP * 6 ? it0 + h * OB_NT : it0, j = it / 6, r = it % 6;
+                const gdbl *M0 = I.rs + (size_t)(2 * j) * OB_RS + RS_CL, *M1 = I.rs + (size_t)(2 * j + 1) * OB_RS + RS_CL, *m1 = M1 + r * 6;
+                b1r[h] = M1[36 + r];
 #pragma unroll
-            for (int q = 0; q < 42; q++) m0[q] = M0[q];
+                for (int q = 0; q < 6; q++) m1r[h][q] = m1[q];
 #pragma unroll
-            for (int cI = 0; cI < 6; cI++)
-                pm[r * 6 + cI] = dot6_tree(0.0, m1r[0], m0[cI], m1r[1], m0[6 + cI], m1r[2], m0[12 + cI], m1r[3], m0[18 + cI], m1r[4], m0[24 + cI], m1r[5], m0[30 + cI]);
-            pm[36 + r] = dot6_tree(b1r, m1r[0], m0[36], m1r[1], m0[37], m1r[2], m0[38], m1r[3], m0[39], m1r[4], m0[40], m1r[5], m0[41]);
+                for (int q = 0; q < 42; q++) m0[h][q] = M0[q];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int it = it0 + h * OB_NT;
+                if (it < NP * 6) {
+                    const int j = it / 6, r = it % 6; gdbl *pm = pairbuf + (size_t)j * 42;
+#pragma unroll
+                    for (int cI = 0; cI < 6; cI++)
+                        pm[r * 6 + cI] = dot6_tree(0.0, m1r[h][0], m0[h][cI], m1r[h][1], m0[h][6 + cI], m1r[h][2], m0[h][12 + cI], m1r[h][3], m0[h][18 + cI], m1r[h][4], m0[h][24 + cI], m1r[h][5], m0[h][30 + cI]);
+                    pm[36 + r] = dot6_tree(b1r[h], m1r[h][0], m0[h][36], m1r[h][1], m0[h][37], m1r[h][2], m0[h][38], m1r[h][3], m0[h][39], m1r[h][4], m0[h][40], m1r[h][5], m0[h][41]);
+                }
+            }
         }
     }
     SYNC();
@@ -1477,7 +1500,7 @@ OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, doub
         // one-sided (>= 0) groups: lam, mu (+ yo), so.  The iterate is read and written in place, so a load placed after a store cannot be
         // hoisted by the compiler (may alias): every group is processed AP_R items per lane at a time, all loads first, then the stores --
         // one memory round trip per chunk instead of one per item.
-#define AP_R 4
+#define AP_R 8
         for (int base = 0; base < M * (N + 1); base += AP_R * OB_NT) {
             double v[AP_R], dv[AP_R], zz[AP_R];
 #pragma unroll
