@@ -1143,81 +1143,66 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     }
     SYNC();
     WAVE0_BEGIN
-#ifdef OBCA_EMU
-        PAR64(lane) { if (lane < 6) sh.traj[lane] = 0.0; }
-        LDS_SYNC();
-        for (int j = 0; j < NP; j++) {
-            PAR64(lane) {
-                if (lane < 12) {
-                    const int r = lane < 6 ? lane : lane - 6;
-                    const gdbl *cl = lane < 6 ? pairbuf + (size_t)j * 42 : I.rs + (size_t)(2 * j) * OB_RS + RS_CL; const double *s_ = sh.traj + (size_t)(2 * j) * 6;
-                    const gdbl *cr = cl + r * 6;
-                    sh.traj[(size_t)(2 * j + (lane < 6 ? 2 : 1)) * 6 + r] = dot6_tree(cl[36 + r], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
-                }
-            }
-            LDS_SYNC();
-        }
-        for (int k = 2 * NP; k < N; k++) {
-            PAR64(lane) {
-                if (lane < 6) {
-                    const gdbl *cl = I.rs + (size_t)k * OB_RS + RS_CL; const double *s_ = sh.traj + (size_t)k * 6;
-                    const gdbl *cr = cl + lane * 6;
-                    sh.traj[(size_t)(k + 1) * 6 + lane] = dot6_tree(cl[36 + lane], cr[0], s_[0], cr[1], s_[1], cr[2], s_[2], cr[3], s_[3], cr[4], s_[4], cr[5], s_[5]);
-                }
-            }
-            LDS_SYNC();
-        }
-#else
-        // v_readlane broadcasts the six values of lanes 0..5 into scalar registers and they enter the next step's products as scalar operands.
-        // Same operation order as the emulation above: bit-identical results.
+        // The six values of lanes 0..5 are broadcast with v_readlane into scalar registers and enter the next step's products as scalar operands (the host
+        // emulation runs the same statements with the per-lane variables as arrays over the lanes: one implementation, bit-identical results).
         {
-            const int tx = (int)threadIdx.x, r = tx < 6 ? tx : (tx < 12 ? tx - 6 : 0), Nn = UNIFORM(N);
-            const bool pr = tx < 6 || tx >= 12;                 // this lane works on the composed map
+            const int Nn = UNIFORM(N), NPc = NP > 0 ? NP - 1 : 0;
             double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_k, wave-uniform (scalar registers); s_0 = 0
-            if (tx < 6) sh.traj[tx] = 0.0;
-            // per-lane base and stride (in doubles) of the map rows: composed maps are 42 apart, plain maps of the even stages 2 * OB_RS apart
-            const gdbl *mb = pr ? pairbuf + r * 6 : I.rs + RS_CL + r * 6; const size_t ms = pr ? 42 : 2 * (size_t)OB_RS; const int bo = 36 - 5 * r;   // bias = row base + bo
-            double ring[FW_D][7];
-            const int NPc = NP > 0 ? NP - 1 : 0;
+            double ring[OBCA_NL][FW_D][7], v[OBCA_NL];
+            // per-lane base and stride (in doubles) of the map rows: composed maps are 42 apart, plain maps of the even stages 2 * OB_RS apart; bias = row base + bo
+            const gdbl *mb[OBCA_NL]; size_t ms[OBCA_NL]; int bo[OBCA_NL], rr[OBCA_NL];
+            PAR64(lane) {
+                const int L_ = LI(lane), r = lane < 6 ? lane : (lane < 12 ? lane - 6 : 0);
+                const bool pr = lane < 6 || lane >= 12;             // this lane works on the composed map
+                rr[L_] = r; mb[L_] = pr ? pairbuf + r * 6 : I.rs + RS_CL + r * 6; ms[L_] = pr ? 42 : 2 * (size_t)OB_RS; bo[L_] = 36 - 5 * r;
+                if (lane < 6) sh.traj[lane] = 0.0;
 #pragma unroll
-            for (int q = 0; q < FW_D; q++) {                    // prologue: steps 0 .. FW_D-1 (clamped: unconditional loads keep the vmcnt bookkeeping exact)
-                const gdbl *cn = mb + (size_t)(q < NPc ? q : NPc) * ms;
+                for (int q = 0; q < FW_D; q++) {                    // prologue: steps 0 .. FW_D-1 (clamped: unconditional loads keep the vmcnt bookkeeping exact)
+                    const gdbl *cn = mb[L_] + (size_t)(q < NPc ? q : NPc) * ms[L_];
 #pragma unroll
-                for (int e = 0; e < 6; e++) ring[q][e] = cn[e];
-                ring[q][6] = cn[bo];
+                    for (int e = 0; e < 6; e++) ring[L_][q][e] = cn[e];
+                    ring[L_][q][6] = cn[bo[L_]];
+                }
             }
             for (int j0 = 0; j0 < NP; j0 += FW_D) {
 #pragma unroll
                 for (int q = 0; q < FW_D; q++) {
                     const int j = j0 + q;
-                    double cr[7];
+                    PAR64(lane) {
+                        const int L_ = LI(lane);
+                        double cr[7];
 #pragma unroll
-                    for (int e = 0; e < 7; e++) cr[e] = ring[q][e];
-                    {   // re-issue the slot for step j + FW_D
-                        const int jn = j + FW_D < NPc ? j + FW_D : NPc; const gdbl *cn = mb + (size_t)jn * ms;
+                        for (int e = 0; e < 7; e++) cr[e] = ring[L_][q][e];
+                        {   // re-issue the slot for step j + FW_D
+                            const int jn = j + FW_D < NPc ? j + FW_D : NPc; const gdbl *cn = mb[L_] + (size_t)jn * ms[L_];
 #pragma unroll
-                        for (int e = 0; e < 6; e++) ring[q][e] = cn[e];
-                        ring[q][6] = cn[bo];
+                            for (int e = 0; e < 6; e++) ring[L_][q][e] = cn[e];
+                            ring[L_][q][6] = cn[bo[L_]];
+                        }
+                        if (j < NP) {
+                            v[L_] = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                            if (lane < 12) sh.traj[(size_t)(2 * j + (lane < 6 ? 2 : 1)) * 6 + rr[L_]] = v[L_];
+                        }
                     }
                     if (j < NP) {
-                        const double v = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                        if (tx < 12) sh.traj[(size_t)(2 * j + (tx < 6 ? 2 : 1)) * 6 + r] = v;
 #pragma unroll
-                        for (int e = 0; e < 6; e++) fw_s[e] = readlane_f64(v, e);
+                        for (int e = 0; e < 6; e++) fw_s[e] = WV_READLANE(v, e);
                     }
                 }
             }
             if (2 * NP < Nn) {                                   // odd horizon: the last stage on its own
-                const int k = 2 * NP; const gdbl *cn = I.rs + (size_t)k * OB_RS + RS_CL + r * 6;
-                double cr[7];
+                const int k = 2 * NP;
+                PAR64(lane) {
+                    const int L_ = LI(lane); const gdbl *cn = I.rs + (size_t)k * OB_RS + RS_CL + rr[L_] * 6;
+                    double cr[7];
 #pragma unroll
-                for (int e = 0; e < 6; e++) cr[e] = cn[e];
-                cr[6] = cn[bo];
-                const double v = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                if (tx < 6) sh.traj[(size_t)(k + 1) * 6 + tx] = v;
+                    for (int e = 0; e < 6; e++) cr[e] = cn[e];
+                    cr[6] = cn[bo[L_]];
+                    v[L_] = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
+                    if (lane < 6) sh.traj[(size_t)(k + 1) * 6 + lane] = v[L_];
+                }
             }
         }
-#endif
     WAVE0_END
     SYNC();
     PROF(I, PF_FWD_SEQ);
