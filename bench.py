@@ -189,7 +189,7 @@ def obstacle_args(cfg, rows, shared, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160, help="timed steps (default 160: a timed region of > 1 s at ~7.5 ms per step)")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of 1.3 s at ~6.4 ms per step)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the BASELINE batch size of the config / 8 GPUs; config 2: 1024)")
