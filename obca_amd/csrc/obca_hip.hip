@@ -452,7 +452,8 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
 static int launch_dualws(obca_batch *bt, double *zdst) {
     long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
     int blocks = (int)((tot + 255) / 256);
-    if (bt->vmax <= OB_VMID) hipLaunchKernelGGL(obca_dualws_kernel<OB_VMID>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
+    if (bt->vmax <= 2) hipLaunchKernelGGL(obca_dualws_kernel<2>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);      // (the sub-problem is sized by the template: the reference's scenarios have <= 2 rows per obstacle)
+    else if (bt->vmax <= OB_VMID) hipLaunchKernelGGL(obca_dualws_kernel<OB_VMID>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     else hipLaunchKernelGGL(obca_dualws_kernel<OB_VMAX>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     HIPCHK(bt, hipGetLastError());
     return 0;
@@ -469,6 +470,8 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
     HIPCHK(bt, hipEventRecord(bt->e0, bt->stream));
     if (!bt->have_duals || dualws_only) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
+    if (!bt->have_duals && !dualws_only) { static const int rep = getenv("OBCA_DUALWS_REPEAT") ? atoi(getenv("OBCA_DUALWS_REPEAT")) : 0;      // diagnostic: marginal cost of the DualMultWS launch in a pipelined run
+        for (int r = 0; r < rep; r++) { int rc = launch_dualws(bt, d.z); if (rc) return rc; } }
     HIPCHK(bt, hipEventRecord(bt->e1, bt->stream));
     if (dualws_only) { HIPCHK(bt, hipEventRecord(bt->e2, bt->stream)); return 0; }
     // Two-launch schedule.  The kernel keeps a fixed number of instances resident; a larger batch is dispatched in blockIdx
