@@ -1,9 +1,9 @@
 #!/bin/bash
 # round 2, final job: GPU suite, smoke, the bench lines of all configs, PCIe-inclusive rates, rocprofv3 kernel stats of synchronous steps, PMC traffic of the
 # parking and quadcopter kernels, MFMA instruction counters, per-phase clocks, streams sweep, the end-to-end example
-mkdir -p gpurun_out/r2y
+mkdir -p gpurun_out/r2x
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r2y; R=$PWD
+O=$PWD/gpurun_out/r2x; R=$PWD
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 cd /tmp
@@ -31,7 +31,7 @@ OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/phase_profile
 OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/quad_gpu.py 64 > $O/quad_phase_B64.txt; OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/quad_gpu.py 1024 > $O/quad_phase_B1024.txt
 python - <<'PY'
 import csv, glob, json
-O="gpurun_out/r2y"
+O="gpurun_out/r2x"
 for c in ("bench","bench_cfg3","bench_cfg4","bench_cfg5","bench_cfg2_hybrid"):
     try:
         d=json.load(open(f"{O}/{c}.json")); k=d["config"]; r=d["roofline"]
