@@ -230,6 +230,7 @@ struct obca_batch {
     DevBufs d; double *stage;                               // stage: dense device staging of the PCIe transfers
     double *h_prob, *h_zin, *h_zout, *h_info; size_t hcap_prob, hcap_zin, hcap_zout, hcap_info, dcap_stage;   // pinned host staging
     std::vector<int> nOb, M, obOff, rowOff;                 // per instance; offsets into the caller's packed obstacle arrays
+    std::vector<double> rowLen;                             // |a_r| of every half-space row of the uploaded instances (index: row offset - rowOff[0]), see batch_upload_range
     int fixTime;
     hipEvent_t e0, e1, e2;
     long long bytes;
@@ -378,6 +379,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         nObMax = std::max(nObMax, bt->nOb[i]); MMax = std::max(MMax, bt->M[i]);
     }
     bt->obOff[n] = in.obOff[lo + n]; bt->rowOff[n] = in.rowOff[lo + n];
+    bt->rowLen.assign((size_t)(bt->rowOff[n] - bt->rowOff[0]), 1.0);
     hipSetDevice(bt->device);
     const size_t B = bt->cap;
     if (!bt->uploaded || nObMax > bt->nObMax || MMax > bt->MMax) {       // (a cached batch keeps the largest shape it has seen)
@@ -425,7 +427,17 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         for (int j = 0; j < no; j++) { const int v = in.vOb[bt->obOff[i] + j]; p[PH_VOB + j] = v; p[PH_ROFF + j] = ro; ro += v; }
         p[PH_ROFF + no] = ro;
         const size_t r0 = bt->rowOff[i];
-        for (int r = 0; r < m; r++) { p[PH_A + 2 * r] = in.A[2 * (r0 + r)]; p[PH_A + 2 * r + 1] = in.A[2 * (r0 + r) + 1]; p[PH_B + r] = in.b[r0 + r]; }
+        // The solve runs on unit-length half-space rows a_r / |a_r|, b_r / |a_r| (the same obstacle; lambda_r scales with |a_r|, A'lam and b'lam do not change) and
+        // hands lambda back in the caller's scaling.  obstHrep.jl:57-86 leaves the rows of a sloped edge unnormalised ([-s 1]: |a| up to 1e3 for a steep edge);
+        // IPOPT's default gradient-based NLP scaling stands between such rows and the reference's solves.  Without either 1.2-1.9 % of the config-5 instances -- all of
+        // them with a row of |a| > 100 -- failed and the iteration counts had a tail up to 400; with unit rows all solve in at most 80.  The
+        // reference's own scenarios have rows of length 1: nothing changes for them, bit for bit.
+        double *rl = bt->rowLen.data() + (r0 - (size_t)bt->rowOff[0]);
+        for (int r = 0; r < m; r++) {
+            const double a1 = in.A[2 * (r0 + r)], a2 = in.A[2 * (r0 + r) + 1]; double nr = hypot(a1, a2);
+            if (!(nr > 0)) nr = 1.0;
+            rl[r] = nr; p[PH_A + 2 * r] = a1 / nr; p[PH_A + 2 * r + 1] = a2 / nr; p[PH_B + r] = in.b[r0 + r] / nr;
+        }
         memcpy(p + OB_HDR, in.rx + (size_t)g * N1, sizeof(double) * N1);
         memcpy(p + OB_HDR + N1, in.ry + (size_t)g * N1, sizeof(double) * N1);
         memcpy(p + OB_HDR + 2 * N1, in.ryaw + (size_t)g * N1, sizeof(double) * N1);
@@ -435,7 +447,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         if (in.uWS) memcpy(z + l.u, in.uWS + (size_t)g * 2 * N, sizeof(double) * 2 * N); else memset(z + l.u, 0, sizeof(double) * 2 * N);
         z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
         if (duals) {
-            memcpy(z + l.lam, in.lWS + r0 * N1, sizeof(double) * m * N1);
+            for (int k = 0; k < N1; k++) for (int r = 0; r < m; r++) z[l.lam + k * m + r] = in.lWS[r0 * N1 + (size_t)k * m + r] * rl[r];      // caller's row scaling -> unit rows
             memcpy(z + l.mu, in.nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * no * N1);
             if ((size_t)l.sl < W) memset(z + l.sl, 0, sizeof(double) * (W - l.sl));      // a smaller instance's layout ends before the widest one's
         }
@@ -527,10 +539,11 @@ static int batch_download_range(obca_batch *bt, const ParkOut &o, int lo) {
         if (o.xp) memcpy(o.xp + g * 4 * N1, z + l.x, sizeof(double) * 4 * N1);
         if (o.up) memcpy(o.up + g * 2 * N, z + l.u, sizeof(double) * 2 * N);
         if (o.ts) for (int k = 0; k < N1; k++) o.ts[g * N1 + k] = bt->fixTime ? 1.0 : z[l.t];   /* ParkingSignedDist.jl:304-308 */
-        if (o.lp) memcpy(o.lp + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+        const double *rl = bt->rowLen.data() + (bt->rowOff[i] - bt->rowOff[0]); const int m = bt->M[i];      // lambda back in the caller's row scaling
+        if (o.lp) for (int k = 0; k < N1; k++) for (int r = 0; r < m; r++) o.lp[(size_t)bt->rowOff[i] * N1 + (size_t)k * m + r] = z[l.lam + k * m + r] / rl[r];
         if (o.np) memcpy(o.np + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
         if (o.slp) memcpy(o.slp + (size_t)bt->obOff[i] * N1, z + l.sl, sizeof(double) * bt->nOb[i] * N1);
-        if (o.lWS) memcpy(o.lWS + (size_t)bt->rowOff[i] * N1, z + l.lam, sizeof(double) * bt->M[i] * N1);
+        if (o.lWS) for (int k = 0; k < N1; k++) for (int r = 0; r < m; r++) o.lWS[(size_t)bt->rowOff[i] * N1 + (size_t)k * m + r] = z[l.lam + k * m + r] / rl[r];
         if (o.nWS) memcpy(o.nWS + (size_t)bt->obOff[i] * 4 * N1, z + l.mu, sizeof(double) * 4 * bt->nOb[i] * N1);
         if (o.exitflag) o.exitflag[g] = (int)bt->h_info[(size_t)i * 8 + 7];
         if (o.info) memcpy(o.info + g * 8, bt->h_info + (size_t)i * 8, sizeof(double) * 8);

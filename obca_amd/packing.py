@@ -36,6 +36,12 @@ def check_obstacles(vOb):
     return vOb
 
 
+def row_lengths(A):
+    """|a_r| of the half-space rows (1 for a zero row): the kernels solve on a_r / |a_r|, b_r / |a_r|; lambda_r scales with |a_r|"""
+    A = np.asarray(A, float).reshape(-1, 2); n = np.hypot(A[:, 0], A[:, 1])          # hypot as in the C packing
+    return np.where(n > 0, n, 1.0)
+
+
 def pack_problem(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, dist=0):
     vOb = check_obstacles(vOb)
     nOb, M = len(vOb), int(vOb.sum())
@@ -53,31 +59,37 @@ def pack_problem(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTi
     p[PH["FIX"]] = int(fixTime); p[PH["NOB"]] = nOb; p[PH["M"]] = M
     p[PH["VOB"]:PH["VOB"] + nOb] = vOb
     p[PH["ROFF"]:PH["ROFF"] + nOb + 1] = np.concatenate([[0], np.cumsum(vOb)])
-    p[PH["A"]:PH["A"] + 2 * M] = A.reshape(-1)
-    p[PH["B"]:PH["B"] + M] = b
+    n = row_lengths(A)                                                  # unit-length rows, as the C ABI packs them (obca_hip.hip: batch_upload_range)
+    p[PH["A"]:PH["A"] + 2 * M] = (A / n[:, None]).reshape(-1)
+    p[PH["B"]:PH["B"] + M] = b / n
     p[OB_HDR:OB_HDR + N + 1] = np.asarray(rx, float).ravel()[:N + 1]
     p[OB_HDR + N + 1:OB_HDR + 2 * (N + 1)] = np.asarray(ry, float).ravel()[:N + 1]
     p[OB_HDR + 2 * (N + 1):] = np.asarray(ryaw, float).ravel()[:N + 1]
     return p
 
 
-def pack_start(N, nOb, M, xWS, uWS, lWS, nWS, zlen=None):
-    """warm start -> iterate buffer (reference :213-222: timeScale=1, x=xWS', u=uWS[1:N,:]', l=lWS', n=nWS')."""
+def pack_start(N, nOb, M, xWS, uWS, lWS, nWS, zlen=None, A=None):
+    """warm start -> iterate buffer (reference :213-222: timeScale=1, x=xWS', u=uWS[1:N,:]', l=lWS', n=nWS').  A: the obstacle rows, if they are not of unit
+    length (lWS comes in the caller's row scaling, the iterate holds lambda for unit rows)."""
     L = layout(N, nOb, M)
     z = np.zeros(zlen or L["len"])
     z[L["x"]:L["x"] + 4 * (N + 1)] = np.asarray(xWS, float)[:N + 1].reshape(-1)
     z[L["u"]:L["u"] + 2 * N] = np.asarray(uWS, float)[:N].reshape(-1)
     z[L["t"]] = 1.0
-    z[L["lam"]:L["lam"] + M * (N + 1)] = np.asarray(lWS, float).reshape(-1)
+    lam = np.asarray(lWS, float).reshape(N + 1, M)
+    z[L["lam"]:L["lam"] + M * (N + 1)] = (lam if A is None else lam * row_lengths(A)[None, :]).reshape(-1)
     z[L["mu"]:L["mu"] + 4 * nOb * (N + 1)] = np.asarray(nWS, float).reshape(-1)
     return z
 
 
-def unpack_solution(z, N, nOb, M):
+def unpack_solution(z, N, nOb, M, A=None):
+    """A: the obstacle rows, if not of unit length (lambda is handed back in the caller's row scaling)"""
     L = layout(N, nOb, M)
     xp = z[L["x"]:L["x"] + 4 * (N + 1)].reshape(N + 1, 4).T.copy()
     up = z[L["u"]:L["u"] + 2 * N].reshape(N, 2).T.copy()
     lp = z[L["lam"]:L["lam"] + M * (N + 1)].reshape(N + 1, M).T.copy()
+    if A is not None:
+        lp /= row_lengths(A)[:, None]
     npp = z[L["mu"]:L["mu"] + 4 * nOb * (N + 1)].reshape(N + 1, 4 * nOb).T.copy()
     sl = z[L["sl"]:L["sl"] + nOb * (N + 1)].reshape(N + 1, nOb).T.copy()
     return xp, up, float(z[L["t"]]), lp, npp, sl

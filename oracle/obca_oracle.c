@@ -42,6 +42,7 @@ typedef struct {
     double Ts, L, g[4], off, XYb[4], x0[4], xF[4];
     const double *A, *b, *rx, *ry, *ryaw; /* A: M x 2 row major */
     double xl[4], xu[4];
+    double An[2 * NOBMAX * VMAX], bn[NOBMAX * VMAX], rn[NOBMAX * VMAX];   /* unit-length rows a_i / |a_i|, b_i / |a_i| and the row lengths |a_i| (setup_prob) */
 } prob_t;
 
 typedef struct {
@@ -1276,7 +1277,7 @@ static void dualws_one(int v, const double *Aj, const double *bj, const double g
 /* ------------------------------------------------------------------ C entry points (called through ctypes by tests) */
 static void setup_prob(prob_t *p, int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime,
                        const double *x0, const double *xF, int nOb, const int *vOb, const double *A, const double *b,
-                       const double *rx, const double *ry, const double *ryaw) {
+                       const double *rx, const double *ry, const double *ryaw, int unit_rows) {
     memset(p, 0, sizeof *p);
     p->N = N; p->Ts = Ts; p->L = L; p->fixTime = fixTime; p->nOb = nOb;
     double W_ev = ego[1] + ego[3], L_ev = ego[0] + ego[2];          /* ParkingSignedDist.jl:182-188 */
@@ -1288,7 +1289,15 @@ static void setup_prob(prob_t *p, int N, double Ts, double L, const double ego[4
     p->roff[0] = 0;
     for (int j = 0; j < nOb; j++) { p->vOb[j] = vOb[j]; p->roff[j + 1] = p->roff[j] + vOb[j]; }
     p->M = p->roff[nOb];
-    p->A = A; p->b = b; p->rx = rx; p->ry = ry; p->ryaw = ryaw;
+    /* The solve runs on unit-length half-space rows: a_i / |a_i|, b_i / |a_i| describe the same obstacle, lambda_i scales with |a_i| (A'lam and b'lam do not
+     * change) and is handed back in the caller's scaling.  obstHrep.jl:57-86 leaves the rows of a sloped edge unnormalised ([-s 1], |a| up to 1e3 for a steep one);
+     * IPOPT's default gradient-based scaling stands between such rows and the reference's solves, nothing did here (config-5 instances with |a| > 100 failed). */
+    for (int r = 0; r < p->M; r++) {
+        double n = unit_rows ? hypot(A[2 * r], A[2 * r + 1]) : 1.0;
+        if (!(n > 0)) n = 1.0;
+        p->rn[r] = n; p->An[2 * r] = A[2 * r] / n; p->An[2 * r + 1] = A[2 * r + 1] / n; p->bn[r] = b[r] / n;
+    }
+    p->A = p->An; p->b = p->bn; p->rx = rx; p->ry = ry; p->ryaw = ryaw;
     p->xl[0] = XYb[0]; p->xu[0] = XYb[1]; p->xl[1] = XYb[2]; p->xu[1] = XYb[3]; p->xl[2] = -1e300; p->xu[2] = 1e300;
     p->xl[3] = -1; p->xu[3] = 2;                                      /* :104-106 */
 }
@@ -1299,12 +1308,13 @@ int obca_oracle_dualmult_ws(int N, int nOb, const int *vOb, const double *A, con
     prob_t p; double XYb[4] = {0, 0, 0, 0};
     if (nOb > NOBMAX) return -1;
     for (int j = 0; j < nOb; j++) if (vOb[j] > VMAX || vOb[j] < 1) return -1;
-    setup_prob(&p, N, 1, 1, ego, XYb, 0, NULL, NULL, nOb, vOb, A, b, rx, ry, ryaw);
+    setup_prob(&p, N, 1, 1, ego, XYb, 0, NULL, NULL, nOb, vOb, A, b, rx, ry, ryaw, 1);
     for (int k = 0; k <= N; k++) {
         double cs = cos(ryaw[k]), sn = sin(ryaw[k]);
         for (int j = 0; j < nOb; j++)
-            dualws_one(p.vOb[j], A + 2 * p.roff[j], b + p.roff[j], p.g, rx[k] + cs * p.off, ry[k] + sn * p.off, cs, sn,
+            dualws_one(p.vOb[j], p.A + 2 * p.roff[j], p.b + p.roff[j], p.g, rx[k] + cs * p.off, ry[k] + sn * p.off, cs, sn,
                        lWS + k * p.M + p.roff[j], nWS + 4 * (k * nOb + j), dd + k * nOb + j);
+        for (int r = 0; r < p.M; r++) lWS[k * p.M + r] /= p.rn[r];          /* back to the caller's row scaling */
     }
     return 0;
 }
@@ -1366,14 +1376,14 @@ static int parking_solve(int dist, int N, double Ts, double L, const double ego[
     if (nOb > NOBMAX) return -1;
     for (int j = 0; j < nOb; j++) if (vOb[j] > VMAX || vOb[j] < 1) return -1;
     if (opt) o = *opt; else obca_oracle_default_opts(&o);
-    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw);
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, 1);
     p.dist = dist;
     make_layout(&p, &l);
     double *z = xcalloc(l.len, sizeof(double));
     memcpy(z + l.x, xWS, sizeof(double) * 4 * (N + 1));
     memcpy(z + l.u, uWS, sizeof(double) * 2 * N);
     z[l.t] = 1.0;                                                      /* ParkingSignedDist.jl:214 */
-    memcpy(z + l.lam, lWS, sizeof(double) * p.M * (N + 1));
+    for (int k = 0; k <= N; k++) for (int q = 0; q < p.M; q++) z[l.lam + k * p.M + q] = lWS[k * p.M + q] * p.rn[q];      /* dual warm start: caller's row scaling -> unit rows */
     memcpy(z + l.mu, nWS, sizeof(double) * 4 * nOb * (N + 1));
     result_t r;
     ipm_solve(&p, &l, &o, z, &r);
@@ -1399,12 +1409,15 @@ static int parking_solve(int dist, int N, double Ts, double L, const double ego[
     memcpy(xp, z + l.x, sizeof(double) * 4 * (N + 1));
     memcpy(up, z + l.u, sizeof(double) * 2 * N);
     for (int k = 0; k <= N; k++) tsp[k] = fixTime ? 1.0 : z[l.t];
-    memcpy(lp, z + l.lam, sizeof(double) * p.M * (N + 1));
+    for (int k = 0; k <= N; k++) for (int q = 0; q < p.M; q++) lp[k * p.M + q] = z[l.lam + k * p.M + q] / p.rn[q];      /* back to the caller's row scaling */
     memcpy(np, z + l.mu, sizeof(double) * 4 * nOb * (N + 1));
     if (slp) memcpy(slp, z + l.sl, sizeof(double) * nOb * (N + 1));
     *exitflag = ef;
     if (info) { info[0] = r.status; info[1] = iters; info[2] = r.obj; info[3] = r.pinf; info[4] = r.dinf; info[5] = r.mu; info[6] = r.nreg; info[7] = r.t; }
-    if (g_zfull) memcpy(g_zfull, z, sizeof(double) * l.len);
+    if (g_zfull) {
+        memcpy(g_zfull, z, sizeof(double) * l.len);
+        for (int k = 0; k <= N; k++) for (int q = 0; q < p.M; q++) { g_zfull[l.lam + k * p.M + q] /= p.rn[q]; g_zfull[l.zlam + k * p.M + q] *= p.rn[q]; }
+    }
     free(z);
     return 0;
 }
@@ -1443,7 +1456,7 @@ int obca_oracle_ref_constraints(int N, double Ts, double L, const double ego[4],
                                 const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *xp,
                                 const double *up, double t, const double *lp, const double *np, int sd) {
     prob_t p; lay_t l;
-    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, NULL, NULL, NULL);
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, NULL, NULL, NULL, 0);
     make_layout(&p, &l);
     double *z = xcalloc(l.len, sizeof(double));
     memcpy(z + l.x, xp, sizeof(double) * 4 * (N + 1)); memcpy(z + l.u, up, sizeof(double) * 2 * N); z[l.t] = t;
@@ -1458,7 +1471,7 @@ int obca_oracle_eval(int N, double Ts, double L, const double ego[4], const doub
                      const double *ry, const double *ryaw, const double *zin /* packed primal in oracle layout */,
                      double *f, double *theta1, double *thetainf) {
     prob_t p; lay_t l;
-    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw);
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, 0);
     make_layout(&p, &l);
     eval_f_theta(&p, &l, zin, f, theta1, thetainf);
     return l.len;
@@ -1478,7 +1491,7 @@ int obca_oracle_newton(int N, double Ts, double L, const double ego[4], const do
                        const double *ry, const double *ryaw, const double *z, double mu, double dw, double dc, double rho,
                        double *d, double *errs /* dinf,pinf,cinf */, int dist) {
     prob_t p; lay_t l;
-    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw);
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, 0);
     p.dist = dist;
     make_layout(&p, &l);
     kkt_t *K = kkt_alloc(&p, &l);

@@ -45,6 +45,7 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
     x0 = np.reshape(x0, (-1, 4)); B = x0.shape[0]
     v = np.ravel(vOb).astype(int); nOb, M = len(v), int(v.sum()); Lz = P.layout(N, nOb, M)
     A = np.asarray(A, float).reshape(M, 2); b = np.ravel(np.asarray(b, float)); ego = np.ravel(np.asarray(ego, float))
+    rl = P.row_lengths(A); An = A / rl[:, None]; bn = b / rl          # the kernels see unit-length rows (obca_hip.hip: batch_upload_range); lambda comes back rescaled
     g = np.array([(ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2, (ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2]); off = (ego[0] + ego[2]) / 2 - ego[2]
     eo = default_opts()
     Tsv = np.broadcast_to(np.asarray(Ts, float), (B,))
@@ -56,7 +57,7 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
         for k in range(N + 1):
             cs, sn = np.cos(rwi[k]), np.sin(rwi[k]); r0 = 0
             for j, vj in enumerate(v):
-                a1 = np.ascontiguousarray(A[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(A[r0:r0 + vj, 1]); bj = np.ascontiguousarray(b[r0:r0 + vj])
+                a1 = np.ascontiguousarray(An[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(An[r0:r0 + vj, 1]); bj = np.ascontiguousarray(bn[r0:r0 + vj])
                 lam = np.zeros(4); mu = np.zeros(4); d = C.c_double(0)
                 emu.emu_dualws(C.c_int(int(vj)), dp(a1), dp(a2), dp(bj), dp(g), C.c_double(rxi[k] + off * cs), C.c_double(ryi[k] + off * sn),
                                C.c_double(cs), C.c_double(sn), dp(lam), dp(mu), C.byref(d))
@@ -65,6 +66,6 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
         z0 = P.pack_start(N, nOb, M, np.asarray(xWS[i], float).reshape(-1, 4)[:N + 1], np.asarray(uWS[i], float).reshape(-1, 2)[:N], lWS, nWS)
         zo = np.zeros_like(z0)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(Lz["len"]), C.byref(eo), dp(zo), dp(info[i]))
-        x_, u_, t_, lp_, np_, sl_ = P.unpack_solution(zo, N, nOb, M)
+        x_, u_, t_, lp_, np_, sl_ = P.unpack_solution(zo, N, nOb, M, A=A)
         xp[i] = x_; up[i] = u_; ts[i] = 1.0 if fixTime else t_; ef[i] = int(info[i, 7]); lps.append(lp_); nps.append(np_); sls.append(sl_)
     return dict(xp=xp, up=up, timeScale=ts, exitflag=ef, lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))

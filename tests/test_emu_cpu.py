@@ -75,7 +75,7 @@ def test_emu_full_solve_matches_oracle(oracle, emu, backwards, dist, N):
                                        xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS, dist=dist)
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                               xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
-        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
         zo = np.zeros_like(z0); info = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
         xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
@@ -118,7 +118,7 @@ def test_emu_exit_flag_after_failed_attempts_follows_the_reference(oracle, emu, 
                                    xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][0], lWS, nWS, opts=oo, dist=dist)
     prob = P.pack_problem(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                           xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
-    z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][0], lWS, nWS)
+    z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][0], lWS, nWS, A=bt["A"])
     zo = np.zeros_like(z0); info = np.zeros(8)
     emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
     assert r["status"] == 1 and int(info[0]) == 1 and int(info[1]) == r["iters"] == 6
@@ -150,7 +150,7 @@ def test_emu_sliced_solve_is_bit_identical(oracle, emu, backwards, budget, max_i
         lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                               xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
         za = np.zeros_like(z0); ia = np.zeros(8); zb = np.zeros_like(z0); ib = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(za), dp(ia))
         launches = emu.emu_solve_sliced(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), C.c_int(budget), dp(zb), dp(ib))
@@ -177,18 +177,19 @@ def test_emu_wide_obstacles_match_oracle(oracle, emu):
         lWS, nWS, dWS = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
         # DualMultWS sub-problem of the widest obstacle through the emulated kernel code
         j = int(np.argmax(v)); r0 = int(v[:j].sum()); vj = int(v[j]); k = 3
-        a1 = np.ascontiguousarray(A[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(A[r0:r0 + vj, 1]); bj = np.ascontiguousarray(b[r0:r0 + vj])
+        rl = P.row_lengths(A)                      # the kernels (and the oracle) work on unit-length rows; lambda is handed back in the caller's row scaling
+        a1 = np.ascontiguousarray(A[r0:r0 + vj, 0] / rl[r0:r0 + vj]); a2 = np.ascontiguousarray(A[r0:r0 + vj, 1] / rl[r0:r0 + vj]); bj = np.ascontiguousarray(b[r0:r0 + vj] / rl[r0:r0 + vj])
         lam = np.zeros(8); mu = np.zeros(4); d = C.c_double(0); cs, sn = np.cos(xWS[k, 2]), np.sin(xWS[k, 2]); g = np.array([2.35, 1.0, 2.35, 1.0])
         emu.emu_dualws(C.c_int(vj), dp(a1), dp(a2), dp(bj), dp(g), C.c_double(xWS[k, 0] + 1.35 * cs), C.c_double(xWS[k, 1] + 1.35 * sn), C.c_double(cs), C.c_double(sn),
                        dp(lam), dp(mu), C.byref(d))
-        assert abs(d.value - dWS[k, j]) < 1e-9 and np.abs(lam[:vj] - lWS[k, r0:r0 + vj]).max() < 1e-8
+        assert abs(d.value - dWS[k, j]) < 1e-9 and np.abs(lam[:vj] / rl[r0:r0 + vj] - lWS[k, r0:r0 + vj]).max() < 1e-8
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b,
                                        xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=A)
         zo = np.zeros_like(z0); info = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
-        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=A)
         assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"]
         assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
         assert np.abs(lp - r["lp"]).max() < 1e-5
@@ -211,10 +212,10 @@ def test_emu_mfma_sweep_variant_matches_oracle(oracle, emu_mfma):
             r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                                            xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
             prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-            z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+            z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
             zo = np.zeros_like(z0); info = np.zeros(8)
             emu_mfma.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
-            xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+            xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=bt["A"])
             assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"]
             assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
 
@@ -234,9 +235,9 @@ def test_emu_fp32_factorisation_variant_converges_to_the_fp64_optimum(oracle, em
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                                        xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
         zo = np.zeros_like(z0); info = np.zeros(8)
         emu_fp32.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
-        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=bt["A"])
         assert int(info[7]) == r["exitflag"] == 1 and abs(int(info[1]) - r["iters"]) <= 3
         assert abs(info[2] - r["obj"]) <= 1e-8 * abs(r["obj"]) and np.abs(xp - r["xp"]).max() < 1e-5 and abs(t - r["t"]) < 1e-7
