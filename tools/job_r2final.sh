@@ -1,9 +1,9 @@
 #!/bin/bash
 # round 2, final job: GPU suite, smoke, the bench lines of all configs, PCIe-inclusive rates, rocprofv3 kernel stats of synchronous steps, PMC traffic of the
 # parking and quadcopter kernels, MFMA instruction counters, per-phase clocks, streams sweep, the end-to-end example
-mkdir -p gpurun_out/r2x
+mkdir -p gpurun_out/r2w
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r2x; R=$PWD
+O=$PWD/gpurun_out/r2w; R=$PWD
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 cd /tmp
@@ -19,9 +19,9 @@ cd $R
 cp $O/pmc_cfg2/FETCH_SIZE_counter_collection.csv profiles/r02_pmc_fetch_size.csv; cp $O/pmc_cfg2/WRITE_SIZE_counter_collection.csv profiles/r02_pmc_write_size.csv
 cp $O/pmc_cfg4/FETCH_SIZE_counter_collection.csv profiles/r02_pmc_quad_fetch_size.csv; cp $O/pmc_cfg4/WRITE_SIZE_counter_collection.csv profiles/r02_pmc_quad_write_size.csv
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-250 $O/bench.json
-timeout 900 python bench.py --config 3 --no-cpu-baseline --steps 48 > $O/bench_cfg3.json 2>/dev/null
-timeout 900 python bench.py --config 4 --no-cpu-baseline --steps 24 > $O/bench_cfg4.json 2>/dev/null
-timeout 900 python bench.py --config 5 --no-cpu-baseline --steps 16 > $O/bench_cfg5.json 2>/dev/null
+timeout 900 python bench.py --config 3 --no-cpu-baseline --steps 56 > $O/bench_cfg3.json 2>/dev/null
+timeout 900 python bench.py --config 4 --no-cpu-baseline --steps 36 > $O/bench_cfg4.json 2>/dev/null
+timeout 900 python bench.py --config 5 --no-cpu-baseline --steps 28 > $O/bench_cfg5.json 2>/dev/null
 timeout 600 python bench.py --no-cpu-baseline --warm-start hybrid --steps 160 > $O/bench_cfg2_hybrid.json 2>/dev/null
 for S_ in 2 6 8; do timeout 300 python bench.py --no-cpu-baseline --steps 120 --streams $S_ 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value',d['value'],'ms',d['ms_per_step'])"; done | tee $O/streams_sweep.txt
 timeout 600 python tools/pcie_rate.py 4096 16384 > $O/pcie_rate.json 2>/dev/null; cat $O/pcie_rate.json
@@ -31,7 +31,7 @@ OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/phase_profile
 OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/quad_gpu.py 64 > $O/quad_phase_B64.txt; OBCA_HIP_LIBRARY=$R/obca_amd/csrc/libobca_hip_prof.so python tools/quad_gpu.py 1024 > $O/quad_phase_B1024.txt
 python - <<'PY'
 import csv, glob, json
-O="gpurun_out/r2x"
+O="gpurun_out/r2w"
 for c in ("bench","bench_cfg3","bench_cfg4","bench_cfg5","bench_cfg2_hybrid"):
     try:
         d=json.load(open(f"{O}/{c}.json")); k=d["config"]; r=d["roofline"]
