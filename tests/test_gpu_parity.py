@@ -412,3 +412,27 @@ def test_512_mixed_obstacle_instances_match_oracle(OA):
         nconv += 1
         assert abs(out["obj"][i] - obj) <= TOL_F * max(1, abs(obj)) and np.abs(out["xp"][i] - xp).max() < TOL_X, i
     assert nconv >= 0.96 * B and hard <= 0.04 * B and sorted(set(len(v) for v in bt["vOb"])) == list(range(1, 11))
+
+
+def test_half_space_rows_of_any_length_describe_the_same_problem(OA, oracle):
+    """the rows of the H-representation may have any length (obstHrep.jl leaves sloped edges unnormalised): through the C ABI, rows scaled by 0.02 .. 1e3 give the
+    same states, inputs and iteration counts, lambda in the caller's scaling (lambda_r / s_r), the same DualMultWS distances -- and a warm start with the returned
+    duals (caller's scaling in, caller's scaling out) is accepted as is"""
+    N, B = 40, 8
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=5)
+    s = np.array([250.0, 0.02, 1e3, 7.0, 0.3])
+    b1 = dict(bt); b1["A"] = bt["A"] * s[:, None]; b1["b"] = bt["b"] * s
+    o0, xWS = _solve_batch(OA, bt); o1, _ = _solve_batch(OA, b1)
+    assert (o0["exitflag"] == 1).all() and (o1["exitflag"] == 1).all() and (o0["iters"] == o1["iters"]).all()
+    assert np.abs(o0["xp"] - o1["xp"]).max() < 1e-9 and np.abs(o0["up"] - o1["up"]).max() < 1e-9
+    for i in range(B):
+        assert np.abs(o0["lp"][i] - o1["lp"][i] * s[:, None]).max() < 1e-8 * max(1.0, np.abs(o0["lp"][i]).max())
+    r = oracle.parking_signed_dist(bt["x0"][3], bt["xF"][3], N, bt["Ts"][3], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], b1["A"], b1["b"],
+                                   xWS[3, :, 0], xWS[3, :, 1], xWS[3, :, 2], 0, xWS[3], bt["uWS"][3])
+    assert r["iters"] == o1["iters"][3] and np.abs(r["xp"] - o1["xp"][3]).max() < TOL_X and np.abs(r["lp"] - o1["lp"][3]).max() < 1e-6 * max(1.0, np.abs(r["lp"]).max())
+    l0, n0, d0 = OA.dualmult_ws_batch(N, bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], bt["ego"])
+    l1, n1, d1 = OA.dualmult_ws_batch(N, bt["vOb"], b1["A"], b1["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], bt["ego"])
+    assert np.abs(np.array(d0) - np.array(d1)).max() < 1e-10 and np.abs(np.array(l0) - np.array(l1) * s[None, None, :]).max() < 1e-9
+    # duals handed back in: the solve starts from them in the caller's scaling
+    o2, _ = _solve_batch(OA, b1, lWS=np.array(l1), nWS=np.array(n1))
+    assert (o2["iters"] == o1["iters"]).all() and np.abs(o2["xp"] - o1["xp"]).max() < 1e-9

@@ -207,3 +207,22 @@ def test_second_order_correction_and_recalc_y_options(oracle):
         changed += r0["iters"] != r1["iters"]
         assert abs(r0["obj"] - r1["obj"]) <= 1e-5 * abs(r0["obj"]) and np.abs(r0["xp"] - r1["xp"]).max() < 2e-3 and abs(r0["t"] - r1["t"]) < 1e-4
     assert changed >= 1
+
+
+def test_half_space_rows_of_any_length_describe_the_same_problem(oracle, backwards):
+    """a_r.p <= b_r and (s_r a_r).p <= s_r b_r are the same half-plane: the solve runs on unit-length rows (what IPOPT's gradient-based scaling does for the
+    reference when obstHrep.jl leaves a steep edge with |a| ~ 1e3) and hands lambda back in the caller's scaling -- states, inputs, iteration count do not depend on
+    the row lengths, lambda_r scales with 1 / s_r (A'lambda and b'lambda do not change).  DualMultWS likewise."""
+    bt = S.make_batch(S.BACKWARDS, 2, 40, seed=5)
+    A, b, v = S.scenario_hrep(S.BACKWARDS)
+    s = np.array([250.0, 0.02, 1e3, 7.0, 0.3])
+    for i in range(2):
+        xWS = bt["xWS"][i]; a = (bt["x0"][i], bt["xF"][i], 40, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v)
+        w = (xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r0 = oracle.parking_signed_dist(*a, A, b, *w); r1 = oracle.parking_signed_dist(*a, A * s[:, None], b * s, *w)
+        assert r0["exitflag"] == r1["exitflag"] == 1 and r0["iters"] == r1["iters"]
+        assert np.abs(r0["xp"] - r1["xp"]).max() < 1e-9 and np.abs(r0["up"] - r1["up"]).max() < 1e-9 and abs(r0["obj"] - r1["obj"]) < 1e-9 * abs(r0["obj"])
+        assert np.abs(r0["lp"] - r1["lp"] * s[:, None]).max() < 1e-8 * max(1.0, np.abs(r0["lp"]).max())
+        l0, n0, d0 = oracle.dualmult_ws(40, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
+        l1, n1, d1 = oracle.dualmult_ws(40, v, A * s[:, None], b * s, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
+        assert np.abs(d0 - d1).max() < 1e-10 and np.abs(l0 - l1 * s[None, :]).max() < 1e-9 and np.abs(n0 - n1).max() < 1e-9
