@@ -17,11 +17,12 @@ def stats(tag, res):
 if __name__ == "__main__":
     B5 = int(sys.argv[1]) if len(sys.argv) > 1 else 512; B3 = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     envs = [dict(), dict(OBCA_SOC="4")] + ([dict(OBCA_RECALC_Y="1"), dict(OBCA_SOC="4", OBCA_RECALC_Y="1")] if "--recalc" in sys.argv else [])
+    if "--lsq" in sys.argv: envs = [dict(), dict(OBCA_LSQ_INIT="1")]
     bt5 = S.make_mixed_batch(B5, 80, seed=20260925, min_obstacles=1) if B5 else None
     bt3 = S.make_batch(S.PARALLEL, B3, 80, seed=20260925, goal_jitter=True) if B3 else None
     out = {}
     for e in envs:
-        for k in ("OBCA_SOC", "OBCA_RECALC_Y"):
+        for k in ("OBCA_SOC", "OBCA_RECALC_Y", "OBCA_LSQ_INIT"):
             os.environ.pop(k, None)
         os.environ.update(e)
         t0 = time.time()
