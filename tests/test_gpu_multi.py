@@ -159,3 +159,20 @@ def test_sharding_collectives_on_rccl(OA):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_nccl_rank, args=(1, 29711 + os.getpid() % 200, ret), nprocs=1, join=True)
     assert ret[0] == (True, True, True, ("hello", 3))
+
+
+def test_caller_kept_output_buffers_are_reused(OA):
+    """`buffers=`: the output arrays of one call are written again by the next call of the same shape (no fresh 280 MB per 16 384-instance call); a call of another
+    shape gets new arrays; results equal the plain call's"""
+    N, B = 40, 96
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=9)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    call = lambda b_, n, **kw: OA.parking_signed_dist_batch(b_["x0"][:n], b_["xF"][:n], N, b_["Ts"][:n], b_["L"], b_["ego"], b_["XYbounds"], b_["vOb"], b_["A"], b_["b"],
+                                                            xWS[:n, :, 0], xWS[:n, :, 1], xWS[:n, :, 2], 0, xWS[:n], b_["uWS"][:n], **kw)
+    ref = call(bt, B)
+    keep = {}
+    o1 = call(bt, B, buffers=keep); p1 = keep["xp"].ctypes.data
+    o2 = call(bt, B, buffers=keep)
+    assert keep["xp"].ctypes.data == p1 and np.array_equal(o1["xp"], ref["xp"]) and np.array_equal(o2["xp"], ref["xp"]) and np.array_equal(o2["up"], ref["up"])
+    o3 = call(bt, B // 2, buffers=keep)
+    assert keep["xp"].shape[0] == B // 2 and np.array_equal(o3["xp"], ref["xp"][:B // 2]) and (o3["exitflag"] == ref["exitflag"][:B // 2]).all()
