@@ -1288,6 +1288,11 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     SYNC();
     if (qph_min_norm2() < 1e-12) { qph_restore(o.bound_push); nrest++; }      // rank-deficient start (the reference's lambda = 0.05): restoration first
     // where IPOPT would enter its restoration phase (line search or inertia correction failed): block restoration, barrier restart, empty filter
+#ifdef OBCA_QUAD_NO_HINT
+#define Q_USE_HINTS 0      /* test variant: every rung of the inertia ladder is assembled (tests/test_emu_quad_cpu.py compares the two builds) */
+#else
+#define Q_USE_HINTS 1
+#endif
 #define Q_NEXT_RUNG(dw_) ((dw_) == 0 ? (dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last)) : (dw_) * (dw_last == 0 ? o.kw_inc0 : o.kw_inc))
 #define Q_RESTORE_AND_CONTINUE { qph_restore(o.bound_push); nrest++; mu = o.mu_init; tau = fmax(o.tau_min, 1 - mu); nf = 0; dw_last = 0; reset_th = 1; continue; }
     for (;;) {
@@ -1299,7 +1304,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         if (dw_first > o.dw_max) { nskip = 0; dw_first = 0; }
         double dw_have = dw_first;                      // the regularisation of the system the records hold
         qph_assemble(mu, dw_have, dc, 0);
-        if (!A.ok) have_hint = 1;
+        if (!A.ok) have_hint = Q_USE_HINTS;
 #ifdef OBCA_SPEC_DEBUG
         fprintf(stderr, "it %d skip %d ok %d\n", it, nskip, A.ok);
 #endif
@@ -1333,7 +1338,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         double dw = dw_first; int ok = 0;
         nreg += nskip;
         for (int tr = 0; tr < 60; tr++) {
-            if (dw != dw_have) { qph_assemble(mu, dw, dc, 0); dw_have = dw; if (!A.ok) have_hint = 1; }
+            if (dw != dw_have) { qph_assemble(mu, dw, dc, 0); dw_have = dw; if (!A.ok) have_hint = Q_USE_HINTS; }
             int a_ = A.ok;
             if (a_) a_ = qph_riccati(o.rho_term);
             if (a_) { qph_direction_main(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }

@@ -59,6 +59,18 @@ def emu_fp32():
 
 
 @pytest.fixture(scope="session")
+def emu_nohint():
+    """the emulation of the quadcopter kernel without the inertia-ladder shortcut (-DOBCA_QUAD_NO_HINT: every rung is assembled)"""
+    import ctypes as C
+    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
+    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_nohint.so")
+    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_QUAD_NO_HINT", "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="session")
 def emu_qlds():
     """the emulation of the quadcopter kernel's build variant -DOBCA_QUAD_RICCATI_LDS (two wavefronts, LDS / VALU sweep, dense stage records)"""
     import ctypes as C

@@ -241,3 +241,23 @@ def test_emu_fp32_factorisation_variant_converges_to_the_fp64_optimum(oracle, em
         xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=bt["A"])
         assert int(info[7]) == r["exitflag"] == 1 and abs(int(info[1]) - r["iters"]) <= 3
         assert abs(info[2] - r["obj"]) <= 1e-8 * abs(r["obj"]) and np.abs(xp - r["xp"]).max() < 1e-5 and abs(t - r["t"]) < 1e-7
+
+
+def test_emu_rows_of_any_length_give_the_same_solve(oracle, emu):
+    """the kernels' packing (obca_amd/packing.py = the C ABI's batch_upload_range) brings the half-space rows to unit length and hands lambda back in the caller's
+    scaling: rows scaled by 0.02 .. 1e3 through the emulated kernels -- DualMultWS + interior point -- give the same states, inputs, iteration counts, and the oracle's
+    lambda for the scaled rows"""
+    import emu_solver as E
+    N, B = 20, 2
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=7)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    s = np.array([250.0, 0.02, 1e3, 7.0, 0.3])
+    a = (bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"])
+    w = (xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    o0 = E.parking_signed_dist_batch(*a, bt["A"], bt["b"], *w); o1 = E.parking_signed_dist_batch(*a, bt["A"] * s[:, None], bt["b"] * s, *w)
+    assert (o0["exitflag"] == 1).all() and (o0["iters"] == o1["iters"]).all() and np.abs(o0["xp"] - o1["xp"]).max() < 1e-9 and np.abs(o0["up"] - o1["up"]).max() < 1e-9
+    for i in range(B):
+        assert np.abs(o0["lp"][i] - o1["lp"][i] * s[:, None]).max() < 1e-8 * max(1.0, np.abs(o0["lp"][i]).max())
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"] * s[:, None], bt["b"] * s,
+                                       xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert r["iters"] == o1["iters"][i] and np.abs(r["xp"] - o1["xp"][i]).max() < 1e-7 and np.abs(r["lp"] - o1["lp"][i]).max() < 1e-5 * max(1.0, np.abs(r["lp"]).max())
