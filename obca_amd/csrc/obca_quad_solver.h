@@ -12,11 +12,7 @@
 namespace obca {
 namespace quad {
 
-#ifdef OBCA_QUAD_RICCATI_LDS
-#define QNT 128                      // the LDS / VALU sweep (build variant) wants two wavefronts: 288..680 items per phase
-#else
 #define QNT 64                       // threads per instance: one wavefront
-#endif
 #define QNMAX 128                    // longest horizon (the forward-sweep trajectory lives in LDS: (QNMAX + 2) x 16 doubles)
 #define QSR 736                      // doubles per stage record: H 20x20 | Fh 16x18 | hc 20x2
 #define QSR_H 0
@@ -37,11 +33,6 @@ namespace quad {
 // (QSP = 288 doubles): QR(o) maps a logical offset o to its slot (structural zeros share one slot that holds 0, the constant 1 of the identity entries another).
 // The kernels are limited by HBM traffic: the dense record cost 5.9 KB per stage and pass to read and -- written 8 bytes at a time into a
 // sparse pattern -- 32 bytes per non-zero to write.  The -DOBCA_QUAD_RICCATI_LDS variant keeps the dense record (its sweep copies records into LDS wholesale).
-#ifdef OBCA_QUAD_RICCATI_LDS
-#define QSP QSR
-OBCA_FN int QR(int o) { return o; }
-#define QR_ZERO (QSR - 1)
-#else
 #define QP_LOC 0        // H[v][v'] over the 10 local variables (angles, rates, inputs)
 #define QP_POS 100      // H[0..2][0..2]
 #define QP_VEL 109      // H[6..8] diagonal
@@ -72,7 +63,6 @@ OBCA_FN int QR(int o) {
     if (i >= QS && j == i - QU) return QP_W + 8 + (i - QS);
     return QR_ZERO;
 }
-#endif
 
 #ifdef OBCA_EMU
 #define QPAR(lane) for (int lane = 0; lane < QNT; ++lane)
@@ -397,11 +387,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 // All index arithmetic of the item -> (row, column) maps is done once per sweep (QRicPlan, registers); the inner loops are
 // branch-free strided LDS reads + fp64 FMAs.  Stage records are gathered QRIC_D stages ahead (same vmcnt discipline as the
 // parking sweep: unconditional loads / stores, single-exit loop).
-#ifdef OBCA_QUAD_NO_OPAQUE
-#define QOPAQUE(x) ((void)0)
-#else
 #define QOPAQUE(x) OPAQUE(x)
-#endif
 #define QTC 18                       // columns of That: x (12), u (4), d, Ft
 #define QTH(a, tc) That[(a) * QTC + (tc)]
 #define QQH(i, cI) Qhat[(i) * QQC + (cI)]
@@ -810,15 +796,10 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
 }
 
 OBCA_FN int q_riccati_backward(QShared &sh, double rho) {
-#ifdef OBCA_QUAD_RICCATI_LDS
-    const int ok = q_riccati_body(sh, rho);
-    QPAR(lane) { if (lane == 0) sh.ric_ok = ok; }
-#else
     const int ok = q_riccati_body_mfma(sh, rho);      // (meaningful on wavefront 0 only: it publishes the flag)
     WAVE0_BEGIN
         PAR64(lane) { if (lane == 0) sh.ric_ok = ok; }
     WAVE0_END
-#endif
     SYNC();
     return sh.ric_ok;
 }
@@ -1288,11 +1269,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
     SYNC();
     if (qph_min_norm2() < 1e-12) { qph_restore(o.bound_push); nrest++; }      // rank-deficient start (the reference's lambda = 0.05): restoration first
     // where IPOPT would enter its restoration phase (line search or inertia correction failed): block restoration, barrier restart, empty filter
-#ifdef OBCA_QUAD_NO_HINT
-#define Q_USE_HINTS 0      /* test variant: every rung of the inertia ladder is assembled (tests/test_emu_quad_cpu.py compares the two builds) */
-#else
 #define Q_USE_HINTS 1
-#endif
 #define Q_NEXT_RUNG(dw_) ((dw_) == 0 ? (dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last)) : (dw_) * (dw_last == 0 ? o.kw_inc0 : o.kw_inc))
 #define Q_RESTORE_AND_CONTINUE { qph_restore(o.bound_push); nrest++; mu = o.mu_init; tau = fmax(o.tau_min, 1 - mu); nf = 0; dw_last = 0; reset_th = 1; continue; }
     for (;;) {
@@ -1305,9 +1282,6 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         double dw_have = dw_first;                      // the regularisation of the system the records hold
         qph_assemble(mu, dw_have, dc, 0);
         if (!A.ok) have_hint = Q_USE_HINTS;
-#ifdef OBCA_SPEC_DEBUG
-        fprintf(stderr, "it %d skip %d ok %d\n", it, nskip, A.ok);
-#endif
         if (reset_th) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); reset_th = 0; }
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;

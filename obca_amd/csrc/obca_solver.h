@@ -44,11 +44,7 @@
 #define OBCA_HD __host__ __device__ inline
 // Phase entry points are real (non-inlined) device functions: each gets its own register allocation, so the unrolled
 // per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
-#ifdef OBCA_PHASE_INLINE
-#define OBCA_PHASE static __device__ __forceinline__
-#else
 #define OBCA_PHASE static __device__ __noinline__
-#endif
 #define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
@@ -59,11 +55,7 @@
 // order (wavefront-scope fences emit no instruction).  Unlike __syncthreads() this does not drain outstanding global loads,
 // which lets the software-pipelined HBM gathers of the sequential sweeps stay in flight across phases.  Use it only where the
 // cross-lane traffic of the surrounding phases goes through LDS.
-#ifdef OBCA_LDS_SYNC_FULL
-#define LDS_SYNC() __syncthreads()
-#else
 #define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#endif
 #define VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   // s_waitcnt vmcnt(0): all outstanding global loads / stores of this wave
 // workgroup barrier for phases that exchange data through LDS only: unlike __syncthreads() it does not drain the global-memory counter
 #define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
@@ -611,25 +603,6 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
     const double t0 = fma(a1, b1, a0 * b0), t1 = fma(a3, b3, a2 * b2), t2 = fma(a5, b5, fma(a4, b4, init));
     return (t0 + t1) + t2;
 }
-// Build variant -DOBCA_RICCATI_FP32 (BASELINE config 5: "fp32 with fp64 KKT refinement"): the factorisation half of a pass -- the three phases of
-// the Riccati recursion, i.e. value function, gains, border constants -- runs in fp32 arithmetic, everything that forms residuals (assembly, termination
-// test, line search) stays fp64.  The interior-point iteration is then an inexact Newton method on fp64 residuals: every outer iteration IS a refinement
-// step, the termination test sees fp64 quantities, so a converged solve meets the same tolerances.  A/B in DESIGN.md section 8.
-#ifdef OBCA_RICCATI_FP32
-typedef float ric_t;
-#else
-typedef double ric_t;
-#endif
-OBCA_FN double dot6_ric(double init, double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3, double a4, double b4,
-                        double a5, double b5) {
-#ifdef OBCA_RICCATI_FP32
-    const float t0 = fmaf((float)a1, (float)b1, (float)a0 * (float)b0), t1 = fmaf((float)a3, (float)b3, (float)a2 * (float)b2),
-                t2 = fmaf((float)a5, (float)b5, fmaf((float)a4, (float)b4, (float)init));
-    return (double)((t0 + t1) + t2);
-#else
-    return dot6_tree(init, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5);
-#endif
-}
 #ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
 #endif
@@ -696,7 +669,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
-            v[r] = dot6_ric(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].a_d] = v[r];
@@ -708,7 +681,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
-            v[r] = dot6_ric(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].b_d] = v[r];
@@ -717,29 +690,20 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     PROF_FINE(I, PF_RIC_P1);
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
     // does not need it (the adjugate products below) runs while it is in flight
-    const ric_t q00 = (ric_t)sh.Qhat[6 * 14 + 6], q10 = (ric_t)sh.Qhat[7 * 14 + 6], q11 = (ric_t)sh.Qhat[7 * 14 + 7];
-    const ric_t det = q00 * q11 - q10 * q10;
+    const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
+    const double det = q00 * q11 - q10 * q10;
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
-#ifdef OBCA_RICCATI_FP32
-    const ric_t idet = 1.0f / det;
-#else
     const double idet = rcp_nr(det);
-#endif
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     PAR(lane) {   // phase C
         double v[RIC_IPL], n0[RIC_IPL], n1[RIC_IPL];
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
-            const ric_t q6 = (ric_t)sh.Qhat[6 * 14 + p.c_col], q7 = (ric_t)sh.Qhat[7 * 14 + p.c_col];
-            const ric_t x6 = (ric_t)L[p.c_x6], x7 = (ric_t)L[p.c_x7], ba = (ric_t)L[p.c_base], s12 = (ric_t)L[p.c_s1] + (ric_t)L[p.c_s2];
-#ifdef OBCA_RICCATI_FP32
-            const ric_t m0 = q10 * q7 - q11 * q6, m1 = q10 * q6 - q00 * q7;
-            n0[r] = m0; n1[r] = m1; v[r] = (double)((x6 * m0 + x7 * m1) * idet + ba + s12);
-#else
+            const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
+            const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
             n0[r] = fma(q10, q7, -(q11 * q6)); n1[r] = fma(q10, q6, -(q00 * q7));       // det * gains of this column
             v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, ba) + s12;
-#endif
         }
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
@@ -750,7 +714,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             L[p.c_d1] = v[r]; L[p.c_d2] = v[r];
-            ro[p.c_rv] = v[r]; ro[p.c_rk0] = (double)((ric_t)n0[r] * idet); ro[p.c_rk1] = (double)((ric_t)n1[r] * idet);
+            ro[p.c_rv] = v[r]; ro[p.c_rk0] = (double)(n0[r] * idet); ro[p.c_rk1] = (double)(n1[r] * idet);
         }
     }
     LDS_BARRIER();
@@ -810,27 +774,10 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     return ok;
 }
 
-// ---------------------------------------------------------------- Riccati backward sweep on the matrix cores (build variant -DOBCA_RICCATI_MFMA; the LDS sweep above is the default)
-// MEASURED AND NOT KEPT AS THE DEFAULT (MI355X, config 2): same records and border constants as the LDS sweep to 1e-13 on the hardware (diagnostic build
-// -DOBCA_RIC_COMPARE), every parity test green, but 2 000 instead of 1 290 clocks per stage for a lone instance and 132 k instead of 141 k solves/s: the blocks
-// fill a third of a tile, MI355X's fp64 matrix rate equals its fp64 vector rate, and a stage stays a chain of dependent steps (5 MFMAs, the Quu pivot,
-// 12 cross-lane moves) whose latencies add up just like the three LDS phases did.  Kept as the reference implementation of the register-resident tile
-// scheme that the quadcopter sweep (full 16 x 16 tiles) uses.
-// The instance is one wavefront, so a stage of the recursion is a chain of v_mfma_f64_16x16x4_f64 operations on 16 x 16 tiles held in registers
-// (the blocks are 6 x 14 and 8 x 14: a third of a tile -- what the matrix cores buy here is not flops but the removal of every LDS round trip from
-// the dependent chain: 1 290 clocks per stage in the LDS version, three phases of ~26 LDS reads per lane each).
-//   lane = 16 g + j.  MFMA(a, b, C): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n)); the f64 accumulator layout is register r of lane (g, j)
-//   = C[g + 4r][j] ("D layout": NOT the 4g + r of the f32 shapes).  A chain over K blocks kb uses A[.][4 kb + k], B[4 kb + k][.]: with that
-//   accumulator layout register kb of a tile in D layout IS the B operand of block kb (B[4 kb + g][j]), and the A operand too if the tile is symmetric.
-// State tile S (D layout; only registers 0, 1 are ever non-zero: rows < 8), in registers for the whole sweep: S[a][b] = P[a][b] (a, b < 6), S[a][8 + c] = p[a][c].
-// Stage k:  T = [0 | p] + P FA          2 MFMAs   A = S masked to the P block (P symmetric), B = FA in D layout, C = S masked to the p block
-//           Q = [H | hc] + FA' T        2 MFMAs   A = the SAME registers as B above (FA'[j][4 kb + g] = FA[4 kb + g][j]), B = T as it comes out, C = [H | hc]
-//                                                 (rows 8, 9 of Q come out as off_m . T[:, 8+b]: the static parts of the bilinear update, for free)
-//           rows 6, 7 of Q (lane groups 2, 3, register 1) broadcast down their columns (two ds_bpermute); Quu from three v_readlane; every lane
-//           computes the gains K[:, j] of its own column
-//           S' = Q + Q[:, 6:8] K        1 MFMA    (Q[i][6+a] taken as Q[6+a][i])
-// Per stage and lane: 4 gathers from the stage record (software-pipelined RIC_D stages ahead), 5 MFMAs, 6 cross-lane moves, 2 stores; the bilinear
-// constants of the border (Bm) are updated by 21 lanes from 48 values passed through LDS.
+// ---------------------------------------------------------------- wave-level matrix-core helpers (used by the quadcopter sweep, obca_quad_solver.h)
+//   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n)); the f64 accumulator layout is register r of lane (g, j)
+//   = C[g + 4r][j] (checked on the hardware by tools/micro/mfma_f64_layout.hip).  The parking blocks (6 x 14, 8 x 14) fill a third of a tile and were
+//   measured slower on the matrix cores than in the three-phase LDS sweep above (round 2), so the parking sweep does not use them.
 #ifdef OBCA_EMU
 OBCA_FN void wv_mfma(double (&acc)[4][OBCA_NLT], const double (&a)[OBCA_NLT], const double (&b)[OBCA_NLT]) {
     double out[4][64];
@@ -852,176 +799,9 @@ OBCA_FN void wv_shfl_group(double (&out)[1], const double (&in)[1], int grp) { o
 OBCA_FN void wv_shfl_xor(double (&out)[1], const double (&in)[1], int m) { out[0] = __shfl_xor(in[0], m, 64); }
 #define WV_READLANE(x, l) readlane_f64((x)[0], (l))
 #endif
-struct MPlan { int idx[4]; double kc[2], fl[4]; int st, sk; };       // gathers: FA rows g, 4+g (0, 1), [H|hc] rows g, 4+g (2, 3); stores: row g of P / p, one gain
-OBCA_FN void mfma_plan(int lane, MPlan &p) {
-    const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int a_ = g + 4 * r;
-        p.idx[r] = AS_DD; p.kc[r] = 0.0; p.fl[r] = 0.0; p.idx[2 + r] = AS_DD; p.fl[2 + r] = 0.0;
-        if (a_ < 6 && j < 14) { int dst; stage_unpack_item(64 + a_ * 14 + j, p.idx[r], dst, p.fl[r], p.kc[r]); }
-        if (j < 8) { p.idx[2 + r] = AS_H + hidx(a_, j); p.fl[2 + r] = 1.0; }
-        else if (j == 8) { p.idx[2 + r] = AS_HB + a_; p.fl[2 + r] = 1.0; }
-        else if (j == 9) { p.idx[2 + r] = AS_HT + a_; p.fl[2 + r] = 1.0; }
-    }
-    p.st = RS_PAD; p.sk = RS_PAD;
-    if (j < 6) { p.st = RS_PX + g * 6 + j; if (g == 0) p.sk = RS_K + j; if (g == 1) p.sk = RS_K + 6 + j; }                            // rows 0..3 of P / p go to HBM (register 0 of group g)
-    else if (j >= 8 && j < 14) { p.st = RS_PV + g * OB_NC + (j - 8); if (g == 0) p.sk = RS_KF + (j - 8); if (g == 1) p.sk = RS_KF + OB_NC + (j - 8); }
-}
-OBCA_FN void mfma_gather(const gdbl *rec, const MPlan &p, double (&v)[4]) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = rec[p.idx[e]];
-}
-// values handed to the bilinear update through LDS (one set per stage parity, in the Qhat scratch): Q[6][8+c], Q[7][8+c], K0[8+c], K1[8+c], W[m][c], V[m][c]
-#define MB_Q6 0
-#define MB_Q7 6
-#define MB_K0 12
-#define MB_K1 18
-#define MB_W 24
-#define MB_V 36
-#define MB_SIZE 48
-template <int PIPE>
-OBCA_FN int riccati_stage_mfma(const Inst &I, Shared &sh, const int k, const MPlan (&plan)[OBCA_NLT], double (&SD)[2][OBCA_NLT], double (&nv)[OBCA_NLT][RIC_D][4], const int slot,
-                               const double (*raw)[4] /* PIPE = 0: the stage's values, gathered by the caller */) {
-    double FAD[2][OBCA_NLT], PA[2][OBCA_NLT], T[4][OBCA_NLT], TC0[OBCA_NLT], Q[4][OBCA_NLT];
-    PAR(lane) {
-        const int L_ = LI(lane), j = lane & 15; const MPlan &p = plan[L_];
-        double v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
-        if (PIPE) { const int kl = k - RIC_D > 0 ? k - RIC_D : 0; mfma_gather(I.as + (size_t)kl * OB_AS, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            FAD[r][L_] = p.kc[r] + p.fl[r] * v[r]; Q[r][L_] = p.fl[2 + r] * v[2 + r];
-            PA[r][L_] = j < 6 ? SD[r][L_] : 0.0; T[r][L_] = j >= 8 ? SD[r][L_] : 0.0;
-        }
-        TC0[L_] = T[0][L_]; T[2][L_] = T[3][L_] = 0.0; Q[2][L_] = Q[3][L_] = 0.0;
-    }
-    wv_mfma(T, PA[0], FAD[0]); wv_mfma(T, PA[1], FAD[1]);           // T = [0 | p] + P FA          (k = 0..7; rows 6, 7 of P and FA are zero)
-    wv_mfma(Q, FAD[0], T[0]); wv_mfma(Q, FAD[1], T[1]);             // Q = [H | hc] + FA' T        (rows 8, 9: W[m][.] = off_m . T)
-    // rows 6, 7 of Q: register 1 of lane groups 2, 3 -> down their columns
-    double q6[OBCA_NLT], q7[OBCA_NLT];
-    wv_shfl_group(q6, Q[1], 2); wv_shfl_group(q7, Q[1], 3);
-    // Quu = [q00 q10; q10 q11] must be positive definite
-    const double q00 = WV_READLANE(q6, 6), q10 = WV_READLANE(q7, 6), q11 = WV_READLANE(q7, 7);
-    const double det = fma(q00, q11, -(q10 * q10));
-    const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);          // (no early exit; after a failed pivot the rest of the group runs on garbage)
-    const double idet = rcp_nr(det);
-    double off0[4], off1[4];                                          // off_m[a] = FA[a][8 + m] (a < 4): register 0 of lane (a, 8 + m), uniform
-#pragma unroll
-    for (int a_ = 0; a_ < 4; a_++) { off0[a_] = WV_READLANE(FAD[0], 16 * a_ + 8); off1[a_] = WV_READLANE(FAD[0], 16 * a_ + 9); }
-    double K0[OBCA_NLT], K1[OBCA_NLT], Aop[OBCA_NLT], Bop[OBCA_NLT], v0[OBCA_NLT], v1[OBCA_NLT], t0[OBCA_NLT], t1[OBCA_NLT];
-    PAR(lane) {
-        const int L_ = LI(lane), g = lane >> 4;
-        K0[L_] = fma(q10, q7[L_], -(q11 * q6[L_])) * idet; K1[L_] = fma(q10, q6[L_], -(q00 * q7[L_])) * idet;      // gains of this lane's column
-        Aop[L_] = g == 0 ? q6[L_] : (g == 1 ? q7[L_] : 0.0);
-        Bop[L_] = g == 0 ? K0[L_] : (g == 1 ? K1[L_] : 0.0);
-        const double o0 = g == 0 ? off0[0] : (g == 1 ? off0[1] : (g == 2 ? off0[2] : off0[3])), o1 = g == 0 ? off1[0] : (g == 1 ? off1[1] : (g == 2 ? off1[2] : off1[3]));
-        v0[L_] = o0 * TC0[L_]; v1[L_] = o1 * TC0[L_];                 // off_m[g] * p[g][.]  (row g of p: register 0)
-    }
-    // V[m][c] = sum_{a<4} off_m[a] p[a][c]: sum over the four lane groups
-    wv_shfl_xor(t0, v0, 16); wv_shfl_xor(t1, v1, 16);
-    PAR(lane) { const int L_ = LI(lane); v0[L_] += t0[L_]; v1[L_] += t1[L_]; }
-    wv_shfl_xor(t0, v0, 32); wv_shfl_xor(t1, v1, 32);
-    gdbl *ro = I.rs + (size_t)k * OB_RS;
-    double *mb = sh.Qhat + (k & 1) * MB_SIZE;
-    PAR(lane) {
-        const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
-        v0[L_] += t0[L_]; v1[L_] += t1[L_];
-        if (j >= 8 && j < 14) {                                       // inputs of the bilinear update
-            if (g == 0) { mb[MB_Q6 + j - 8] = q6[L_]; mb[MB_Q7 + j - 8] = q7[L_]; mb[MB_K0 + j - 8] = K0[L_]; mb[MB_K1 + j - 8] = K1[L_]; mb[MB_W + j - 8] = Q[2][L_]; }
-            if (g == 1) { mb[MB_W + 6 + j - 8] = Q[2][L_]; mb[MB_V + j - 8] = v0[L_]; mb[MB_V + 6 + j - 8] = v1[L_]; }
-        }
-    }
-    wv_mfma(Q, Aop, Bop);                                             // S' = Q + Q[:, 6:8] K
-    LDS_SYNC();
-    PAR(lane) {
-        const int L_ = LI(lane), g = lane >> 4, j = lane & 15; const MPlan &p = plan[L_];
-        const bool col = j < 6 || (j >= 8 && j < 14);
-        SD[0][L_] = col ? Q[0][L_] : 0.0; SD[1][L_] = (col && g < 2) ? Q[1][L_] : 0.0;
-        ro[p.st] = SD[0][L_]; ro[p.sk] = g == 0 ? K0[L_] : K1[L_];
-        if (lane < 21) {                                              // B(a,b) += Q[6:8][8+a] . K[:, 8+b] + off_a . (P off_b + p_b) + off_b . p_a   (a <= b)
-            int a_, b_; pair_of(lane, a_, b_);
-            double bm = fma(mb[MB_Q6 + a_], mb[MB_K0 + b_], mb[MB_Q7 + a_] * mb[MB_K1 + b_]);
-            if (a_ < 2) bm += mb[MB_W + a_ * 6 + b_];
-            if (b_ < 2) bm += mb[MB_V + b_ * 6 + a_];
-            const double v = sh.Bm[a_ * 6 + b_] + bm;
-            sh.Bm[a_ * 6 + b_] = v; sh.Bm[b_ * 6 + a_] = v;
-        }
-    }
-    return ok;
-}
-
-OBCA_FN int riccati_body_mfma(const Inst &I, Shared &sh, double rho) {
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
-    const gdbl *z = I.z;
-    double nv[OBCA_NLT][RIC_D][4], SD[2][OBCA_NLT], raw[OBCA_NLT][4];
-    MPlan plan[OBCA_NLT];
-    PAR(lane) {   // terminal cost-to-go: P_N = H_N (+ rho on the position / heading / speed diagonal), p_N = (hb_N - rho e, Ht_N, e_i)
-        const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
-        mfma_plan(lane, plan[L_]);
-        const gdbl *rec = I.as + (size_t)N * OB_AS;
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int a_ = g + 4 * r; double v = 0.0;
-            if (a_ < 6 && j < 6) { v = rec[AS_H + hidx(a_, j)]; if (a_ == j && a_ < 4) v += rho; }
-            else if (a_ < 6 && j == 8) { const double e = a_ < 4 ? -(z[l.x + 4 * N + a_] - c.xF[a_]) : 0.0; v = rec[AS_HB + a_] - (a_ < 4 ? rho * e : 0.0); }
-            else if (a_ < 6 && j == 9) v = rec[AS_HT + a_];
-            else if (a_ < 4 && j == 10 + a_) v = 1.0;
-            SD[r][L_] = v;
-        }
-        if (lane < 36) sh.Bm[lane] = 0;
-    }
-    LDS_SYNC();
-    // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
-    int k = N - 1;
-    for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
-        PAR(lane) { mfma_gather(I.as + (size_t)k * OB_AS, plan[LI(lane)], raw[LI(lane)]); }
-        if (!riccati_stage_mfma<0>(I, sh, k, plan, SD, nv, 0, raw)) { PROF(I, PF_RIC_BWD); return 0; }
-    }
-    if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
-    PAR(lane) {   // start the gathers of stages k .. k-RIC_D+1; stage kb - ju of the loop below finds its values in slot ju
-#pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++) { const int st = k - ju > 0 ? k - ju : 0; mfma_gather(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][ju]); }
-#ifndef OBCA_EMU
-#pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) asm volatile("" : "+v"(nv[0][ju][e]));
-#endif
-    }
-    int ok = 1;
-    for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
-#pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage_mfma<1>(I, sh, kb - ju, plan, SD, nv, ju, nullptr);
-    }
-    PROF(I, PF_RIC_BWD);
-    return ok;
-}
 
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
-#if defined(OBCA_RIC_COMPARE) && !defined(OBCA_EMU)
-    // diagnostic build: both sweeps on the same records; prof[13] = relative difference of a checksum of the Riccati records, prof[14] = largest
-    // difference of the border constants, prof[15] = 10 ok_lds + ok_mfma (first call of the solve only)
     const int ok = riccati_body(I, sh, rho);
-    if (sh.prof[15] == 0.0) {
-        const int NR = (sh.c.N) * OB_RS;
-        double c1 = 0; for (int i = threadIdx.x; i < NR; i += OB_NT) { const int e = i % OB_RS; if (e < RS_CL) c1 += I.rs[i] * (1 + (i % 7)); }
-        sh.red[0][threadIdx.x] = c1; if (threadIdx.x < 36) sh.red[2][threadIdx.x] = sh.Bm[threadIdx.x];
-        SYNC(); const double C1 = red_sum(sh.red[0]); SYNC();
-        const int ok2 = riccati_body_mfma(I, sh, rho);
-        double c2 = 0; for (int i = threadIdx.x; i < NR; i += OB_NT) { const int e = i % OB_RS; if (e < RS_CL) c2 += I.rs[i] * (1 + (i % 7)); }
-        sh.red[0][threadIdx.x] = c2; sh.red[1][threadIdx.x] = threadIdx.x < 36 ? fabs(sh.red[2][threadIdx.x] - sh.Bm[threadIdx.x]) : 0.0;
-        SYNC(); const double C2 = red_sum(sh.red[0]), dB = red_max(sh.red[1]); SYNC();
-        if (threadIdx.x == 0) { sh.prof[13] = fabs(C1 - C2) / fabs(C1); sh.prof[14] = dB; sh.prof[15] = 10 * ok + ok2 + 100; }
-        SYNC();
-        riccati_body(I, sh, rho);       // leave the LDS sweep's results behind
-    }
-#elif defined(OBCA_RICCATI_MFMA)
-    const int ok = riccati_body_mfma(I, sh, rho);
-#else
-    const int ok = riccati_body(I, sh, rho);
-#endif
     PAR(lane) { if (lane == 0) sh.ric_ok = ok; }
     SYNC();
     return sh.ric_ok;
@@ -1651,19 +1431,6 @@ OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double ta
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
-// one factorisation pass of the common (<= 2 rows per obstacle) case in ONE non-inlined function: every call of a register-hungry phase saves /
-// restores the callee-saved registers it uses through scratch (112 VGPRs + the AGPRs beyond a31: ~1-2 KB per lane and call), and that traffic
-// is a fifth of what the kernel moves.  -DOBCA_FUSE_NEWTON (A/B switch)
-OBCA_PHASE int ph_newton2(double mu, double dw, double dc, double rho, double tau, int assemble) {
-    Shared &sh = g_sh;
-    if (assemble) { assemble_obs<2>(sh.inst, sh, mu, dw, dc); assemble_stage(sh.inst, sh, mu, dw, dc, sh.A); }
-    if (!sh.A.ok) return 0;
-    if (!riccati_backward(sh.inst, sh, rho)) return 0;
-    direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
-    if (!sh.S.ok) return 0;
-    direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S);
-    return 1;
-}
 OBCA_PHASE void ph_trial2(double alpha) { Shared &sh = g_sh; eval_trial<2>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
 OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMID>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
 OBCA_PHASE void ph_trial8(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
@@ -1792,14 +1559,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         for (int tr = 0; tr < 60; tr++) {
             // (a single call for the whole Newton pass saves one more callee-saved-register round trip but costs more in-body spills in the
             // stage assembly: measured 1.3 % slower, so assembly and direction stay separate calls)
-#ifndef OBCA_FUSE_NEWTON
             int a_;
-#endif
-#ifdef OBCA_FUSE_NEWTON
-            int a_;
-            if (sh.vm2) { PROF(sh.inst, PF_OTHER); a_ = ph_newton2(mu, dw, dc, o.rho_term, tau, tr > 0 || mu_changed); }
-            else
-#endif
             {
             PROF(sh.inst, PF_OTHER); if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
             a_ = A.ok;

@@ -35,54 +35,6 @@ def emu():
 
 
 @pytest.fixture(scope="session")
-def emu_mfma():
-    """the same emulation with the Riccati sweep of the build variant -DOBCA_RICCATI_MFMA (register tiles + emulated v_mfma_f64_16x16x4_f64)"""
-    import ctypes as C
-    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_mfma.so")
-    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_RICCATI_MFMA", "-o", so, src])
-    return C.CDLL(so)
-
-
-@pytest.fixture(scope="session")
-def emu_fp32():
-    """the emulation with the Riccati factorisation in fp32 arithmetic (build variant -DOBCA_RICCATI_FP32: BASELINE config 5's "fp32 with fp64 KKT refinement")"""
-    import ctypes as C
-    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_fp32.so")
-    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_RICCATI_FP32", "-o", so, src])
-    return C.CDLL(so)
-
-
-@pytest.fixture(scope="session")
-def emu_nohint():
-    """the emulation of the quadcopter kernel without the inertia-ladder shortcut (-DOBCA_QUAD_NO_HINT: every rung is assembled)"""
-    import ctypes as C
-    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_nohint.so")
-    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_QUAD_NO_HINT", "-o", so, src])
-    return C.CDLL(so)
-
-
-@pytest.fixture(scope="session")
-def emu_qlds():
-    """the emulation of the quadcopter kernel's build variant -DOBCA_QUAD_RICCATI_LDS (two wavefronts, LDS / VALU sweep, dense stage records)"""
-    import ctypes as C
-    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu_qlds.so")
-    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DOBCA_QUAD_RICCATI_LDS", "-o", so, src])
-    return C.CDLL(so)
-
-
-@pytest.fixture(scope="session")
 def backwards():
     from obca_amd import scenarios as S
     A, b, v = S.scenario_hrep(S.BACKWARDS)

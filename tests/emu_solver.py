@@ -5,7 +5,7 @@ import ctypes as C
 import os
 import subprocess
 import numpy as np
-from obca_amd import packing as P
+import packing as P
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D = C.POINTER(C.c_double)

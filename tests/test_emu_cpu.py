@@ -1,7 +1,8 @@
 """The HIP solver source, compiled as a host emulation (64 lanes as a loop), against the oracle: kernel LOGIC without a GPU."""
 import ctypes as C
 import numpy as np
-from obca_amd import scenarios as S, packing as P
+from obca_amd import scenarios as S
+import packing as P
 
 D = C.POINTER(C.c_double)
 dp = lambda a: a.ctypes.data_as(D)
@@ -195,52 +196,6 @@ def test_emu_wide_obstacles_match_oracle(oracle, emu):
         assert np.abs(lp - r["lp"]).max() < 1e-5
         done += 1
     assert done >= 2
-
-
-def test_emu_mfma_sweep_variant_matches_oracle(oracle, emu_mfma):
-    """build variant -DOBCA_RICCATI_MFMA: the Riccati recursion on 16 x 16 register tiles (v_mfma_f64_16x16x4_f64, emulated with the hardware's operand and
-    accumulator layout, which tools/micro/mfma_f64_layout.hip checks on the GPU); odd horizon and a horizon that is not a multiple of the gather depth"""
-    for N in (21, 40):
-        bt = S.make_batch(S.BACKWARDS, 2, N)
-        v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
-        oo = oracle.default_opts(); eo = EOpts()
-        for n, _ in EOpts._fields_:
-            setattr(eo, n, getattr(oo, n))
-        for i in range(2):
-            xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
-            lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
-            r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
-                                           xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
-            prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-            z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
-            zo = np.zeros_like(z0); info = np.zeros(8)
-            emu_mfma.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
-            xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=bt["A"])
-            assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"]
-            assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
-
-
-def test_emu_fp32_factorisation_variant_converges_to_the_fp64_optimum(oracle, emu_fp32):
-    """build variant -DOBCA_RICCATI_FP32 (BASELINE config 5's arithmetic mode): Riccati factorisation in fp32, residuals / termination test / line search in fp64
-    = an inexact Newton iteration on fp64 residuals.  It must converge by the same fp64 termination test to the oracle's optimum (the outer iterations are
-    the refinement steps); iteration counts may differ by a few"""
-    N = 40; bt = S.make_batch(S.BACKWARDS, 4, N)
-    v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
-    oo = oracle.default_opts(); eo = EOpts()
-    for n, _ in EOpts._fields_:
-        setattr(eo, n, getattr(oo, n))
-    for i in range(4):
-        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
-        lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
-        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
-                                       xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
-        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
-        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
-        zo = np.zeros_like(z0); info = np.zeros(8)
-        emu_fp32.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
-        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=bt["A"])
-        assert int(info[7]) == r["exitflag"] == 1 and abs(int(info[1]) - r["iters"]) <= 3
-        assert abs(info[2] - r["obj"]) <= 1e-8 * abs(r["obj"]) and np.abs(xp - r["xp"]).max() < 1e-5 and abs(t - r["t"]) < 1e-7
 
 
 def test_emu_rows_of_any_length_give_the_same_solve(oracle, emu):

@@ -2,7 +2,7 @@
 import ctypes as C
 import numpy as np
 import pytest
-from obca_amd import packing as P
+import packing as P
 from test_emu_cpu import EOpts, dp
 
 
@@ -85,39 +85,3 @@ def test_emu_quadcopter_dist_variant_matches_oracle(Q, emu):
     assert abs(info[2] - r["obj"]) < 1e-8 * abs(r["obj"]) and np.abs(z[L["s"]:L["so"]]).max() == 0
     xp = z[L["x"]:L["u"]].reshape(N + 1, 12).T
     assert np.abs(xp - r["xp"]).max() < 1e-4
-
-
-def test_emu_quad_lds_sweep_variant_matches_oracle(Q, emu_qlds):
-    """build variant -DOBCA_QUAD_RICCATI_LDS: the round-1 LDS / VALU sweep on two wavefronts with dense stage records, kept for A/B; the default is the MFMA sweep
-    (one wavefront, packed records), which the other tests of this file run"""
-    N = 30; Ts = round(0.25 * 80 / N * 100) / 100
-    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
-    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
-    oo = Q.default_opts(); eo = EOpts()
-    for f, _ in EOpts._fields_:
-        setattr(eo, f, getattr(oo, f))
-    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
-    z = np.zeros(L["len"]); info = np.zeros(8)
-    emu_qlds.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
-    assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"] and int(info[6]) == r["nreg"]
-    assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"])
-
-
-def test_skipped_rungs_of_the_inertia_ladder_change_nothing(Q, emu, emu_nohint):
-    """q_block_bad: a rung of the delta_w ladder that a remembered box block is known to fail is counted and skipped without being assembled.  Against the build that
-    assembles every rung (-DOBCA_QUAD_NO_HINT): the same iterate bit for bit, the same iteration and regularisation counts"""
-    from obca_amd import scenarios as S
-    N = 30
-    q = S.make_quad_batch(3, N, seed=4, random_endpoints=True)
-    oo = Q.default_opts(); eo = EOpts()
-    for f, _ in EOpts._fields_:
-        setattr(eo, f, getattr(oo, f))
-    L = P.quad_layout(N); skipped = 0
-    for i in range(3):
-        prob = P.pack_quad_problem(q["x0"][i], q["xF"][i], N, q["Ts"], q["R"], q["ob"], q["xWS"][i], 1.0, dual_ws=1)
-        z0 = np.zeros(L["len"]); i0 = np.zeros(8); z1 = np.zeros(L["len"]); i1 = np.zeros(8)
-        emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z0), dp(i0))
-        emu_nohint.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z1), dp(i1))
-        assert i0[7] == 1 and np.array_equal(i0, i1) and np.array_equal(z0, z1)
-        skipped += int(i0[6])
-    assert skipped > 10          # the ladder was climbed: there was something to skip
