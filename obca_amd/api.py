@@ -15,6 +15,7 @@ ctypes binding of libobca_hip.so and the Python mirror of the reference's entry 
 plus batched variants (leading batch dimension) that keep everything resident on the GPU between upload and download.
 """
 import ctypes as C
+import numbers
 import os
 import subprocess
 import time
@@ -159,7 +160,9 @@ def _ctx(device=0):
     """cached context of one device index, of a tuple of indices, or of "all" visible devices"""
     if isinstance(device, Context):
         return device
-    key = device if isinstance(device, (int, str)) else tuple(device)
+    if isinstance(device, numbers.Integral):          # np.int64 local ranks, torch scalars' .item(), ...
+        device = int(device)
+    key = device if isinstance(device, (int, str)) else tuple(int(d) for d in device)
     if key not in _default_ctx:
         _default_ctx[key] = Context(device) if isinstance(key, int) else Context(devices=device)
     return _default_ctx[key]
@@ -177,6 +180,27 @@ def _norm_obstacles(B, vOb, A, b):
     M = int(v.sum())
     A = np.asarray(A, float).reshape(M, 2); b = np.ravel(np.asarray(b, float))
     return np.full(B, len(v), np.int32), np.tile(v, B), np.tile(A, (B, 1)), np.tile(b, B)
+
+
+def _warm_start(xWS, uWS, B, N):
+    """xWS (B, >= N+1, 4), uWS (B, >= N, 2) cut to the horizon -- checked here, because the C side reads N+1 / N rows through raw pointers"""
+    xWS = np.asarray(xWS, float).reshape(B, -1, 4); uWS = np.asarray(uWS, float).reshape(B, -1, 2)
+    if xWS.shape[1] < N + 1 or uWS.shape[1] < N:
+        raise ObcaError(f"warm start too short: xWS has {xWS.shape[1]} stages (need N+1 = {N + 1}), uWS {uWS.shape[1]} (need N = {N})")
+    return xWS[:, :N + 1], uWS[:, :N]
+
+
+def _dual_start(lWS, nWS, Mt, nt, N):
+    """optional dual warm start, packed per instance ((N+1) x M_i, (N+1) x 4 nOb_i blocks); sizes checked before raw pointers go to C"""
+    if lWS is None or nWS is None:
+        return None, None
+    if not isinstance(lWS, np.ndarray):
+        lWS = np.concatenate([np.ravel(x) for x in lWS])
+    if not isinstance(nWS, np.ndarray):
+        nWS = np.concatenate([np.ravel(x) for x in nWS])
+    if lWS.size != Mt * (N + 1) or nWS.size != 4 * nt * (N + 1):
+        raise ObcaError(f"dual warm start has the wrong size: lWS {lWS.size} (need {Mt * (N + 1)}), nWS {nWS.size} (need {4 * nt * (N + 1)})")
+    return lWS, nWS
 
 
 def _row_counts(nObs, vflat):
@@ -201,11 +225,10 @@ class Batch:
         self.nObs, self.vflat = nObs, vflat
         self.Ms = _row_counts(nObs, vflat)
         Ts = np.broadcast_to(np.asarray(Ts, float), (B,))
-        if lWS is not None and not isinstance(lWS, np.ndarray):
-            lWS = np.concatenate([np.ravel(x) for x in lWS]); nWS = np.concatenate([np.ravel(x) for x in nWS])
+        lWS, nWS = _dual_start(lWS, nWS, int(self.Ms.sum()), int(nObs.sum()), N)
         keep = [_d(Ts), _d(ego), _d(XYbounds), _d(np.reshape(x0, (B, 4))), _d(np.reshape(xF, (B, 4))), _i(nObs), _i(vflat),
                 _d(Aflat), _d(bflat), _d(np.reshape(rx, (B, N + 1))), _d(np.reshape(ry, (B, N + 1))), _d(np.reshape(ryaw, (B, N + 1))),
-                _d(np.asarray(xWS, float).reshape(B, -1, 4)[:, :N + 1]), _d(np.asarray(uWS, float).reshape(B, -1, 2)[:, :N]),
+                *(_d(w) for w in _warm_start(xWS, uWS, B, N)),
                 _d(lWS), _d(nWS)]
         p = [k[1] for k in keep]
         rc = _load().obca_batch_upload(self._h, p[0], C.c_double(float(L)), p[1], p[2], C.c_int(int(fixTime)), p[3], p[4], p[5], p[6],
@@ -286,11 +309,10 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
     Ms = _row_counts(nObs, vflat)
     Mt, nt = int(Ms.sum()), int(nObs.sum())
     Tsv = np.ascontiguousarray(np.broadcast_to(np.asarray(Ts, float), (B,)))
-    if lWS is not None and not isinstance(lWS, np.ndarray):
-        lWS = np.concatenate([np.ravel(x) for x in lWS]); nWS = np.concatenate([np.ravel(x) for x in nWS])
+    lWS, nWS = _dual_start(lWS, nWS, Mt, nt, N)
     keep = [_d(Tsv), _d(ego), _d(XYbounds), _d(x0), _d(np.reshape(xF, (B, 4))), _i(nObs), _i(vflat), _d(Aflat), _d(bflat),
             _d(np.reshape(rx, (B, N + 1))), _d(np.reshape(ry, (B, N + 1))), _d(np.reshape(ryaw, (B, N + 1))),
-            _d(np.asarray(xWS, float).reshape(B, -1, 4)[:, :N + 1]), _d(np.asarray(uWS, float).reshape(B, -1, 2)[:, :N]), _d(lWS), _d(nWS)]
+            *(_d(w) for w in _warm_start(xWS, uWS, B, N)), _d(lWS), _d(nWS)]
     p = [k[1] for k in keep]
     shapes = dict(xp=(B, N + 1, 4), up=(B, N, 2), ts=(B, N + 1), lp=(Mt * (N + 1),), npp=(4 * nt * (N + 1),), sl=(nt * (N + 1),), info=(B, 8))
     bufs = buffers if buffers is not None else {}

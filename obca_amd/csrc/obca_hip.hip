@@ -6,7 +6,7 @@
 //   obca_quad_ipm_kernel    : the same for the quadcopter NLP (obca_quad_solver.h).
 //   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
-//   prob  header+rx,ry,ryaw   [411]      z  primal-dual iterate [6554]      d  search direction [3804 used]
+//   prob  header+rx,ry,ryaw   [411]      z, zn  primal-dual iterate and the line search's trial point (they swap) [6797 each]      d  stage part of the search direction [~650 used]
 //   as    assembled stage records (N+1) x 88 [7128]     rs  Riccati records (N+1) x 116 [9396]
 //   oc    condensed obstacle records (N+1) x nOb x 12 [2916]    traj (N+2) x 6
 #include <hip/hip_runtime.h>
@@ -29,7 +29,7 @@ static_assert(OBCA_QUAD_NMAX == QNMAX, "ABI limits must match the kernels");
 static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX && OBCA_MMAX == OB_MMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
-    double *prob, *z0, *z, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;
+    double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
     double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
     int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
     size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     if (threadIdx.x == 0) {
         Inst &I = g_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
-        I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
+        I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.zn = (gdbl *)(b.zn + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
         I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc); I.traj = (gdbl *)(b.traj + (size_t)inst * b.s_traj);
 #ifdef OBCA_PROFILE
@@ -67,6 +67,18 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
 #endif
+}
+
+// instances resident per CU: registers allow 4 x OBCA_IPM_WAVES_PER_EU, LDS (static Shared + the horizon-sized dynamic part) may allow fewer -- ask the runtime
+static int parking_resident_per_cu(int N) {
+    static int cache[OB_NMAX + 1];                       // 0 = not asked yet
+    if (N < 0 || N > OB_NMAX) return OBCA_RESIDENT_PER_CU;
+    if (!cache[N]) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, obca_parking_ipm_kernel, OB_NT, OB_DYN_LDS_DOUBLES(N) * sizeof(double)) != hipSuccess || n < 1) n = OBCA_RESIDENT_PER_CU;
+        cache[N] = n;
+    }
+    return cache[N];
 }
 
 // difficulty class of a parked instance (0..63, higher = dispatched earlier)
@@ -197,13 +209,13 @@ __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_ker
 //   scatter: dst[i * ds + j] = j < W ? src[i * W + j] : 0   for j < zero_to   (upload: primal prefix of the iterate, rest of the row cleared)
 //   gather : dst[i * W + j] = src[i * ss + j]                                   (download: the output prefix of the iterate)
 __global__ __launch_bounds__(256) void obca_scatter_rows_kernel(double *dst, size_t ds, const double *src, size_t W, size_t zero_to) {
-    const size_t i = blockIdx.y;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < zero_to; j += (size_t)gridDim.x * blockDim.x)
+    const size_t i = blockIdx.x;                     // row (instance) in grid.x: no 65 535 limit on the batch size
+    for (size_t j = (size_t)blockIdx.y * blockDim.x + threadIdx.x; j < zero_to; j += (size_t)gridDim.y * blockDim.x)
         dst[i * ds + j] = j < W ? src[i * W + j] : 0.0;
 }
 __global__ __launch_bounds__(256) void obca_gather_rows_kernel(double *dst, size_t W, const double *src, size_t ss) {
-    const size_t i = blockIdx.y;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < W; j += (size_t)gridDim.x * blockDim.x)
+    const size_t i = blockIdx.x;
+    for (size_t j = (size_t)blockIdx.y * blockDim.x + threadIdx.x; j < W; j += (size_t)gridDim.y * blockDim.x)
         dst[i * W + j] = src[i * ss + j];
 }
 
@@ -279,24 +291,26 @@ int obca_create_multi(obca_ctx **out, const int *devices, int ndev) {
     else devs.assign(devices, devices + ndev);
     int nslot = 4;                                       // worker lanes per device (OBCA_SLOTS)
     if (const char *ev = getenv("OBCA_SLOTS")) { nslot = atoi(ev); if (nslot < 1) nslot = 1; if (nslot > 8) nslot = 8; }
+    // every device is validated before anything is created, so that a bad index cannot leave a half-built context (or a leaked stream) behind
+    std::vector<hipDeviceProp_t> props(devs.size());
+    for (size_t di = 0; di < devs.size(); di++) {
+        const int dv = devs[di];
+        if (dv < 0 || dv >= n) { g_create_err = "device index out of range"; return -1; }
+        if (hipGetDeviceProperties(&props[di], dv) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; return -2; }
+        if (std::string(props[di].gcnArchName).find("gfx950") == std::string::npos) {
+            g_create_err = std::string("device is ") + props[di].gcnArchName + ", libobca_hip is built for gfx950 only"; return -2;
+        }
+    }
     obca_ctx *c = new obca_ctx();
     c->devices = devs;
-    std::vector<hipStream_t> made;
+    c->name = std::string(props[0].name) + " (" + props[0].gcnArchName + ")"; c->cus = props[0].multiProcessorCount;
     for (int s = 0; s < nslot; s++) for (size_t di = 0; di < devs.size(); di++) {       // slot order interleaves the devices
-        const int dv = devs[di];
-        if (dv < 0 || dv >= n) { g_create_err = "device index out of range"; delete c; return -1; }
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, dv) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; delete c; return -2; }
-        if (std::string(pr.gcnArchName).find("gfx950") == std::string::npos) {
-            g_create_err = std::string("device is ") + pr.gcnArchName + ", libobca_hip is built for gfx950 only"; delete c; return -2;
-        }
-        if (s == 0 && di == 0) { c->name = std::string(pr.name) + " (" + pr.gcnArchName + ")"; c->cus = pr.multiProcessorCount; }
-        Slot sl; sl.device = dv; sl.pb = nullptr; sl.qb = nullptr; sl.cus = pr.multiProcessorCount; sl.stream = nullptr;
+        Slot sl; sl.device = devs[di]; sl.pb = nullptr; sl.qb = nullptr; sl.cus = props[di].multiProcessorCount; sl.stream = nullptr;
         // Non-blocking: the streams never synchronise implicitly with the legacy default stream, which other libraries in the process may use.
         // Only the primary lane gets its stream now; the others are created when a call first needs them: HIP spreads streams over a handful of
         // hardware queues in creation order, and a process that keeps several single-lane contexts busy at once (bench.py) would otherwise find
         // its four primary streams on ONE queue, serialised (measured: 103 k instead of 132 k solves/s).
-        if (s == 0 && di == 0 && (hipSetDevice(dv) != hipSuccess || hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess)) {
+        if (s == 0 && di == 0 && (hipSetDevice(sl.device) != hipSuccess || hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess)) {
             g_create_err = "hipStreamCreate failed"; delete c; return -2;
         }
         c->slots.push_back(sl);
@@ -337,7 +351,7 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
     if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
     bt->dcap_stage = 0;
@@ -383,7 +397,10 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
     hipSetDevice(bt->device);
     const size_t B = bt->cap;
     if (!bt->uploaded || nObMax > bt->nObMax || MMax > bt->MMax) {       // (a cached batch keeps the largest shape it has seen)
+        // (re)allocation: the batch counts as empty until every buffer exists -- a failed hipMalloc must leave a state the next call can recover from,
+        // not a batch that still claims to be uploaded with null device pointers
         free_dev(bt);
+        bt->uploaded = 0; bt->bytes = 0;
         bt->nObMax = std::max(nObMax, bt->nObMax); bt->MMax = std::max(MMax, bt->MMax);
         Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
         bt->zlen = lmax.len;
@@ -391,14 +408,15 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
         d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_traj = std::max((size_t)(N + 2) * 6, (size_t)(N / 2) * 42);   // traj: composed stage-pair maps of the forward sweep
         size_t tot = 0;
-#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); HIPCHK(bt, hipMalloc((void **)&(ptr), by_)); tot += by_; } while (0)
-        ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_z);
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = hipMalloc((void **)&(ptr), by_); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
+        ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.zn, B * d.s_z); ALLOC(d.d, B * d.s_z);
         ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
         ALLOC(d.info, B * 8); ALLOC(d.dws, B * N1 * bt->nObMax); ALLOC(d.prof, B * 16);
         ALLOC(d.slice, B * SL_SIZE);
         bt->dcap_stage = B * (size_t)lmax.nprimal;                       // nprimal >= the output prefix
         ALLOC(bt->stage, bt->dcap_stage);
-        HIPCHK(bt, hipMalloc((void **)&d.order, (B + 1) * sizeof(int))); tot += (B + 1) * sizeof(int);
+        if (hipMalloc((void **)&d.order, (B + 1) * sizeof(int)) != hipSuccess) { bt->err = "hipMalloc(order) failed"; free_dev(bt); return -2; }
+        tot += (B + 1) * sizeof(int);
 #undef ALLOC
         bt->bytes = (long long)tot;
     }
@@ -455,7 +473,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
     bt->have_duals = duals ? 1 : 0; bt->fixTime = in.fixTime ? 1 : 0;
     HIPCHK(bt, hipMemcpyAsync(d.prob, bt->h_prob, (size_t)n * d.s_prob * sizeof(double), hipMemcpyHostToDevice, bt->stream));
     HIPCHK(bt, hipMemcpyAsync(bt->stage, bt->h_zin, (size_t)n * W * sizeof(double), hipMemcpyHostToDevice, bt->stream));
-    hipLaunchKernelGGL(obca_scatter_rows_kernel, dim3((unsigned)((d.s_z + 1023) / 1024), n), dim3(256), 0, bt->stream, d.z0, d.s_z, (const double *)bt->stage, W, d.s_z);
+    hipLaunchKernelGGL(obca_scatter_rows_kernel, dim3(n, (unsigned)((d.s_z + 1023) / 1024)), dim3(256), 0, bt->stream, d.z0, d.s_z, (const double *)bt->stage, W, d.s_z);
     HIPCHK(bt, hipGetLastError());
     bt->uploaded = 1;
     return 0;
@@ -495,18 +513,19 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     int budget = 6;
     if (const char *e = getenv("OBCA_SLICE_PASSES")) budget = atoi(e);
     const bool slice_only = getenv("OBCA_SLICE_ONLY") && atoi(getenv("OBCA_SLICE_ONLY"));
-    const int slots = OBCA_RESIDENT_PER_CU * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
+    const size_t dyn_lds = OB_DYN_LDS_DOUBLES(bt->N) * sizeof(double);      // forward-sweep trajectory + stage buffers / pair maps, sized for the horizon (obca_solver.h)
+    const int slots = parking_resident_per_cu(bt->N) * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
     bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0);
         HIPCHK(bt, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget);
         HIPCHK(bt, hipGetLastError());
         if (!slice_only) {
             hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
             HIPCHK(bt, hipGetLastError());
-            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), 0, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0);
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0);
             HIPCHK(bt, hipGetLastError());
         }
     }
@@ -526,7 +545,7 @@ static int batch_download_range(obca_batch *bt, const ParkOut &o, int lo) {
     if (pinned_reserve(bt->err, &bt->h_zout, &bt->hcap_zout, (size_t)bt->cap * std::max(W, (size_t)N1 * bt->nObMax)) ||
         pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return -2;
     if (want_z) {
-        hipLaunchKernelGGL(obca_gather_rows_kernel, dim3((unsigned)((W + 1023) / 1024), B), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
+        hipLaunchKernelGGL(obca_gather_rows_kernel, dim3(B, (unsigned)((W + 1023) / 1024)), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
         HIPCHK(bt, hipGetLastError());
         HIPCHK(bt, hipMemcpyAsync(bt->h_zout, bt->stage, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
     }
@@ -614,7 +633,7 @@ static int parking_call(obca_ctx *ctx, int dist, int dualws_only, int B, int N, 
     if (!in.Ts || !in.ego || !in.XYb || !in.nOb || !in.vOb || !in.A || !in.b || !in.rx || !in.ry || !in.ryaw) { ctx->err = "NULL argument"; return -1; }
     if (!dualws_only && N < 2) { ctx->err = "the NLP needs a horizon N>=2"; return -1; }
     if (int rc = park_prefix(ctx->err, B, in.nOb, in.vOb, in)) return rc;
-    const int chunk = pick_chunk(ctx, B, OBCA_RESIDENT_PER_CU);
+    const int chunk = pick_chunk(ctx, B, 4);
     return run_chunks(ctx, B, chunk, [&](Slot &s, int lo, int n, std::string &err) -> int {
         int rc = slot_parking_batch(ctx, s, std::min(chunk, B), N, dist, err);
         if (rc) return rc;
@@ -805,7 +824,7 @@ static int quad_download_range(obca_quad_batch *bt, const QuadOut &o, int lo) {
     hipSetDevice(bt->device);
     const size_t W = (size_t)l.so;                          // outputs are a prefix of the iterate: x, u, t, lam, s
     if (pinned_reserve(bt->err, &bt->h_z, &bt->hcap_z, (size_t)bt->cap * W) || pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return -2;
-    hipLaunchKernelGGL(obca_gather_rows_kernel, dim3((unsigned)((W + 1023) / 1024), B), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
+    hipLaunchKernelGGL(obca_gather_rows_kernel, dim3(B, (unsigned)((W + 1023) / 1024)), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipMemcpyAsync(bt->h_z, bt->stage, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, bt->stream));
     QCHK(bt, hipMemcpyAsync(bt->h_info, d.info, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToHost, bt->stream));

@@ -214,7 +214,8 @@ OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
            (in.Y + sn * c.off) * p2 - beta + (c.dist ? 0.0 : in.sl) - OB_DMIN - in.so;   // ParkingDist.jl:207-208: no slack
 }
 
-struct ObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
+struct ObsStats { double dmax, pmax, cmax0, cmin, cmax, sumz, sumy; int bad; };   // cmin / cmax: smallest / largest complementarity product s z (the error w.r.t. ANY barrier
+                                                                                   // parameter follows from the two: max |s z - mu| = max(|cmax - mu|, |cmin - mu|), rounding is monotone)
 
 struct ObsCond {          // result of the condensation onto the pose
     double Hpp[6];        // symmetric 3x3: 00 01 02 11 12 22
@@ -272,7 +273,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         { const double im = rcp_nr(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr(in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); st->dmax = fmax(st->dmax, rz);
-            double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
+            double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
             st->sumz += fabs(in.zm[i]);
         }
     }
@@ -283,7 +284,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
             { const double il = rcp_nr(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); st->dmax = fmax(st->dmax, rz);
-                double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
+                double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
                 st->sumz += fabs(in.zl[i]);
             }
         } else { r_lam[i] = 0; Dlam[i] = 1; }
@@ -291,8 +292,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     if (MODE == 0) {
         double rz = fabs(-y[3] - in.zso); st->dmax = fmax(st->dmax, rz);
         { const double rzs = c.dist ? fabs(y[0] - in.zs1) : fabs(r_sl); st->dmax = fmax(st->dmax, rzs); }
-        if (c.dist) { const double c1 = in.sl * in.zs1; st->cmax0 = fmax(st->cmax0, fabs(c1)); st->cmaxmu = fmax(st->cmaxmu, fabs(c1 - mu_b)); st->sumz += fabs(in.zs1); }
-        double cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
+        if (c.dist) { const double c1 = in.sl * in.zs1; st->cmax0 = fmax(st->cmax0, fabs(c1)); st->cmin = fmin(st->cmin, c1); st->cmax = fmax(st->cmax, c1); st->sumz += fabs(in.zs1); }
+        double cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
         st->sumz += fabs(in.zso);
 #pragma unroll
         for (int r = 0; r < 4; r++) { st->pmax = fmax(st->pmax, fabs(cr[r])); st->sumy += fabs(y[r]); }

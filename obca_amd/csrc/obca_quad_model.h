@@ -131,7 +131,7 @@ OBCA_FN void q_obs_rows(const QConsts &c, const QObsIn &in, double r[2], double 
     r[1] = -bl + in.p[0] * q[0] + in.p[1] * q[1] + in.p[2] * q[2] + (c.dist ? 0.0 : 0.01 * in.s) - c.R - in.so;
 }
 
-struct QObsStats { double dmax, pmax, cmax0, cmaxmu, sumz, sumy; int bad; };
+struct QObsStats { double dmax, pmax, cmax0, cmin, cmax, sumz, sumy; int bad; };   // cmin / cmax: extreme complementarity products (obca_model.h: ObsStats)
 struct QObsStep { double dlam[QL], ds, dso, dy[2]; };
 
 // MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp;
@@ -151,7 +151,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         rl[i] = gl - mu_b * il; Dl[i] = 2e-4 + in.zl[i] * il + dw;
         if (MODE == 0) {
             double rz = fabs(gl - in.zl[i]); st->dmax = fmax(st->dmax, rz);
-            double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
+            double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
             st->sumz += fabs(in.zl[i]);
         }
     }
@@ -163,8 +163,8 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     if (MODE == 0) {
         double rz = c.dist ? 0.0 : fabs(gs - in.zs); st->dmax = fmax(st->dmax, rz);
         rz = fabs(gso - in.zso); st->dmax = fmax(st->dmax, rz);
-        double cc = c.dist ? 0.0 : in.s * in.zs; st->cmax0 = fmax(st->cmax0, fabs(cc)); if (!c.dist && fabs(cc - mu_b) > st->cmaxmu) st->cmaxmu = fabs(cc - mu_b);
-        cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmaxmu = fmax(st->cmaxmu, fabs(cc - mu_b));
+        double cc = c.dist ? 0.0 : in.s * in.zs; st->cmax0 = fmax(st->cmax0, fabs(cc)); if (!c.dist) { st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc); }
+        cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
         st->sumz += (c.dist ? 0.0 : fabs(in.zs)) + fabs(in.zso);
         st->pmax = fmax(st->pmax, fabs(cr[0])); st->pmax = fmax(st->pmax, fabs(cr[1]));
         st->sumy += fabs(y[0]) + fabs(y[1]);

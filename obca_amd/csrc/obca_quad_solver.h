@@ -148,7 +148,7 @@ OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &
 OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z;
     QPAR(lane) {
-        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0; int badit = -1;
         for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
@@ -175,14 +175,14 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
                 bar += log_prod(dd);
             }
         }
-        sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
+        sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmin; sh.red[12][lane] = st.cmax;
         sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
         sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
         if (st.bad) sh.hintl[lane] = badit;
     }
     SYNC();
     AsmOut &P = sh.Ap;
-    P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cinfmu = red_max(sh.red[3]);
+    P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cmin = red_min(sh.red[3]); P.cmax = red_max(sh.red[12]);
     P.sumz = red_sum(sh.red[4]); P.sumy = red_sum(sh.red[5]); P.f = red_sum(sh.red[6]); P.th1 = red_sum(sh.red[7]);
     P.bar = red_sum(sh.red[8]);
     P.ok = !(red_max(sh.red[9]) > 0.5);
@@ -197,7 +197,7 @@ OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const gdbl *z = sh.inst.z;
     QPAR(lane) {
         const int it = sh.hintl[lane];
-        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        QObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         if (it >= 0) {
             const int k = it / QOB, j = it - k * QOB;
             QObsIn in; q_load_obs(sh, z, k, j, in);
@@ -215,11 +215,11 @@ OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
 OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmOut &out) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
     const double t = z[l.t], tau = t * c.Ts;
-    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
+    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
     QPAR(lane) {
-        double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lgtb = 0, lgtz = 0;
+        double dmax = 0, pmax = 0, lc0 = 0, lcmn = 1e300, lcmx = -1e300, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lgtb = 0, lgtz = 0;
         for (int k = lane; k <= N; k += QNT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSP;
             double x[QX], hz[QX], hb[QX], xd[QX], Hpos[6] = {0, 0, 0, 0, 0, 0};
@@ -231,7 +231,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 hz[i] = gx; hb[i] = gx; xd[i] = (i >= 9 ? 2e-4 : 0.0) + dw;
                 if (i >= 9) lf += 1e-4 * x[i] * x[i];
                 if (k >= 1) {
-                    B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmn, lcmx, lsz);
                     xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; bar_mul(i < 6 ? ba : bb, x[i] - q_xlb(i, c.dist), q_xub(i, c.dist) - x[i]);
                 }
             }
@@ -318,7 +318,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             double hzu[QU], hbu[QU], hzw[QU], ud[QU], wn[QU];
 #pragma unroll
             for (int j = 0; j < QU; j++) {
-                B2 b = bound2(u[j], Q_ULO, Q_UHI, zLu[j], zUu[j], mu, 1, lc0, lcmu, lsz);
+                B2 b = bound2(u[j], Q_ULO, Q_UHI, zLu[j], zUu[j], mu, 1, lc0, lcmn, lcmx, lsz);
                 bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
                 double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
                 lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
@@ -356,23 +356,23 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             }
             lbar += bar_log(ba) + bar_log(bb) + bar_log(bu);
         }
-        sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmu;
+        sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmn; sh.red[12][lane] = lcmx;
         sh.red[4][lane] = lsz; sh.red[5][lane] = lsy; sh.red[6][lane] = lf; sh.red[7][lane] = lth;
         sh.red[8][lane] = lbar; sh.red[10][lane] = lgtb; sh.red[11][lane] = lgtz;
     }
     SYNC();
-    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmu = fmax(cmu, red_max(sh.red[3]));
+    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmn = fmin(cmn, red_min(sh.red[3])); cmx = fmax(cmx, red_max(sh.red[12]));
     sumz += red_sum(sh.red[4]); sumy += red_sum(sh.red[5]); f += red_sum(sh.red[6]); th1 += red_sum(sh.red[7]); bar += red_sum(sh.red[8]);
     double gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
     SYNC();
-    double d0 = 0, d1 = 0, d2 = 0;
-    B2 b = bound2(t, Q_TLO, Q_THI, z[l.zL + l.t], z[l.zU + l.t], mu, N + 1, d0, d1, d2);
-    c0 = fmax(c0, d0); cmu = fmax(cmu, d1); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
+    double d0 = 0, d2 = 0;
+    B2 b = bound2(t, Q_TLO, Q_THI, z[l.zL + l.t], z[l.zU + l.t], mu, N + 1, d0, cmn, cmx, d2);
+    c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
     const double gf = (N + 1) * (0.25 + 10 * t);
     gtb += gf + b.gb; gtz += gf + b.gz;
     f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     dinf = fmax(dinf, fabs(gtz));
-    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
+    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
     out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2 - (c.dist ? 1 : 0)) * QOB * (N + 1);
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
@@ -1291,15 +1291,14 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
         int mu_changed = 0;
         {
-            double cm = A.cinfmu;
+            double cm = cinf_mu(A, mu);
             for (;;) {
                 const double Emu = fmax(dinf / sd, fmax(pinf, cm / sc));
                 if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
                     mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
                     tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
                     dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu;
-                    qph_assemble(mu, 0.0, dc_val, 1);
-                    cm = sh.A2.cinfmu;
+                    cm = cinf_mu(A, mu);      // complementarity error w.r.t. the new mu, from the extreme products of the assembly at hand (no re-assembly)
                 } else break;
             }
         }

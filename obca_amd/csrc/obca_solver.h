@@ -37,6 +37,7 @@
 #define OBCA_NLT OB_NT
 #define UNIFORM(x) (x)
 #define OPAQUE(x) ((void)0)
+#define SEAM(x) ((void)0)
 #define OBCA_NL 64          // per-lane variables that live across a SYNC are arrays over the lanes in the emulation
 #define LI(lane) (lane)
 #else
@@ -61,6 +62,9 @@
 #define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define OBCA_NLT 1
 #define OPAQUE(x) asm volatile("" : "+v"(x))   // hide a loop-invariant register from LICM: what is derived from it is recomputed, not kept live
+// SEAM: a value formed by the fused line search enters the assembly as if it had been loaded from the iterate -- the compiler must not contract its producing
+// expression into the consumers, or a resumed solve (which assembles the stored point) would walk through different bits than an uninterrupted one
+#define SEAM(x) asm volatile("" : "+v"(x))
 #define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // value known to be wave-uniform: keep it in an SGPR (scalar branches, scalar loop counters)
 #define OBCA_NL 1
 #define LI(lane) 0
@@ -80,7 +84,7 @@ namespace obca {
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
 #define OB_NMAX 128  // longest horizon (the forward-sweep trajectory lives in LDS)
 #define OB_AS 88     // doubles per assembled stage record
-#define OB_RS 116    // doubles per Riccati stage record
+#define OB_RS 74     // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
 #define OB_HDR 168   // doubles of problem header (scalars + A + b) in front of rx, ry, ryaw
 // header indices
@@ -116,8 +120,7 @@ namespace obca {
 #define RS_KF 12
 #define RS_PX 24
 #define RS_PV 48
-#define RS_CL 72     // closed loop: Acl (6x6) then bcl (6)
-#define RS_PAD 115   // unused slot: target of the dummy stores of lanes without an item
+#define RS_PAD 72    // unused slot: target of the dummy stores of lanes without an item
 #define OB_FILT 224
 
 struct Opts {
@@ -142,37 +145,69 @@ OBCA_HD void make_layout(int N, int nOb, int M, Lay &l) {
     l.zso = o; o += nOb * N1; l.zssL = o; o += N; l.zssU = o; o += N; l.zs1 = o; o += nOb * N1; l.len = o;
 }
 
-struct AsmOut { int ok; double dinf, pinf, cinf0, cinfmu, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };
-struct StepOut { int ok; double ap, az, gd; };
+struct AsmOut { int ok; double dinf, pinf, cinf0, cmin, cmax, sumy, sumz, f, th1, bar, Htt, gtb; int nb, nm; };   // cmin, cmax: extreme complementarity products
+template <class P> OBCA_FN void asm_pack(P *o, const AsmOut &A) {
+    o[0] = A.ok; o[1] = A.dinf; o[2] = A.pinf; o[3] = A.cinf0; o[4] = A.cmin; o[5] = A.cmax; o[6] = A.sumy; o[7] = A.sumz; o[8] = A.f; o[9] = A.th1; o[10] = A.bar; o[11] = A.Htt; o[12] = A.gtb;
+    o[13] = A.nb; o[14] = A.nm;
+}
+template <class P> OBCA_FN void asm_unpack(AsmOut &A, const P *o) {
+    A.ok = (int)o[0]; A.dinf = o[1]; A.pinf = o[2]; A.cinf0 = o[3]; A.cmin = o[4]; A.cmax = o[5]; A.sumy = o[6]; A.sumz = o[7]; A.f = o[8]; A.th1 = o[9]; A.bar = o[10]; A.Htt = o[11]; A.gtb = o[12];
+    A.nb = (int)o[13]; A.nm = (int)o[14];
+}
+OBCA_HD double cinf_mu(const AsmOut &A, double mu) { return fmax(fabs(A.cmax - mu), fabs(A.cmin - mu)); }      // complementarity error w.r.t. the barrier parameter mu: max |s z - mu|
+struct StepOut { int ok; double ap, az, gd, gr; };   // gr: rate-cost part of d phi / d t (summed in the stage back-substitution, used with dt at the end)
 struct Consts; struct Lay;
 struct Inst {              // uniform: pointers of this instance
     const gdbl *prob;      // header + rx, ry, ryaw
-    gdbl *z, *d, *as, *rs, *oc, *traj;
+    gdbl *z, *zn, *d, *as, *rs, *oc, *traj;   // z: the current iterate; zn: the buffer the line search writes its trial point to (the two swap when a trial is accepted);
+                                              // d: stage part of the search direction (u, ss, pi, yg; the obstacle part is recomputed where it is needed, x lives in LDS)
     mutable long long tlast;           // diagnostic builds (-DOBCA_PROFILE): time stamp of the previous phase boundary
 };
 
+enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_HAVE, SL_ASM = 16, SL_FILT = 32, SL_SIZE = SL_FILT + 2 * OB_FILT };
+// SL_HAVE / SL_ASM: a solve parked right after an accepted trial keeps that trial's assembly -- the scalars here, the stage records in the instance's own buffers, which
+// outlive the launch -- so the resumed solve continues from exactly the state an uninterrupted one has at that point, without assembling again
+struct Slice {
+    gdbl *st;        // slice record of this instance (never null: the filter's overflow entries live there too)
+    int resume;      // 1: the next ipm_attempt continues from the record instead of starting at the warm start
+    int budget;      // factorisation passes (iterations + inertia retries) this launch may spend; 0 = no limit
+    int used;        // passes spent so far in this launch
+};
+struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
+struct Sol { gdbl *home; Slice sl; Result R; int att, it_prev, nreg_prev, ef, iters, nreg, retry; };      // state of solve_instance (wave-uniform, in LDS)
+struct Drv {                // state of the interior-point driver (wave-uniform; see ipm_attempt)
+    double mu, tau, dw, dw_last, dc_mu, dc_val, th_min, th_max, f, pinf, dinf, sd, sc, cm, th, phi, gd, az, pw_th, pw_gd, amin, alpha;
+    int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc;
+};
+#define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
+
 struct Shared {
     double hdr[OB_HDR];
-    double red[12][OB_NT];
-    double stg[2][200];        // double-buffered unpacked stage data (+ pad slot for lanes without an item) of the Riccati backward sweep (SG_* offsets)
     double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
     double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
     double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
-    double filt[OB_FILT][2];
+    double filt[OB_FILT_LDS][2];
+    Drv drv; Sol sol;
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
-    Inst inst; AsmOut A, A2, Ap; StepOut S; double trial[4]; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
-    double traj[(OB_NMAX + 2) * 6];   // closed-loop state trajectory of the forward sweep
-    // (the closed-loop maps of the stages, 42 doubles each, live in the Riccati records in HBM / L2 -- RS_CL -- and the composed stage-pair maps
-    //  in the instance's `traj` buffer: with them in LDS an instance needed 78 KB and only two fitted a CU; the forward sweep prefetches them)
+    Inst inst; AsmOut A, A2, An, Ap; StepOut S; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
 };
 
+// Dynamic LDS behind `Shared`, sized for the horizon at launch (OB_DYN_LDS_DOUBLES): the closed-loop state trajectory of the forward sweep (s_k = (dx_k, dw_k): the x part of the
+// search direction lives here and nowhere else), and behind it EITHER the double-buffered unpacked stage data of the Riccati backward sweep (2 x OB_STG doubles, SG_* offsets,
+// + a pad slot for lanes without an item) OR the composed closed-loop maps of the stage pairs of the forward sweep (the two sweeps never overlap in time).
+#define OB_STG 200
+#define OB_DYN_LDS_DOUBLES(N) ((size_t)((N) + 2) * 6 + ((size_t)((N) / 2 + 1) * 42 > 2 * OB_STG ? (size_t)((N) / 2 + 1) * 42 : (size_t)2 * OB_STG))
 #ifdef OBCA_EMU
 static Shared g_sh;
+static double g_traj[OB_DYN_LDS_DOUBLES(OB_NMAX)];
 #else
-__shared__ Shared g_sh;     // the one LDS block of the workgroup (= two wavefronts = one problem instance)
+__shared__ Shared g_sh;     // the static LDS block of the workgroup (= one wavefront = one problem instance)
+extern __shared__ double g_traj[];
 #endif
+
+OBCA_FN double *stg_base(const Shared &sh) { return g_traj + (size_t)(sh.c.N + 2) * 6; }     // stage buffers of the backward sweep / pair maps of the forward sweep
 
 // phase ids of the diagnostic cycle counters
 enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_SEQ, PF_BS_STAGE, PF_BS_OBS, PF_TRIAL, PF_APPLY, PF_OTHER, PF_RIC_P1, PF_RIC_P2, PF_N };
@@ -229,6 +264,35 @@ OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are ca
         return v;                                                                                                \
     }
 #endif
+// the same butterflies on per-lane REGISTER values (one-wavefront instances: nothing goes through LDS).  In the host emulation a per-lane value that lives
+// across the lanes' loop is an array over the lanes (OBCA_NL = 64), on the GPU it is one register (OBCA_NL = 1).
+#ifdef OBCA_EMU
+#define WRED_IMPL(NAME, COMB)                                                                                    \
+    OBCA_FN double NAME(const double (&r)[OBCA_NL]) {                                                            \
+        double a[64], b[64];                                                                                     \
+        for (int i = 0; i < 64; i++) a[i] = r[i];                                                                \
+        for (int o = 1; o < 64; o <<= 1) {                                                                       \
+            for (int i = 0; i < 64; i++) { double v = a[i], w = a[i ^ o]; b[i] = COMB; }                         \
+            for (int i = 0; i < 64; i++) a[i] = b[i];                                                            \
+        }                                                                                                        \
+        return a[0];                                                                                             \
+    }
+#else
+#define WRED_IMPL(NAME, COMB)                                                                                    \
+    OBCA_FN double NAME(const double (&r)[OBCA_NL]) {                                                            \
+        double v = r[0], w;                                                                                      \
+        w = dpp_f64<0xB1>(v); v = COMB;                                                                          \
+        w = dpp_f64<0x4E>(v); v = COMB;                                                                          \
+        w = dpp_f64<0x141>(v); v = COMB;                                                                         \
+        w = dpp_f64<0x140>(v); v = COMB;                                                                         \
+        w = __shfl_xor(v, 16, 64); v = COMB;                                                                     \
+        w = __shfl_xor(v, 32, 64); v = COMB;                                                                     \
+        return v;                                                                                                \
+    }
+#endif
+WRED_IMPL(wred_sum, (v + w))
+WRED_IMPL(wred_max, ((w > v || w != w) ? w : v))      // NaN-propagating max
+WRED_IMPL(wred_min, ((w < v) ? w : v))
 RED_IMPL(red_sum_t, (v + w))
 RED_IMPL(red_max_t, ((w > v || w != w) ? w : v))      // NaN-propagating max
 RED_IMPL(red_min_t, ((w < v) ? w : v))
@@ -255,14 +319,13 @@ OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int
 }
 
 struct B2 { double Sig, gz, gb; };
-OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmu, double &sumz) {
+OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmn, double &cmx, double &sumz) {
     const double dL = v - lo, dU = hi - v, iL = rcp_nr(dL), iU = rcp_nr(dU);
     B2 r; r.Sig = mult * (zL * iL + zU * iU); r.gz = mult * (-zL + zU); r.gb = mult * mu * (iU - iL);
     double c1 = dL * zL, c2 = dU * zU;
     c0 = fmax(c0, fabs(c1));
     c0 = fmax(c0, fabs(c2));
-    cmu = fmax(cmu, fabs(c1 - mu));
-    cmu = fmax(cmu, fabs(c2 - mu));
+    cmn = fmin(cmn, fmin(c1, c2)); cmx = fmax(cmx, fmax(c1, c2));
     sumz += fabs(zL) + fabs(zU);
     return r;
 }
@@ -291,21 +354,78 @@ OBCA_FN double bar_log(const BarAcc &a) { const double lg = log(a.p0 * a.p1); re
 OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; return a_ * 8 - a_ * (a_ - 1) / 2 + (b_ - a_); }
 
 
+// ---------------------------------------------------------------- accepting a step: new bound multipliers
+OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu * rcp_nr(dist), lo = q * rcp_nr(ks), hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
+// bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
+OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr(dist); return zz + az * (mu * id - zz - zz * id * dv); }
+
+
 // ---------------------------------------------------------------- assemble the condensed Newton system
+// The line search is fused into the assembly (FUSED = 1): the trial point z + alpha d is formed on the fly, written to the second iterate buffer
+// (Inst::zn) and assembled right there -- objective, constraint norm and barrier of the trial point ARE the f / th1 / bar of its assembly, and when the
+// trial is accepted (the first one, as a rule) the two buffers swap and the next iteration starts with its Newton system already assembled.  Against
+// separate trial / accept / assemble phases (round 2) the iterate is read once instead of three times per iteration and the obstacle part of the search
+// direction is never stored: a (stage, obstacle) block recomputes its step from the pose step (obs_block<1>, the same code direction_obs ran).
+// The obstacle part of the search direction (d lambda, d mu, d sl, d so, d y per (stage, obstacle) block) is needed twice: for the step lengths (direction_obs) and for
+// the trial point (fused assembly).  OBCA_STORE_DOBS = 1: direction_obs writes it to `d` and the fused assembly loads it with the block's iterate (one more operand in a
+// load batch that is issued anyway); 0: the fused assembly recomputes it (obs_block<1>: ~25 % of that phase's arithmetic, no traffic).  A/B in DESIGN.md section 5.
+#ifndef OBCA_STORE_DOBS
+#define OBCA_STORE_DOBS 1
+#endif
+struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal, equality multipliers, bound multipliers), kappa_sigma, delta_w of the factorisation that gave d
 // part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
-template <int VM>
-OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc) {
+template <int VM, int FUSED>
+OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
-    const gdbl *z = I.z;
-    const double t = z[l.t], q = t * c.Ts;
+    const gdbl *z = I.z; gdbl *zn = I.zn;
+    double red[11][OBCA_NL];                 // per-lane partial results, reduced over the wavefront in registers
     // ---- (a) obstacle blocks: one lane per (stage, obstacle)
     PAR(lane) {
-        ObsStats st; st.dmax = st.pmax = st.cmax0 = st.cmaxmu = st.sumz = st.sumy = 0; st.bad = 0;
+        ObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0;
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
+            if (FUSED) {
+                const double dp[3] = {g_traj[(size_t)k * 6], g_traj[(size_t)k * 6 + 1], g_traj[(size_t)k * 6 + 2]};      // pose step of the stage (x_0 is fixed: s_0 = 0)
+                ObsStep<VM> sp;
+                const int r0 = sh.roff[j];
+                if (OBCA_STORE_DOBS) {
+                    const gdbl *d = I.d;
+#pragma unroll
+                    for (int i = 0; i < VM; i++) sp.dlam[i] = i < in.v ? d[l.lam + k * M + r0 + i] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { sp.dmu[i] = d[l.mu + 4 * it + i]; sp.dy[i] = d[l.yo + 4 * it + i]; }
+                    sp.dsl = d[l.sl + it]; sp.dso = d[l.so + it];
+                } else obs_block<1, VM>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp);
+#pragma unroll
+                for (int i = 0; i < VM; i++) if (i < in.v) {
+                    const double v1 = fma(fa.alpha, sp.dlam[i], in.lam[i]), z1 = zstep(in.zl[i], in.lam[i], sp.dlam[i], mu, fa.az);
+                    in.lam[i] = v1; in.zl[i] = clampz(z1, v1, mu, fa.ks);
+                    zn[l.lam + k * M + r0 + i] = in.lam[i]; zn[l.zlam + k * M + r0 + i] = in.zl[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double v1 = fma(fa.alpha, sp.dmu[i], in.mu[i]), z1 = zstep(in.zm[i], in.mu[i], sp.dmu[i], mu, fa.az);
+                    in.mu[i] = v1; in.zm[i] = clampz(z1, v1, mu, fa.ks); in.y[i] = fma(fa.ay, sp.dy[i], in.y[i]);
+                    zn[l.mu + 4 * it + i] = in.mu[i]; zn[l.zmu + 4 * it + i] = in.zm[i]; zn[l.yo + 4 * it + i] = in.y[i];
+                }
+                {
+                    const double v1 = fma(fa.alpha, sp.dso, in.so), z1 = zstep(in.zso, in.so, sp.dso, mu, fa.az);
+                    in.so = v1; in.zso = clampz(z1, v1, mu, fa.ks);
+                    const double s1 = fma(fa.alpha, sp.dsl, in.sl);
+                    if (c.dist) in.zs1 = clampz(zstep(in.zs1, in.sl, sp.dsl, mu, fa.az), s1, mu, fa.ks);
+                    in.sl = s1;
+                    zn[l.so + it] = in.so; zn[l.zso + it] = in.zso; zn[l.sl + it] = in.sl; zn[l.zs1 + it] = in.zs1;
+                }
+                in.X = fma(fa.alpha, dp[0], in.X); in.Y = fma(fa.alpha, dp[1], in.Y); in.psi = fma(fa.alpha, dp[2], in.psi);      // (explicit fma: the stage part forms the same values from the same operands, bit for bit)
+#pragma unroll
+                for (int i = 0; i < VM; i++) { SEAM(in.lam[i]); SEAM(in.zl[i]); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { SEAM(in.mu[i]); SEAM(in.zm[i]); SEAM(in.y[i]); }
+                SEAM(in.so); SEAM(in.zso); SEAM(in.sl); SEAM(in.zs1); SEAM(in.X); SEAM(in.Y); SEAM(in.psi);
+            }
             ObsCond cd;
             obs_block<0, VM>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
             gdbl *o = I.oc + (size_t)it * OB_OC;
@@ -326,33 +446,48 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
                 bar += log_prod(dd);
             }
         }
-        sh.red[0][lane] = st.dmax; sh.red[1][lane] = st.pmax; sh.red[2][lane] = st.cmax0; sh.red[3][lane] = st.cmaxmu;
-        sh.red[4][lane] = st.sumz; sh.red[5][lane] = st.sumy; sh.red[6][lane] = fsl; sh.red[7][lane] = th;
-        sh.red[8][lane] = bar; sh.red[9][lane] = st.bad ? 1.0 : 0.0;
+        red[0][LI(lane)] = st.dmax; red[1][LI(lane)] = st.pmax; red[2][LI(lane)] = st.cmax0; red[3][LI(lane)] = st.cmin; red[10][LI(lane)] = st.cmax;
+        red[4][LI(lane)] = st.sumz; red[5][LI(lane)] = st.sumy; red[6][LI(lane)] = fsl; red[7][LI(lane)] = th;
+        red[8][LI(lane)] = bar; red[9][LI(lane)] = st.bad ? 1.0 : 0.0;
     }
-    SYNC();
     AsmOut &P = sh.Ap;
-    P.dinf = red_max(sh.red[0]); P.pinf = red_max(sh.red[1]); P.cinf0 = red_max(sh.red[2]); P.cinfmu = red_max(sh.red[3]);
-    P.sumz = red_sum(sh.red[4]); P.sumy = red_sum(sh.red[5]); P.f = red_sum(sh.red[6]); P.th1 = red_sum(sh.red[7]);
-    P.bar = red_sum(sh.red[8]);
-    P.ok = !(red_max(sh.red[9]) > 0.5);
+    P.dinf = wred_max(red[0]); P.pinf = wred_max(red[1]); P.cinf0 = wred_max(red[2]); P.cmin = wred_min(red[3]); P.cmax = wred_max(red[10]);
+    P.sumz = wred_sum(red[4]); P.sumy = wred_sum(red[5]); P.f = wred_sum(red[6]); P.th1 = wred_sum(red[7]);
+    P.bar = wred_sum(red[8]);
+    P.ok = !(wred_max(red[9]) > 0.5);
     SYNC();
-    PROF(I, PF_ASM_OBS);
+    PROF(I, FUSED ? PF_TRIAL : PF_ASM_OBS);      // (diagnostic counters: the fused line-search step is booked under the former trial / apply slots)
 }
 
 // part (b): one lane per stage; combines with the partial results of part (a)
-OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, AsmOut &out) {
+template <int FUSED>
+OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa, AsmOut &out) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
-    const gdbl *z = I.z;
-    const double t = z[l.t], q = t * c.Ts;
+    const gdbl *z = I.z, *d = I.d; gdbl *zn = I.zn;
+    // time scale: uniform.  FUSED: the trial value and its bound multipliers, stored by lane 0 below
+    double t = z[l.t], ztL = z[l.ztL], ztU = z[l.ztU];
+    if (FUSED && !c.fixTime) {
+        const double dt = sh.coef[0], dL = t - OB_TL, dU = OB_TU - t;
+        const double zL = zstep(ztL, dL, dt, mu, fa.az), zU = zstep(ztU, dU, -dt, mu, fa.az);
+        t = fma(fa.alpha, dt, t);
+        ztL = clampz(zL, t - OB_TL, mu, fa.ks); ztU = clampz(zU, OB_TU - t, mu, fa.ks);
+        SEAM(t); SEAM(ztL); SEAM(ztU);
+    }
+    const double q = t * c.Ts;
     const double iq = 1.0 / q, it_ = 1.0 / t;          // uniform: one division each, the stage code multiplies
-    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmu = sh.Ap.cinfmu, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
+    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
+    double red[13][OBCA_NL];
     // ---- (b) stages: one lane per stage
     PAR(lane) {
-        double dmax = 0, pmax = 0, lc0 = 0, lcmu = 0, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
+        double dmax = 0, pmax = 0, lc0 = 0, lcmn = 1e300, lcmx = -1e300, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
+        if (FUSED && lane == 0) {
+            zn[l.t] = t; zn[l.ztL] = ztL; zn[l.ztU] = ztU;
+#pragma unroll
+            for (int i = 0; i < 4; i++) zn[l.nu + i] = fma(fa.ay, sh.coef[1 + i], z[l.nu + i]);
+        }
         for (int k = lane; k <= N; k += OB_NT) {
             BarAcc ba; bar_init(ba);                  // barrier distances of the stage: x (3 pairs), u (2), steering rate (1)
             double Hp[36], hz[8], hb[8], Ht[8];     // Hp: packed upper triangle of the symmetric 8x8 stage Hessian (HH(i,j), i<=j)
@@ -364,17 +499,70 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
             // every global load of this stage is issued here, before the first store to the stage record: the record may alias the
             // iterate as far as the compiler knows, so a load placed after a store would cost its own memory round trip
             const int kc = k < N ? k : N - 1, km = k >= 1 ? k - 1 : 0, kn = k + 1 < N ? k + 1 : kc;
-            double x[4], xn[4], pi[4], pim[4], nu4[4];
+            double x[4], xn[4], pi[4], pim[4], nu4[4], zxL[4], zxU[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 x[i] = z[l.x + 4 * k + i]; xn[i] = z[l.x + 4 * (kc + 1) + i]; pi[i] = z[l.pi + 4 * kc + i]; pim[i] = z[l.pi + 4 * km + i];
-                nu4[i] = z[l.nu + i];
+                nu4[i] = z[l.nu + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i];
             }
-            const double u[2] = {z[l.u + 2 * kc], z[l.u + 2 * kc + 1]}, um[2] = {z[l.u + 2 * km], z[l.u + 2 * km + 1]};
-            const double un[2] = {z[l.u + 2 * kn], z[l.u + 2 * kn + 1]}, ygn = z[l.yg + kn];
-            const double zuL[2] = {z[l.zuL + 2 * kc], z[l.zuL + 2 * kc + 1]}, zuU[2] = {z[l.zuU + 2 * kc], z[l.zuU + 2 * kc + 1]};
-            const double ss = z[l.ss + kc], yg = z[l.yg + kc], zssL = z[l.zssL + kc], zssU = z[l.zssU + kc];
+            double u[2] = {z[l.u + 2 * kc], z[l.u + 2 * kc + 1]}, um[2] = {z[l.u + 2 * km], z[l.u + 2 * km + 1]};
+            double un[2] = {z[l.u + 2 * kn], z[l.u + 2 * kn + 1]}, ygn = z[l.yg + kn];
+            double zuL[2] = {z[l.zuL + 2 * kc], z[l.zuL + 2 * kc + 1]}, zuU[2] = {z[l.zuU + 2 * kc], z[l.zuU + 2 * kc + 1]};
+            double ss = z[l.ss + kc], yg = z[l.yg + kc], zssL = z[l.zssL + kc], zssU = z[l.zssU + kc];
+            double oH[6] = {0, 0, 0, 0, 0, 0}, og[3] = {0, 0, 0}, ogc[3] = {0, 0, 0};     // condensed obstacle contributions of this stage (written by part (a))
+            for (int j = 0; j < nOb; j++) {
+                const gdbl *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
+#pragma unroll
+                for (int i = 0; i < 6; i++) oH[i] += o[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { og[i] += o[6 + i]; ogc[i] += o[9 + i]; }
+            }
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            if (FUSED) {
+                // the trial point of this stage and what the assembly needs of its neighbours: x_{k+1}, u_{k-1}, u_{k+1}, pi_{k-1}, yg_{k+1}  (steps: x in LDS, the rest in d)
+                double dpi[4], dpim[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { dpi[i] = d[l.pi + 4 * kc + i]; dpim[i] = d[l.pi + 4 * km + i]; }
+                const double du[2] = {d[l.u + 2 * kc], d[l.u + 2 * kc + 1]}, dum[2] = {d[l.u + 2 * km], d[l.u + 2 * km + 1]}, dun[2] = {d[l.u + 2 * kn], d[l.u + 2 * kn + 1]};
+                const double dygn = d[l.yg + kn], dyg = d[l.yg + kc], dss = d[l.ss + kc];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double dx = g_traj[(size_t)k * 6 + i], dxn = g_traj[(size_t)(kc + 1) * 6 + i];
+                    const double v = fma(fa.alpha, dx, x[i]);      // explicit fma wherever a trial value is formed: neighbouring stages (and the obstacle blocks) form the same value again
+                                                                  // and a parked solve reads the stored one -- all of them must be the same bits
+                    if (i != 2 && k >= 1) {
+                        const double zL = zstep(zxL[i], x[i] - c.xl[i], dx, mu, fa.az), zU = zstep(zxU[i], c.xu[i] - x[i], -dx, mu, fa.az);
+                        zxL[i] = clampz(zL, v - c.xl[i], mu, fa.ks); zxU[i] = clampz(zU, c.xu[i] - v, mu, fa.ks);
+                    }
+                    x[i] = v; xn[i] = fma(fa.alpha, dxn, xn[i]);
+                    pi[i] = fma(fa.ay, dpi[i], pi[i]); pim[i] = fma(fa.ay, dpim[i], pim[i]); nu4[i] = fma(fa.ay, sh.coef[1 + i], nu4[i]);
+                    zn[l.x + 4 * k + i] = x[i]; zn[l.zxL + 4 * k + i] = zxL[i]; zn[l.zxU + 4 * k + i] = zxU[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
+                    const double zL = zstep(zuL[i], u[i] - lo, du[i], mu, fa.az), zU = zstep(zuU[i], hi - u[i], -du[i], mu, fa.az), v = fma(fa.alpha, du[i], u[i]);
+                    u[i] = v; zuL[i] = clampz(zL, v - lo, mu, fa.ks); zuU[i] = clampz(zU, hi - v, mu, fa.ks);
+                    um[i] = fma(fa.alpha, dum[i], um[i]); un[i] = fma(fa.alpha, dun[i], un[i]);
+                }
+                {
+                    const double zL = zstep(zssL, ss + OB_SSB, dss, mu, fa.az), zU = zstep(zssU, OB_SSB - ss, -dss, mu, fa.az), v = fma(fa.alpha, dss, ss);
+                    ss = v; zssL = clampz(zL, v + OB_SSB, mu, fa.ks); zssU = clampz(zU, OB_SSB - v, mu, fa.ks);
+                }
+                yg = fma(fa.ay, dyg, yg); ygn = fma(fa.ay, dygn, ygn);
+                if (k < N) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { zn[l.u + 2 * k + i] = u[i]; zn[l.zuL + 2 * k + i] = zuL[i]; zn[l.zuU + 2 * k + i] = zuU[i]; }
+                    zn[l.ss + k] = ss; zn[l.zssL + k] = zssL; zn[l.zssU + k] = zssU; zn[l.yg + k] = yg;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) zn[l.pi + 4 * k + i] = pi[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { SEAM(x[i]); SEAM(xn[i]); SEAM(pi[i]); SEAM(pim[i]); SEAM(nu4[i]); SEAM(zxL[i]); SEAM(zxU[i]); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { SEAM(u[i]); SEAM(um[i]); SEAM(un[i]); SEAM(zuL[i]); SEAM(zuU[i]); }
+                SEAM(ss); SEAM(yg); SEAM(ygn); SEAM(zssL); SEAM(zssU);
+            }
             const double gx[4] = {2e-3 * (x[0] - rx), 2e-3 * (x[1] - ry), 2 * c.wpsi * (x[2] - ryaw), 2e-4 * x[3]};
             const double hx[4] = {2e-3, 2e-3, 2 * c.wpsi, 2e-4};
             lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
@@ -383,18 +571,15 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 hz[i] = gx[i]; hb[i] = gx[i];
                 double Sig = 0;
                 if (i != 2 && k >= 1) {
-                    B2 b = bound2(x[i], c.xl[i], c.xu[i], z[l.zxL + 4 * k + i], z[l.zxU + 4 * k + i], mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(x[i], c.xl[i], c.xu[i], zxL[i], zxU[i], mu, 1, lc0, lcmn, lcmx, lsz);
                     Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb;
                     bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
                 }
                 HH(i, i) = hx[i] + Sig + dw;
             }
-            for (int j = 0; j < nOb; j++) {   // condensed obstacle contributions of this stage
-                const gdbl *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
-                HH(0, 0) += o[0]; HH(0, 1) += o[1]; HH(0, 2) += o[2]; HH(1, 1) += o[3]; HH(1, 2) += o[4]; HH(2, 2) += o[5];
+            HH(0, 0) += oH[0]; HH(0, 1) += oH[1]; HH(0, 2) += oH[2]; HH(1, 1) += oH[3]; HH(1, 2) += oH[4]; HH(2, 2) += oH[5];
 #pragma unroll
-                for (int i = 0; i < 3; i++) { hz[i] += o[6 + i]; hb[i] += o[6 + i] - o[9 + i]; }
-            }
+            for (int i = 0; i < 3; i++) { hz[i] += og[i]; hb[i] += og[i] - ogc[i]; }
             gdbl *rec = I.as + (size_t)k * OB_AS;
             if (k == N) {
 #pragma unroll
@@ -415,7 +600,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double ei = i ? e2 : e1, lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     const double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
                     hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
-                    B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmn, lcmx, lsz);
                     hz[6 + i] += b.gz; hb[6 + i] += b.gb;
                     bar_mul(ba, u[i] - lo, hi - u[i]);
                     HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
@@ -426,7 +611,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
                     const double g = (w[0] - u[0]) * iq;
                     const double gg[3] = {iq, -iq, c.fixTime ? 0.0 : -g * it_};
-                    B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmu, lsz);
+                    B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmn, lcmx, lsz);
                     bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
@@ -505,22 +690,21 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
             for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; rec[AS_HT + i] = Ht[i]; }
         }
-        sh.red[0][lane] = dmax; sh.red[1][lane] = pmax; sh.red[2][lane] = lc0; sh.red[3][lane] = lcmu;
-        sh.red[4][lane] = lsz; sh.red[5][lane] = lsy; sh.red[6][lane] = lf; sh.red[7][lane] = lth;
-        sh.red[8][lane] = lbar; sh.red[9][lane] = lHtt; sh.red[10][lane] = lgtb; sh.red[11][lane] = lgtz;
+        red[0][LI(lane)] = dmax; red[1][LI(lane)] = pmax; red[2][LI(lane)] = lc0; red[3][LI(lane)] = lcmn; red[12][LI(lane)] = lcmx;
+        red[4][LI(lane)] = lsz; red[5][LI(lane)] = lsy; red[6][LI(lane)] = lf; red[7][LI(lane)] = lth;
+        red[8][LI(lane)] = lbar; red[9][LI(lane)] = lHtt; red[10][LI(lane)] = lgtb; red[11][LI(lane)] = lgtz;
     }
-    SYNC();
-    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmu = fmax(cmu, red_max(sh.red[3]));
-    sumz += red_sum(sh.red[4]); sumy += red_sum(sh.red[5]); f += red_sum(sh.red[6]); th1 += red_sum(sh.red[7]);
-    bar += red_sum(sh.red[8]);
-    double Htt = red_sum(sh.red[9]), gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
+    dinf = fmax(dinf, wred_max(red[0])); pinf = fmax(pinf, wred_max(red[1])); c0 = fmax(c0, wred_max(red[2])); cmn = fmin(cmn, wred_min(red[3])); cmx = fmax(cmx, wred_max(red[12]));
+    sumz += wred_sum(red[4]); sumy += wred_sum(red[5]); f += wred_sum(red[6]); th1 += wred_sum(red[7]);
+    bar += wred_sum(red[8]);
+    double Htt = wred_sum(red[9]), gtb = wred_sum(red[10]), gtz = wred_sum(red[11]);
     SYNC();
     int nb = 6 * N + 4 * N + 2 * N + (M + (c.dist ? 6 : 5) * nOb) * (N + 1);
     int nm = 4 * N + 4 + N + 4 * nOb * (N + 1);
     if (!c.fixTime) {
-        double d0 = 0, d1 = 0, d2 = 0;
-        B2 b = bound2(t, OB_TL, OB_TU, z[l.ztL], z[l.ztU], mu, N + 1, d0, d1, d2);
-        c0 = fmax(c0, d0); cmu = fmax(cmu, d1); sumz += (N + 1) * (fabs(z[l.ztL]) + fabs(z[l.ztU]));
+        double d0 = 0, d2 = 0;
+        B2 b = bound2(t, OB_TL, OB_TU, ztL, ztU, mu, N + 1, d0, cmn, cmx, d2);
+        c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(ztL) + fabs(ztU));
         nb += 2 * (N + 1);
         double gf = (N + 1) * (0.5 + 2 * t);
         Htt += 2.0 * (N + 1) + b.Sig + dw;
@@ -529,9 +713,9 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
         bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));
         dinf = fmax(dinf, fabs(gtz));
     } else { Htt = 1.0; gtb = 0; }
-    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cinfmu = cmu; out.sumy = sumy; out.sumz = sumz;
+    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = Htt; out.gtb = gtb; out.nb = nb; out.nm = nm;
-    PROF(I, PF_ASM_STAGE);
+    PROF(I, FUSED ? PF_APPLY : PF_ASM_STAGE);
 }
 
 // ---------------------------------------------------------------- Riccati backward sweep
@@ -583,10 +767,10 @@ OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
 #pragma unroll
     for (int r = 0; r < 2; r++) { double fl; stage_unpack_item(stage_var_position(lane + OB_NT * r), p.idx[r], p.dst[r], fl, p.kc[r]); }
 }
-OBCA_FN void stage_unpack_constants(Shared &sh, int lane) {     // once per sweep, both buffers (+ the pad slot)
+OBCA_FN void stage_unpack_constants(double *sg, int lane) {     // once per sweep, both buffers (+ the pad slot)
     for (int it = lane; it <= SG_SIZE; it += OB_NT) {
         int idx, dst; double fl, kc; stage_unpack_item(it, idx, dst, fl, kc);
-        if (fl == 0.0) { sh.stg[0][dst] = kc; sh.stg[1][dst] = kc; }
+        if (fl == 0.0) { sg[dst] = kc; sg[OB_STG + dst] = kc; }
     }
 }
 OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[2]) {   // independent, branch-free gathers;
@@ -625,7 +809,7 @@ struct RicPlan { RicItem it[RIC_IPL]; };
 OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {     // `lane` = item number 0..127
     const double *L = (const double *)&sh;
     const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.cl[0] - L),
-              oSG = (int)(sh.stg[0] - L), oZ = (int)(&sh.zero - L), oD = (int)(&sh.dump - L);
+              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oD = (int)(&sh.dump - L);
     // A: T[a][cc] = [cc >= 8] p[a][cc-8] + sum_b P[a][b] FA[b][cc]   (items 0..83);  u2[m][b] = sum_i FA[i][8+m] p[i][b]   (items 84..95; rows 4, 5 of the off columns are 0)
     p.a_a = oZ; p.a_as = 0; p.a_b = oZ; p.a_bs = 0; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
     if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_as = 1; p.a_b = oSG + SG_FA + cc; p.a_bs = 14; p.a_sg = 2;
@@ -658,9 +842,9 @@ OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
 }
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicPlan (&rp)[OBCA_NLT],
-                          double (&nv)[OBCA_NLT][RIC_D][2], const int slot) {
+                          double (&nv)[OBCA_NLT][RIC_D][2], const int slot, double *sg0) {
     double *L = (double *)&sh;
-    const int sgo = (k & 1) * (int)(sh.stg[1] - sh.stg[0]);         // which of the two stage buffers holds stage k
+    const int sgo = (k & 1) * OB_STG;         // which of the two stage buffers holds stage k
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
     // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
@@ -707,7 +891,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         }
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
-            stage_unpack_store(sh.stg[kp & 1], plan[LI(lane)], nv[LI(lane)][slot]);
+            stage_unpack_store(sg0 + (kp & 1) * OB_STG, plan[LI(lane)], nv[LI(lane)][slot]);
             stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
 #pragma unroll
@@ -726,10 +910,11 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
     double nv[OBCA_NLT][RIC_D][2];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
+    double *sg0 = stg_base(sh);      // the two stage buffers (dynamic LDS)
     UnpackPlan plan[OBCA_NLT]; RicPlan rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
         stage_unpack_plan(lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
-        stage_unpack_constants(sh, lane);
+        stage_unpack_constants(sg0, lane);
         if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
@@ -749,14 +934,14 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
-        PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sh.stg[k & 1], plan[LI(lane)], v); }
+        PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
         LDS_BARRIER();
-        if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0)) { PROF(I, PF_RIC_BWD); return 0; }
+        if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0)) { PROF(I, PF_RIC_BWD); return 0; }
     }
     if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
     PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
         double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
-        stage_unpack_store(sh.stg[k & 1], plan[LI(lane)], v);
+        stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v);
 #pragma unroll
         for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
 #ifndef OBCA_EMU
@@ -768,7 +953,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     int ok = 1;
     for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D);
+        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0);
     }
     PROF(I, PF_RIC_BWD);
     return ok;
@@ -840,173 +1025,129 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     so.ok = ok;
     if (!ok) return;
     const double coef[OB_NC] = {1.0, dt, nu[0], nu[1], nu[2], nu[3]};
-    // ---- closed-loop maps per stage (parallel over stages): Acl = [A+BK ; K] (6x6), bcl = [B kf + off ; kf]; written into the Riccati record (RS_CL)
+    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k with the closed-loop maps Acl = [A + B K ; K] (6x6), bcl = [B kf + off ; kf].  The recursion is a chain of N
+    // dependent steps (~280 clocks each: a 4-deep fp64 dependency plus the broadcast), so it runs TWO stages per step.  One lane per stage pair j builds the maps
+    // of stages 2j and 2j+1 from the Riccati gains and the stage records, composes them (Pm_j = Acl_{2j+1} Acl_{2j}, pb_j = Acl_{2j+1} bcl_{2j} + bcl_{2j+1}) into
+    // LDS and KEEPS the plain map of stage 2j in registers; the sequential loop then produces the even states s_{2j+2} from the composed maps (rows read from LDS
+    // one step ahead, the state itself in scalar registers via v_readlane), and afterwards every pair lane fills in its odd state s_{2j+1} = Acl_{2j} s_{2j} + bcl_{2j}.
+    // (Round 2 wrote the 42-double closed-loop map of every stage to the Riccati record and the composed maps to a second HBM buffer, and the sequential loop
+    // gathered both back through a ring of registers: 0.1 MB of traffic per pass and a loop whose step time followed the memory latency under load.)
+    const int NP = UNIFORM(N / 2), NH = UNIFORM((N + 1) / 2);     // pairs; pair lanes incl. the single last stage of an odd horizon
+    double *pm = stg_base(sh);                                    // composed maps: NP x 42 doubles behind the trajectory (the backward sweep's stage buffers are dead by now)
+    double M0[OBCA_NL][42];
     PAR(lane) {
-        // a lane takes stages k and k + OB_NT (N <= 2 OB_NT) together: both stages' loads before the first store, one memory round trip instead of two
-        for (int k0 = lane; k0 < N; k0 += 2 * OB_NT) {
-            double K0[2][6], K1[2][6], kf0[2] = {0, 0}, kf1[2] = {0, 0}, b0[2][4], b1[2][4], a2[2][4], a3[2][4], dd[2][4], ft[2][4];
+        const int L_ = LI(lane);
+        if (lane < NH) {
+            double M1[42];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int k = k0 + h * OB_NT < N ? k0 + h * OB_NT : k0;      // (clamped: the second half may not exist)
+                const int k = 2 * lane + h < N ? 2 * lane + h : 2 * lane;      // (clamped: the second stage of the last lane may not exist)
                 const gdbl *rec = I.as + (size_t)k * OB_AS, *ro = I.rs + (size_t)k * OB_RS;
+                double K0[6], K1[6], kf0 = 0, kf1 = 0, b0[4], b1[4], a2[4], a3[4], dd[4], ft[4];
 #pragma unroll
-                for (int j = 0; j < 6; j++) { K0[h][j] = ro[RS_K + j]; K1[h][j] = ro[RS_K + 6 + j]; }
+                for (int j = 0; j < 6; j++) { K0[j] = ro[RS_K + j]; K1[j] = ro[RS_K + 6 + j]; }
 #pragma unroll
-                for (int cc = 0; cc < OB_NC; cc++) { kf0[h] += ro[RS_KF + cc] * coef[cc]; kf1[h] += ro[RS_KF + OB_NC + cc] * coef[cc]; }
+                for (int cc = 0; cc < OB_NC; cc++) { kf0 += ro[RS_KF + cc] * coef[cc]; kf1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
 #pragma unroll
-                for (int i = 0; i < 4; i++) { b0[h][i] = rec[AS_DF + 5 * i + 2]; b1[h][i] = rec[AS_DF + 5 * i + 3]; a2[h][i] = rec[AS_DF + 5 * i + 0]; a3[h][i] = rec[AS_DF + 5 * i + 1];
-                                              dd[h][i] = rec[AS_DD + i]; ft[h][i] = rec[AS_DF + 5 * i + 4]; }
-            }
+                for (int i = 0; i < 4; i++) { b0[i] = rec[AS_DF + 5 * i + 2]; b1[i] = rec[AS_DF + 5 * i + 3]; a2[i] = rec[AS_DF + 5 * i + 0]; a3[i] = rec[AS_DF + 5 * i + 1];
+                                              dd[i] = rec[AS_DD + i]; ft[i] = rec[AS_DF + 5 * i + 4]; }
+                double *cm = h ? M1 : M0[L_];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int k = k0 + h * OB_NT;
-                if (k < N) {
-                    gdbl *cm = I.rs + (size_t)k * OB_RS + RS_CL;
+                for (int i = 0; i < 4; i++) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-#pragma unroll
-                        for (int j = 0; j < 6; j++) {
-                            double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
-                            if (j == 2) a_ += a2[h][i];
-                            if (j == 3) a_ += a3[h][i];
-                            cm[i * 6 + j] = a_ + b0[h][i] * K0[h][j] + b1[h][i] * K1[h][j];
-                        }
-                        cm[36 + i] = dd[h][i] + dt * ft[h][i] + b0[h][i] * kf0[h] + b1[h][i] * kf1[h];
+                    for (int j = 0; j < 6; j++) {
+                        double a_ = (j < 4 && i == j) ? 1.0 : 0.0;
+                        if (j == 2) a_ += a2[i];
+                        if (j == 3) a_ += a3[i];
+                        cm[i * 6 + j] = a_ + b0[i] * K0[j] + b1[i] * K1[j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 6; j++) { cm[24 + j] = K0[h][j]; cm[30 + j] = K1[h][j]; }
-                    cm[40] = kf0[h]; cm[41] = kf1[h];
+                    cm[36 + i] = dd[i] + dt * ft[i] + b0[i] * kf0 + b1[i] * kf1;
                 }
+#pragma unroll
+                for (int j = 0; j < 6; j++) { cm[24 + j] = K0[j]; cm[30 + j] = K1[j]; }
+                cm[40] = kf0; cm[41] = kf1;
             }
-        }
-        if (lane < 8) { sh.s[0][lane] = 0; sh.s[1][lane] = 0; }
-    }
-    SYNC();
-    PROF(I, PF_BORDER_CL);
-    // ---- forward recursion s_{k+1} = Acl_k s_k + bcl_k.  The recursion is a chain of N dependent steps (~280 clocks each: a 4-deep fp64
-    // dependency plus the broadcast), so it is run TWO stages per step: the maps of stages 2j and 2j+1 are composed first (stage-parallel:
-    // Pm_j = Acl_{2j+1} Acl_{2j}, pb_j = Acl_{2j+1} bcl_{2j} + bcl_{2j+1}, into the instance's `traj` buffer in HBM / L2), then every
-    // sequential step produces s_{2j+2} (lanes 0..5, composed map) and s_{2j+1} (lanes 6..11, plain map) from s_{2j}.  A last odd stage is
-    // stepped on its own.  The maps are read from memory FW_D steps ahead into a rotating register set (7 doubles per lane and step), the
-    // state itself never leaves the wavefront's scalar registers; the trajectory goes to LDS for the stage-parallel phases that follow.
-#ifndef FW_D
-#define FW_D 4
-#endif
-    const int NP = UNIFORM(N / 2);
-    gdbl *pairbuf = I.traj;                                   // NP * 42 doubles
-    PAR(lane) {
-        // two (pair, row) items per lane and round, both items' loads before the first store (NP * 6 = 240 items at N = 80: two rounds instead of four)
-        for (int it0 = lane; it0 < NP * 6; it0 += 2 * OB_NT) {
-            double m1r[2][6], m0[2][42], b1r[2];
+            if (lane < NP) {
+                double *po = pm + (size_t)lane * 42; const double *m0 = M0[L_];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int it = it0 + h * OB_NT < NP * 6 ? it0 + h * OB_NT : it0, j = it / 6, r = it % 6;
-                const gdbl *M0 = I.rs + (size_t)(2 * j) * OB_RS + RS_CL, *M1 = I.rs + (size_t)(2 * j + 1) * OB_RS + RS_CL, *m1 = M1 + r * 6;
-                b1r[h] = M1[36 + r];
-#pragma unroll
-                for (int q = 0; q < 6; q++) m1r[h][q] = m1[q];
-#pragma unroll
-                for (int q = 0; q < 42; q++) m0[h][q] = M0[q];
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int it = it0 + h * OB_NT;
-                if (it < NP * 6) {
-                    const int j = it / 6, r = it % 6; gdbl *pm = pairbuf + (size_t)j * 42;
+                for (int r = 0; r < 6; r++) {
+                    const double *m1r = M1 + r * 6;
 #pragma unroll
                     for (int cI = 0; cI < 6; cI++)
-                        pm[r * 6 + cI] = dot6_tree(0.0, m1r[h][0], m0[h][cI], m1r[h][1], m0[h][6 + cI], m1r[h][2], m0[h][12 + cI], m1r[h][3], m0[h][18 + cI], m1r[h][4], m0[h][24 + cI], m1r[h][5], m0[h][30 + cI]);
-                    pm[36 + r] = dot6_tree(b1r[h], m1r[h][0], m0[h][36], m1r[h][1], m0[h][37], m1r[h][2], m0[h][38], m1r[h][3], m0[h][39], m1r[h][4], m0[h][40], m1r[h][5], m0[h][41]);
+                        po[r * 6 + cI] = dot6_tree(0.0, m1r[0], m0[cI], m1r[1], m0[6 + cI], m1r[2], m0[12 + cI], m1r[3], m0[18 + cI], m1r[4], m0[24 + cI], m1r[5], m0[30 + cI]);
+                    po[36 + r] = dot6_tree(M1[36 + r], m1r[0], m0[36], m1r[1], m0[37], m1r[2], m0[38], m1r[3], m0[39], m1r[4], m0[40], m1r[5], m0[41]);
                 }
             }
         }
+        if (lane < 6) g_traj[lane] = 0.0;                         // s_0 = 0 (x_0 is fixed)
     }
-    SYNC();
+    LDS_SYNC();
+    PROF(I, PF_BORDER_CL);
     WAVE0_BEGIN
-        // The six values of lanes 0..5 are broadcast with v_readlane into scalar registers and enter the next step's products as scalar operands (the host
-        // emulation runs the same statements with the per-lane variables as arrays over the lanes: one implementation, bit-identical results).
         {
-            const int Nn = UNIFORM(N), NPc = NP > 0 ? NP - 1 : 0;
-            double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_k, wave-uniform (scalar registers); s_0 = 0
-            double ring[OBCA_NL][FW_D][7], v[OBCA_NL];
-            // per-lane base and stride (in doubles) of the map rows: composed maps are 42 apart, plain maps of the even stages 2 * OB_RS apart; bias = row base + bo
-            const gdbl *mb[OBCA_NL]; size_t ms[OBCA_NL]; int bo[OBCA_NL], rr[OBCA_NL];
+            double fw_s[6] = {0, 0, 0, 0, 0, 0};               // s_2j, wave-uniform (scalar registers)
+            double cr[OBCA_NL][7], nx[OBCA_NL][7], v[OBCA_NL];
             PAR64(lane) {
-                const int L_ = LI(lane), r = lane < 6 ? lane : (lane < 12 ? lane - 6 : 0);
-                const bool pr = lane < 6 || lane >= 12;             // this lane works on the composed map
-                rr[L_] = r; mb[L_] = pr ? pairbuf + r * 6 : I.rs + RS_CL + r * 6; ms[L_] = pr ? 42 : 2 * (size_t)OB_RS; bo[L_] = 36 - 5 * r;
-                if (lane < 6) sh.traj[lane] = 0.0;
+                const int L_ = LI(lane), r = lane < 6 ? lane : 0; const double *row = pm + r * 6;
 #pragma unroll
-                for (int q = 0; q < FW_D; q++) {                    // prologue: steps 0 .. FW_D-1 (clamped: unconditional loads keep the vmcnt bookkeeping exact)
-                    const gdbl *cn = mb[L_] + (size_t)(q < NPc ? q : NPc) * ms[L_];
-#pragma unroll
-                    for (int e = 0; e < 6; e++) ring[L_][q][e] = cn[e];
-                    ring[L_][q][6] = cn[bo[L_]];
-                }
+                for (int e = 0; e < 6; e++) cr[L_][e] = row[e];
+                cr[L_][6] = pm[36 + r];
             }
-            for (int j0 = 0; j0 < NP; j0 += FW_D) {
-#pragma unroll
-                for (int q = 0; q < FW_D; q++) {
-                    const int j = j0 + q;
-                    PAR64(lane) {
-                        const int L_ = LI(lane);
-                        double cr[7];
-#pragma unroll
-                        for (int e = 0; e < 7; e++) cr[e] = ring[L_][q][e];
-                        {   // re-issue the slot for step j + FW_D
-                            const int jn = j + FW_D < NPc ? j + FW_D : NPc; const gdbl *cn = mb[L_] + (size_t)jn * ms[L_];
-#pragma unroll
-                            for (int e = 0; e < 6; e++) ring[L_][q][e] = cn[e];
-                            ring[L_][q][6] = cn[bo[L_]];
-                        }
-                        if (j < NP) {
-                            v[L_] = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                            if (lane < 12) sh.traj[(size_t)(2 * j + (lane < 6 ? 2 : 1)) * 6 + rr[L_]] = v[L_];
-                        }
-                    }
-                    if (j < NP) {
-#pragma unroll
-                        for (int e = 0; e < 6; e++) fw_s[e] = WV_READLANE(v, e);
-                    }
-                }
-            }
-            if (2 * NP < Nn) {                                   // odd horizon: the last stage on its own
-                const int k = 2 * NP;
+            for (int j = 0; j < NP; j++) {
                 PAR64(lane) {
-                    const int L_ = LI(lane); const gdbl *cn = I.rs + (size_t)k * OB_RS + RS_CL + rr[L_] * 6;
-                    double cr[7];
+                    const int L_ = LI(lane), r = lane < 6 ? lane : 0;
+                    const double *pn_ = pm + (size_t)(j + 1 < NP ? j + 1 : j) * 42;          // the next step's row: its LDS reads are in flight during this step's arithmetic
 #pragma unroll
-                    for (int e = 0; e < 6; e++) cr[e] = cn[e];
-                    cr[6] = cn[bo[L_]];
-                    v[L_] = dot6_tree(cr[6], cr[0], fw_s[0], cr[1], fw_s[1], cr[2], fw_s[2], cr[3], fw_s[3], cr[4], fw_s[4], cr[5], fw_s[5]);
-                    if (lane < 6) sh.traj[(size_t)(k + 1) * 6 + lane] = v[L_];
+                    for (int e = 0; e < 6; e++) nx[L_][e] = pn_[r * 6 + e];
+                    nx[L_][6] = pn_[36 + r];
+                    v[L_] = dot6_tree(cr[L_][6], cr[L_][0], fw_s[0], cr[L_][1], fw_s[1], cr[L_][2], fw_s[2], cr[L_][3], fw_s[3], cr[L_][4], fw_s[4], cr[L_][5], fw_s[5]);
+                    if (lane < 6) g_traj[(size_t)(2 * j + 2) * 6 + lane] = v[L_];
+#pragma unroll
+                    for (int e = 0; e < 7; e++) cr[L_][e] = nx[L_][e];
                 }
+#pragma unroll
+                for (int e = 0; e < 6; e++) fw_s[e] = WV_READLANE(v, e);
             }
         }
     WAVE0_END
-    SYNC();
+    LDS_SYNC();
+    PAR(lane) {     // odd states (and the last state of an odd horizon) from the plain maps kept in registers
+        const int L_ = LI(lane);
+        if (lane < NH) {
+            double s_[6]; const double *m0 = M0[L_];
+#pragma unroll
+            for (int e = 0; e < 6; e++) s_[e] = g_traj[(size_t)(2 * lane) * 6 + e];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+                g_traj[(size_t)(2 * lane + 1) * 6 + r] = dot6_tree(m0[36 + r], m0[r * 6 + 0], s_[0], m0[r * 6 + 1], s_[1], m0[r * 6 + 2], s_[2], m0[r * 6 + 3], s_[3], m0[r * 6 + 4], s_[4], m0[r * 6 + 5], s_[5]);
+        }
+    }
+    LDS_SYNC();
     PROF(I, PF_FWD_SEQ);
     // ---- stage-parallel: primal steps of x,u; costates; bound terms of x,u ; steering rows
+    double red[4][OBCA_NL];
     PAR(lane) {
-        double ap = 1.0, az = 1.0, gd = 0, cc_;
+        double ap = 1.0, az = 1.0, gd = 0, gr = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < az) az = cc_; }
-        const double t = z[l.t], q = t * c.Ts;
+        const double t = z[l.t], q = t * c.Ts, rr_t = 0.1 / (q * q);
         for (int k = lane; k <= N; k += OB_NT) {
             // Every load of the stage first, every store last: d, z and the records may alias as far as the compiler knows, so a load behind a store waits for
             // its own round trip (the stage used to take seven of them; a lone wavefront per SIMD has nothing to hide them with).
             double s[6], sn[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { s[i] = sh.traj[(size_t)k * 6 + i]; sn[i] = sh.traj[(size_t)(k < N ? k + 1 : N) * 6 + i]; }
+            for (int i = 0; i < 6; i++) { s[i] = g_traj[(size_t)k * 6 + i]; sn[i] = g_traj[(size_t)(k < N ? k + 1 : N) * 6 + i]; }
             const int ku = k < N ? k : N - 1;                                    // (clamped: the loads of the last stage's absent input part are unused)
             const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
             double x[4], zxL[4], zxU[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i]; }
-            const gdbl *ro = I.rs + (size_t)ku * OB_RS, *cm = ro + RS_CL, *rec = I.as + (size_t)ku * OB_AS;
-            double cmK[12], cmk0 = cm[40], cmk1 = cm[41];
+            const gdbl *ro = I.rs + (size_t)ku * OB_RS, *rec = I.as + (size_t)ku * OB_AS;
+            double cmK[12], cmk0 = 0, cmk1 = 0;                                    // gains K_k and feed-forward kf_k = KF_k . coef (the same sums as the pair lanes of the forward sweep)
 #pragma unroll
-            for (int j = 0; j < 12; j++) cmK[j] = cm[24 + j];
+            for (int j = 0; j < 12; j++) cmK[j] = ro[RS_K + j];
+#pragma unroll
+            for (int cc = 0; cc < OB_NC; cc++) { cmk0 += ro[RS_KF + cc] * coef[cc]; cmk1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
             const double u[2] = {z[l.u + 2 * ku], z[l.u + 2 * ku + 1]};
             const double w[2] = {ku ? z[l.u + 2 * ku - 2] : 0.0, ku ? z[l.u + 2 * ku - 1] : 0.0};
             const double zuL[2] = {z[l.zuL + 2 * ku], z[l.zuL + 2 * ku + 1]}, zuU[2] = {z[l.zuU + 2 * ku], z[l.zuU + 2 * ku + 1]};
@@ -1054,6 +1195,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #pragma unroll
                 for (int j = 0; j < 6; j++) { du[0] += cmK[j] * s[j]; du[1] += cmK[6 + j] * s[j]; }
                 d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
+                if (!c.fixTime) { const double e1 = u[0] - w[0], e2 = u[1] - w[1]; gr += -2 * rr_t * (e1 * e1 + e2 * e2) / t; }
                 const double cu[2] = {0.01, c.wa}, iq = 1.0 / q, rr = 0.1 * (iq * iq);
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
@@ -1076,25 +1218,25 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 for (int i = 0; i < 4; i++) d[l.pi + 4 * k + i] = dpi[i];
             }
         }
-        sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;
+        red[0][LI(lane)] = ap; red[1][LI(lane)] = az; red[2][LI(lane)] = gd; red[3][LI(lane)] = gr;
 #undef FTBP
 #undef FTBZ
     }
-    SYNC();
-    so.ap = red_min(sh.red[0]); so.az = red_min(sh.red[1]); so.gd = red_sum(sh.red[2]);
+    so.ap = wred_min(red[0]); so.az = wred_min(red[1]); so.gd = wred_sum(red[2]); so.gr = wred_sum(red[3]);
     PAR(lane) { if (lane == 0) { sh.coef[0] = dt; sh.coef[1] = nu[0]; sh.coef[2] = nu[1]; sh.coef[3] = nu[2]; sh.coef[4] = nu[3]; } }
     SYNC();
     PROF(I, PF_BS_STAGE);
 }
 
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
-template <int VM>
+template <int VM, int DBG>      // DBG = 1 (host emulation tests only): the obstacle part of the direction is also written to d
 OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
     double ap = so.ap, az = so.az, gd = so.gd;
     const double dt = sh.coef[0], nu[4] = {sh.coef[1], sh.coef[2], sh.coef[3], sh.coef[4]};
     // ---- obstacle blocks: back-substitution (the block is re-factorised instead of being stored)
+    double red[3][OBCA_NL];
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
@@ -1102,248 +1244,49 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
-            const double dp[3] = {d[l.x + 4 * k], d[l.x + 4 * k + 1], d[l.x + 4 * k + 2]};
+            const double dp[3] = {g_traj[(size_t)k * 6], g_traj[(size_t)k * 6 + 1], g_traj[(size_t)k * 6 + 2]};
             ObsStep<VM> st;
             obs_block<1, VM>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
             const int r0 = sh.roff[j];
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
-                d[l.lam + k * M + r0 + i] = st.dlam[i];
+                if (DBG || OBCA_STORE_DOBS) d[l.lam + k * M + r0 + i] = st.dlam[i];
                 lgd -= rdiv(mu, in.lam[i]) * st.dlam[i];
                 FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv(mu, in.lam[i]) - in.zl[i] - rdiv(in.zl[i], in.lam[i]) * st.dlam[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                d[l.mu + 4 * it + i] = st.dmu[i]; d[l.yo + 4 * it + i] = st.dy[i];
+                if (DBG || OBCA_STORE_DOBS) { d[l.mu + 4 * it + i] = st.dmu[i]; d[l.yo + 4 * it + i] = st.dy[i]; }
                 lgd -= rdiv(mu, in.mu[i]) * st.dmu[i];
                 FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], rdiv(mu, in.mu[i]) - in.zm[i] - rdiv(in.zm[i], in.mu[i]) * st.dmu[i]);
             }
-            d[l.sl + it] = st.dsl; d[l.so + it] = st.dso;
+            if (DBG || OBCA_STORE_DOBS) { d[l.sl + it] = st.dsl; d[l.so + it] = st.dso; }
             lgd += (c.dist ? -rdiv(mu, in.sl) : 1e2 + 2e4 * in.sl) * st.dsl - rdiv(mu, in.so) * st.dso;
             if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, rdiv(mu, in.sl) - in.zs1 - rdiv(in.zs1, in.sl) * st.dsl); }
             FTBP(in.so, st.dso); FTBZ(in.zso, rdiv(mu, in.so) - in.zso - rdiv(in.zso, in.so) * st.dso);
         }
-        sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
+        red[0][LI(lane)] = lap; red[1][LI(lane)] = laz; red[2][LI(lane)] = lgd;
 #undef FTBP
 #undef FTBZ
     }
-    SYNC();
-    ap = fmin(ap, red_min(sh.red[0])); az = fmin(az, red_min(sh.red[1])); gd += red_sum(sh.red[2]);
-    SYNC();
+    ap = fmin(ap, wred_min(red[0])); az = fmin(az, wred_min(red[1])); gd += wred_sum(red[2]);
     // ---- t and nu (uniform)
     if (!c.fixTime) {
-        const double t = z[l.t], q = t * c.Ts, dL = t - OB_TL, dU = OB_TU - t, zL = z[l.ztL], zU = z[l.ztU];
-        // d f / d t needs sum_k -2 rv_k / t : recompute from the gradient bookkeeping:  gtb = sum(-2rv/t) + steer/dyn/J^T y terms.
-        // The barrier-function gradient (no constraint terms) is formed separately below.
-        (void)q;
+        const double t = z[l.t], dL = t - OB_TL, dU = OB_TU - t, zL = z[l.ztL], zU = z[l.ztU];
         double cc_;
         cc_ = dt < 0 ? -tau * dL * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
         cc_ = -dt < 0 ? tau * dU * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
         double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
         cc_ = dzL < 0 ? -tau * zL * rcp_nr(dzL) : 1e300; if (cc_ < az) az = cc_;
         cc_ = dzU < 0 ? -tau * zU * rcp_nr(dzU) : 1e300; if (cc_ < az) az = cc_;
-    }
-    PAR(lane) {   // rate-cost part of d phi / d t
-        double g = 0;
-        if (!c.fixTime) {
-            const double t = z[l.t], q = t * c.Ts, rr = 0.1 / (q * q);
-            for (int k = lane; k < N; k += OB_NT) {
-                double e1 = z[l.u + 2 * k] - (k ? z[l.u + 2 * k - 2] : 0.0), e2 = z[l.u + 2 * k + 1] - (k ? z[l.u + 2 * k - 1] : 0.0);
-                g += -2 * rr * (e1 * e1 + e2 * e2) / t;
-            }
-        }
-        sh.red[0][lane] = g;
-        if (lane < 4) d[l.nu + lane] = nu[lane];
-        if (lane == 4) d[l.t] = dt;
-    }
-    SYNC();
-    if (!c.fixTime) {
-        const double t = z[l.t];
-        double gt = red_sum(sh.red[0]) + (N + 1) * (0.5 + 2 * t) + (N + 1) * (-mu / (t - OB_TL) + mu / (OB_TU - t));
+        // d phi / d t: rate cost (so.gr, summed over the stages by the back-substitution above) + time cost + barrier of its bounds
+        const double gt = so.gr + (N + 1) * (0.5 + 2 * t) + (N + 1) * (-mu / (t - OB_TL) + mu / (OB_TU - t));
         gd += gt * dt;
     }
-    SYNC();
+    if (DBG) { PAR(lane) { if (lane < 4) d[l.nu + lane] = nu[lane]; if (lane == 4) d[l.t] = dt; } }
+    if (DBG || OBCA_STORE_DOBS) SYNC();      // the stored steps are read back by the fused assembly
     so.ap = ap; so.az = az; so.gd = gd;
     PROF(I, PF_BS_OBS);
-}
-
-// ---------------------------------------------------------------- objective / constraint 1-norm / barrier at z + alpha d (primal part)
-template <int VM>
-OBCA_FN void eval_trial(const Inst &I, Shared &sh, double alpha, double &f, double &th1, double &bar) {
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    const gdbl *z = I.z, *d = I.d;
-    const double t = z[l.t] + alpha * d[l.t], q = t * c.Ts, iq = 1.0 / q, rr = 0.1 * (iq * iq);
-    PAR(lane) {
-        double lf = 0, lth = 0, lbar = 0;
-#define OBS_PREFETCH(VM_) ((VM_) <= 2)      /* classes whose blocks fit the register file twice (VM = 4: measured 14 % slower, the second block spills) */
-        // two blocks in flight per lane: the next block's iterate and step are loaded before this block's arithmetic (nothing is stored in this phase, but the
-        // compiler does not move loads across the loop edge on its own, and a lone wavefront per SIMD has nothing else to hide a round trip with)
-        struct TrialStep { double lam[VM], mu[4], sl, so, X, Y, psi; };
-        auto load_step = [&](int it_, ObsIn<VM> &in_, TrialStep &ts_) {
-            const int k_ = it_ / nOb, j_ = it_ - k_ * nOb, r0_ = sh.roff[j_];
-            load_obs<VM>(I, sh, z, k_, j_, in_);
-#pragma unroll
-            for (int i = 0; i < VM; i++) ts_.lam[i] = i < in_.v ? d[l.lam + k_ * M + r0_ + i] : 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) ts_.mu[i] = d[l.mu + 4 * it_ + i];
-            ts_.sl = d[l.sl + it_]; ts_.so = d[l.so + it_]; ts_.X = d[l.x + 4 * k_]; ts_.Y = d[l.x + 4 * k_ + 1]; ts_.psi = d[l.x + 4 * k_ + 2];
-        };
-        const int cnt = (N + 1) * nOb;
-        ObsIn<VM> in, nx; TrialStep ts, tn;
-        if (OBS_PREFETCH(VM) && lane < cnt) load_step(lane, in, ts);
-        for (int it = lane; it < cnt; it += OB_NT) {
-            if (OBS_PREFETCH(VM)) load_step(it + OB_NT < cnt ? it + OB_NT : it, nx, tn); else load_step(it, in, ts);
-#pragma unroll
-            for (int i = 0; i < VM; i++) if (i < in.v) in.lam[i] += alpha * ts.lam[i];
-#pragma unroll
-            for (int i = 0; i < 4; i++) in.mu[i] += alpha * ts.mu[i];
-            in.sl += alpha * ts.sl; in.so += alpha * ts.so;
-            {
-                double dd[VM + 6];
-#pragma unroll
-                for (int i = 0; i < VM; i++) dd[i] = i < in.v ? in.lam[i] : 1.0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) dd[VM + i] = in.mu[i];
-                dd[VM + 4] = in.so; dd[VM + 5] = c.dist ? in.sl : 1.0;
-                lbar += log_prod(dd);
-            }
-            in.X += alpha * ts.X; in.Y += alpha * ts.Y; in.psi += alpha * ts.psi;
-            double r[4]; obs_rows<VM>(c, in, r);
-            lth += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
-            if (!c.dist) lf += 1e2 * in.sl + 1e4 * in.sl * in.sl;
-            if (OBS_PREFETCH(VM)) { in = nx; ts = tn; }
-        }
-        for (int k = lane; k <= N; k += OB_NT) {
-            double x[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i] + alpha * d[l.x + 4 * k + i];
-            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
-            lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
-            BarAcc ba; bar_init(ba);                  // same order of the products as in assemble_stage
-            if (k >= 1) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) if (i != 2) bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
-            }
-            if (k == N) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) lth += fabs(x[i] - c.xF[i]);
-            } else {
-                const double u[2] = {z[l.u + 2 * k] + alpha * d[l.u + 2 * k], z[l.u + 2 * k + 1] + alpha * d[l.u + 2 * k + 1]};
-                const double w[2] = {k ? z[l.u + 2 * k - 2] + alpha * d[l.u + 2 * k - 2] : 0.0, k ? z[l.u + 2 * k - 1] + alpha * d[l.u + 2 * k - 1] : 0.0};
-                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rr * ((u[0] - w[0]) * (u[0] - w[0]) + (u[1] - w[1]) * (u[1] - w[1]));   // same form as assemble_stage
-                bar_mul(ba, u[0] - OB_UL0, OB_UU0 - u[0]); bar_mul(ba, u[1] - OB_UL1, OB_UU1 - u[1]);
-                const double ss = z[l.ss + k] + alpha * d[l.ss + k];
-                bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
-                lth += fabs((w[0] - u[0]) * iq - ss);
-                double F[4]; dyn_value(c, x, u, t, F);
-#pragma unroll
-                for (int i = 0; i < 4; i++) lth += fabs(z[l.x + 4 * (k + 1) + i] + alpha * d[l.x + 4 * (k + 1) + i] - F[i]);
-            }
-            lbar += bar_log(ba);
-        }
-        sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
-    }
-    SYNC();
-    // f, th1, bar live in LDS and BOTH wavefronts write them: finish the values in registers and store each exactly once (a read-modify-write
-    // of the shared slot here was a data race: the slower wavefront could add the t terms on top of the faster one's finished value)
-    double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
-    SYNC();
-    if (!c.fixTime) { fr += (N + 1) * (0.5 * t + t * t); br += (N + 1) * log((t - OB_TL) * (OB_TU - t)); }
-    f = fr; th1 = tr; bar = br;
-    PROF(I, PF_TRIAL);
-}
-
-// ---------------------------------------------------------------- accept the step
-OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu * rcp_nr(dist), lo = q * rcp_nr(ks), hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
-// bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
-OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr(dist); return zz + az * (mu * id - zz - zz * id * dv); }
-
-OBCA_FN void apply_step(const Inst &I, Shared &sh, double alpha, double ay, double az, double mu, double ks) {
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
-    gdbl *z = I.z; const gdbl *d = I.d;
-    PAR(lane) {
-        // one-sided (>= 0) groups: lam, mu (+ yo), so.  The iterate is read and written in place, so a load placed after a store cannot be
-        // hoisted by the compiler (may alias): every group is processed AP_R items per lane at a time, all loads first, then the stores --
-        // one memory round trip per chunk instead of one per item.
-#define AP_R 8
-        for (int base = 0; base < M * (N + 1); base += AP_R * OB_NT) {
-            double v[AP_R], dv[AP_R], zz[AP_R];
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < M * (N + 1) ? i : 0; v[r] = z[l.lam + ic]; dv[r] = d[l.lam + ic]; zz[r] = z[l.zlam + ic]; }
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < M * (N + 1)) {
-                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
-                z[l.lam + i] = v1; z[l.zlam + i] = clampz(z1, v1, mu, ks); } }
-        }
-        for (int base = 0; base < 4 * nOb * (N + 1); base += AP_R * OB_NT) {
-            double v[AP_R], dv[AP_R], zz[AP_R], yv[AP_R], dyv[AP_R];
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < 4 * nOb * (N + 1) ? i : 0;
-                v[r] = z[l.mu + ic]; dv[r] = d[l.mu + ic]; zz[r] = z[l.zmu + ic]; yv[r] = z[l.yo + ic]; dyv[r] = d[l.yo + ic]; }
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < 4 * nOb * (N + 1)) {
-                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
-                z[l.mu + i] = v1; z[l.zmu + i] = clampz(z1, v1, mu, ks); z[l.yo + i] = yv[r] + ay * dyv[r]; } }
-        }
-        for (int base = 0; base < nOb * (N + 1); base += AP_R * OB_NT) {
-            double v[AP_R], dv[AP_R], zz[AP_R], sv[AP_R], dsv[AP_R], z1v[AP_R];
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r, ic = i < nOb * (N + 1) ? i : 0;
-                v[r] = z[l.so + ic]; dv[r] = d[l.so + ic]; zz[r] = z[l.zso + ic]; sv[r] = z[l.sl + ic]; dsv[r] = d[l.sl + ic]; z1v[r] = z[l.zs1 + ic]; }
-#pragma unroll
-            for (int r = 0; r < AP_R; r++) { const int i = base + lane + OB_NT * r; if (i < nOb * (N + 1)) {
-                const double z1 = zstep(zz[r], v[r], dv[r], mu, az), v1 = v[r] + alpha * dv[r];
-                z[l.so + i] = v1; z[l.zso + i] = clampz(z1, v1, mu, ks);
-                const double s1 = sv[r] + alpha * dsv[r];
-                z[l.sl + i] = s1;
-                if (c.dist) z[l.zs1 + i] = clampz(zstep(z1v[r], sv[r], dsv[r], mu, az), s1, mu, ks); } }
-        }
-        for (int k = lane; k <= N; k += OB_NT) {   // one stage per lane: all loads of the stage first (clamped indices), then the stores
-            const int ku = k < N ? k : N - 1;
-            double xv[4], dxv[4], zxl[4], zxu[4], uv[2], duv[2], zul[2], zuu[2], piv[4], dpi[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const int idx = 4 * k + i; xv[i] = z[l.x + idx]; dxv[i] = d[l.x + idx]; zxl[i] = z[l.zxL + idx]; zxu[i] = z[l.zxU + idx];
-                                          piv[i] = z[l.pi + 4 * ku + i]; dpi[i] = d[l.pi + 4 * ku + i]; }
-#pragma unroll
-            for (int i = 0; i < 2; i++) { const int idx = 2 * ku + i; uv[i] = z[l.u + idx]; duv[i] = d[l.u + idx]; zul[i] = z[l.zuL + idx]; zuu[i] = z[l.zuU + idx]; }
-            const double ssv = z[l.ss + ku], dss = d[l.ss + ku], zsl = z[l.zssL + ku], zsu = z[l.zssU + ku], ygv = z[l.yg + ku], dyg = d[l.yg + ku];
-            if (k >= 1) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int idx = 4 * k + i; const double v = xv[i] + alpha * dxv[i];
-                    if (i != 2) {
-                        const double zL = zstep(zxl[i], xv[i] - c.xl[i], dxv[i], mu, az), zU = zstep(zxu[i], c.xu[i] - xv[i], -dxv[i], mu, az);
-                        z[l.zxL + idx] = clampz(zL, v - c.xl[i], mu, ks); z[l.zxU + idx] = clampz(zU, c.xu[i] - v, mu, ks);
-                    }
-                    z[l.x + idx] = v;
-                }
-            }
-            if (k < N) {
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const int idx = 2 * k + i; const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
-                    const double zL = zstep(zul[i], uv[i] - lo, duv[i], mu, az), zU = zstep(zuu[i], hi - uv[i], -duv[i], mu, az), v = uv[i] + alpha * duv[i];
-                    z[l.u + idx] = v; z[l.zuL + idx] = clampz(zL, v - lo, mu, ks); z[l.zuU + idx] = clampz(zU, hi - v, mu, ks);
-                }
-                {
-                    const double zL = zstep(zsl, ssv + OB_SSB, dss, mu, az), zU = zstep(zsu, OB_SSB - ssv, -dss, mu, az), v = ssv + alpha * dss;
-                    z[l.ss + k] = v; z[l.zssL + k] = clampz(zL, v + OB_SSB, mu, ks); z[l.zssU + k] = clampz(zU, OB_SSB - v, mu, ks);
-                }
-                z[l.yg + k] = ygv + ay * dyg;
-#pragma unroll
-                for (int i = 0; i < 4; i++) z[l.pi + 4 * k + i] = piv[i] + ay * dpi[i];
-            }
-        }
-        if (lane < 4) z[l.nu + lane] += ay * d[l.nu + lane];
-        if (lane == 5 && !c.fixTime) {
-            double v = z[l.t], dv = d[l.t], dL = v - OB_TL, dU = OB_TU - v, zL = z[l.ztL], zU = z[l.ztU];
-            zL = zstep(zL, dL, dv, mu, az); zU = zstep(zU, dU, -dv, mu, az);
-            v += alpha * dv;
-            z[l.t] = v; z[l.ztL] = clampz(zL, v - OB_TL, mu, ks); z[l.ztU] = clampz(zU, OB_TU - v, mu, ks);
-        }
-    }
-    SYNC();
-    PROF(I, PF_APPLY);
 }
 
 // ---------------------------------------------------------------- starting point (IPOPT sec. 3.6: push into the bounds, z=1, y=0)
@@ -1406,36 +1349,52 @@ OBCA_PHASE void ph_init(double bound_push, double bound_frac) {
     VM_CALL(init_point, sh.inst, sh, po);
     PROF(sh.inst, PF_INIT);
 }
-OBCA_PHASE void ph_assemble_obs2(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<2>(sh.inst, sh, mu, dw, dc); }
-OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMID>(sh.inst, sh, mu, dw, dc); }
-OBCA_PHASE void ph_assemble_obs8(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc); }
+// Assembly of the Newton system at the current iterate (`which` = 0 -> sh.A, 1 -> sh.A2), and the fused line-search step (ph_fused: trial point -> Inst::zn,
+// assembled -> sh.An).  The (stage, obstacle) part and the stage part of the common (<= 2 rows per obstacle) case share ONE non-inlined function.
+#define OB_NOFUSE FuseArgs{0.0, 0.0, 0.0, 0.0, 0.0}
+OBCA_PHASE void ph_assemble_obs2(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<2, 0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); }
+OBCA_PHASE void ph_assemble_obs4(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMID, 0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); }
+OBCA_PHASE void ph_assemble_obs8(double mu, double dw, double dc) { Shared &sh = g_sh; assemble_obs<OB_VMAX, 0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); }
 OBCA_FN void ph_assemble_obs(double mu, double dw, double dc) { if (g_sh.vmc == 0) ph_assemble_obs2(mu, dw, dc); else if (g_sh.vmc == 1) ph_assemble_obs4(mu, dw, dc); else ph_assemble_obs8(mu, dw, dc); }
-OBCA_PHASE void ph_assemble_stage(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
-// the two assembly parts of the common (<= 2 rows per obstacle) case share ONE non-inlined function: every call of a register-hungry phase
-// saves / restores the 112 callee-saved VGPRs through scratch, so fewer calls = less HBM traffic
-OBCA_PHASE void ph_assemble2(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_obs<2>(sh.inst, sh, mu, dw, dc); assemble_stage(sh.inst, sh, mu, dw, dc, second ? sh.A2 : sh.A); }
+OBCA_PHASE void ph_assemble_stage(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_stage<0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE, second ? sh.A2 : sh.A); }
+OBCA_PHASE void ph_assemble2(double mu, double dw, double dc, int second) { Shared &sh = g_sh; assemble_obs<2, 0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); assemble_stage<0>(sh.inst, sh, mu, dw, dc, OB_NOFUSE, second ? sh.A2 : sh.A); }
 OBCA_FN void ph_assemble(double mu, double dw, double dc, int second) { if (g_sh.vm2) ph_assemble2(mu, dw, dc, second); else { ph_assemble_obs(mu, dw, dc); ph_assemble_stage(mu, dw, dc, second); } }
+OBCA_PHASE void ph_fused_obs4(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) { Shared &sh = g_sh; const FuseArgs fa = {alpha, ay, az, ks, dwd}; assemble_obs<OB_VMID, 1>(sh.inst, sh, mu, 0.0, dc, fa); }
+OBCA_PHASE void ph_fused_obs8(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) { Shared &sh = g_sh; const FuseArgs fa = {alpha, ay, az, ks, dwd}; assemble_obs<OB_VMAX, 1>(sh.inst, sh, mu, 0.0, dc, fa); }
+OBCA_PHASE void ph_fused_stage(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) { Shared &sh = g_sh; const FuseArgs fa = {alpha, ay, az, ks, dwd}; assemble_stage<1>(sh.inst, sh, mu, 0.0, dc, fa, sh.An); }
+OBCA_PHASE void ph_fused2(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) {
+    Shared &sh = g_sh; const FuseArgs fa = {alpha, ay, az, ks, dwd};
+    assemble_obs<2, 1>(sh.inst, sh, mu, 0.0, dc, fa); assemble_stage<1>(sh.inst, sh, mu, 0.0, dc, fa, sh.An);
+}
+OBCA_FN void ph_fused(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) {
+    if (g_sh.vm2) { ph_fused2(mu, dc, alpha, ay, az, ks, dwd); return; }
+    if (g_sh.vmc == 1) ph_fused_obs4(mu, dc, alpha, ay, az, ks, dwd); else ph_fused_obs8(mu, dc, alpha, ay, az, ks, dwd);
+    ph_fused_stage(mu, dc, alpha, ay, az, ks, dwd);
+}
 OBCA_PHASE int ph_riccati(double rho) { Shared &sh = g_sh; return riccati_backward(sh.inst, sh, rho); }
 OBCA_PHASE void ph_direction_main(double mu, double dw, double dc, double rho, double tau) { Shared &sh = g_sh; direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
-OBCA_PHASE void ph_direction_obs2(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
-OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMID>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
-OBCA_PHASE void ph_direction_obs8(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs2(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<2, 0>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs4(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMID, 0>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
+OBCA_PHASE void ph_direction_obs8(double mu, double dw, double dc, double tau) { Shared &sh = g_sh; direction_obs<OB_VMAX, 0>(sh.inst, sh, mu, dw, dc, tau, sh.S); }
 OBCA_FN void ph_direction_obs(double mu, double dw, double dc, double tau) { if (g_sh.vmc == 0) ph_direction_obs2(mu, dw, dc, tau); else if (g_sh.vmc == 1) ph_direction_obs4(mu, dw, dc, tau); else ph_direction_obs8(mu, dw, dc, tau); }
 OBCA_PHASE void ph_direction2(double mu, double dw, double dc, double rho, double tau) {   // both parts in one call, see ph_assemble2
     Shared &sh = g_sh;
     direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
-    if (sh.S.ok) direction_obs<2>(sh.inst, sh, mu, dw, dc, tau, sh.S);
+    if (sh.S.ok) direction_obs<2, 0>(sh.inst, sh, mu, dw, dc, tau, sh.S);
 }
 OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double tau) {
     if (g_sh.vm2) { ph_direction2(mu, dw, dc, rho, tau); return; }
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
-OBCA_PHASE void ph_trial2(double alpha) { Shared &sh = g_sh; eval_trial<2>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_PHASE void ph_trial4(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMID>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_PHASE void ph_trial8(double alpha) { Shared &sh = g_sh; eval_trial<OB_VMAX>(sh.inst, sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); }
-OBCA_FN void ph_trial(double alpha) { if (g_sh.vmc == 0) ph_trial2(alpha); else if (g_sh.vmc == 1) ph_trial4(alpha); else ph_trial8(alpha); }
-OBCA_PHASE void ph_apply(double alpha, double ay, double az, double mu, double ks) { Shared &sh = g_sh; apply_step(sh.inst, sh, alpha, ay, az, mu, ks); }
+// the iterate the solve ends with (or is parked at) must sit in the instance's own buffer `home`: copy it over if the last accepted trial left it in the other one
+OBCA_PHASE void ph_bring_home() {
+    Shared &sh = g_sh; Inst &I = sh.inst;
+    PAR(lane) { for (int i = lane; i < sh.l.len; i += OB_NT) I.zn[i] = I.z[i]; }
+    SYNC();
+    PAR(lane) { if (lane == 0) { gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; } }
+    SYNC();
+}
 
 // ---------------------------------------------------------------- the interior-point driver
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2, ST_SUSPENDED = 3 };
@@ -1444,14 +1403,7 @@ enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2, ST_SUSPENDED = 3 };
 // a later launch: everything the iteration loop carries across iterations besides the iterate itself (which lives in HBM anyway) is a
 // handful of scalars and the filter, saved in the instance's slice record.  A resumed solve recomputes the assembly at the same point, so
 // the sequence of iterates is bit-identical to an uninterrupted solve.  Record layout (doubles):
-enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_FILT = 16, SL_SIZE = SL_FILT + 2 * OB_FILT };
-struct Slice {
-    gdbl *st;        // slice record of this instance (may be null when budget == 0 and resume == 0)
-    int resume;      // 1: the next ipm_attempt continues from the record instead of starting at the warm start
-    int budget;      // factorisation passes (iterations + inertia retries) this launch may spend; 0 = no limit
-    int used;        // passes spent so far in this launch
-};
-struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
+OBCA_FN double filt_get(const Shared &sh, const gdbl *st, int i, int c) { return i < OB_FILT_LDS ? sh.filt[i][c] : st[SL_FILT + 2 * i + c]; }
 
 // The reference's acceptance test on the current iterate, with its quirks (ParkingConstraints.jl:29-149): in variable-time
 // mode only the speed row of the dynamics is kept (:76-79), only the LAST obstacle's rows survive (:108-130), the separation row is
@@ -1460,6 +1412,7 @@ template <int VM>
 OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M; const gdbl *z = I.z;
     const double t = c.fixTime ? 1.0 : z[l.t];
+    double red[1][OBCA_NL];
     PAR(lane) {
         double w = -1e300;                                     // running max of every "should be <= 0" quantity
         for (int i = lane; i < M * (N + 1); i += OB_NT) w = fmax(w, -z[l.lam + i]);
@@ -1492,126 +1445,130 @@ OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
                               (in.Y + sn * c.off) * p2 - beta - OB_DMIN;
             w = fmax(w, fmax(sd ? fabs(r0 + 1) - 1 : r0, fmax(fmax(fabs(r1), fabs(r2)), -r3)));
         }
-        sh.red[0][lane] = w;
+        red[0][LI(lane)] = w;
     }
-    SYNC();
-    const double worst = red_max(sh.red[0]);
-    SYNC();
+    const double worst = wred_max(red[0]);
     return worst <= 5e-5;
 }
 OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 0 ? ref_constraints<2>(sh.inst, sh, sd) : (sh.vmc == 1 ? ref_constraints<OB_VMID>(sh.inst, sh, sd) : ref_constraints<OB_VMAX>(sh.inst, sh, sd)); }
 
+// What the iteration loop carries lives in LDS (Shared::drv), not in registers: the phases are non-inlined calls that use the whole register file, so every
+// value the driver kept in a register was spilled to scratch -- i.e. to HBM -- before each call and fetched back after it (~500 spill instructions in round 2's
+// kernel body, a memory round trip behind every phase).  An LDS slot costs a ~100-clock read where the value is needed and nothing at a call.
 OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
-    Shared &sh = g_sh;
-    double mu = o.mu_init, dw_last = 0;
-    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0;
-    double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
-    if (sl.resume) {
-        const gdbl *st = sl.st;
-        it = (int)st[SL_IT]; nf = (int)st[SL_NF]; nreg = (int)st[SL_NREG]; mu = st[SL_MU]; dw_last = st[SL_DWLAST]; th_min = st[SL_THMIN]; th_max = st[SL_THMAX];
-        pinf = st[SL_PINF];
-        PAR(lane) { for (int i = lane; i < 2 * nf; i += OB_NT) (&sh.filt[0][0])[i] = st[SL_FILT + i]; }
-        SYNC();
-        sl.resume = 0;
-    } else ph_init(o.bound_push, o.bound_frac);
-    double tau = fmax(o.tau_min, 1 - mu);
-    const int p_start = it + nreg;
-    double dc_mu = -1.0, dc_val = 0;
+    Shared &sh = g_sh; Drv &D = sh.drv;
+    gdbl *const st = sl.st;
     const AsmOut &A = sh.A;
+    D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
+    if (sl.resume) {
+        D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN]; D.th_max = st[SL_THMAX];
+        D.pinf = st[SL_PINF];
+        if ((int)st[SL_HAVE]) { PAR(lane) { if (lane == 0) asm_unpack(sh.A, st + SL_ASM); } }
+        PAR(lane) { const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS; for (int i = lane; i < 2 * nl; i += OB_NT) (&sh.filt[0][0])[i] = st[SL_FILT + i]; }
+        SYNC();
+        D.have_asm = (int)st[SL_HAVE];
+        sl.resume = 0;
+    } else { ph_init(o.bound_push, o.bound_frac); D.have_asm = 0; }
+    D.tau = fmax(o.tau_min, 1 - D.mu);
+    D.p_start = D.it + D.nreg;
+    D.dc_mu = -1.0; D.dc_val = 0;
+    // D.have_asm = 1: sh.A already holds the assembly of the current iterate, left behind by the accepted trial of the previous iteration (ph_fused)
     for (;;) {
-        if (sl.budget > 0 && sl.used + (it + nreg - p_start) >= sl.budget) {   // out of budget: park the loop state, a later launch continues
-            gdbl *st = sl.st;
+        if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) >= sl.budget) {   // out of budget: park the loop state, a later launch continues
             PAR(lane) {
-                if (lane == 0) { st[SL_IT] = it; st[SL_NF] = nf; st[SL_NREG] = nreg; st[SL_MU] = mu; st[SL_DWLAST] = dw_last; st[SL_THMIN] = th_min; st[SL_THMAX] = th_max; st[SL_PINF] = pinf; }
-                for (int i = lane; i < 2 * nf; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
+                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
+                const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS;                 // (entries beyond the LDS part are in the record already)
+                for (int i = lane; i < 2 * nl; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
             }
-            status = ST_SUSPENDED; break;
+            D.status = ST_SUSPENDED; break;
         }
-        if (mu != dc_mu) { dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
-        double dc = dc_val;
-        PROF(sh.inst, PF_OTHER); ph_assemble(mu, 0.0, dc, 0);
-        if (it == 0) { th_min = 1e-4 * fmax(1.0, A.th1); th_max = 1e4 * fmax(1.0, A.th1); }
-        f = A.f; pinf = A.pinf; dinf = A.dinf;
-        const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
-        const double sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
-        const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
-        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
-        if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
-        if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
-        // barrier update: mu <- max(tol/10, min(kappa_mu mu, mu^theta_mu)) while the barrier problem is solved to kappa_eps mu
-        int mu_changed = 0;
+        if (D.mu != D.dc_mu) { D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
+        PROF(sh.inst, PF_OTHER); if (!D.have_asm) ph_assemble(D.mu, 0.0, D.dc_val, 0);
+        D.have_asm = 0;
+        if (D.it == 0) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); }
+        D.f = A.f; D.pinf = A.pinf; D.dinf = A.dinf;
         {
-            double cm = A.cinfmu;
-            for (;;) {
-                double Emu = fmax(dinf / sd, fmax(pinf, cm / sc));
-                if (Emu <= o.kappa_eps * mu && mu > o.tol / 10) {
-                    mu = fmax(o.tol / 10, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-                    tau = fmax(o.tau_min, 1 - mu); nf = 0; mu_changed = 1;
-                    dc_val = o.dc_bar * pow(mu, o.kappa_c); dc_mu = mu;
-                    PROF(sh.inst, PF_OTHER); ph_assemble(mu, 0.0, dc_val, 1);   // complementarity error w.r.t. the new mu
-                    cm = sh.A2.cinfmu;
-                } else break;
-            }
+            const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
+            const double sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
+            const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
+            if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { D.status = ST_OPTIMAL; break; }
+            if (D.it >= o.max_iter) { D.status = ST_USERLIMIT; break; }
+            if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { D.status = ST_ERROR; break; }
+            D.sd = sd; D.sc = sc;
         }
-        dc = dc_val;
+        // barrier update: mu <- max(tol/10, min(kappa_mu mu, mu^theta_mu)) while the barrier problem is solved to kappa_eps mu
+        D.mu_changed = 0;
+        D.cm = cinf_mu(A, D.mu);
+        for (;;) {
+            const double Emu = fmax(D.dinf / D.sd, fmax(D.pinf, D.cm / D.sc));
+            if (Emu <= o.kappa_eps * D.mu && D.mu > o.tol / 10) {
+                D.mu = fmax(o.tol / 10, fmin(o.kappa_mu * D.mu, pow(D.mu, o.theta_mu)));
+                D.tau = fmax(o.tau_min, 1 - D.mu); D.nf = 0; D.mu_changed = 1;
+                D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu;
+                D.cm = cinf_mu(A, D.mu);      // complementarity error w.r.t. the new mu: from the extreme products of the assembly at hand (round 2 re-assembled for it)
+            } else break;
+        }
         // search direction with inertia correction (IPOPT Algorithm IC)
-        double dw = 0; int ok = 0;
-        for (int tr = 0; tr < 60; tr++) {
-            // (a single call for the whole Newton pass saves one more callee-saved-register round trip but costs more in-body spills in the
-            // stage assembly: measured 1.3 % slower, so assembly and direction stay separate calls)
-            int a_;
-            {
-            PROF(sh.inst, PF_OTHER); if (tr > 0 || mu_changed) ph_assemble(mu, dw, dc, 0);
-            a_ = A.ok;
+        D.dw = 0; D.ok = 0;
+        for (D.tr = 0; D.tr < 60; D.tr++) {
+            PROF(sh.inst, PF_OTHER); if (D.tr > 0 || D.mu_changed) ph_assemble(D.mu, D.dw, D.dc_val, 0);
+            int a_ = A.ok;
             PROF(sh.inst, PF_OTHER); if (a_) a_ = ph_riccati(o.rho_term);
-            PROF(sh.inst, PF_OTHER); if (a_) { ph_direction(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
-            }
-            if (a_) { ok = 1; break; }
-            nreg++;
-            if (dw == 0) dw = dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * dw_last);
-            else dw *= (dw_last == 0 ? o.kw_inc0 : o.kw_inc);
-            if (dw > o.dw_max) break;
+            PROF(sh.inst, PF_OTHER); if (a_) { ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau); a_ = sh.S.ok; }
+            if (a_) { D.ok = 1; break; }
+            D.nreg++;
+            if (D.dw == 0) D.dw = D.dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * D.dw_last);
+            else D.dw *= (D.dw_last == 0 ? o.kw_inc0 : o.kw_inc);
+            if (D.dw > o.dw_max) break;
         }
-        if (!ok) { status = ST_ERROR; break; }
-        if (dw > 0) dw_last = dw;
-        const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
-        double amin, pw_th = 0, pw_gd = 0;
-        if (gd < 0) {
-            amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
-            pw_th = pow(th, o.s_theta); pw_gd = pow(-gd, o.s_phi);      // once per iteration (also the switching condition of every trial)
-            if (th <= th_min) amin = fmin(amin, o.delta * pw_th / pw_gd);
-        } else amin = o.gamma_theta;
-        amin *= o.gamma_alpha;
-        double alpha = sh.S.ap; int acc = 0;
-        while (alpha >= amin) {
-            PROF(sh.inst, PF_OTHER); ph_trial(alpha);
-            const double ft = sh.trial[0], tht = sh.trial[1], pht = ft - mu * sh.trial[2];
-            if (ft == ft && tht == tht && pht == pht && tht < th_max) {
-                int okf = 1;
-                for (int i = 0; i < nf && okf; i++) if (!(tht < sh.filt[i][0] || pht < sh.filt[i][1])) okf = 0;
+        if (!D.ok) { D.status = ST_ERROR; break; }
+        if (D.dw > 0) D.dw_last = D.dw;
+        {
+            const double th = A.th1, gd = sh.S.gd;
+            D.th = th; D.phi = A.f - D.mu * A.bar; D.gd = gd; D.az = sh.S.az; D.pw_th = 0; D.pw_gd = 0;
+            double amin;
+            if (gd < 0) {
+                amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
+                D.pw_th = pow(th, o.s_theta); D.pw_gd = pow(-gd, o.s_phi);      // once per iteration (also the switching condition of every trial)
+                if (th <= D.th_min) amin = fmin(amin, o.delta * D.pw_th / D.pw_gd);
+            } else amin = o.gamma_theta;
+            D.amin = amin * o.gamma_alpha;
+        }
+        D.alpha = sh.S.ap; D.acc = 0;
+        while (D.alpha >= D.amin) {
+            // the trial point z + alpha d goes to the second iterate buffer together with its assembly (mu as is, delta_w = 0: what the next iteration starts from)
+            PROF(sh.inst, PF_OTHER); ph_fused(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw);
+            const double ft = sh.An.f, tht = sh.An.th1, pht = ft - D.mu * sh.An.bar, alpha = D.alpha, th = D.th, phi = D.phi, gd = D.gd;
+            if (ft == ft && tht == tht && pht == pht && tht < D.th_max) {
+                int okf = 1; const int nf = D.nf;
+                for (int i = 0; i < nf && okf; i++) if (!(tht < filt_get(sh, st, i, 0) || pht < filt_get(sh, st, i, 1))) okf = 0;
                 if (okf) {
-                    int sw = gd < 0 && alpha * pw_gd > o.delta * pw_th;
-                    int armijo = pht <= phi + o.eta_phi * alpha * gd;
-                    if (th <= th_min && sw) { if (armijo) { acc = 1; break; } }
+                    const int sw = gd < 0 && alpha * D.pw_gd > o.delta * D.pw_th;
+                    const int armijo = pht <= phi + o.eta_phi * alpha * gd;
+                    if (th <= D.th_min && sw) { if (armijo) { D.acc = 1; break; } }
                     else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
-                        acc = 1;
+                        D.acc = 1;
                         if (!(sw && armijo) && nf < OB_FILT) {
-                            PAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
+                            PAR(lane) { if (lane == 0) { const double f0 = (1 - o.gamma_theta) * th, f1 = phi - o.gamma_phi * th;
+                                                         if (nf < OB_FILT_LDS) { sh.filt[nf][0] = f0; sh.filt[nf][1] = f1; } else { st[SL_FILT + 2 * nf] = f0; st[SL_FILT + 2 * nf + 1] = f1; } } }
                             SYNC();
-                            nf++;
+                            D.nf = nf + 1;
                         }
                         break;
                     }
                 }
             }
-            alpha *= 0.5;
+            D.alpha = 0.5 * alpha;
         }
-        if (!acc) { status = ST_ERROR; break; }   // IPOPT would enter restoration here
-        PROF(sh.inst, PF_OTHER); ph_apply(alpha, fmin(alpha, az), az, mu, o.kappa_sigma);
-        it++;
+        if (!D.acc) { D.status = ST_ERROR; break; }   // IPOPT would enter restoration here
+        // accepted: the trial buffer becomes the iterate, its assembly the current one
+        PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
+        LDS_SYNC();
+        D.have_asm = 1;
+        D.it++;
     }
-    sl.used += it + nreg - p_start;
-    R.status = status; R.iters = it; R.nreg = nreg; R.obj = f; R.pinf = pinf; R.dinf = dinf; R.mu = mu;
+    sl.used += D.it + D.nreg - D.p_start;
+    R.status = D.status; R.iters = D.it; R.nreg = D.nreg; R.obj = D.f; R.pinf = D.pinf; R.dinf = D.dinf; R.mu = D.mu;
 }
 
 // Full solve of one instance (pointers already in g_sh.inst): first attempt, and on Error/UserLimit one re-solve from the last
@@ -1642,34 +1599,36 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullp
     SYNC();
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
-    Slice sl = {st, mode == 1, st ? budget : 0, 0};
-    int att = 0, it_prev = 0, nreg_prev = 0;
-    if (mode == 1) { att = (int)st[SL_ATT]; it_prev = (int)st[SL_ITPREV]; nreg_prev = (int)st[SL_NREGPREV]; }
-    Result R; R.status = ST_ERROR; R.iters = 0; R.nreg = 0; R.obj = R.pinf = R.dinf = R.mu = 0;
-    int ef = 0, iters = 0, nreg = 0, retry = att;
-    if (att == 0) {
-        ipm_attempt(o, R, sl);
-        iters = R.iters; nreg = R.nreg;
-        if (R.status != ST_SUSPENDED) {
-            ef = (R.status == ST_OPTIMAL); retry = !ef;
-            if (retry && sh.c.dist && ph_ref_constraints(0)) { ef = 1; retry = 0; }
-            if (retry) { att = 1; it_prev = R.iters; nreg_prev = R.nreg; }
+    // (this function's own state lives in LDS as well -- Shared::sol -- for the reason given at ipm_attempt)
+    Sol &X = sh.sol;
+    X.home = sh.inst.z;
+    X.sl.st = st; X.sl.resume = mode == 1; X.sl.budget = budget; X.sl.used = 0;
+    X.att = 0; X.it_prev = 0; X.nreg_prev = 0;
+    if (mode == 1) { X.att = (int)st[SL_ATT]; X.it_prev = (int)st[SL_ITPREV]; X.nreg_prev = (int)st[SL_NREGPREV]; }
+    X.R.status = ST_ERROR; X.R.iters = 0; X.R.nreg = 0; X.R.obj = X.R.pinf = X.R.dinf = X.R.mu = 0;
+    X.ef = 0; X.iters = 0; X.nreg = 0; X.retry = X.att;
+    if (X.att == 0) {
+        ipm_attempt(o, X.R, X.sl);
+        X.iters = X.R.iters; X.nreg = X.R.nreg;
+        if (X.R.status != ST_SUSPENDED) {
+            X.ef = (X.R.status == ST_OPTIMAL); X.retry = !X.ef;
+            if (X.retry && sh.c.dist && ph_ref_constraints(0)) { X.ef = 1; X.retry = 0; }
+            if (X.retry) { X.att = 1; X.it_prev = X.R.iters; X.nreg_prev = X.R.nreg; }
         }
     }
-    if (retry && R.status != ST_SUSPENDED) {
-        Result R2;
-        ipm_attempt(o, R2, sl);
-        iters = it_prev + R2.iters; nreg = nreg_prev + R2.nreg;
-        if (R2.status == ST_OPTIMAL) ef = 1;
-        else if (R2.status != ST_SUSPENDED) { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); ef = sh.c.dist ? !feas : feas; }
-        R = R2;
+    if (X.retry && X.R.status != ST_SUSPENDED) {
+        ipm_attempt(o, X.R, X.sl);
+        X.iters = X.it_prev + X.R.iters; X.nreg = X.nreg_prev + X.R.nreg;
+        if (X.R.status == ST_OPTIMAL) X.ef = 1;
+        else if (X.R.status != ST_SUSPENDED) { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); X.ef = sh.c.dist ? !feas : feas; }
     }
-    if (R.status == ST_SUSPENDED) {
-        PAR(lane) { if (lane == 0) { st[SL_ATT] = att; st[SL_ITPREV] = it_prev; st[SL_NREGPREV] = nreg_prev; } }
-        ef = 0;
+    if (X.R.status == ST_SUSPENDED) {
+        PAR(lane) { if (lane == 0) { st[SL_ATT] = X.att; st[SL_ITPREV] = X.it_prev; st[SL_NREGPREV] = X.nreg_prev; } }
+        X.ef = 0;
     }
+    if (sh.inst.z != X.home) ph_bring_home();      // the accepted trial points alternate between the two iterate buffers; results and parked solves live in the instance's own
     PAR(lane) {
-        if (lane == 0) { info[0] = R.status; info[1] = iters; info[2] = R.obj; info[3] = R.pinf; info[4] = R.dinf; info[5] = R.mu; info[6] = nreg; info[7] = ef; }
+        if (lane == 0) { info[0] = X.R.status; info[1] = X.iters; info[2] = X.R.obj; info[3] = X.R.pinf; info[4] = X.R.dinf; info[5] = X.R.mu; info[6] = X.nreg; info[7] = X.ef; }
     }
     SYNC();
 }

@@ -11,17 +11,17 @@
 #include "../../obca_amd/csrc/obca_quad_solver.h"
 using namespace obca;
 
-struct Scratch { double *z, *d, *as, *rs, *oc, *traj; };
+struct Scratch { double *z, *zn, *d, *as, *rs, *oc, *traj; };
 static void alloc_scratch(int N, int len, Scratch &s) {
-    s.z = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
+    s.z = (double *)calloc(len, 8); s.zn = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
     s.as = (double *)calloc((size_t)(N + 1) * OB_AS, 8); s.rs = (double *)calloc((size_t)(N + 1) * OB_RS, 8);
     s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.traj = (double *)calloc((size_t)(N + 2) * 42, 8);
 }
-static void free_scratch(Scratch &s) { free(s.z); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.traj); }
+static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.traj); }
 
 static void setup(int N, const double *prob, Scratch &s) {
     Shared &sh = g_sh; Inst &I = sh.inst;
-    I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+    I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
     for (int i = 0; i < OB_HDR; i++) sh.hdr[i] = prob[i];
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
@@ -39,42 +39,51 @@ static void setup(int N, const double *prob, Scratch &s) {
 extern "C" {
 int emu_opts_size() { return (int)sizeof(Opts); }
 
-// one Newton direction at a full primal-dual point (oracle layout); returns inertia-ok
-int emu_newton(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau,
-               double *dout, double *aux /* dinf,pinf,cinf0,cinfmu,f,th1,bar,ap,az,gd */) {
+// one Newton direction at a full primal-dual point (oracle layout); returns inertia-ok.  alpha >= 0: the fused line-search step is run as well --
+// znext = the trial point z + alpha d with the new multipliers (ay = min(alpha, az)), aux[10..15] = f, th1, bar, dinf, pinf, cinf0 of ITS assembly
+static int newton_impl(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau,
+                       double *dout, double *aux, double alpha, double ks, double *znext) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zin, sizeof(double) * len);
     setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
-    AsmOut A;
-    if (sh.vmc == 0) assemble_obs<2>(I, sh, mu, dw, dc); else if (sh.vmc == 1) assemble_obs<OB_VMID>(I, sh, mu, dw, dc); else assemble_obs<OB_VMAX>(I, sh, mu, dw, dc);
-    assemble_stage(I, sh, mu, dw, dc, A);
+    AsmOut A; const FuseArgs nf = {0, 0, 0, 0, 0};
+    if (sh.vmc == 0) assemble_obs<2, 0>(I, sh, mu, dw, dc, nf); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0>(I, sh, mu, dw, dc, nf); else assemble_obs<OB_VMAX, 0>(I, sh, mu, dw, dc, nf);
+    assemble_stage<0>(I, sh, mu, dw, dc, nf, A);
     int ok = A.ok;
     StepOut S; S.ap = S.az = S.gd = 0;
     if (ok) ok = riccati_backward(I, sh, rho);
     if (ok) { direction_main(I, sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; }
-    if (ok) { if (sh.vmc == 0) direction_obs<2>(I, sh, mu, dw, dc, tau, S); else if (sh.vmc == 1) direction_obs<OB_VMID>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX>(I, sh, mu, dw, dc, tau, S); }
+    if (ok) { if (sh.vmc == 0) direction_obs<2, 1>(I, sh, mu, dw, dc, tau, S); else if (sh.vmc == 1) direction_obs<OB_VMID, 1>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX, 1>(I, sh, mu, dw, dc, tau, S); }
     memcpy(dout, s.d, sizeof(double) * len);
-    aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = A.cinfmu; aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
+    aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = cinf_mu(A, mu); aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
     aux[7] = S.ap; aux[8] = S.az; aux[9] = S.gd;
+    if (ok && alpha >= 0 && znext) {
+        const FuseArgs fa = {alpha, alpha < S.az ? alpha : S.az, S.az, ks, dw}; AsmOut An;
+        if (sh.vmc == 0) assemble_obs<2, 1>(I, sh, mu, 0.0, dc, fa); else if (sh.vmc == 1) assemble_obs<OB_VMID, 1>(I, sh, mu, 0.0, dc, fa); else assemble_obs<OB_VMAX, 1>(I, sh, mu, 0.0, dc, fa);
+        assemble_stage<1>(I, sh, mu, 0.0, dc, fa, An);
+        memcpy(znext, s.zn, sizeof(double) * len);
+        aux[10] = An.f; aux[11] = An.th1; aux[12] = An.bar; aux[13] = An.dinf; aux[14] = An.pinf; aux[15] = An.cinf0;
+    }
     free_scratch(s);
     return ok;
 }
-
-int emu_eval_trial(int N, const double *prob, const double *zin, const double *din, int len, double alpha, double *out3) {
-    Scratch s; alloc_scratch(N, len, s);
-    memcpy(s.z, zin, sizeof(double) * len); memcpy(s.d, din, sizeof(double) * len);
-    setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
-    if (sh.vmc == 0) eval_trial<2>(I, sh, alpha, out3[0], out3[1], out3[2]); else if (sh.vmc == 1) eval_trial<OB_VMID>(I, sh, alpha, out3[0], out3[1], out3[2]); else eval_trial<OB_VMAX>(I, sh, alpha, out3[0], out3[1], out3[2]);
-    free_scratch(s);
-    return 0;
+int emu_newton(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau,
+               double *dout, double *aux /* dinf,pinf,cinf0,cinfmu,f,th1,bar,ap,az,gd */) {
+    return newton_impl(N, prob, zin, len, mu, dw, dc, rho, tau, dout, aux, -1.0, 0.0, nullptr);
+}
+int emu_newton_fused(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau, double alpha, double ks,
+                     double *dout, double *aux /* 16 */, double *znext) {
+    return newton_impl(N, prob, zin, len, mu, dw, dc, rho, tau, dout, aux, alpha, ks, znext);
 }
 
 // full solve; zinit holds the primal warm start in the oracle layout (x,u,t,lam,mu; sl=0)
 int emu_solve(int N, const double *prob, const double *zinit, int len, const void *opts, double *zout, double *info) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zinit, sizeof(double) * len);
-    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
-    solve_instance(N, *(const Opts *)opts, info);
+    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+    double *st = (double *)calloc(SL_SIZE, 8);
+    solve_instance(N, *(const Opts *)opts, info, st);
+    free(st);
     memcpy(zout, s.z, sizeof(double) * len);
     free_scratch(s);
     return 0;
@@ -88,7 +97,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     int launches = 0;
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
-        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
         solve_instance(N, *(const Opts *)opts, info, st, mode, budget);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
@@ -147,7 +156,7 @@ int emu_quad_newton(int N, const double *prob, const double *zin, double mu, dou
     if (ok) quad::q_direction_obs(sh, mu, dw, dc, tau, S);
     aux[10] = fail;
     memcpy(dout, s.d, sizeof(double) * (l.n + l.m));
-    aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = A.cinfmu; aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
+    aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = cinf_mu(A, mu); aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
     aux[7] = S.ap; aux[8] = S.az; aux[9] = S.gd;
     q_free(s);
     return ok;

@@ -54,10 +54,23 @@ def test_emu_newton_direction_matches_oracle(oracle, emu, backwards, dist):
         if dist:
             assert np.abs(d[L["sl"]:L["so"]]).max() > 0       # the norm-row slack moves
         assert np.allclose(aux[:3], errs, rtol=1e-10)
-        # objective / constraint norm / barrier of eval_trial at alpha=0 equal the assembly's
-        out = np.zeros(3)
-        emu.emu_eval_trial(C.c_int(N), dp(prob), dp(z), dp(d2), C.c_int(L["len"]), C.c_double(0.0), dp(out))
-        assert np.allclose(out, aux[4:7], rtol=1e-12)
+        # the fused line-search step (trial point -> second iterate buffer, assembled there): at alpha = 0 the primal point and its f / th1 / bar are the assembly's;
+        # at alpha > 0 the trial point is z + alpha d with y + min(alpha, az) dy, and its assembly equals a stand-alone assembly of that point
+        for alpha in (0.0, 0.5 * min(aux[7], 1.0)):        # (aux[7]: the fraction-to-boundary step length)
+            aux2 = np.zeros(16); d3 = np.zeros_like(z); zn = np.zeros_like(z)
+            ok3 = emu.emu_newton_fused(C.c_int(N), dp(prob), dp(z), C.c_int(L["len"]), C.c_double(mu), C.c_double(dw), C.c_double(dc), C.c_double(1e3), C.c_double(0.99),
+                                       C.c_double(alpha), C.c_double(1e10), dp(d3), dp(aux2), dp(zn))
+            assert ok3 == 1 and np.array_equal(d3, d2)
+            npr = L["pi"]; ay = min(alpha, aux2[8])
+            assert np.abs(zn[:npr] - (z[:npr] + alpha * d2[:npr])).max() < 1e-14 * max(1.0, np.abs(zn[:npr]).max())
+            assert np.abs(zn[npr:nd] - (z[npr:nd] + ay * d2[npr:nd])).max() < 1e-14 * max(1.0, np.abs(zn[npr:nd]).max())      # (the kernel forms them with one rounding: fma)
+            if alpha == 0.0:
+                assert np.allclose(aux2[10:13], aux[4:7], rtol=1e-12)
+            d4 = np.zeros_like(z); aux3 = np.zeros(10)
+            emu.emu_newton(C.c_int(N), dp(prob), dp(zn), C.c_int(L["len"]), C.c_double(mu), C.c_double(0.0), C.c_double(dc), C.c_double(1e3), C.c_double(0.99), dp(d4), dp(aux3))
+            assert np.allclose(aux2[10:13], aux3[4:7], rtol=1e-13, atol=0) and np.allclose(aux2[13:16], aux3[0:3], rtol=1e-12)
+            # bound multipliers of the trial point: z + az dz, clamped to [mu / (ks s), ks mu / s] (ks = 1e10: not active here)
+            assert (zn[nd:] > 0).all()
 
 
 @pytest.mark.parametrize("dist,N", [(0, 20), (1, 20), (0, 21), (0, 99)], ids=["signed_dist", "dist", "odd_horizon", "beyond_the_composed_pairs"])
