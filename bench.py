@@ -21,14 +21,16 @@ last instance leaves the GPU idle for half of its duration.  After the timed reg
 steps (one launch alone on the GPU, HIP events on the launch stream): that is the per-launch kernel time the roofline is computed from.
 
 Extra objects in the JSON line:
-  roofline     : dominant kernel (obca_parking_ipm_kernel / obca_quad_ipm_kernel).  SURVEY 8d Model B ("condensed variant: compute /
-                 latency-bound on fp64 VALU; HBM bytes = I/O only"): achieved = EXECUTED fp64 flops of one launch (F_PASS x the passes the
-                 kernel reports) / the launch's HIP-event duration; peak = 78.6 TFLOP/s (MI355X fp64 vector = fp64 matrix peak); no MFMA
-                 instruction is issued by the parking kernel.  Also reported, separately named: `streamed_model_gbs` (the per-pass HBM
-                 streaming model of DESIGN.md section 5 / that duration), `pipelined_*` (the same work / the wall time per step of the
-                 pipelined region: a device-utilisation figure, not a kernel roofline) and `traffic` (PMC bytes per launch from the
-                 committed rocprofv3 pass of `bench.py --streams 1 --steps 1` named in `traffic_source` -- not collected in this run).
-  cpu_baseline : the CPU oracle (C restatement, NOT IPOPT) on a bounded sample of the same instances, on the box's host cores.
+  roofline     : dominant kernel (obca_parking_ipm_kernel / obca_quad_ipm_kernel), one launch alone on the GPU, HIP events on its stream.  Two fractions are formed and
+                 `bound` names the larger one: "hbm" = ALGORITHMIC bytes of the launch (the per-pass streaming model of DESIGN.md section 5 -- every array of the
+                 per-instance state times the number of times a factorisation pass reads / writes it -- x the passes the kernel reports) / the launch time / 8 TB/s;
+                 "mfma" = executed fp64 flops (SURVEY 8d Model B) / the launch time / 78.6 TFLOP/s (fp64 vector = fp64 matrix peak).  `traffic` = HBM bytes of one launch
+                 measured in THIS run: bench.py re-runs itself once per counter under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace` (separate passes,
+                 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); null if rocprofv3 is not available (`--no-pmc` skips it).
+                 `pipelined_*` relate the same work to the wall time per pipelined step (device utilisation, not a kernel roofline).
+  cpu_baseline : the CPU oracle (C restatement, NOT IPOPT; gcc -O3 -march=native) on a bounded sample of the same instances, on the box's host cores.
+  config       : besides the workload, what a caller of the drop-in sees (never `value`): `host_pointer_solves_per_s` = obca_parking_signed_dist_batch on 16 384
+                 host-array instances, PCIe and (un)packing included (what a Julia ccall gets), `single_batch_sync_solves_per_s` = one batch issued and waited for.
 """
 import argparse
 import json
@@ -59,37 +61,61 @@ CONFIGS = {
 def f_pass_parking(N, blocks_per_stage):
     """executed-algorithm fp64 flops per factorisation pass of one parking instance (SURVEY 8d Model B): (stage, obstacle)
     blocks x (700 condense + 600 back-substitute) + stages x 3000 (bicycle Hessians, costs) + Riccati backward N x 3500 + closed loop / forward
-    N x 400 + line-search evaluations (111 per block + 1 per ... ~27e3 at N=80 / 3 obstacles)"""
+    N x 400 + trial-point formation (60 per block, 150 per stage)"""
     nb = (N + 1) * blocks_per_stage
     return nb * 1300 + (N + 1) * 3000 + N * 3500 + N * 400 + nb * 60 + (N + 1) * 150
 
 
 def b_pass_parking(N, nOb, M):
-    """per-pass HBM streaming model of DESIGN.md section 5 (iterate, direction, stage / Riccati / obstacle records streamed a fixed number of times
-    per pass), scaled from the measured N=80 / 3 obstacles / 5 rows layout (56.5k doubles read + 29.55k written)"""
-    zlen = lambda n, no, m: 28 * n + 22 + (2 * m + 19 * no) * (n + 1)
-    return (56500 + 29550) * 8.0 * (zlen(N, nOb, M) + 204 * (N + 1) + 12 * nOb * (N + 1)) / (zlen(80, 3, 5) + 204 * 81 + 12 * 3 * 81)
+    """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-3 kernel.  Per (stage, obstacle)
+    block: iterate part zb = 2 v + 15 doubles (lambda, mu, sl, slack, their multipliers), step db = v + 10, condensed record 12.  Per stage: iterate part 26, step 8,
+    stage record 88, Riccati record 72, reference 3.  A pass streams: direction_obs zb (read) + db (write); fused line search zb + db (read), zb + 12 (write), per stage
+    26 + 8 + 12 nOb + 3 (read), 26 + 88 (write); backward sweep 88 (read) + 72 (write); forward sweep / back-substitution 48 + 21 + 72 + 7 (read) + 8 (write); plus 0.16
+    stand-alone assemblies per pass (first iterate, barrier updates, inertia retries)."""
+    N1 = N + 1
+    zb = 2.0 * M + 15.0 * nOb; db = 1.0 * M + 10.0 * nOb           # per stage, all obstacles
+    rd = N1 * (zb + (zb + db) + (26 + 8 + 12 * nOb + 3) + 88 + (48 + 21 + 72 + 7))
+    wr = N1 * (db + (zb + 12 * nOb) + (26 + 88) + 72 + 8)
+    asm = 0.16 * N1 * ((zb + 26 + 12 * nOb) + (12 * nOb + 88))
+    return 8.0 * (rd + wr + asm)
 
 
 F_PASS_QUAD = 60 * 33000 + 305 * 2400 + 61 * 2500 + 1.0e5   # Riccati 16-state sweep + 305 box blocks + stage derivatives + trial evaluations (DESIGN.md section 9)
 
 
-def committed_pmc_traffic(kernel, tag=""):
-    """HBM bytes PER LAUNCH of `kernel` from the committed rocprofv3 --pmc passes of `bench.py --streams 1 --steps 1 --sync-steps 1` (profiles/r02_pmc_*.csv,
-    FETCH_SIZE and WRITE_SIZE in separate passes): 2 x FETCH_SIZE + WRITE_SIZE, KiB units, averaged over the launches in the trace.  The factor 2 and what the
-    counters see were calibrated this round (tools/micro/fetch_calib.hip, profiles/r02_pmc_calib_*.csv): FETCH_SIZE reports half the bytes of wide, of coalesced
-    8-byte and of one-double-per-128-byte-line loads alike (i.e. whole 128-byte lines), does NOT count re-reads served by the Infinity Cache (a 64 MiB buffer read
-    8 times counts once), WRITE_SIZE is exact for streaming stores and counts 32 bytes per isolated 8-byte store.  NOT collected in this run."""
-    import csv
-    try:
-        vals = {}; cnt = {}
-        for name, fn in (("FETCH_SIZE", f"r02_pmc_{tag}fetch_size.csv"), ("WRITE_SIZE", f"r02_pmc_{tag}write_size.csv")):
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
-                if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == name:
-                    vals[name] = vals.get(name, 0.0) + float(r["Counter_Value"]) * 1024.0; cnt[name] = cnt.get(name, 0) + 1
-        return 2.0 * vals["FETCH_SIZE"] / cnt["FETCH_SIZE"] + vals["WRITE_SIZE"] / cnt["WRITE_SIZE"], f"profiles/r02_pmc_{tag}fetch_size.csv + r02_pmc_{tag}write_size.csv (committed rocprofv3 --pmc passes of this command, not this run)"
-    except Exception:
-        return None, None
+def live_pmc_traffic(kernel, cfg, batch):
+    """HBM bytes PER LAUNCH of `kernel`, measured now: this script is run again, once per counter, under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass on gfx950) in its `--pmc-child` mode -- the same batch, one step + one synchronous step, nothing else.  Returns (bytes, note) with
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2: FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950, MI355X_MICROARCH.md / HBM, calibrated
+    for 8-byte gathers by tools/micro/fetch_calib.hip), averaged over the launches of the child; (None, reason) if rocprofv3 cannot be run."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="obca_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--config", str(cfg), "--batch", str(batch)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            tot = n = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] == ctr:
+                        tot += float(r["Counter_Value"]) * 1024.0; n += 1
+            if n == 0:
+                return None, f"no {ctr} rows for {kernel} in the rocprofv3 output"
+            vals[ctr] = tot / n
+        except Exception as e:      # noqa: BLE001 -- the bench line must not depend on the profiler
+            return None, f"rocprofv3 --pmc {ctr} failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) around "
+                                                            "`bench.py --pmc-child`, 2 x FETCH_SIZE + WRITE_SIZE per launch")
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle = test infrastructure, used here only as the timed CPU leg)
@@ -113,7 +139,8 @@ def cpu_baseline():
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    O.build()
+    os.environ["OBCA_ORACLE_NATIVE"] = "1"      # the workers time the -O3 -march=native build, compiled here on the machine that runs it
+    O.build_native()
     cores = min(os.cpu_count() or 1, 64)
     per = 256
     n = per * cores
@@ -124,21 +151,39 @@ def cpu_baseline():
     wall = time.perf_counter() - t0
     ok = sum(r[0] for r in res); its = sum(r[1] for r in res)
     busy = max(r[2] for r in res)
+    os.environ.pop("OBCA_ORACLE_NATIVE", None)
     return dict(value=round(ok / busy, 2), unit="solves/s", cores=cores, kind="port",
                 sample=f"{n} instances of the config-2 distribution (seed 20260925+1000k), {per} per core, one oracle/obca_oracle.c solve at a time per core "
-                       f"(CPU restatement of the reference's IPOPT path, not IPOPT itself); "
+                       f"(CPU restatement of the reference's IPOPT path, not IPOPT itself; gcc -O3 -march=native); "
                        f"{ok}/{n} converged, mean {its / n:.1f} iterations, wall {wall:.1f}s")
 
 
 # ---------------------------------------------------------------- batch generation (rank 0) and the scatter
-def make_host_batch(cfg, B, seed, hybrid=False):
-    """the whole job's batch as a dict of (B, K) float64 arrays + the shared scalars"""
-    from obca_amd import scenarios as S
+def needs_planner(cfg, hybrid):
+    return cfg in (3, 4) or (cfg == 2 and hybrid)
+
+
+def make_host_batch(cfg, B, seed, hybrid=False, world=1):
+    """The whole job's batch on rank 0, as a dict of (B, K) float64 arrays + the shared scalars.  Configs whose warm starts come from a planner (Hybrid A* / 3-D A*: the
+    step before the path, host side) only carry the problem DEFINITIONS here (start / goal poses): every rank plans the warm starts of its own slice after the scatter
+    (complete_rows), on its share of the host cores -- rank 0 planning 16 384 parallel-parking paths would take minutes while the other ranks wait.  Config 5's unequal
+    instances are dealt to the ranks by (nOb, M) buckets, round-robin (sharding.balanced_permutation)."""
+    from obca_amd import scenarios as S, sharding
     c = CONFIGS[cfg]; N = c["N"]
-    if c["kind"] == "quad":
+    if needs_planner(cfg, hybrid) and world > 1:
+        rng = np.random.default_rng(seed)
+        if c["kind"] == "quad":
+            x0 = np.tile(S.QUAD_X0, (B, 1)); xF = np.tile(S.QUAD_XF, (B, 1))
+            for i in range(1, B):
+                x0[i, :3], xF[i, :3] = S._draw_quad_endpoints(rng)
+            return dict(x0=x0, xF=xF), dict(R=S.QUAD_R, ob=S.QUAD_OB.copy())
+        sc = S.BACKWARDS if cfg == 2 else S.PARALLEL
+        x0, xF = S.sample_poses(sc, B, rng, goal_jitter=(cfg == 3))
+        A, b, v = S.scenario_hrep(sc)
+        return dict(x0=x0, xF=xF), dict(L=S.L_WHEELBASE, ego=S.EGO.copy(), XYbounds=S.XYBOUNDS.copy(), vOb=v, A=A, b=b)
+    if c["kind"] == "quad":      # (single rank: planned here, in one random stream -- the batch the GPU parity tests use)
         q = S.make_quad_batch(B, N, seed=seed, random_endpoints=True)
-        rows = dict(x0=q["x0"], xF=q["xF"], Ts=np.full((B, 1), q["Ts"]), timeWS=np.full((B, 1), q["timeWS"]), xWS=q["xWS"].reshape(B, -1))
-        return rows, dict(R=q["R"], ob=q["ob"])
+        return dict(x0=q["x0"], xF=q["xF"], Ts=np.full((B, 1), q["Ts"]), timeWS=np.full((B, 1), q["timeWS"]), xWS=q["xWS"].reshape(B, -1)), dict(R=q["R"], ob=q["ob"])
     if cfg == 2:
         bt = S.make_batch(S.BACKWARDS, B, N, seed=seed, planner=True, smooth=True) if hybrid else S.make_batch(S.BACKWARDS, B, N, seed=seed)
     elif cfg == 3:
@@ -153,9 +198,30 @@ def make_host_batch(cfg, B, seed, hybrid=False):
         for i in range(B):
             v = np.ravel(bt["vOb"][i]); vo[i, :len(v)] = v; Aa[i, :2 * v.sum()] = np.ravel(bt["A"][i]); bb[i, :v.sum()] = np.ravel(bt["b"][i])
         rows.update(vOb=vo, A=Aa, b=bb)
+        if world > 1:
+            perm, _ = sharding.balanced_permutation((vo > 0).sum(1) * 100 + vo.sum(1), world)
+            rows = {k: v_[perm] for k, v_ in rows.items()}
     else:
         shared.update(vOb=bt["vOb"], A=bt["A"], b=bt["b"])
     return rows, shared
+
+
+def complete_rows(cfg, rows, shared, seed, rank, world, hybrid=False):
+    """every rank: the planner-made warm starts of ITS slice (spawned worker processes on 1 / world of the host cores; a pose without a path is re-drawn locally)"""
+    if not needs_planner(cfg, hybrid) or world == 1:
+        return rows
+    from obca_amd import scenarios as S
+    N = CONFIGS[cfg]["N"]; n = rows["x0"].shape[0]
+    rng = np.random.default_rng(seed + 1000003 * (rank + 1))
+    x0 = np.array(rows["x0"]); xF = np.array(rows["xF"])
+    if CONFIGS[cfg]["kind"] == "quad":
+        xWS = S.plan_quad_batch(x0, xF, N, rng, first_is_fixed=(rank == 0))
+        return dict(x0=x0, xF=xF, Ts=np.full((n, 1), S.quad_sample_time(N)), timeWS=np.full((n, 1), 1.0), xWS=xWS.reshape(n, -1))
+    sc = S.BACKWARDS if cfg == 2 else S.PARALLEL
+    workers = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    Ts, xWS, uWS = S.plan_batch(sc, x0, xF, N, rng, planner=True, workers=workers, smooth=(cfg == 2))
+    xWS = xWS.copy(); xWS[:, 0, :] = x0
+    return dict(x0=x0, xF=xF, Ts=Ts.reshape(n, 1), xWS=xWS.reshape(n, -1), uWS=uWS.reshape(n, -1))
 
 
 def scatter_job(rows, shared, B_total, rank, world, dist, backend):
@@ -200,7 +266,12 @@ def main():
     ap.add_argument("--warm-start", default="primitive", choices=["primitive", "hybrid"], help="config 2 only: line/arc/line primitives (default) or the reference's "
                     "pipeline main.jl:216-248 -- Hybrid A* path, velocity smoother, resampling (planned on the host cores before the timed region)")
     ap.add_argument("--seed-offset", type=int, default=0, help="diagnostic: shift the seed of the job's batch")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-host-rate", action="store_true", help="skip the host-pointer (PCIe-inclusive) call behind config.host_pointer_solves_per_s")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: the run rocprofv3 wraps (one step + one synchronous step of the same batch, no output)")
     a = ap.parse_args()
+    if a.pmc_child:
+        a.steps, a.warmup, a.streams, a.sync_steps, a.no_cpu_baseline, a.no_pmc, a.no_host_rate = 1, 0, 1, 1, True, True, True
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if a.steps < 1:
@@ -212,7 +283,7 @@ def main():
     rows = shared = None
     B = a.batch or C["per_gpu"]; B_total = B * world
     if rank == 0:
-        rows, shared = make_host_batch(cfg, B_total, SEED + a.seed_offset, hybrid=(a.warm_start == "hybrid"))      # (config 3 / 4 plan their warm starts on the host cores here, before HIP is up)
+        rows, shared = make_host_batch(cfg, B_total, SEED + a.seed_offset, hybrid=(a.warm_start == "hybrid"), world=world)
     import torch
     import obca_amd
     from obca_amd import sharding, validate as V
@@ -228,6 +299,7 @@ def main():
             torch.cuda.set_device(local)
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     rows, shared = scatter_job(rows, shared, B_total, rank, world, dist, a.backend)
+    rows = complete_rows(cfg, rows, shared, SEED + a.seed_offset, rank, world, hybrid=(a.warm_start == "hybrid"))
     lo, hi = sharding.shard_range(B_total, rank, world); n = hi - lo
     assert n == B and rows["x0"].shape[0] == B
     nS = max(1, a.streams)
@@ -267,15 +339,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     # ---- per-launch kernel time: synchronous steps of copy 0, one launch alone on the GPU, HIP events on the launch stream (outside the timed region)
-    ipm_ms, dws_ms = [], []
+    ipm_ms, dws_ms, sync_s = [], [], []
     for k in range(max(1, a.sync_steps)):
-        batches[0].solve(sync=True)
+        ts0 = time.perf_counter(); batches[0].solve(sync=True); sync_s.append(time.perf_counter() - ts0)
         m = batches[0].kernel_ms()
         if quad:
             ipm_ms.append(m)
         else:
             ipm_ms.append(m[0]); dws_ms.append(m[1])
     fence()
+    if a.pmc_child:
+        return
+    # ---- what a caller of the drop-in gets (outside the timed region, never `value`): the host-pointer entry point on 16 384 host-array instances, PCIe included
+    host_rate = None
+    if rank == 0 and world == 1 and not quad and not a.no_host_rate:
+        reps = max(1, 16384 // B); tile = lambda x: np.concatenate([np.asarray(x)] * reps, axis=0)
+        hv, hA, hb = (vOb * reps, A * reps, b * reps) if cfg == 5 else (vOb, A, b)
+        hx = tile(xWS); keep = {}; best = None
+        for rep_ in range(3):       # the caller keeps its output arrays between calls (fresh ones cost a page fault per 4 KB inside the C call)
+            th0 = time.perf_counter()
+            ho = obca_amd.parking_signed_dist_batch(tile(rows["x0"]), tile(rows["xF"]), N, tile(rows["Ts"][:, 0]), shared["L"], shared["ego"], shared["XYbounds"], hv, hA, hb,
+                                                    hx[:, :, 0], hx[:, :, 1], hx[:, :, 2], 0, hx, tile(uWS), device=local, buffers=keep)
+            th = time.perf_counter() - th0; best = th if best is None else min(best, th)
+        host_rate = dict(instances=B * reps, solves_per_s=round(int((ho["exitflag"] == 1).sum()) / best, 1), seconds=round(best, 4), c_call_seconds=round(float(ho["time"]), 4))
     # ---- results: every copy solved the same inputs and must hold the same bits
     outs = [bq.download() for bq in batches[:min(nS, a.steps + a.warmup)]]
     out = outs[0]
@@ -343,25 +429,34 @@ def main():
                 f_pass = f_pass_parking(N, len(np.ravel(vOb))); b_pass = b_pass_parking(N, len(np.ravel(vOb)), int(np.sum(vOb)))
             kernel = "obca_parking_ipm_kernel"
         tflops = passes0 * f_pass / (k_ms * 1e-3) / 1e12
-        traffic, tsrc = committed_pmc_traffic(kernel, "" if cfg == 2 else "quad_") if (cfg in (2, 4) and B == 1024) else (None, None)
-        roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5),
+        traffic, tsrc = (None, "skipped (--no-pmc)") if a.no_pmc or world > 1 else live_pmc_traffic(kernel, cfg, B)
+        fp64_frac = tflops / FP64_PEAK_TFLOPS
+        gbs = passes0 * b_pass / (k_ms * 1e-3) / 1e9 if b_pass is not None else None
+        hbm_frac = gbs / HBM_PEAK_GBS if gbs is not None else None
+        hbm_binds = hbm_frac is not None and hbm_frac >= fp64_frac
+        roof = {"bound": "hbm" if hbm_binds else "mfma",
+                "achieved": round(gbs, 1) if hbm_binds else round(tflops, 3), "peak": HBM_PEAK_GBS if hbm_binds else FP64_PEAK_TFLOPS, "unit": "GB/s" if hbm_binds else "TFLOP/s",
+                "frac": round(hbm_frac if hbm_binds else fp64_frac, 5),
                 "traffic": traffic, "traffic_source": tsrc,
-                "bound_detail": "fp64 arithmetic of the executed algorithm (SURVEY 8d Model B: the condensed KKT solve is compute / latency bound, HBM carries I/O only); "
-                                "peak = MI355X fp64 vector peak = fp64 matrix (MFMA) peak, 78.6 TFLOP/s",
+                "bound_detail": "two fractions of one launch alone on the GPU, the larger one is reported: hbm = algorithmic bytes (per-pass streaming model of the per-instance state, "
+                                "DESIGN.md section 5, x passes) / launch time / 8 TB/s; mfma = executed fp64 flops (SURVEY 8d Model B) / launch time / 78.6 TFLOP/s (fp64 vector = matrix peak; "
+                                "the parking kernel issues no MFMA).  Neither roof binds a LONE launch: it ends with its slowest instance (3-4 x the mean number of passes) and the sweeps of an "
+                                "instance are chains of dependent LDS round trips; see pipelined_* for the device under the pipelined load `value` is measured at",
+                "fp64_tflops": round(tflops, 3), "fp64_frac": round(fp64_frac, 5),
+                "hbm_algorithmic_gbs": round(gbs, 1) if gbs is not None else None, "hbm_algorithmic_frac": round(hbm_frac, 5) if hbm_frac is not None else None,
                 "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_ms_all": [round(x, 3) for x in ipm_ms],
                 "kernel_timing": "HIP events on the launch stream around the interior-point launches of ONE synchronous step of rank 0's batch, measured in this process after the "
                                  "timed region (median of %d); nothing else runs on the GPU" % len(ipm_ms),
-                "passes_per_launch": int(passes0), "flops_per_pass_model": f_pass,
-                "pipelined_tflops": round(passes0 * f_pass / (dt / a.steps) / 1e12, 3), "pipelined_frac": round(passes0 * f_pass / (dt / a.steps) / 1e12 / FP64_PEAK_TFLOPS, 5),
+                "passes_per_launch": int(passes0), "flops_per_pass_model": f_pass, "bytes_per_pass_model": b_pass,
+                "pipelined_tflops": round(passes0 * f_pass / (dt / a.steps) / 1e12, 3), "pipelined_fp64_frac": round(passes0 * f_pass / (dt / a.steps) / 1e12 / FP64_PEAK_TFLOPS, 5),
                 "pipelined_note": "the same work / (timed wall time / steps) with %d steps in flight: device utilisation of the timed region, not a kernel roofline" % nS}
-        if traffic is not None:     # measured HBM bytes (committed PMC passes) over the kernel time / the pipelined step time of THIS run
+        if b_pass is not None:
+            roof.update(pipelined_hbm_algorithmic_gbs=round(passes0 * b_pass / (dt / a.steps) / 1e9, 1), pipelined_hbm_algorithmic_frac=round(passes0 * b_pass / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5))
+        if traffic is not None:     # measured HBM bytes of one launch over the kernel time / the pipelined step time of THIS run
             roof.update(hbm_measured_gbs_one_launch=round(traffic / (k_ms * 1e-3) / 1e9, 1), hbm_measured_frac_one_launch=round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         hbm_measured_gbs_pipelined=round(traffic / (dt / a.steps) / 1e9, 1), hbm_measured_frac_pipelined=round(traffic / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                        hbm_measured_note="PMC bytes per launch / kernel time, and / wall time per pipelined step: the kernels stream their per-instance state through HBM "
-                                          "(it does not fit LDS), so this -- not the fp64 fraction -- is the roof the pipelined rate runs into (DESIGN.md section 5)")
-        if b_pass is not None:
-            roof.update(streamed_model_gbs=round(passes0 * b_pass / (k_ms * 1e-3) / 1e9, 1), streamed_model_frac_of_hbm=round(passes0 * b_pass / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        streamed_model_note="per-pass streaming model of DESIGN.md section 5 (%.3g bytes per pass), NOT a SURVEY 8d quantity and not measured" % b_pass)
+                        traffic_over_algorithmic=round(traffic / (passes0 * b_pass), 3) if b_pass is not None else None)
+        if not quad:
             sched = batches[0].last_schedule()
             roof.update(ipm_launches_per_step=sched[0], slice_passes=sched[1], dualws_kernel_ms=round(float(np.median(dws_ms)), 3))
         line = {
@@ -373,7 +468,11 @@ def main():
                                    f"gathered on rank 0 (one gather) and validated there; no collective inside the timed region",
                        "streams": nS, "timed_region_s": round(dt, 3), "converged": conv_all, "exitflag_ok": conv_flag, "instances": B_total,
                        "exitflag2": int((ef == 2).sum()), "copies_bit_identical": bool(same), "mean_iterations": round(float(iters.mean()), 2), "max_iterations": int(iters.max()),
-                       "p95_iterations": float(np.percentile(iters, 95)), "mean_passes": round(passes_all / B_total, 2)},
+                       "p95_iterations": float(np.percentile(iters, 95)), "mean_passes": round(passes_all / B_total, 2),
+                       "single_batch_sync_solves_per_s": round(conv_all / world / float(np.median(sync_s)), 1),
+                       "single_batch_sync_note": "one batch issued and waited for (reset + DualMultWS + interior point, inputs resident): what a caller without several batches in flight gets",
+                       "host_pointer": host_rate,
+                       "host_pointer_note": "obca_parking_signed_dist_batch on host arrays (the entry point the Julia shim binds): packing, PCIe both ways, kernels, unpacking; never `value`"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -181,13 +181,15 @@ struct Drv {                // state of the interior-point driver (wave-uniform;
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
-struct Shared {
+struct alignas(16) Shared {
     double hdr[OB_HDR];
-    double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];
-    double Bm[36], sB[24], s[2][8], coef[8], cl[2][48];
-    double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
+    // Riccati backward sweep.  Every operand of its dot products is a CONTIGUOUS, 16-byte aligned 6-vector (P rows, the rows of the transposed FA', T', p'), read as three
+    // ds_read_b128: a lone wavefront per SIMD issues 8-byte LDS reads at a fifth of the LDS rate but 16-byte reads at the full rate (MI355X_MICROARCH.md, LDS).
+    alignas(16) double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];     // P (row-major, symmetric), p' (pn[c * 6 + a]: right-hand side c, state a), Qhat (8 x 14 row-major)
+    alignas(16) double Bm[36], sB[24], coef[8], TT[14 * 6];     // border constants, their static parts, (dt, nu), T' (TT[cc * 6 + a])
+    alignas(16) double zero6[6]; double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
     double filt[OB_FILT_LDS][2];
-    Drv drv; Sol sol;
+    Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
@@ -201,10 +203,10 @@ struct Shared {
 #define OB_DYN_LDS_DOUBLES(N) ((size_t)((N) + 2) * 6 + ((size_t)((N) / 2 + 1) * 42 > 2 * OB_STG ? (size_t)((N) / 2 + 1) * 42 : (size_t)2 * OB_STG))
 #ifdef OBCA_EMU
 static Shared g_sh;
-static double g_traj[OB_DYN_LDS_DOUBLES(OB_NMAX)];
+alignas(16) static double g_traj[OB_DYN_LDS_DOUBLES(OB_NMAX)];
 #else
 __shared__ Shared g_sh;     // the static LDS block of the workgroup (= one wavefront = one problem instance)
-extern __shared__ double g_traj[];
+extern __shared__ __attribute__((aligned(16))) double g_traj[];
 #endif
 
 OBCA_FN double *stg_base(const Shared &sh) { return g_traj + (size_t)(sh.c.N + 2) * 6; }     // stage buffers of the backward sweep / pair maps of the forward sweep
@@ -727,7 +729,7 @@ OBCA_FN void pair_of(int p, int &a_, int &b_) {   // p-th pair (a<=b) of the 6 c
     b_ = p - (6 * a_ - a_ * (a_ - 1) / 2) + a_;
 }
 
-// unpacked stage data in LDS (one of two buffers): H (8x8 full), FA = [Fm | off] (6x14), hc (8x6)
+// unpacked stage data in LDS (one of two buffers): H (8x8 full), FA' = [Fm | off]' (14x6: FA'[cc * 6 + a]), hc (8x6)
 #define SG_H 0
 #define SG_FA 64
 #define SG_HC 148
@@ -741,7 +743,7 @@ OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &k
     idx = AS_DD; fl = 0.0; kc = 0.0; dst = SG_SIZE;              // default: harmless gather, store to the pad slot behind the buffer
     if (it < 64) { idx = AS_H + hidx(it >> 3, it & 7); fl = 1.0; dst = SG_H + it; }
     else if (it < 64 + 84) {
-        const int e = it - 64, a_ = e / 14, cc = e % 14; dst = SG_FA + e;
+        const int e = it - 64, a_ = e / 14, cc = e % 14; dst = SG_FA + cc * 6 + a_;      // FA is staged TRANSPOSED: row cc of FA' = column cc of FA, contiguous
         if (cc < 8) {
             if (a_ < 4) {
                 if (cc < 4) kc = (a_ == cc) ? 1.0 : 0.0;
@@ -800,32 +802,32 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
 // (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
 // memory operation the compiler's in-order vmcnt bookkeeping stays exact and old gathers retire without draining the younger ones.
 struct RicItem {      // offsets in doubles from the start of Shared
-    int a_a, a_as, a_b, a_bs, a_i, a_d, a_sg;      // phase A: operand A (offset, stride), operand B, initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
-    int b_a, b_as, b_b, b_bs, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
+    int a_a, a_b, a_i, a_d, a_sg;      // phase A: the two operand vectors (6 contiguous doubles each), initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
+    int b_a, b_b, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
     int c_x6, c_x7, c_col, c_base, c_s1, c_s2, c_d1, c_d2, c_rv, c_rk0, c_rk1;   // phase C: see riccati_stage
 };
 #define RIC_IPL 2       // items per lane and phase: 96 / 124 / 93 items over 64 lanes
 struct RicPlan { RicItem it[RIC_IPL]; };
 OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {     // `lane` = item number 0..127
     const double *L = (const double *)&sh;
-    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.cl[0] - L),
-              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oD = (int)(&sh.dump - L);
-    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + sum_b P[a][b] FA[b][cc]   (items 0..83);  u2[m][b] = sum_i FA[i][8+m] p[i][b]   (items 84..95; rows 4, 5 of the off columns are 0)
-    p.a_a = oZ; p.a_as = 0; p.a_b = oZ; p.a_bs = 0; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
-    if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_as = 1; p.a_b = oSG + SG_FA + cc; p.a_bs = 14; p.a_sg = 2;
-                     p.a_i = cc < 8 ? oZ : opn + a_ * OB_NC + (cc - 8); p.a_d = oT + lane; }
-    else if (lane < 96) { const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; p.a_a = oSG + SG_FA + 8 + m; p.a_as = 14; p.a_sg = 1; p.a_b = opn + b_; p.a_bs = OB_NC; p.a_d = osB + 12 + m * 6 + b_; }
-    // B: Qhat[i][cc] = [H | hc][i][cc] + sum_a FA[a][i] T[a][cc]   (items 0..111);  u1[m][b] = sum_i FA[i][8+m] T[i][8+b]   (items 112..123)
-    p.b_a = oZ; p.b_as = 0; p.b_b = oZ; p.b_bs = 0; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
-    if (lane < 112) { const int i = lane / 14, cc = lane % 14; p.b_a = oSG + SG_FA + i; p.b_as = 14; p.b_b = oT + cc; p.b_bs = 14; p.b_sg = 1 | 4;
+    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.TT - L),
+              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oZ6 = (int)(sh.zero6 - L), oD = (int)(&sh.dump - L);
+    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + P[a][:] . FA[:][cc]   (items 0..83; stored as T'[cc][a]);  u2[m][b] = FA[:][8+m] . p[:][b]   (items 84..95; rows 4, 5 of the off columns are 0)
+    p.a_a = oZ6; p.a_b = oZ6; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
+    if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2;
+                     p.a_i = cc < 8 ? oZ : opn + (cc - 8) * 6 + a_; p.a_d = oT + cc * 6 + a_; }
+    else if (lane < 96) { const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; p.a_a = oSG + SG_FA + (8 + m) * 6; p.a_sg = 1; p.a_b = opn + b_ * 6; p.a_d = osB + 12 + m * 6 + b_; }
+    // B: Qhat[i][cc] = [H | hc][i][cc] + FA[:][i] . T[:][cc]   (items 0..111);  u1[m][b] = FA[:][8+m] . T[:][8+b]   (items 112..123)
+    p.b_a = oZ6; p.b_b = oZ6; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
+    if (lane < 112) { const int i = lane / 14, cc = lane % 14; p.b_a = oSG + SG_FA + i * 6; p.b_b = oT + cc * 6; p.b_sg = 1 | 4;
                       p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + lane; }
-    else if (lane < 124) { const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; p.b_a = oSG + SG_FA + 8 + m; p.b_as = 14; p.b_sg = 1; p.b_b = oT + 8 + b_; p.b_bs = 14; p.b_d = osB + m * 6 + b_; }
+    else if (lane < 124) { const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; p.b_a = oSG + SG_FA + (8 + m) * 6; p.b_sg = 1; p.b_b = oT + (8 + b_) * 6; p.b_d = osB + m * 6 + b_; }
     // C: value = base + (X6 n0 + X7 n1) / det + s1 + s2 with (n0, n1) = adj(Quu) applied to column c_col of rows 6, 7 of Qhat
-    //    items 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry);  items 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
+    //    items 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry; p is stored transposed);  items 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
     p.c_x6 = oZ; p.c_x7 = oZ; p.c_col = 0; p.c_base = oZ; p.c_s1 = oZ; p.c_s2 = oZ; p.c_d1 = oD; p.c_d2 = oD; p.c_rv = RS_PAD; p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
     if (lane < 72) {
         const int r = lane / 36, i = (lane % 36) / 6, cc = lane % 6, qc = r ? cc + 8 : cc;
-        p.c_x6 = oQ + i * 14 + 6; p.c_x7 = oQ + i * 14 + 7; p.c_col = qc; p.c_base = oQ + i * 14 + qc; p.c_d1 = r ? opn + (lane - 36) : oPn + lane;
+        p.c_x6 = oQ + i * 14 + 6; p.c_x7 = oQ + i * 14 + 7; p.c_col = qc; p.c_base = oQ + i * 14 + qc; p.c_d1 = r ? opn + cc * 6 + i : oPn + lane;
         if (i < 4) p.c_rv = (r ? RS_PV : RS_PX) + i * 6 + cc;                 // rows 0..3 of P / p go to HBM; row 0 carries the gains
         if (i == 0) { p.c_rk0 = (r ? RS_KF : RS_K) + cc; p.c_rk1 = (r ? RS_KF + OB_NC : RS_K + 6) + cc; }
     } else if (lane < 93) {
@@ -835,6 +837,16 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {     // `lane` = 
         if (a_ < 2) p.c_s1 = osB + a_ * 6 + b_;                               // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the
         if (b_ < 2) p.c_s2 = osB + 12 + b_ * 6 + a_;                          // columns 0 (main) and 1 (t) only
     }
+}
+// six contiguous, 16-byte aligned doubles from LDS: three ds_read_b128
+OBCA_FN void ld6(const double *q, double (&v)[6]) {
+#ifdef OBCA_EMU
+    for (int i = 0; i < 6; i++) v[i] = q[i];
+#else
+    const double2 *q2 = (const double2 *)__builtin_assume_aligned(q, 16);
+    const double2 a = q2[0], b = q2[1], c = q2[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+#endif
 }
 OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
 #pragma unroll
@@ -852,25 +864,25 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
-            const double *A = L + p.a_a + ((p.a_sg & 1) ? sgo : 0), *B = L + p.a_b + ((p.a_sg & 2) ? sgo : 0); const int as = p.a_as, bs = p.a_bs;
-            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            double A[6], B[6]; ld6(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld6(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
+            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].a_d] = v[r];
     }
-    LDS_BARRIER();
+    LDS_SYNC();
     PAR(lane) {   // phase B
         double v[RIC_IPL];
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
-            const double *A = L + p.b_a + ((p.b_sg & 1) ? sgo : 0), *B = L + p.b_b; const int as = p.b_as, bs = p.b_bs;
-            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[as], B[bs], A[2 * as], B[2 * bs], A[3 * as], B[3 * bs], A[4 * as], B[4 * bs], A[5 * as], B[5 * bs]);
+            double A[6], B[6]; ld6(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld6(L + p.b_b, B);
+            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
         }
 #pragma unroll
         for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].b_d] = v[r];
     }
-    LDS_BARRIER();
+    LDS_SYNC();
     PROF_FINE(I, PF_RIC_P1);
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
     // does not need it (the adjugate products below) runs while it is in flight
@@ -901,7 +913,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
             ro[p.c_rv] = v[r]; ro[p.c_rk0] = (double)(n0[r] * idet); ro[p.c_rk1] = (double)(n1[r] * idet);
         }
     }
-    LDS_BARRIER();
+    LDS_SYNC();
     PROF_FINE(I, PF_RIC_P2);
     return ok;
 }
@@ -916,6 +928,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         stage_unpack_plan(lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
         stage_unpack_constants(sg0, lane);
         if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
+        if (lane < 6) sh.zero6[lane] = 0.0;
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
@@ -925,17 +938,17 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         }
         if (lane < 6) {
             double e = lane < 4 ? -(z[l.x + 4 * N + lane] - c.xF[lane]) : 0.0;
-            sh.pn[lane * OB_NC + 0] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);
-            sh.pn[lane * OB_NC + 1] = rec[AS_HT + lane];
-            for (int cc = 0; cc < 4; cc++) sh.pn[lane * OB_NC + 2 + cc] = (lane == cc) ? 1.0 : 0.0;
+            sh.pn[0 * 6 + lane] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);      // (p is kept transposed: pn[c * 6 + a])
+            sh.pn[1 * 6 + lane] = rec[AS_HT + lane];
+            for (int cc = 0; cc < 4; cc++) sh.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
         }
     }
-    LDS_BARRIER();
+    LDS_SYNC();
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
         PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
-        LDS_BARRIER();
+        LDS_SYNC();
         if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0)) { PROF(I, PF_RIC_BWD); return 0; }
     }
     if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
@@ -949,7 +962,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j][0]), "+v"(nv[0][j][1]));
 #endif
     }
-    LDS_BARRIER();
+    LDS_SYNC();
     int ok = 1;
     for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
@@ -1454,7 +1467,10 @@ OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 
 
 // What the iteration loop carries lives in LDS (Shared::drv), not in registers: the phases are non-inlined calls that use the whole register file, so every
 // value the driver kept in a register was spilled to scratch -- i.e. to HBM -- before each call and fetched back after it (~500 spill instructions in round 2's
-// kernel body, a memory round trip behind every phase).  An LDS slot costs a ~100-clock read where the value is needed and nothing at a call.
+// kernel body, a memory round trip behind every phase).  An LDS slot costs a ~100-clock read where the value is needed and nothing at a call.  (Measured and not
+// kept: the state in registers between the calls and copied to / from LDS around each call -- the register allocator then spills MORE, 277 scratch stores / 571
+// loads in the kernel body against 96 / 279.)
+#define PH(call) call
 OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh; Drv &D = sh.drv;
     gdbl *const st = sl.st;
@@ -1468,7 +1484,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         SYNC();
         D.have_asm = (int)st[SL_HAVE];
         sl.resume = 0;
-    } else { ph_init(o.bound_push, o.bound_frac); D.have_asm = 0; }
+    } else { PH(ph_init(o.bound_push, o.bound_frac)); D.have_asm = 0; }
     D.tau = fmax(o.tau_min, 1 - D.mu);
     D.p_start = D.it + D.nreg;
     D.dc_mu = -1.0; D.dc_val = 0;
@@ -1483,7 +1499,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             D.status = ST_SUSPENDED; break;
         }
         if (D.mu != D.dc_mu) { D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
-        PROF(sh.inst, PF_OTHER); if (!D.have_asm) ph_assemble(D.mu, 0.0, D.dc_val, 0);
+        PROF(sh.inst, PF_OTHER); if (!D.have_asm) PH(ph_assemble(D.mu, 0.0, D.dc_val, 0));
         D.have_asm = 0;
         if (D.it == 0) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); }
         D.f = A.f; D.pinf = A.pinf; D.dinf = A.dinf;
@@ -1511,10 +1527,10 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         // search direction with inertia correction (IPOPT Algorithm IC)
         D.dw = 0; D.ok = 0;
         for (D.tr = 0; D.tr < 60; D.tr++) {
-            PROF(sh.inst, PF_OTHER); if (D.tr > 0 || D.mu_changed) ph_assemble(D.mu, D.dw, D.dc_val, 0);
+            PROF(sh.inst, PF_OTHER); if (D.tr > 0 || D.mu_changed) PH(ph_assemble(D.mu, D.dw, D.dc_val, 0));
             int a_ = A.ok;
-            PROF(sh.inst, PF_OTHER); if (a_) a_ = ph_riccati(o.rho_term);
-            PROF(sh.inst, PF_OTHER); if (a_) { ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau); a_ = sh.S.ok; }
+            PROF(sh.inst, PF_OTHER); if (a_) { PH(a_ = ph_riccati(o.rho_term)); }
+            PROF(sh.inst, PF_OTHER); if (a_) { PH(ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau)); a_ = sh.S.ok; }
             if (a_) { D.ok = 1; break; }
             D.nreg++;
             if (D.dw == 0) D.dw = D.dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * D.dw_last);
@@ -1537,7 +1553,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         D.alpha = sh.S.ap; D.acc = 0;
         while (D.alpha >= D.amin) {
             // the trial point z + alpha d goes to the second iterate buffer together with its assembly (mu as is, delta_w = 0: what the next iteration starts from)
-            PROF(sh.inst, PF_OTHER); ph_fused(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw);
+            PROF(sh.inst, PF_OTHER); PH(ph_fused(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw));
             const double ft = sh.An.f, tht = sh.An.th1, pht = ft - D.mu * sh.An.bar, alpha = D.alpha, th = D.th, phi = D.phi, gd = D.gd;
             if (ft == ft && tht == tht && pht == pht && tht < D.th_max) {
                 int okf = 1; const int nf = D.nf;
@@ -1575,10 +1591,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
 // Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
 // solve was parked; the iterate buffer then holds the point to continue from).
-OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0) {
+OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
+        if (lane == 0) sh.o = o_arg;
     }
     SYNC();
     PAR(lane) {
@@ -1600,7 +1617,7 @@ OBCA_FN void solve_instance(int N, const Opts &o, double *info, gdbl *st = nullp
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
     // (this function's own state lives in LDS as well -- Shared::sol -- for the reason given at ipm_attempt)
-    Sol &X = sh.sol;
+    Sol &X = sh.sol; const Opts &o = sh.o;
     X.home = sh.inst.z;
     X.sl.st = st; X.sl.resume = mode == 1; X.sl.budget = budget; X.sl.used = 0;
     X.att = 0; X.it_prev = 0; X.nreg_prev = 0;

@@ -173,15 +173,15 @@ def _ws_job(args):
 
 
 def warm_start_many(sc, x0, xF, N, workers=None, smooth=False):
-    """warm starts of a batch on the host cores (one search per forked process).  Call it before a HIP context exists in this process, or
-    pass workers=1: fork() next to a live GPU runtime is not safe."""
+    """warm starts of a batch on the host cores, one search per worker process.  The workers are SPAWNED, not forked: safe next to a live HIP runtime, so every
+    rank of a multi-GPU job can plan its own slice after its device is up."""
     jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N, bool(smooth)) for a, g in zip(x0, xF)]
     workers = min(len(jobs), workers or os.cpu_count() or 1)
     if workers <= 1 or len(jobs) < 4:
         return [_ws_job(j) for j in jobs]
     _load()
     import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
+    with mp.get_context("spawn").Pool(workers) as pool:
         return pool.map(_ws_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
 
 

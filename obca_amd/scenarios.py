@@ -178,22 +178,29 @@ def warm_start_parallel(x0, xF, N, R=4.5):
     return Ts, xWS, uWS
 
 
-def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, workers=None, smooth=False):
-    """Synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0.
-    planner=None: geometric line/arc primitives for the backwards scenario, Hybrid A* (obca_amd/planner.py) for the parallel one, whose
-    6 m bay needs a multi-manoeuvre path; planner=True/False forces the choice.  Instances for which the planner finds no path
-    are re-drawn."""
-    rng = np.random.default_rng(seed)
-    A, b, vrows = scenario_hrep(sc)
-    use_planner = (sc["name"] != "backwards") if planner is None else bool(planner)
-    x0 = np.zeros((B, 4)); xF = np.zeros((B, 4)); Ts = np.zeros(B)
-    xWS = np.zeros((B, N + 1, 4)); uWS = np.zeros((B, N, 2))
-    draw = lambda: np.array([rng.uniform(-10, 10), rng.uniform(6.5, 9.5), rng.uniform(-0.2, 0.2), 0.0])
+def _draw_start(rng):
+    return np.array([rng.uniform(-10, 10), rng.uniform(6.5, 9.5), rng.uniform(-0.2, 0.2), 0.0])
+
+
+def sample_poses(sc, B, rng, goal_jitter=False):
+    """start / goal poses of a synthetic batch per SURVEY.md section 8d: X0~U[-10,10], Y0~U[6.5,9.5] (main.jl:165-168), psi0~U[-0.2,0.2], v0=0; goal = the scenario's,
+    X_F~U[-1.85,-0.85] with goal_jitter (BASELINE config 3)"""
+    x0 = np.zeros((B, 4)); xF = np.zeros((B, 4))
     for i in range(B):
-        x0[i] = draw()
+        x0[i] = _draw_start(rng)
         xF[i] = sc["xF"]
         if goal_jitter:
             xF[i, 0] = rng.uniform(-1.85, -0.85)
+    return x0, xF
+
+
+def plan_batch(sc, x0, xF, N, rng, planner=None, workers=None, smooth=False):
+    """warm starts (the step before the path, host side) for given poses: geometric line/arc primitives for the backwards scenario, Hybrid A* (obca_amd/planner.py) for
+    the parallel one, whose 6 m bay needs a multi-manoeuvre path; planner=True/False forces the choice.  A start pose for which the planner finds no path is re-drawn
+    from `rng` (x0 is updated in place).  Returns Ts (B,), xWS (B,N+1,4), uWS (B,N,2)."""
+    B = len(x0)
+    use_planner = (sc["name"] != "backwards") if planner is None else bool(planner)
+    Ts = np.zeros(B); xWS = np.zeros((B, N + 1, 4)); uWS = np.zeros((B, N, 2))
     if not use_planner:
         ws = warm_start_backwards if sc["name"] == "backwards" else warm_start_parallel
         for i in range(B):
@@ -206,10 +213,19 @@ def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, work
             nxt = []
             for i, r in zip(todo, res):
                 if r is None:
-                    x0[i] = draw(); nxt.append(i)
+                    x0[i] = _draw_start(rng); nxt.append(i)
                 else:
                     Ts[i], xWS[i], uWS[i] = r
             todo = nxt
+    return Ts, xWS, uWS
+
+
+def make_batch(sc, B, N=80, seed=20260925, goal_jitter=False, planner=None, workers=None, smooth=False):
+    """Synthetic batch: sample_poses + plan_batch from one random stream (seed)."""
+    rng = np.random.default_rng(seed)
+    A, b, vrows = scenario_hrep(sc)
+    x0, xF = sample_poses(sc, B, rng, goal_jitter)
+    Ts, xWS, uWS = plan_batch(sc, x0, xF, N, rng, planner=planner, workers=workers, smooth=smooth)
     return dict(x0=x0, xF=xF, Ts=Ts, xWS=xWS, uWS=uWS, A=A, b=b, vOb=vrows, N=N, L=L_WHEELBASE,
                 ego=EGO.copy(), XYbounds=XYBOUNDS.copy())
 
@@ -241,6 +257,26 @@ def quad_warm_start(x0, xF, N, via=QUAD_VIA):
     return xWS
 
 
+def _draw_quad_endpoints(rng):
+    return [rng.uniform(0.5, 1.6), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)], [rng.uniform(8.0, 9.5), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)]
+
+
+def plan_quad_batch(x0, xF, N, rng, first_is_fixed=True):
+    """3-D grid A* warm starts (obca_amd/planner.py, the reference's a_star_3D.jl step) for given end points; an instance without a path gets new end points from `rng`
+    (x0 / xF updated in place).  Returns xWS (B,N+1,12)."""
+    from . import planner as PL
+    B = len(x0); xWS = np.zeros((B, N + 1, 12))
+    for i in range(B):
+        while True:
+            w = PL.quad_warm_start(x0[i], xF[i], N)
+            if w is not None:
+                xWS[i] = w; break
+            if i == 0 and first_is_fixed:
+                raise RuntimeError("no path for the shipped quadcopter scenario")
+            x0[i, :3], xF[i, :3] = _draw_quad_endpoints(rng)
+    return xWS
+
+
 def make_quad_batch(B, N=60, seed=20260925, jitter=0.3, random_endpoints=False):
     """B instances of the quadcopter scenario.  Default: the shipped start / goal jittered uniformly by +-jitter (instance 0 exact) with the
     way-point warm start.  random_endpoints=True: start anywhere in front of the first wall, goal anywhere behind the second, warm start from
@@ -257,8 +293,7 @@ def make_quad_batch(B, N=60, seed=20260925, jitter=0.3, random_endpoints=False):
         for i in range(B):
             while True:
                 if i:
-                    x0[i, :3] = [rng.uniform(0.5, 1.6), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)]
-                    xF[i, :3] = [rng.uniform(8.0, 9.5), rng.uniform(0.5, 9.5), rng.uniform(0.5, 4.5)]
+                    x0[i, :3], xF[i, :3] = _draw_quad_endpoints(rng)
                 w = PL.quad_warm_start(x0[i], xF[i], N)
                 if w is not None:
                     xWS[i] = w; break

@@ -21,6 +21,22 @@ def shard_range(B, rank, world):
     return lo, min(B, lo + per)
 
 
+def balanced_permutation(keys, world):
+    """Order in which a batch of UNEQUAL instances is handed to the contiguous slices of scatter_rows (BASELINE config 5: 1-10 obstacles per instance): the
+    instances are bucketed by `keys` (any per-instance cost key, e.g. (nOb, M) as one number) and the buckets dealt round-robin, so that every rank receives the same mix.
+    Returns `perm` (rank r gets the instances perm[r*ceil(B/G) : (r+1)*ceil(B/G)]) and its inverse (to put the gathered results back in the caller's order)."""
+    keys = np.asarray(keys); B = len(keys); per = -(-B // world)
+    order = np.argsort(keys, kind="stable")                         # buckets, in ascending cost
+    perm = np.empty(B, np.int64); fill = [0] * world
+    for j, i in enumerate(order):                                   # deal in snake order (0 .. G-1, G-1 .. 0): no rank always gets the dearer one of a round
+        r = j % world if (j // world) % 2 == 0 else world - 1 - j % world
+        while fill[r] >= min(per, B - r * per) and fill[r] >= 0:
+            r = (r + 1) % world
+        perm[r * per + fill[r]] = i; fill[r] += 1
+    inv = np.empty(B, np.int64); inv[perm] = np.arange(B)
+    return perm, inv
+
+
 def _dist():
     import torch
     import torch.distributed as dist
@@ -134,6 +150,62 @@ def parking_signed_dist_sharded(batch, N, L, ego, XYbounds, vOb, A, b, fixTime, 
                 exitflag=out["exitflag"][:, 0].astype(np.int32), lp=list(np.transpose(out["lp"].reshape(B, N1, M), (0, 2, 1))),
                 np=list(np.transpose(out["np"].reshape(B, N1, 4 * nOb), (0, 2, 1))), sl=list(np.transpose(out["sl"].reshape(B, N1, nOb), (0, 2, 1))),
                 info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
+
+
+def parking_signed_dist_sharded_ragged(batch, N, L, ego, XYbounds, fixTime, rank, world, src=0, solver=None, device=None, local_device=0):
+    """BASELINE config 5 over the ranks: every instance brings its OWN obstacle set.  `batch` (rank `src` only): the keys of parking_signed_dist_sharded plus the
+    per-instance lists vOb, A, b.  The instances are dealt to the ranks by (nOb, M) buckets, round-robin (balanced_permutation), the obstacle sets travel with the
+    rows (padded to OBCA_NOBMAX / OBCA_MMAX), results come back in the caller's order.  One scatter, one gather."""
+    torch, dist = _dist()
+    N1 = N + 1; NOB, MM = 10, 40                                   # OBCA_NOBMAX, OBCA_MMAX (include/obca_hip.h)
+    inp = [("x0", 4), ("xF", 4), ("Ts", 1), ("rx", N1), ("ry", N1), ("ryaw", N1), ("xWS", 4 * N1), ("uWS", 2 * N), ("vOb", NOB), ("A", 2 * MM), ("b", MM)]
+    outw = [("xp", 4 * N1), ("up", 2 * N), ("timeScale", N1), ("exitflag", 1), ("lp", MM * N1), ("np", 4 * NOB * N1), ("sl", NOB * N1), ("info", 8)]
+    Bt = torch.zeros(1, dtype=torch.int64, device=_dev(device))
+    full = None; inv = None
+    if rank == src:
+        B = int(np.reshape(batch["x0"], (-1, 4)).shape[0]); Bt[0] = B
+        vo = np.zeros((B, NOB)); Aa = np.zeros((B, 2 * MM)); bb = np.zeros((B, MM))
+        for i in range(B):
+            v = np.ravel(batch["vOb"][i]).astype(int); m = int(v.sum())
+            vo[i, :len(v)] = v; Aa[i, :2 * m] = np.ravel(np.asarray(batch["A"][i], float)); bb[i, :m] = np.ravel(np.asarray(batch["b"][i], float))
+        cols = dict(vOb=vo, A=Aa, b=bb)
+        full = np.concatenate([cols[k] if k in cols else (np.asarray(batch[k], float).reshape(B, -1, 2)[:, :N].reshape(B, -1) if k == "uWS" else np.asarray(batch[k], float).reshape(B, -1)[:, :w])
+                               for k, w in inp], axis=1)
+        perm, inv = balanced_permutation((vo > 0).sum(1) * 100 + vo.sum(1), world)
+        full = full[perm]
+    dist.broadcast(Bt, src=src)
+    B = int(Bt.item())
+    loc = scatter_rows(full, B, sum(w for _, w in inp), rank, world, src, device)
+    n = loc.shape[0]
+    f = {}; o = 0
+    for k, w in inp:
+        f[k] = loc[:, o:o + w]; o += w
+    if solver is None:
+        from . import api
+        solver = lambda *a, **kw: api.parking_signed_dist_batch(*a, device=local_device, **kw)
+    res = np.zeros((n, sum(w for _, w in outw)))
+    if n > 0:
+        vl, Al, bl = [], [], []
+        for i in range(n):
+            v = f["vOb"][i]; v = v[v > 0].astype(int); m = int(v.sum())
+            vl.append(v); Al.append(f["A"][i, :2 * m].reshape(m, 2)); bl.append(f["b"][i, :m])
+        r = solver(f["x0"], f["xF"], N, f["Ts"][:, 0], L, ego, XYbounds, vl, Al, bl, f["rx"], f["ry"], f["ryaw"], fixTime, f["xWS"].reshape(n, N1, 4), f["uWS"].reshape(n, N, 2))
+        pad = lambda lst, rws: np.stack([np.concatenate([np.asarray(x).T.reshape(-1), np.zeros((rws - np.asarray(x).shape[0]) * N1)]) for x in lst])
+        res = np.concatenate([np.transpose(r["xp"], (0, 2, 1)).reshape(n, -1), np.transpose(r["up"], (0, 2, 1)).reshape(n, -1), np.asarray(r["timeScale"]).reshape(n, -1),
+                              np.asarray(r["exitflag"], float).reshape(n, 1), pad(r["lp"], MM), pad(r["np"], 4 * NOB), pad(r["sl"], NOB), np.asarray(r["info"]).reshape(n, 8)], axis=1)
+    allr = gather_rows(res, B, rank, world, src, device)
+    if rank != src:
+        return None
+    allr = allr[inv]                                                 # back to the caller's order
+    out = {}; o = 0
+    for k, w in outw:
+        out[k] = allr[:, o:o + w]; o += w
+    info = out["info"]; lp, npp, sl = [], [], []
+    for i in range(B):
+        v = np.ravel(batch["vOb"][i]).astype(int); m = int(v.sum()); no = len(v)
+        lp.append(out["lp"][i, :m * N1].reshape(N1, m).T); npp.append(out["np"][i, :4 * no * N1].reshape(N1, 4 * no).T); sl.append(out["sl"][i, :no * N1].reshape(N1, no).T)
+    return dict(xp=np.transpose(out["xp"].reshape(B, N1, 4), (0, 2, 1)), up=np.transpose(out["up"].reshape(B, N, 2), (0, 2, 1)), timeScale=out["timeScale"],
+                exitflag=out["exitflag"][:, 0].astype(np.int32), lp=lp, np=npp, sl=sl, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
 
 
 # ---------------------------------------------------------------- quadcopter: QuadcopterSignedDist / QuadcopterDist over the ranks

@@ -29,10 +29,25 @@ def build():
     return so
 
 
+def build_native():
+    """-O3 -march=native build for bench.py's cpu_baseline leg, compiled on the machine that times it (oracle/_native/, not tracked).  The parity
+    tests keep the portable -O2 build: -march=native lets gcc contract into FMAs, which moves the last bits of the iterates."""
+    import hashlib
+    try:      # one build per CPU model: a copy made on another machine (the tree travels to the GPU box) must not be picked up
+        cpu = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        cpu = []
+    d = os.path.join(_HERE, "_native", hashlib.sha1("".join(cpu).encode()).hexdigest()[:12]); os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libobca_oracle.so"); src = os.path.join(_HERE, "obca_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-w", "-shared", "-o", so, src, "-lm"])
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(build_native() if os.environ.get("OBCA_ORACLE_NATIVE") == "1" else build())
     return _LIB
 
 

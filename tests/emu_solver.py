@@ -69,3 +69,19 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
         x_, u_, t_, lp_, np_, sl_ = P.unpack_solution(zo, N, nOb, M, A=A)
         xp[i] = x_; up[i] = u_; ts[i] = 1.0 if fixTime else t_; ef[i] = int(info[i, 7]); lps.append(lp_); nps.append(np_); sls.append(sl_)
     return dict(xp=xp, up=up, timeScale=ts, exitflag=ef, lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))
+
+
+def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, dist=False, **_):
+    """the quadcopter kernel source (obca_quad_solver.h) as a host emulation, with the signature of obca_amd.quadcopter_signed_dist_batch"""
+    emu = load()
+    x0 = np.reshape(x0, (-1, 12)); B = x0.shape[0]; xF = np.reshape(xF, (-1, 12)); L = P.quad_layout(N); N1 = N + 1
+    Tsv = np.broadcast_to(np.asarray(Ts, float), (B,)); tw = np.broadcast_to(np.asarray(timeWS, float), (B,))
+    xp = np.zeros((B, 12, N1)); up = np.zeros((B, 4, N)); ts = np.zeros((B, N1)); ef = np.zeros(B, np.int32); info = np.zeros((B, 8)); lp = np.zeros((B, 30, N1)); sl = np.zeros((B, 5, N1))
+    eo = default_opts(); eo.max_iter = 3000; eo.dw_min = 1e-10            # QuadcopterSignedDist.jl:28-31 (obca_quadcopter_default_opts)
+    for i in range(B):
+        prob = P.pack_quad_problem(x0[i], xF[i], N, Tsv[i], R, ob, np.asarray(xWS[i], float).reshape(N1, 12), tw[i], dual_ws=int(bool(dual_ws)), dist=int(bool(dist)))
+        z = np.zeros(L["len"])
+        emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info[i]))
+        xp[i] = z[L["x"]:L["u"]].reshape(N1, 12).T; up[i] = z[L["u"]:L["t"]].reshape(N, 4).T; ts[i] = z[L["t"]]; ef[i] = int(info[i, 7])
+        lp[i] = z[L["lam"]:L["s"]].reshape(N1, 30).T; sl[i] = z[L["s"]:L["so"]].reshape(N1, 5).T
+    return dict(xp=xp, up=up, timeScale=ts, exitflag=ef, lp=lp, slack=sl, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int))

@@ -102,7 +102,7 @@ def test_parking_matches_oracle_config3_parallel(OA, oracle):
     import checkers as K
     g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
     A, b, v = S.scenario_hrep(S.PARALLEL)
-    fresh = S.make_batch(S.PARALLEL, 32, N, seed=7, workers=1)      # planned in-process: no fork() next to a live HIP runtime
+    fresh = S.make_batch(S.PARALLEL, 32, N, seed=7)                 # (the planner's worker processes are spawned: safe next to a live HIP runtime)
     bt = dict(x0=g["x0"], xF=g["xF"], Ts=g["Ts"], xWS=g["xWS"], uWS=g["uWS"], A=A, b=b, vOb=v, N=N, L=S.L_WHEELBASE, ego=S.EGO, XYbounds=S.XYBOUNDS)
     out, _ = _solve_batch(OA, bt)
     assert (out["exitflag"] == 1).all() and (out["iters"] == g["iters"]).all()
@@ -110,7 +110,7 @@ def test_parking_matches_oracle_config3_parallel(OA, oracle):
     assert np.abs(out["obj"] - g["obj"]).max() < TOL_F * np.abs(g["obj"]).max()
     bt = fresh
     out, xWS = _solve_batch(OA, bt)
-    assert (out["exitflag"] == 1).mean() >= 0.9
+    assert (out["exitflag"] == 1).all()
     for i in range(0, 32, 5):
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
                                        bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
@@ -164,7 +164,7 @@ def test_full_size_properties_config2(OA):
     bt = S.make_batch(S.BACKWARDS, B, N)
     out, _ = _solve_batch(OA, bt)
     ok = out["exitflag"] == 1
-    assert ok.mean() >= 0.97
+    assert ok.all()
     assert np.abs(out["xp"][:, :, 0] - bt["x0"]).max() == 0.0
     assert np.abs(out["xp"][ok][:, :, N] - bt["xF"][ok]).max() < 5e-5
     for i in np.flatnonzero(ok)[::8]:
@@ -285,7 +285,7 @@ def test_config5_mixed_obstacle_counts_up_to_the_limits(OA, oracle):
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
     out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
                                        xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
-    assert (out["exitflag"] == 1).mean() >= 0.95          # ~2 % of these synthetic instances do not converge (neither does the oracle on them)
+    assert (out["exitflag"] == 1).all()                   # (every instance converges since the half-space rows enter with unit length)
     for i in range(0, B, 9):
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i],
                                        bt["b"][i], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
@@ -356,7 +356,7 @@ def test_wide_obstacles_up_to_eight_rows(OA, oracle):
     assert max(int(np.max(v)) for v in bt["vOb"]) >= 7 and min(int(np.max(v)) for v in bt["vOb"]) == 2
     out, xWS = _solve_batch(OA, dict(bt, N=N))
     ls, ns, ds = OA.dualmult_ws_batch(N, bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], bt["ego"])
-    assert (out["exitflag"] == 1).mean() >= 0.9
+    assert (out["exitflag"] == 1).all()
     n = 0
     for i in range(B):
         if np.max(bt["vOb"][i]) <= 4 and i % 4:
@@ -394,24 +394,45 @@ def test_hip_reproduces_the_independently_certified_solutions(OA):
 
 
 @pytest.mark.timeout(900)
-def test_512_mixed_obstacle_instances_match_oracle(OA):
-    """BASELINE config 5 at size: 512 instances with 1-10 obstacles of 1-4 rows each (per-instance H-rep packing, the three block-size instantiations mixed in one
-    launch) against the oracle on all host cores: exit flags, iteration counts and trajectories (1e-6) equal on every instance the oracle solves within 100 iterations"""
+def test_every_instance_of_the_config5_bench_batch_matches_oracle(OA):
+    """BASELINE config 5 at size -- rank 0's batch of `bench.py --config 5`: 4 096 instances with 1-10 obstacles of 1-4 rows each (per-instance H-rep packing, the three
+    block-size instantiations mixed in one call) against the oracle on all host cores: every exit flag, every iteration count, every trajectory (1e-6).  No instance is
+    exempt (round 2 skipped those beyond 100 iterations; with unit-length rows there is nothing left to skip)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import oracle_pool
-    N, B = 80, 512
+    N, B = 80, 4096
     bt = S.make_mixed_batch(B, N, seed=20260925, min_obstacles=1)
     out, xWS = _solve_batch(OA, dict(bt, N=N))
     ref = oracle_pool.mixed_oracle_all(bt, xWS)
-    nconv = hard = 0
+    assert len(ref) == B and (out["exitflag"] == 1).all()
+    worst_x = worst_f = 0.0
     for (i, ef, it, obj, xp) in ref:
-        if ef != 1 or it > 100:      # the ~2 % of these synthetic instances on which the iteration wanders for hundreds of steps (or fails): round-off decides the path
-            hard += 1; continue
-        assert out["exitflag"][i] == ef and out["iters"][i] == it, (i, out["exitflag"][i], ef, out["iters"][i], it)
-        nconv += 1
-        assert abs(out["obj"][i] - obj) <= TOL_F * max(1, abs(obj)) and np.abs(out["xp"][i] - xp).max() < TOL_X, i
-    assert nconv >= 0.96 * B and hard <= 0.04 * B and sorted(set(len(v) for v in bt["vOb"])) == list(range(1, 11))
+        assert out["exitflag"][i] == ef == 1 and out["iters"][i] == it, (i, out["exitflag"][i], ef, out["iters"][i], it)
+        worst_f = max(worst_f, abs(out["obj"][i] - obj) / max(1, abs(obj))); worst_x = max(worst_x, np.abs(out["xp"][i] - xp).max())
+    assert worst_x < TOL_X and worst_f < TOL_F, (worst_x, worst_f)
+    assert sorted(set(len(v) for v in bt["vOb"])) == list(range(1, 11))
+
+
+@pytest.mark.timeout(1200)
+def test_every_instance_of_the_config3_bench_batch_matches_oracle(OA):
+    """BASELINE config 3 at size -- rank 0's batch of `bench.py --config 3`: 2 048 parallel-parking instances (4 obstacles / 6 rows, randomised start and goal, Hybrid A*
+    warm starts planned here on the host cores) against the oracle: every exit flag and every trajectory (1e-6); iteration counts equal except where round-off decides an
+    acceptance test on a knife edge (measured: 1 of 2 048, 51 against 52 iterations to the same point) -- at most 4 are tolerated."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_pool
+    N, B = 80, 2048
+    bt = S.make_batch(S.PARALLEL, B, N, seed=20260925, goal_jitter=True)
+    out, xWS = _solve_batch(OA, bt)
+    ref = oracle_pool.parking_oracle_all(bt, xWS)
+    assert len(ref) == B and (out["exitflag"] == 1).all()
+    off = 0; worst_x = worst_f = 0.0
+    for (i, ef, it, obj, xp, up, t) in ref:
+        assert out["exitflag"][i] == ef == 1, (i, out["exitflag"][i], ef)
+        off += int(out["iters"][i] != it)
+        worst_f = max(worst_f, abs(out["obj"][i] - obj) / max(1, abs(obj))); worst_x = max(worst_x, np.abs(out["xp"][i] - xp).max())
+    assert off <= 4 and worst_x < TOL_X and worst_f < TOL_F, (off, worst_x, worst_f)
 
 
 def test_half_space_rows_of_any_length_describe_the_same_problem(OA, oracle):

@@ -132,3 +132,59 @@ def test_hybrid_astar_finishes_on_the_exact_goal_with_the_analytic_expansion(bac
     for q in p1:
         assert not PL.collides(q, v, A, b, margin=0.1 - 1e-9)
     assert np.all(np.hypot(np.diff(p1[:, 0]), np.diff(p1[:, 1])) <= 0.2 + 1e-6)
+
+
+def _check_path(path, start, goal, step, pose_tol=0.01, step_tol=0.001):
+    """the reference's acceptance criteria for a Reeds-Shepp path (reeds_shepp.jl:846-869, check_path): starts on the start pose, ends on the end pose
+    (x, y, yaw to 0.01), course sampled every STEP_SIZE (0.001; the reference's loop `for i in length(d)` only looks at the last interior step -- here all of them)"""
+    ang = lambda a, b: abs((a - b + np.pi) % (2 * np.pi) - np.pi)
+    assert abs(path[0, 0] - start[0]) <= pose_tol and abs(path[0, 1] - start[1]) <= pose_tol and ang(path[0, 2], start[2]) <= pose_tol
+    assert abs(path[-1, 0] - goal[0]) <= pose_tol and abs(path[-1, 1] - goal[1]) <= pose_tol and ang(path[-1, 2], goal[2]) <= pose_tol
+    d = np.hypot(np.diff(path[:-1, 0]), np.diff(path[:-1, 1]))
+    # the reference walks STEP_SIZE along the word and adds the segment ends (its own test only looks at ONE step, `for i in length(d)`); this planner spaces the
+    # samples of every segment evenly, at most STEP_SIZE of arc apart (a chord is shorter than its arc): never farther apart than the reference's, rarely much closer
+    assert d.max() <= step + step_tol
+    assert (d >= 0.5 * step).mean() > 0.9
+
+
+def test_reeds_shepp_reference_test_cases():
+    """The six fixed cases of the reference's own Reeds-Shepp test (reeds_shepp.jl:871-932; tests/golden/reeds_shepp_cases.json) -- the only numerical fixtures the
+    reference holds.  (1) obca_plan_reeds_shepp passes the reference's acceptance criteria; (2) the restatement of the reference's path families
+    (oracle/reeds_shepp_ref.py) is pinned by the same criteria: every candidate word ends on the goal pose; (3) the planner returns the word and the length the
+    reference's calc_shortest_path selects, to 1e-9."""
+    import json, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import reeds_shepp_ref as R
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reeds_shepp_cases.json")))
+    ang = lambda a, b: abs((a - b + np.pi) % (2 * np.pi) - np.pi)
+    assert len(g["cases"]) == 6
+    for c in g["cases"]:
+        path, dr, w, seg, tot = PL.reeds_shepp(c["start"], c["goal"], 1.0 / c["maxc"], step=g["step_size"])
+        _check_path(path, c["start"], c["goal"], g["step_size"], g["pose_tol"], g["step_tol"])
+        cands = R.calc_paths(c["start"], c["goal"], c["maxc"])
+        assert len(cands) >= 1                                             # check_path: `@test length(paths) >= 1`
+        for L, ls, word in cands:
+            ex, ey, eth = R.end_pose(c["start"], [l * c["maxc"] for l in ls], word, c["maxc"])
+            assert abs(ex - c["goal"][0]) <= 1e-9 and abs(ey - c["goal"][1]) <= 1e-9 and ang(eth, c["goal"][2]) <= 1e-9
+        best = R.shortest(c["start"], c["goal"], c["maxc"])
+        assert w == best[2] and abs(tot - best[0]) <= 1e-9 * max(1.0, tot)
+        assert np.abs(np.asarray(seg) - np.asarray(best[1])).max() <= 1e-8 * max(1.0, tot)
+        assert w == c["regression_word"] and abs(tot - c["regression_length"]) <= 1e-9 * max(1.0, tot)
+
+
+def test_reeds_shepp_random_cases_against_the_reference_families():
+    """the reference's random test (reeds_shepp.jl:934-945: poses in [-50, 50]^2 x [-180, 180] deg, max curvature U[0, 0.1]): the planner's path meets the reference's
+    criteria and is never longer than the shortest word of the reference's families (it knows all 48 Reeds-Shepp words; the reference's family set is not complete)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import reeds_shepp_ref as R
+    rng = np.random.default_rng(20260925); equal = 0
+    for i in range(100):
+        s = [rng.uniform(-50, 50), rng.uniform(-50, 50), np.deg2rad(rng.uniform(-180, 180))]; e = [rng.uniform(-50, 50), rng.uniform(-50, 50), np.deg2rad(rng.uniform(-180, 180))]
+        maxc = max(rng.uniform(0, 0.1), 0.005)                           # (a radius beyond 200 m only makes the sampled path long)
+        path, dr, w, seg, tot = PL.reeds_shepp(s, e, 1.0 / maxc, step=0.5)
+        _check_path(path, s, e, 0.5, step_tol=0.005)
+        best = R.shortest(s, e, maxc)
+        assert tot <= best[0] + 1e-9 * max(1.0, tot), (i, tot, best)
+        equal += abs(tot - best[0]) <= 1e-9 * max(1.0, tot)
+    assert equal >= 80
