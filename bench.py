@@ -69,14 +69,14 @@ def f_pass_parking(N, blocks_per_stage):
 def b_pass_parking(N, nOb, M):
     """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-3 kernel.  Per (stage, obstacle)
     block: iterate part zb = 2 v + 15 doubles (lambda, mu, sl, slack, their multipliers), step db = v + 10, condensed record 12.  Per stage: iterate part 26, step 8,
-    stage record 88, Riccati record 72, reference 3.  A pass streams: direction_obs zb (read) + db (write); fused line search zb + db (read), zb + 12 (write), per stage
-    26 + 8 + 12 nOb + 3 (read), 26 + 88 (write); backward sweep 88 (read) + 72 (write); forward sweep / back-substitution 48 + 21 + 72 + 7 (read) + 8 (write); plus 0.16
+    stage record 60 (the entries that can be non-zero), Riccati record 72, reference 3.  A pass streams: direction_obs zb (read) + db (write); fused line search zb + db (read), zb + 12 (write), per stage
+    26 + 8 + 12 nOb + 3 (read), 26 + 60 (write); backward sweep 60 (read) + 72 (write); forward sweep / back-substitution 44 + 21 + 72 + 7 (read) + 8 (write); plus 0.16
     stand-alone assemblies per pass (first iterate, barrier updates, inertia retries)."""
     N1 = N + 1
     zb = 2.0 * M + 15.0 * nOb; db = 1.0 * M + 10.0 * nOb           # per stage, all obstacles
-    rd = N1 * (zb + (zb + db) + (26 + 8 + 12 * nOb + 3) + 88 + (48 + 21 + 72 + 7))
-    wr = N1 * (db + (zb + 12 * nOb) + (26 + 88) + 72 + 8)
-    asm = 0.16 * N1 * ((zb + 26 + 12 * nOb) + (12 * nOb + 88))
+    rd = N1 * (zb + (zb + db) + (26 + 8 + 12 * nOb + 3) + 60 + (44 + 21 + 72 + 7))
+    wr = N1 * (db + (zb + 12 * nOb) + (26 + 60) + 72 + 8)
+    asm = 0.16 * N1 * ((zb + 26 + 12 * nOb) + (12 * nOb + 60))
     return 8.0 * (rd + wr + asm)
 
 

@@ -8,7 +8,7 @@
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
 //   prob  header+rx,ry,ryaw   [411]      z, zn  primal-dual iterate and the line search's trial point (they swap) [6797 each]      d  stage part of the search direction [~650 used]
 //   as    assembled stage records (N+1) x 88 [7128]     rs  Riccati records (N+1) x 116 [9396]
-//   oc    condensed obstacle records (N+1) x nOb x 12 [2916]    traj (N+2) x 6
+//   oc    condensed obstacle records (N+1) x nOb x 12 [2916]   (the forward-sweep trajectory and the composed stage-pair maps live in LDS)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -29,10 +29,10 @@ static_assert(OBCA_QUAD_NMAX == QNMAX, "ABI limits must match the kernels");
 static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX && OBCA_MMAX == OB_MMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
-    double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *traj, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
+    double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
     double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
     int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
-    size_t s_prob, s_z, s_as, s_rs, s_oc, s_traj;   // strides in doubles
+    size_t s_prob, s_z, s_as, s_rs, s_oc;   // strides in doubles
 };
 
 // One wavefront per SIMD (four one-wavefront instances per CU): each wave may then use 256 VGPRs + 256 AGPRs, and the register-hungry per-lane phases
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.zn = (gdbl *)(b.zn + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
-        I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc); I.traj = (gdbl *)(b.traj + (size_t)inst * b.s_traj);
+        I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc);
 #ifdef OBCA_PROFILE
         I.tlast = clock64();
 #endif
@@ -351,7 +351,7 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.traj, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
     if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
     bt->dcap_stage = 0;
@@ -406,11 +406,11 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         bt->zlen = lmax.len;
         DevBufs &d = bt->d;
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
-        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_traj = std::max((size_t)(N + 2) * 6, (size_t)(N / 2) * 42);   // traj: composed stage-pair maps of the forward sweep
+        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC;
         size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = hipMalloc((void **)&(ptr), by_); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.zn, B * d.s_z); ALLOC(d.d, B * d.s_z);
-        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc); ALLOC(d.traj, B * d.s_traj);
+        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc);
         ALLOC(d.info, B * 8); ALLOC(d.dws, B * N1 * bt->nObMax); ALLOC(d.prof, B * 16);
         ALLOC(d.slice, B * SL_SIZE);
         bt->dcap_stage = B * (size_t)lmax.nprimal;                       // nprimal >= the output prefix

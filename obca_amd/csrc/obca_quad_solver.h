@@ -378,224 +378,9 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
 }
 
-// ---------------------------------------------------------------- Riccati backward sweep (wavefront 0)
-// Per stage (all 128 lanes, four short LDS phases separated by LDS-only workgroup barriers):
-//   A  That = Pn FX + [0 | pn]          16 x 18   FX = [A B d Ft ; 0 I 0 0] is the dense 16 x 18 block of the stage record
-//   B  Qhat = [H | hc | 0] + F'That     20 x 34   (rows / columns of the input copy w carry no product: F has zero columns there)
-//   C  Quu = LDL', gains Khat for the 16 state columns and the 14 right-hand sides
-//   D  new Pn, pn (16 x 30), bilinear border constants (105 pairs); park the next stage record in LDS
-// All index arithmetic of the item -> (row, column) maps is done once per sweep (QRicPlan, registers); the inner loops are
-// branch-free strided LDS reads + fp64 FMAs.  Stage records are gathered QRIC_D stages ahead (same vmcnt discipline as the
-// parking sweep: unconditional loads / stores, single-exit loop).
-#define QOPAQUE(x) OPAQUE(x)
-#define QTC 18                       // columns of That: x (12), u (4), d, Ft
-#define QTH(a, tc) That[(a) * QTC + (tc)]
-#define QQH(i, cI) Qhat[(i) * QQC + (cI)]
-#define QRIC_D 2
-#define QREC_PER ((QSR + QNT - 1) / QNT)     // doubles of one stage record per lane (6)
-OBCA_FN void q_pair(int p, int &a_, int &b_) { a_ = 0; int rem = p; while (rem >= QC - a_) { rem -= QC - a_; a_++; } b_ = a_ + rem; }
-
-// item maps, bit-packed so that the whole plan lives in 15 registers:
-//   A: row | col << 5 | (pn column + 1) << 10                       (row 31 = no item)
-//   B: h | t << 10 | (fx + 1) << 22 | (id + 1) << 27                 h: [H|hc] source offset in sg; t: offset of the T column in LDS
-//      (fx: FX column, 0 = no product; id: identity row, 0 = none); the destination is the item number itself
-//   D: i | cc << 5 | qc << 10 | rs << 16                             (i 31 = no item; rs: offset in the Riccati record)
-struct QRicPlan { unsigned a[3], b[6], d[4]; int pa, pb; };
 #define QRR_PAD 767                                  // unused slot of the Riccati record: target of dummy stores
-OBCA_FN void q_ric_plan(int lane, int off_That, int off_pn, QRicPlan &p) {
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int it = lane + QNT * r; const bool on = it < QS * QTC; const int tc = it % QTC;
-        p.a[r] = on ? (unsigned)(it / QTC) | (unsigned)tc << 5 | (unsigned)(tc >= 16 ? tc - 16 + 1 : 0) << 10 : 31u;
-    }
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const int it = lane + QNT * r; const bool on = it < QZ * QQC;
-        const int i = on ? it / QQC : 0, cI = on ? it % QQC : 0;
-        const bool wrow = i >= QX && i < QS, wcol = cI >= QX && cI < QS;
-        const int h = cI < QZ ? QSR_H + i * QZ + cI : (cI < QZ + 2 ? QSR_HC + 2 * i + (cI - QZ) : QSR - 1);   // QSR-1: a zero of the record padding
-        const int ip = i < QX ? i : i - QU;                                       // column of FX that belongs to stage-vector row i
-        const int fx = (on && !wrow && !wcol) ? ip + 1 : 0;
-        const int tc = cI < QX ? cI : (cI < QZ ? cI - QU : -1);                   // That column for x / u columns
-        const int t = cI < QZ + 2 ? off_That + (cI < QZ ? (tc < 0 ? 0 : tc) : 16 + (cI - QZ)) : off_pn + (cI - QZ);
-        const int id = (on && i >= QS && !wcol) ? QX + (i - QS) + 1 : 0;
-        p.b[r] = (unsigned)h | (unsigned)t << 10 | (unsigned)fx << 22 | (unsigned)id << 27;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int it = lane + QNT * r; const bool on = it < QS * 30;
-        const int i = on ? it / 30 : 0, cc = on ? it % 30 : 0, qc = cc < QS ? cc : QZ + (cc - QS);
-        const int rs = (on && i < QX) ? (cc < QS ? QRR_PX + i * QS + cc : QRR_PV + i * QC + (cc - QS)) : QRR_PAD;
-        p.d[r] = (unsigned)(on ? i : 31) | (unsigned)cc << 5 | (unsigned)qc << 10 | (unsigned)rs << 16;
-    }
-    if (lane < QC * (QC + 1) / 2) q_pair(lane, p.pa, p.pb); else { p.pa = -1; p.pb = 0; }
-}
-
-template <int PIPE>
-OBCA_FN int q_riccati_stage(QShared &sh, const int k, const QRicPlan (&plan)[QNLT], double (&nv)[QNLT][QRIC_D][QREC_PER], const int slot) {
-    double *That = &sh.red[0][0], *Qhat = That + QS * QTC;      // 288 + 680 doubles <= 16 * QNT
-    double *L = &sh.red[0][0];                                   // base of the plan's LDS offsets
-    const double *sg = sh.sg;
-    QPAR(lane) {   // A
-        const QRicPlan &p = plan[LI(lane)];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            unsigned wa = p.a[r]; QOPAQUE(wa);
-            const int a = wa & 31, tc = (wa >> 5) & 31, pc = (int)((wa >> 10) & 31) - 1;
-            if (a < QS) {
-                double ac[4] = {pc >= 0 ? sh.pn[a * QC + pc] : 0.0, 0.0, 0.0, 0.0};   // four chains: a dependent fp64 FMA costs ~45 clocks
-#pragma unroll
-                for (int b_ = 0; b_ < QS; b_++) ac[b_ & 3] += sh.Pn[a * QS + b_] * sg[QSR_F + b_ * QFC + tc];
-                QTH(a, tc) = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-            }
-        }
-    }
-    LDS_BARRIER();
-    const int off_pn = (int)(sh.pn - L);
-    QPAR(lane) {   // B
-        const QRicPlan &p = plan[LI(lane)];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const int it = lane + QNT * r;
-            if (it < QZ * QQC) {
-                unsigned w = p.b[r]; QOPAQUE(w);
-                const int h = w & 1023, t = (w >> 10) & 4095, fx = (int)((w >> 22) & 31) - 1, id = (int)(w >> 27) - 1;
-                double ac[4] = {sg[h], 0.0, 0.0, 0.0};
-                if (fx >= 0) {
-                    const double *tp = L + t; const int ts = t >= off_pn ? QC : QTC, fo = QSR_F + fx;
-#pragma unroll
-                    for (int a = 0; a < QX; a++) ac[a & 3] += sg[fo + a * QFC] * tp[a * ts];
-                    if (id >= 0) ac[0] += tp[id * ts];
-                }
-                Qhat[it] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-            }
-        }
-        if (lane < 2 * QC) {   // sB[m][b] = off_m . That[:, rhs b] ; sB[2+m][b] = off_m . pn[:, b]   (m = 0: d, 1: Ft)
-            const int m = lane / QC, b_ = lane % QC; double u1[2] = {0, 0}, u2[2] = {0, 0};
-            const double *tp = b_ < 2 ? That + 16 + b_ : sh.pn + b_; const int ts = b_ < 2 ? QTC : QC;
-#pragma unroll
-            for (int i = 0; i < QX; i++) { const double o = sg[QSR_F + i * QFC + 16 + m]; u1[i & 1] += o * tp[i * ts]; u2[i & 1] += o * sh.pn[i * QC + b_]; }
-            sh.sB[m * QC + b_] = u1[0] + u1[1]; sh.sB[(2 + m) * QC + b_] = u2[0] + u2[1];
-        }
-    }
-    LDS_BARRIER();
-    // C: Quu -> LDL' (every lane, uniform), gains for the 30 columns (16 state columns + 14 right-hand sides)
-    double Lq[QU * QU];
-#pragma unroll
-    for (int i = 0; i < QU; i++)
-#pragma unroll
-        for (int j = 0; j < QU; j++) Lq[i * QU + j] = QQH(QS + i, QS + j);
-    const int ok = UNIFORM(ldl_fact<QU>(QU, Lq) ? 0 : 1);        // (no early exit, see the parking sweep)
-    gdbl *ro = sh.inst.rs + (size_t)k * QRR;
-    QPAR(lane) {
-        const int cc = lane < 30 ? lane : 0, qc = cc < QS ? cc : QZ + (cc - QS);
-        double b[QU];
-#pragma unroll
-        for (int i = 0; i < QU; i++) b[i] = -QQH(QS + i, qc);
-        ldl_solve<QU>(QU, Lq, b);
-#pragma unroll
-        for (int i = 0; i < QU; i++) {
-            if (lane < 30) sh.Khat[i * 30 + cc] = b[i];
-            ro[lane < 30 ? (cc < QS ? QRR_K + i * QS + cc : QRR_KF + i * QC + (cc - QS)) : QRR_PAD] = b[i];
-        }
-    }
-    LDS_BARRIER();
-    QPAR(lane) {   // D
-        const QRicPlan &p = plan[LI(lane)];
-        if (PIPE) {   // park the record of stage k-1 (gathered QRIC_D stages ago) and re-issue the slot
-            const int kl = k - 1 - QRIC_D > 0 ? k - 1 - QRIC_D : 0;
-            const gdbl *rn = sh.inst.as + (size_t)kl * QSP;
-#pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; sh.sg[e < QSR ? e : QSR - 1] = e < QSR ? nv[LI(lane)][slot][r] : 0.0; }
-#pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; nv[LI(lane)][slot][r] = rn[e < QSR ? e : QSR - 1]; }
-        }
-        double pv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            unsigned w = p.d[r]; QOPAQUE(w);
-            const int i = (w & 31) < QS ? (int)(w & 31) : 0, cc = (w >> 5) & 31, qc = (w >> 10) & 63, rs = w >> 16;
-            double v = QQH(i, qc);
-#pragma unroll
-            for (int a = 0; a < QU; a++) v += QQH(i, QS + a) * sh.Khat[a * 30 + cc];
-            if (cc < QS && cc != i) {   // keep the value function exactly symmetric
-                double w_ = QQH(cc, i);
-#pragma unroll
-                for (int a = 0; a < QU; a++) w_ += QQH(cc, QS + a) * sh.Khat[a * 30 + i];
-                v = 0.5 * (v + w_);
-            }
-            pv[r] = v;
-            ro[rs] = v;
-        }
-        double bm = 0;
-        int pa_ = p.pa, pb_ = p.pb; QOPAQUE(pa_); QOPAQUE(pb_);
-        if (pa_ >= 0) {
-            const int a_ = pa_, b_ = pb_;
-#pragma unroll
-            for (int i = 0; i < QU; i++) bm += QQH(QS + i, QZ + a_) * sh.Khat[i * 30 + QS + b_];
-            if (a_ < 2) bm += sh.sB[a_ * QC + b_];
-            if (b_ < 2) bm += sh.sB[(2 + b_) * QC + a_];
-            sh.Bm[a_ * QC + b_] += bm; if (a_ != b_) sh.Bm[b_ * QC + a_] += bm;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            unsigned w = p.d[r]; QOPAQUE(w); const int i = w & 31, cc = (w >> 5) & 31;
-            if (i < QS) { if (cc < QS) sh.Pn[i * QS + cc] = pv[r]; else sh.pn[i * QC + (cc - QS)] = pv[r]; }
-        }
-    }
-    LDS_BARRIER();
-    return ok;
-}
-
-OBCA_FN int q_riccati_body(QShared &sh, double rho) {
-    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = UNIFORM(c.N); const gdbl *z = sh.inst.z;
-    double nv[QNLT][QRIC_D][QREC_PER];
-    QRicPlan plan[QNLT];
-    QPAR(lane) {
-        q_ric_plan(lane, 0, (int)(sh.pn - &sh.red[0][0]), plan[LI(lane)]);
-        const gdbl *rec = sh.inst.as + (size_t)N * QSP;
-        for (int it = lane; it < QS * QS; it += QNT) { int i = it / QS, j = it % QS; double v = (i < QX && j < QX) ? rec[QR(QSR_H + i * QZ + j)] : 0.0; if (i == j && i < QX) v += rho; sh.Pn[it] = v; }
-        for (int it = lane; it < QS * QC; it += QNT) {
-            int i = it / QC, cc = it % QC; double v = 0;
-            if (i < QX) { if (cc == 0) v = rec[QR(QSR_HC + 2 * i)] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (cc >= 2) v = (cc - 2 == i) ? 1.0 : 0.0; }
-            sh.pn[it] = v;
-        }
-        for (int it = lane; it < QC * QC; it += QNT) sh.Bm[it] = 0;
-    }
-    // head: synchronous gathers until the remaining stage count is a multiple of QRIC_D
-    int k = N - 1;
-    for (; k >= 0 && (k + 1) % QRIC_D != 0; k--) {
-        QPAR(lane) { const gdbl *r1 = sh.inst.as + (size_t)k * QSP; for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i]; }
-        LDS_BARRIER();
-        if (!q_riccati_stage<0>(sh, k, plan, nv, 0)) return 0;
-    }
-    if (k < 0) return 1;
-    QPAR(lane) {
-        const gdbl *r1 = sh.inst.as + (size_t)k * QSP;
-        for (int i = lane; i < QSR; i += QNT) sh.sg[i] = r1[i];
-#pragma unroll
-        for (int j = 0; j < QRIC_D; j++) {
-            const int st = k - 1 - j > 0 ? k - 1 - j : 0; const gdbl *rn = sh.inst.as + (size_t)st * QSP;
-#pragma unroll
-            for (int r = 0; r < QREC_PER; r++) { const int e = lane + QNT * r; nv[LI(lane)][(j + 1) % QRIC_D][r] = rn[e < QSR ? e : QSR - 1]; }
-        }
-#ifndef OBCA_EMU
-#pragma unroll
-        for (int j = 0; j < QRIC_D; j++)
-#pragma unroll
-            for (int r = 0; r < QREC_PER; r++) asm volatile("" : "+v"(nv[0][j][r]));
-#endif
-    }
-    LDS_BARRIER();
-    int ok = 1;
-    for (int kb = k; kb >= QRIC_D - 1 && ok; kb -= QRIC_D) {
-#pragma unroll
-        for (int ju = 0; ju < QRIC_D; ju++) ok &= q_riccati_stage<1>(sh, kb - ju, plan, nv, (ju + 1) % QRIC_D);
-    }
-    return ok;
-}
-// ---------------------------------------------------------------- Riccati backward sweep on the matrix cores (default; -DOBCA_QUAD_RICCATI_LDS keeps the LDS / VALU sweep above)
-// The LDS sweep is bound by LDS bandwidth (every fp64 FMA of its products reads two operands from LDS: 10 k clocks per stage with two instances per CU).  Here the
+// ---------------------------------------------------------------- Riccati backward sweep on the matrix cores
+// (Round 1 ran the sweep as four LDS / VALU phases: bound by LDS bandwidth, every fp64 FMA of its products read two operands from LDS, 10 k clocks per stage.)  Here the
 // whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (27 per stage); the stage record is gathered
 // from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
 //   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").

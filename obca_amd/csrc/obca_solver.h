@@ -83,7 +83,7 @@ namespace obca {
 
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
 #define OB_NMAX 128  // longest horizon (the forward-sweep trajectory lives in LDS)
-#define OB_AS 88     // doubles per assembled stage record
+#define OB_AS 60     // doubles per assembled stage record (only the entries that can be non-zero are kept: as_h / as_df below)
 #define OB_RS 74     // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
 #define OB_HDR 168   // doubles of problem header (scalars + A + b) in front of rx, ry, ryaw
@@ -105,16 +105,16 @@ namespace obca {
 #define PH_A 48
 #define PH_B 128
 // stage record
-#define AS_H 0
-#define AS_HB 36
-#define AS_HT 44
-#define AS_DF 52
-#define AS_DD 72
-#define AS_SIG 76
-#define AS_RG 77
-#define AS_GG 78
-#define AS_DSS 81
-#define AS_RSS 82
+#define AS_H 0       // 19 entries of the symmetric 8 x 8 stage Hessian (variables X, Y, psi, v, w0, w1, delta, a): slot as_h(i, j)
+#define AS_HB 19     // gradient (8)
+#define AS_HT 27     // d/dt column of the rows psi .. a (6: row i at AS_HT + i - 2; rows X, Y are zero)
+#define AS_DF 33     // 16 entries of the bicycle Jacobian d(F - x)/d(psi, v, delta, a, t) (4 x 5): slot as_df(i, j)
+#define AS_DD 49     // residual (4)
+#define AS_SIG 53
+#define AS_RG 54
+#define AS_GG 55
+#define AS_DSS 58
+#define AS_RSS 59
 // Riccati record
 #define RS_K 0
 #define RS_KF 12
@@ -159,7 +159,7 @@ struct StepOut { int ok; double ap, az, gd, gr; };   // gr: rate-cost part of d 
 struct Consts; struct Lay;
 struct Inst {              // uniform: pointers of this instance
     const gdbl *prob;      // header + rx, ry, ryaw
-    gdbl *z, *zn, *d, *as, *rs, *oc, *traj;   // z: the current iterate; zn: the buffer the line search writes its trial point to (the two swap when a trial is accepted);
+    gdbl *z, *zn, *d, *as, *rs, *oc;   // z: the current iterate; zn: the buffer the line search writes its trial point to (the two swap when a trial is accepted);
                                               // d: stage part of the search direction (u, ss, pi, yg; the obstacle part is recomputed where it is needed, x lives in LDS)
     mutable long long tlast;           // diagnostic builds (-DOBCA_PROFILE): time stamp of the previous phase boundary
 };
@@ -190,7 +190,7 @@ struct alignas(16) Shared {
     alignas(16) double zero6[6]; double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
     double filt[OB_FILT_LDS][2];
     Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
-    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok;
+    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok, upl[OB_NT], ucn[3][OB_NT];      // upl, ucn: which positions of the unpacked stage data a lane serves (init_unpack_table)
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     Inst inst; AsmOut A, A2, An, Ap; StepOut S; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
@@ -354,6 +354,18 @@ OBCA_FN void bar_init(BarAcc &a) { a.p0 = a.p1 = a.mn = 1.0; }
 OBCA_FN void bar_mul(BarAcc &a, double dlo, double dhi) { a.p0 *= dlo; a.p1 *= dhi; a.mn = fmin(a.mn, fmin(dlo, dhi)); }
 OBCA_FN double bar_log(const BarAcc &a) { const double lg = log(a.p0 * a.p1); return a.mn > 0 ? lg : NAN; }
 OBCA_FN int hidx(int i, int j) { int a_ = i < j ? i : j, b_ = i < j ? j : i; return a_ * 8 - a_ * (a_ - 1) / 2 + (b_ - a_); }
+// Which entries of a stage record exist.  Hessian: pose block (obstacles, tracking), the (psi, v, delta, a) block of the bicycle model, the rate terms (w, u) and the
+// steering row (w0, delta) -- 19 of 36; everything else is structurally zero and neither stored nor gathered by the backward sweep (-1).
+OBCA_FN int as_h(int i, int j) {
+    const int a_ = i < j ? i : j, b_ = i < j ? j : i;
+    switch (a_ * 8 + b_) {
+        case 0: return 0; case 1: return 1; case 2: return 2; case 9: return 3; case 10: return 4; case 18: return 5; case 19: return 6; case 22: return 7; case 23: return 8;
+        case 27: return 9; case 30: return 10; case 31: return 11; case 36: return 12; case 38: return 13; case 45: return 14; case 47: return 15; case 54: return 16;
+        case 55: return 17; case 63: return 18; default: return -1;
+    }
+}
+// Jacobian: F_psi does not depend on psi itself beyond the identity, F_v only on a and t
+OBCA_FN int as_df(int i, int j) { return i < 2 ? 5 * i + j : (i == 2 ? (j >= 1 ? 9 + j : -1) : (j >= 3 ? 11 + j : -1)); }
 
 
 // ---------------------------------------------------------------- accepting a step: new bound multipliers
@@ -369,10 +381,11 @@ OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { 
 // separate trial / accept / assemble phases (round 2) the iterate is read once instead of three times per iteration and the obstacle part of the search
 // direction is never stored: a (stage, obstacle) block recomputes its step from the pose step (obs_block<1>, the same code direction_obs ran).
 // The obstacle part of the search direction (d lambda, d mu, d sl, d so, d y per (stage, obstacle) block) is needed twice: for the step lengths (direction_obs) and for
-// the trial point (fused assembly).  OBCA_STORE_DOBS = 1: direction_obs writes it to `d` and the fused assembly loads it with the block's iterate (one more operand in a
-// load batch that is issued anyway); 0: the fused assembly recomputes it (obs_block<1>: ~25 % of that phase's arithmetic, no traffic).  A/B in DESIGN.md section 5.
+// the trial point (fused assembly).  OBCA_STORE_DOBS = 0 (default): the fused assembly recomputes it (obs_block<1>: ~25 % of that phase's arithmetic, no traffic);
+// 1: direction_obs writes it to `d` and the fused assembly loads it with the block's iterate.  Measured on MI355X (config 2, profiles/r03_ab_obstacle_steps.txt): the same
+// pipelined rate (212.8 k / 214.6 k solves/s), storing is 5 % quicker per pass for a lone instance and moves 10 % more HBM bytes (15.9 against 14.4 GB per launch).
 #ifndef OBCA_STORE_DOBS
-#define OBCA_STORE_DOBS 1
+#define OBCA_STORE_DOBS 0
 #endif
 struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal, equality multipliers, bound multipliers), kappa_sigma, delta_w of the factorisation that gave d
 // part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
@@ -638,7 +651,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
 #pragma unroll
-                        for (int j = 0; j < 5; j++) rec[AS_DF + 5 * i + j] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
+                        for (int j = 0; j < 5; j++) if (as_df(i, j) >= 0) rec[AS_DF + as_df(i, j)] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
                         double r = xn[i] - dy.F[i];
                         rec[AS_DD + i] = -r; pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                         lsy += fabs(pi[i]);
@@ -687,10 +700,12 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
             }
             lbar += bar_log(ba);
 #pragma unroll
-            for (int i = 0; i < 36; i++) rec[AS_H + i] = Hp[i];
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = i; j < 8; j++) if (as_h(i, j) >= 0) rec[AS_H + as_h(i, j)] = HH(i, j);
 #undef HH
 #pragma unroll
-            for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; rec[AS_HT + i] = Ht[i]; }
+            for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; if (i >= 2) rec[AS_HT + i - 2] = Ht[i]; }
         }
         red[0][LI(lane)] = dmax; red[1][LI(lane)] = pmax; red[2][LI(lane)] = lc0; red[3][LI(lane)] = lcmn; red[12][LI(lane)] = lcmx;
         red[4][LI(lane)] = lsz; red[5][LI(lane)] = lsy; red[6][LI(lane)] = lf; red[7][LI(lane)] = lth;
@@ -736,51 +751,55 @@ OBCA_FN void pair_of(int p, int &a_, int &b_) {   // p-th pair (a<=b) of the 6 c
 #define SG_SIZE 196
 // Staged values of a stage: 196, of which 92 are constants of the layout (identity / zero pattern of FA, unused right-hand-side columns of hc):
 // those are written ONCE per sweep into both buffers (stage_unpack_constants); the 104 that change with the stage -- H (64, the symmetric entries
-// twice), the 24 bicycle-model entries of FA, the 16 gradient / time columns of hc -- are gathered per stage, two per lane (value = kc + rec[idx]).
-#define SG_NVAR 104
-struct UnpackPlan { int idx[2], dst[2]; double kc[2]; };
+// twice), the 24 bicycle-model entries of FA, the 16 gradient / time columns of hc -- of which 64 can be non-zero (as_h, as_df) -- are gathered per stage, ONE per lane
+// (value = kc + rec[idx]); which position a lane serves is tabulated once per solve (Shared::upos).
+#define SG_NVAR 64
+struct UnpackPlan { int idx, dst; double kc; };
 OBCA_FN void stage_unpack_item(int it, int &idx, int &dst, double &fl, double &kc) {     // all 196 positions: what is stored where (fl = 0: the constant kc)
     idx = AS_DD; fl = 0.0; kc = 0.0; dst = SG_SIZE;              // default: harmless gather, store to the pad slot behind the buffer
-    if (it < 64) { idx = AS_H + hidx(it >> 3, it & 7); fl = 1.0; dst = SG_H + it; }
+    if (it < 64) { dst = SG_H + it; if (as_h(it >> 3, it & 7) >= 0) { idx = AS_H + as_h(it >> 3, it & 7); fl = 1.0; } }
     else if (it < 64 + 84) {
         const int e = it - 64, a_ = e / 14, cc = e % 14; dst = SG_FA + cc * 6 + a_;      // FA is staged TRANSPOSED: row cc of FA' = column cc of FA, contiguous
         if (cc < 8) {
             if (a_ < 4) {
                 if (cc < 4) kc = (a_ == cc) ? 1.0 : 0.0;
-                if (cc == 2) { idx = AS_DF + 5 * a_ + 0; fl = 1.0; }
-                if (cc == 3) { idx = AS_DF + 5 * a_ + 1; fl = 1.0; }
-                if (cc == 6) { idx = AS_DF + 5 * a_ + 2; fl = 1.0; }
-                if (cc == 7) { idx = AS_DF + 5 * a_ + 3; fl = 1.0; }
+                const int jc = cc == 2 ? 0 : (cc == 3 ? 1 : (cc == 6 ? 2 : (cc == 7 ? 3 : -1)));
+                if (jc >= 0 && as_df(a_, jc) >= 0) { idx = AS_DF + as_df(a_, jc); fl = 1.0; }
             } else kc = (cc == a_ + 2) ? 1.0 : 0.0;
-        } else if (a_ < 4) { const int col = cc - 8; if (col == 0) { idx = AS_DD + a_; fl = 1.0; } if (col == 1) { idx = AS_DF + 5 * a_ + 4; fl = 1.0; } }
+        } else if (a_ < 4) { const int col = cc - 8; if (col == 0) { idx = AS_DD + a_; fl = 1.0; } if (col == 1) { idx = AS_DF + as_df(a_, 4); fl = 1.0; } }
     } else if (it < SG_SIZE) {
         const int e = it - 148, i = e / OB_NC, cc = e % OB_NC; dst = SG_HC + e;
         if (cc == 0) { idx = AS_HB + i; fl = 1.0; }
-        if (cc == 1) { idx = AS_HT + i; fl = 1.0; }
+        if (cc == 1 && i >= 2) { idx = AS_HT + i - 2; fl = 1.0; }
     }
 }
-OBCA_FN int stage_var_position(int v) {     // v-th stage-dependent value -> its position among the 196
-    if (v < 64) return v;
-    if (v < 88) { const int a_ = (v - 64) / 6, q = (v - 64) % 6; const int cc = q < 2 ? 2 + q : (q < 4 ? 4 + q : 4 + q); return 64 + a_ * 14 + cc; }     // columns 2, 3, 6, 7, 8, 9
-    if (v < SG_NVAR) { const int i = (v - 88) / 2, cc = (v - 88) % 2; return 148 + i * OB_NC + cc; }
-    return SG_SIZE;
+// The item maps above are irregular (a divergent switch per position), so they are evaluated ONCE per solve into two small LDS tables; a sweep only reads them:
+//   upl[lane]    = (idx << 8) | dst | one << 16 : the stage-dependent position this lane gathers (there are exactly SG_NVAR = OB_NT of them)
+//   ucn[r][lane] = dst | one << 16, or -1       : the constant positions (+ the pad slot) this lane rewrites at the start of a sweep (the stage buffers share
+//                                                  their LDS with the forward sweep's pair maps)
+#define SG_NCONST_ROUNDS 3      // (SG_SIZE + 1 - SG_NVAR = 133 constant positions over 64 lanes)
+OBCA_FN void init_unpack_table(Shared &sh) {
+    PAR(lane) {
+        int nv_ = 0, nc_ = 0;
+        for (int r = 0; r < SG_NCONST_ROUNDS; r++) sh.ucn[r][lane] = -1;
+        for (int it = 0; it <= SG_SIZE; it++) {
+            int idx, dst; double fl, kc; stage_unpack_item(it, idx, dst, fl, kc);
+            const int one = kc != 0.0 ? (1 << 16) : 0;
+            if (fl != 0.0) { if (nv_ == lane) sh.upl[lane] = (idx << 8) | dst | one; nv_++; }
+            else { if (nc_ % OB_NT == lane && nc_ / OB_NT < SG_NCONST_ROUNDS) sh.ucn[nc_ / OB_NT][lane] = dst | one; nc_++; }
+        }
+    }
 }
-OBCA_FN void stage_unpack_plan(int lane, UnpackPlan &p) {
+OBCA_FN void stage_unpack_plan(const Shared &sh, int lane, UnpackPlan &p) { const int w = sh.upl[lane]; p.idx = (w >> 8) & 0xff; p.dst = w & 0xff; p.kc = (w >> 16) & 1 ? 1.0 : 0.0; }
+OBCA_FN void stage_unpack_constants(const Shared &sh, double *sg, int lane) {     // once per sweep, both buffers (+ the pad slot)
 #pragma unroll
-    for (int r = 0; r < 2; r++) { double fl; stage_unpack_item(stage_var_position(lane + OB_NT * r), p.idx[r], p.dst[r], fl, p.kc[r]); }
-}
-OBCA_FN void stage_unpack_constants(double *sg, int lane) {     // once per sweep, both buffers (+ the pad slot)
-    for (int it = lane; it <= SG_SIZE; it += OB_NT) {
-        int idx, dst; double fl, kc; stage_unpack_item(it, idx, dst, fl, kc);
-        if (fl == 0.0) { sg[dst] = kc; sg[OB_STG + dst] = kc; }
+    for (int r = 0; r < SG_NCONST_ROUNDS; r++) {
+        const int w = sh.ucn[r][lane];
+        if (w >= 0) { const double kc = (w >> 16) & 1 ? 1.0 : 0.0; sg[w & 0xffff] = kc; sg[OB_STG + (w & 0xffff)] = kc; }
     }
 }
-OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double v[2]) {   // independent, branch-free gathers;
-    v[0] = rec[p.idx[0]]; v[1] = rec[p.idx[1]];                                         // the raw values are only touched at store time
-}
-OBCA_FN void stage_unpack_store(double *sg, const UnpackPlan &p, const double v[2]) {
-    sg[p.dst[0]] = p.kc[0] + v[0]; sg[p.dst[1]] = p.kc[1] + v[1];
-}
+OBCA_FN void stage_unpack_load(const gdbl *rec, const UnpackPlan &p, double &v) { v = rec[p.idx]; }      // an independent, branch-free gather; the raw value is only touched at store time
+OBCA_FN void stage_unpack_store(double *sg, const UnpackPlan &p, const double v) { sg[p.dst] = p.kc + v; }
 
 // A dependent fp64 operation costs ~45 clock ticks when an instance runs alone on its CU (one wavefront per SIMD: nothing fills the pipeline;
 // tools/micro/lds_barrier_latency.hip), so the short dot products of the sequential sweeps are summed as a tree (depth 4 instead of 7).
@@ -854,7 +873,7 @@ OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
 }
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicPlan (&rp)[OBCA_NLT],
-                          double (&nv)[OBCA_NLT][RIC_D][2], const int slot, double *sg0) {
+                          double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0) {
     double *L = (double *)&sh;
     const int sgo = (k & 1) * OB_STG;         // which of the two stage buffers holds stage k
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
@@ -921,25 +940,25 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
 OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
-    double nv[OBCA_NLT][RIC_D][2];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
+    double nv[OBCA_NLT][RIC_D];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
     double *sg0 = stg_base(sh);      // the two stage buffers (dynamic LDS)
     UnpackPlan plan[OBCA_NLT]; RicPlan rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
-        stage_unpack_plan(lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
-        stage_unpack_constants(sg0, lane);
+        stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
+        stage_unpack_constants(sh, sg0, lane);
         if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
         if (lane < 6) sh.zero6[lane] = 0.0;
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
-            double v = rec[AS_H + hidx(i, j)];
+            double v = as_h(i, j) >= 0 ? rec[AS_H + as_h(i, j)] : 0.0;
             if (i == j && i < 4) v += rho;
             sh.Pn[lane] = v; sh.Bm[lane] = 0;
         }
         if (lane < 6) {
             double e = lane < 4 ? -(z[l.x + 4 * N + lane] - c.xF[lane]) : 0.0;
             sh.pn[0 * 6 + lane] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);      // (p is kept transposed: pn[c * 6 + a])
-            sh.pn[1 * 6 + lane] = rec[AS_HT + lane];
+            sh.pn[1 * 6 + lane] = lane >= 2 ? rec[AS_HT + lane - 2] : 0.0;
             for (int cc = 0; cc < 4; cc++) sh.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
         }
     }
@@ -947,19 +966,19 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
-        PAR(lane) { double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
+        PAR(lane) { double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
         LDS_SYNC();
         if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0)) { PROF(I, PF_RIC_BWD); return 0; }
     }
     if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
     PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
-        double v[2]; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
+        double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
         stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v);
 #pragma unroll
         for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
 #ifndef OBCA_EMU
 #pragma unroll
-        for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j][0]), "+v"(nv[0][j][1]));
+        for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j]));
 #endif
     }
     LDS_SYNC();
@@ -1062,8 +1081,8 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #pragma unroll
                 for (int cc = 0; cc < OB_NC; cc++) { kf0 += ro[RS_KF + cc] * coef[cc]; kf1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
 #pragma unroll
-                for (int i = 0; i < 4; i++) { b0[i] = rec[AS_DF + 5 * i + 2]; b1[i] = rec[AS_DF + 5 * i + 3]; a2[i] = rec[AS_DF + 5 * i + 0]; a3[i] = rec[AS_DF + 5 * i + 1];
-                                              dd[i] = rec[AS_DD + i]; ft[i] = rec[AS_DF + 5 * i + 4]; }
+                for (int i = 0; i < 4; i++) { b0[i] = as_df(i, 2) >= 0 ? rec[AS_DF + as_df(i, 2)] : 0.0; b1[i] = rec[AS_DF + as_df(i, 3)]; a2[i] = as_df(i, 0) >= 0 ? rec[AS_DF + as_df(i, 0)] : 0.0;
+                                              a3[i] = as_df(i, 1) >= 0 ? rec[AS_DF + as_df(i, 1)] : 0.0; dd[i] = rec[AS_DD + i]; ft[i] = rec[AS_DF + as_df(i, 4)]; }
                 double *cm = h ? M1 : M0[L_];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -1183,9 +1202,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     double e = -(z[l.x + 4 * N + i] - c.xF[i]);
-                    double a_ = (rN[AS_HB + i] - rho * e) + rN[AS_HT + i] * dt + nu[i];
+                    double a_ = (rN[AS_HB + i] - rho * e) + (i >= 2 ? rN[AS_HT + i - 2] : 0.0) * dt + nu[i];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) a_ += (rN[AS_H + hidx(i, j)] + ((i == j) ? rho : 0.0)) * sn[j];
+                    for (int j = 0; j < 6; j++) a_ += ((as_h(i, j) >= 0 ? rN[AS_H + as_h(i, j)] : 0.0) + ((i == j) ? rho : 0.0)) * sn[j];
                     dpi[i] = -a_;
                 }
             }
@@ -1613,6 +1632,7 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
             sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
         }
     }
+    init_unpack_table(sh);
     SYNC();
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)

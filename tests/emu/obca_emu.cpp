@@ -11,17 +11,17 @@
 #include "../../obca_amd/csrc/obca_quad_solver.h"
 using namespace obca;
 
-struct Scratch { double *z, *zn, *d, *as, *rs, *oc, *traj; };
+struct Scratch { double *z, *zn, *d, *as, *rs, *oc; };
 static void alloc_scratch(int N, int len, Scratch &s) {
     s.z = (double *)calloc(len, 8); s.zn = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
     s.as = (double *)calloc((size_t)(N + 1) * OB_AS, 8); s.rs = (double *)calloc((size_t)(N + 1) * OB_RS, 8);
-    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.traj = (double *)calloc((size_t)(N + 2) * 42, 8);
+    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8);
 }
-static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.traj); }
+static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); }
 
 static void setup(int N, const double *prob, Scratch &s) {
     Shared &sh = g_sh; Inst &I = sh.inst;
-    I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+    I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
     for (int i = 0; i < OB_HDR; i++) sh.hdr[i] = prob[i];
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
@@ -34,6 +34,7 @@ static void setup(int N, const double *prob, Scratch &s) {
     make_layout(c.N, c.nOb, c.M, sh.l);
     int vmx = 0; for (int j = 0; j < c.nOb; j++) if (sh.vOb[j] > vmx) vmx = sh.vOb[j];
     sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
+    init_unpack_table(sh);
 }
 
 extern "C" {
@@ -80,7 +81,7 @@ int emu_newton_fused(int N, const double *prob, const double *zin, int len, doub
 int emu_solve(int N, const double *prob, const double *zinit, int len, const void *opts, double *zout, double *info) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zinit, sizeof(double) * len);
-    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
     double *st = (double *)calloc(SL_SIZE, 8);
     solve_instance(N, *(const Opts *)opts, info, st);
     free(st);
@@ -97,7 +98,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     int launches = 0;
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
-        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; I.traj = s.traj;
+        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
         solve_instance(N, *(const Opts *)opts, info, st, mode, budget);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;

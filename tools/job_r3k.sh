@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, job k: table-driven unpack plan (Riccati regression of the packed records), census of the IPOPT options the kernels do not have
+mkdir -p gpurun_out/r3k; O=$PWD/gpurun_out/r3k; R=$PWD; C=$R/obca_amd/csrc
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "not config3_bench" 2>&1 | tail -4 > $O/pytest.log; cat $O/pytest.log
+timeout 600 python bench.py --no-cpu-baseline --no-host-rate --steps 200 > $O/bench.json 2> $O/bench.err; python -c "
+import json; d=json.load(open('$O/bench.json')); r=d['roofline']; print('value', d['value'], 'traffic', r['traffic'], 'kernel_ms', r['kernel_ms'], r.get('traffic_over_algorithmic'), 'sync', d['config']['single_batch_sync_solves_per_s'])"
+for B in 64 1024; do OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py $B > $O/phase_B$B.txt 2>&1; grep -v "^ric_p\|^init" $O/phase_B$B.txt; done
+timeout 1500 python tools/parity_census.py 2 3 5 --ipopt-options > $O/census_ipopt_options.txt 2>&1; grep "config" $O/census_ipopt_options.txt
