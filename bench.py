@@ -67,15 +67,19 @@ def f_pass_parking(N, blocks_per_stage):
 
 
 def b_pass_parking(N, nOb, M):
-    """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-3 kernel.  Per (stage, obstacle)
-    block: iterate part zb = 2 v + 15 doubles (lambda, mu, sl, slack, their multipliers), step db = v + 10, condensed record 12.  Per stage: iterate part 26, step 8,
-    stage record 60 (the entries that can be non-zero), Riccati record 72, reference 3.  A pass streams: direction_obs zb (read) + db (write); fused line search zb + db (read), zb + 12 (write), per stage
-    26 + 8 + 12 nOb + 3 (read), 26 + 60 (write); backward sweep 60 (read) + 72 (write); forward sweep / back-substitution 44 + 21 + 72 + 7 (read) + 8 (write); plus 0.16
-    stand-alone assemblies per pass (first iterate, barrier updates, inertia retries)."""
+    """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-3 kernel (default build: the obstacle
+    part of the search direction is recomputed, never stored).  Per stage and pass, in doubles; zb = iterate part of the stage's (stage, obstacle) blocks = 2 v + 15 per block
+    (lambda, mu, sl, slack, their multipliers):
+      direction_obs        read zb
+      fused line search    obstacle part: read zb, write zb + condensed records 12 nOb;  stage part: read 26 (iterate) + 8 (step) + 12 nOb (condensed records) + 3 (reference),
+                           write 26 (trial iterate) + 60 (stage record)
+      backward sweep       read 60, write 72 (Riccati record)
+      forward sweep + stage back-substitution   read 44 + 21 (stage record) + 72 (Riccati record) + 7, write 8 (stage step)
+    plus 0.16 stand-alone assemblies per pass (first iterate, barrier updates, inertia retries)."""
     N1 = N + 1
-    zb = 2.0 * M + 15.0 * nOb; db = 1.0 * M + 10.0 * nOb           # per stage, all obstacles
-    rd = N1 * (zb + (zb + db) + (26 + 8 + 12 * nOb + 3) + 60 + (44 + 21 + 72 + 7))
-    wr = N1 * (db + (zb + 12 * nOb) + (26 + 60) + 72 + 8)
+    zb = 2.0 * M + 15.0 * nOb
+    rd = N1 * (zb + zb + (26 + 8 + 12 * nOb + 3) + 60 + (44 + 21 + 72 + 7))
+    wr = N1 * ((zb + 12 * nOb) + (26 + 60) + 72 + 8)
     asm = 0.16 * N1 * ((zb + 26 + 12 * nOb) + (12 * nOb + 60))
     return 8.0 * (rd + wr + asm)
 
@@ -252,6 +256,40 @@ def obstacle_args(cfg, rows, shared, n):
     return vl, Al, bl
 
 
+def single_process(a):
+    """ONE process, every visible GPU: the route a Julia caller takes (julia/OBCAHip.jl: MultiContext).  The host-pointer entry point cuts each call into chunks and the
+    worker lanes of all devices pull them from one queue (include/obca_hip.h: obca_create_multi); inputs and outputs are host arrays, PCIe is inside the timed region."""
+    import obca_amd
+    from obca_amd import validate as V
+    cfg = a.config; C = CONFIGS[cfg]; N = C["N"]
+    assert C["kind"] == "parking", "--single-process: parking configs (2, 3, 5)"
+    from obca_amd import api
+    ndev = max(1, int(api._load().obca_visible_device_count()))
+    B = (a.batch or C["per_gpu"]) * max(1, ndev)
+    rows, shared = make_host_batch(cfg, B, SEED + a.seed_offset, hybrid=(a.warm_start == "hybrid"))
+    vOb, A, b = obstacle_args(cfg, rows, shared, B)
+    xWS = rows["xWS"].reshape(B, N + 1, 4); uWS = rows["uWS"].reshape(B, N, 2); keep = {}
+    call = lambda: obca_amd.parking_signed_dist_batch(rows["x0"], rows["xF"], N, rows["Ts"][:, 0], shared["L"], shared["ego"], shared["XYbounds"], vOb, A, b,
+                                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, uWS, device="all", buffers=keep)
+    for _ in range(max(1, a.warmup // 4)):
+        out = call()
+    steps = max(1, a.steps // 10)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = call()
+    dt = time.perf_counter() - t0
+    ok = 0
+    for i in np.flatnonzero(out["exitflag"] == 1):
+        v = np.ravel(vOb[i] if cfg == 5 else vOb)
+        ok += bool(V.validate_parking(rows["x0"][i], rows["xF"][i], N, rows["Ts"][i, 0], shared["L"], shared["ego"], shared["XYbounds"], v, A[i] if cfg == 5 else A, b[i] if cfg == 5 else b,
+                                      out["xp"][i], out["up"][i], out["timeScale"][i], out["lp"][i], out["np"][i], out["sl"][i], tol=1e-4)[0])
+    print(json.dumps({"metric": "OBCA NLP solves/sec (N=80, 3 obs, batch) at 1/2/4/8 MI355X vs IPOPT-CPU", "value": round(ok * steps / dt, 2), "unit": "solves/s", "n_gpus": ndev,
+                      "steps": steps, "warmup": max(1, a.warmup // 4), "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": C["name"], "config": cfg, "mode": "single process, multi-device context (obca_create_multi), host-pointer entry point: host arrays in, host arrays out, "
+                                 "PCIe and (un)packing inside the timed region", "instances_per_step": B, "converged": ok}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,10 +306,14 @@ def main():
     ap.add_argument("--seed-offset", type=int, default=0, help="diagnostic: shift the seed of the job's batch")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the host-pointer (PCIe-inclusive) call behind config.host_pointer_solves_per_s")
+    ap.add_argument("--single-process", action="store_true", help="the Julia route: ONE process drives every visible GPU through a multi-device context (obca_create_multi) and the "
+                    "host-pointer entry point; a step = one call on batch x devices host-array instances, PCIe included (parking configs)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the run rocprofv3 wraps (one step + one synchronous step of the same batch, no output)")
     a = ap.parse_args()
     if a.pmc_child:
         a.steps, a.warmup, a.streams, a.sync_steps, a.no_cpu_baseline, a.no_pmc, a.no_host_rate = 1, 0, 1, 1, True, True, True
+    if a.single_process:
+        return single_process(a)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if a.steps < 1:

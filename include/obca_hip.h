@@ -34,7 +34,14 @@ extern "C" {
 typedef struct obca_ctx obca_ctx;
 typedef struct obca_batch obca_batch;
 
-/* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults. */
+/* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults.
+ * What the solver behind them is: IPOPT's Algorithm A (monotone barrier, filter line search, inertia-correction ladder, alpha_for_y = min) on a structured KKT solve.
+ * IPOPT semantics the reference relies on that the kernels do NOT have: recalc_y = "yes" (:41), the second-order correction, a general restoration phase (the
+ * quadcopter kernel has a block restoration), least-squares initial multipliers, kappa_d damping, gradient-based NLP scaling (half-space rows enter with unit length
+ * instead).  recalc_y and the second-order correction exist as options of the CPU checker (oracle/obca_oracle.c); on the full bench batches of BASELINE configs 2, 3
+ * and 5 (1 024 + 2 048 + 4 096 instances) the kernels' results and the checker's WITH both switched on have identical exit flags -- every instance is solved either
+ * way -- while 70 / 711 / 220 iteration counts differ and, the NLP being non-convex, 0 / a handful / a few instances end in another local solution
+ * (profiles/r03_census_soc_recalc_y.txt, tools/parity_census.py --ipopt-options).  DESIGN.md section 2. */
 typedef struct obca_opts {
     double tol; int max_iter;
     double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
@@ -49,7 +56,7 @@ int obca_create(obca_ctx **out, int device);
  * (solve times are heavy-tailed: a static slice per device would wait for the unluckiest one); every device runs OBCA_SLOTS (default 4)
  * chunks at a time on streams of their own, so that the PCIe transfers and the host-side packing of one chunk overlap the solves of the
  * others.  Instances are independent: no collective touches the data path.  Results do not depend on the device count, the chunk size
- * (OBCA_CHUNK, default = twice the instances resident on one GPU) or the slot count: every instance is solved by one workgroup either way.
+ * (OBCA_CHUNK, default = the 1 024 instances resident on one GPU: four per CU) or the slot count: every instance is solved by one workgroup either way.
  * The device-resident obca_batch_* / obca_quad_batch_* calls of a multi-device context run on its first device. */
 int obca_create_multi(obca_ctx **out, const int *devices, int ndev);
 int obca_device_count(const obca_ctx *ctx);          /* devices this context drives */
@@ -111,8 +118,9 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-pha
  * x is 12 x (N+1) stage-contiguous, u 4 x N; ob is 6 x 5 per instance: ob1..ob5 back to back, each [xmax,ymax,zmax,-xmin,-ymin,-zmin]
  * (the `b` of A = [I;-I], :162-166); lp is 30 x (N+1): [l1;l2;l3;l4;l5] stacked as the reference returns it (:295).
  * uWS is accepted for signature parity and ignored like the reference does (:202 starts every input at the hover speed).
- * dual_ws != 0 starts the multipliers at the closed-form point-to-box dual solution (recommended; the reference's lambda = 0.05
- * start has a rank-deficient Jacobian and relies on IPOPT's restoration phase, which this solver does not have -- DESIGN.md).
+ * dual_ws != 0 starts the multipliers at the closed-form point-to-box dual solution (recommended).  dual_ws = 0 is the reference's own start (lambda = 0.05,
+ * :204-208): its Jacobian is rank deficient there, IPOPT leaves the point through its restoration phase, this solver through a block feasibility restoration that
+ * stands in for it (closed-form distance duals at the current positions, at most three times per solve).
  * exitflag: 1 = solved, 2 = solved but sum(slack) > 1e-3 (:285-288), 0 = failed.  max_iter default 3000, see obca_quadcopter_default_opts. */
 #define OBCA_QUAD_NMAX 128   /* mainQuadcopter.jl:116-131: the A* path on the 1.0 grid from x = 10 to 90 gives N_as >= 80 */
 typedef struct obca_quad_batch obca_quad_batch;

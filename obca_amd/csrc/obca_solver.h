@@ -1,19 +1,19 @@
 // obca_solver.h -- one OBCA parking NLP instance solved by ONE wavefront (workgroup of OB_NT = 64 threads, gfx950), persistent over the whole
-// interior-point solve; the kernel runs one wavefront per SIMD (256 VGPRs + 256 AGPRs per wave), FOUR instances per CU (25 KB of LDS each).
-// (Round 1 used two wavefronts per instance and two instances per CU: while wavefront 0 ran a sequential sweep the other one idled on its SIMD, and
-// every exchange between the two cost a workgroup barrier.  With the instance inside one wavefront all cross-lane traffic is wave-local.)
+// interior-point solve; the kernel runs one wavefront per SIMD (256 VGPRs + 256 AGPRs per wave), FOUR instances per CU (6.3 KB of static LDS +
+// OB_DYN_LDS_DOUBLES(N) * 8 bytes sized for the horizon at launch: 24 KB at N = 80).
 //
-// Programming model: code outside a PAR(lane){...} region is workgroup-uniform (every lane computes the same scalars); PAR regions
-// distribute work items over the 128 lanes; data crosses lanes only through LDS (`Shared`), the per-instance records in HBM, or -- inside
-// wavefront 0 -- DPP / v_readlane; never through registers held across a SYNC().
+// Programming model: code outside a PAR(lane){...} region is wave-uniform (every lane computes the same scalars; what must survive a phase call lives
+// in LDS: Shared::drv / sol / o); PAR regions distribute work items over the 64 lanes; data crosses lanes through LDS (`Shared`, g_traj), the per-instance
+// records in HBM, or DPP / ds_bpermute / v_readlane.
 //   * (stage, obstacle) blocks  -> one lane per block        (condensation / back-substitution, obca_model.h)
 //   * stages                    -> one lane per stage        (bicycle model derivatives, costs, bounds)
-//   * Riccati backward sweep    -> sequential in the stage index; per stage three short LDS phases, one matrix entry per lane on both waves
-//   * forward sweep             -> wavefront 0, two stages per dependent step, state broadcast with v_readlane
-//   * reductions (norms, step lengths, objective) -> LDS fold of the second wave + 64-lane butterfly (DPP for the in-row exchanges)
-// Phases are non-inlined device functions (ph_*) with all uniform state in LDS; a solve can be parked at the top of an iteration and
-// resumed by a later launch (Slice, two-launch schedule).  The algorithm is the primal-dual interior-point method stated in DESIGN.md
-// (IPOPT's Algorithm A with the option values of ParkingSignedDist.jl:41-43).
+//   * Riccati backward sweep    -> sequential in the stage index; per stage three short LDS phases, two matrix entries per lane, 16-byte LDS operands
+//   * forward sweep             -> two stages per dependent step: pair maps composed into LDS, state broadcast with v_readlane
+//   * reductions (norms, step lengths, objective) -> 64-lane register butterfly (DPP inside a row of 16 lanes, ds_bpermute across rows)
+//   * line search               -> fused into the next assembly (assemble_obs / assemble_stage <FUSED = 1>): the trial point goes to the second iterate buffer
+// Phases are non-inlined device functions (ph_*), each with its own register allocation; a solve can be parked right after an accepted trial and
+// resumed by a later launch with the assembly at hand (Slice, two-launch schedule).  The algorithm is the primal-dual interior-point method stated in
+// DESIGN.md (IPOPT's Algorithm A with the option values of ParkingSignedDist.jl:41-43).
 //
 // The same source is compiled by tests/emu (g++, -DOBCA_EMU) where PAR is a plain loop over the lanes: that build exists only so that
 // the kernel logic can be unit-tested on a machine without a GPU.  It is not linked into the product.
