@@ -24,6 +24,14 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
                            const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
                            int *expansions /* may be NULL */);
 
+/* The same search for B independent (start, goal) pairs in one obstacle field, on `threads` host threads (0 = one per hardware thread) inside the library: what a rank
+ * calls for its slice of a batch before the solve (main.jl:216-252 plans one instance; a batch of 2 048 parallel-parking starts takes ~0.2 core-seconds each).
+ * starts / goals: B x 3; paths: B x cap x 3; dirs: B x cap; counts[i] = what obca_plan_hybrid_astar returns for pair i; expansions (may be NULL): B.
+ * Returns 0, or -1 on bad arguments. */
+int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
+                                 const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
+                                 int *counts, int *expansions /* may be NULL */, int threads);
+
 /* Shortest Reeds-Shepp path (forward and reverse arcs of radius R and straight lines; stands where hybrid_a_star.jl:262-300 calls
  * reeds_shepp.calc_shortest_path, reeds_shepp.jl) from start to goal (x, y, yaw), sampled every `step` metres: path[3k..3k+2] = pose k,
  * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5 doubles, may be NULL) their

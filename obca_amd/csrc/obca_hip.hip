@@ -182,9 +182,7 @@ struct QDevBufs {
 __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
-    extern __shared__ double q_dyn_lds[];
     if (threadIdx.x == 0) {
-        quad::gq_sh.traj = q_dyn_lds;
         quad::QInst &I = quad::gq_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_d);
@@ -885,7 +883,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * QS * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;

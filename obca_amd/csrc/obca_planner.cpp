@@ -14,6 +14,8 @@
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include "../../include/obca_plan.h"
 
 namespace {
@@ -336,6 +338,29 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
 /* Shortest Reeds-Shepp path from start to goal (x, y, yaw) for turning radius R, sampled every `step` metres: path[3k..] = pose k,
  * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5, may be NULL) their signed
  * lengths in metres.  Returns the number of samples (start and goal included), -1 on bad arguments / cap too small. */
+int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
+                                 const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
+                                 int *counts, int *expansions, int threads) {
+    if (B < 0 || !starts || !goals || !paths || !dirs || !counts || cap < 2) return -1;
+    unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > (unsigned)B) nt = (unsigned)(B > 0 ? B : 1);
+    std::atomic<int> next(0);      // the searches differ by two orders of magnitude in length: a shared counter, not static slices
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < B; i = next.fetch_add(1)) {
+            int ne = 0;
+            counts[i] = obca_plan_hybrid_astar(starts + 3 * (size_t)i, goals + 3 * (size_t)i, nOb, vOb, A, b, ego, L, XYbounds, opts, paths + 3 * (size_t)cap * i,
+                                               dirs + (size_t)cap * i, cap, &ne);
+            if (expansions) expansions[i] = ne;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return 0;
+}
+
 int obca_plan_reeds_shepp(const double start[3], const double goal[3], double R, double step, double *path, int *dir, int cap, char *word,
                           double *seglen, double *total) {
     if (!start || !goal || !(R > 0) || !(step > 0) || !path || !dir || cap < 2) return -1;

@@ -98,24 +98,28 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R
 struct QShared {
     QConsts c; QLay l; QInst inst; AsmOut A, A2, Ap; StepOut S; double trial[4];
     double ob[QOB * QL];
-    double red[16][QNT];               // reductions; during the sweeps the same memory holds That|Qhat or -- together with Pn, pn, sg behind it, which are dead
+    alignas(16) double red[16][QNT];   // reductions; during the sweeps the same memory holds That|Qhat or -- together with Pn, pn, sg behind it, which are dead
                                        // by then -- the forward-sweep ring (2 x QFW_CH x QFW_SZ = 2 016 doubles <= 16 QNT + 256 + 224 + 736)
     double Pn[QS * QS], pn[QS * QC], sg[QSR], Khat[QU * 30], Bm[QC * QC], sB[4 * QC], Lq[QU * QU];
     double bord[13 * 13 + 3 * 13], coef[QC];
 #ifdef OBCA_EMU
-    double traj[(QNMAX + 2) * QS];
-#else
-    double *traj;                      // (N + 2) x 16 doubles of dynamic LDS behind this block: the launch sizes it for the batch's horizon (N = 60: 7.9 KB, four instances per CU)
+    alignas(16) double traj[(QNMAX + 2) * (QS + QU)];
 #endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
     int hintl[QNT];                    // per lane: a box block whose inertia was wrong in an earlier assembly (-1: none), see q_block_bad
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
+// The forward-sweep trajectory ((N + 2) x 16 doubles) and, behind it, kf_k(coef) (N x 4) live in dynamic LDS behind the static block: the launch sizes it for the
+// batch's horizon (N = 60: 9.9 KB, four instances per CU).  It is addressed through the array itself, never through a pointer kept in memory: a loaded pointer is
+// "generic", its accesses become flat_load / flat_store, and a flat access waits for vmcnt(0) -- for every HBM gather in flight -- before it returns.
 #ifdef OBCA_EMU
 static QShared gq_sh;
+#define QTRAJ(sh) ((sh).traj)
 #else
 __shared__ QShared gq_sh;
+extern __shared__ __attribute__((aligned(16))) double gq_traj[];
+#define QTRAJ(sh) gq_traj
 #endif
 #if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
 #define QPROF(id) do { long long now_ = clock64(); if (LANE0) { gq_sh.prof[id] += (double)(now_ - gq_sh.tlast); gq_sh.tlast = now_; } } while (0)
@@ -638,74 +642,119 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         if (!ok) return;
     }
     const double dt = sh.coef[1];
-    QPROF(QPF_CL);
-    // ---- forward recursion on wavefront 0:  u_k = K_k s_k + kf_k(coef),  x_{k+1} = A_k x_k + B_k u_k + d_k + dt Ft_k,  w_{k+1} = u_k.
-    // Per stage the first 12 rows of the dense FX block (216 doubles, stage record) and the gains K | KF (120 doubles, Riccati record) are
-    // staged through LDS in chunks of QFW_CH stages (ring in the reduction scratch, gathered one chunk ahead); no closed-loop matrices are
-    // formed.  Two LDS phases per stage: partial inputs (lanes 0..3: K s, lanes 4..7: KF coef), then the 16 state rows.
-#define QFW_CH 3
+    // ---- forward recursion:  u_k = K_k s_k + kf_k(coef),  x_{k+1} = A_k x_k + B_k u_k + d_k + dt Ft_k,  w_{k+1} = u_k  (s = (x, w); no closed-loop matrices are formed).
+    // A chain of N dependent steps, so what counts is the latency of one step.  Lane 4 i + c owns chunk c (four terms) of row i: the 16 terms of a gain row / the 12 + 4
+    // terms of a state row are summed inside a quad of lanes (two DPP exchanges), the four inputs reach every lane through v_readlane, and the new state goes to the LDS
+    // trajectory -- one LDS round trip per stage, every LDS operand a 16-byte read.  What does not depend on the state is taken out of the chain: kf_k(coef) for all stages
+    // is formed stage-parallel beforehand (LDS, behind the trajectory), and the stage data (the first 12 rows of the dense FX block, 216 doubles of the stage record, and
+    // the gains K, 64 doubles of the Riccati record) is gathered from HBM QFWD stages ahead, five values per lane through offsets tabulated once per sweep, into a
+    // double-buffered LDS slot.  (Round 2: two LDS phases per stage with 16- and 18-term sums on 8 + 12 lanes, 8-byte LDS reads, record offsets recomputed for every
+    // gathered value, chunks of three stages gathered one chunk ahead: 1 800 clocks per stage alone, 2 700 with four instances per CU.)
+#ifndef QFWD
+#define QFWD 6                       // stages the gathers run ahead
+#endif
 #define QFW_F 216
-#define QFW_SZ (QFW_F + 120)
-#define QFW_PER ((QFW_CH * QFW_SZ + 63) / 64)
-    WAVE0_BEGIN
-        double pf[OBCA_NL][QFW_PER];
+#define QFW_SZ (QFW_F + QU * QS)     // 280 values per stage
+#define QFW_SLOT 288                 // slot stride (16-byte aligned; [280, 288) is the pad the lanes without a fifth value write to)
+#define QFW_PER 5
+    {
         double *ring = &sh.red[0][0];
-        double *up = sh.sB;                       // 8 partial inputs (free after the backward sweep)
-        PAR64(lane) {
-            if (lane < QS) sh.traj[lane] = 0.0;
+        double *kfc = QTRAJ(sh) + (size_t)(N + 2) * QS;          // kf_k(coef): N x 4, behind the trajectory (dynamic LDS)
+        int fo[OBCA_NL][QFW_PER];                              // per lane: where its values of a stage live (>= 0: stage record, < 0: -1 - offset in the Riccati record)
+        double nvf[OBCA_NL][QFWD][QFW_PER];
+        QPAR(lane) {
+            const int L_ = LI(lane);
 #pragma unroll
-            for (int r = 0; r < QFW_PER; r++) {
-                const int e = lane + 64 * r, st = e / QFW_SZ, j = e % QFW_SZ;
-                if (e < QFW_CH * QFW_SZ && st < N) ring[e] = j < QFW_F ? (sh.inst.as + (size_t)st * QSP)[QR(QSR_F + j)] : (sh.inst.rs + (size_t)st * QRR)[QRR_K + (j - QFW_F)];
+            for (int r = 0; r < QFW_PER; r++) { const int e = lane + 64 * r; fo[L_][r] = e < QFW_F ? QR(QSR_F + e) : (e < QFW_SZ ? -1 - (QRR_K + (e - QFW_F)) : QR(QSR_F)); }
+            for (int it = lane; it < QU * N; it += QNT) {
+                const gdbl *kf = sh.inst.rs + (size_t)(it >> 2) * QRR + QRR_KF + (it & 3) * QC;
+                double a0 = 0, a1 = 0;
+#pragma unroll
+                for (int cc = 0; cc < QC; cc += 2) { a0 = fma(kf[cc], sh.coef[cc], a0); a1 = fma(kf[cc + 1], sh.coef[cc + 1], a1); }
+                kfc[it] = a0 + a1;
             }
+            if (lane < QS) QTRAJ(sh)[lane] = 0.0;
+#define QFW_LOAD(st_, dst_) { const int sc_ = (st_) < N ? (st_) : N - 1; const gdbl *as_ = sh.inst.as + (size_t)sc_ * QSP, *rs_ = sh.inst.rs + (size_t)sc_ * QRR; \
+                              _Pragma("unroll") for (int r = 0; r < QFW_PER; r++) { const int o_ = fo[L_][r]; (dst_)[r] = o_ >= 0 ? as_[o_] : rs_[-1 - o_]; } }
+#define QFW_STORE(st_, src_) { double *sl_ = ring + (size_t)((st_) & 1) * QFW_SLOT; \
+                               _Pragma("unroll") for (int r = 0; r < QFW_PER; r++) { const int e_ = lane + 64 * r; sl_[e_ < QFW_SZ ? e_ : QFW_SZ + (lane & 7)] = (src_)[r]; } }
+            { double v0[QFW_PER]; QFW_LOAD(0, v0); QFW_STORE(0, v0); }
+#pragma unroll
+            for (int j = 0; j < QFWD; j++) QFW_LOAD(1 + j, nvf[L_][(1 + j) % QFWD]);
         }
         LDS_SYNC();
-        for (int k0 = 0; k0 < N; k0 += QFW_CH) {
-            const int cb = (k0 / QFW_CH) & 1;
-            PAR64(lane) {
+        QPROF(QPF_CL);
+        for (int kb = 0; kb < N; kb += QFWD) {
 #pragma unroll
-                for (int r = 0; r < QFW_PER; r++) {
-                    const int e = lane + 64 * r, st = k0 + QFW_CH + e / QFW_SZ, j = e % QFW_SZ; const int sc = st < N ? st : N - 1;
-                    const double v = j < QFW_F ? (sh.inst.as + (size_t)sc * QSP)[QR(QSR_F + j)] : (sh.inst.rs + (size_t)sc * QRR)[QRR_K + (j - QFW_F)];
-                    pf[LI(lane)][r] = v;
-                }
-            }
-            for (int k = k0; k < k0 + QFW_CH && k < N; k++) {
-                const double *rec = ring + (size_t)(cb * QFW_CH + (k - k0)) * QFW_SZ, *s_ = sh.traj + (size_t)k * QS;
-                PAR64(lane) {   // one branch-free 16-term product for both kinds of lane (a divergent if / else would run both sides in turn)
-                    const bool fb = lane < QU; const int ln = lane < 2 * QU ? lane : 0;
-                    const double *ap = rec + QFW_F + (fb ? ln * QS : 64 + (ln - QU) * QC), *bp = fb ? s_ : sh.coef;
-                    double ac[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int j = 0; j < QS; j++) {
-                        const bool on = j < QC || fb; const int jj = on ? j : 0;
-                        const double bv = bp[jj]; ac[j & 3] += ap[jj] * (on ? bv : 0.0);
+            for (int ju = 0; ju < QFWD; ju++) {
+                const int k = kb + ju;
+                if (k < N) {
+                    const double *rec = ring + (size_t)(k & 1) * QFW_SLOT, *s_ = QTRAJ(sh) + (size_t)k * QS;
+                    double fa[OBCA_NL][4], pK[OBCA_NL], t1[OBCA_NL], cst[OBCA_NL], uq[OBCA_NL], p2[OBCA_NL], xs[OBCA_NL];
+                    QPAR(lane) {
+                        const int L_ = LI(lane), i = lane >> 2, cI = lane & 3, ir = i < QX ? i : 0;
+                        double sv[4], ka[4];
+                        ldv<4>(s_ + 4 * cI, sv); ldv<4>(rec + ir * QFC + 4 * cI, fa[L_]); ldv<4>(rec + QFW_F + (i & 3) * QS + 4 * cI, ka);
+                        cst[L_] = rec[ir * QFC + 16] + dt * rec[ir * QFC + 17];
+                        pK[L_] = dot4_tree(cI == 0 ? kfc[QU * k + (i & 3)] : 0.0, ka, sv);
+                        t1[L_] = dot4_tree(0.0, fa[L_], sv);
                     }
-                    if (lane < 2 * QU) up[lane] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                    wquad_sum(pK, uq);
+                    const double uu[4] = {WV_READLANE(uq, 0), WV_READLANE(uq, 4), WV_READLANE(uq, 8), WV_READLANE(uq, 12)};
+                    QPAR(lane) { const int L_ = LI(lane); p2[L_] = (lane & 3) == 3 ? dot4_tree(cst[L_], fa[L_], uu) : t1[L_]; }
+                    wquad_sum(p2, xs);
+                    QPAR(lane) {
+                        const int L_ = LI(lane), i = lane >> 2;
+                        if ((lane & 3) == 0) QTRAJ(sh)[(size_t)(k + 1) * QS + i] = i < QX ? xs[L_] : (i == QX ? uu[0] : (i == QX + 1 ? uu[1] : (i == QX + 2 ? uu[2] : uu[3])));
+                        // the gather of stage k+1 (issued QFWD stages ago) goes to the other slot; its registers take stage k+1+QFWD
+#ifndef OBCA_QFW_NOGATHER      /* (diagnostic: the chain without its HBM gathers) */
+                        QFW_STORE(k + 1, nvf[L_][(ju + 1) % QFWD]);
+                        QFW_LOAD(k + 1 + QFWD, nvf[L_][(ju + 1) % QFWD]);
+#endif
+                    }
+                    LDS_SYNC();
                 }
-                LDS_SYNC();
-                PAR64(lane) {
-                    if (lane < QX) {
-                        double ac[4] = {rec[lane * QFC + 16] + dt * rec[lane * QFC + 17], 0, 0, 0};
-#pragma unroll
-                        for (int j = 0; j < QX; j++) ac[j & 3] += rec[lane * QFC + j] * s_[j];
-#pragma unroll
-                        for (int a = 0; a < QU; a++) ac[a] += rec[lane * QFC + 12 + a] * (up[a] + up[QU + a]);
-                        sh.traj[(size_t)(k + 1) * QS + lane] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-                    } else if (lane < QS) sh.traj[(size_t)(k + 1) * QS + lane] = up[lane - QX] + up[QU + lane - QX];
-                }
-                LDS_SYNC();
             }
-            PAR64(lane) {
-#pragma unroll
-                for (int r = 0; r < QFW_PER; r++) { int e = lane + 64 * r; if (e < QFW_CH * QFW_SZ) ring[(size_t)(1 - cb) * QFW_CH * QFW_SZ + e] = pf[LI(lane)][r]; }
-            }
-            LDS_SYNC();
         }
-    WAVE0_END
+#undef QFW_LOAD
+#undef QFW_STORE
+    }
     SYNC();
     QPROF(QPF_FWD);
-    // ---- stage-parallel: steps of x, u; costate increments; step-length / descent partials of x, u
+    // ---- costate increments of the stages with a Riccati record behind them, d pi_k = -(P_{k+1} s_{k+1} + p_{k+1} coef): one (stage, row) item per lane, so that
+    // consecutive lanes read consecutive rows of the records (with one STAGE per lane every load of the 360 values touched 64 different lines); three items per
+    // lane in flight, all loads before the first store (d may alias the records as far as the compiler knows)
+    QPAR(lane) {
+        const int nit = QX * (N - 1);
+#define QCS_R 3
+        for (int base = 0; base < nit; base += QCS_R * QNT) {
+            double pv[QCS_R][QC], px[QCS_R][QS], a_[QCS_R];
+#pragma unroll
+            for (int r = 0; r < QCS_R; r++) {
+                const int it = base + lane + QNT * r, ic = it < nit ? it : 0, k = ic / QX, i = ic - k * QX;
+                const gdbl *r1 = sh.inst.rs + (size_t)(k + 1) * QRR;
+#pragma unroll
+                for (int cc = 0; cc < QC; cc++) pv[r][cc] = r1[QRR_PV + i * QC + cc];
+#pragma unroll
+                for (int j = 0; j < QS; j++) px[r][j] = r1[QRR_PX + i * QS + j];
+            }
+#pragma unroll
+            for (int r = 0; r < QCS_R; r++) {
+                const int it = base + lane + QNT * r, ic = it < nit ? it : 0, k = ic / QX;
+                const double *sn = QTRAJ(sh) + (size_t)(k + 1) * QS;
+                double a = 0;
+#pragma unroll
+                for (int cc = 0; cc < QC; cc++) a += pv[r][cc] * sh.coef[cc];
+#pragma unroll
+                for (int j = 0; j < QS; j++) a += px[r][j] * sn[j];
+                a_[r] = -a;
+            }
+#pragma unroll
+            for (int r = 0; r < QCS_R; r++) { const int it = base + lane + QNT * r; if (it < nit) d[l.pi + it] = a_[r]; }
+        }
+#undef QCS_R
+    }
+    // ---- stage-parallel: steps of x, u; the last costate increment; step-length / descent partials of x, u
     QPAR(lane) {
         double ap = 1.0, az = 1.0, gd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < ap) ap = cc_; }
@@ -713,25 +762,14 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         for (int k = lane; k <= N; k += QNT) {
             // All loads of the stage come first and all stores last: d and z may alias as far as the compiler knows, so a load after a store would wait for its
             // own round trip (the stage used to take one round trip per state and per costate row).
-            const double *s = sh.traj + (size_t)k * QS, *sn = sh.traj + (size_t)(k + 1 <= N ? k + 1 : N) * QS;
+            const double *s = QTRAJ(sh) + (size_t)k * QS, *sn = QTRAJ(sh) + (size_t)(k + 1 <= N ? k + 1 : N) * QS;
             const int ku = k < N ? k : N - 1, km = ku >= 1 ? ku - 1 : 0;
             double xv[QX], zLx[QX], zUx[QX], uv[QU], um[QU], zLu[QU], zUu[QU], dpi[QX];
 #pragma unroll
             for (int i = 0; i < QX; i++) { xv[i] = z[l.x + QX * k + i]; zLx[i] = z[l.zL + l.x + QX * k + i]; zUx[i] = z[l.zU + l.x + QX * k + i]; }
 #pragma unroll
             for (int j = 0; j < QU; j++) { uv[j] = z[l.u + QU * ku + j]; um[j] = z[l.u + QU * km + j]; zLu[j] = z[l.zL + l.u + QU * ku + j]; zUu[j] = z[l.zU + l.u + QU * ku + j]; }
-            if (k + 1 < N) {
-                const gdbl *r1 = sh.inst.rs + (size_t)(k + 1) * QRR;
-#pragma unroll
-                for (int i = 0; i < QX; i++) {
-                    double a_ = 0;
-#pragma unroll
-                    for (int cc = 0; cc < QC; cc++) a_ += r1[QRR_PV + i * QC + cc] * sh.coef[cc];
-#pragma unroll
-                    for (int j = 0; j < QS; j++) a_ += r1[QRR_PX + i * QS + j] * sn[j];
-                    dpi[i] = -a_;
-                }
-            } else if (k < N) {
+            if (k + 1 == N) {
                 const gdbl *rN = sh.inst.as + (size_t)N * QSP;
 #pragma unroll
                 for (int i = 0; i < QX; i++) {
@@ -765,8 +803,10 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                     FTBP(dL, du); FTBP(dU, -du);
                     FTBZ(zL, rdiv(mu, dL) - zL - rdiv(zL, dL) * du); FTBZ(zU, rdiv(mu, dU) - zU + rdiv(zU, dU) * du);
                 }
+                if (k + 1 == N) {
 #pragma unroll
-                for (int i = 0; i < QX; i++) d[l.pi + QX * k + i] = dpi[i];
+                    for (int i = 0; i < QX; i++) d[l.pi + QX * k + i] = dpi[i];
+                }
             }
         }
         sh.red[0][lane] = ap; sh.red[1][lane] = az; sh.red[2][lane] = gd;

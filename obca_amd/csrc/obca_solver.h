@@ -292,6 +292,16 @@ OBCA_FN double dpp_f64(double v) {   // every lane active (the reductions are ca
         return v;                                                                                                \
     }
 #endif
+// sum over each quad of lanes (4 q .. 4 q + 3), left in all four of them: two DPP exchanges
+#ifdef OBCA_EMU
+OBCA_FN void wquad_sum(const double (&r)[OBCA_NL], double (&out)[OBCA_NL]) {
+    double a[64];
+    for (int i = 0; i < 64; i++) a[i] = r[i] + r[i ^ 1];
+    for (int i = 0; i < 64; i++) out[i] = a[i] + a[i ^ 2];
+}
+#else
+OBCA_FN void wquad_sum(const double (&r)[OBCA_NL], double (&out)[OBCA_NL]) { double v = r[0]; v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); out[0] = v; }
+#endif
 WRED_IMPL(wred_sum, (v + w))
 WRED_IMPL(wred_max, ((w > v || w != w) ? w : v))      // NaN-propagating max
 WRED_IMPL(wred_min, ((w < v) ? w : v))
@@ -807,6 +817,18 @@ OBCA_FN double dot6_tree(double init, double a0, double b0, double a1, double b1
                          double a5, double b5) {
     const double t0 = fma(a1, b1, a0 * b0), t1 = fma(a3, b3, a2 * b2), t2 = fma(a5, b5, fma(a4, b4, init));
     return (t0 + t1) + t2;
+}
+OBCA_FN double dot4_tree(double init, const double (&a)[4], const double *b) { return fma(a[1], b[1], a[0] * b[0]) + fma(a[3], b[3], fma(a[2], b[2], init)); }
+// NV contiguous, 16-byte aligned doubles from LDS as ds_read_b128
+template <int NV>
+OBCA_FN void ldv(const double *q, double (&v)[NV]) {
+#ifdef OBCA_EMU
+    for (int i = 0; i < NV; i++) v[i] = q[i];
+#else
+    const double2 *q2 = (const double2 *)__builtin_assume_aligned(q, 16);
+#pragma unroll
+    for (int i = 0; i < NV / 2; i++) { const double2 t = q2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+#endif
 }
 #ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)

@@ -20,7 +20,7 @@ _lib = None
 
 def build_library(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", _LIB, _SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC])
     return _LIB
 
 
@@ -167,22 +167,43 @@ def warm_start(sc, x0, xF, N, smooth=False, **kw):
     return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom, smooth=smooth)
 
 
-def _ws_job(args):
-    name, x0, xF, N, smooth = args
-    return warm_start(S.BACKWARDS if name == "backwards" else S.PARALLEL, x0, xF, N, smooth=smooth)
+def hybrid_astar_many(starts, goals, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.XYBOUNDS, threads=0, cap=1024, **kw):
+    """B searches in one obstacle field on the host threads of the library (obca_plan_hybrid_astar_batch): returns a list of (path, dir, expansions) / None
+    (no path, or the start / goal pose collides)."""
+    o = dict(DEFAULT_OPTS); o.update(kw)
+    opts = np.array([o[k] for k in DEFAULT_OPTS], float)
+    vOb = np.ascontiguousarray(vOb, np.int32); A = np.ascontiguousarray(A, float); b = np.ascontiguousarray(b, float)
+    s = np.ascontiguousarray(np.asarray(starts, float)[:, :3]); g = np.ascontiguousarray(np.asarray(goals, float)[:, :3]); B = len(s)
+    e = np.ascontiguousarray(ego, float); xy = np.ascontiguousarray(XYbounds, float)
+    paths = np.zeros((B, cap, 3)); dirs = np.zeros((B, cap), np.int32); cnt = np.zeros(B, np.int32); nexp = np.zeros(B, np.int32)
+    rc = _load().obca_plan_hybrid_astar_batch(C.c_int(B), s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
+                                              b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D),
+                                              paths.ctypes.data_as(_D), dirs.ctypes.data_as(_I), C.c_int(cap), cnt.ctypes.data_as(_I), nexp.ctypes.data_as(_I), C.c_int(int(threads or 0)))
+    if rc != 0:
+        raise ValueError("bad arguments")
+    out = []
+    for i in range(B):
+        if cnt[i] == -1:          # a path longer than cap nodes (or bad arguments, which the single call reports)
+            try:
+                out.append(hybrid_astar(s[i], g[i], vOb, A, b, ego, L, XYbounds, **kw))
+            except ValueError:
+                out.append(None)
+        else:
+            out.append((paths[i, :cnt[i]].copy(), dirs[i, :cnt[i]].copy(), int(nexp[i])) if cnt[i] > 0 else None)
+    return out
 
 
-def warm_start_many(sc, x0, xF, N, workers=None, smooth=False):
-    """warm starts of a batch on the host cores, one search per worker process.  The workers are SPAWNED, not forked: safe next to a live HIP runtime, so every
-    rank of a multi-GPU job can plan its own slice after its device is up."""
-    jobs = [(sc["name"], np.asarray(a, float), np.asarray(g, float), N, bool(smooth)) for a, g in zip(x0, xF)]
-    workers = min(len(jobs), workers or os.cpu_count() or 1)
-    if workers <= 1 or len(jobs) < 4:
-        return [_ws_job(j) for j in jobs]
-    _load()
-    import multiprocessing as mp
-    with mp.get_context("spawn").Pool(workers) as pool:
-        return pool.map(_ws_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+def warm_start_many(sc, x0, xF, N, workers=None, smooth=False, **kw):
+    """warm starts of a batch: the searches run on the host threads of the planner library (one call, no worker processes: safe next to a live HIP runtime, so
+    every rank of a multi-GPU job plans its own slice after its device is up); resampling to the horizon is numpy per instance.  workers = threads (default: all)."""
+    A, b, vrows = S.scenario_hrep(sc)
+    o, v_nom = SCENARIO_OPTS.get(sc["name"], (dict(), 0.5))
+    o = dict(o); o.update(kw)
+    x0 = np.asarray(x0, float); xF = np.asarray(xF, float)
+    if len(x0) == 0:
+        return []
+    res = hybrid_astar_many(x0[:, :3], xF[:, :3], vrows, A, b, threads=workers or 0, **o)
+    return [None if r is None else path_to_warm_start(r[0], r[1], N, xF[i], v_nom=v_nom, smooth=smooth) for i, r in enumerate(res)]
 
 
 # ---------------------------------------------------------------- quadcopter: 3-D grid A* (a_star_3D.jl, mainQuadcopter.jl:108-138)

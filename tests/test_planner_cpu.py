@@ -52,7 +52,7 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_reeds_shepp"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp"] and all(hasattr(lib, s) for s in syms)
 
 
 def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
@@ -188,3 +188,28 @@ def test_reeds_shepp_random_cases_against_the_reference_families():
         assert tot <= best[0] + 1e-9 * max(1.0, tot), (i, tot, best)
         equal += abs(tot - best[0]) <= 1e-9 * max(1.0, tot)
     assert equal >= 80
+
+
+def test_batched_search_on_library_threads_equals_the_single_calls():
+    """obca_plan_hybrid_astar_batch (threads inside the library, one shared work counter) returns exactly what one obca_plan_hybrid_astar call per pair returns,
+    colliding start poses included; warm_start_many is built on it"""
+    rng = np.random.default_rng(11)
+    x0, xF = S.sample_poses(S.BACKWARDS, 24, rng, False)
+    x0[3, :2] = [0.0, -5.0]                                      # inside an obstacle: no path
+    A, b, v = S.scenario_hrep(S.BACKWARDS)
+    many = PL.hybrid_astar_many(x0[:, :3], xF[:, :3], v, A, b, threads=4)
+    for i in range(len(x0)):
+        try:
+            one = PL.hybrid_astar(x0[i, :3], xF[i, :3], v, A, b)
+        except ValueError:
+            one = None
+        assert (one is None) == (many[i] is None)
+        if one is not None:
+            assert np.array_equal(one[0], many[i][0]) and np.array_equal(one[1], many[i][1]) and one[2] == many[i][2]
+    assert many[3] is None
+    ws = PL.warm_start_many(S.BACKWARDS, x0, xF, 80, workers=3)
+    ref = [PL.warm_start(S.BACKWARDS, x0[i], xF[i], 80) for i in range(len(x0))]
+    for a_, b_ in zip(ws, ref):
+        assert (a_ is None) == (b_ is None)
+        if a_ is not None:
+            assert a_[0] == b_[0] and np.array_equal(a_[1], b_[1]) and np.array_equal(a_[2], b_[2])
