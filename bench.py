@@ -139,13 +139,13 @@ def _cpu_worker(args):
 
 
 def cpu_baseline():
-    """oracle (kind 'port') on all host cores (<=64), 256 instances of the config-2 distribution per core (~10-15 s each)."""
+    """oracle (kind 'port') on the host cores this process may use (<=64), 256 instances of the config-2 distribution per core (~10-15 s each)."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     os.environ["OBCA_ORACLE_NATIVE"] = "1"      # the workers time the -O3 -march=native build, compiled here on the machine that runs it (SURVEY 8d)
     O.build_native()
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(effective_cpus(), 64)            # the threads this process may really use (affinity mask and cgroup quota), not the CPUs the box shows
     per = 256
     n = per * cores
     ctx = mp.get_context("fork")
@@ -163,6 +163,11 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------- batch generation (rank 0) and the scatter
+def effective_cpus():
+    from obca_amd import planner
+    return planner.effective_cpus()
+
+
 def needs_planner(cfg, hybrid):
     return cfg in (3, 4) or (cfg == 2 and hybrid)
 
@@ -222,7 +227,7 @@ def complete_rows(cfg, rows, shared, seed, rank, world, hybrid=False):
         xWS = S.plan_quad_batch(x0, xF, N, rng, first_is_fixed=(rank == 0))
         return dict(x0=x0, xF=xF, Ts=np.full((n, 1), S.quad_sample_time(N)), timeWS=np.full((n, 1), 1.0), xWS=xWS.reshape(n, -1))
     sc = S.BACKWARDS if cfg == 2 else S.PARALLEL
-    workers = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    workers = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     Ts, xWS, uWS = S.plan_batch(sc, x0, xF, N, rng, planner=True, workers=workers, smooth=(cfg == 2))
     xWS = xWS.copy(); xWS[:, 0, :] = x0
     return dict(x0=x0, xF=xF, Ts=Ts.reshape(n, 1), xWS=xWS.reshape(n, -1), uWS=uWS.reshape(n, -1))
@@ -402,13 +407,16 @@ def main():
     if rank == 0 and world == 1 and not quad and not a.no_host_rate:
         reps = max(1, 16384 // B); tile = lambda x: np.concatenate([np.asarray(x)] * reps, axis=0)
         hv, hA, hb = (vOb * reps, A * reps, b * reps) if cfg == 5 else (vOb, A, b)
-        hx = tile(xWS); keep = {}; best = None
+        hx = tile(xWS); hx0, hxF, hTs, hu = tile(rows["x0"]), tile(rows["xF"]), tile(rows["Ts"][:, 0]), tile(uWS); keep = {}; best = bestc = None
         for rep_ in range(3):       # the caller keeps its output arrays between calls (fresh ones cost a page fault per 4 KB inside the C call)
             th0 = time.perf_counter()
-            ho = obca_amd.parking_signed_dist_batch(tile(rows["x0"]), tile(rows["xF"]), N, tile(rows["Ts"][:, 0]), shared["L"], shared["ego"], shared["XYbounds"], hv, hA, hb,
-                                                    hx[:, :, 0], hx[:, :, 1], hx[:, :, 2], 0, hx, tile(uWS), device=local, buffers=keep)
-            th = time.perf_counter() - th0; best = th if best is None else min(best, th)
-        host_rate = dict(instances=B * reps, solves_per_s=round(int((ho["exitflag"] == 1).sum()) / best, 1), seconds=round(best, 4), c_call_seconds=round(float(ho["time"]), 4))
+            ho = obca_amd.parking_signed_dist_batch(hx0, hxF, N, hTs, shared["L"], shared["ego"], shared["XYbounds"], hv, hA, hb,
+                                                    hx[:, :, 0], hx[:, :, 1], hx[:, :, 2], 0, hx, hu, device=local, buffers=keep)
+            th = time.perf_counter() - th0; best = th if best is None else min(best, th); bestc = float(ho["time"]) if bestc is None else min(bestc, float(ho["time"]))
+        nok = int((ho["exitflag"] == 1).sum())
+        host_rate = dict(instances=B * reps, solves_per_s=round(nok / best, 1), seconds=round(best, 4), c_call_seconds=round(bestc, 4), c_call_solves_per_s=round(nok / bestc, 1),
+                         note="solves_per_s: around the Python wrapper (input normalisation, per-instance views of the results); c_call_*: inside obca_parking_signed_dist_batch itself, "
+                              "which is what a ccall from Julia pays")
     # ---- results: every copy solved the same inputs and must hold the same bits
     outs = [bq.download() for bq in batches[:min(nS, a.steps + a.warmup)]]
     out = outs[0]
@@ -519,7 +527,7 @@ def main():
                        "single_batch_sync_solves_per_s": round(conv_all / world / float(np.median(sync_s)), 1),
                        "single_batch_sync_note": "one batch issued and waited for (reset + DualMultWS + interior point, inputs resident): what a caller without several batches in flight gets",
                        "planning": None if not needs_planner(cfg, a.warm_start == "hybrid") else {
-                           "seconds": round(t_plan, 2), "instances_per_rank": B, "host_threads": os.cpu_count(),
+                           "seconds": round(t_plan, 2), "instances_per_rank": B, "host_cpus_visible": os.cpu_count(), "host_cpus_effective": effective_cpus(),
                            "end_to_end_solves_per_s": round(conv_all / (t_plan + dt / a.steps), 1),
                            "note": "warm starts of this config come from the host-side planner (Hybrid A* on the library's threads / 3-D A*), run ONCE before the timed region, "
                                    "every rank for its own slice; end_to_end = validated solves of one batch / (planning + one step): the planner, not the solve, bounds a "

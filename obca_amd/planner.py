@@ -167,6 +167,18 @@ def warm_start(sc, x0, xF, N, smooth=False, **kw):
     return path_to_warm_start(r[0], r[1], N, xF, v_nom=v_nom, smooth=smooth)
 
 
+def effective_cpus():
+    """host threads this process may really use: the affinity mask, cut by the cgroup CPU quota if there is one (a container may see 256 CPUs and be allowed a dozen)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def hybrid_astar_many(starts, goals, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.XYBOUNDS, threads=0, cap=1024, **kw):
     """B searches in one obstacle field on the host threads of the library (obca_plan_hybrid_astar_batch): returns a list of (path, dir, expansions) / None
     (no path, or the start / goal pose collides)."""
@@ -202,7 +214,7 @@ def warm_start_many(sc, x0, xF, N, workers=None, smooth=False, **kw):
     x0 = np.asarray(x0, float); xF = np.asarray(xF, float)
     if len(x0) == 0:
         return []
-    res = hybrid_astar_many(x0[:, :3], xF[:, :3], vrows, A, b, threads=workers or 0, **o)
+    res = hybrid_astar_many(x0[:, :3], xF[:, :3], vrows, A, b, threads=workers or effective_cpus(), **o)
     return [None if r is None else path_to_warm_start(r[0], r[1], N, xF[i], v_nom=v_nom, smooth=smooth) for i, r in enumerate(res)]
 
 
