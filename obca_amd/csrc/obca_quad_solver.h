@@ -935,7 +935,7 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
         for (int base = 0; base < l.n; base += QAP_R * QNT) {
             double v[QAP_R], dv[QAP_R], zl[QAP_R], zu[QAP_R];
 #pragma unroll
-            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.n ? i : 0; v[r] = z[ic]; dv[r] = d[ic]; zl[r] = z[l.zL + ic]; zu[r] = z[l.zU + ic]; }
+            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.n ? i : 0; v[r] = z[ic]; dv[r] = d[ic]; zl[r] = z[l.zL + ic]; zu[r] = ic < l.lam ? z[l.zU + ic] : 0.0; }      // (only x, u, t have upper bounds)
 #pragma unroll
             for (int r = 0; r < QAP_R; r++) {
                 const int i = base + lane + QNT * r;
