@@ -1,7 +1,9 @@
 """
 main.jl-equivalent driver (AutonomousParking/main.jl:36-330, without the plots) on the MI355X path:
   scenario table -> obstHrep -> Hybrid A* warm start -> ParkingDist (collision-free) -> ParkingSignedDist (min-penetration) -> validate.
-Usage:  python examples/main_parking.py [backwards|parallel] [N]
+Usage:  python examples/main_parking.py [backwards|parallel] [N] [--reference-planner]
+  --reference-planner: the warm start as main.jl builds it (BASELINE config 1): the reference's own Hybrid A* restated (REFERENCE mode of the planner library, point-cloud
+  obstacles of main.jl:111-133 / 172-198), speed profile, veloSmooth, steering, every third sample; the horizon then follows from the path length (N argument ignored).
 Needs libobca_hip.so and a gfx950 device (no CPU fallback); the planner and the validation are host-side numpy / C++.
 """
 import os, sys, time
@@ -12,12 +14,20 @@ from obca_amd import scenarios as S, planner as PL, validate as V
 
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "backwards"
-    N = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]; ref_planner = "--reference-planner" in sys.argv
+    name = args[0] if len(args) > 0 else "backwards"
+    N = int(args[1]) if len(args) > 1 else 80
     sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
     A, b, vOb = S.scenario_hrep(sc)                                        # main.jl:99-108 / 151-162: obstHrep, vObMPC = vOb - 1
     nOb = len(vOb); x0, xF = sc["x0"], sc["xF"]
-    t0 = time.time(); ws = PL.warm_start(sc, x0, xF, N); t_plan = time.time() - t0     # main.jl:216-252
+    t0 = time.time()
+    if ref_planner:
+        ws = PL.reference_warm_start(sc, x0, xF)                           # main.jl:216-252 as it stands
+        if ws is not None:
+            N, ws = ws[0], ws[1:4]
+    else:
+        ws = PL.warm_start(sc, x0, xF, N)
+    t_plan = time.time() - t0
     if ws is None:
         print("planner: no path"); return 1
     Ts, xWS, uWS = ws

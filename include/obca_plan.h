@@ -32,6 +32,15 @@ int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goal
                                  const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
                                  int *counts, int *expansions /* may be NULL */, int threads);
 
+/* REFERENCE mode: the reference's own Hybrid A* restated step by step (obca_amd/csrc/obca_planner_ref.cpp follows hybrid_a_star.jl:104-552, a_star.jl:47-281,
+ * collision_check.jl:31-98): what main.jl:216-219 calls.  Obstacles are the POINT CLOUD main.jl builds (ox, oy: nob points), not H-representations.
+ * opts (may be NULL = the reference's constants) = {xy grid 0.3, yaw grid deg 5, motion step 0.1, steer commands per side 5, max steer 0.6, wheelbase 2.7,
+ *   switch-back cost 10, reverse factor 0, steer-change cost 10, steer cost 0, heuristic weight 1, disc radius of the heuristic 1.0, max expansions 2e6}.
+ * Output: path[3k..3k+2] = x, y, yaw of the k-th pose (0.1 m apart; rx, ry, ryaw of the reference), at most cap poses.
+ * Returns the number of poses (>= 2); 0 = no path; -1 = bad arguments / cap too small. */
+int obca_plan_reference_hybrid_astar(const double start[3], const double goal[3], int nob, const double *ox, const double *oy, const double *opts,
+                                     double *path, int cap, int *expansions /* may be NULL */);
+
 /* Shortest Reeds-Shepp path (forward and reverse arcs of radius R and straight lines; stands where hybrid_a_star.jl:262-300 calls
  * reeds_shepp.calc_shortest_path, reeds_shepp.jl) from start to goal (x, y, yaw), sampled every `step` metres: path[3k..3k+2] = pose k,
  * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5 doubles, may be NULL) their

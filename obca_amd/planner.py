@@ -13,14 +13,15 @@ from . import scenarios as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "csrc", "obca_planner.cpp")
+_SRC_REF = os.path.join(_HERE, "csrc", "obca_planner_ref.cpp")      # REFERENCE mode: the reference's Hybrid A* restated
 _LIB = os.path.join(_HERE, "csrc", "libobca_plan.so")
 _D = C.POINTER(C.c_double); _I = C.POINTER(C.c_int)
 _lib = None
 
 
 def build_library(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC])
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_SRC_REF)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC, _SRC_REF])
     return _LIB
 
 
@@ -59,6 +60,45 @@ def hybrid_astar(start, goal, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.
     if n == 0:
         return None
     return path[:n].copy(), dr[:n].copy(), nexp.value
+
+
+REFERENCE_OPTS = dict(xy_res=0.3, yaw_res_deg=5.0, motion_step=0.1, steer_samples=5, max_steer=0.6, wheelbase=2.7, switch_cost=10.0, reverse_cost=0.0,
+                      steer_change_cost=10.0, steer_cost=0.0, h_cost=1.0, vehicle_radius=1.0, max_expansions=2000000)      # hybrid_a_star.jl:44-68
+
+
+def reference_hybrid_astar(start, goal, ox, oy, **kw):
+    """REFERENCE mode: the reference's Hybrid A* (hybrid_a_star.jl: calc_hybrid_astar_path) on its point-cloud obstacles (scenarios.reference_obstacle_points).
+    Returns (path (K,3): rx, ry, ryaw at 0.1 m spacing, expansions) or None."""
+    o = dict(REFERENCE_OPTS); o.update(kw)
+    opts = np.array([o[k] for k in REFERENCE_OPTS], float)
+    ox = np.ascontiguousarray(ox, float); oy = np.ascontiguousarray(oy, float)
+    s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()
+    cap = 20000; path = np.zeros((cap, 3)); nexp = C.c_int(0)
+    n = _load().obca_plan_reference_hybrid_astar(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(ox)), ox.ctypes.data_as(_D), oy.ctypes.data_as(_D),
+                                                 opts.ctypes.data_as(_D), path.ctypes.data_as(_D), C.c_int(cap), C.byref(nexp))
+    if n < 0:
+        raise ValueError("bad arguments")
+    return None if n == 0 else (path[:n].copy(), nexp.value)
+
+
+def reference_warm_start(sc, x0, xF, sampleN=3, motion_step=0.1, a_max=0.3, **kw):
+    """main.jl:216-252 as it stands: the reference search on the scenario's point cloud, the speed profile from the path differences (Ts / sampleN per 0.1 m step),
+    veloSmooth at 0.3 m/s^2, the steering angle from the yaw differences, every sampleN-th sample.  The horizon follows from the path length: N = samples - 1.
+    Returns (N, Ts, xWS (N+1,4), uWS (N,2), path) or None."""
+    ox, oy = S.reference_obstacle_points(sc)
+    r = reference_hybrid_astar(np.asarray(x0, float)[:3], np.asarray(xF, float)[:3], ox, oy, **kw)
+    if r is None:
+        return None
+    P = r[0]; rx, ry, ryaw = P[:, 0], P[:, 1], P[:, 2]
+    Ts = sc["Ts"]; dts = Ts / sampleN
+    rv = np.zeros(len(rx)); rv[:-1] = (np.diff(rx) * np.cos(ryaw[:-1]) + np.diff(ry) * np.sin(ryaw[:-1])) / dts      # main.jl:222-229
+    v, a = velo_smooth(rv, a_max, dts)                                                                             # :230-231
+    delta = np.arctan(np.diff(ryaw) * S.L_WHEELBASE / motion_step * np.sign(v[:-1]))                                # :233
+    sl = slice(None, None, sampleN)
+    xWS = np.stack([rx[sl], ry[sl], ryaw[sl], v[sl]], axis=1)                                                       # :237-248
+    uWS = np.stack([delta[sl], a[sl]], axis=1)
+    N = xWS.shape[0] - 1
+    return N, Ts, xWS, uWS[:N], P
 
 
 def reeds_shepp(start, goal, R, step=0.2):

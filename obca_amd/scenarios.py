@@ -59,6 +59,25 @@ PARALLEL = dict(
     xF=np.array([-L_WHEELBASE / 2, 4.0, 0.0, 0.0]), x0=np.array([-6.0, 9.5, 0.0, 0.0]))
 
 
+def reference_obstacle_points(sc):
+    """the obstacle POINT CLOUD main.jl hands to its Hybrid A* (main.jl:111-133 backwards, :172-198 parallel): walls sampled every 0.1 m along x and every 1 m
+    along y, the far side of the aisle every 1 m.  Returns (ox, oy)."""
+    fr = lambda a, b: np.round(np.arange(int(round(a * 10)), int(round(b * 10)) + 1) / 10.0, 10)      # Julia's a:0.1:b
+    ir = lambda a, b: np.arange(a, b + 1, dtype=float)                                                  # a:b
+    P = []
+    if sc["name"] == "backwards":
+        P += [(x, 5.0) for x in fr(-12, -1.3)] + [(-1.3, y) for y in ir(-2, 5)]          # obstacle 1
+        P += [(1.3, y) for y in ir(-2, 5)] + [(x, 5.0) for x in fr(1.3, 12)]             # obstacle 2
+        P += [(x, 11.0) for x in ir(-12, 12)]                                            # obstacle 3
+    else:
+        P += [(x, 5.0) for x in fr(-12, -3.0)] + [(-3.0, y) for y in ir(-2, 5)]          # obstacle 1
+        P += [(x, 2.5) for x in ir(-3, 3)]                                               # obstacle 2
+        P += [(3.0, y) for y in ir(-2, 5)] + [(x, 5.0) for x in fr(3, 12)]               # obstacle 3
+        P += [(x, 11.5) for x in ir(-12, 12)]                                            # obstacle 4
+    P = np.array(P, float)
+    return P[:, 0].copy(), P[:, 1].copy()
+
+
 def scenario_hrep(sc):
     A, b = obst_hrep(sc["nOb"], sc["vOb"], sc["lOb"])
     vrows = np.asarray(sc["vOb"]) - 1          # vObMPC = vOb-1  (main.jl:101)

@@ -457,3 +457,22 @@ def test_half_space_rows_of_any_length_describe_the_same_problem(OA, oracle):
     # duals handed back in: the solve starts from them in the caller's scaling
     o2, _ = _solve_batch(OA, b1, lWS=np.array(l1), nWS=np.array(n1))
     assert (o2["iters"] == o1["iters"]).all() and np.abs(o2["xp"] - o1["xp"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["backwards", "parallel"])
+def test_reference_main_jl_call_runs_as_is(OA, oracle, name):
+    """BASELINE config 1 (main.jl as it stands, single instance): the reference's own Hybrid A* on its point-cloud obstacles (REFERENCE mode of the planner:
+    hybrid_a_star.jl restated), the speed profile / veloSmooth / steering / every-third-sample warm start of main.jl:216-252, the horizon the path length gives
+    (N = 64 / 60), then ParkingDist (main.jl:258) and ParkingSignedDist (:269) from that warm start -- both against the oracle"""
+    from obca_amd import planner as PL
+    import checkers as K
+    sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
+    N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
+    A, b, v = S.scenario_hrep(sc); x0, xF = sc["x0"], sc["xF"]; nOb = len(v)
+    rx, ry, ryaw = xWS[:, 0].copy(), xWS[:, 1].copy(), xWS[:, 2].copy()
+    for fn, ofn in ((OA.ParkingDist, oracle.parking_dist), (OA.ParkingSignedDist, oracle.parking_signed_dist)):
+        xp, up, ts, ef, t, lp, npp = fn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, nOb, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
+        r = ofn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
+        assert ef == r["exitflag"] == 1
+        assert xp.shape == (4, N + 1) and up.shape == (2, N)
+        assert np.abs(xp - r["xp"]).max() < TOL_X and np.abs(up - r["up"]).max() < TOL_X and abs(float(np.ravel(ts)[0]) - r["t"]) < 1e-9

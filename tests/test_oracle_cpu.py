@@ -226,3 +226,21 @@ def test_half_space_rows_of_any_length_describe_the_same_problem(oracle, backwar
         l0, n0, d0 = oracle.dualmult_ws(40, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
         l1, n1, d1 = oracle.dualmult_ws(40, v, A * s[:, None], b * s, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
         assert np.abs(d0 - d1).max() < 1e-10 and np.abs(l0 - l1 * s[None, :]).max() < 1e-9 and np.abs(n0 - n1).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["backwards", "parallel"])
+def test_oracle_solves_the_reference_main_jl_call(oracle, name):
+    """BASELINE config 1 on the CPU side: warm start of main.jl:216-252 from the REFERENCE-mode search (hybrid_a_star.jl restated, its own point-cloud obstacles),
+    horizon from the path length, ParkingDist then ParkingSignedDist; both reach exit flag 1 and the collision-free solution passes the reference's acceptance test"""
+    import checkers as K
+    from obca_amd import planner as PL
+    sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
+    N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
+    assert N == (64 if name == "backwards" else 60)
+    A, b, v = S.scenario_hrep(sc); x0, xF = sc["x0"], sc["xF"]
+    rx, ry, ryaw = xWS[:, 0].copy(), xWS[:, 1].copy(), xWS[:, 2].copy()
+    r20 = oracle.parking_dist(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
+    r10 = oracle.parking_signed_dist(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
+    assert r20["exitflag"] == 1 and r10["exitflag"] == 1
+    ts = np.full(N + 1, r20["t"])
+    assert K.parking_constraints_ref(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, len(v), v, A, b, r20["xp"], r20["up"], r20["lp"], r20["np"], ts, 0, 0) == 1

@@ -52,7 +52,7 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp", "obca_plan_reference_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
 
 
 def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
@@ -213,3 +213,67 @@ def test_batched_search_on_library_threads_equals_the_single_calls():
         assert (a_ is None) == (b_ is None)
         if a_ is not None:
             assert a_[0] == b_[0] and np.array_equal(a_[1], b_[1]) and np.array_equal(a_[2], b_[2])
+
+
+def _ref_rect_hit(x, y, yaw, px, py):
+    """the reference's point-in-car test (collision_check.jl:57-98) written independently of the product: signed angles subtended by the four edges of the car
+    rectangle (3.7 m ahead of / 1.0 m behind the rear axle, 2.0 m wide) at the obstacle point; a sum of pi or more means the point lies inside"""
+    c, s = np.cos(-yaw), np.sin(-yaw); lx = c * (px - x) - s * (py - y); ly = s * (px - x) + c * (py - y)
+    vx = np.array([3.7, 3.7, -1.0, -1.0, 3.7]) - lx; vy = np.array([-1.0, 1.0, 1.0, -1.0, -1.0]) - ly
+    tot = 0.0
+    for i in range(4):
+        d = np.hypot(vx[i], vy[i]) * np.hypot(vx[i + 1], vy[i + 1]); cosang = min((vx[i] * vx[i + 1] + vy[i] * vy[i + 1]) / d, 1.0)
+        cross = vx[i] * vy[i + 1] - vy[i] * vx[i + 1]
+        tot += np.arccos(cosang) if cross >= 0 else -np.arccos(cosang)
+    return tot >= np.pi
+
+
+@pytest.mark.parametrize("name", ["backwards", "parallel"])
+def test_reference_mode_search_reproduces_the_reference_call(name):
+    """REFERENCE mode (obca_planner_ref.cpp: hybrid_a_star.jl restated) on main.jl's own call: the scenario's point cloud (main.jl:111-133 / 172-198), start
+    x0 = (-6, 9.5, 0), the reference's grid constants.  The path starts on the start pose, ends on the goal pose, advances 0.1 m per pose (the Euler steps of
+    calc_next_node / the sampling of the analytic expansion), never turns tighter than the steering lock allows and every pose passes the reference's own
+    collision test, evaluated here by an independent restatement."""
+    sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
+    ox, oy = S.reference_obstacle_points(sc)
+    assert len(ox) == (257 if name == "backwards" else 230)                      # 108 + 8 + 8 + 108 + 25 / 91 + 8 + 7 + 8 + 91 + 25 points
+    r = PL.reference_hybrid_astar(sc["x0"][:3], sc["xF"][:3], ox, oy)
+    assert r is not None
+    path, nexp = r
+    assert np.abs(path[0] - sc["x0"][:3]).max() < 1e-12 and np.abs(path[-1, :2] - sc["xF"][:2]).max() < 1e-9
+    assert abs(np.angle(np.exp(1j * (path[-1, 2] - sc["xF"][2])))) < 1e-9
+    d = np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1]))
+    assert d.max() <= 0.1 + 1e-9 and d.min() > 0.05                              # (the last sample of a Reeds-Shepp segment may be shorter)
+    dyaw = np.abs(np.angle(np.exp(1j * np.diff(path[:, 2]))))
+    assert dyaw.max() <= 0.1 * np.tan(0.6) / 2.7 + 1e-9                           # |d yaw| <= step * tan(max steer) / wheelbase
+    for x, y, yaw in path:
+        cx, cy = x + 1.35 * np.cos(yaw), y + 1.35 * np.sin(yaw)
+        near = np.hypot(ox - cx, oy - cy) <= 2.35
+        assert not any(_ref_rect_hit(x, y, yaw, px, py) for px, py in zip(ox[near], oy[near]))
+    assert 1 <= nexp < 20000
+
+
+def test_reference_mode_node_costs_follow_the_reference_constants():
+    """a switch-back costs 10, reverse arcs are free, a steer change costs 10 per radian (hybrid_a_star.jl:60-63): with the switch-back cost raised the search must not
+    return a path with MORE direction changes; with every cost but the arc length removed the path is not longer than with the reference's costs"""
+    sc = S.PARALLEL; ox, oy = S.reference_obstacle_points(sc)
+    def switches(path):
+        s = np.sign(np.diff(path[:, 0]) * np.cos(path[:-1, 2]) + np.diff(path[:, 1]) * np.sin(path[:-1, 2])); s = s[s != 0]
+        return int((np.diff(s) != 0).sum())
+    base = PL.reference_hybrid_astar(sc["x0"][:3], sc["xF"][:3], ox, oy)[0]
+    dear = PL.reference_hybrid_astar(sc["x0"][:3], sc["xF"][:3], ox, oy, switch_cost=100.0)[0]
+    assert switches(dear) <= switches(base)
+    plain = PL.reference_hybrid_astar(sc["x0"][:3], sc["xF"][:3], ox, oy, switch_cost=0.0, steer_change_cost=0.0, reverse_cost=1.0)[0]
+    length = lambda p: np.hypot(np.diff(p[:, 0]), np.diff(p[:, 1])).sum()
+    assert length(plain) <= length(base) + 0.5
+
+
+def test_reference_warm_start_pipeline_matches_main_jl():
+    """main.jl:216-252 on the reference search: speed from the path differences at Ts / sampleN per step (0.5 m/s backwards, 0.333 m/s parallel), veloSmooth at
+    0.3 m/s^2, steering from the yaw differences, every third sample; the horizon is what the path length gives (N = samples - 1)"""
+    for sc, vnom in ((S.BACKWARDS, 0.5), (S.PARALLEL, 1.0 / 3.0)):
+        N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
+        assert Ts == sc["Ts"] and xWS.shape == (N + 1, 4) and uWS.shape == (N, 2) and N == (len(path) - 1) // 3
+        assert np.array_equal(xWS[:, :3], path[::3]) and np.abs(xWS[:, 3]).max() <= vnom + 1e-9
+        assert np.abs(uWS[:, 0]).max() <= 0.6 + 1e-9 and np.abs(uWS[:, 1]).max() <= 0.32      # steering lock; the ramps of the smoother take round(v / 0.3 / dt) samples, so their slope is 0.3 up to that rounding (0.3125)
+        assert abs(xWS[0, 3]) < 1e-12 or abs(xWS[0, 3]) <= vnom                                        # (the smoother ramps up from rest)

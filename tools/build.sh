@@ -6,5 +6,5 @@ hipcc $F -o $R/obca_amd/csrc/libobca_hip.so $R/obca_amd/csrc/obca_hip.hip -Rpass
 hipcc $F -DOBCA_PROFILE -o $R/obca_amd/csrc/libobca_hip_prof.so $R/obca_amd/csrc/obca_hip.hip 2>&1 | grep -E "error" &
 g++ -O1 -std=c++17 -fPIC -shared -Wno-unknown-pragmas -o $R/tests/emu/libobca_emu.so $R/tests/emu/obca_emu.cpp 2>&1 | grep -E "error" -A3 &
 make -C $R/oracle -s &
-g++ -O2 -std=c++17 -shared -fPIC -pthread -o $R/obca_amd/csrc/libobca_plan.so $R/obca_amd/csrc/obca_planner.cpp &
+g++ -O2 -std=c++17 -shared -fPIC -pthread -o $R/obca_amd/csrc/libobca_plan.so $R/obca_amd/csrc/obca_planner.cpp $R/obca_amd/csrc/obca_planner_ref.cpp &
 wait
