@@ -21,7 +21,7 @@ print(json.dumps(dict(B=B, N=N, kernel_ms=ms, wall_ms=dt * 1e3, solves_per_s=B /
                       scratch_MB=qb.scratch_bytes() / 1e6)))
 pc = qb.phase_cycles()
 if pc.sum() > 0:
-    names = "init asm_obs asm_stage riccati border closed_loop fwd_seq bs_stage bs_obs trial apply other".split()
+    names = "init asm_obs asm_stage riccati border fwd_setup fwd_seq bs_stage bs_obs trial apply other".split()      # fwd_setup: gather tables, kf_k(coef) of all stages, first gathers of the forward sweep
     passes = out["info"][:, 1] + out["info"][:, 6]; tot = pc[:, :len(names)].sum(1)
     print("cycles per pass: mean %.0f" % (tot / passes).mean())
     for i, n in enumerate(names):
