@@ -21,18 +21,17 @@
 
 namespace obca {
 
-// Reciprocal for the latency-critical pivots: v_rcp_f64 refined by two Newton steps (5 dependent instructions; the IEEE division
-// sequence with its scaling and fix-up is 11, and a dependent fp64 instruction costs a lone wavefront some 45 clocks).  The result is
-// within an ulp or two of 1/d for the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN, and those
-// are rejected by the positivity tests next to every use.  The host emulation divides.
+// Reciprocal for the latency-critical pivots: v_rcp_f64 (good to 2^-24.4) refined as r (1 + e + e^2) with e = 1 - d r: FOUR dependent instructions (two Newton
+// steps are five, the IEEE division sequence with its scaling and fix-up eleven), and a dependent fp64 instruction costs a lone wavefront ~47 clocks
+// (tools/micro/lds_barrier_latency.hip: (724 - 440) / 6 clocks per fma of a chain).  Measured on MI355X over 80 binades: 1.00 ulp, the same as two Newton steps
+// (tools/micro/rcp_accuracy.hip, profiles/r03_rcp_accuracy.txt).  For the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN,
+// and those are rejected by the positivity tests next to every use.  The host emulation divides.
 OBCA_FN double rcp_nr(double d) {
 #ifdef OBCA_EMU
     return 1.0 / d;
 #else
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(r, fma(-d, r, 1.0), r);
-    r = fma(r, fma(-d, r, 1.0), r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);      // e = 1 - d r: 2^-24 at most
+    return fma(r, fma(e, e, e), r);                                     // r (1 + e + e^2) = (1/d)(1 - e^3)
 #endif
 }
 

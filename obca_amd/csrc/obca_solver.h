@@ -938,9 +938,9 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         for (int r = 0; r < RIC_IPL; r++) {
             const RicItem &p = rp[LI(lane)].it[r];
             const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
-            const double x6 = L[p.c_x6], x7 = L[p.c_x7], ba = L[p.c_base], s12 = L[p.c_s1] + L[p.c_s2];
+            const double x6 = L[p.c_x6], x7 = L[p.c_x7], bs = L[p.c_base] + (L[p.c_s1] + L[p.c_s2]);      // (the static parts join the base before the division is ready: one dependent operation less behind it)
             n0[r] = fma(q10, q7, -(q11 * q6)); n1[r] = fma(q10, q6, -(q00 * q7));       // det * gains of this column
-            v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, ba) + s12;
+            v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, bs);
         }
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
