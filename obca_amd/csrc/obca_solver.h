@@ -187,7 +187,7 @@ struct alignas(16) Shared {
     // ds_read_b128: a lone wavefront per SIMD issues 8-byte LDS reads at a fifth of the LDS rate but 16-byte reads at the full rate (MI355X_MICROARCH.md, LDS).
     alignas(16) double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];     // P (row-major, symmetric), p' (pn[c * 6 + a]: right-hand side c, state a), Qhat (8 x 14 row-major)
     alignas(16) double Bm[36], sB[24], coef[8], TT[14 * 6];     // border constants, their static parts, (dt, nu), T' (TT[cc * 6 + a])
-    alignas(16) double zero6[6]; double zero, dump;        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
+    alignas(16) double zero6[6]; double zero, dump, dump4[4];        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
     double filt[OB_FILT_LDS][2];
     Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok, upl[OB_NT], ucn[3][OB_NT];      // upl, ucn: which positions of the unpacked stage data a lane serves (init_unpack_table)
@@ -200,7 +200,7 @@ struct alignas(16) Shared {
 // search direction lives here and nowhere else), and behind it EITHER the double-buffered unpacked stage data of the Riccati backward sweep (2 x OB_STG doubles, SG_* offsets,
 // + a pad slot for lanes without an item) OR the composed closed-loop maps of the stage pairs of the forward sweep (the two sweeps never overlap in time).
 #define OB_STG 200
-#define OB_DYN_LDS_DOUBLES(N) ((size_t)((N) + 2) * 6 + ((size_t)((N) / 2 + 1) * 42 > 2 * OB_STG ? (size_t)((N) / 2 + 1) * 42 : (size_t)2 * OB_STG))
+#define OB_DYN_LDS_DOUBLES(N) ((size_t)((N) + 2) * 6 + ((size_t)((N) / 2 + 1) * 42 > 2 * OB_STG + (size_t)16 * (N) ? (size_t)((N) / 2 + 1) * 42 : 2 * OB_STG + (size_t)16 * (N)))
 #ifdef OBCA_EMU
 static Shared g_sh;
 alignas(16) static double g_traj[OB_DYN_LDS_DOUBLES(OB_NMAX)];
@@ -833,11 +833,20 @@ OBCA_FN void ldv(const double *q, double (&v)[NV]) {
 #ifndef RIC_D
 #define RIC_D 4   // stage records are gathered from HBM this many stages before they are needed (memory latency >> one stage of math)
 #endif
-// One stage of the sweep on the 64 lanes of the wavefront: three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), up to
-// two small items per lane and phase, wave-local LDS barriers in between (no cross-wavefront synchronisation: the instance IS one wavefront).
-// Every lane runs the SAME straight-line code in every phase: what differs between the item kinds of a phase (a T entry or one of the
-// partial sums of the bilinear update; a P / p entry or a bilinear constant) is only where the operands live, and that is a per-lane table
-// of LDS offsets built once per sweep (RicPlan).
+// One stage of the sweep on the 64 lanes of the wavefront: three short LDS phases (T = P [F|off] + [0|p];  Qhat = [H|hc] + F'T;  eliminate u_k), ONE item per lane and
+// phase, wave-local LDS ordering in between (no cross-wavefront synchronisation: the instance IS one wavefront).  Every lane runs the SAME straight-line code in every phase:
+// what differs between the item kinds of a phase is only where the operands live, and that is a per-lane table of LDS offsets built once per sweep (RicItem).
+// A phase costs what its one wavefront ISSUES (a 16-byte LDS read ~16 clocks, a dependent fp64 operation ~47: profiles/r03_ab_reciprocal_and_early_quu.txt), so the items are
+// cut down to the products that are not structure (rounds 1-3 computed all 96 / 124 / 93 entries, two per lane):
+//   * FA = [F | off] has the unit columns 0, 1 (X, Y), the zero columns 4, 5 (the input copy w: x+ does not depend on it) and 10..13 (the nu right-hand sides): the columns
+//     0, 1, 4, 5, 10..13 of T are columns of P, zero, or columns of p -- phase B reads them where they are; phase A forms the six others (36 items).
+//   * rows 4, 5 and columns 4, 5 of Qhat are [H | hc] itself (F has nothing there): phase C reads them from the stage buffer; rows 0, 1 of Qhat are [H | hc] + T rows 0, 1:
+//     for the copied columns that is one more phase-A item each (16), for the others a phase-B item with a unit-vector operand (12).  Phase B: rows psi, v, delta, a over the
+//     twelve live columns (48) + those 12 + 4.
+//   * P is symmetric: phase C forms the 21 entries i <= c once and stores them twice (exactly symmetric, where rounds 1-3 computed both halves), and the 36 entries of p.
+//   * the static parts of the bilinear constants ACCUMULATE in their own slots over the stages (the item's initial value is its previous sum); u1[m][b] = off_m . T(8+b)
+//     equals u2[m][b] = off_m . p(b) for b >= 2 (T(8+b) = p(b) there) and is not formed.  The dynamic part - Qhat_u(a)' Quu^-1 Qhat_u(b) is not needed before the sweep ends:
+//     every stage leaves Qhat_u of its six right-hand sides, Quu and 1 / det in LDS (RIC_BD doubles) and the 21 sums over the stages are formed afterwards, three lanes per pair.
 // PIPE = 1: steady state of the software pipeline -- the last phase first retires the gather of stage k-1 (issued RIC_D stages ago into
 // nv[..][slot]) into the LDS buffer and re-issues the slot for stage k-1-RIC_D.  Every global load / store is issued unconditionally
 // (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
@@ -845,38 +854,52 @@ OBCA_FN void ldv(const double *q, double (&v)[NV]) {
 struct RicItem {      // offsets in doubles from the start of Shared
     int a_a, a_b, a_i, a_d, a_sg;      // phase A: the two operand vectors (6 contiguous doubles each), initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
     int b_a, b_b, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
-    int c_x6, c_x7, c_col, c_base, c_s1, c_s2, c_d1, c_d2, c_rv, c_rk0, c_rk1;   // phase C: see riccati_stage
+    int c_x6, c_x7, c_q6, c_q7, c_base, c_sg, c_d1, c_d2, c_bd, c_rv, c_rv2, c_rk0, c_rk1;   // phase C: see riccati_stage (c_sg: bits 0..4 = x6, x7, q6, q7, base live in the stage buffer)
 };
-#define RIC_IPL 2       // items per lane and phase: 96 / 124 / 93 items over 64 lanes
-struct RicPlan { RicItem it[RIC_IPL]; };
-OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {     // `lane` = item number 0..127
+#define RIC_BD 16       // per stage: Qhat_u (rows 6, 7) of the six right-hand sides, then q00, q10, q11, 1 / det
+OBCA_FN int ric_qsrc(int oQ, int oSG, int r, int c, int bit, int &sg) {      // where phase C finds Qhat[r][c]: rows / columns 4, 5 are [H | hc] in the stage buffer
+    if (r == 4 || r == 5 || c == 4 || c == 5) { sg |= bit; return oSG + (c < 8 ? SG_H + r * 8 + c : SG_HC + r * OB_NC + (c - 8)); }
+    return oQ + r * 14 + c;
+}
+OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
     const double *L = (const double *)&sh;
-    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), oBm = (int)(sh.Bm - L), osB = (int)(sh.sB - L), oT = (int)(sh.TT - L),
-              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oZ6 = (int)(sh.zero6 - L), oD = (int)(&sh.dump - L);
-    // A: T[a][cc] = [cc >= 8] p[a][cc-8] + P[a][:] . FA[:][cc]   (items 0..83; stored as T'[cc][a]);  u2[m][b] = FA[:][8+m] . p[:][b]   (items 84..95; rows 4, 5 of the off columns are 0)
+    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), osB = (int)(sh.sB - L), oT = (int)(sh.TT - L),
+              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oZ6 = (int)(sh.zero6 - L), oD = (int)(&sh.dump - L), oD4 = (int)(sh.dump4 - L);
+    const int S6[6] = {2, 3, 6, 7, 8, 9}, R8[8] = {0, 1, 4, 5, 10, 11, 12, 13}, I4[4] = {2, 3, 6, 7}, C12[12] = {0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13};
+    // A: items 0..35 T[a][cc] = [cc >= 8] p[a][cc-8] + P[a][:] . FA[:][cc] for the six live columns (stored as T'[cc][a]);  36..47 u2[m][b] += FA[:][8+m] . p[:][b];
+    //    48..63 Qhat[a][cc] = [H | p][a][cc] + P[a][:] . FA[:][cc] for a = 0, 1 and the copied columns (FA[:][cc] is a unit vector or zero there)
     p.a_a = oZ6; p.a_b = oZ6; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
-    if (lane < 84) { const int a_ = lane / 14, cc = lane % 14; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2;
+    if (lane < 36) { const int cc = S6[lane / 6], a_ = lane % 6; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2;
                      p.a_i = cc < 8 ? oZ : opn + (cc - 8) * 6 + a_; p.a_d = oT + cc * 6 + a_; }
-    else if (lane < 96) { const int m = (lane - 84) / 6, b_ = (lane - 84) % 6; p.a_a = oSG + SG_FA + (8 + m) * 6; p.a_sg = 1; p.a_b = opn + b_ * 6; p.a_d = osB + 12 + m * 6 + b_; }
-    // B: Qhat[i][cc] = [H | hc][i][cc] + FA[:][i] . T[:][cc]   (items 0..111);  u1[m][b] = FA[:][8+m] . T[:][8+b]   (items 112..123)
+    else if (lane < 48) { const int m = (lane - 36) / 6, b_ = (lane - 36) % 6; p.a_a = oSG + SG_FA + (8 + m) * 6; p.a_sg = 1; p.a_b = opn + b_ * 6; p.a_i = p.a_d = osB + 12 + m * 6 + b_; }
+    else { const int a_ = (lane - 48) / 8, cc = R8[(lane - 48) % 8]; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2; p.a_d = oQ + a_ * 14 + cc;
+           if (cc < 8) { p.a_i = oSG + SG_H + a_ * 8 + cc; p.a_sg |= 4; } else p.a_i = opn + (cc - 8) * 6 + a_; }
+    // B: items 0..47 Qhat[i][cc] = [H | hc][i][cc] + FA[:][i] . T[:][cc] for the rows psi, v, delta, a and the twelve live columns;  48..59 the same for rows X, Y and the six
+    //    columns phase A formed;  60..63 u1[m][b] += FA[:][8+m] . T[:][8+b], b = 0, 1.  T[:][cc] is read where it lives: a row of P (symmetric), a column of p', or T'
     p.b_a = oZ6; p.b_b = oZ6; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
-    if (lane < 112) { const int i = lane / 14, cc = lane % 14; p.b_a = oSG + SG_FA + i * 6; p.b_b = oT + cc * 6; p.b_sg = 1 | 4;
-                      p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + lane; }
-    else if (lane < 124) { const int m = (lane - 112) / 6, b_ = (lane - 112) % 6; p.b_a = oSG + SG_FA + (8 + m) * 6; p.b_sg = 1; p.b_b = oT + (8 + b_) * 6; p.b_d = osB + m * 6 + b_; }
-    // C: value = base + (X6 n0 + X7 n1) / det + s1 + s2 with (n0, n1) = adj(Quu) applied to column c_col of rows 6, 7 of Qhat
-    //    items 0..35 P[i][cc], 36..71 p[i][cc] (base = Qhat entry; p is stored transposed);  items 72..92 bilinear constant B(a,b) (base = its old value, s1 / s2 = the static parts)
-    p.c_x6 = oZ; p.c_x7 = oZ; p.c_col = 0; p.c_base = oZ; p.c_s1 = oZ; p.c_s2 = oZ; p.c_d1 = oD; p.c_d2 = oD; p.c_rv = RS_PAD; p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
-    if (lane < 72) {
-        const int r = lane / 36, i = (lane % 36) / 6, cc = lane % 6, qc = r ? cc + 8 : cc;
-        p.c_x6 = oQ + i * 14 + 6; p.c_x7 = oQ + i * 14 + 7; p.c_col = qc; p.c_base = oQ + i * 14 + qc; p.c_d1 = r ? opn + cc * 6 + i : oPn + lane;
-        if (i < 4) p.c_rv = (r ? RS_PV : RS_PX) + i * 6 + cc;                 // rows 0..3 of P / p go to HBM; row 0 carries the gains
-        if (i == 0) { p.c_rk0 = (r ? RS_KF : RS_K) + cc; p.c_rk1 = (r ? RS_KF + OB_NC : RS_K + 6) + cc; }
-    } else if (lane < 93) {
-        int a_, b_; pair_of(lane - 72, a_, b_);
-        p.c_x6 = oQ + 6 * 14 + 8 + a_; p.c_x7 = oQ + 7 * 14 + 8 + a_; p.c_col = 8 + b_; p.c_base = oBm + a_ * 6 + b_; p.c_d1 = oBm + a_ * 6 + b_;
-        if (a_ != b_) p.c_d2 = oBm + b_ * 6 + a_;
-        if (a_ < 2) p.c_s1 = osB + a_ * 6 + b_;                               // static part: off_a . (P off_b + p_b) + off_b . p_a ; off is non-zero for the
-        if (b_ < 2) p.c_s2 = osB + 12 + b_ * 6 + a_;                          // columns 0 (main) and 1 (t) only
+    if (lane < 60) {
+        const int i = lane < 48 ? I4[lane / 12] : (lane - 48) / 6, cc = lane < 48 ? C12[lane % 12] : S6[(lane - 48) % 6];
+        p.b_a = oSG + SG_FA + i * 6; p.b_sg = 1 | 4;
+        p.b_b = cc < 2 ? oPn + cc * 6 : (cc >= 10 ? opn + (cc - 8) * 6 : oT + cc * 6);
+        p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + i * 14 + cc;
+    } else { const int m = (lane - 60) / 2, b_ = (lane - 60) % 2; p.b_a = oSG + SG_FA + (8 + m) * 6; p.b_sg = 1; p.b_b = oT + (8 + b_) * 6; p.b_i = p.b_d = osB + m * 6 + b_; }
+    // C: value = base + (X6 n0 + X7 n1) / det with (n0, n1) = adj(Quu) applied to rows 6, 7 of the item's column of Qhat
+    //    items 0..20 P[i][cc], i <= cc (stored twice);  21..56 p[i][c] (stored transposed);  the items (0, c) carry the gains of their column
+    p.c_x6 = oZ; p.c_x7 = oZ; p.c_q6 = oZ; p.c_q7 = oZ; p.c_base = oZ; p.c_sg = 0; p.c_d1 = oD; p.c_d2 = oD; p.c_bd = -1; p.c_rv = RS_PAD; p.c_rv2 = RS_PAD; p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
+    (void)oD4;
+    if (lane < 57) {
+        int r, i, cc;
+        if (lane < 21) { r = 0; pair_of(lane, i, cc); } else { r = 1; i = (lane - 21) / 6; cc = (lane - 21) % 6; }
+        const int qc = r ? cc + 8 : cc;
+        p.c_x6 = ric_qsrc(oQ, oSG, i, 6, 1, p.c_sg); p.c_x7 = ric_qsrc(oQ, oSG, i, 7, 2, p.c_sg);
+        p.c_q6 = ric_qsrc(oQ, oSG, 6, qc, 4, p.c_sg); p.c_q7 = ric_qsrc(oQ, oSG, 7, qc, 8, p.c_sg); p.c_base = ric_qsrc(oQ, oSG, i, qc, 16, p.c_sg);
+        if (r) { p.c_d1 = opn + cc * 6 + i; if (i < 4) p.c_rv = RS_PV + i * 6 + cc; if (i == 0) { p.c_rk0 = RS_KF + cc; p.c_rk1 = RS_KF + OB_NC + cc; p.c_bd = 2 * cc; } }
+        else {
+            p.c_d1 = oPn + i * 6 + cc; if (i != cc) p.c_d2 = oPn + cc * 6 + i;
+            if (i < 4) p.c_rv = RS_PX + i * 6 + cc;                              // rows 0..3 of P go to HBM (the costate recovery reads them)
+            if (cc < 4 && i != cc) p.c_rv2 = RS_PX + cc * 6 + i;
+            if (i == 0) { p.c_rk0 = RS_K + cc; p.c_rk1 = RS_K + 6 + cc; }
+        }
     }
 }
 // six contiguous, 16-byte aligned doubles from LDS: three ds_read_b128
@@ -889,39 +912,23 @@ OBCA_FN void ld6(const double *q, double (&v)[6]) {
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
 #endif
 }
-OBCA_FN void ric_plan(const Shared &sh, int lane, RicPlan &p) {
-#pragma unroll
-    for (int r = 0; r < RIC_IPL; r++) ric_item(sh, lane + OB_NT * r, p.it[r]);
-}
 template <int PIPE>
-OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicPlan (&rp)[OBCA_NLT],
+OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicItem (&rp)[OBCA_NLT],
                           double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0) {
     double *L = (double *)&sh;
     const int sgo = (k & 1) * OB_STG;         // which of the two stage buffers holds stage k
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
     // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
-        double v[RIC_IPL];
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) {
-            const RicItem &p = rp[LI(lane)].it[r];
-            double A[6], B[6]; ld6(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld6(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
-            v[r] = dot6_tree(L[p.a_i], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
-        }
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].a_d] = v[r];
+        const RicItem &p = rp[LI(lane)];
+        double A[6], B[6]; ld6(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld6(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
+        L[p.a_d] = dot6_tree(L[p.a_i + ((p.a_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
     }
     LDS_SYNC();
     PAR(lane) {   // phase B
-        double v[RIC_IPL];
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) {
-            const RicItem &p = rp[LI(lane)].it[r];
-            double A[6], B[6]; ld6(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld6(L + p.b_b, B);
-            v[r] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
-        }
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) L[rp[LI(lane)].it[r].b_d] = v[r];
+        const RicItem &p = rp[LI(lane)];
+        double A[6], B[6]; ld6(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld6(L + p.b_b, B);
+        L[p.b_d] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
     }
     LDS_SYNC();
     PROF_FINE(I, PF_RIC_P1);
@@ -932,27 +939,21 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
     const double idet = rcp_nr(det);
     gdbl *ro = I.rs + (size_t)k * OB_RS;
+    double *bd = sg0 + 2 * OB_STG + (size_t)k * RIC_BD;
     PAR(lane) {   // phase C
-        double v[RIC_IPL], n0[RIC_IPL], n1[RIC_IPL];
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) {
-            const RicItem &p = rp[LI(lane)].it[r];
-            const double q6 = sh.Qhat[6 * 14 + p.c_col], q7 = sh.Qhat[7 * 14 + p.c_col];
-            const double x6 = L[p.c_x6], x7 = L[p.c_x7], bs = L[p.c_base] + (L[p.c_s1] + L[p.c_s2]);      // (the static parts join the base before the division is ready: one dependent operation less behind it)
-            n0[r] = fma(q10, q7, -(q11 * q6)); n1[r] = fma(q10, q6, -(q00 * q7));       // det * gains of this column
-            v[r] = fma(fma(x6, n0[r], x7 * n1[r]), idet, bs);
-        }
+        const RicItem &p = rp[LI(lane)];
+        const double x6 = L[p.c_x6 + ((p.c_sg & 1) ? sgo : 0)], x7 = L[p.c_x7 + ((p.c_sg & 2) ? sgo : 0)], q6 = L[p.c_q6 + ((p.c_sg & 4) ? sgo : 0)],
+                     q7 = L[p.c_q7 + ((p.c_sg & 8) ? sgo : 0)], ba = L[p.c_base + ((p.c_sg & 16) ? sgo : 0)];
+        const double n0 = fma(q10, q7, -(q11 * q6)), n1 = fma(q10, q6, -(q00 * q7));       // det * gains of this column
+        const double v = fma(fma(x6, n0, x7 * n1), idet, ba);
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
             stage_unpack_store(sg0 + (kp & 1) * OB_STG, plan[LI(lane)], nv[LI(lane)][slot]);
             stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
-#pragma unroll
-        for (int r = 0; r < RIC_IPL; r++) {
-            const RicItem &p = rp[LI(lane)].it[r];
-            L[p.c_d1] = v[r]; L[p.c_d2] = v[r];
-            ro[p.c_rv] = v[r]; ro[p.c_rk0] = (double)(n0[r] * idet); ro[p.c_rk1] = (double)(n1[r] * idet);
-        }
+        L[p.c_d1] = v; L[p.c_d2] = v;
+        if (p.c_bd >= 0) { bd[p.c_bd] = q6; bd[p.c_bd + 1] = q7; if (p.c_bd == 0) { bd[12] = q00; bd[13] = q10; bd[14] = q11; bd[15] = idet; } }
+        ro[p.c_rv] = v; ro[p.c_rv2] = v; ro[p.c_rk0] = (double)(n0 * idet); ro[p.c_rk1] = (double)(n1 * idet);
     }
     LDS_SYNC();
     PROF_FINE(I, PF_RIC_P2);
@@ -963,19 +964,20 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
     double nv[OBCA_NLT][RIC_D];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
-    double *sg0 = stg_base(sh);      // the two stage buffers (dynamic LDS)
-    UnpackPlan plan[OBCA_NLT]; RicPlan rp[OBCA_NLT];
+    double *sg0 = stg_base(sh);      // the two stage buffers, behind them the per-stage border data (dynamic LDS)
+    UnpackPlan plan[OBCA_NLT]; RicItem rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
-        stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_plan(sh, lane, rp[LI(lane)]);
+        stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_item(sh, lane, rp[LI(lane)]);
         stage_unpack_constants(sh, sg0, lane);
         if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
         if (lane < 6) sh.zero6[lane] = 0.0;
+        if (lane < 24) sh.sB[lane] = 0.0;                      // the static parts of the bilinear constants accumulate here
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
             double v = as_h(i, j) >= 0 ? rec[AS_H + as_h(i, j)] : 0.0;
             if (i == j && i < 4) v += rho;
-            sh.Pn[lane] = v; sh.Bm[lane] = 0;
+            sh.Pn[lane] = v;
         }
         if (lane < 6) {
             double e = lane < 4 ? -(z[l.x + 4 * N + lane] - c.xF[lane]) : 0.0;
@@ -986,31 +988,58 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     }
     LDS_SYNC();
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
-    int k = N - 1;
-    for (; k >= 0 && (k + 1) % RIC_D != 0; k--) {
+    int k = N - 1, ok = 1;
+    for (; k >= 0 && (k + 1) % RIC_D != 0 && ok; k--) {
         PAR(lane) { double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
         LDS_SYNC();
-        if (!riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0)) { PROF(I, PF_RIC_BWD); return 0; }
+        ok = riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0);
     }
-    if (k < 0) { PROF(I, PF_RIC_BWD); return 1; }
-    PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
-        double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
-        stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v);
+    if (ok && k >= 0) {
+        PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
+            double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
+            stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v);
 #pragma unroll
-        for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
+            for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
 #ifndef OBCA_EMU
 #pragma unroll
-        for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j]));
+            for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j]));
 #endif
+        }
+        LDS_SYNC();
+        for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
+#pragma unroll
+            for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0);
+        }
+    }
+    if (!ok) { PROF(I, PF_RIC_BWD); return 0; }
+    // bilinear constants: B(a,b) = sum over the stages of Qhat_u(a) . (adj(Quu) Qhat_u(b)) / det + the accumulated static parts; lane 3 p + q sums every third stage of pair p
+    PAR(lane) {
+        if (lane < 63) {
+            int a_, b_; pair_of(lane / 3, a_, b_);
+            const double *bd = sg0 + 2 * OB_STG;
+            double acc = 0;
+            for (int kk = lane % 3; kk < N; kk += 3) {
+                const double *r = bd + (size_t)kk * RIC_BD;
+                const double q6a = r[2 * a_], q7a = r[2 * a_ + 1], q6b = r[2 * b_], q7b = r[2 * b_ + 1], q00 = r[12], q10 = r[13], q11 = r[14], idet = r[15];
+                const double n0 = fma(q10, q7b, -(q11 * q6b)), n1 = fma(q10, q6b, -(q00 * q7b));
+                acc = fma(fma(q6a, n0, q7a * n1), idet, acc);
+            }
+            sh.TT[lane] = acc;
+        }
     }
     LDS_SYNC();
-    int ok = 1;
-    for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
-#pragma unroll
-        for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0);
+    PAR(lane) {
+        if (lane < 21) {
+            int a_, b_; pair_of(lane, a_, b_);
+            double v = (sh.TT[3 * lane] + sh.TT[3 * lane + 1]) + sh.TT[3 * lane + 2];
+            if (a_ < 2) v += b_ < 2 ? sh.sB[a_ * 6 + b_] : sh.sB[12 + a_ * 6 + b_];      // off_a . (P off_b + p_b): u1[a][b], = u2[a][b] for the right-hand sides b >= 2
+            if (b_ < 2) v += sh.sB[12 + b_ * 6 + a_];                                     // off_b . p_a
+            sh.Bm[a_ * 6 + b_] = v; sh.Bm[b_ * 6 + a_] = v;
+        }
     }
+    LDS_SYNC();
     PROF(I, PF_RIC_BWD);
-    return ok;
+    return 1;
 }
 
 // ---------------------------------------------------------------- wave-level matrix-core helpers (used by the quadcopter sweep, obca_quad_solver.h)
