@@ -302,6 +302,12 @@ OBCA_FN void wquad_sum(const double (&r)[OBCA_NL], double (&out)[OBCA_NL]) {
 #else
 OBCA_FN void wquad_sum(const double (&r)[OBCA_NL], double (&out)[OBCA_NL]) { double v = r[0]; v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); out[0] = v; }
 #endif
+// value of lane l (a constant) of a per-lane variable as a wave-uniform scalar (v_readlane; the emulation keeps per-lane variables as arrays over the lanes)
+#ifdef OBCA_EMU
+#define WV_READLANE(x, l) ((x)[l])
+#else
+#define WV_READLANE(x, l) readlane_f64((x)[0], (l))
+#endif
 WRED_IMPL(wred_sum, (v + w))
 WRED_IMPL(wred_max, ((w > v || w != w) ? w : v))      // NaN-propagating max
 WRED_IMPL(wred_min, ((w < v) ? w : v))
@@ -852,8 +858,8 @@ OBCA_FN void ldv(const double *q, double (&v)[NV]) {
 // (clamped stage index, dummy slot RS_PAD for the lanes without an item) and the loop has a single exit: with no branch around a
 // memory operation the compiler's in-order vmcnt bookkeeping stays exact and old gathers retire without draining the younger ones.
 struct RicItem {      // offsets in doubles from the start of Shared
-    int a_a, a_b, a_i, a_d, a_sg;      // phase A: the two operand vectors (6 contiguous doubles each), initial value, destination; *_sg: bit 0/1/2 = A/B/init live in the
-    int b_a, b_b, b_i, b_d, b_sg;      //          stage buffer (its parity offset is added at run time); phase B likewise
+    int a_a, a_b, a_i, a_j, a_d, a_sg;      // phase A: the two operand vectors (4 contiguous doubles each), two initial values, destination; *_sg: bit 0/1/2 = A/B/first initial
+    int b_a, b_b, b_i, b_j, b_d, b_sg;      //          value live in the stage buffer (its parity offset is added at run time); phase B likewise
     int c_x6, c_x7, c_q6, c_q7, c_base, c_sg, c_d1, c_d2, c_bd, c_rv, c_rv2, c_rk0, c_rk1;   // phase C: see riccati_stage (c_sg: bits 0..4 = x6, x7, q6, q7, base live in the stage buffer)
 };
 #define RIC_BD 16       // per stage: Qhat_u (rows 6, 7) of the six right-hand sides, then q00, q10, q11, 1 / det
@@ -868,19 +874,22 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
     const int S6[6] = {2, 3, 6, 7, 8, 9}, R8[8] = {0, 1, 4, 5, 10, 11, 12, 13}, I4[4] = {2, 3, 6, 7}, C12[12] = {0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13};
     // A: items 0..35 T[a][cc] = [cc >= 8] p[a][cc-8] + P[a][:] . FA[:][cc] for the six live columns (stored as T'[cc][a]);  36..47 u2[m][b] += FA[:][8+m] . p[:][b];
     //    48..63 Qhat[a][cc] = [H | p][a][cc] + P[a][:] . FA[:][cc] for a = 0, 1 and the copied columns (FA[:][cc] is a unit vector or zero there)
-    p.a_a = oZ6; p.a_b = oZ6; p.a_i = oZ; p.a_d = oD; p.a_sg = 0;
+    // (F acts through its rows 0..3 only -- the bicycle model -- plus the selector rows w+ = u, whose coefficient is exactly 1: every product is a 4-term dot product with up
+    //  to two initial values, and the dependency chain of an item is three operations deep instead of four)
+    p.a_a = oZ6; p.a_b = oZ6; p.a_i = oZ; p.a_j = oZ; p.a_d = oD; p.a_sg = 0;
     if (lane < 36) { const int cc = S6[lane / 6], a_ = lane % 6; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2;
-                     p.a_i = cc < 8 ? oZ : opn + (cc - 8) * 6 + a_; p.a_d = oT + cc * 6 + a_; }
+                     p.a_i = cc < 8 ? oZ : opn + (cc - 8) * 6 + a_; p.a_j = cc == 6 ? oPn + a_ * 6 + 4 : (cc == 7 ? oPn + a_ * 6 + 5 : oZ); p.a_d = oT + cc * 6 + a_; }
     else if (lane < 48) { const int m = (lane - 36) / 6, b_ = (lane - 36) % 6; p.a_a = oSG + SG_FA + (8 + m) * 6; p.a_sg = 1; p.a_b = opn + b_ * 6; p.a_i = p.a_d = osB + 12 + m * 6 + b_; }
     else { const int a_ = (lane - 48) / 8, cc = R8[(lane - 48) % 8]; p.a_a = oPn + a_ * 6; p.a_b = oSG + SG_FA + cc * 6; p.a_sg = 2; p.a_d = oQ + a_ * 14 + cc;
            if (cc < 8) { p.a_i = oSG + SG_H + a_ * 8 + cc; p.a_sg |= 4; } else p.a_i = opn + (cc - 8) * 6 + a_; }
     // B: items 0..47 Qhat[i][cc] = [H | hc][i][cc] + FA[:][i] . T[:][cc] for the rows psi, v, delta, a and the twelve live columns;  48..59 the same for rows X, Y and the six
     //    columns phase A formed;  60..63 u1[m][b] += FA[:][8+m] . T[:][8+b], b = 0, 1.  T[:][cc] is read where it lives: a row of P (symmetric), a column of p', or T'
-    p.b_a = oZ6; p.b_b = oZ6; p.b_i = oZ; p.b_d = oD; p.b_sg = 0;
+    p.b_a = oZ6; p.b_b = oZ6; p.b_i = oZ; p.b_j = oZ; p.b_d = oD; p.b_sg = 0;
     if (lane < 60) {
         const int i = lane < 48 ? I4[lane / 12] : (lane - 48) / 6, cc = lane < 48 ? C12[lane % 12] : S6[(lane - 48) % 6];
         p.b_a = oSG + SG_FA + i * 6; p.b_sg = 1 | 4;
         p.b_b = cc < 2 ? oPn + cc * 6 : (cc >= 10 ? opn + (cc - 8) * 6 : oT + cc * 6);
+        p.b_j = i == 6 ? p.b_b + 4 : (i == 7 ? p.b_b + 5 : oZ);                 // the selector rows of F: + T[4][cc] for the delta row, + T[5][cc] for the a row
         p.b_i = oSG + (cc < 8 ? SG_H + i * 8 + cc : SG_HC + i * OB_NC + (cc - 8)); p.b_d = oQ + i * 14 + cc;
     } else { const int m = (lane - 60) / 2, b_ = (lane - 60) % 2; p.b_a = oSG + SG_FA + (8 + m) * 6; p.b_sg = 1; p.b_b = oT + (8 + b_) * 6; p.b_i = p.b_d = osB + m * 6 + b_; }
     // C: value = base + (X6 n0 + X7 n1) / det with (n0, n1) = adj(Quu) applied to rows 6, 7 of the item's column of Qhat
@@ -902,6 +911,18 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
         }
     }
 }
+// four contiguous, 16-byte aligned doubles from LDS: two ds_read_b128
+OBCA_FN void ld4(const double *q, double (&v)[4]) {
+#ifdef OBCA_EMU
+    for (int i = 0; i < 4; i++) v[i] = q[i];
+#else
+    const double2 *q2 = (const double2 *)__builtin_assume_aligned(q, 16);
+    const double2 a = q2[0], b = q2[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+#endif
+}
+// i1 + i2 + a . b over four terms, three dependent operations deep (two chains of two fma, one add)
+OBCA_FN double dot4_two(double i1, double i2, const double (&a)[4], const double (&b)[4]) { return fma(a[1], b[1], fma(a[0], b[0], i1)) + fma(a[3], b[3], fma(a[2], b[2], i2)); }
 // six contiguous, 16-byte aligned doubles from LDS: three ds_read_b128
 OBCA_FN void ld6(const double *q, double (&v)[6]) {
 #ifdef OBCA_EMU
@@ -921,20 +942,23 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
         const RicItem &p = rp[LI(lane)];
-        double A[6], B[6]; ld6(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld6(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
-        L[p.a_d] = dot6_tree(L[p.a_i + ((p.a_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
+        double A[4], B[4]; ld4(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld4(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
+        L[p.a_d] = dot4_two(L[p.a_i + ((p.a_sg & 4) ? sgo : 0)], L[p.a_j], A, B);
     }
     LDS_SYNC();
+    double vB[OBCA_NLT];
     PAR(lane) {   // phase B
         const RicItem &p = rp[LI(lane)];
-        double A[6], B[6]; ld6(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld6(L + p.b_b, B);
-        L[p.b_d] = dot6_tree(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], A[0], B[0], A[1], B[1], A[2], B[2], A[3], B[3], A[4], B[4], A[5], B[5]);
+        double A[4], B[4]; ld4(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld4(L + p.b_b, B);
+        vB[LI(lane)] = dot4_two(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], L[p.b_j], A, B);
+        L[p.b_d] = vB[LI(lane)];
     }
+    // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division.  The three entries come straight out of the
+    // registers of the lanes that formed them (phase-B items (delta, delta), (a, delta), (a, a) = lanes 28, 40, 41), so that the pivot test and the division run in the
+    // shadow of phase B's LDS round trip instead of behind it
+    const double q00 = WV_READLANE(vB, 28), q10 = WV_READLANE(vB, 40), q11 = WV_READLANE(vB, 41);
     LDS_SYNC();
     PROF_FINE(I, PF_RIC_P1);
-    // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse is adj(Quu) / det: ONE division, and everything that
-    // does not need it (the adjugate products below) runs while it is in flight
-    const double q00 = sh.Qhat[6 * 14 + 6], q10 = sh.Qhat[7 * 14 + 6], q11 = sh.Qhat[7 * 14 + 7];
     const double det = q00 * q11 - q10 * q10;
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
     const double idet = rcp_nr(det);
@@ -1055,7 +1079,6 @@ OBCA_FN void wv_mfma(double (&acc)[4][OBCA_NLT], const double (&a)[OBCA_NLT], co
 }
 OBCA_FN void wv_shfl_group(double (&out)[OBCA_NLT], const double (&in)[OBCA_NLT], int grp) { for (int l = 0; l < 64; l++) out[l] = in[16 * grp + (l & 15)]; }   // lane (grp, j) -> every lane (g, j)
 OBCA_FN void wv_shfl_xor(double (&out)[OBCA_NLT], const double (&in)[OBCA_NLT], int m) { for (int l = 0; l < 64; l++) out[l] = in[l ^ m]; }
-#define WV_READLANE(x, l) ((x)[l])
 #else
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 OBCA_FN void wv_mfma(double (&acc)[4][1], const double (&a)[1], const double (&b)[1]) {
@@ -1065,7 +1088,6 @@ OBCA_FN void wv_mfma(double (&acc)[4][1], const double (&a)[1], const double (&b
 }
 OBCA_FN void wv_shfl_group(double (&out)[1], const double (&in)[1], int grp) { out[0] = __shfl(in[0], 16 * grp + ((int)threadIdx.x & 15), 64); }
 OBCA_FN void wv_shfl_xor(double (&out)[1], const double (&in)[1], int m) { out[0] = __shfl_xor(in[0], m, 64); }
-#define WV_READLANE(x, l) readlane_f64((x)[0], (l))
 #endif
 
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
