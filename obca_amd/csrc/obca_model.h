@@ -26,16 +26,27 @@ namespace obca {
 // (tools/micro/lds_barrier_latency.hip: (724 - 440) / 6 clocks per fma of a chain).  Measured on MI355X over 80 binades: 1.00 ulp, the same as two Newton steps
 // (tools/micro/rcp_accuracy.hip, profiles/r03_rcp_accuracy.txt).  For the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN,
 // and those are rejected by the positivity tests next to every use.  The host emulation divides.
+// RS = 0: the two-Newton-step form (five dependent operations, the same 1.00 ulp).  The (stage, obstacle) code instantiated for more than two rows per obstacle keeps it:
+// there the register allocation of the short form costs more than its shorter chain gains (same-box A/B on BASELINE config 5: 3.5 % fewer solves/s with the short form in
+// those instantiations, while config 2 -- two rows -- gains 3.7 % from it; profiles/r03_ab_reciprocal_and_early_quu.txt).
+template <int RS = 1>
 OBCA_FN double rcp_nr(double d) {
 #ifdef OBCA_EMU
     return 1.0 / d;
 #else
-    const double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);      // e = 1 - d r: 2^-24 at most
-    return fma(r, fma(e, e, e), r);                                     // r (1 + e + e^2) = (1/d)(1 - e^3)
+    if (RS) {
+        const double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);      // e = 1 - d r: 2^-24 at most
+        return fma(r, fma(e, e, e), r);                                     // r (1 + e + e^2) = (1/d)(1 - e^3)
+    }
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
 #endif
 }
 
-OBCA_FN double rdiv(double a, double b) { return a * rcp_nr(b); }   // a / b to an ulp or two, 6 instructions instead of 12
+template <int RS = 1>
+OBCA_FN double rdiv(double a, double b) { return a * rcp_nr<RS>(b); }   // a / b to an ulp or two, 6 instructions instead of 12
 
 struct Consts {               // uniform per instance
     double Ts, L, iL, g[4], off, xl[4], xu[4], x0[4], xF[4];   // iL = 1 / L (the wheelbase divides a dozen terms per stage)
@@ -120,7 +131,7 @@ OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], d
 }
 
 // ---------------------------------------------------------------- small dense helpers (compile-time sizes)
-template <int NMAX>
+template <int NMAX, int RS = 1>
 OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower triangle in; out: L (strict lower), 1/D (diagonal)
     int bad = 0;
     double D[NMAX];
@@ -133,7 +144,7 @@ OBCA_FN int ldl_fact(int n, double *A) {   // A: NMAX x NMAX row-major; lower tr
             for (int k = 0; k < NMAX; k++) if (k < j) d -= A[j * NMAX + k] * A[j * NMAX + k] * D[k];
             if (!(d > 0)) bad = 1;
             D[j] = d;
-            const double id = rcp_nr(d);
+            const double id = rcp_nr<RS>(d);
             A[j * NMAX + j] = id;
 #pragma unroll
             for (int i = 0; i < NMAX; i++) if (i > j && i < n) {
@@ -229,6 +240,7 @@ template <int MODE, int VM>
 OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
                        const double dp[3], ObsStep<VM> *step) {
     const int v = in.v;
+    constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr)
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
     for (int i = 0; i < VM; i++) if (i < v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
@@ -258,18 +270,18 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     // d rows 2..4 / d mu
     const double Jmu[3][4] = {{1, 0, -1, 0}, {0, 1, 0, -1}, {-c.g[0], -c.g[1], -c.g[2], -c.g[3]}};
     // local stationarity residuals, diagonals
-    const double iso = rcp_nr(in.so);
+    const double iso = rcp_nr<RS_>(in.so);
     // sl: the free penetration slack of ParkingSignedDist (cost 1e2 sl + 1e4 sl^2, enters row 4) or, in the ParkingDist formulation,
     // the slack s1 >= 0 of the norm row 1 (no cost, barrier, multiplier zs1); either way a diagonal pivot
-    const double isl = c.dist ? rcp_nr(in.sl) : 0.0;
-    const double iDso = rcp_nr(in.zso * iso + dw), iDsl = rcp_nr((c.dist ? in.zs1 * isl : 2e4) + dw);
+    const double isl = c.dist ? rcp_nr<RS_>(in.sl) : 0.0;
+    const double iDso = rcp_nr<RS_>(in.zso * iso + dw), iDsl = rcp_nr<RS_>((c.dist ? in.zs1 * isl : 2e4) + dw);
     const double iDs4 = c.dist ? 0.0 : iDsl, iDs1 = c.dist ? iDsl : 0.0;          // where the pivot lands: row 4 or row 1
     double r_so = -y[3] - mu_b * iso, r_sl = c.dist ? y[0] - mu_b * isl : 1e2 + 2e4 * in.sl + y[3];
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
-        { const double im = rcp_nr(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr(in.zm[i] * im + dw); }
+        { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); st->dmax = fmax(st->dmax, rz);
             double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -280,7 +292,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     for (int i = 0; i < VM; i++) {
         if (i < v) {
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
-            { const double il = rcp_nr(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
+            { const double il = rcp_nr<RS_>(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); st->dmax = fmax(st->dmax, rz);
                 double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -318,7 +330,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         r234[r] = a_;
     }
     r234[2] += -r_so * iDso + r_sl * iDs4;
-    int bad = ldl_fact<3>(3, Tm);
+    int bad = ldl_fact<3, RS_>(3, Tm);
     // W = T^{-1} [Jl234 | Jp234 | r234]
     double W[3][VM + 4];
 #pragma unroll
@@ -368,7 +380,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double alpha = Jl[0][0] > 0 ? -nq : nq, nw = 0;
 #pragma unroll
     for (int i = 0; i < VM; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
-    const double hb = nw > 0 ? 2.0 * rcp_nr(nw) : 0.0;
+    const double hb = nw > 0 ? 2.0 * rcp_nr<RS_>(nw) : 0.0;
     // Ht = Qh Kb Qh
 #pragma unroll
     for (int j = 0; j < VM; j++) {
@@ -383,7 +395,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     for (int i = 0; i < VM; i++) hh_apply<VM>(v, hw, hb, Kb + i * VM);
     double a00 = Kb[0], det = a00 * (-dc1) - alpha * alpha;
     if (!(det < 0)) bad = 1;
-    const double idet = rcp_nr(det), Mi0 = -dc1 * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
+    const double idet = rcp_nr<RS_>(det), Mi0 = -dc1 * idet, Mi1 = -alpha * idet, Mi2 = a00 * idet;
     double hc[VM - 1], Hr[(VM - 1) * (VM - 1)];
 #pragma unroll
     for (int i = 0; i < VM - 1; i++) hc[i] = (i + 1 < v) ? Kb[(i + 1) * VM] : 0.0;
@@ -391,7 +403,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     for (int i = 0; i < VM - 1; i++)
 #pragma unroll
         for (int j = 0; j < VM - 1; j++) Hr[i * (VM - 1) + j] = Kb[(i + 1) * VM + (j + 1)] - Mi0 * hc[i] * hc[j];
-    if (v > 1) bad |= ldl_fact<(VM > 1 ? VM - 1 : 1)>(v - 1, Hr);
+    if (v > 1) bad |= ldl_fact<(VM > 1 ? VM - 1 : 1), RS_>(v - 1, Hr);
     // solve K^{-1} col  for col = [r_lam(v); r_y]
     auto ksolve = [&](double *col /* VM+1 */) {
         hh_apply<VM>(v, hw, hb, col);

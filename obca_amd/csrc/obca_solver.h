@@ -7,7 +7,7 @@
 // records in HBM, or DPP / ds_bpermute / v_readlane.
 //   * (stage, obstacle) blocks  -> one lane per block        (condensation / back-substitution, obca_model.h)
 //   * stages                    -> one lane per stage        (bicycle model derivatives, costs, bounds)
-//   * Riccati backward sweep    -> sequential in the stage index; per stage three short LDS phases, two matrix entries per lane, 16-byte LDS operands
+//   * Riccati backward sweep    -> sequential in the stage index; per stage three short LDS phases, one structure-aware item per lane, 16-byte LDS operands
 //   * forward sweep             -> two stages per dependent step: pair maps composed into LDS, state broadcast with v_readlane
 //   * reductions (norms, step lengths, objective) -> 64-lane register butterfly (DPP inside a row of 16 lanes, ds_bpermute across rows)
 //   * line search               -> fused into the next assembly (assemble_obs / assemble_stage <FUSED = 1>): the trial point goes to the second iterate buffer
@@ -385,9 +385,11 @@ OBCA_FN int as_df(int i, int j) { return i < 2 ? 5 * i + j : (i == 2 ? (j >= 1 ?
 
 
 // ---------------------------------------------------------------- accepting a step: new bound multipliers
-OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu * rcp_nr(dist), lo = q * rcp_nr(ks), hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
+template <int RS = 1>
+OBCA_FN double clampz(double zz, double dist, double mu, double ks) { const double q = mu * rcp_nr<RS>(dist), lo = q * rcp_nr<RS>(ks), hi = ks * q; return zz < lo ? lo : (zz > hi ? hi : zz); }
 // bound-multiplier step for a lower bound at distance `dist` (upper bound: pass -dv):  z += az (mu/dist - z - z/dist dv)
-OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr(dist); return zz + az * (mu * id - zz - zz * id * dv); }
+template <int RS = 1>
+OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { const double id = rcp_nr<RS>(dist); return zz + az * (mu * id - zz - zz * id * dv); }
 
 
 // ---------------------------------------------------------------- assemble the condensed Newton system
@@ -409,6 +411,7 @@ template <int VM, int FUSED>
 OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
+    constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const gdbl *z = I.z; gdbl *zn = I.zn;
     double red[11][OBCA_NL];                 // per-lane partial results, reduced over the wavefront in registers
     // ---- (a) obstacle blocks: one lane per (stage, obstacle)
@@ -432,21 +435,21 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
                 } else obs_block<1, VM>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp);
 #pragma unroll
                 for (int i = 0; i < VM; i++) if (i < in.v) {
-                    const double v1 = fma(fa.alpha, sp.dlam[i], in.lam[i]), z1 = zstep(in.zl[i], in.lam[i], sp.dlam[i], mu, fa.az);
-                    in.lam[i] = v1; in.zl[i] = clampz(z1, v1, mu, fa.ks);
+                    const double v1 = fma(fa.alpha, sp.dlam[i], in.lam[i]), z1 = zstep<RS_>(in.zl[i], in.lam[i], sp.dlam[i], mu, fa.az);
+                    in.lam[i] = v1; in.zl[i] = clampz<RS_>(z1, v1, mu, fa.ks);
                     zn[l.lam + k * M + r0 + i] = in.lam[i]; zn[l.zlam + k * M + r0 + i] = in.zl[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const double v1 = fma(fa.alpha, sp.dmu[i], in.mu[i]), z1 = zstep(in.zm[i], in.mu[i], sp.dmu[i], mu, fa.az);
-                    in.mu[i] = v1; in.zm[i] = clampz(z1, v1, mu, fa.ks); in.y[i] = fma(fa.ay, sp.dy[i], in.y[i]);
+                    const double v1 = fma(fa.alpha, sp.dmu[i], in.mu[i]), z1 = zstep<RS_>(in.zm[i], in.mu[i], sp.dmu[i], mu, fa.az);
+                    in.mu[i] = v1; in.zm[i] = clampz<RS_>(z1, v1, mu, fa.ks); in.y[i] = fma(fa.ay, sp.dy[i], in.y[i]);
                     zn[l.mu + 4 * it + i] = in.mu[i]; zn[l.zmu + 4 * it + i] = in.zm[i]; zn[l.yo + 4 * it + i] = in.y[i];
                 }
                 {
-                    const double v1 = fma(fa.alpha, sp.dso, in.so), z1 = zstep(in.zso, in.so, sp.dso, mu, fa.az);
-                    in.so = v1; in.zso = clampz(z1, v1, mu, fa.ks);
+                    const double v1 = fma(fa.alpha, sp.dso, in.so), z1 = zstep<RS_>(in.zso, in.so, sp.dso, mu, fa.az);
+                    in.so = v1; in.zso = clampz<RS_>(z1, v1, mu, fa.ks);
                     const double s1 = fma(fa.alpha, sp.dsl, in.sl);
-                    if (c.dist) in.zs1 = clampz(zstep(in.zs1, in.sl, sp.dsl, mu, fa.az), s1, mu, fa.ks);
+                    if (c.dist) in.zs1 = clampz<RS_>(zstep<RS_>(in.zs1, in.sl, sp.dsl, mu, fa.az), s1, mu, fa.ks);
                     in.sl = s1;
                     zn[l.so + it] = in.so; zn[l.zso + it] = in.zso; zn[l.sl + it] = in.sl; zn[l.zs1 + it] = in.zs1;
                 }
@@ -1336,6 +1339,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
 template <int VM, int DBG>      // DBG = 1 (host emulation tests only): the obstacle part of the direction is also written to d
 OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
+    constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
     double ap = so.ap, az = so.az, gd = so.gd;
@@ -1344,8 +1348,8 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
     double red[3][OBCA_NL];
     PAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
-#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
-#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < laz) laz = cc_; }
+#define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr<RS_>(dv) : 1e300; if (cc_ < lap) lap = cc_; }
+#define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr<RS_>(dv) : 1e300; if (cc_ < laz) laz = cc_; }
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
@@ -1356,19 +1360,19 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
                 if (DBG || OBCA_STORE_DOBS) d[l.lam + k * M + r0 + i] = st.dlam[i];
-                lgd -= rdiv(mu, in.lam[i]) * st.dlam[i];
-                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv(mu, in.lam[i]) - in.zl[i] - rdiv(in.zl[i], in.lam[i]) * st.dlam[i]);
+                lgd -= rdiv<RS_>(mu, in.lam[i]) * st.dlam[i];
+                FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv<RS_>(mu, in.lam[i]) - in.zl[i] - rdiv<RS_>(in.zl[i], in.lam[i]) * st.dlam[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (DBG || OBCA_STORE_DOBS) { d[l.mu + 4 * it + i] = st.dmu[i]; d[l.yo + 4 * it + i] = st.dy[i]; }
-                lgd -= rdiv(mu, in.mu[i]) * st.dmu[i];
-                FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], rdiv(mu, in.mu[i]) - in.zm[i] - rdiv(in.zm[i], in.mu[i]) * st.dmu[i]);
+                lgd -= rdiv<RS_>(mu, in.mu[i]) * st.dmu[i];
+                FTBP(in.mu[i], st.dmu[i]); FTBZ(in.zm[i], rdiv<RS_>(mu, in.mu[i]) - in.zm[i] - rdiv<RS_>(in.zm[i], in.mu[i]) * st.dmu[i]);
             }
             if (DBG || OBCA_STORE_DOBS) { d[l.sl + it] = st.dsl; d[l.so + it] = st.dso; }
-            lgd += (c.dist ? -rdiv(mu, in.sl) : 1e2 + 2e4 * in.sl) * st.dsl - rdiv(mu, in.so) * st.dso;
-            if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, rdiv(mu, in.sl) - in.zs1 - rdiv(in.zs1, in.sl) * st.dsl); }
-            FTBP(in.so, st.dso); FTBZ(in.zso, rdiv(mu, in.so) - in.zso - rdiv(in.zso, in.so) * st.dso);
+            lgd += (c.dist ? -rdiv<RS_>(mu, in.sl) : 1e2 + 2e4 * in.sl) * st.dsl - rdiv<RS_>(mu, in.so) * st.dso;
+            if (c.dist) { FTBP(in.sl, st.dsl); FTBZ(in.zs1, rdiv<RS_>(mu, in.sl) - in.zs1 - rdiv<RS_>(in.zs1, in.sl) * st.dsl); }
+            FTBP(in.so, st.dso); FTBZ(in.zso, rdiv<RS_>(mu, in.so) - in.zso - rdiv<RS_>(in.zso, in.so) * st.dso);
         }
         red[0][LI(lane)] = lap; red[1][LI(lane)] = laz; red[2][LI(lane)] = lgd;
 #undef FTBP
@@ -1379,11 +1383,11 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
     if (!c.fixTime) {
         const double t = z[l.t], dL = t - OB_TL, dU = OB_TU - t, zL = z[l.ztL], zU = z[l.ztU];
         double cc_;
-        cc_ = dt < 0 ? -tau * dL * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
-        cc_ = -dt < 0 ? tau * dU * rcp_nr(dt) : 1e300; if (cc_ < ap) ap = cc_;
-        double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
-        cc_ = dzL < 0 ? -tau * zL * rcp_nr(dzL) : 1e300; if (cc_ < az) az = cc_;
-        cc_ = dzU < 0 ? -tau * zU * rcp_nr(dzU) : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dt < 0 ? -tau * dL * rcp_nr<RS_>(dt) : 1e300; if (cc_ < ap) ap = cc_;
+        cc_ = -dt < 0 ? tau * dU * rcp_nr<RS_>(dt) : 1e300; if (cc_ < ap) ap = cc_;
+        double dzL = rdiv<RS_>(mu, dL) - zL - rdiv<RS_>(zL, dL) * dt, dzU = rdiv<RS_>(mu, dU) - zU + rdiv<RS_>(zU, dU) * dt;
+        cc_ = dzL < 0 ? -tau * zL * rcp_nr<RS_>(dzL) : 1e300; if (cc_ < az) az = cc_;
+        cc_ = dzU < 0 ? -tau * zU * rcp_nr<RS_>(dzU) : 1e300; if (cc_ < az) az = cc_;
         // d phi / d t: rate cost (so.gr, summed over the stages by the back-substitution above) + time cost + barrier of its bounds
         const double gt = so.gr + (N + 1) * (0.5 + 2 * t) + (N + 1) * (-mu / (t - OB_TL) + mu / (OB_TU - t));
         gd += gt * dt;
