@@ -9,7 +9,7 @@ timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest_gpu.
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sync -o t -- python $R/bench.py --steps 8 --warmup 2 --streams 1 --sync-steps 4 --no-cpu-baseline --no-pmc --no-host-rate > $O/bench_sync_under_rocprof.json 2> $O/stats_sync.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sync -o t -- python $R/bench.py --steps 8 --warmup 2 --streams 1 --sync-steps 4 --no-cpu-baseline --no-pmc --no-host-rate --no-distinct > $O/bench_sync_under_rocprof.json 2> $O/stats_sync.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_quad -o t -- python $R/bench.py --config 4 --steps 4 --warmup 1 --streams 1 --sync-steps 2 --no-cpu-baseline --no-pmc --no-host-rate > $O/bench_quad_sync_under_rocprof.json 2> $O/stats_quad.err
 for K in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $K --kernel-trace --output-format csv -d $O/pmc_cfg2 -o $K -- python $R/bench.py --pmc-child > /dev/null 2> $O/pmc_cfg2_$K.err
