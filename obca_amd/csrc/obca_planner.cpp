@@ -3,10 +3,14 @@
 //   /root/reference/AutonomousParking/hybrid_a_star.jl (search over motion primitives, grid-based holonomic heuristic,
 //   collision check of the car rectangle against the obstacles), main.jl:216-248 (path -> rx, ry, ryaw -> down-sampling).
 // This is a re-design, not a port: obstacles are the same convex H-representations the NLP uses (A p <= b per obstacle, obstHrep.jl),
-// the collision test clips the inflated car rectangle against each obstacle's half-planes (exact for convex sets, no KD-tree of
-// sampled obstacle points), the heuristic is max(obstacle-aware 2-D Dijkstra distance of a disc robot, Euclid) and the analytic
-// Reeds-Shepp expansion is replaced by a goal tolerance (the NLP's terminal constraint closes the gap).
-// Build: g++ -O2 -shared -fPIC -o libobca_plan.so obca_planner.cpp   (tools/build.sh, __graft_entry__.build()).
+// the collision test is the overlap area of the inflated car rectangle with each obstacle (the rectangle clipped by the obstacle's
+// half-planes: exact for convex sets, no KD-tree of sampled obstacle points; separating-axis tests settle nearly every call before
+// the clip), the heuristic is max(obstacle-aware 2-D Dijkstra distance of a disc robot, turning-radius bound on the heading error)
+// and the analytic Reeds-Shepp expansion (hybrid_a_star.jl:193-214, reeds_shepp.jl) ends the search on the exact goal pose.
+// (obca_planner_ref.cpp is the REFERENCE mode: hybrid_a_star.jl restated on its point-cloud obstacles.)
+// Cost per expanded node (config-3 bay, 0.1 m / 3 deg cells): ~3.3 us on one core -- 1.4 us the 44 Reeds-Shepp family evaluations
+// (which share one sin / cos pair and two polar forms per mirror image), the rest ~26 collision tests, libm and the heap.
+// Build: g++ -O2 -shared -fPIC -pthread -o libobca_plan.so obca_planner.cpp obca_planner_ref.cpp   (tools/build.sh, __graft_entry__.build()).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -27,6 +31,9 @@ struct World {
     double xmin, xmax, ymin, ymax;                               // XYbounds of the rear-axle position
     double ego[4], margin;                                        // front, left, rear, right extents from the rear axle; inflation
     mutable std::vector<P2> bufA, bufB;                           // clip scratch of collides(), sized for the obstacle with the most rows
+    std::vector<double> rn;                                       // 1 / |a_i| of every row
+    std::vector<P2> vert; std::vector<int> voff;                  // obstacle j as a polygon (cut to a box far outside the bounds if it is unbounded): vert[voff[j] .. voff[j+1])
+    void finish();
 };
 
 // convex polygon clipped by the half-plane a.p <= bb (Sutherland-Hodgman); returns the number of vertices left
@@ -41,16 +48,52 @@ static int clip(const P2 *in, int n, double ax, double ay, double bb, P2 *out) {
     return m;
 }
 
-static bool collides(const World &w, double x, double y, double yaw) {
+void World::finish() {     // what collides() needs besides the rows: their norms, the obstacles' vertices, the clip scratch
+    int vmax = 0; for (int j = 0; j < nOb; j++) vmax = std::max(vmax, v[j]);
+    bufA.resize(4 + vmax + 1); bufB.resize(4 + vmax + 1);         // every half-plane adds at most one vertex to a convex polygon
+    rn.resize(off[nOb]);
+    for (int r = 0; r < off[nOb]; r++) { const double n = std::hypot(A[2 * r], A[2 * r + 1]); rn[r] = n > 0 ? 1.0 / n : 0.0; }
+    const double far_ = 1e3 + std::max(std::max(std::fabs(xmin), std::fabs(xmax)), std::max(std::fabs(ymin), std::fabs(ymax)));
+    voff.assign(nOb + 1, 0); vert.clear();
+    std::vector<P2> pa(4 + vmax + 1), pb(4 + vmax + 1);
+    for (int j = 0; j < nOb; j++) {
+        int n = 4; pa[0] = {far_, far_}; pa[1] = {-far_, far_}; pa[2] = {-far_, -far_}; pa[3] = {far_, -far_};
+        P2 *cur = pa.data(), *nxt = pb.data();
+        for (int i = 0; i < v[j] && n > 0; i++) { const int r = off[j] + i; n = clip(cur, n, A[2 * r], A[2 * r + 1], b[r], nxt); std::swap(cur, nxt); }
+        vert.insert(vert.end(), cur, cur + n); voff[j + 1] = (int)vert.size();
+    }
+}
+
+// Does the (inflated) car rectangle at the pose overlap an obstacle?  The answer is DEFINED by the clipped overlap area (car cut by every half-plane of the obstacle,
+// area > 1e-9); nearly every call is settled before that by the separating-axis tests of a rectangle against a convex polygon, which agree with it: a row all four corners
+// violate (the clip would leave nothing), a car side every vertex of the obstacle lies beyond, or a corner deep inside every row.
+static bool collides_cs(const World &w, double x, double y, double c, double s) {      // c, s = cos, sin of the heading
     if (x < w.xmin || x > w.xmax || y < w.ymin || y > w.ymax) return true;
-    const double c = std::cos(yaw), s = std::sin(yaw), m = w.margin;
+    const double m = w.margin;
     const double f = w.ego[0] + m, l = w.ego[1] + m, r = w.ego[2] + m, rt = w.ego[3] + m;
     const P2 car[4] = {{x + f * c - l * s, y + f * s + l * c}, {x - r * c - l * s, y - r * s + l * c},
                        {x - r * c + rt * s, y - r * s - rt * c}, {x + f * c + rt * s, y + f * s - rt * c}};
-    int vmax = 0; for (int j = 0; j < w.nOb; j++) vmax = std::max(vmax, w.v[j]);
-    std::vector<P2> &bufA = w.bufA, &bufB = w.bufB;              // every half-plane adds at most one vertex to a convex polygon
-    if ((int)bufA.size() < 4 + vmax + 1) { bufA.resize(4 + vmax + 1); bufB.resize(4 + vmax + 1); }
+    std::vector<P2> &bufA = w.bufA, &bufB = w.bufB;
     for (int j = 0; j < w.nOb; j++) {
+        bool apart = false; double deep[4] = {1e300, 1e300, 1e300, 1e300};      // deep[q]: how far corner q is inside the obstacle (least over its rows)
+        for (int i = 0; i < w.v[j]; i++) {
+            const int rix = w.off[j] + i; const double ax = w.A[2 * rix], ay = w.A[2 * rix + 1], bb = w.b[rix];
+            const double d0 = ax * car[0].x + ay * car[0].y - bb, d1 = ax * car[1].x + ay * car[1].y - bb, d2 = ax * car[2].x + ay * car[2].y - bb, d3 = ax * car[3].x + ay * car[3].y - bb;
+            if (d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0) { apart = true; break; }
+            const double n_ = w.rn[rix];
+            deep[0] = std::min(deep[0], -d0 * n_); deep[1] = std::min(deep[1], -d1 * n_); deep[2] = std::min(deep[2], -d2 * n_); deep[3] = std::min(deep[3], -d3 * n_);
+        }
+        if (apart) continue;
+        if (std::max(std::max(deep[0], deep[1]), std::max(deep[2], deep[3])) > 1e-3) return true;   // a quarter disc of radius 1e-3 around that corner is overlap: area > 7e-7
+        {   // the car's own sides: in its frame the obstacle's vertices are (u, v_); a side with every vertex beyond it (by more than a rounding margin) separates
+            const int v0 = w.voff[j], v1 = w.voff[j + 1];
+            double umin = 1e300, umax = -1e300, wmin = 1e300, wmax = -1e300;
+            for (int q = v0; q < v1; q++) {
+                const double dx = w.vert[q].x - x, dy = w.vert[q].y - y, u = c * dx + s * dy, v_ = -s * dx + c * dy;
+                umin = std::min(umin, u); umax = std::max(umax, u); wmin = std::min(wmin, v_); wmax = std::max(wmax, v_);
+            }
+            if (v1 > v0 && (umin > f + 1e-7 || umax < -r - 1e-7 || wmin > l + 1e-7 || wmax < -rt - 1e-7)) continue;
+        }
         int n = 4; std::memcpy(bufA.data(), car, sizeof car);
         P2 *cur = bufA.data(), *nxt = bufB.data();
         for (int i = 0; i < w.v[j] && n > 0; i++) {
@@ -65,6 +108,7 @@ static bool collides(const World &w, double x, double y, double yaw) {
     }
     return false;
 }
+static inline bool collides(const World &w, double x, double y, double yaw) { return collides_cs(w, x, y, std::cos(yaw), std::sin(yaw)); }
 
 static bool disc_collides(const World &w, double x, double y, double rad) {
     for (int j = 0; j < w.nOb; j++) {   // distance of the point to the convex set (intersection of half-planes), conservative via max row slack
@@ -94,7 +138,7 @@ static inline double wrap(double a) { while (a > M_PI) a -= 2 * M_PI; while (a <
 namespace rs {
 struct Path { char type[5]; double len[5]; int n; double total; };
 static const double PI = M_PI, ZERO = 1e-12;
-static inline double mod2pi(double x) { double v = std::fmod(x, 2 * PI); if (v < -PI) v += 2 * PI; else if (v > PI) v -= 2 * PI; return v; }
+static inline double mod2pi(double x) { double v = std::fabs(x) < 2 * PI ? x : std::fmod(x, 2 * PI); if (v < -PI) v += 2 * PI; else if (v > PI) v -= 2 * PI; return v; }   // (fmod returns such an x itself)
 static inline void polar(double x, double y, double &r, double &th) { r = std::hypot(x, y); th = std::atan2(y, x); }
 static inline void tau_omega(double u, double v, double xi, double eta, double phi, double &tau, double &omega) {
     const double delta = mod2pi(u - v), A = std::sin(u) - std::sin(delta), B = std::cos(u) - std::cos(delta) - 1.0;
@@ -102,47 +146,60 @@ static inline void tau_omega(double u, double v, double xi, double eta, double p
     tau = t2 < 0 ? mod2pi(t1 + PI) : mod2pi(t1);
     omega = mod2pi(tau - u + v - phi);
 }
-static bool LpSpLp(double x, double y, double phi, double &t, double &u, double &v) {
-    polar(x - std::sin(phi), y - 1.0 + std::cos(phi), u, t);
-    if (t >= -ZERO) { v = mod2pi(phi - t); if (v >= -ZERO) return true; }
+// One mirror image of the query, (x, y, phi), with what the families share: sin / cos of phi, the two centre offsets (xi, eta) = (x -+ sin phi, y - 1 +- cos phi) and
+// their polar forms.  A family is a few lines on top of these; evaluating the 44 family calls of a query from scratch costs ~200 libm calls, from here ~50.
+struct Pre {
+    double x, y, phi, sp, cp;
+    double xm, em, rm, tm;        // (x - sin phi, y - 1 + cos phi) and its polar form         (LSL, LRL, LRSL)
+    double xp, ep, rp, tp;        // (x + sin phi, y - 1 - cos phi) and its polar form         (LSR, LRLR, LRSR, LRSLR)
+};
+static inline Pre make_pre(double x, double y, double phi, double sp, double cp, bool polar_p) {
+    Pre q; q.x = x; q.y = y; q.phi = phi; q.sp = sp; q.cp = cp;
+    q.xm = x - sp; q.em = y - 1.0 + cp; polar(q.xm, q.em, q.rm, q.tm);
+    q.xp = x + sp; q.ep = y - 1.0 - cp; q.rp = std::hypot(q.xp, q.ep); q.tp = polar_p && q.rp >= 2.0 ? std::atan2(q.ep, q.xp) : 0;      // (the angle: LSR only, which needs rp >= 2)
+    return q;
+}
+static bool LpSpLp(const Pre &q, double &t, double &u, double &v) {
+    u = q.rm; t = q.tm;
+    if (t >= -ZERO) { v = mod2pi(q.phi - t); if (v >= -ZERO) return true; }
     return false;
 }
-static bool LpSpRp(double x, double y, double phi, double &t, double &u, double &v) {
-    double t1, u1; polar(x + std::sin(phi), y - 1.0 - std::cos(phi), u1, t1);
+static bool LpSpRp(const Pre &q, double &t, double &u, double &v) {
+    double u1 = q.rp; const double t1 = q.tp;
     u1 *= u1;
-    if (u1 >= 4.0) { u = std::sqrt(u1 - 4.0); const double th = std::atan2(2.0, u); t = mod2pi(t1 + th); v = mod2pi(t - phi); return t >= -ZERO && v >= -ZERO; }
+    if (u1 >= 4.0) { u = std::sqrt(u1 - 4.0); const double th = std::atan2(2.0, u); t = mod2pi(t1 + th); v = mod2pi(t - q.phi); return t >= -ZERO && v >= -ZERO; }
     return false;
 }
-static bool LpRmL(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x - std::sin(phi), eta = y - 1.0 + std::cos(phi); double u1, th; polar(xi, eta, u1, th);
-    if (u1 <= 4.0) { u = -2.0 * std::asin(0.25 * u1); t = mod2pi(th + 0.5 * u + PI); v = mod2pi(phi - t + u); return t >= -ZERO && u <= ZERO; }
+static bool LpRmL(const Pre &q, double &t, double &u, double &v) {
+    const double u1 = q.rm, th = q.tm;
+    if (u1 <= 4.0) { u = -2.0 * std::asin(0.25 * u1); t = mod2pi(th + 0.5 * u + PI); v = mod2pi(q.phi - t + u); return t >= -ZERO && u <= ZERO; }
     return false;
 }
-static bool LpRupLumRm(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi), rho = 0.25 * (2.0 + std::hypot(xi, eta));
-    if (rho <= 1.0) { u = std::acos(rho); tau_omega(u, -u, xi, eta, phi, t, v); return t >= -ZERO && v <= ZERO; }
+static bool LpRupLumRm(const Pre &q, double &t, double &u, double &v) {
+    const double rho = 0.25 * (2.0 + q.rp);
+    if (rho <= 1.0) { u = std::acos(rho); tau_omega(u, -u, q.xp, q.ep, q.phi, t, v); return t >= -ZERO && v <= ZERO; }
     return false;
 }
-static bool LpRumLumRp(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi), rho = (20.0 - xi * xi - eta * eta) / 16.0;
-    if (rho >= 0 && rho <= 1) { u = -std::acos(rho); if (u >= -0.5 * PI) { tau_omega(u, u, xi, eta, phi, t, v); return t >= -ZERO && v >= -ZERO; } }
+static bool LpRumLumRp(const Pre &q, double &t, double &u, double &v) {
+    const double rho = (20.0 - q.xp * q.xp - q.ep * q.ep) / 16.0;
+    if (rho >= 0 && rho <= 1) { u = -std::acos(rho); if (u >= -0.5 * PI) { tau_omega(u, u, q.xp, q.ep, q.phi, t, v); return t >= -ZERO && v >= -ZERO; } }
     return false;
 }
-static bool LpRmSmLm(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x - std::sin(phi), eta = y - 1.0 + std::cos(phi); double rho, th; polar(xi, eta, rho, th);
-    if (rho >= 2.0) { const double r = std::sqrt(rho * rho - 4.0); u = 2.0 - r; t = mod2pi(th + std::atan2(r, -2.0)); v = mod2pi(phi - 0.5 * PI - t); return t >= -ZERO && u <= ZERO && v <= ZERO; }
+static bool LpRmSmLm(const Pre &q, double &t, double &u, double &v) {
+    const double rho = q.rm, th = q.tm;
+    if (rho >= 2.0) { const double r = std::sqrt(rho * rho - 4.0); u = 2.0 - r; t = mod2pi(th + std::atan2(r, -2.0)); v = mod2pi(q.phi - 0.5 * PI - t); return t >= -ZERO && u <= ZERO && v <= ZERO; }
     return false;
 }
-static bool LpRmSmRm(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi); double rho, th; polar(-eta, xi, rho, th);
-    if (rho >= 2.0) { t = th; u = 2.0 - rho; v = mod2pi(t + 0.5 * PI - phi); return t >= -ZERO && u <= ZERO && v <= ZERO; }
+static bool LpRmSmRm(const Pre &q, double &t, double &u, double &v) {
+    const double rho = q.rp;                                       // polar form of (-eta, xi): the same radius, the angle atan2(xi, -eta) -- negative (a reject) for xi < 0
+    if (rho >= 2.0 && !(q.xp < -1e-9 * (1.0 + std::fabs(q.ep)))) { t = std::atan2(q.xp, -q.ep); u = 2.0 - rho; v = mod2pi(t + 0.5 * PI - q.phi); return t >= -ZERO && u <= ZERO && v <= ZERO; }
     return false;
 }
-static bool LpRmSLmRp(double x, double y, double phi, double &t, double &u, double &v) {
-    const double xi = x + std::sin(phi), eta = y - 1.0 - std::cos(phi); double rho, th; polar(xi, eta, rho, th);
+static bool LpRmSLmRp(const Pre &q, double &t, double &u, double &v) {
+    const double xi = q.xp, eta = q.ep, rho = q.rp;
     if (rho >= 2.0) {
         u = 4.0 - std::sqrt(rho * rho - 4.0);
-        if (u <= ZERO) { t = mod2pi(std::atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta)); v = mod2pi(t - phi); return t >= -ZERO && v >= -ZERO; }
+        if (u <= ZERO) { t = mod2pi(std::atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta)); v = mod2pi(t - q.phi); return t >= -ZERO && v >= -ZERO; }
     }
     return false;
 }
@@ -150,14 +207,13 @@ static void offer(Path &best, const char *ty, int n, const double *len) {
     double tot = 0; for (int i = 0; i < n; i++) tot += std::fabs(len[i]);
     if (tot < best.total) { best.n = n; best.total = tot; for (int i = 0; i < n; i++) { best.type[i] = ty[i]; best.len[i] = len[i]; } }
 }
-// every family is tried on (x, y, phi), its time flip (-x, y, -phi: all lengths negated), its reflection (x, -y, -phi: L <-> R) and both
-template <class F> static void four(Path &best, F f, double x, double y, double phi, const char *ty, const char *tyr, int n,
-                                    void (*fill)(double, double, double, double *)) {
+// every family is tried on (x, y, phi), its time flip (-x, y, -phi: all lengths negated), its reflection (x, -y, -phi: L <-> R) and both: q[0..3]
+template <class F> static void four(Path &best, F f, const Pre *q, const char *ty, const char *tyr, int n, void (*fill)(double, double, double, double *)) {
     double t, u, v, len[5];
-    if (f(x, y, phi, t, u, v)) { fill(t, u, v, len); offer(best, ty, n, len); }
-    if (f(-x, y, -phi, t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, ty, n, len); }
-    if (f(x, -y, -phi, t, u, v)) { fill(t, u, v, len); offer(best, tyr, n, len); }
-    if (f(-x, -y, phi, t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, tyr, n, len); }
+    if (f(q[0], t, u, v)) { fill(t, u, v, len); offer(best, ty, n, len); }
+    if (f(q[1], t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, ty, n, len); }
+    if (f(q[2], t, u, v)) { fill(t, u, v, len); offer(best, tyr, n, len); }
+    if (f(q[3], t, u, v)) { fill(t, u, v, len); for (int i = 0; i < n; i++) len[i] = -len[i]; offer(best, tyr, n, len); }
 }
 static void f_tuv(double t, double u, double v, double *l) { l[0] = t; l[1] = u; l[2] = v; }
 static void f_vut(double t, double u, double v, double *l) { l[0] = v; l[1] = u; l[2] = t; }
@@ -168,24 +224,32 @@ static void f_v_u_q_t(double t, double u, double v, double *l) { l[0] = v; l[1] 
 static void f_t_q_u_q_v(double t, double u, double v, double *l) { l[0] = t; l[1] = -0.5 * PI; l[2] = u; l[3] = -0.5 * PI; l[4] = v; }
 static Path shortest(double x, double y, double phi) {
     Path best; best.n = 0; best.total = 1e300;
-    four(best, LpSpLp, x, y, phi, "LSL", "RSR", 3, f_tuv);
-    four(best, LpSpRp, x, y, phi, "LSR", "RSL", 3, f_tuv);
-    four(best, LpRmL, x, y, phi, "LRL", "RLR", 3, f_tuv);
-    const double xb = x * std::cos(phi) + y * std::sin(phi), yb = x * std::sin(phi) - y * std::cos(phi);       // the same word driven backwards
-    four(best, LpRmL, xb, yb, phi, "LRL", "RLR", 3, f_vut);
-    four(best, LpRupLumRm, x, y, phi, "LRLR", "RLRL", 4, f_tuuv_m);
-    four(best, LpRumLumRp, x, y, phi, "LRLR", "RLRL", 4, f_tuuv_p);
-    four(best, LpRmSmLm, x, y, phi, "LRSL", "RLSR", 4, f_t_q_u_v);
-    four(best, LpRmSmRm, x, y, phi, "LRSR", "RLSL", 4, f_t_q_u_v);
-    four(best, LpRmSmLm, xb, yb, phi, "LSRL", "RSLR", 4, f_v_u_q_t);
-    four(best, LpRmSmRm, xb, yb, phi, "RSRL", "LSLR", 4, f_v_u_q_t);
-    four(best, LpRmSLmRp, x, y, phi, "LRSLR", "RLSRL", 5, f_t_q_u_q_v);
+    const double sp = std::sin(phi), cp = std::cos(phi);        // (sin, cos of -phi are -sp, cp: libm's sin is odd and its cos even to the last bit)
+    const double xb = x * cp + y * sp, yb = x * sp - y * cp;    // the same word driven backwards
+    const Pre q[4] = {make_pre(x, y, phi, sp, cp, true), make_pre(-x, y, -phi, -sp, cp, true), make_pre(x, -y, -phi, -sp, cp, true), make_pre(-x, -y, phi, sp, cp, true)};
+    const Pre qb[4] = {make_pre(xb, yb, phi, sp, cp, false), make_pre(-xb, yb, -phi, -sp, cp, false), make_pre(xb, -yb, -phi, -sp, cp, false), make_pre(-xb, -yb, phi, sp, cp, false)};
+    four(best, LpSpLp, q, "LSL", "RSR", 3, f_tuv);
+    four(best, LpSpRp, q, "LSR", "RSL", 3, f_tuv);
+    four(best, LpRmL, q, "LRL", "RLR", 3, f_tuv);
+    four(best, LpRmL, qb, "LRL", "RLR", 3, f_vut);
+    four(best, LpRupLumRm, q, "LRLR", "RLRL", 4, f_tuuv_m);
+    four(best, LpRumLumRp, q, "LRLR", "RLRL", 4, f_tuuv_p);
+    four(best, LpRmSmLm, q, "LRSL", "RLSR", 4, f_t_q_u_v);
+    four(best, LpRmSmRm, q, "LRSR", "RLSL", 4, f_t_q_u_v);
+    four(best, LpRmSmLm, qb, "LSRL", "RSLR", 4, f_v_u_q_t);
+    four(best, LpRmSmRm, qb, "RSRL", "LSLR", 4, f_v_u_q_t);
+    four(best, LpRmSLmRp, q, "LRSLR", "RLSRL", 5, f_t_q_u_q_v);
     return best;
 }
 // advance a pose along one segment by the signed amount s (unit radius)
 static inline void advance(char ty, double s, double &x, double &y, double &yaw) {
     if (ty == 'S') { x += s * std::cos(yaw); y += s * std::sin(yaw); }
     else { const double k = ty == 'L' ? 1.0 : -1.0, y1 = yaw + k * s; x += k * (std::sin(y1) - std::sin(yaw)); y += -k * (std::cos(y1) - std::cos(yaw)); yaw = y1; }
+}
+// the same with sin / cos of the heading carried along (sy, cy: of `yaw` on entry and on exit) -- a walk along a path asks libm for each angle once
+static inline void advance_sc(char ty, double s, double &x, double &y, double &yaw, double &sy, double &cy) {
+    if (ty == 'S') { x += s * cy; y += s * sy; }
+    else { const double k = ty == 'L' ? 1.0 : -1.0, y1 = yaw + k * s, s1 = std::sin(y1), c1 = std::cos(y1); x += k * (s1 - sy); y += -k * (c1 - cy); yaw = y1; sy = s1; cy = c1; }
 }
 }  // namespace rs
 
@@ -214,7 +278,7 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
     for (int j = 0; j < nOb; j++) { if (vOb[j] < 1) return -1; w.off[j + 1] = w.off[j] + vOb[j]; }
     w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
     w.xmin = XYbounds[0]; w.xmax = XYbounds[1]; w.ymin = XYbounds[2]; w.ymax = XYbounds[3];
-    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin;
+    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin; w.finish();
     if (collides(w, start[0], start[1], start[2]) || collides(w, goal[0], goal[1], goal[2])) return -2;
 
     // holonomic heuristic: Dijkstra on the xy grid from the goal for a disc of the car's half width (hybrid_a_star.jl's grid heuristic)
@@ -253,58 +317,68 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
         return (iy * (nx + 1) + ix) * nyaw + ia;
     };
     std::vector<Node> nodes; nodes.reserve(1 << 16);
-    std::unordered_map<long long, double> best;
+    // cheapest cost-to-come seen per (x, y, yaw) cell: a dense table that lives with the thread (a search touches a small part of it: those cells are reset afterwards)
+    static thread_local std::vector<double> best; static thread_local std::vector<long long> touched;
+    const long long ncell = (long long)(nx + 1) * (ny + 1) * nyaw;
+    if ((long long)best.size() < ncell) best.assign((size_t)ncell, 1e300);
+    struct Reset { std::vector<double> &b; std::vector<long long> &t; ~Reset() { for (long long k : t) b[(size_t)k] = 1e300; t.clear(); } } reset_{best, touched};
+    auto cell = [&](double x, double y, double yaw) -> long long { const long long k = key(x, y, yaw); return k >= 0 && k < ncell ? k : -1; };
     typedef std::pair<double, int> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> open;
     nodes.push_back({start[0], start[1], wrap(start[2]), 0.0, -1, 0, 0});
-    open.push({heur(start[0], start[1], start[2]), 0}); best[key(start[0], start[1], start[2])] = 0.0;
+    open.push({heur(start[0], start[1], start[2]), 0}); { const long long k = cell(start[0], start[1], start[2]); if (k >= 0) { best[(size_t)k] = 0.0; touched.push_back(k); } }
     long nexp = 0; int found = -1;
     const int sub = std::max(1, (int)std::ceil(step / 0.2));
     const double Rmin = L / std::tan(smax * (analytic > 0 ? std::min(1.0, analytic) : 1.0));
+    std::vector<double> kappa(2 * nst + 1); for (int si = -nst; si <= nst; si++) kappa[si + nst] = std::tan(smax * si / nst) / L;      // curvature of every steering command
     std::vector<double> tail; std::vector<int> taild;     // collision-free Reeds-Shepp connection of node `found` to the exact goal pose
     while (!open.empty() && nexp < maxexp) {
         const QE e = open.top(); open.pop();
         const Node cur = nodes[e.second];
-        { auto it = best.find(key(cur.x, cur.y, cur.yaw)); if (it != best.end() && it->second < cur.g - 1e-9) continue; }
-        if (std::hypot(cur.x - goal[0], cur.y - goal[1]) <= gtol && std::fabs(wrap(cur.yaw - goal[2])) <= ytol) { found = e.second; break; }
+        { const long long k = cell(cur.x, cur.y, cur.yaw); if (k >= 0 && best[(size_t)k] < cur.g - 1e-9) continue; }
+        const double dgoal = std::hypot(cur.x - goal[0], cur.y - goal[1]);
+        if (dgoal <= gtol && std::fabs(wrap(cur.yaw - goal[2])) <= ytol) { found = e.second; break; }
         nexp++;
-        if (analytic > 0 && (std::hypot(cur.x - goal[0], cur.y - goal[1]) < 6.0 * Rmin || nexp % 16 == 0)) {
+        const double sy0 = std::sin(cur.yaw), cy0 = std::cos(cur.yaw);
+        if (analytic > 0 && (dgoal < 6.0 * Rmin || nexp % 16 == 0)) {
             // shortest Reeds-Shepp curve from this node to the goal: if the car can follow it without touching anything, the search is over
-            const double dx = goal[0] - cur.x, dy = goal[1] - cur.y, c = std::cos(cur.yaw), s_ = std::sin(cur.yaw);
+            const double dx = goal[0] - cur.x, dy = goal[1] - cur.y, c = cy0, s_ = sy0;
             const rs::Path p = rs::shortest((c * dx + s_ * dy) / Rmin, (-s_ * dx + c * dy) / Rmin, wrap(goal[2] - cur.yaw));
-            if (p.n > 0) {
-                tail.clear(); taild.clear();
-                double x = 0, y = 0, yaw = 0; bool ok = true;
-                for (int i = 0; i < p.n && ok; i++) {
+            // the walk along it, sampled every <= 0.2 m: nearly every curve hits something within a few samples, so the first pass only tests (heading cos / sin by the
+            // addition theorem from those the walk carries) and the one curve that passes is walked again to record its poses
+            auto walk = [&](bool record) {
+                double x = 0, y = 0, yaw = 0, sy = std::sin(0.0), cy = std::cos(0.0);
+                for (int i = 0; i < p.n; i++) {
                     const double L_ = std::fabs(p.len[i]); if (L_ < 1e-12) continue;
                     const int d = p.len[i] >= 0 ? 1 : -1, m = std::max(1, (int)std::ceil(L_ * Rmin / 0.2));
-                    for (int q = 0; q < m && ok; q++) {
-                        rs::advance(p.type[i], p.len[i] / m, x, y, yaw);
-                        const double wx = cur.x + Rmin * (c * x - s_ * y), wy = cur.y + Rmin * (s_ * x + c * y), wyaw = wrap(cur.yaw + yaw);
-                        ok = !collides(w, wx, wy, wyaw);
-                        tail.insert(tail.end(), {wx, wy, wyaw}); taild.push_back(d);
+                    for (int q = 0; q < m; q++) {
+                        rs::advance_sc(p.type[i], p.len[i] / m, x, y, yaw, sy, cy);
+                        const double wx = cur.x + Rmin * (c * x - s_ * y), wy = cur.y + Rmin * (s_ * x + c * y);
+                        if (record) { tail.insert(tail.end(), {wx, wy, wrap(cur.yaw + yaw)}); taild.push_back(d); }
+                        else if (collides_cs(w, wx, wy, c * cy - s_ * sy, s_ * cy + c * sy)) return false;
                     }
                 }
-                if (ok) { found = e.second; break; }
-                tail.clear(); taild.clear();
-            }
+                return true;
+            };
+            if (p.n > 0 && walk(false)) { tail.clear(); taild.clear(); walk(true); found = e.second; break; }
         }
         for (int d = 1; d >= -1; d -= 2)
             for (int si = -nst; si <= nst; si++) {
-                const double steer = smax * si / nst, kap = std::tan(steer) / L;
-                double x = cur.x, y = cur.y, yaw = cur.yaw; bool ok = true;
+                const double steer = smax * si / nst, kap = kappa[si + nst];
+                double x = cur.x, y = cur.y, yaw = cur.yaw, sy = sy0, cy = cy0; bool ok = true;      // (sy, cy: sin, cos of yaw -- each angle goes to libm once)
                 for (int q = 0; q < sub && ok; q++) {
                     const double ds = d * step / sub;
-                    if (std::fabs(kap) < 1e-9) { x += ds * std::cos(yaw); y += ds * std::sin(yaw); }
-                    else { const double y1 = yaw + ds * kap; x += (std::sin(y1) - std::sin(yaw)) / kap; y += -(std::cos(y1) - std::cos(yaw)) / kap; yaw = y1; }
-                    ok = !collides(w, x, y, yaw);
+                    if (std::fabs(kap) < 1e-9) { x += ds * cy; y += ds * sy; }
+                    else { const double y1 = yaw + ds * kap, s1 = std::sin(y1), c1 = std::cos(y1); x += (s1 - sy) / kap; y += -(c1 - cy) / kap; yaw = y1; sy = s1; cy = c1; }
+                    ok = !collides_cs(w, x, y, cy, sy);
                 }
                 if (!ok) continue;
                 double g = cur.g + step * (d > 0 ? 1.0 : crev) + cst * std::fabs(steer) * step + cchg * std::fabs(steer - smax * cur.steer / nst);
                 if (cur.dir != 0 && cur.dir != d) g += csw;
-                const long long k = key(x, y, yaw);
-                auto it = best.find(k);
-                if (it != best.end() && it->second <= g) continue;
-                best[k] = g;
+                const long long k = cell(x, y, yaw);
+                if (k < 0) continue;                                   // (cannot happen inside XYbounds)
+                if (best[(size_t)k] <= g) continue;
+                if (best[(size_t)k] == 1e300) touched.push_back(k);
+                best[(size_t)k] = g;
                 nodes.push_back({x, y, wrap(yaw), g, e.second, (int8_t)d, (int8_t)si});
                 open.push({g + heur(x, y, yaw), (int)nodes.size() - 1});
             }
@@ -395,7 +469,7 @@ int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, 
     for (int j = 0; j < nOb; j++) w.off[j + 1] = w.off[j] + vOb[j];
     w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
     w.xmin = XYbounds[0]; w.xmax = XYbounds[1]; w.ymin = XYbounds[2]; w.ymax = XYbounds[3];
-    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin;
+    std::memcpy(w.ego, ego, sizeof w.ego); w.margin = margin; w.finish();
     return collides(w, x, y, yaw) ? 1 : 0;
 }
 

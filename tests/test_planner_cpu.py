@@ -32,6 +32,40 @@ def test_collision_test_known_answers():
         PL.hybrid_astar([0.0, 4.0, 0.0], S.PARALLEL["xF"][:3], v, A, b)
 
 
+def _overlap_area2(pose, rows_A, rows_b, ego, margin):
+    """twice the area of (car rectangle inflated by margin) cut by the half-planes rows_A p <= rows_b: the definition of the planner's collision test, in numpy"""
+    x, y, yaw = pose; c, s = np.cos(yaw), np.sin(yaw); f, l, r, rt = (e + margin for e in ego)
+    poly = [(x + f * c - l * s, y + f * s + l * c), (x - r * c - l * s, y - r * s + l * c), (x - r * c + rt * s, y - r * s - rt * c), (x + f * c + rt * s, y + f * s - rt * c)]
+    for (ax, ay), bb in zip(rows_A, rows_b):
+        out = []
+        for i, p in enumerate(poly):
+            q = poly[(i + 1) % len(poly)]; dp = ax * p[0] + ay * p[1] - bb; dq = ax * q[0] + ay * q[1] - bb
+            if dp <= 0:
+                out.append(p)
+            if dp * dq < 0:
+                t = dp / (dp - dq); out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+        poly = out
+        if not poly:
+            return 0.0
+    return abs(sum(p[0] * q[1] - q[0] * p[1] for p, q in zip(poly, poly[1:] + poly[:1]))) if len(poly) >= 3 else 0.0
+
+
+@pytest.mark.parametrize("sc", [S.BACKWARDS, S.PARALLEL], ids=lambda s: s["name"])
+def test_collision_test_equals_its_definition_on_random_poses(sc):
+    """the separating-axis shortcuts of the planner's collision test (a row every corner violates, a car side every obstacle vertex lies beyond, a corner deep inside)
+    must agree with the overlap area that defines it -- bounded and unbounded obstacles, poses concentrated where the car nearly touches"""
+    A, b, v = S.scenario_hrep(sc); A = np.asarray(A, float).reshape(-1, 2); b = np.ravel(b); off = np.concatenate([[0], np.cumsum(v)])
+    rng = np.random.default_rng(11); xy = S.XYBOUNDS; n_hit = 0
+    for k in range(1500):
+        pose = np.array([rng.uniform(xy[0], xy[1]), rng.uniform(xy[2], xy[3]), rng.uniform(-np.pi, np.pi)]); margin = [0.0, 0.02, 0.1][k % 3]
+        area = max(_overlap_area2(pose, A[off[j]:off[j + 1]], b[off[j]:off[j + 1]], S.EGO, margin) for j in range(len(v)))
+        if abs(area - 1e-9) < 1e-10:
+            continue
+        assert PL.collides(pose, v, A, b, margin=margin) == (area > 1e-9), (pose, margin, area)
+        n_hit += area > 1e-9
+    assert n_hit > 200 and n_hit < 1300
+
+
 def test_path_to_warm_start_shapes_and_consistency():
     sc = S.PARALLEL; N = 80
     Ts, xWS, uWS = PL.warm_start(sc, sc["x0"], sc["xF"], N)
