@@ -385,7 +385,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #define QRR_PAD 767                                  // unused slot of the Riccati record: target of dummy stores
 // ---------------------------------------------------------------- Riccati backward sweep on the matrix cores
 // (Round 1 ran the sweep as four LDS / VALU phases: bound by LDS bandwidth, every fp64 FMA of its products read two operands from LDS, 10 k clocks per stage.)  Here the
-// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (27 per stage); the stage record is gathered
+// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (23 per stage); the stage record is gathered
 // from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
 //   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
 //   Register kb of a tile in D layout is the B operand of K-block kb (rows 4 kb .. 4 kb + 3), and the A operand of the TRANSPOSED tile.
@@ -398,8 +398,9 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 //   columns there -- and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww, gradient hc[w]; they are written over register 3 once the u rows are used up.)
 //   Quu = Q0[u rows][u columns]: LDL' (uniform);  every lane solves the gains of its own column (x | w columns and the rhs columns)
 //   P' = Q0(x rows | closed-form w rows) + Q[., u] K    p' = Q1 + Q[., u] Kf    (Q[., u] = transpose of the u rows / the closed-form w rows), P' symmetrised through LDS
-//   border constants  Bm += FXD1' Th1 + pnD' FXD1 + Q1[u rows]' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a and the gain part, all into one accumulator tile)
-//   27 MFMAs per stage (a v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 clocks on gfx950: fp64 matrix rate = fp64 vector rate).
+//   border constants  Bm += FXD1' (Th1 + pnD) + Q1[u rows]' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a -- the last one as its transpose, the tile is symmetrised
+//   at the end -- and the gain part, all into one accumulator tile)
+//   23 MFMAs per stage (a v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 clocks on gfx950: fp64 matrix rate = fp64 vector rate).
 #if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
 #define QSEG(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); seg[i] += (double)(t_ - segt); segt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)      // diagnostic: where a stage of the sweep spends its clocks (prof[12..15])
 #else
@@ -461,10 +462,18 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
     }
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) { wv_mfma(Th0, PD[kb], FXD0[kb]); wv_mfma(Th1, PD[kb], FXD1[kb]); }
+    // static parts of the border constants, FXD1' Th1 + pnD' FXD1 (pnD: still the next stage's p): the second product is the transpose of FXD1' pnD and the accumulator
+    // tile is symmetrised when the sweep ends (sh.Bm = (B + B') / 2), so FXD1' (Th1 + pnD) carries both -- four products per stage instead of eight
+    double Tb[4][OBCA_NLT];
+    PAR64(lane) {
+        const int L_ = LI(lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Tb[r][L_] = Th1[r][L_] + pnD[r][L_];
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
         wv_mfma(Q0, FXD0[kb], Th0[kb]); wv_mfma(Q1, FXD0[kb], Th1[kb]);
-        wv_mfma(BmD, FXD1[kb], Th1[kb]); wv_mfma(BmD, pnD[kb], FXD1[kb]);       // static parts of the border constants (pnD: still the next stage's p)
+        wv_mfma(BmD, FXD1[kb], Tb[kb]);
     }
     QSEG(0);
     // Quu = Q0[u rows][u columns]: lane (a, 12 + b) of register 3

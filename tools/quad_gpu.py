@@ -27,5 +27,5 @@ if pc.sum() > 0:
     for i, n in enumerate(names):
         print("%-12s %5.1f%%   cycles/pass %9.0f" % (n, 100 * pc[:, i].sum() / tot.sum(), (pc[:, i] / passes).mean()))
     if pc[:, 12:16].sum() > 0:       # segments of one stage of the backward sweep (pipelined part), clocks per pass
-        for i, n in enumerate(("ric: operands + 24 MFMA", "ric: Quu readlane + LDL + shuffles", "ric: gains solve + stores", "ric: 3 MFMA + symmetrise P via LDS")):
+        for i, n in enumerate(("ric: operands + 20 MFMA", "ric: Quu readlane + LDL + shuffles", "ric: gains solve + stores", "ric: 3 MFMA + symmetrise P via LDS")):
             print("%-36s cycles/pass %9.0f" % (n, (pc[:, 12 + i] / passes).mean()))
