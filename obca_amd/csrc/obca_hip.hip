@@ -24,13 +24,14 @@
 
 using namespace obca;
 
-static_assert(sizeof(obca_opts) == sizeof(Opts), "obca_opts must mirror obca::Opts");
+static_assert(sizeof(obca_opts) == sizeof(OptsAbi) && offsetof(obca_opts, max_soc) == offsetof(OptsAbi, max_soc), "obca_opts must mirror obca::OptsAbi");
 static_assert(OBCA_QUAD_NMAX == QNMAX, "ABI limits must match the kernels");
 static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == OB_NMAX && OBCA_MMAX == OB_MMAX, "ABI limits must match the kernels");
 
 struct DevBufs {
     double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
     double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
+    double *csoc; size_t s_csoc;                     // second-order correction (opts.max_soc > 0): the corrected right-hand-side rows of every instance; allocated at the first such solve
     int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
     size_t s_prob, s_z, s_as, s_rs, s_oc;   // strides in doubles
 };
@@ -43,7 +44,7 @@ struct DevBufs {
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
 #define OBCA_RESIDENT_PER_CU (4 * OBCA_IPM_WAVES_PER_EU)   // parking instances (one wavefront each) resident per CU
-__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget) {
+__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
     const int inst = mode ? b.order[blockIdx.x] : (int)blockIdx.x;
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.zn = (gdbl *)(b.zn + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
         I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc);
+        g_sh.soc.csoc = b.csoc ? (gdbl *)(b.csoc + (size_t)inst * b.s_csoc) : nullptr;
 #ifdef OBCA_PROFILE
         I.tlast = clock64();
 #endif
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = mode ? b.prof[(size_t)inst * 16 + threadIdx.x] : 0.0;   // counters add up over the slices
 #endif
     __syncthreads();
-    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget);
+    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
@@ -273,6 +275,7 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
+    o->max_soc = 0; o->reserved_ = 0;                  /* IPOPT's default is 4; off here as in the checker the parity tests run against */
     return 0;
 }
 
@@ -349,7 +352,7 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     return 0;
 }
 static void free_dev(obca_batch *bt) {
-    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->stage};
+    double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->d.csoc, &bt->stage};
     for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
     if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
     bt->dcap_stage = 0;
@@ -404,7 +407,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         bt->zlen = lmax.len;
         DevBufs &d = bt->d;
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
-        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC;
+        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_csoc = (size_t)(lmax.zxL - lmax.pi);
         size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = hipMalloc((void **)&(ptr), by_); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.zn, B * d.s_z); ALLOC(d.d, B * d.s_z);
@@ -494,6 +497,12 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
+    if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
+    if (o.max_soc > 0 && !bt->d.csoc) {      // the second-order correction keeps its right-hand-side rows per instance
+        hipError_t e_ = hipMalloc((void **)&bt->d.csoc, (size_t)bt->cap * bt->d.s_csoc * sizeof(double));
+        if (e_ != hipSuccess) { bt->d.csoc = nullptr; bt->err = std::string("hipMalloc(csoc): ") + hipGetErrorString(e_); return -2; }
+        bt->bytes += (long long)((size_t)bt->cap * bt->d.s_csoc * sizeof(double));
+    }
     const DevBufs &d = bt->d;
     HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
     HIPCHK(bt, hipEventRecord(bt->e0, bt->stream));
@@ -515,15 +524,15 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     const int slots = parking_resident_per_cu(bt->N) * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
     bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc);
         HIPCHK(bt, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc);
         HIPCHK(bt, hipGetLastError());
         if (!slice_only) {
             hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
             HIPCHK(bt, hipGetLastError());
-            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0);
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0, o.max_soc);
             HIPCHK(bt, hipGetLastError());
         }
     }

@@ -236,9 +236,11 @@ template <int VM>
 struct ObsStep { double dlam[VM], dmu[4], dsl, dso, dy[4]; };
 
 // MODE 0: condense (fills cond, stats) ; MODE 1: back-substitute for a given pose step dp (fills step)
-template <int MODE, int VM>
+// SOC = 1 (second-order correction, IPOPT A-5.5..A-5.9): the right-hand side takes the four row values from crs (c_soc = alpha c(z) + c(z + alpha d)) instead of
+// the rows at z; the violation statistics keep the true rows.
+template <int MODE, int VM, int SOC = 0>
 OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
-                       const double dp[3], ObsStep<VM> *step) {
+                       const double dp[3], ObsStep<VM> *step, const double *crs = nullptr) {
     const int v = in.v;
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr)
     double p1 = 0, p2 = 0, beta = 0;
@@ -324,7 +326,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double r234[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        double a_ = -cr[r + 1];
+        double a_ = -(SOC ? crs[r + 1] : cr[r + 1]);
 #pragma unroll
         for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] * iDmu[i];
         r234[r] = a_;
@@ -370,7 +372,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + 3];
         rk[i] = i < v ? a_ : 0.0;
     }
-    rk[VM] = -cr[0] + r_sl * iDs1;
+    rk[VM] = -(SOC ? crs[0] : cr[0]) + r_sl * iDs1;
     const double dc1 = dc + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
     // Householder Qh q = alpha e1
     double hw[VM], nq = 0;

@@ -130,6 +130,8 @@ struct Opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
+struct OptsAbi { Opts o; int max_soc, reserved_; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
+                                                          // the default here as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
 struct Lay {
     int x, u, t, lam, mu, sl, so, ss, pi, nu, yg, yo, zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, zs1, nprimal, len;   // zs1: multiplier of the norm-row slack (ParkingDist only)
@@ -179,6 +181,10 @@ struct Drv {                // state of the interior-point driver (wave-uniform;
     double mu, tau, dw, dw_last, dc_mu, dc_val, th_min, th_max, f, pinf, dinf, sd, sc, cm, th, phi, gd, az, pw_th, pw_gd, amin, alpha;
     int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc;
 };
+struct Soc {                // second-order correction (cold path; at the END of Shared: nothing the phases address moves)
+    gdbl *csoc;             // c_soc = alpha c(z) + c(z + alpha d) of the instance, layout pi | nu | yg | yo as in the iterate (null unless max_soc > 0)
+    int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
+};
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
 struct alignas(16) Shared {
@@ -194,6 +200,7 @@ struct alignas(16) Shared {
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     Inst inst; AsmOut A, A2, An, Ap; StepOut S; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
+    Soc soc;
 };
 
 // Dynamic LDS behind `Shared`, sized for the horizon at launch (OB_DYN_LDS_DOUBLES): the closed-loop state trajectory of the forward sweep (s_k = (dx_k, dw_k): the x part of the
@@ -407,7 +414,9 @@ OBCA_FN double zstep(double zz, double dist, double dv, double mu, double az) { 
 #endif
 struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal, equality multipliers, bound multipliers), kappa_sigma, delta_w of the factorisation that gave d
 // part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
-template <int VM, int FUSED>
+// SOC = 1: the system of a second-order correction step -- FUSED = 0: condensation with c_soc on the right-hand side; FUSED = 1: the block steps of the trial are those of
+// the correction direction (recomputed with c_soc), the assembly at the trial point is the ordinary one.
+template <int VM, int FUSED, int SOC = 0>
 OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
@@ -421,6 +430,11 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
+            double crs[4] = {0, 0, 0, 0};
+            if (SOC) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) crs[r] = sh.soc.csoc[(l.yo - l.pi) + 4 * it + r];
+            }
             if (FUSED) {
                 const double dp[3] = {g_traj[(size_t)k * 6], g_traj[(size_t)k * 6 + 1], g_traj[(size_t)k * 6 + 2]};      // pose step of the stage (x_0 is fixed: s_0 = 0)
                 ObsStep<VM> sp;
@@ -432,7 +446,7 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
 #pragma unroll
                     for (int i = 0; i < 4; i++) { sp.dmu[i] = d[l.mu + 4 * it + i]; sp.dy[i] = d[l.yo + 4 * it + i]; }
                     sp.dsl = d[l.sl + it]; sp.dso = d[l.so + it];
-                } else obs_block<1, VM>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp);
+                } else obs_block<1, VM, SOC>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp, crs);
 #pragma unroll
                 for (int i = 0; i < VM; i++) if (i < in.v) {
                     const double v1 = fma(fa.alpha, sp.dlam[i], in.lam[i]), z1 = zstep<RS_>(in.zl[i], in.lam[i], sp.dlam[i], mu, fa.az);
@@ -461,7 +475,7 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
                 SEAM(in.so); SEAM(in.zso); SEAM(in.sl); SEAM(in.zs1); SEAM(in.X); SEAM(in.Y); SEAM(in.psi);
             }
             ObsCond cd;
-            obs_block<0, VM>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            obs_block<0, VM, (SOC && !FUSED) ? 1 : 0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, crs);
             gdbl *o = I.oc + (size_t)it * OB_OC;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
@@ -494,7 +508,7 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
 }
 
 // part (b): one lane per stage; combines with the partial results of part (a)
-template <int FUSED>
+template <int FUSED, int SOC = 0>      // SOC = 1 (with FUSED = 0): steering and dynamics rows enter the right-hand side with c_soc
 OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa, AsmOut &out) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
@@ -651,7 +665,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double rz = -yg + b.gz, rb = -yg + b.gb;
                     dmax = fmax(dmax, fabs(rz));
                     const double res = g - ss; pmax = fmax(pmax, fabs(res)); lth += fabs(res);
-                    const double Dss = b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = res + rb * iDss;
+                    const double Dss = b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = (SOC ? (double)sh.soc.csoc[(l.yg - l.pi) + k] : res) + rb * iDss;
                     rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
                     rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
                     const int id[2] = {4, 6};
@@ -672,7 +686,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
                         for (int j = 0; j < 5; j++) if (as_df(i, j) >= 0) rec[AS_DF + as_df(i, j)] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
                         double r = xn[i] - dy.F[i];
-                        rec[AS_DD + i] = -r; pmax = fmax(pmax, fabs(r)); lth += fabs(r);
+                        rec[AS_DD + i] = SOC ? -(double)sh.soc.csoc[4 * k + i] : -r; pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                         lsy += fabs(pi[i]);
                     }
                     const int id[4] = {2, 3, 6, 7};
@@ -987,6 +1001,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     return ok;
 }
 
+template <int SOC = 0>      // SOC = 1: the terminal row enters with c_soc
 OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
@@ -1007,7 +1022,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
             sh.Pn[lane] = v;
         }
         if (lane < 6) {
-            double e = lane < 4 ? -(z[l.x + 4 * N + lane] - c.xF[lane]) : 0.0;
+            double e = lane < 4 ? (SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + lane] : -(z[l.x + 4 * N + lane] - c.xF[lane])) : 0.0;
             sh.pn[0 * 6 + lane] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);      // (p is kept transposed: pn[c * 6 + a])
             sh.pn[1 * 6 + lane] = lane >= 2 ? rec[AS_HT + lane - 2] : 0.0;
             for (int cc = 0; cc < 4; cc++) sh.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
@@ -1093,8 +1108,9 @@ OBCA_FN void wv_shfl_group(double (&out)[1], const double (&in)[1], int grp) { o
 OBCA_FN void wv_shfl_xor(double (&out)[1], const double (&in)[1], int m) { out[0] = __shfl_xor(in[0], m, 64); }
 #endif
 
+template <int SOC = 0>
 OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
-    const int ok = riccati_body(I, sh, rho);
+    const int ok = riccati_body<SOC>(I, sh, rho);
     PAR(lane) { if (lane == 0) sh.ric_ok = ok; }
     SYNC();
     return sh.ric_ok;
@@ -1103,6 +1119,7 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
 // ---------------------------------------------------------------- border solve + forward sweep + back-substitution
 
 // part 1: border, closed loop, forward sweep, stage-parallel back-substitution; leaves partial (ap, az, gd) and (dt, nu) in LDS
+template <int SOC = 0>      // SOC = 1: the terminal row enters with c_soc
 OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
@@ -1112,7 +1129,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     {
         const double *B = sh.Bm;
         double e[4];
-        for (int i = 0; i < 4; i++) e[i] = -(z[l.x + 4 * N + i] - c.xF[i]);
+        for (int i = 0; i < 4; i++) e[i] = SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + i] : -(z[l.x + 4 * N + i] - c.xF[i]);
         double att = A.Htt + B[1 * 6 + 1], rt = -A.gtb - B[1 * 6 + 0];
         double S[16], col[4], colr[4];
         for (int a_ = 0; a_ < 4; a_++) {
@@ -1277,7 +1294,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 const gdbl *rN = I.as + (size_t)N * OB_AS;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    double e = -(z[l.x + 4 * N + i] - c.xF[i]);
+                    double e = SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + i] : -(z[l.x + 4 * N + i] - c.xF[i]);
                     double a_ = (rN[AS_HB + i] - rho * e) + (i >= 2 ? rN[AS_HT + i - 2] : 0.0) * dt + nu[i];
 #pragma unroll
                     for (int j = 0; j < 6; j++) a_ += ((as_h(i, j) >= 0 ? rN[AS_H + as_h(i, j)] : 0.0) + ((i == j) ? rho : 0.0)) * sn[j];
@@ -1337,7 +1354,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 }
 
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
-template <int VM, int DBG>      // DBG = 1 (host emulation tests only): the obstacle part of the direction is also written to d
+template <int VM, int DBG, int SOC = 0>      // DBG = 1 (host emulation tests only): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
 OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
@@ -1355,7 +1372,12 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             const double dp[3] = {g_traj[(size_t)k * 6], g_traj[(size_t)k * 6 + 1], g_traj[(size_t)k * 6 + 2]};
             ObsStep<VM> st;
-            obs_block<1, VM>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
+            double crs[4] = {0, 0, 0, 0};
+            if (SOC) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) crs[r] = sh.soc.csoc[(l.yo - l.pi) + 4 * it + r];
+            }
+            obs_block<1, VM, SOC>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, crs);
             const int r0 = sh.roff[j];
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
@@ -1496,6 +1518,60 @@ OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double ta
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
 }
+// ---- second-order correction (IPOPT A-5.5..A-5.9; Opts::max_soc > 0; cold path: one non-inlined function per step, every obstacle width inside)
+// c_soc <- asoc * (first ? c(z) : c_soc) + c(zn)   (zn: the rejected trial point; rows as the assembly forms them: dynamics x_{k+1} - F, terminal x_N - xF, steering, obstacle rows)
+template <int VM>
+OBCA_FN void soc_accumulate(const Inst &I, Shared &sh, double asoc, int first) {
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb; gdbl *cs = sh.soc.csoc;
+    PAR(lane) {
+        for (int k = lane; k < N; k += OB_NT) {
+            double v[2][5];
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const gdbl *z = w ? I.zn : I.z; const double t = z[l.t];
+                double x[4], u[2], F[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = z[l.x + 4 * k + i];
+                u[0] = z[l.u + 2 * k]; u[1] = z[l.u + 2 * k + 1];
+                dyn_value(c, x, u, t, F);
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[w][i] = z[l.x + 4 * (k + 1) + i] - F[i];
+                v[w][4] = ((k ? z[l.u + 2 * k - 2] : 0.0) - u[0]) / (t * c.Ts) - z[l.ss + k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) cs[4 * k + i] = asoc * (first ? v[0][i] : (double)cs[4 * k + i]) + v[1][i];
+            cs[(l.yg - l.pi) + k] = asoc * (first ? v[0][4] : (double)cs[(l.yg - l.pi) + k]) + v[1][4];
+        }
+        if (lane < 4) { const int o_ = (l.nu - l.pi) + lane; cs[o_] = asoc * (first ? I.z[l.x + 4 * N + lane] - c.xF[lane] : (double)cs[o_]) + (I.zn[l.x + 4 * N + lane] - c.xF[lane]); }
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
+            const int k = it / nOb, j = it - k * nOb; double r0[4], r1[4];
+            { ObsIn<VM> in; load_obs<VM>(I, sh, I.z, k, j, in); obs_rows<VM>(c, in, r0); }
+            { ObsIn<VM> in; load_obs<VM>(I, sh, I.zn, k, j, in); obs_rows<VM>(c, in, r1); }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int o_ = (l.yo - l.pi) + 4 * it + r; cs[o_] = asoc * (first ? r0[r] : (double)cs[o_]) + r1[r]; }
+        }
+    }
+    SYNC();
+}
+OBCA_PHASE void ph_soc_accumulate(double asoc, int first) { Shared &sh = g_sh; VM_CALL(soc_accumulate, sh.inst, sh, asoc, first); }
+OBCA_PHASE void ph_soc_assemble(double mu, double dw, double dc) {      // the system at z with c_soc on the right-hand side (sh.A keeps the values of the iterate: f, theta, errors use the true rows)
+    Shared &sh = g_sh;
+    if (sh.vmc == 0) assemble_obs<2, 0, 1>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0, 1>(sh.inst, sh, mu, dw, dc, OB_NOFUSE); else assemble_obs<OB_VMAX, 0, 1>(sh.inst, sh, mu, dw, dc, OB_NOFUSE);
+    assemble_stage<0, 1>(sh.inst, sh, mu, dw, dc, OB_NOFUSE, sh.A);
+}
+OBCA_PHASE int ph_soc_riccati(double rho) { Shared &sh = g_sh; return riccati_backward<1>(sh.inst, sh, rho); }
+OBCA_PHASE void ph_soc_direction(double mu, double dw, double dc, double rho, double tau) {
+    Shared &sh = g_sh;
+    direction_main<1>(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
+    if (!sh.S.ok) return;
+    if (sh.vmc == 0) direction_obs<2, 0, 1>(sh.inst, sh, mu, dw, dc, tau, sh.S); else if (sh.vmc == 1) direction_obs<OB_VMID, 0, 1>(sh.inst, sh, mu, dw, dc, tau, sh.S); else direction_obs<OB_VMAX, 0, 1>(sh.inst, sh, mu, dw, dc, tau, sh.S);
+}
+OBCA_PHASE void ph_soc_fused(double mu, double dc, double alpha, double ay, double az, double ks, double dwd) {      // trial point along the correction direction, assembled there as usual
+    Shared &sh = g_sh; const FuseArgs fa = {alpha, ay, az, ks, dwd};
+    if (sh.vmc == 0) assemble_obs<2, 1, 1>(sh.inst, sh, mu, 0.0, dc, fa); else if (sh.vmc == 1) assemble_obs<OB_VMID, 1, 1>(sh.inst, sh, mu, 0.0, dc, fa); else assemble_obs<OB_VMAX, 1, 1>(sh.inst, sh, mu, 0.0, dc, fa);
+    assemble_stage<1>(sh.inst, sh, mu, 0.0, dc, fa, sh.An);
+}
+
 // the iterate the solve ends with (or is parked at) must sit in the instance's own buffer `home`: copy it over if the last accepted trial left it in the other one
 OBCA_PHASE void ph_bring_home() {
     Shared &sh = g_sh; Inst &I = sh.inst;
@@ -1567,10 +1643,58 @@ OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 
 // kept: the state in registers between the calls and copied to / from LDS around each call -- the register allocator then spills MORE, 277 scratch stores / 571
 // loads in the kernel body against 96 / 279.)
 #define PH(call) call
+// Second-order correction after the FIRST trial step of an iteration was rejected without reducing theta (IPOPT A-5.5..A-5.9, kappa_soc = 0.99): up to max_soc steps that
+// solve the system of the iterate again with c_soc = alpha c(z) + c(trial) on the right-hand side, each tested like a trial step (with the ORIGINAL alpha in the switching and
+// Armijo conditions).  1 = accepted: the trial buffer holds z + asoc d_soc with its assembly, D.alpha / D.az are those of the correction.  0: the Newton direction of the
+// iteration is rebuilt (the correction overwrote it) and the backtracking goes on.  The phases are fused (factorise + solve), so a correction costs a full pass.
+OBCA_PHASE int ph_soc_try(double tht_first) {
+    Shared &sh = g_sh; Drv &D = sh.drv; const Opts &o = sh.o; gdbl *const st = sh.sol.sl.st;
+    const double alpha = D.alpha, th = D.th, phi = D.phi, gd = D.gd;
+    double th_old = 0, th_tr = tht_first, asoc = alpha, azs = D.az; int acc = 0;
+    for (int ps = 0; ps < sh.soc.max_soc && !acc && (ps == 0 || th_tr <= 0.99 * th_old); ps++) {
+        th_old = th_tr;
+        ph_soc_accumulate(asoc, ps == 0);
+        ph_soc_assemble(D.mu, D.dw, D.dc_val);
+        int a_ = sh.A.ok;
+        if (a_) a_ = ph_soc_riccati(o.rho_term);
+        if (a_) { ph_soc_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau); a_ = sh.S.ok; }
+        if (!a_) break;
+        asoc = sh.S.ap; azs = sh.S.az;
+        ph_soc_fused(D.mu, D.dc_val, asoc, fmin(asoc, azs), azs, o.kappa_sigma, D.dw);
+        sh.soc.nsoc++;
+        const double ft = sh.An.f, tht = sh.An.th1, pht = ft - D.mu * sh.An.bar;
+        if (!(ft == ft && tht == tht)) break;
+        th_tr = tht;
+        if (pht == pht && tht < D.th_max) {
+            int okf = 1; const int nf = D.nf;
+            for (int i = 0; i < nf && okf; i++) if (!(tht < filt_get(sh, st, i, 0) || pht < filt_get(sh, st, i, 1))) okf = 0;
+            if (okf) {
+                const int sw = gd < 0 && alpha * D.pw_gd > o.delta * D.pw_th;
+                const int armijo = pht <= phi + o.eta_phi * alpha * gd;
+                if (th <= D.th_min && sw) { if (armijo) acc = 1; }
+                else if (tht <= (1 - o.gamma_theta) * th || pht <= phi - o.gamma_phi * th) {
+                    acc = 1;
+                    if (!(sw && armijo) && nf < OB_FILT) {
+                        PAR(lane) { if (lane == 0) { const double f0 = (1 - o.gamma_theta) * th, f1 = phi - o.gamma_phi * th;
+                                                     if (nf < OB_FILT_LDS) { sh.filt[nf][0] = f0; sh.filt[nf][1] = f1; } else { st[SL_FILT + 2 * nf] = f0; st[SL_FILT + 2 * nf + 1] = f1; } } }
+                        SYNC();
+                        D.nf = nf + 1;
+                    }
+                }
+            }
+        }
+    }
+    if (acc) { D.alpha = asoc; D.az = azs; sh.soc.nsoc_acc++; return 1; }
+    // not accepted: the records and d hold a correction system -- rebuild the Newton system and direction of this iteration (same point, same delta_w: the same numbers)
+    ph_assemble(D.mu, D.dw, D.dc_val, 0);
+    if (sh.A.ok && ph_riccati(o.rho_term)) ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau);
+    return 0;
+}
 OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh; Drv &D = sh.drv;
     gdbl *const st = sl.st;
     const AsmOut &A = sh.A;
+    sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0;
     D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
     if (sl.resume) {
         D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN]; D.th_max = st[SL_THMAX];
@@ -1670,6 +1794,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
                     }
                 }
             }
+            if (sh.soc.max_soc > 0 && alpha == sh.S.ap && ft == ft && tht == tht && tht >= th) {      // second-order correction: first trial step only (alpha is still the full step sh.S.ap), and only if it did not reduce theta
+                if (ph_soc_try(tht)) { D.acc = 1; break; }
+            }
             D.alpha = 0.5 * alpha;
         }
         if (!D.acc) { D.status = ST_ERROR; break; }   // IPOPT would enter restoration here
@@ -1687,11 +1814,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
 // Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
 // solve was parked; the iterate buffer then holds the point to continue from).
-OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0) {
+OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
-        if (lane == 0) sh.o = o_arg;
+        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; }      // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
     }
     SYNC();
     PAR(lane) {

@@ -11,17 +11,17 @@
 #include "../../obca_amd/csrc/obca_quad_solver.h"
 using namespace obca;
 
-struct Scratch { double *z, *zn, *d, *as, *rs, *oc; };
+struct Scratch { double *z, *zn, *d, *as, *rs, *oc, *csoc; };
 static void alloc_scratch(int N, int len, Scratch &s) {
     s.z = (double *)calloc(len, 8); s.zn = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
     s.as = (double *)calloc((size_t)(N + 1) * OB_AS, 8); s.rs = (double *)calloc((size_t)(N + 1) * OB_RS, 8);
-    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8);
+    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.csoc = (double *)calloc(len, 8);      // (c_soc: the equality rows, fewer than len)
 }
-static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); }
+static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.csoc); }
 
 static void setup(int N, const double *prob, Scratch &s) {
     Shared &sh = g_sh; Inst &I = sh.inst;
-    I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
+    I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; g_sh.soc.csoc = s.csoc;
     for (int i = 0; i < OB_HDR; i++) sh.hdr[i] = prob[i];
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
@@ -38,7 +38,8 @@ static void setup(int N, const double *prob, Scratch &s) {
 }
 
 extern "C" {
-int emu_opts_size() { return (int)sizeof(Opts); }
+int emu_opts_size() { return (int)sizeof(OptsAbi); }
+int emu_last_soc(int *accepted) { if (accepted) *accepted = g_sh.soc.nsoc_acc; return g_sh.soc.nsoc; }      // second-order corrections of the last attempt of the last solve
 
 // one Newton direction at a full primal-dual point (oracle layout); returns inertia-ok.  alpha >= 0: the fused line-search step is run as well --
 // znext = the trial point z + alpha d with the new multipliers (ay = min(alpha, az)), aux[10..15] = f, th1, bar, dinf, pinf, cinf0 of ITS assembly
@@ -81,9 +82,9 @@ int emu_newton_fused(int N, const double *prob, const double *zin, int len, doub
 int emu_solve(int N, const double *prob, const double *zinit, int len, const void *opts, double *zout, double *info) {
     Scratch s; alloc_scratch(N, len, s);
     memcpy(s.z, zinit, sizeof(double) * len);
-    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
+    Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; g_sh.soc.csoc = s.csoc;
     double *st = (double *)calloc(SL_SIZE, 8);
-    solve_instance(N, *(const Opts *)opts, info, st);
+    solve_instance(N, ((const OptsAbi *)opts)->o, info, st, 0, 0, ((const OptsAbi *)opts)->max_soc);
     free(st);
     memcpy(zout, s.z, sizeof(double) * len);
     free_scratch(s);
@@ -98,8 +99,8 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     int launches = 0;
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
-        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc;
-        solve_instance(N, *(const Opts *)opts, info, st, mode, budget);
+        Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; g_sh.soc.csoc = s.csoc;
+        solve_instance(N, ((const OptsAbi *)opts)->o, info, st, mode, budget, ((const OptsAbi *)opts)->max_soc);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
     }

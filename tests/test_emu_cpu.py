@@ -8,11 +8,20 @@ D = C.POINTER(C.c_double)
 dp = lambda a: a.ctypes.data_as(D)
 
 
-class EOpts(C.Structure):
+class EOpts(C.Structure):      # obca::Opts (obca_solver.h); every field but the padding exists under the same name in the oracle's option record
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int)] + \
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
-                                   "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()]
+                                   "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
+        [("max_soc", C.c_int), ("reserved_", C.c_int)]
+
+
+def copy_opts(oo):
+    eo = EOpts()
+    for n, _ in EOpts._fields_:
+        if n != "reserved_":
+            setattr(eo, n, getattr(oo, n))
+    return eo
 
 
 def test_layouts_agree(oracle):
@@ -78,9 +87,7 @@ def test_emu_full_solve_matches_oracle(oracle, emu, backwards, dist, N):
     B = 3 if N <= 21 else 1
     bt = S.make_batch(S.BACKWARDS, B, N)
     v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
-    oo = oracle.default_opts(); eo = EOpts()
-    for n, _ in EOpts._fields_:
-        setattr(eo, n, getattr(oo, n))
+    oo = oracle.default_opts(); eo = copy_opts(oo)
     assert emu.emu_opts_size() == C.sizeof(eo)
     for i in range(B):
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
@@ -123,9 +130,7 @@ def test_emu_exit_flag_after_failed_attempts_follows_the_reference(oracle, emu, 
     before the retry and INVERTS it afterwards (infeasible -> exitflag 1, ParkingDist.jl:277-282) -- reproduced, not fixed"""
     N = 20; bt = S.make_batch(S.BACKWARDS, 1, N)
     v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
-    oo = oracle.default_opts(); oo.max_iter = 3; eo = EOpts()
-    for n, _ in EOpts._fields_:
-        setattr(eo, n, getattr(oo, n))
+    oo = oracle.default_opts(); oo.max_iter = 3; eo = copy_opts(oo)
     xWS = bt["xWS"][0].copy(); xWS[0] = bt["x0"][0]
     lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
     r = oracle.parking_signed_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
@@ -156,9 +161,7 @@ def test_emu_sliced_solve_is_bit_identical(oracle, emu, backwards, budget, max_i
     exactly the same iterates as an uninterrupted solve -- also when the cut falls into the second attempt (max_iter small forces the retry)"""
     N = 20; bt = S.make_batch(S.BACKWARDS, 2, N)
     v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
-    oo = oracle.default_opts(); oo.max_iter = max_iter; eo = EOpts()
-    for n, _ in EOpts._fields_:
-        setattr(eo, n, getattr(oo, n))
+    oo = oracle.default_opts(); oo.max_iter = max_iter; eo = copy_opts(oo)
     for i in range(2):
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
         lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
@@ -178,9 +181,7 @@ def test_emu_wide_obstacles_match_oracle(oracle, emu):
     (stage, obstacle) block code against the oracle -- Newton direction sizes, DualMultWS and the full solve"""
     N = 16
     bt = S.make_mixed_batch(6, N, seed=11, rows=(5, 8), max_extra=4)
-    oo = oracle.default_opts(); eo = EOpts()
-    for n, _ in EOpts._fields_:
-        setattr(eo, n, getattr(oo, n))
+    oo = oracle.default_opts(); eo = copy_opts(oo)
     done = 0
     for i in range(6):
         v = np.asarray(bt["vOb"][i]); A = bt["A"][i]; b = bt["b"][i]
@@ -229,3 +230,24 @@ def test_emu_rows_of_any_length_give_the_same_solve(oracle, emu):
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"] * s[:, None], bt["b"] * s,
                                        xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
         assert r["iters"] == o1["iters"][i] and np.abs(r["xp"] - o1["xp"][i]).max() < 1e-7 and np.abs(r["lp"] - o1["lp"][i]).max() < 1e-5 * max(1.0, np.abs(r["lp"]).max())
+
+
+def test_second_order_correction_in_the_kernels_follows_the_oracle(oracle):
+    """obca_opts.max_soc > 0 (IPOPT's second-order correction, A-5.5..A-5.9): the kernels' correction steps -- c_soc accumulated from the iterate and the rejected trial, the
+    system of the iterate re-assembled with it, the trial along the correction direction, the Newton direction rebuilt when no correction is accepted -- against the
+    oracle's max_soc option on config-3 instances: the same iterations (corrections change the count on some of them), the same optimum."""
+    import emu_solver as E
+    bt = S.make_batch(S.PARALLEL, 12, 80, seed=20260925, goal_jitter=True)
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    base, soc = oracle.default_opts(), oracle.default_opts(); soc.max_soc = 4
+    changed = tried = 0
+    for i in (0, 1, 5, 8, 10, 11):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        a = (bt["x0"][i], bt["xF"][i], 80, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r0 = oracle.parking_signed_dist(*a, opts=base); r1 = oracle.parking_signed_dist(*a, opts=soc)
+        e = E.parking_signed_dist_batch(bt["x0"][i:i + 1], bt["xF"][i:i + 1], 80, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[None, :, 0], xWS[None, :, 1],
+                                        xWS[None, :, 2], 0, xWS[None], bt["uWS"][i:i + 1], max_soc=4)
+        assert e["exitflag"][0] == r1["exitflag"] == 1 and e["iters"][0] == r1["iters"]
+        assert np.abs(e["xp"][0] - r1["xp"]).max() < 1e-8 and abs(e["obj"][0] - r1["obj"]) < 1e-9 * abs(r1["obj"])
+        changed += r0["iters"] != r1["iters"]; tried += e["nsoc"][0, 0] > 0
+    assert changed >= 3 and tried >= 5

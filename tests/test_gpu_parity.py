@@ -97,6 +97,27 @@ def test_parking_matches_golden_fixture(OA):
     assert np.abs(out["obj"] - g["obj"]).max() < 1e-7
 
 
+def test_second_order_correction_matches_the_oracle_option(OA, oracle):
+    """obca_opts.max_soc = 4 (IPOPT's default second-order correction; off by default here): 64 config-3 instances through the C ABI against the oracle with the same
+    option -- exit flags, iteration counts (the corrections change them on about a third of the instances), trajectories."""
+    N, B = 80, 64
+    bt = S.make_batch(S.PARALLEL, B, N, seed=20260925, goal_jitter=True)
+    o = OA.default_opts(); o.max_soc = 4
+    out, xWS = _solve_batch(OA, bt, opts=o)
+    base, xW0 = _solve_batch(OA, bt)
+    oo = oracle.default_opts(); oo.max_soc = 4
+    changed = 0
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                       bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i], opts=oo)
+        assert out["exitflag"][i] == r["exitflag"] == 1 and out["iters"][i] == r["iters"], (i, out["iters"][i], r["iters"])
+        assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and abs(out["obj"][i] - r["obj"]) < TOL_F * abs(r["obj"])
+        changed += out["iters"][i] != base["iters"][i]
+    assert changed >= 8                                             # the option does something
+    with pytest.raises(OA.ObcaError):
+        o.max_soc = 99; _solve_batch(OA, bt, opts=o)
+
+
 def test_parking_matches_oracle_config3_parallel(OA, oracle):
     """BASELINE config 3: parallel parking, 4 obstacles / 6 half-space rows, Hybrid A* warm starts (golden fixture + a fresh batch)"""
     import checkers as K
