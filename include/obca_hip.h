@@ -36,15 +36,17 @@ typedef struct obca_batch obca_batch;
 
 /* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults.
  * What the solver behind them is: IPOPT's Algorithm A (monotone barrier, filter line search, inertia-correction ladder, alpha_for_y = min) on a structured KKT solve.
- * IPOPT's second-order correction (A-5.5..A-5.9 of Waechter & Biegler, max_soc trials with kappa_soc = 0.99 after a rejected first trial step that did not reduce
- * the constraint violation) is in the parking kernels behind `max_soc` (0 = off, the default, as in the CPU checker the parity tests run against; IPOPT's own default
- * is 4): with it on, the kernels follow the checker's max_soc option iteration for iteration (tests/test_gpu_parity.py, tests/test_emu_cpu.py).
- * IPOPT semantics the reference relies on that the kernels do NOT have: recalc_y = "yes" (:41), a general restoration phase (the quadcopter kernel has a block
- * restoration), least-squares initial multipliers, kappa_d damping, gradient-based NLP scaling (half-space rows enter with unit length instead).  recalc_y exists as an
- * option of the CPU checker (oracle/obca_oracle.c); on the full bench batches of BASELINE configs 2, 3 and 5 (1 024 + 2 048 + 4 096 instances) the kernels' results and
- * the checker's WITH the correction and recalc_y switched on have identical exit flags -- every instance is solved either way -- while 70 / 711 / 220 iteration counts
- * differ and, the NLP being non-convex, 0 / a handful / a few instances end in another local solution (profiles/r03_census_soc_recalc_y.txt,
- * tools/parity_census.py --ipopt-options).  DESIGN.md section 2. */
+ * Two IPOPT semantics the reference relies on are switches of the parking kernels, both off by default (as in the CPU checker the parity tests run against):
+ *   max_soc  -- the second-order correction (A-5.5..A-5.9 of Waechter & Biegler: up to max_soc corrections with kappa_soc = 0.99 after a rejected first trial step that
+ *               did not reduce the constraint violation; IPOPT's own default is 4);
+ *   recalc_y -- recalc_y = "yes" (ParkingSignedDist.jl:41): the equality multipliers are replaced by their least-squares estimate (the structured solve with H := I)
+ *               whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6.
+ * With either on, the kernels follow the checker's option of the same name iteration for iteration (tests/test_gpu_parity.py, tests/test_emu_cpu.py).
+ * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), least-squares INITIAL multipliers, kappa_d damping, gradient-based NLP
+ * scaling (half-space rows enter with unit length instead).  On the full bench batches of BASELINE configs 2, 3 and 5 (1 024 + 2 048 + 4 096 instances) the kernels'
+ * default results and the checker's WITH the correction and recalc_y switched on have identical exit flags -- every instance is solved either way -- while
+ * 70 / 711 / 220 iteration counts differ and, the NLP being non-convex, 0 / a handful / a few instances end in another local solution
+ * (profiles/r03_census_soc_recalc_y.txt, tools/parity_census.py --ipopt-options).  DESIGN.md section 2. */
 typedef struct obca_opts {
     double tol; int max_iter;
     double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
@@ -52,7 +54,8 @@ typedef struct obca_opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
     int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off, the default of obca_default_opts; parking kernels only */
-    int reserved_;    /* 0 */
+    int recalc_y;     /* 1: recalc_y = "yes" as the reference sets it (ParkingSignedDist.jl:41; recalc_y_feas_tol 1e-6): least-squares equality multipliers whenever the
+                         iterate's constraint violation is below 1e-6; 0 = off, the default of obca_default_opts; parking kernels only */
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);

@@ -48,13 +48,35 @@ lasterr(c) = unsafe_string(ccall((:obca_last_error, LIB), Cstring, (Ptr{Cvoid},)
 f64(a) = convert(Array{Float64}, a)
 
 """
+Interior-point options: the record `obca_opts` of include/obca_hip.h, field for field.  `default_opts()` = the reference's IPOPT call (ParkingSignedDist.jl:41-43) with the two
+IPOPT semantics the kernels carry as switches OFF; `ipopt_opts()` switches them on as the reference's IPOPT has them (second-order correction: IPOPT's default max_soc = 4;
+recalc_y = "yes": ParkingSignedDist.jl:41).  Pass as the keyword `opts` of the batched parking calls; `nothing` = the library's defaults.
+"""
+mutable struct Opts
+    tol::Cdouble; max_iter::Cint
+    mu_init::Cdouble; kappa_eps::Cdouble; kappa_mu::Cdouble; theta_mu::Cdouble; tau_min::Cdouble; bound_push::Cdouble; bound_frac::Cdouble
+    dw_min::Cdouble; dw0::Cdouble; dw_max::Cdouble; kw_inc0::Cdouble; kw_inc::Cdouble; kw_dec::Cdouble; dc_bar::Cdouble; kappa_c::Cdouble
+    gamma_theta::Cdouble; gamma_phi::Cdouble; delta::Cdouble; s_theta::Cdouble; s_phi::Cdouble; eta_phi::Cdouble; gamma_alpha::Cdouble; s_max::Cdouble; kappa_sigma::Cdouble
+    constr_viol_tol::Cdouble; dual_inf_tol::Cdouble; compl_inf_tol::Cdouble; rho_term::Cdouble
+    max_soc::Cint; recalc_y::Cint
+    Opts() = new()
+end
+function default_opts()
+    o = Opts()
+    ccall((:obca_default_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_default_opts failed")
+    return o
+end
+ipopt_opts() = (o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o)
+optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
+
+"""
     ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
 
 Batched form: x0, xF are 4xB; rx, ry, ryaw (N+1)xB; xWS 4x(N+1)xB (already transposed to the x layout); uWS 2xNxB; Ts a vector of
 length B; the obstacle set (nOb, vOb, A (Mx2), b) is shared by the batch.  Returns (xp 4x(N+1)xB, up 2xNxB, timeScale (N+1)xB,
 exitflag B, time, lp Mx(N+1)xB, np 4nObx(N+1)xB).
 """
-function ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
+function ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS; opts=nothing)
     B = size(x0, 2); M = sum(vOb)
     nObs = fill(Cint(nOb), B); vflat = repeat(Cint.(vec(vOb)), B)
     At = repeat(vec(permutedims(f64(A))), B)         # row k of A as (A[k,1], A[k,2]), per instance
@@ -62,14 +84,14 @@ function ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b
     xp = zeros(4, N + 1, B); up = zeros(2, N, B); ts = zeros(N + 1, B); ef = zeros(Cint, B)
     lp = zeros(M, N + 1, B); np = zeros(4nOb, N + 1, B); info = zeros(8, B)
     t0 = time()
-    rc = ccall((:obca_parking_signed_dist_batch, LIB), Cint,
+    rc = GC.@preserve opts ccall((:obca_parking_signed_dist_batch, LIB), Cint,
                (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
                 Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble},
                 Ptr{Cdouble}, Ptr{Cdouble}),
                ctx().h, B, N, f64(vec(Ts)), L, f64(vec(ego)), f64(vec(XYbounds)), fixTime, f64(x0), f64(xF), nObs, vflat, At, bt,
                f64(rx), f64(ry), f64(ryaw), f64(xWS), f64(uWS), C_NULL, C_NULL,   # lWS = nWS = NULL: DualMultWS runs on the GPU
-               C_NULL, xp, up, ts, ef, lp, np, C_NULL, info)
+               optsptr(opts), xp, up, ts, ef, lp, np, C_NULL, info)
     rc == 0 || error("obca_parking_signed_dist_batch failed: " * lasterr(ctx()))
     return xp, up, ts, ef, time() - t0, lp, np
 end

@@ -238,7 +238,9 @@ struct ObsStep { double dlam[VM], dmu[4], dsl, dso, dy[4]; };
 // MODE 0: condense (fills cond, stats) ; MODE 1: back-substitute for a given pose step dp (fills step)
 // SOC = 1 (second-order correction, IPOPT A-5.5..A-5.9): the right-hand side takes the four row values from crs (c_soc = alpha c(z) + c(z + alpha d)) instead of
 // the rows at z; the violation statistics keep the true rows.
-template <int MODE, int VM, int SOC = 0>
+// LSQ = 1 (least-squares multipliers, IPOPT recalc_y / eq. (36) of Waechter & Biegler): Hessian := identity on every variable of the block, no second derivatives, no
+// regularisation, zero constraint right-hand side, stationarity residuals in their z-form (bound multipliers instead of mu / distance); call with mu_b = dw = dc = 0.
+template <int MODE, int VM, int SOC = 0, int LSQ = 0>
 OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
                        const double dp[3], ObsStep<VM> *step, const double *crs = nullptr) {
     const int v = in.v;
@@ -276,14 +278,15 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     // sl: the free penetration slack of ParkingSignedDist (cost 1e2 sl + 1e4 sl^2, enters row 4) or, in the ParkingDist formulation,
     // the slack s1 >= 0 of the norm row 1 (no cost, barrier, multiplier zs1); either way a diagonal pivot
     const double isl = c.dist ? rcp_nr<RS_>(in.sl) : 0.0;
-    const double iDso = rcp_nr<RS_>(in.zso * iso + dw), iDsl = rcp_nr<RS_>((c.dist ? in.zs1 * isl : 2e4) + dw);
+    const double iDso = LSQ ? 1.0 : rcp_nr<RS_>(in.zso * iso + dw), iDsl = LSQ ? 1.0 : rcp_nr<RS_>((c.dist ? in.zs1 * isl : 2e4) + dw);
     const double iDs4 = c.dist ? 0.0 : iDsl, iDs1 = c.dist ? iDsl : 0.0;          // where the pivot lands: row 4 or row 1
-    double r_so = -y[3] - mu_b * iso, r_sl = c.dist ? y[0] - mu_b * isl : 1e2 + 2e4 * in.sl + y[3];
+    double r_so = LSQ ? -y[3] - in.zso : -y[3] - mu_b * iso, r_sl = c.dist ? (LSQ ? y[0] - in.zs1 : y[0] - mu_b * isl) : 1e2 + 2e4 * in.sl + y[3];
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
-        { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
+        if (LSQ) { r_mu[i] = jy - in.zm[i]; iDmu[i] = 1.0; }
+        else { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); st->dmax = fmax(st->dmax, rz);
             double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -294,7 +297,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     for (int i = 0; i < VM; i++) {
         if (i < v) {
             double jy = Jl[0][i] * y[0] + Jl[1][i] * y[1] + Jl[2][i] * y[2] + Jl[3][i] * y[3];
-            { const double il = rcp_nr<RS_>(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
+            if (LSQ) { r_lam[i] = jy - in.zl[i]; Dlam[i] = 1.0; }
+            else { const double il = rcp_nr<RS_>(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); st->dmax = fmax(st->dmax, rz);
                 double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -326,7 +330,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double r234[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        double a_ = -(SOC ? crs[r + 1] : cr[r + 1]);
+        double a_ = LSQ ? 0.0 : -(SOC ? crs[r + 1] : cr[r + 1]);
 #pragma unroll
         for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] * iDmu[i];
         r234[r] = a_;
@@ -352,14 +356,14 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
 #pragma unroll
         for (int m = 0; m < VM; m++) {
             double b1 = m < v ? in.a1[m] : 0.0, b2 = m < v ? in.a2[m] : 0.0;
-            double a_ = y[0] * 2 * (a1 * b1 + a2 * b2);
+            double a_ = LSQ ? 0.0 : y[0] * 2 * (a1 * b1 + a2 * b2);
 #pragma unroll
             for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][m];
             Kb[i * VM + m] = a_;
         }
         Kb[i * VM + i] += Dlam[i];
-        const double Hlp[3] = {y[3] * a1, y[3] * a2,
-                               y[1] * (-sn * a1 + cs * a2) + y[2] * (-cs * a1 - sn * a2) + y[3] * off * (-sn * a1 + cs * a2)};
+        const double Hlp[3] = {LSQ ? 0.0 : y[3] * a1, LSQ ? 0.0 : y[3] * a2,
+                               LSQ ? 0.0 : y[1] * (-sn * a1 + cs * a2) + y[2] * (-cs * a1 - sn * a2) + y[3] * off * (-sn * a1 + cs * a2)};
 #pragma unroll
         for (int cI = 0; cI < 3; cI++) {
             double a_ = Hlp[cI];
@@ -372,8 +376,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + 3];
         rk[i] = i < v ? a_ : 0.0;
     }
-    rk[VM] = -(SOC ? crs[0] : cr[0]) + r_sl * iDs1;
-    const double dc1 = dc + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
+    rk[VM] = LSQ ? 0.0 : -(SOC ? crs[0] : cr[0]) + r_sl * iDs1;
+    const double dc1 = LSQ ? 0.0 : dc + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
     // Householder Qh q = alpha e1
     double hw[VM], nq = 0;
 #pragma unroll
@@ -439,7 +443,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
 #pragma unroll
             for (int i = 0; i <= VM; i++) Z[i][cI] = col[i];
         }
-        const double Hpp22 = y[1] * (-cs * p1 - sn * p2) + y[2] * (sn * p1 - cs * p2) + y[3] * off * (-cs * p1 - sn * p2);
+        const double Hpp22 = LSQ ? 0.0 : y[1] * (-cs * p1 - sn * p2) + y[2] * (sn * p1 - cs * p2) + y[3] * off * (-cs * p1 - sn * p2);
         int q = 0;
 #pragma unroll
         for (int a_ = 0; a_ < 3; a_++) {

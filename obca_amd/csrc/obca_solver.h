@@ -130,7 +130,7 @@ struct Opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
-struct OptsAbi { Opts o; int max_soc, reserved_; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
+struct OptsAbi { Opts o; int max_soc, recalc_y; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
                                                           // the default here as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
 struct Lay {
@@ -184,6 +184,7 @@ struct Drv {                // state of the interior-point driver (wave-uniform;
 struct Soc {                // second-order correction (cold path; at the END of Shared: nothing the phases address moves)
     gdbl *csoc;             // c_soc = alpha c(z) + c(z + alpha d) of the instance, layout pi | nu | yg | yo as in the iterate (null unless max_soc > 0)
     int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
+    int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
@@ -416,7 +417,7 @@ struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal
 // part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
 // SOC = 1: the system of a second-order correction step -- FUSED = 0: condensation with c_soc on the right-hand side; FUSED = 1: the block steps of the trial are those of
 // the correction direction (recomputed with c_soc), the assembly at the trial point is the ordinary one.
-template <int VM, int FUSED, int SOC = 0>
+template <int VM, int FUSED, int SOC = 0, int LSQ = 0>      // LSQ = 1 (with FUSED = 0): the blocks of the least-squares multiplier system (obs_block)
 OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
@@ -475,7 +476,7 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
                 SEAM(in.so); SEAM(in.zso); SEAM(in.sl); SEAM(in.zs1); SEAM(in.X); SEAM(in.Y); SEAM(in.psi);
             }
             ObsCond cd;
-            obs_block<0, VM, (SOC && !FUSED) ? 1 : 0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, crs);
+            obs_block<0, VM, (SOC && !FUSED) ? 1 : 0, LSQ>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, crs);
             gdbl *o = I.oc + (size_t)it * OB_OC;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
@@ -508,7 +509,8 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
 }
 
 // part (b): one lane per stage; combines with the partial results of part (a)
-template <int FUSED, int SOC = 0>      // SOC = 1 (with FUSED = 0): steering and dynamics rows enter the right-hand side with c_soc
+template <int FUSED, int SOC = 0, int LSQ = 0>      // SOC = 1 (with FUSED = 0): steering and dynamics rows enter the right-hand side with c_soc;  LSQ = 1 (with FUSED = 0, mu = dw = dc = 0):
+// the least-squares multiplier system -- unit Hessian, no second derivatives, zero constraint right-hand side, gradients in their z-form
 OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa, AsmOut &out) {
     const Consts &c = sh.c; const Lay &l = sh.l;
     const int N = c.N, nOb = c.nOb, M = c.M;
@@ -620,10 +622,10 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                 double Sig = 0;
                 if (i != 2 && k >= 1) {
                     B2 b = bound2(x[i], c.xl[i], c.xu[i], zxL[i], zxU[i], mu, 1, lc0, lcmn, lcmx, lsz);
-                    Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb;
+                    Sig = b.Sig; hz[i] += b.gz; hb[i] += LSQ ? b.gz : b.gb;
                     bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
                 }
-                HH(i, i) = hx[i] + Sig + dw;
+                HH(i, i) = LSQ ? 1.0 : hx[i] + Sig + dw;
             }
             HH(0, 0) += oH[0]; HH(0, 1) += oH[1]; HH(0, 2) += oH[2]; HH(1, 1) += oH[3]; HH(1, 2) += oH[4]; HH(2, 2) += oH[5];
 #pragma unroll
@@ -649,23 +651,23 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
                     hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
                     B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmn, lcmx, lsz);
-                    hz[6 + i] += b.gz; hb[6 + i] += b.gb;
+                    hz[6 + i] += b.gz; hb[6 + i] += LSQ ? b.gz : b.gb;
                     bar_mul(ba, u[i] - lo, hi - u[i]);
-                    HH(6 + i, 6 + i) += 2 * cu[i] + 2 * rr + b.Sig + dw;
-                    HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr;
-                    if (!c.fixTime) { Ht[6 + i] += -4 * rr * ei * it_; Ht[4 + i] += 4 * rr * ei * it_; }
+                    HH(6 + i, 6 + i) += LSQ ? 1.0 : 2 * cu[i] + 2 * rr + b.Sig + dw;
+                    if (!LSQ) { HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr; }
+                    if (!c.fixTime && !LSQ) { Ht[6 + i] += -4 * rr * ei * it_; Ht[4 + i] += 4 * rr * ei * it_; }
                 }
-                if (!c.fixTime) { lgtz += -2 * rv * it_; lgtb += -2 * rv * it_; lHtt += 6 * rv * (it_ * it_); }
+                if (!c.fixTime) { lgtz += -2 * rv * it_; lgtb += -2 * rv * it_; if (!LSQ) lHtt += 6 * rv * (it_ * it_); }
                 {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
                     const double g = (w[0] - u[0]) * iq;
                     const double gg[3] = {iq, -iq, c.fixTime ? 0.0 : -g * it_};
                     B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmn, lcmx, lsz);
                     bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
-                    const double rz = -yg + b.gz, rb = -yg + b.gb;
+                    const double rz = -yg + b.gz, rb = LSQ ? rz : -yg + b.gb;
                     dmax = fmax(dmax, fabs(rz));
                     const double res = g - ss; pmax = fmax(pmax, fabs(res)); lth += fabs(res);
-                    const double Dss = b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = (SOC ? (double)sh.soc.csoc[(l.yg - l.pi) + k] : res) + rb * iDss;
+                    const double Dss = LSQ ? 1.0 : b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = (LSQ ? 0.0 : (SOC ? (double)sh.soc.csoc[(l.yg - l.pi) + k] : res)) + rb * iDss;
                     rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
                     rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
                     const int id[2] = {4, 6};
@@ -674,9 +676,9 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                         hz[id[a_]] += gg[a_] * yg; hb[id[a_]] += gg[a_] * (yg + sig * rg);
 #pragma unroll
                         for (int b_ = 0; b_ < 2; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += sig * gg[a_] * gg[b_];
-                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + yg * (a_ == 0 ? -(iq * it_) : iq * it_);
+                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + (LSQ ? 0.0 : yg * (a_ == 0 ? -(iq * it_) : iq * it_));
                     }
-                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + yg * 2 * g * (it_ * it_); }
+                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + (LSQ ? 0.0 : yg * 2 * g * (it_ * it_)); }
                 }
                 {   // dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
                     DynOut dy; double HL[5][5];
@@ -686,17 +688,17 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
 #pragma unroll
                         for (int j = 0; j < 5; j++) if (as_df(i, j) >= 0) rec[AS_DF + as_df(i, j)] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
                         double r = xn[i] - dy.F[i];
-                        rec[AS_DD + i] = SOC ? -(double)sh.soc.csoc[4 * k + i] : -r; pmax = fmax(pmax, fabs(r)); lth += fabs(r);
+                        rec[AS_DD + i] = LSQ ? 0.0 : (SOC ? -(double)sh.soc.csoc[4 * k + i] : -r); pmax = fmax(pmax, fabs(r)); lth += fabs(r);
                         lsy += fabs(pi[i]);
                     }
                     const int id[4] = {2, 3, 6, 7};
 #pragma unroll
-                    for (int a_ = 0; a_ < 4; a_++) {
+                    for (int a_ = 0; a_ < 4; a_++) if (!LSQ) {
 #pragma unroll
                         for (int b_ = 0; b_ < 4; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += -HL[a_][b_];
                         if (!c.fixTime) Ht[id[a_]] += -HL[a_][4];
                     }
-                    if (!c.fixTime) lHtt += -HL[4][4];
+                    if (!c.fixTime && !LSQ) lHtt += -HL[4][4];
                     // J^T pi: x_k rows get +pi_{k-1} - A_k^T pi_k ; u_k rows -B_k^T pi_k ; t gets -Ft^T pi
                     double ATpi[4] = {pi[0], pi[1], pi[2], pi[3]};
 #pragma unroll
@@ -757,8 +759,8 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
         c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(ztL) + fabs(ztU));
         nb += 2 * (N + 1);
         double gf = (N + 1) * (0.5 + 2 * t);
-        Htt += 2.0 * (N + 1) + b.Sig + dw;
-        gtb += gf + b.gb; gtz += gf + b.gz;
+        Htt += LSQ ? 1.0 : 2.0 * (N + 1) + b.Sig + dw;
+        gtb += gf + (LSQ ? b.gz : b.gb); gtz += gf + b.gz;
         f += (N + 1) * (0.5 * t + t * t);
         bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));
         dinf = fmax(dinf, fabs(gtz));
@@ -1119,7 +1121,7 @@ OBCA_FN int riccati_backward(const Inst &I, Shared &sh, double rho) {
 // ---------------------------------------------------------------- border solve + forward sweep + back-substitution
 
 // part 1: border, closed loop, forward sweep, stage-parallel back-substitution; leaves partial (ap, az, gd) and (dt, nu) in LDS
-template <int SOC = 0>      // SOC = 1: the terminal row enters with c_soc
+template <int SOC = 0, int LSQ = 0>      // SOC = 1: the terminal row enters with c_soc;  LSQ = 1: with zero (least-squares multiplier system; call with mu = dw = dc = rho = 0)
 OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
@@ -1129,7 +1131,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
     {
         const double *B = sh.Bm;
         double e[4];
-        for (int i = 0; i < 4; i++) e[i] = SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + i] : -(z[l.x + 4 * N + i] - c.xF[i]);
+        for (int i = 0; i < 4; i++) e[i] = LSQ ? 0.0 : (SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + i] : -(z[l.x + 4 * N + i] - c.xF[i]));
         double att = A.Htt + B[1 * 6 + 1], rt = -A.gtb - B[1 * 6 + 0];
         double S[16], col[4], colr[4];
         for (int a_ = 0; a_ < 4; a_++) {
@@ -1354,7 +1356,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 }
 
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
-template <int VM, int DBG, int SOC = 0>      // DBG = 1 (host emulation tests only): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
+template <int VM, int DBG, int SOC = 0, int LSQ = 0>      // DBG = 1 (host emulation tests, least-squares multipliers): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
 OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
@@ -1377,7 +1379,7 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, doub
 #pragma unroll
                 for (int r = 0; r < 4; r++) crs[r] = sh.soc.csoc[(l.yo - l.pi) + 4 * it + r];
             }
-            obs_block<1, VM, SOC>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, crs);
+            obs_block<1, VM, SOC, LSQ>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, crs);
             const int r0 = sh.roff[j];
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
@@ -1572,6 +1574,26 @@ OBCA_PHASE void ph_soc_fused(double mu, double dc, double alpha, double ay, doub
     assemble_stage<1>(sh.inst, sh, mu, 0.0, dc, fa, sh.An);
 }
 
+// ---- recalc_y = "yes" (ParkingSignedDist.jl:41; IPOPT recalc_y_feas_tol = 1e-6): once the iterate is (nearly) feasible its equality multipliers are replaced by the
+// least-squares estimate -- the same structured solve with H := I, zero constraint right-hand side, gradients in their z-form; only the multiplier part of the solution is used.
+// Cold path: one non-inlined function, every obstacle width inside.  1 = the multipliers were replaced (the assembly at hand is then stale).
+OBCA_PHASE int ph_recalc_y() {
+    Shared &sh = g_sh; const Inst &I = sh.inst; const Lay &l = sh.l;
+    if (sh.vmc == 0) assemble_obs<2, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else assemble_obs<OB_VMAX, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE);
+    assemble_stage<0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE, sh.A2);
+    if (!riccati_backward(I, sh, 0.0)) return 0;
+    direction_main<0, 1>(I, sh, sh.A2, 0.0, 0.0, 0.0, 0.0, 0.99, sh.S);
+    if (!sh.S.ok) return 0;
+    if (sh.vmc == 0) direction_obs<2, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S); else if (sh.vmc == 1) direction_obs<OB_VMID, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S); else direction_obs<OB_VMAX, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S);
+    double red[1][OBCA_NL];
+    PAR(lane) { double w = 0; for (int i = l.pi + lane; i < l.zxL; i += OB_NT) { const double v = I.d[i]; w = (v == v && fabs(v) <= 1e300) ? fmax(w, 0.0) : 1e301; } red[0][LI(lane)] = w; }
+    if (wred_max(red[0]) > 1e300) return 0;                                  // a non-finite entry: keep the multipliers
+    PAR(lane) { for (int i = l.pi + lane; i < l.zxL; i += OB_NT) I.z[i] += I.d[i]; }
+    SYNC();
+    sh.soc.nrecalc++;
+    return 1;
+}
+
 // the iterate the solve ends with (or is parked at) must sit in the instance's own buffer `home`: copy it over if the last accepted trial left it in the other one
 OBCA_PHASE void ph_bring_home() {
     Shared &sh = g_sh; Inst &I = sh.inst;
@@ -1694,7 +1716,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh; Drv &D = sh.drv;
     gdbl *const st = sl.st;
     const AsmOut &A = sh.A;
-    sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0;
+    sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0;
     D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
     if (sl.resume) {
         D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN]; D.th_max = st[SL_THMAX];
@@ -1804,6 +1826,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
         LDS_SYNC();
         D.have_asm = 1;
+        if (sh.soc.recalc_y && sh.A.pinf < 1e-6) { if (ph_recalc_y()) D.have_asm = 0; }      // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate; the assembly at hand is of the old ones
         D.it++;
     }
     sl.used += D.it + D.nreg - D.p_start;
@@ -1814,11 +1837,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
 // Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
 // solve was parked; the iterate buffer then holds the point to continue from).
-OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0) {
+OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0, int recalc_y = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
-        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; }      // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
+        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; sh.soc.recalc_y = recalc_y; }      // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
     }
     SYNC();
     PAR(lane) {

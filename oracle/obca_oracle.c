@@ -366,11 +366,11 @@ static void lamblock_solve(const obs_fact *F, int v, double *col /* in: [r_lam; 
 
 /* two-sided bound helper: returns Sigma, adds gradient contributions */
 static inline void bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double *Sig,
-                          double *gz, double *gb, double *cmax, double *sumz) {
+                          double *gz, double *gb, double *cmax, double *sumz, int lsq) {
     double dL = v - lo, dU = hi - v;
     *Sig = mult * (zL / dL + zU / dU);
     *gz += mult * (-zL + zU);
-    *gb += mult * (-mu / dL + mu / dU);
+    *gb += lsq ? mult * (-zL + zU) : mult * (-mu / dL + mu / dU);   /* least-squares multiplier mode: the right-hand side is the gradient of the Lagrangian WITH the bound multipliers */
     double c1 = fabs(dL * zL), c2 = fabs(dU * zU); /* complementarity at mu=0 */
     if (c1 > *cmax) *cmax = c1; if (c2 > *cmax) *cmax = c2;
     *sumz += fabs(zL) + fabs(zU);
@@ -392,7 +392,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
     K->Htt = 0; K->gt_z = 0; K->gt_b = 0;
     if (!p->fixTime) {
         double Sig, gz = 0, gb = 0;
-        bound2(t, TL, TU, z[l->ztL], z[l->ztU], mu, N + 1, &Sig, &gz, &gb, &cmax, &sumz);
+        bound2(t, TL, TU, z[l->ztL], z[l->ztU], mu, N + 1, &Sig, &gz, &gb, &cmax, &sumz, lsq);
         nb += 2 * (N + 1); sumz += N * (fabs(z[l->ztL]) + fabs(z[l->ztU]));
         double gf = (N + 1) * (0.5 + 2 * t);
         K->Htt = lsq ? 1.0 : (2.0 * (N + 1) + Sig + dw);
@@ -411,7 +411,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             hz[i] = gx[i]; hb[i] = gx[i];
             double Sig = 0;
             if (i != 2 && k >= 1) {
-                bound2(x[i], p->xl[i], p->xu[i], z[l->zxL + 4 * k + i], z[l->zxU + 4 * k + i], mu, 1, &Sig, &hz[i], &hb[i], &cmax, &sumz);
+                bound2(x[i], p->xl[i], p->xu[i], z[l->zxL + 4 * k + i], z[l->zxU + 4 * k + i], mu, 1, &Sig, &hz[i], &hb[i], &cmax, &sumz, lsq);
                 nb += 2;
             }
             H[i][i] = lsq ? 1.0 : (hx[i] + Sig + dw);
@@ -453,7 +453,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             F->r_so = lsq ? rso_z : rso_b; F->r_sl = rsl;
             if (p->dist) {   /* the sl slot holds the slack of the norm row: s1 >= 0, gradient y1, multiplier zs1 */
                 double zs1 = z[l->zs1 + k * nOb + j];
-                rsl = y[0] - zs1; F->r_sl = y[0] - mu / sl; F->Dsl = zs1 / sl + dw;
+                rsl = y[0] - zs1; F->r_sl = lsq ? rsl : y[0] - mu / sl; F->Dsl = lsq ? 1.0 : zs1 / sl + dw;
                 double c_ = fabs(sl * zs1); if (c_ > cmax) cmax = c_; sumz += fabs(zs1); nb++;
             }
             if (fabs(rso_z) > dmax) dmax = fabs(rso_z); if (fabs(rsl) > dmax) dmax = fabs(rsl);
@@ -572,7 +572,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
             hz[6 + i] += gu; hb[6 + i] += gu;
             hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
-            bound2(u[i], UL[i], UU[i], z[l->zuL + 2 * k + i], z[l->zuU + 2 * k + i], mu, 1, &Sig, &hz[6 + i], &hb[6 + i], &cmax, &sumz);
+            bound2(u[i], UL[i], UU[i], z[l->zuL + 2 * k + i], z[l->zuU + 2 * k + i], mu, 1, &Sig, &hz[6 + i], &hb[6 + i], &cmax, &sumz, lsq);
             nb += 2;
             H[6 + i][6 + i] += lsq ? 1.0 : (2 * cu[i] + 2 * rr + Sig + dw);
             H[4 + i][4 + i] += hsc * 2 * rr;
@@ -586,7 +586,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
             double gg[3] = {1 / q, -1 / q, p->fixTime ? 0 : -g / t};
             memcpy(K->gg[k], gg, sizeof gg);
             double Sig, gz = 0, gb = 0;
-            bound2(ss, -SSB, SSB, z[l->zssL + k], z[l->zssU + k], mu, 1, &Sig, &gz, &gb, &cmax, &sumz);
+            bound2(ss, -SSB, SSB, z[l->zssL + k], z[l->zssU + k], mu, 1, &Sig, &gz, &gb, &cmax, &sumz, lsq);
             nb += 2; nm += 1; sumy += fabs(yg);
             double rz = -yg + gz, rb = -yg + gb;
             if (fabs(rz) > dmax) dmax = fabs(rz);
@@ -1012,11 +1012,8 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
     for (int i = l->zxL; i < l->len; i++) z[i] = 1.0;
     if (o->lsq_init) {
         /* least-squares multipliers: the same structured solve with H := I */
-        kkt_assemble(K, z, 0.0, 0, 0, 1);
-        /* in lsq mode the rhs gradient must be the z-form gradient; assemble put barrier(mu=0)=0 into hb, so add -zL+zU */
+        kkt_assemble(K, z, 0.0, 0, 0, 1);      /* (lsq mode: the right-hand side is the z-form gradient, bound2) */
         stage_dual_inf(K, z);
-        for (int k = 0; k <= N; k++) memcpy(K->hb[k], K->hz[k], sizeof K->hb[k]);
-        K->gt_b = K->gt_z;
         if (kkt_solve(K, z, 0.0, 0, 0.0, 1, d)) {
             double ymax = 0;
             for (int i = l->pi; i < l->zxL; i++) { double a = fabs(z[i] + d[i]); if (a > ymax || a != a) ymax = a; }
@@ -1158,10 +1155,8 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             double f2, th2, thi2;
             eval_f_theta(p, l, z, &f2, &th2, &thi2);
             if (thi2 < 1e-6) {
-                kkt_assemble(K, z, 0.0, 0, 0, 1);
+                kkt_assemble(K, z, 0.0, 0, 0, 1);      /* (lsq mode: every gradient in its z-form, the condensed blocks' corrections included) */
                 stage_dual_inf(K, z);
-                for (int k = 0; k <= N; k++) memcpy(K->hb[k], K->hz[k], sizeof K->hb[k]);
-                K->gt_b = K->gt_z;
                 if (kkt_solve(K, z, 0.0, 0, 0.0, 1, dsoc)) {
                     int fin = 1;
                     for (int i = l->pi; i < l->zxL; i++) if (!(dsoc[i] == dsoc[i]) || fabs(dsoc[i]) > 1e300) fin = 0;

@@ -17,7 +17,7 @@ class EOpts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("reserved_", C.c_int)]
+        [("max_soc", C.c_int), ("recalc_y", C.c_int)]
 
 
 def load():
@@ -41,14 +41,14 @@ def default_opts():
     return o
 
 
-def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, dist=False, max_soc=0, **_):
+def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, dist=False, max_soc=0, recalc_y=0, **_):
     emu = load()
     x0 = np.reshape(x0, (-1, 4)); B = x0.shape[0]
     v = np.ravel(vOb).astype(int); nOb, M = len(v), int(v.sum()); Lz = P.layout(N, nOb, M)
     A = np.asarray(A, float).reshape(M, 2); b = np.ravel(np.asarray(b, float)); ego = np.ravel(np.asarray(ego, float))
     rl = P.row_lengths(A); An = A / rl[:, None]; bn = b / rl          # the kernels see unit-length rows (obca_hip.hip: batch_upload_range); lambda comes back rescaled
     g = np.array([(ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2, (ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2]); off = (ego[0] + ego[2]) / 2 - ego[2]
-    eo = default_opts(); eo.max_soc = int(max_soc); nsoc = np.zeros((B, 2), int)
+    eo = default_opts(); eo.max_soc = int(max_soc); eo.recalc_y = int(recalc_y); nsoc = np.zeros((B, 3), int)
     Tsv = np.broadcast_to(np.asarray(Ts, float), (B,))
     xp = np.zeros((B, 4, N + 1)); up = np.zeros((B, 2, N)); ts = np.zeros((B, N + 1)); ef = np.zeros(B, np.int32); info = np.zeros((B, 8))
     lps, nps, sls = [], [], []
@@ -67,7 +67,7 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
         z0 = P.pack_start(N, nOb, M, np.asarray(xWS[i], float).reshape(-1, 4)[:N + 1], np.asarray(uWS[i], float).reshape(-1, 2)[:N], lWS, nWS)
         zo = np.zeros_like(z0)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(Lz["len"]), C.byref(eo), dp(zo), dp(info[i]))
-        acc_ = C.c_int(0); nsoc[i, 0] = emu.emu_last_soc(C.byref(acc_)); nsoc[i, 1] = acc_.value
+        acc_ = C.c_int(0); nsoc[i, 0] = emu.emu_last_soc(C.byref(acc_)); nsoc[i, 1] = acc_.value; nsoc[i, 2] = emu.emu_last_recalc()
         x_, u_, t_, lp_, np_, sl_ = P.unpack_solution(zo, N, nOb, M, A=A)
         xp[i] = x_; up[i] = u_; ts[i] = 1.0 if fixTime else t_; ef[i] = int(info[i, 7]); lps.append(lp_); nps.append(np_); sls.append(sl_)
     return dict(xp=xp, up=up, timeScale=ts, exitflag=ef, lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int), nsoc=nsoc)

@@ -39,9 +39,8 @@ def test_opts_struct_matches_and_defaults(lib):
     import oracle as O
     oo = O.default_opts()
     for n, _ in Opts._fields_:
-        if n != "reserved_":      # (padding of the record; every option exists under the same name in the checker)
-            assert getattr(o, n) == getattr(oo, n), n
-    assert o.max_soc == 0 and o.reserved_ == 0
+        assert getattr(o, n) == getattr(oo, n), n      # every option exists under the same name in the checker
+    assert o.max_soc == 0 and o.recalc_y == 0
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -13,13 +13,13 @@ class EOpts(C.Structure):      # obca::Opts (obca_solver.h); every field but the
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("reserved_", C.c_int)]
+        [("max_soc", C.c_int), ("recalc_y", C.c_int)]
 
 
 def copy_opts(oo):
     eo = EOpts()
     for n, _ in EOpts._fields_:
-        if n != "reserved_":
+        if True:
             setattr(eo, n, getattr(oo, n))
     return eo
 
@@ -251,3 +251,31 @@ def test_second_order_correction_in_the_kernels_follows_the_oracle(oracle):
         assert np.abs(e["xp"][0] - r1["xp"]).max() < 1e-8 and abs(e["obj"][0] - r1["obj"]) < 1e-9 * abs(r1["obj"])
         changed += r0["iters"] != r1["iters"]; tried += e["nsoc"][0, 0] > 0
     assert changed >= 3 and tried >= 5
+
+
+def test_recalc_y_in_the_kernels_follows_the_oracle(oracle, emu):
+    """obca_opts.recalc_y = 1 (recalc_y = "yes", ParkingSignedDist.jl:41): once the accepted iterate's constraint violation is below 1e-6 the equality multipliers are replaced
+    by their least-squares estimate -- the structured solve with H := I, zero constraint right-hand side, z-form gradients (template parameter LSQ of the phases).  Against
+    the oracle's option: the same iterations, and the multipliers (pi, nu, y_g, y_o) of the final iterate -- the re-estimated ones -- to 1e-12."""
+    import emu_solver as E
+    N = 80; sc = S.BACKWARDS
+    bt = S.make_batch(sc, 5, N, seed=20260925)
+    A, b, v = S.scenario_hrep(sc); v = np.ravel(v).astype(int); nOb, M = len(v), int(v.sum()); L = P.layout(N, nOb, M)
+    oo = oracle.default_opts(); oo.recalc_y = 1; eo = copy_opts(oo)
+    assert eo.recalc_y == 1 and eo.max_soc == 0
+    n_re = 0; ys = slice(L["pi"], L["zxL"])
+    for i in range(5):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
+        a = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+        r = oracle.parking_signed_dist(*a, opts=oo, full=True); r0 = oracle.parking_signed_dist(*a, full=True)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i][:N], lWS, nWS); zo = np.zeros_like(z0); info = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+        assert int(info[1]) == r["iters"] and int(info[7]) == r["exitflag"] == 1
+        assert np.abs(zo[ys] - r["zfull"][ys]).max() < 1e-12 and np.abs(zo[:L["nprimal"]] - r["zfull"][:L["nprimal"]]).max() < 1e-9
+        if emu.emu_last_recalc() > 0:
+            n_re += 1
+            assert np.abs(r["zfull"][ys] - r0["zfull"][ys]).max() > 0          # the estimate is not the multiplier the iteration carried (it agrees with it to ~1e-9 at the solution)
+            assert np.abs(r["zfull"][ys] - r0["zfull"][ys]).max() < 1e-6
+    assert n_re >= 3

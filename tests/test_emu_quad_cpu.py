@@ -59,7 +59,7 @@ def test_emu_quad_full_solve_matches_oracle(Q, emu, N, dws):
     r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=dws)
     oo = Q.default_opts(); eo = EOpts()
     for f, _ in EOpts._fields_:
-        if hasattr(oo, f):      # (max_soc / padding: parking options, not in the quadcopter checker's record; zero)
+        if hasattr(oo, f):      # (max_soc, recalc_y: parking options, not in the quadcopter checker's record; zero)
             setattr(eo, f, getattr(oo, f))
     L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=dws)
     z = np.zeros(L["len"]); info = np.zeros(8)
@@ -78,7 +78,7 @@ def test_emu_quadcopter_dist_variant_matches_oracle(Q, emu):
     r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
     oo = Q.default_opts(); eo = EOpts()
     for f, _ in EOpts._fields_:
-        if hasattr(oo, f):      # (max_soc / padding: parking options, not in the quadcopter checker's record; zero)
+        if hasattr(oo, f):      # (max_soc, recalc_y: parking options, not in the quadcopter checker's record; zero)
             setattr(eo, f, getattr(oo, f))
     L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dist=1)
     z = np.zeros(L["len"]); info = np.zeros(8)

@@ -118,6 +118,25 @@ def test_second_order_correction_matches_the_oracle_option(OA, oracle):
         o.max_soc = 99; _solve_batch(OA, bt, opts=o)
 
 
+def test_recalc_y_matches_the_oracle_option(OA, oracle):
+    """obca_opts.recalc_y = 1 (the reference's recalc_y = "yes", ParkingSignedDist.jl:41; off by default here): 48 config-3 instances through the C ABI against the oracle
+    with the same option -- exit flags, iteration counts, trajectories; and both switches together (max_soc = 4, recalc_y = 1)."""
+    N, B = 80, 48
+    bt = S.make_batch(S.PARALLEL, B, N, seed=20260926, goal_jitter=True)
+    base, xWS = _solve_batch(OA, bt)
+    for soc in (0, 4):
+        o = OA.default_opts(); o.recalc_y = 1; o.max_soc = soc
+        oo = oracle.default_opts(); oo.recalc_y = 1; oo.max_soc = soc
+        out, _ = _solve_batch(OA, bt, opts=o)
+        for i in range(B):
+            r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                           bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i], opts=oo)
+            assert out["exitflag"][i] == r["exitflag"] == 1 and out["iters"][i] == r["iters"], (soc, i, out["iters"][i], r["iters"])
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and abs(out["obj"][i] - r["obj"]) < TOL_F * abs(r["obj"])
+        if soc == 0:
+            assert (out["xp"] != base["xp"]).any()                  # the option does something (an instance that re-estimates before its last iteration continues from other multipliers)
+
+
 def test_parking_matches_oracle_config3_parallel(OA, oracle):
     """BASELINE config 3: parallel parking, 4 obstacles / 6 half-space rows, Hybrid A* warm starts (golden fixture + a fresh batch)"""
     import checkers as K

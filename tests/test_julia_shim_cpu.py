@@ -60,3 +60,19 @@ def test_quadcopter_warm_start_orientation():
     assert "f64(xWS)[:, 1:N+1]" in src and "permutedims(f64(xWS)[1:N+1, :])), C_NULL,\n               [Float64(timeWS)]" not in src
     for f in ("QuadcopterSignedDist(", "QuadcopterDist(", "ParkingSignedDist(", "ParkingDist(", "DualMultWS(", "MultiContext("):
         assert f in src, f
+
+
+def test_julia_options_record_mirrors_the_header():
+    """julia/OBCAHip.jl `Opts` must list the fields of `obca_opts` (include/obca_hip.h) in order and kind -- the record is handed to the library by pointer"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct obca_opts \{(.*?)\} obca_opts;", hdr, flags=re.S).group(1)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            kind, names = decl.split(None, 1)
+            c_fields += [(n.strip(), kind) for n in names.split(",")]
+    src = open(os.path.join(ROOT, "julia", "OBCAHip.jl")).read()
+    jl = re.search(r"mutable struct Opts\n(.*?)\n\s*Opts\(\) = new\(\)", src, flags=re.S).group(1)
+    j_fields = [(m.group(1), JL[m.group(2)]) for m in re.finditer(r"(\w+)::(Cdouble|Cint)", jl)]
+    assert j_fields == c_fields and len(c_fields) == 32 and c_fields[-2:] == [("max_soc", "int"), ("recalc_y", "int")]
