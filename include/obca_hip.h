@@ -36,13 +36,14 @@ typedef struct obca_batch obca_batch;
 
 /* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults.
  * What the solver behind them is: IPOPT's Algorithm A (monotone barrier, filter line search, inertia-correction ladder, alpha_for_y = min) on a structured KKT solve.
- * Two IPOPT semantics the reference relies on are switches of the parking kernels, both off by default (as in the CPU checker the parity tests run against):
+ * Three IPOPT semantics the reference relies on are switches of the parking kernels, all off by default (as in the CPU checker the parity tests run against):
  *   max_soc  -- the second-order correction (A-5.5..A-5.9 of Waechter & Biegler: up to max_soc corrections with kappa_soc = 0.99 after a rejected first trial step that
  *               did not reduce the constraint violation; IPOPT's own default is 4);
  *   recalc_y -- recalc_y = "yes" (ParkingSignedDist.jl:41): the equality multipliers are replaced by their least-squares estimate (the structured solve with H := I)
  *               whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6.
- * With either on, the kernels follow the checker's option of the same name iteration for iteration (tests/test_gpu_parity.py, tests/test_emu_cpu.py).
- * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), least-squares INITIAL multipliers, kappa_d damping, gradient-based NLP
+ *   lsq_init -- IPOPT's default initial multipliers: the same least-squares estimate at the starting point (constr_mult_init_max = 1e3) instead of y0 = 0.
+ * With any of them on, the kernels follow the checker's option of the same name iteration for iteration (tests/test_gpu_parity.py, tests/test_emu_cpu.py).
+ * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, gradient-based NLP
  * scaling (half-space rows enter with unit length instead).  On the full bench batches of BASELINE configs 2, 3 and 5 (1 024 + 2 048 + 4 096 instances) the kernels'
  * default results and the checker's WITH the correction and recalc_y switched on have identical exit flags -- every instance is solved either way -- while
  * 70 / 711 / 220 iteration counts differ and, the NLP being non-convex, 0 / a handful / a few instances end in another local solution
@@ -56,6 +57,9 @@ typedef struct obca_opts {
     int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off, the default of obca_default_opts; parking kernels only */
     int recalc_y;     /* 1: recalc_y = "yes" as the reference sets it (ParkingSignedDist.jl:41; recalc_y_feas_tol 1e-6): least-squares equality multipliers whenever the
                          iterate's constraint violation is below 1e-6; 0 = off, the default of obca_default_opts; parking kernels only */
+    int lsq_init;     /* 1: IPOPT's initial equality multipliers -- the least-squares estimate at the starting point, kept if its max-norm is <= constr_mult_init_max = 1e3;
+                         0 = y0 = 0, the default of obca_default_opts (the reference runs IPOPT's default, i.e. 1); parking kernels only */
+    int reserved_;    /* 0 */
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);

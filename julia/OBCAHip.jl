@@ -50,7 +50,7 @@ f64(a) = convert(Array{Float64}, a)
 """
 Interior-point options: the record `obca_opts` of include/obca_hip.h, field for field.  `default_opts()` = the reference's IPOPT call (ParkingSignedDist.jl:41-43) with the two
 IPOPT semantics the kernels carry as switches OFF; `ipopt_opts()` switches them on as the reference's IPOPT has them (second-order correction: IPOPT's default max_soc = 4;
-recalc_y = "yes": ParkingSignedDist.jl:41).  Pass as the keyword `opts` of the batched parking calls; `nothing` = the library's defaults.
+recalc_y = "yes": ParkingSignedDist.jl:41; least-squares initial multipliers: IPOPT's default).  Pass as the keyword `opts` of the batched parking calls; `nothing` = the library's defaults.
 """
 mutable struct Opts
     tol::Cdouble; max_iter::Cint
@@ -58,7 +58,7 @@ mutable struct Opts
     dw_min::Cdouble; dw0::Cdouble; dw_max::Cdouble; kw_inc0::Cdouble; kw_inc::Cdouble; kw_dec::Cdouble; dc_bar::Cdouble; kappa_c::Cdouble
     gamma_theta::Cdouble; gamma_phi::Cdouble; delta::Cdouble; s_theta::Cdouble; s_phi::Cdouble; eta_phi::Cdouble; gamma_alpha::Cdouble; s_max::Cdouble; kappa_sigma::Cdouble
     constr_viol_tol::Cdouble; dual_inf_tol::Cdouble; compl_inf_tol::Cdouble; rho_term::Cdouble
-    max_soc::Cint; recalc_y::Cint
+    max_soc::Cint; recalc_y::Cint; lsq_init::Cint; reserved_::Cint
     Opts() = new()
 end
 function default_opts()
@@ -66,7 +66,7 @@ function default_opts()
     ccall((:obca_default_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_default_opts failed")
     return o
 end
-ipopt_opts() = (o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o)
+ipopt_opts() = (o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1; o)
 optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
 
 """

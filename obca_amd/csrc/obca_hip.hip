@@ -44,7 +44,7 @@ struct DevBufs {
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
 #define OBCA_RESIDENT_PER_CU (4 * OBCA_IPM_WAVES_PER_EU)   // parking instances (one wavefront each) resident per CU
-__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc, int recalc_y) {
+__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc, int recalc_y, int lsq_init) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
     const int inst = mode ? b.order[blockIdx.x] : (int)blockIdx.x;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = mode ? b.prof[(size_t)inst * 16 + threadIdx.x] : 0.0;   // counters add up over the slices
 #endif
     __syncthreads();
-    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y);
+    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
@@ -275,7 +275,7 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
-    o->max_soc = 0; o->recalc_y = 0;                  /* IPOPT's default max_soc is 4 and the reference sets recalc_y = "yes"; both off here as in the checker the parity tests run against */
+    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->reserved_ = 0;                  /* IPOPT's default max_soc is 4 and the reference sets recalc_y = "yes"; both off here as in the checker the parity tests run against */
     return 0;
 }
 
@@ -524,15 +524,15 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     const int slots = parking_resident_per_cu(bt->N) * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
     bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc, o.recalc_y != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
         HIPCHK(bt, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc, o.recalc_y != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
         HIPCHK(bt, hipGetLastError());
         if (!slice_only) {
             hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
             HIPCHK(bt, hipGetLastError());
-            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0, o.max_soc, o.recalc_y != 0);
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
             HIPCHK(bt, hipGetLastError());
         }
     }

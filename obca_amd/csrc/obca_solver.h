@@ -130,7 +130,7 @@ struct Opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
-struct OptsAbi { Opts o; int max_soc, recalc_y; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
+struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, reserved_; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
                                                           // the default here as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
 struct Lay {
@@ -185,6 +185,7 @@ struct Soc {                // second-order correction (cold path; at the END of
     gdbl *csoc;             // c_soc = alpha c(z) + c(z + alpha d) of the instance, layout pi | nu | yg | yo as in the iterate (null unless max_soc > 0)
     int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
     int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
+    int lsq_init;                     // option: least-squares initial multipliers (IPOPT's default initialisation, constr_mult_init_max = 1e3)
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
@@ -1577,7 +1578,7 @@ OBCA_PHASE void ph_soc_fused(double mu, double dc, double alpha, double ay, doub
 // ---- recalc_y = "yes" (ParkingSignedDist.jl:41; IPOPT recalc_y_feas_tol = 1e-6): once the iterate is (nearly) feasible its equality multipliers are replaced by the
 // least-squares estimate -- the same structured solve with H := I, zero constraint right-hand side, gradients in their z-form; only the multiplier part of the solution is used.
 // Cold path: one non-inlined function, every obstacle width inside.  1 = the multipliers were replaced (the assembly at hand is then stale).
-OBCA_PHASE int ph_recalc_y() {
+OBCA_PHASE int ph_recalc_y(int init) {      // init = 1: IPOPT's initial multipliers (least-squares estimate at the starting point, kept only if its max-norm is <= constr_mult_init_max = 1e3)
     Shared &sh = g_sh; const Inst &I = sh.inst; const Lay &l = sh.l;
     if (sh.vmc == 0) assemble_obs<2, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else assemble_obs<OB_VMAX, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE);
     assemble_stage<0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE, sh.A2);
@@ -1586,11 +1587,12 @@ OBCA_PHASE int ph_recalc_y() {
     if (!sh.S.ok) return 0;
     if (sh.vmc == 0) direction_obs<2, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S); else if (sh.vmc == 1) direction_obs<OB_VMID, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S); else direction_obs<OB_VMAX, 1, 0, 1>(I, sh, 0.0, 0.0, 0.0, 0.99, sh.S);
     double red[1][OBCA_NL];
-    PAR(lane) { double w = 0; for (int i = l.pi + lane; i < l.zxL; i += OB_NT) { const double v = I.d[i]; w = (v == v && fabs(v) <= 1e300) ? fmax(w, 0.0) : 1e301; } red[0][LI(lane)] = w; }
-    if (wred_max(red[0]) > 1e300) return 0;                                  // a non-finite entry: keep the multipliers
+    PAR(lane) { double w = 0; for (int i = l.pi + lane; i < l.zxL; i += OB_NT) { const double v = I.d[i], y1 = fabs(I.z[i] + v); w = (v == v && fabs(v) <= 1e300 && w <= 1e300) ? fmax(w, y1) : 1e301; } red[0][LI(lane)] = w; }
+    const double ymax = wred_max(red[0]);
+    if (ymax > 1e300 || (init && ymax > 1e3)) return 0;                      // a non-finite entry (or, at the start, an estimate beyond constr_mult_init_max): keep the multipliers
     PAR(lane) { for (int i = l.pi + lane; i < l.zxL; i += OB_NT) I.z[i] += I.d[i]; }
     SYNC();
-    sh.soc.nrecalc++;
+    if (!init) sh.soc.nrecalc++;
     return 1;
 }
 
@@ -1726,7 +1728,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         SYNC();
         D.have_asm = (int)st[SL_HAVE];
         sl.resume = 0;
-    } else { PH(ph_init(o.bound_push, o.bound_frac)); D.have_asm = 0; }
+    } else { PH(ph_init(o.bound_push, o.bound_frac)); D.have_asm = 0; if (sh.soc.lsq_init) ph_recalc_y(1); }      // (IPOPT's default initial multipliers, an option here: Opts lsq_init)
     D.tau = fmax(o.tau_min, 1 - D.mu);
     D.p_start = D.it + D.nreg;
     D.dc_mu = -1.0; D.dc_val = 0;
@@ -1826,7 +1828,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
         LDS_SYNC();
         D.have_asm = 1;
-        if (sh.soc.recalc_y && sh.A.pinf < 1e-6) { if (ph_recalc_y()) D.have_asm = 0; }      // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate; the assembly at hand is of the old ones
+        if (sh.soc.recalc_y && sh.A.pinf < 1e-6) { if (ph_recalc_y(0)) D.have_asm = 0; }      // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate; the assembly at hand is of the old ones
         D.it++;
     }
     sl.used += D.it + D.nreg - D.p_start;
@@ -1837,11 +1839,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
 // Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
 // solve was parked; the iterate buffer then holds the point to continue from).
-OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0, int recalc_y = 0) {
+OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0, int recalc_y = 0, int lsq_init = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
-        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; sh.soc.recalc_y = recalc_y; }      // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
+        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; sh.soc.recalc_y = recalc_y; sh.soc.lsq_init = lsq_init; }      // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
     }
     SYNC();
     PAR(lane) {

@@ -85,7 +85,7 @@ int emu_solve(int N, const double *prob, const double *zinit, int len, const voi
     memcpy(s.z, zinit, sizeof(double) * len);
     Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; g_sh.soc.csoc = s.csoc;
     double *st = (double *)calloc(SL_SIZE, 8);
-    solve_instance(N, ((const OptsAbi *)opts)->o, info, st, 0, 0, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y);
+    solve_instance(N, ((const OptsAbi *)opts)->o, info, st, 0, 0, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init);
     free(st);
     memcpy(zout, s.z, sizeof(double) * len);
     free_scratch(s);
@@ -101,7 +101,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
         Inst &I = g_sh.inst; I.prob = prob; I.z = s.z; I.zn = s.zn; I.d = s.d; I.as = s.as; I.rs = s.rs; I.oc = s.oc; g_sh.soc.csoc = s.csoc;
-        solve_instance(N, ((const OptsAbi *)opts)->o, info, st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y);
+        solve_instance(N, ((const OptsAbi *)opts)->o, info, st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
     }

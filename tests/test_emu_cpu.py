@@ -13,13 +13,13 @@ class EOpts(C.Structure):      # obca::Opts (obca_solver.h); every field but the
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int)]
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("reserved_", C.c_int)]
 
 
 def copy_opts(oo):
     eo = EOpts()
     for n, _ in EOpts._fields_:
-        if True:
+        if n != "reserved_":
             setattr(eo, n, getattr(oo, n))
     return eo
 
@@ -279,3 +279,23 @@ def test_recalc_y_in_the_kernels_follows_the_oracle(oracle, emu):
             assert np.abs(r["zfull"][ys] - r0["zfull"][ys]).max() > 0          # the estimate is not the multiplier the iteration carried (it agrees with it to ~1e-9 at the solution)
             assert np.abs(r["zfull"][ys] - r0["zfull"][ys]).max() < 1e-6
     assert n_re >= 3
+
+
+def test_least_squares_initial_multipliers_in_the_kernels_follow_the_oracle(oracle):
+    """obca_opts.lsq_init = 1 (IPOPT's default initialisation of the equality multipliers: least-squares estimate at the starting point, constr_mult_init_max = 1e3): the same
+    LSQ phases as recalc_y, here far from a solution -- the iteration counts move by up to 50 % against y0 = 0, and the kernels' follow the oracle's option exactly."""
+    import emu_solver as E
+    bt = S.make_batch(S.PARALLEL, 6, 80, seed=20260925, goal_jitter=True)
+    A, b, v = S.scenario_hrep(S.PARALLEL)
+    oo = oracle.default_opts(); oo.lsq_init = 1
+    changed = 0
+    for i in (1, 2, 3, 5):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        a = (bt["x0"][i], bt["xF"][i], 80, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r0 = oracle.parking_signed_dist(*a); r1 = oracle.parking_signed_dist(*a, opts=oo)
+        e = E.parking_signed_dist_batch(bt["x0"][i:i + 1], bt["xF"][i:i + 1], 80, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[None, :, 0], xWS[None, :, 1],
+                                        xWS[None, :, 2], 0, xWS[None], bt["uWS"][i:i + 1], lsq_init=1)
+        assert e["exitflag"][0] == r1["exitflag"] == 1 and e["iters"][0] == r1["iters"]
+        assert np.abs(e["xp"][0] - r1["xp"]).max() < 1e-8 and abs(e["obj"][0] - r1["obj"]) < 1e-9 * abs(r1["obj"])
+        changed += r0["iters"] != r1["iters"]
+    assert changed >= 3

@@ -137,6 +137,25 @@ def test_recalc_y_matches_the_oracle_option(OA, oracle):
             assert (out["xp"] != base["xp"]).any()                  # the option does something (an instance that re-estimates before its last iteration continues from other multipliers)
 
 
+def test_least_squares_initial_multipliers_match_the_oracle_option(OA, oracle):
+    """obca_opts.lsq_init = 1 (IPOPT's default initial multipliers; y0 = 0 by default here): 32 config-3 instances through the C ABI against the oracle with the same option, and
+    all three IPOPT switches together (lsq_init, max_soc = 4, recalc_y) -- the reference's IPOPT configuration as far as the kernels carry it."""
+    N, B = 80, 32
+    bt = S.make_batch(S.PARALLEL, B, N, seed=20260927, goal_jitter=True)
+    base, xWS = _solve_batch(OA, bt)
+    for soc, rc in ((0, 0), (4, 1)):
+        o = OA.default_opts(); o.lsq_init = 1; o.max_soc = soc; o.recalc_y = rc
+        oo = oracle.default_opts(); oo.lsq_init = 1; oo.max_soc = soc; oo.recalc_y = rc
+        out, _ = _solve_batch(OA, bt, opts=o)
+        for i in range(B):
+            r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
+                                           bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i], opts=oo)
+            assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"], (soc, rc, i, out["iters"][i], r["iters"])
+            if r["exitflag"] == 1:
+                assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and abs(out["obj"][i] - r["obj"]) < TOL_F * abs(r["obj"])
+        assert (out["iters"] != base["iters"]).sum() >= B // 2          # the initial estimate changes the path of most instances
+
+
 def test_parking_matches_oracle_config3_parallel(OA, oracle):
     """BASELINE config 3: parallel parking, 4 obstacles / 6 half-space rows, Hybrid A* warm starts (golden fixture + a fresh batch)"""
     import checkers as K
