@@ -205,8 +205,11 @@ def _dual_start(lWS, nWS, Mt, nt, N):
 
 
 def _row_counts(nObs, vflat):
-    starts = np.concatenate([[0], np.cumsum(nObs)[:-1]])
-    return np.array([vflat[s:s + n].sum() for s, n in zip(starts, nObs)], np.int64)
+    """half-space rows per instance: segment sums of vflat (one numpy call -- a Python loop over 16 384 instances cost a third of the wrapper's time)"""
+    nObs = np.asarray(nObs, np.int64)
+    csum = np.concatenate([[0], np.cumsum(np.asarray(vflat, np.int64))])
+    ends = np.cumsum(nObs)
+    return csum[ends] - csum[ends - nObs]
 
 
 class Batch:
@@ -344,11 +347,11 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
 
 
 def _unpack_parking(B, N, nObs, Ms, xp, up, ts, ef, lp, npp, sl, info):
-    """C-ABI output arrays -> the reference's shapes: xp (B,4,N+1), up (B,2,N), per-instance lp (M,N+1) / np (4nOb,N+1) / sl (nOb,N+1)"""
+    """C-ABI output arrays -> the reference's shapes: xp (B,4,N+1), up (B,2,N), per-instance lp (M,N+1) / np (4nOb,N+1) / sl (nOb,N+1): lists for ragged obstacle sets, (B, ., N+1) arrays for uniform ones"""
     if len(set(Ms.tolist())) == 1 and len(set(nObs.tolist())) == 1:          # uniform obstacle sets: one reshape, views per instance
         m, n = int(Ms[0]), int(nObs[0])
         L3 = lp.reshape(B, N + 1, m).transpose(0, 2, 1); N3 = npp.reshape(B, N + 1, 4 * n).transpose(0, 2, 1); S3 = sl.reshape(B, N + 1, n).transpose(0, 2, 1)
-        lps, nps, sls = list(L3), list(N3), list(S3)
+        lps, nps, sls = L3, N3, S3                                             # (B, M, N+1) views: lp[i] is instance i's (M, N+1) array, as in the ragged case -- no 3 x B Python objects
     else:
         lps, nps, sls = [], [], []
         ro = oo = 0
