@@ -1,6 +1,7 @@
 """The HIP solver source, compiled as a host emulation (64 lanes as a loop), against the oracle: kernel LOGIC without a GPU."""
 import ctypes as C
 import numpy as np
+import pytest
 from obca_amd import scenarios as S
 import packing as P
 
@@ -299,3 +300,33 @@ def test_least_squares_initial_multipliers_in_the_kernels_follow_the_oracle(orac
         assert np.abs(e["xp"][0] - r1["xp"]).max() < 1e-8 and abs(e["obj"][0] - r1["obj"]) < 1e-9 * abs(r1["obj"])
         changed += r0["iters"] != r1["iters"]
     assert changed >= 3
+
+
+@pytest.mark.parametrize("rows", [(3, 4), (5, 8)], ids=["rows_up_to_4", "rows_up_to_8"])
+def test_ipopt_switches_on_wide_obstacles_follow_the_oracle(oracle, emu, rows):
+    """max_soc, recalc_y and lsq_init together on instances whose obstacles have up to 4 / up to 8 half-space rows: the OB_VMID and OB_VMAX instantiations of the correction
+    and least-squares phases (the other switch tests run on <= 2 rows) against the oracle with the same options"""
+    N = 24
+    bt = S.make_mixed_batch(8, N, seed=23, rows=rows, max_extra=4)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; eo = copy_opts(oo)
+    base = oracle.default_opts()
+    done = changed = 0
+    for i in range(8):
+        v = np.asarray(bt["vOb"][i]); A = bt["A"][i]; b = bt["b"][i]
+        if v.max() < rows[0]:
+            continue
+        nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        a = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+        r = oracle.parking_signed_dist(*a, opts=oo); r0 = oracle.parking_signed_dist(*a, opts=base)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=A)
+        zo = np.zeros_like(z0); info = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M, A=A)
+        assert int(info[7]) == r["exitflag"] and int(info[1]) == r["iters"], (i, info[1], r["iters"])
+        if r["exitflag"] == 1:
+            assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
+        done += 1; changed += r["iters"] != r0["iters"]
+    assert done >= 3 and changed >= 2

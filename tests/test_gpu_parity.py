@@ -431,6 +431,24 @@ def test_wide_obstacles_up_to_eight_rows(OA, oracle):
     assert n >= 8
 
 
+def test_ipopt_switches_on_wide_obstacles_match_the_oracle_options(OA, oracle):
+    """max_soc = 4, recalc_y and lsq_init together on a ragged batch with 2- to 8-row obstacles: every row-class instantiation of the correction and least-squares phases
+    through the C ABI against the oracle with the same options"""
+    N, B = 40, 24
+    bt = S.make_mixed_batch(B, N, seed=11, rows=(5, 8), max_extra=4)
+    o = OA.default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    out, xWS = _solve_batch(OA, dict(bt, N=N), opts=o)
+    base, _ = _solve_batch(OA, dict(bt, N=N))
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i],
+                                       bt["b"][i], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i], opts=oo)
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"], (i, out["iters"][i], r["iters"])
+        if r["exitflag"] == 1:
+            assert abs(out["obj"][i] - r["obj"]) <= TOL_F * max(1, abs(r["obj"])) and np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+    assert (out["iters"] != base["iters"]).sum() >= B // 2
+
+
 def test_hip_reproduces_the_independently_certified_solutions(OA):
     """tests/golden/kkt_pin.npz: solutions whose optimality is certified with independent (autograd) derivatives at the benchmark size (test_pin_cpu.py):
     the HIP path must return the same arrays -- config 2 and config 3 at N = 80, quadcopter at N = 60 -- without the oracle at run time"""
