@@ -376,8 +376,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][VM + 3];
         rk[i] = i < v ? a_ : 0.0;
     }
-    rk[VM] = LSQ ? 0.0 : -(SOC ? crs[0] : cr[0]) + r_sl * iDs1;
-    const double dc1 = LSQ ? 0.0 : dc + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
+    rk[VM] = (LSQ ? 0.0 : -(SOC ? crs[0] : cr[0])) + r_sl * iDs1;      // (the eliminated norm-row slack of ParkingDist stays in the least-squares system too)
+    const double dc1 = (LSQ ? 0.0 : dc) + iDs1;            // (y1, y1) pivot: -(delta_c + 1/D_s1)
     // Householder Qh q = alpha e1
     double hw[VM], nq = 0;
 #pragma unroll

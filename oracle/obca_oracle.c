@@ -527,8 +527,8 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
                 for (int r = 0; r < 3; r++) a_ += F->Jl[r + 1][i] * W[r][v + 3];
                 F->rk[i] = a_;
             }
-            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = lsq ? 0.0 : -cr[0] + (p->dist ? F->r_sl / F->Dsl : 0.0);
-            if (!lamblock_factor(F, v, Kb, F->Jl[0], lsq ? 0.0 : dc + (p->dist ? 1.0 / F->Dsl : 0.0))) {
+            F->Cp[v][0] = F->Cp[v][1] = F->Cp[v][2] = 0; F->rk[v] = (lsq ? 0.0 : -cr[0]) + (p->dist ? F->r_sl / F->Dsl : 0.0);   /* (the eliminated norm-row slack of ParkingDist stays in the least-squares system too) */
+            if (!lamblock_factor(F, v, Kb, F->Jl[0], (lsq ? 0.0 : dc) + (p->dist ? 1.0 / F->Dsl : 0.0))) {
                 ok = 0;
                 if (getenv("OBCA_DBG")) fprintf(stderr, "lamblock fail k=%d j=%d y1=%g dw=%g\n", k, j, y[0], dw);
             }
@@ -1482,6 +1482,23 @@ int obca_oracle_layout(int N, int nOb, const int *vOb, int *out /* 26 ints */) {
 }
 
 /* one regularised Newton direction at a full primal-dual point z (oracle layout); returns inertia-ok flag */
+/* the least-squares multiplier step at z (what recalc_y and lsq_init take): d[pi .. zxL) = the increment of the equality multipliers; tests/test_oracle_cpu.py pins it against a
+ * dense solve of [I J'; J 0] with autograd derivatives */
+int obca_oracle_lsq_multipliers(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
+                                const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *rx,
+                                const double *ry, const double *ryaw, const double *z, double *d, int dist) {
+    prob_t p; lay_t l;
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, 0);
+    p.dist = dist;
+    make_layout(&p, &l);
+    kkt_t *K = kkt_alloc(&p, &l);
+    kkt_assemble(K, z, 0.0, 0, 0, 1);
+    stage_dual_inf(K, z);
+    int ok = kkt_solve(K, z, 0.0, 0, 0.0, 1, d);
+    kkt_free(K);
+    return ok;
+}
+
 int obca_oracle_newton(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
                        const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *rx,
                        const double *ry, const double *ryaw, const double *z, double mu, double dw, double dc, double rho,

@@ -70,6 +70,16 @@ static int newton_impl(int N, const double *prob, const double *zin, int len, do
     free_scratch(s);
     return ok;
 }
+// the least-squares multiplier step of the kernels (ph_recalc_y: recalc_y / lsq_init) at a given point: dout = z_after - z_before (non-zero on [pi, zxL) only)
+int emu_lsq(int N, const double *prob, const double *zin, int len, double *dout) {
+    Scratch s; alloc_scratch(N, len, s);
+    memcpy(s.z, zin, sizeof(double) * len);
+    setup(N, prob, s);
+    const int ok = ph_recalc_y(0);
+    for (int i = 0; i < len; i++) dout[i] = s.z[i] - zin[i];
+    free_scratch(s);
+    return ok;
+}
 int emu_newton(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau,
                double *dout, double *aux /* dinf,pinf,cinf0,cinfmu,f,th1,bar,ap,az,gd */) {
     return newton_impl(N, prob, zin, len, mu, dw, dc, rho, tau, dout, aux, -1.0, 0.0, nullptr);

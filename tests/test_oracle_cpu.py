@@ -176,6 +176,65 @@ def test_newton_direction_vs_dense_autograd(oracle, backwards, dist):
     assert abs(errs[0] - np.abs(rd).max()) < 1e-9 * np.abs(rd).max() and abs(errs[1] - np.abs(c).max()) < 1e-12
 
 
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_least_squares_multipliers_vs_dense_autograd(oracle, emu, backwards, dist):
+    """recalc_y / lsq_init: the least-squares multiplier estimate through the structured solve (unit Hessian on every variable, z-form gradients, zero constraint right-hand
+    side) == the dense solve of [I J'; J 0](w, y) = (-(grad f - zL + zU), 0) with autograd derivatives -- for the oracle AND for the kernels' phases (host emulation), at a random
+    interior point far from a solution"""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from nlp_ref import ParkingNLP
+    import packing as P
+    rng = np.random.default_rng(5)
+    N = 5; sc = S.BACKWARDS; A, b, v = backwards["A"], backwards["b"], backwards["vOb"]; nOb = len(v); M = int(v.sum())
+    x0 = np.array([-6, 9.5, 0.1, 0.]); Ts, xWS, uWS = S.warm_start_backwards(x0, sc["xF"], N); Ts = 0.6
+    nlp = ParkingNLP(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], dist=dist)
+    L = oracle.layout(N, v)
+    z = np.zeros(L["len"])
+    X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 4)); X[0] = x0
+    z[L["x"]:L["x"] + 4 * (N + 1)] = X.reshape(-1)
+    z[L["u"]:L["u"] + 2 * N] = np.clip(uWS + 0.05 * rng.standard_normal((N, 2)), -0.3, 0.3).reshape(-1)
+    z[L["t"]] = 1.05
+    for k, lo, hi in (("lam", 0.1, 1), ("mu", 0.1, 1), ("so", 0.1, 1), ("ss", -0.3, 0.3)):
+        n_ = L[oracle.LAYOUT_FIELDS[oracle.LAYOUT_FIELDS.index(k) + 1]] - L[k]
+        z[L[k]:L[k] + n_] = rng.uniform(lo, hi, n_)
+    z[L["sl"]:L["so"]] = rng.uniform(0.1, 1, L["so"] - L["sl"]) if dist else 0.01 * rng.standard_normal(L["so"] - L["sl"])
+    z[L["pi"]:L["zxL"]] = rng.standard_normal(L["zxL"] - L["pi"])
+    z[L["zxL"]:] = rng.uniform(0.1, 2, L["len"] - L["zxL"])
+
+    def to_ref(w):
+        vv = np.zeros(nlp.n)
+        vv[nlp.ix] = w[L["x"] + 4:L["x"] + 4 * (N + 1)]; vv[nlp.it] = w[L["t"]]; vv[nlp.iu] = w[L["u"]:L["u"] + 2 * N]
+        vv[nlp.il] = w[L["lam"]:L["lam"] + M * (N + 1)]; vv[nlp.im] = w[L["mu"]:L["mu"] + 4 * nOb * (N + 1)]
+        vv[nlp.isl] = w[L["sl"]:L["sl"] + nOb * (N + 1)]; vv[nlp.iss] = w[L["ss"]:L["ss"] + N]; vv[nlp.iso] = w[L["so"]:L["so"] + nOb * (N + 1)]
+        return vv
+    ym = lambda w: np.concatenate([w[L["pi"]:L["pi"] + 4 * N], w[L["nu"]:L["nu"] + 4], w[L["yg"]:L["yg"] + N], w[L["yo"]:L["yo"] + 4 * nOb * (N + 1)]])
+    vv, y = to_ref(z), ym(z)
+    f, g, c, J, H = nlp.eval_all(vv, y)
+    n, m = nlp.n, nlp.m
+    zL = np.zeros(n); zU = np.zeros(n)
+    zL[nlp.ix] = z[L["zxL"]:L["zxL"] + 4 * (N + 1)].reshape(N + 1, 4)[1:].reshape(-1)
+    zU[nlp.ix] = z[L["zxU"]:L["zxU"] + 4 * (N + 1)].reshape(N + 1, 4)[1:].reshape(-1)
+    zL[nlp.it] = z[L["ztL"]]; zU[nlp.it] = z[L["ztU"]]
+    zL[nlp.iu] = z[L["zuL"]:L["zuL"] + 2 * N]; zU[nlp.iu] = z[L["zuU"]:L["zuU"] + 2 * N]
+    zL[nlp.il] = z[L["zlam"]:L["zlam"] + M * (N + 1)]; zL[nlp.im] = z[L["zmu"]:L["zmu"] + 4 * nOb * (N + 1)]
+    zL[nlp.iso] = z[L["zso"]:L["zso"] + nOb * (N + 1)]
+    zL[nlp.isl] = z[L["zs1"]:L["zs1"] + nOb * (N + 1)]
+    zL[nlp.iss] = z[L["zssL"]:L["zssL"] + N]; zU[nlp.iss] = z[L["zssU"]:L["zssU"] + N]
+    IL = np.isfinite(nlp.lb); IU = np.isfinite(nlp.ub); zL[~IL] = 0; zU[~IU] = 0
+    K = np.block([[np.eye(n), J.T], [J, np.zeros((m, m))]])
+    sol = np.linalg.solve(K, -np.concatenate([g - nlp.mult * zL + nlp.mult * zU, np.zeros(m)]))       # y_new = sol[n:] (absolute); the structured solves return y_new - y
+    ok, d = oracle.lsq_multipliers(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, dist=dist)
+    assert ok == 1
+    scale = max(1.0, np.abs(sol[n:]).max())
+    assert np.abs(y + ym(d) - sol[n:]).max() < 1e-9 * scale
+    assert np.abs(sol[n:] - y).max() > 0.1                       # far from a solution: the estimate is not the multiplier at hand
+    prob = P.pack_problem(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
+    d2 = np.zeros_like(z); D_ = C.POINTER(C.c_double)
+    assert emu.emu_lsq(C.c_int(N), prob.ctypes.data_as(D_), z.ctypes.data_as(D_), C.c_int(L["len"]), d2.ctypes.data_as(D_)) == 1
+    assert np.abs(y + ym(d2) - sol[n:]).max() < 1e-9 * scale and np.abs(d2[:L["pi"]]).max() == 0 and np.abs(d2[L["zxL"]:]).max() == 0
+
+
 def test_oracle_fixtime_and_retry_paths(oracle, backwards):
     N = 30
     x0 = np.array([-3.0, 8.5, 0.05, 0.0]); sc = S.BACKWARDS
