@@ -1482,6 +1482,26 @@ int obca_oracle_layout(int N, int nOb, const int *vOb, int *out /* 26 ints */) {
 }
 
 /* one regularised Newton direction at a full primal-dual point z (oracle layout); returns inertia-ok flag */
+/* the Newton system of z with GIVEN constraint values on the right-hand side (what a second-order correction solves: csoc in the layout pi | nu | yg | yo);
+ * tests/test_oracle_cpu.py pins it against a dense solve with autograd derivatives */
+int obca_oracle_newton_soc(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,
+                           const double *xF, int nOb, const int *vOb, const double *A, const double *b, const double *rx,
+                           const double *ry, const double *ryaw, const double *z, double mu, double dw, double dc, double rho,
+                           const double *csoc, double *d, int dist) {
+    prob_t p; lay_t l;
+    setup_prob(&p, N, Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, 0);
+    p.dist = dist;
+    make_layout(&p, &l);
+    kkt_t *K = kkt_alloc(&p, &l);
+    K->csoc = csoc;
+    int ok = kkt_assemble(K, z, mu, dw, dc, 0);
+    stage_dual_inf(K, z);
+    if (ok) ok = kkt_solve(K, z, mu, dc, rho, 0, d);
+    K->csoc = NULL;
+    kkt_free(K);
+    return ok;
+}
+
 /* the least-squares multiplier step at z (what recalc_y and lsq_init take): d[pi .. zxL) = the increment of the equality multipliers; tests/test_oracle_cpu.py pins it against a
  * dense solve of [I J'; J 0] with autograd derivatives */
 int obca_oracle_lsq_multipliers(int N, double Ts, double L, const double ego[4], const double XYb[4], int fixTime, const double *x0,

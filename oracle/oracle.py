@@ -134,6 +134,17 @@ def ref_constraints(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, xp, up, t, lp, n
                                              C.c_int(len(vOb_)), pv, a[4][1], a[5][1], a[6][1], a[7][1], C.c_double(t), a[8][1], a[9][1], C.c_int(int(sd)))
 
 
+def newton_soc(N, Ts, L, ego, XYbounds, fixTime, x0, xF, vOb, A, b, rx, ry, ryaw, z, mu, dw, dc, csoc, rho=1e3, dist=0):
+    """Newton system of z with the constraint values csoc (layout pi | nu | yg | yo) on the right-hand side: the step of a second-order correction"""
+    vOb_, pv = _i(vOb); nOb = len(vOb_)
+    a = [_d(v) for v in (ego, XYbounds, x0, xF, A, b, rx, ry, ryaw, z, csoc)]
+    d = np.zeros_like(a[9][0])
+    ok = lib().obca_oracle_newton_soc(C.c_int(N), C.c_double(Ts), C.c_double(L), a[0][1], a[1][1], C.c_int(int(fixTime)), a[2][1], a[3][1],
+                                      C.c_int(nOb), pv, a[4][1], a[5][1], a[6][1], a[7][1], a[8][1], a[9][1], C.c_double(mu),
+                                      C.c_double(dw), C.c_double(dc), C.c_double(rho), a[10][1], d.ctypes.data_as(_D), C.c_int(int(dist)))
+    return ok, d
+
+
 def lsq_multipliers(N, Ts, L, ego, XYbounds, fixTime, x0, xF, vOb, A, b, rx, ry, ryaw, z, dist=0):
     """least-squares multiplier step at z (recalc_y / lsq_init): returns (ok, d) with d[pi:zxL] = the increment of the equality multipliers"""
     vOb_, pv = _i(vOb); nOb = len(vOb_)

@@ -70,6 +70,24 @@ static int newton_impl(int N, const double *prob, const double *zin, int len, do
     free_scratch(s);
     return ok;
 }
+// the kernels' second-order-correction step at a given point for given constraint values csoc (layout pi | nu | yg | yo): the SOC = 1 instantiations of the phases
+int emu_newton_soc(int N, const double *prob, const double *zin, int len, double mu, double dw, double dc, double rho, double tau, const double *csoc, double *dout) {
+    Scratch s; alloc_scratch(N, len, s);
+    memcpy(s.z, zin, sizeof(double) * len);
+    setup(N, prob, s); Shared &sh = g_sh; Inst &I = sh.inst;
+    memcpy(s.csoc, csoc, sizeof(double) * (sh.l.zxL - sh.l.pi));
+    AsmOut A; const FuseArgs nf = {0, 0, 0, 0, 0};
+    if (sh.vmc == 0) assemble_obs<2, 0, 1>(I, sh, mu, dw, dc, nf); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0, 1>(I, sh, mu, dw, dc, nf); else assemble_obs<OB_VMAX, 0, 1>(I, sh, mu, dw, dc, nf);
+    assemble_stage<0, 1>(I, sh, mu, dw, dc, nf, A);
+    int ok = A.ok;
+    StepOut S; S.ap = S.az = S.gd = 0;
+    if (ok) ok = riccati_backward<1>(I, sh, rho);
+    if (ok) { direction_main<1>(I, sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; }
+    if (ok) { if (sh.vmc == 0) direction_obs<2, 1, 1>(I, sh, mu, dw, dc, tau, S); else if (sh.vmc == 1) direction_obs<OB_VMID, 1, 1>(I, sh, mu, dw, dc, tau, S); else direction_obs<OB_VMAX, 1, 1>(I, sh, mu, dw, dc, tau, S); }
+    memcpy(dout, s.d, sizeof(double) * len);
+    free_scratch(s);
+    return ok;
+}
 // the least-squares multiplier step of the kernels (ph_recalc_y: recalc_y / lsq_init) at a given point: dout = z_after - z_before (non-zero on [pi, zxL) only)
 int emu_lsq(int N, const double *prob, const double *zin, int len, double *dout) {
     Scratch s; alloc_scratch(N, len, s);

@@ -117,7 +117,7 @@ def test_oracle_config3_parallel_parking_golden_and_reference_checker(oracle):
 
 
 @pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
-def test_newton_direction_vs_dense_autograd(oracle, backwards, dist):
+def test_newton_direction_vs_dense_autograd(oracle, emu, backwards, dist):
     """closed-form derivatives + condensation + Riccati + border == dense solve of the autograd KKT system
     (both formulations: ParkingSignedDist and the next-1 sibling ParkingDist)"""
     torch = pytest.importorskip("torch")
@@ -174,6 +174,20 @@ def test_newton_direction_vs_dense_autograd(oracle, backwards, dist):
     assert np.abs(ym(d) - sol[n:]).max() < 1e-8 * max(1, np.abs(sol[n:]).max())
     rd = g + J.T @ y - nlp.mult * zL + nlp.mult * zU
     assert abs(errs[0] - np.abs(rd).max()) < 1e-9 * np.abs(rd).max() and abs(errs[1] - np.abs(c).max()) < 1e-12
+    # second-order correction: the same matrix, GIVEN constraint values on the right-hand side (c_soc = alpha c(z) + c(trial) in the solver) -- oracle and kernel phases
+    csoc = 0.3 * c + 0.05 * rng.standard_normal(m)
+    cfull = np.zeros(L["zxL"] - L["pi"]); cfull[:] = csoc          # (pi | nu | yg | yo are contiguous in the layout, in the order of the dense rows)
+    sol2 = np.linalg.solve(K, -np.concatenate([gphi + J.T @ y, csoc]))
+    ok2, d2 = oracle.newton_soc(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, mu, dw, dc, cfull, dist=dist)
+    assert ok2 == 1 and np.abs(to_ref(d2) - sol2[:n]).max() < 1e-9 * max(1, np.abs(sol2[:n]).max()) and np.abs(ym(d2) - sol2[n:]).max() < 1e-8 * max(1, np.abs(sol2[n:]).max())
+    assert np.abs(sol2[:n] - sol[:n]).max() > 1e-3                 # it is a different step
+    import ctypes as C, packing as P
+    D_ = C.POINTER(C.c_double)
+    prob = P.pack_problem(x0, sc["xF"], N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
+    d3 = np.zeros_like(z)
+    assert emu.emu_newton_soc(C.c_int(N), prob.ctypes.data_as(D_), z.ctypes.data_as(D_), C.c_int(L["len"]), C.c_double(mu), C.c_double(dw), C.c_double(dc), C.c_double(1e3),
+                              C.c_double(0.99), cfull.ctypes.data_as(D_), d3.ctypes.data_as(D_)) == 1
+    assert np.abs(to_ref(d3) - sol2[:n]).max() < 1e-9 * max(1, np.abs(sol2[:n]).max()) and np.abs(ym(d3) - sol2[n:]).max() < 1e-8 * max(1, np.abs(sol2[n:]).max())
 
 
 @pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
