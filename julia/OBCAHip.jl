@@ -97,10 +97,10 @@ function ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b
 end
 
 "Drop-in for ParkingSignedDist.jl:29 (one instance): same arguments, same 7-tuple."
-function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
+function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS; opts=nothing)      # opts: `ipopt_opts()` = the reference's IPOPT semantics switched on
     xp, up, ts, ef, t, lp, np = ParkingSignedDist_batch(reshape(f64(vec(x0)), 4, 1), reshape(f64(vec(xF)), 4, 1), N, [Float64(Ts)], L, ego,
         XYbounds, nOb, vOb, A, b, reshape(f64(rx)[1:N+1], N + 1, 1), reshape(f64(ry)[1:N+1], N + 1, 1), reshape(f64(ryaw)[1:N+1], N + 1, 1),
-        fixTime, reshape(permutedims(f64(xWS)[1:N+1, :]), 4, N + 1, 1), reshape(permutedims(f64(uWS)[1:N, :]), 2, N, 1))
+        fixTime, reshape(permutedims(f64(xWS)[1:N+1, :]), 4, N + 1, 1), reshape(permutedims(f64(uWS)[1:N, :]), 2, N, 1); opts=opts)
     timeScalep = fixTime == 1 ? ones(1, N + 1) : ts[:, 1]          # ParkingSignedDist.jl:304-308
     return xp[:, :, 1], up[:, :, 1], timeScalep, Int(ef[1]), t, lp[:, :, 1], np[:, :, 1]
 end
