@@ -130,8 +130,8 @@ struct Opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
-struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, reserved_; };      // obca_opts of the C ABI: the interior-point options + max_soc, second-order correction trials per iteration (IPOPT's default: 4; 0 = off,
-                                                          // the default here as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
+struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, reserved_; };      // obca_opts of the C ABI: the interior-point options + the three IPOPT switches (max_soc: second-order correction trials per iteration,
+                                                          // IPOPT's default 4; recalc_y; lsq_init; all 0 = off by default, as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
 struct Lay {
     int x, u, t, lam, mu, sl, so, ss, pi, nu, yg, yo, zxL, zxU, zuL, zuU, ztL, ztU, zlam, zmu, zso, zssL, zssU, zs1, nprimal, len;   // zs1: multiplier of the norm-row slack (ParkingDist only)
@@ -181,7 +181,8 @@ struct Drv {                // state of the interior-point driver (wave-uniform;
     double mu, tau, dw, dw_last, dc_mu, dc_val, th_min, th_max, f, pinf, dinf, sd, sc, cm, th, phi, gd, az, pw_th, pw_gd, amin, alpha;
     int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc;
 };
-struct Soc {                // second-order correction (cold path; at the END of Shared: nothing the phases address moves)
+struct Soc {                // state of the three IPOPT switches (second-order correction, recalc_y, least-squares initial multipliers: cold paths); at the END of Shared, so that
+                            // nothing the phases of the default path address moves (their code is instruction-for-instruction that of the build without the switches)
     gdbl *csoc;             // c_soc = alpha c(z) + c(z + alpha d) of the instance, layout pi | nu | yg | yo as in the iterate (null unless max_soc > 0)
     int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
     int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
