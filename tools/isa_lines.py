@@ -1,5 +1,5 @@
 """Which SOURCE LINES the instructions of a phase function come from: python tools/isa_lines.py ph_fused2 [top-level-loop-index] [N]
-(hipcc -save-temps -gline-tables-only; per source line of obca_solver.h / obca_model.h: instructions by class inside the chosen Depth-1 loop of the function, largest first).
+(loop index past the last loop = the code outside the loops; hipcc -save-temps -gline-tables-only; per source line of obca_solver.h / obca_model.h: instructions by class inside the chosen Depth-1 loop of the function, largest first).
 Companion of tools/isa_mix.py; read next to profiles/r03_pmc_sq_counters.txt."""
 import collections, os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,10 +44,10 @@ while i < len(L):
             m2 = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", ln)
             if m2: loc = (int(m2.group(1)), int(m2.group(2))); continue
             t = ln.split()
-            if t and not t[0].startswith((";", ".")) and not t[0].endswith(":") and cur:
+            if t and not t[0].startswith((";", ".")) and not t[0].endswith(":"):
                 c = cls(t[0])
-                if c: loops.setdefault(cur, collections.defaultdict(collections.Counter))[loc][c] += 1
-        keys = [k for k in loops if k != "hdr"]
+                if c: loops.setdefault(cur or "outside", collections.defaultdict(collections.Counter))[loc][c] += 1
+        keys = [k for k in loops if k not in ("hdr", "outside")] + ["outside"]
         key = keys[which] if which < len(keys) else (keys[-1] if keys else "hdr")
         tab = loops.get(key, {})
         tot = collections.Counter()
