@@ -36,6 +36,7 @@ typedef struct {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
     int lsq_init, verbose;
+    int max_soc;      /* second-order correction trials per iteration (IPOPT's default: 4); 0 = off (default; environment OBCA_QSOC: tools/soc_probe.py --quad) */
 } opts_t;
 
 void obca_oracle_quad_default_opts(opts_t *o) {
@@ -48,6 +49,7 @@ void obca_oracle_quad_default_opts(opts_t *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
+    o->max_soc = getenv("OBCA_QSOC") ? atoi(getenv("OBCA_QSOC")) : 0;
 }
 
 /* model constants, QuadcopterSignedDist.jl:51-62 */
@@ -257,6 +259,7 @@ typedef struct {
     double (*P)[NS][NS], (*K)[NU][NS], (*Lq)[NU * NU];
     double (*pv)[NC][NS], (*kf)[NC][NU], (*ds)[NC][NS], (*du)[NC][NU], (*pic)[NC][NXS];
     double dinf, pinf, cinf0, cinfmu, sumy, sumz; int nb, nm;
+    const double *csoc;      /* second-order correction: constraint values that replace c(v) on the right-hand side (layout pi | nu | yo), or NULL */
 } kkt_t;
 static kkt_t *kkt_alloc(const model_t *M) {
     kkt_t *K = xcalloc(1, sizeof *K); int N1 = M->p->N + 1; K->M = M; K->N = M->p->N;
@@ -323,7 +326,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
               if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_so = gs + b.gb; F->Dso = b.Sig + dw; }
             /* row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2 */
             F->T2 = 1e-4 / F->Ds + 1.0 / F->Dso + dc; F->iT2 = 1.0 / F->T2;
-            F->r2 = -F->c[1] + 0.01 * F->r_s / F->Ds - F->r_so / F->Dso;
+            F->r2 = -(K->csoc ? K->csoc[l->yo + 2 * bo + 1] : F->c[1]) + 0.01 * F->r_s / F->Ds - F->r_so / F->Dso;
             for (int i = 0; i < 3; i++) { hz[i] += F->q[i] * yv[1]; hb[i] += F->q[i] * yv[1]; }
             double Hb[NL * NL];
             for (int i = 0; i < NL; i++) {
@@ -336,7 +339,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 for (int c_ = 0; c_ < 3; c_++) F->Cp[i][c_] = (c_ == a ? yv[1] * sg : 0.0) + F->g2[i] * F->q[c_] * F->iT2;
                 F->rk[i] = -rl_b[i] + F->g2[i] * F->r2 * F->iT2;
             }
-            F->rk[NL] = -F->c[0];
+            F->rk[NL] = -(K->csoc ? K->csoc[l->yo + 2 * bo] : F->c[0]);
             if (!lamblock_factor(F, Hb, F->g1, dc)) { ok = 0; if (getenv("OBCA_DBG")) fprintf(stderr, "lamblock fail k=%d j=%d\n", k, j); }
             double Z[NL + 1][4];
             for (int c_ = 0; c_ < 4; c_++) { double col[NL + 1]; for (int i = 0; i < NL; i++) col[i] = c_ < 3 ? F->Cp[i][c_] : F->rk[i]; col[NL] = c_ < 3 ? 0 : F->rk[NL];
@@ -366,7 +369,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 for (int c_ = 0; c_ < NV; c_++) { int id = VIDX[c_]; if (id < NXS) K->A[k][i][id] += tau * dg[i][c_]; else K->B[k][i][id - NS] += tau * dg[i][c_]; }
                 K->Ft[k][i] = p->Ts * g[i];
                 double r = v[l->x + NXS * (k + 1) + i] - x[i] - tau * g[i];
-                K->dd[k][i] = -r; if (fabs(r) > pmax) pmax = fabs(r); sumy += fabs(pi[i]);
+                K->dd[k][i] = -(K->csoc ? K->csoc[l->pi + NXS * k + i] : r); if (fabs(r) > pmax) pmax = fabs(r); sumy += fabs(pi[i]);
             }
             nm += NXS;
             /* Lagrangian Hessian of -pi'(t Ts g): -tau sum pi_i Hess g_i on the local variables; cross terms with t: -Ts pi'dg */
@@ -412,7 +415,7 @@ static int kkt_solve(kkt_t *K, const double *v, double dc, double rho, double *d
     double e[NXS];
     memset(K->P[N], 0, sizeof K->P[N]); memset(K->pv[N], 0, sizeof K->pv[N]);
     for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) K->P[N][i][j] = K->H[N][i][j];
-    for (int i = 0; i < NXS; i++) { e[i] = -(v[l->x + NXS * N + i] - p->xF[i]); K->P[N][i][i] += rho; }
+    for (int i = 0; i < NXS; i++) { e[i] = -(K->csoc ? K->csoc[l->nu + i] : v[l->x + NXS * N + i] - p->xF[i]); K->P[N][i][i] += rho; }
     for (int i = 0; i < NS; i++) { K->pv[N][0][i] = K->hb[N][i]; K->pv[N][1][i] = K->Ht[N][i]; }
     for (int i = 0; i < NXS; i++) { K->pv[N][0][i] -= rho * e[i]; K->pv[N][2 + i][i] = 1.0; }
     for (int k = N - 1; k >= 0; k--) {
@@ -564,12 +567,26 @@ static void restore_blocks(const model_t *M, const opts_t *o, double *v, double 
 }
 
 /* -------------------------------------------------------------- interior-point driver */
+/* equality rows at v in the layout of the multipliers (pi | nu | yo), as the assembly forms them: what a second-order correction accumulates */
+static void constraint_values(const model_t *M, const double *v, double *c) {
+    const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N; double tau = v[l->t] * p->Ts;
+    for (int k = 0; k < N; k++) {
+        double g[NXS]; const double *x = v + l->x + NXS * k;
+        dyn_g(p, x, v + l->u + NU * k, g, NULL, NULL, NULL);
+        for (int i = 0; i < NXS; i++) c[l->pi + NXS * k + i] = v[l->x + NXS * (k + 1) + i] - x[i] - tau * g[i];
+    }
+    for (int i = 0; i < NXS; i++) c[l->nu + i] = v[l->x + NXS * N + i] - p->xF[i];
+    for (int k = 0; k <= N; k++) for (int j = 0; j < NOB; j++) { int bo = k * NOB + j; double q[3];
+        obs_rows(p, j, v + l->x + NXS * k, v + l->lam + NL * bo, v[l->s + bo], v[l->so + bo], c + l->yo + 2 * bo, q); }
+}
 typedef struct { int status, iters, nreg; double obj, pinf, dinf, mu, t; } result_t;
 enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 #define FILT_MAX 4096
 
 #define RESTORE_AND_CONTINUE do { restore_blocks(M, o, v, y, zL); nrest++; mu = o->mu_init; tau = fmax(o->tau_min, 1 - mu); nf = 0; dw_last = 0; \
         eval_f_theta(M, v, &f, &th, &thinf); th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th); goto next_iter; } while (0)
+static int g_nsoc = 0, g_nsoc_acc = 0;      /* diagnostic: corrections tried / accepted (process-wide) */
+int obca_oracle_quad_soc_counts(int *acc) { if (acc) *acc = g_nsoc_acc; return g_nsoc; }
 static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, double *zL, double *zU, result_t *res) {
     const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, n = l->n, m = l->m;
     kkt_t *K = kkt_alloc(M);
@@ -673,6 +690,52 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
                     else if (tht <= (1 - o->gamma_theta) * th || pht <= phi - o->gamma_phi * th) { acc = 1;
                         if (!(sw && armijo) && nf < FILT_MAX) { filt[nf][0] = (1 - o->gamma_theta) * th; filt[nf][1] = phi - o->gamma_phi * th; nf++; } break; }
                 }
+            }
+            /* second-order correction (IPOPT A-5.5..A-5.9, kappa_soc = 0.99): after a rejected FIRST trial step that did not reduce theta; option max_soc */
+            if (o->max_soc > 0 && alpha == ap && ft == ft && tht == tht && tht >= th) {
+                double *cs = xcalloc(m, 8), *ct = xcalloc(m, 8), *dvs = xcalloc(n, 8), *dys = xcalloc(m, 8);
+                double th_old = 0, th_tr = tht, asoc = alpha, azs = az;
+                constraint_values(M, v, cs);
+                for (int ps = 0; ps < o->max_soc && !acc && (ps == 0 || th_tr <= 0.99 * th_old); ps++) {
+                    th_old = th_tr;
+                    constraint_values(M, vt, ct);
+                    for (int i = 0; i < m; i++) cs[i] = asoc * cs[i] + ct[i];
+                    K->csoc = cs;
+                    int a = kkt_assemble(K, v, y, zL, zU, mu, dw, dc);
+                    stage_dual_inf(K, y);
+                    if (a) a = kkt_solve(K, v, dc, o->rho_term, dvs, dys);
+                    K->csoc = NULL;
+                    if (!a) break;
+                    asoc = 1; azs = 1;
+                    for (int i = 0; i < n; i++) {
+                        if (i >= l->x && i < l->x + NXS) continue;
+                        if (isfinite(M->lb[i])) { double d = v[i] - M->lb[i], dz = mu / d - zL[i] - zL[i] / d * dvs[i]; if (dvs[i] < 0) asoc = fmin(asoc, -tau * d / dvs[i]); if (dz < 0) azs = fmin(azs, -tau * zL[i] / dz); }
+                        if (isfinite(M->ub[i])) { double d = M->ub[i] - v[i], dz = mu / d - zU[i] + zU[i] / d * dvs[i]; if (dvs[i] > 0) asoc = fmin(asoc, tau * d / dvs[i]); if (dz < 0) azs = fmin(azs, -tau * zU[i] / dz); }
+                    }
+                    for (int i = 0; i < n; i++) vt[i] = v[i] + asoc * dvs[i];
+                    eval_f_theta(M, vt, &ft, &tht, &thi); g_nsoc++;
+                    if (!(ft == ft && tht == tht)) break;
+                    th_tr = tht;
+                    if (tht < th_max) {
+                        double pht = ft - mu * barrier_sum(M, vt); int okf = (pht == pht);
+                        for (int i = 0; i < nf && okf; i++) if (!(tht < filt[i][0] || pht < filt[i][1])) okf = 0;
+                        if (okf) {
+                            int sw = gd < 0 && alpha * pow(-gd, o->s_phi) > o->delta * pow(th, o->s_theta), armijo = pht <= phi + o->eta_phi * alpha * gd;
+                            if (th <= th_min && sw) { if (armijo) acc = 1; }
+                            else if (tht <= (1 - o->gamma_theta) * th || pht <= phi - o->gamma_phi * th) { acc = 1;
+                                if (!(sw && armijo) && nf < FILT_MAX) { filt[nf][0] = (1 - o->gamma_theta) * th; filt[nf][1] = phi - o->gamma_phi * th; nf++; } }
+                        }
+                    }
+                    if (acc) {      /* the correction is the step: its multiplier steps with it */
+                        memcpy(dv, dvs, sizeof(double) * n); memcpy(dy, dys, sizeof(double) * m); alpha = asoc; az = azs; g_nsoc_acc++;
+                        for (int i = 0; i < n; i++) { dzL[i] = dzU[i] = 0; if (i >= l->x && i < l->x + NXS) continue;
+                            if (isfinite(M->lb[i])) { double d = v[i] - M->lb[i]; dzL[i] = mu / d - zL[i] - zL[i] / d * dv[i]; }
+                            if (isfinite(M->ub[i])) { double d = M->ub[i] - v[i]; dzU[i] = mu / d - zU[i] + zU[i] / d * dv[i]; } }
+                    }
+                }
+                free(cs); free(ct); free(dvs); free(dys);
+                if (acc) break;
+                kkt_assemble(K, v, y, zL, zU, mu, dw, dc); stage_dual_inf(K, y);      /* (the workspace holds the correction system: back to the iteration's own, as the block records are used again) */
             }
             alpha *= 0.5;
         }
