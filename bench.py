@@ -261,6 +261,101 @@ def obstacle_args(cfg, rows, shared, n):
     return vl, Al, bl
 
 
+# ---------------------------------------------------------------- pieces shared by the extra legs of the default line (outside the timed region, never `value`)
+def validated_mask(cfg, rows, shared, out, N):
+    """which instances of a downloaded batch (Batch.download / QuadBatch.download) count: exit flag 1 AND the a-posteriori checker accepts the trajectory at 1e-4"""
+    from obca_amd import validate as V
+    B = len(out["exitflag"]); ok = np.zeros(B, bool)
+    if CONFIGS[cfg]["kind"] == "quad":
+        for i in np.flatnonzero(out["exitflag"] == 1):
+            ok[i] = V.validate_quadcopter(out["xp"][i], out["up"][i], out["timeScale"][i], rows["x0"][i], rows["xF"][i], rows["Ts"][i, 0], out["lp"][i], shared["ob"], shared["R"])[0]
+        return ok
+    vOb, A, b = obstacle_args(cfg, rows, shared, B)
+    for i in np.flatnonzero(out["exitflag"] == 1):
+        v = np.ravel(vOb[i] if cfg == 5 else vOb)
+        ok[i] = V.validate_parking(rows["x0"][i], rows["xF"][i], N, rows["Ts"][i, 0], shared["L"], shared["ego"], shared["XYbounds"], v, A[i] if cfg == 5 else A, b[i] if cfg == 5 else b,
+                                   out["xp"][i], out["up"][i], out["timeScale"][i], out["lp"][i], out["np"][i], out["sl"][i], tol=1e-4)[0]
+    return ok
+
+
+def device_batches(cfg, rows, shared, B, N, nS, local):
+    """nS device-resident copies of one host batch, each with its own context / HIP stream"""
+    import obca_amd
+    out = []
+    for _ in range(nS):
+        ctx = obca_amd.Context(local)
+        if CONFIGS[cfg]["kind"] == "quad":
+            bq = obca_amd.QuadBatch(ctx, B, N)
+            bq.upload(rows["x0"], rows["xF"], rows["Ts"][:, 0], shared["R"], shared["ob"], rows["xWS"].reshape(B, N + 1, 12), rows["timeWS"][:, 0])
+        else:
+            vOb, A, b = obstacle_args(cfg, rows, shared, B)
+            xWS = rows["xWS"].reshape(B, N + 1, 4); uWS = rows["uWS"].reshape(B, N, 2)
+            bq = obca_amd.Batch(ctx, B, N)
+            bq.upload(rows["x0"], rows["xF"], rows["Ts"][:, 0], shared["L"], shared["ego"], shared["XYbounds"], vOb, A, b, xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, uWS)
+        out.append(bq)
+    return out
+
+
+def pipelined_rate(batches, steps, warmup, opts=None):
+    """`steps` pipelined steps over the copies (step k on copy k mod nS, no host synchronisation in between); seconds of the timed steps"""
+    import torch
+    nS = len(batches)
+    for w in range(warmup):
+        batches[w % nS].solve(opts=opts, sync=False)
+    for bq in batches:
+        bq.sync()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        batches[k % nS].solve(opts=opts, sync=False)
+    for bq in batches:
+        bq.sync()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def other_config_line(cfg, local, steps=10, streams=4, seed=SEED):
+    """compact, driver-visible rate of another BASELINE config at its per-GPU batch size: `steps` pipelined steps, every instance validated; warm starts planned before the
+    timed steps (the planner is host code outside the path)"""
+    C_ = CONFIGS[cfg]; N = C_["N"]; B = C_["per_gpu"]
+    t0 = time.perf_counter(); rows, shared = make_host_batch(cfg, B, seed); t_make = time.perf_counter() - t0
+    bs = device_batches(cfg, rows, shared, B, N, streams, local)
+    dt = pipelined_rate(bs, steps, streams)
+    bs[0].solve(sync=True); k_ms = bs[0].kernel_ms(); k_ms = float(k_ms if CONFIGS[cfg]["kind"] == "quad" else k_ms[0])
+    out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
+    for bq in bs:
+        bq.close()
+    return dict(config=cfg, workload=C_["name"], batch_per_gpu=B, steps=steps, streams=streams, solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
+                validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
+                mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3), batch_made_in_s=round(t_make, 2))
+
+
+def ipopt_options_leg(cfg, rows, shared, B, N, nS, local, steps, out_default):
+    """the SAME batch solved with the reference's IPOPT configuration switched on (max_soc = 4, recalc_y = "yes", least-squares initial multipliers: obca_amd.ipopt_opts(),
+    ParkingSignedDist.jl:41-43 + IPOPT defaults): pipelined rate, iterations / passes, and how many instances end somewhere else than with the default options"""
+    import obca_amd
+    o = obca_amd.ipopt_opts()
+    bs = device_batches(cfg, rows, shared, B, N, nS, local)
+    dt = pipelined_rate(bs, steps, nS, opts=o)
+    bs[0].solve(opts=o, sync=True); k_ms = float(bs[0].kernel_ms()[0])
+    out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
+    for bq in bs:
+        bq.close()
+    both = (out["exitflag"] == 1) & (out_default["exitflag"] == 1)
+    dx = np.array([np.abs(np.asarray(out["xp"][i]) - np.asarray(out_default["xp"][i])).max() for i in range(B)])
+    du = np.array([np.abs(np.asarray(out["up"][i]) - np.asarray(out_default["up"][i])).max() for i in range(B)])
+    df = np.abs(out["obj"] - out_default["obj"]) / np.maximum(1.0, np.abs(out_default["obj"]))
+    dts = np.abs(out["timeScale"][:, 0] - out_default["timeScale"][:, 0])
+    differs = both & ((dx > 1e-3) | (du > 1e-3) | (df > 1e-4) | (dts > 1e-4))
+    return dict(options="max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
+                mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3),
+                exitflag_differs_from_default=int((out["exitflag"] != out_default["exitflag"]).sum()), iterations_differ_from_default=int((out["info"][:, 1] != out_default["info"][:, 1]).sum()),
+                solution_differs_from_default=int(differs.sum()), worst_dx=float(dx[both].max()) if both.any() else None, worst_rel_objective=float(df[both].max()) if both.any() else None,
+                note="solution_differs_from_default: instances solved by both settings whose states / inputs differ by more than 1e-3, time scale by 1e-4 or objective by 1e-4 relative "
+                     "(the path's stated tolerance, SURVEY 8c): the NLP is non-convex, another iteration path may end in another local solution; never `value`")
+
+
+
 def single_process(a):
     """ONE process, every visible GPU: the route a Julia caller takes (julia/OBCAHip.jl: MultiContext).  The host-pointer entry point cuts each call into chunks and the
     worker lanes of all devices pull them from one queue (include/obca_hip.h: obca_create_multi); inputs and outputs are host arrays, PCIe is inside the timed region."""
@@ -315,13 +410,27 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="the Julia route: ONE process drives every visible GPU through a multi-device context (obca_create_multi) and the "
                     "host-pointer entry point; a step = one call on batch x devices host-array instances, PCIe included (parking configs)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the run rocprofv3 wraps (one step + one synchronous step of the same batch, no output)")
+    ap.add_argument("--ipopt-options", action="store_true", help="parking configs: the TIMED steps run the reference's IPOPT configuration (max_soc = 4, recalc_y, least-squares initial "
+                    "multipliers: obca_amd.ipopt_opts()) instead of the library defaults")
+    ap.add_argument("--no-ipopt-leg", action="store_true", help="skip config.ipopt_options (the same batch with the reference's IPOPT configuration switched on)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (compact rates of BASELINE configs 4 and 5)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.single_process:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (the contract's launch line), so that an 8-GPU run cannot be lost to a missing torchrun
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     if a.pmc_child:
-        a.steps, a.warmup, a.streams, a.sync_steps, a.no_cpu_baseline, a.no_pmc, a.no_host_rate, a.no_distinct = 1, 0, 1, 1, True, True, True, True
+        a.steps, a.warmup, a.streams, a.sync_steps, a.no_cpu_baseline, a.no_pmc, a.no_host_rate, a.no_distinct, a.no_ipopt_leg, a.no_other_configs = 1, 0, 1, 1, True, True, True, True, True, True
     if a.single_process:
         return single_process(a)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus}, or without a launcher: bench.py starts its own ranks)")
     if a.steps < 1:
         raise SystemExit("bench.py: --steps must be >= 1")
     cfg = a.config; C = CONFIGS[cfg]; N = C["N"]; quad = C["kind"] == "quad"
@@ -379,14 +488,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_opts = obca_amd.ipopt_opts() if (a.ipopt_options and not quad) else None
     for w in range(a.warmup):
-        batches[w % nS].solve(sync=False)
+        batches[w % nS].solve(opts=run_opts, sync=False)
     for bq in batches:
         bq.sync()
     fence()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        batches[k % nS].solve(sync=False)   # queued behind the previous step of the same stream; overlaps the other streams
+        batches[k % nS].solve(opts=run_opts, sync=False)   # queued behind the previous step of the same stream; overlaps the other streams
     for bq in batches:
         bq.sync()
     fence()
@@ -394,7 +504,7 @@ def main():
     # ---- per-launch kernel time: synchronous steps of copy 0, one launch alone on the GPU, HIP events on the launch stream (outside the timed region)
     ipm_ms, dws_ms, sync_s = [], [], []
     for k in range(max(1, a.sync_steps)):
-        ts0 = time.perf_counter(); batches[0].solve(sync=True); sync_s.append(time.perf_counter() - ts0)
+        ts0 = time.perf_counter(); batches[0].solve(opts=run_opts, sync=True); sync_s.append(time.perf_counter() - ts0)
         m = batches[0].kernel_ms()
         if quad:
             ipm_ms.append(m)
@@ -452,6 +562,11 @@ def main():
     # ---- results: every copy solved the same inputs and must hold the same bits
     outs = [bq.download() for bq in batches[:min(nS, a.steps + a.warmup)]]
     out = outs[0]
+    ipopt_leg = None; others = None
+    if rank == 0 and world == 1 and not quad and not a.no_ipopt_leg and not a.ipopt_options:
+        ipopt_leg = ipopt_options_leg(cfg, rows, shared, B, N, nS, local, max(8, min(a.steps, 40)), out)
+    if rank == 0 and world == 1 and cfg == 2 and not a.no_other_configs:
+        others = [other_config_line(c_, local) for c_ in (4, 5)]
     same = all(np.array_equal(o["info"], out["info"]) and np.array_equal(np.asarray(o["xp"]), np.asarray(out["xp"])) for o in outs[1:])
     # ---- gather the full result tuple of every instance on rank 0 (one gather), validate there: a solve counts only if exitflag == 1 AND the
     # returned trajectory passes the a-posteriori checker (obca_amd/validate.py, pure numpy, outside the timed region)
@@ -565,6 +680,9 @@ def main():
                                    "every rank for its own slice; end_to_end = validated solves of one batch / (planning + one step): the planner, not the solve, bounds a "
                                    "pipeline that plans every instance afresh; never `value`"},
                        "distinct_batches": distinct,
+                       "options": "obca_amd.ipopt_opts(): max_soc = 4, recalc_y = yes, lsq_init = 1" if run_opts is not None else "library defaults (obca_default_opts)",
+                       "ipopt_options": ipopt_leg,
+                       "other_configs": others,
                        "host_pointer": host_rate,
                        "host_pointer_note": "obca_parking_signed_dist_batch on host arrays (the entry point the Julia shim binds): packing, PCIe both ways, kernels, unpacking; never `value`"},
             "roofline": roof,

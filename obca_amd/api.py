@@ -97,6 +97,13 @@ def default_opts():
     return o
 
 
+def ipopt_opts():
+    """the reference's IPOPT configuration as far as the kernels carry it: default options + second-order correction (IPOPT's default max_soc = 4), recalc_y = "yes"
+    (ParkingSignedDist.jl:41) and IPOPT's least-squares initial multipliers"""
+    o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
+    return o
+
+
 def _d(a):
     if a is None:
         return None, None

@@ -73,19 +73,20 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
 
 // instances resident per CU: registers allow 4 x OBCA_IPM_WAVES_PER_EU, LDS (static Shared + the horizon-sized dynamic part) may allow fewer -- ask the runtime
 static int parking_resident_per_cu(int N) {
-    static int cache[OB_NMAX + 1];                       // 0 = not asked yet
+    static std::atomic<int> cache[OB_NMAX + 1];          // 0 = not asked yet.  Worker lanes of several devices call this concurrently: atomics (the answer depends on the
+                                                         // code object and the horizon only -- every device of a context is a gfx950 with 160 KB of LDS per CU, obca_create_multi checks)
     if (N < 0 || N > OB_NMAX) return OBCA_RESIDENT_PER_CU;
-    if (!cache[N]) {
-        int n = 0;
+    int n = cache[N].load(std::memory_order_relaxed);
+    if (!n) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, obca_parking_ipm_kernel, OB_NT, OB_DYN_LDS_DOUBLES(N) * sizeof(double)) != hipSuccess || n < 1) n = OBCA_RESIDENT_PER_CU;
-        cache[N] = n;
+        cache[N].store(n, std::memory_order_relaxed);
     }
-    return cache[N];
+    return n;
 }
 
 // difficulty class of a parked instance (0..63, higher = dispatched earlier)
 __device__ inline int obca_slice_class(const double *st) {
-    const int nreg = (int)st[SL_NREG] + (int)st[SL_NREGPREV];
+    const int nreg = (int)st[SL_NREG] + (int)st[SL_NREGPREV] + (int)st[SL_XPASS];      // inertia rungs so far + the correction / re-estimate passes of the IPOPT switches
     const double pinf = st[SL_PINF];
     int c = 8 * (nreg < 7 ? nreg : 7);
     // within the same retry count: the constraint violation that is left, one class per decade from 1e-6 up

@@ -64,6 +64,32 @@ struct Consts {               // uniform per instance
 #define OB_SSB 0.6
 #define OB_DMIN 0.05
 
+// ---------------------------------------------------------------- sin / cos of a bounded angle
+// The library's sincos (ocml: Payne-Hanek reduction for arbitrary arguments, table-free kernels, ~235 instructions per call on gfx950) is a fifth of the instructions of an
+// obstacle item (tools/isa_lines.py: two calls per item in the fused line search, one in the back-substitution) and this kernel is within 1.6 x of its instruction-issue roof in
+// those phases.  Headings, steering and Euler angles of these problems are a few radians: Cody-Waite reduction by pi/2 in three FMA steps (exact to
+// 1e-33 |n|) and the fdlibm kernels on [-pi/4, pi/4] -- ~45 instructions, straight-line, <= 1.6 ulp for |x| <= 1e5 (the library: <= 1); the quadrant is an int: valid for
+// |x| < 3e9, not-a-number and infinity come back as not-a-number.  (No branch to the library for larger arguments: the compiler would inline that path into every caller
+// and the phases would pay its registers.)
+OBCA_FN void sincos_bounded(double x, double *sp, double *cp) {
+    const double n = rint(x * 6.36619772367581382433e-01);                 // 2 / pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);                     // pi / 2 = P1 + P2 + P3, each the rounded remainder of the previous
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    r = fma(-n, -1.49738490485916983294e-33, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double sr = fma(r * z, ps, r);                                   // sin r = r + r^3 S(z)
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));                   // cos r = 1 - z / 2 + z^2 C(z)
+    const int q = (int)n;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    *sp = (q & 2) ? -s0 : s0;
+    *cp = ((q + 1) & 2) ? -c0 : c0;
+}
+OBCA_FN double tan_bounded(double x) { double s_, c_; sincos_bounded(x, &s_, &c_); return s_ / c_; }      // (steering angles: |x| <= 0.6, cos >= 0.8)
+
 // ---------------------------------------------------------------- bicycle model, vars (psi, v, delta, a, t)
 struct DynOut {
     double F[4];
@@ -71,9 +97,9 @@ struct DynOut {
 };
 
 OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], double t, double F[4]) {
-    double tau = c.Ts * t, s = x[3] + 0.5 * tau * u[1], T = tan(u[0]);
+    double tau = c.Ts * t, s = x[3] + 0.5 * tau * u[1], T = tan_bounded(u[0]);
     double phi = x[2] + tau * x[3] * T * (0.5 * c.iL), sn, cs;
-    sincos(phi, &sn, &cs);
+    sincos_bounded(phi, &sn, &cs);
     F[0] = x[0] + tau * s * cs; F[1] = x[1] + tau * s * sn; F[2] = x[2] + tau * s * T * c.iL; F[3] = x[3] + tau * u[1];
 }
 
@@ -81,9 +107,9 @@ OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], do
 OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], double t, const double w[4], DynOut &o,
                         double HL[5][5]) {
     double Ts = c.Ts, iL = c.iL, i2L = 0.5 * c.iL, v = x[3], a = u[1];
-    double tau = Ts * t, s = v + 0.5 * tau * a, T = tan(u[0]), Tp = 1 + T * T;
+    double tau = Ts * t, s = v + 0.5 * tau * a, T = tan_bounded(u[0]), Tp = 1 + T * T;
     double phi = x[2] + tau * v * T * i2L, sn, cs;
-    sincos(phi, &sn, &cs);
+    sincos_bounded(phi, &sn, &cs);
     o.F[0] = x[0] + tau * s * cs; o.F[1] = x[1] + tau * s * sn; o.F[2] = x[2] + tau * s * T * iL; o.F[3] = v + tau * a;
     const double dtau[5] = {0, 0, 0, 0, Ts};
     const double ds[5] = {0, 1, 0, 0.5 * tau, 0.5 * Ts * a};
@@ -190,11 +216,14 @@ OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
 template <int VM>
 OBCA_FN void hh_apply(int v, const double *w, double beta, double *x) {   // x <- (I - beta w w') x, beta = 2 / (w'w): w is NOT normalised
     double s = 0;                                                         // (a square root and a division less on the dependent chain)
+    // No predicate on i < v: the callers' w is zero beyond the obstacle's v rows and their x finite there (the rows an obstacle does not have enter every block matrix as
+    // identity rows), so those terms are exact zeros -- the same bits as with the predicate, which cost two selects per term (140 of an obstacle item's 2 500 instructions).
+    (void)v;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < v) s += w[i] * x[i];
+    for (int i = 0; i < VM; i++) s += w[i] * x[i];
     s *= beta;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < v) x[i] -= s * w[i];
+    for (int i = 0; i < VM; i++) x[i] -= s * w[i];
 }
 
 // ---------------------------------------------------------------- one (stage, obstacle) block
@@ -214,9 +243,9 @@ template <int VM>
 OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }      // (rows beyond in.v: a = b = 0, lam = 1 -- load_obs -- exact zeros, no predicate needed)
     double sn, cs;
-    sincos(in.psi, &sn, &cs);
+    sincos_bounded(in.psi, &sn, &cs);
     r[0] = p1 * p1 + p2 * p2 - 1 + (c.dist ? in.sl : 0.0);          // ParkingDist.jl:200: <= 1 (its slack is kept in the sl slot)
     r[1] = in.mu[0] - in.mu[2] + cs * p1 + sn * p2;
     r[2] = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
@@ -247,9 +276,9 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr)
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
+    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }      // (rows beyond v: a = b = 0, lam = 1 -- load_obs)
     double sn, cs;
-    sincos(in.psi, &sn, &cs);
+    sincos_bounded(in.psi, &sn, &cs);
     const double off = c.off;
     double cr[4];
     cr[0] = p1 * p1 + p2 * p2 - 1 + (c.dist ? in.sl : 0.0);
@@ -262,11 +291,11 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double Jl[4][VM];
 #pragma unroll
     for (int i = 0; i < VM; i++) {
-        double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
+        double a1 = in.a1[i], a2 = in.a2[i];                                   // (zero beyond the obstacle's v rows: load_obs)
         Jl[0][i] = 2 * (p1 * a1 + p2 * a2);
         Jl[1][i] = cs * a1 + sn * a2;
         Jl[2][i] = -sn * a1 + cs * a2;
-        Jl[3][i] = (in.X + cs * off) * a1 + (in.Y + sn * off) * a2 - (i < v ? in.b[i] : 0.0);
+        Jl[3][i] = (in.X + cs * off) * a1 + (in.Y + sn * off) * a2 - in.b[i];
     }
     // rows 2..4 w.r.t. pose (X,Y,psi): only these entries are non-zero
     const double jp2 = -sn * p1 + cs * p2, jp3 = -cs * p1 - sn * p2;
@@ -284,7 +313,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        double jy = Jmu[0][i] * y[1] + Jmu[1][i] * y[2] + Jmu[2][i] * y[3];
+        const double jy = (i == 0 ? y[1] : (i == 1 ? y[2] : (i == 2 ? -y[1] : -y[2]))) + Jmu[2][i] * y[3];      // Jmu' y with the 0 / +-1 entries of Jmu written out (a product with a literal
+                                                                                                                    // zero cannot be folded by the compiler -- 0 x inf -- and cost two operations each)
         if (LSQ) { r_mu[i] = jy - in.zm[i]; iDmu[i] = 1.0; }
         else { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
         if (MODE == 0) {
@@ -316,24 +346,24 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 4; r++) { st->pmax = fmax(st->pmax, fabs(cr[r])); st->sumy += fabs(y[r]); }
     }
     // rows 2..4 after eliminating so, sl, mu:   Jl dlam + Jp dpose - T dy = r234
+    // T = Jmu diag(1 / D_mu) Jmu' + delta_c I with Jmu = [1 0 -1 0; 0 1 0 -1; -g'] written out (same terms in the same order as the triple loop over its entries; the loop
+    // multiplied by the literal zeros, which the compiler may not fold: 62 + 40 operations per block against 25)
     double Tm[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int s_ = 0; s_ < 3; s_++) {
-            double a_ = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * Jmu[s_][i] * iDmu[i];
-            Tm[r * 3 + s_] = a_ + (r == s_ ? dc : 0.0);
-        }
+    {
+        const double g0 = Jmu[2][0], g1 = Jmu[2][1], g2 = Jmu[2][2], g3 = Jmu[2][3];      // (= -c.g[i])
+        Tm[0] = (iDmu[0] + iDmu[2]) + dc; Tm[1] = Tm[3] = 0.0;
+        Tm[2] = Tm[6] = g0 * iDmu[0] + (-g2) * iDmu[2];
+        Tm[4] = (iDmu[1] + iDmu[3]) + dc;
+        Tm[5] = Tm[7] = g1 * iDmu[1] + (-g3) * iDmu[3];
+        Tm[8] = ((((g0 * g0) * iDmu[0] + (g1 * g1) * iDmu[1]) + (g2 * g2) * iDmu[2]) + (g3 * g3) * iDmu[3]) + dc;
+    }
     Tm[8] += iDso + iDs4;
     double r234[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        double a_ = LSQ ? 0.0 : -(SOC ? crs[r + 1] : cr[r + 1]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) a_ += Jmu[r][i] * r_mu[i] * iDmu[i];
-        r234[r] = a_;
+    {
+        const double c1 = LSQ ? 0.0 : -(SOC ? crs[1] : cr[1]), c2 = LSQ ? 0.0 : -(SOC ? crs[2] : cr[2]), c3 = LSQ ? 0.0 : -(SOC ? crs[3] : cr[3]);
+        r234[0] = (c1 + r_mu[0] * iDmu[0]) + (-r_mu[2]) * iDmu[2];
+        r234[1] = (c2 + r_mu[1] * iDmu[1]) + (-r_mu[3]) * iDmu[3];
+        r234[2] = (((c3 + (Jmu[2][0] * r_mu[0]) * iDmu[0]) + (Jmu[2][1] * r_mu[1]) * iDmu[1]) + (Jmu[2][2] * r_mu[2]) * iDmu[2]) + (Jmu[2][3] * r_mu[3]) * iDmu[3];
     }
     r234[2] += -r_so * iDso + r_sl * iDs4;
     int bad = ldl_fact<3, RS_>(3, Tm);
@@ -352,10 +382,10 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double Kb[VM * VM], Cp[VM][3], rk[VM + 1];
 #pragma unroll
     for (int i = 0; i < VM; i++) {
-        double a1 = i < v ? in.a1[i] : 0.0, a2 = i < v ? in.a2[i] : 0.0;
+        double a1 = in.a1[i], a2 = in.a2[i];
 #pragma unroll
         for (int m = 0; m < VM; m++) {
-            double b1 = m < v ? in.a1[m] : 0.0, b2 = m < v ? in.a2[m] : 0.0;
+            double b1 = in.a1[m], b2 = in.a2[m];
             double a_ = LSQ ? 0.0 : y[0] * 2 * (a1 * b1 + a2 * b2);
 #pragma unroll
             for (int r = 0; r < 3; r++) a_ += Jl[r + 1][i] * W[r][m];
@@ -381,11 +411,11 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     // Householder Qh q = alpha e1
     double hw[VM], nq = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) if (i < v) nq += Jl[0][i] * Jl[0][i];
+    for (int i = 0; i < VM; i++) nq += Jl[0][i] * Jl[0][i];                    // (Jl is zero beyond v)
     nq = sqrt(nq);
     double alpha = Jl[0][0] > 0 ? -nq : nq, nw = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) { hw[i] = i < v ? Jl[0][i] - (i == 0 ? alpha : 0.0) : 0.0; nw += hw[i] * hw[i]; }
+    for (int i = 0; i < VM; i++) { hw[i] = Jl[0][i] - (i == 0 ? alpha : 0.0); nw += hw[i] * hw[i]; }
     const double hb = nw > 0 ? 2.0 * rcp_nr<RS_>(nw) : 0.0;
     // Ht = Qh Kb Qh
 #pragma unroll
@@ -486,7 +516,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int i = 0; i < VM; i++) step->dlam[i] = col[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            double jy = Jmu[0][i] * r3[0] + Jmu[1][i] * r3[1] + Jmu[2][i] * r3[2];
+            const double jy = (i == 0 ? r3[0] : (i == 1 ? r3[1] : (i == 2 ? -r3[0] : -r3[1]))) + Jmu[2][i] * r3[2];
             step->dmu[i] = (-r_mu[i] - jy) * iDmu[i];
         }
         step->dsl = (-r_sl - (c.dist ? col[VM] : r3[2])) * iDsl;

@@ -45,7 +45,7 @@ OBCA_FN int q_vidx(int a) { return a < 3 ? 3 + a : (a < 6 ? 6 + a : QS + (a - 6)
 // g(x,u) with x+ = x + t Ts g ; rows 0..2 are x7..x9 (linear, handled by the caller)
 OBCA_FN void dyn_g_value(const QConsts &c, const double *x, const double *u, double g[QX]) {
     double s4, c4, s5, c5, s6, c6;
-    sincos(x[3], &s4, &c4); sincos(x[4], &s5, &c5); sincos(x[5], &s6, &c6);
+    sincos_bounded(x[3], &s4, &c4); sincos_bounded(x[4], &s5, &c5); sincos_bounded(x[5], &s6, &c6);
     const double S4 = rcp_nr(c4), T4 = s4 * S4, r10 = x[9], r11 = x[10], r12 = x[11];
     const double U = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3], kap = Q_KF / Q_MASS, h = s5 * r10 - c5 * r12;
     g[0] = x[6]; g[1] = x[7]; g[2] = x[8];
@@ -60,7 +60,7 @@ OBCA_FN void dyn_g_value(const QConsts &c, const double *x, const double *u, dou
 OBCA_FN int q_pidx(int a, int b) { int i = a < b ? a : b, j = a < b ? b : a; return i * QV - i * (i - 1) / 2 + (j - i); }
 OBCA_FN void dyn_g_derivs(const QConsts &c, const double *x, const double *u, const double *w, double g[QX], double dg[9][QV], double HG[55]) {
     double s4, c4, s5, c5, s6, c6;
-    sincos(x[3], &s4, &c4); sincos(x[4], &s5, &c5); sincos(x[5], &s6, &c6);
+    sincos_bounded(x[3], &s4, &c4); sincos_bounded(x[4], &s5, &c5); sincos_bounded(x[5], &s6, &c6);
     const double S4 = rcp_nr(c4), T4 = s4 * S4, r10 = x[9], r11 = x[10], r12 = x[11];
     const double U = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3], kap = Q_KF / Q_MASS;
     const double g4 = c5 * r10 + s5 * r12, h = s5 * r10 - c5 * r12;

@@ -166,7 +166,8 @@ struct Inst {              // uniform: pointers of this instance
     mutable long long tlast;           // diagnostic builds (-DOBCA_PROFILE): time stamp of the previous phase boundary
 };
 
-enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_HAVE, SL_ASM = 16, SL_FILT = 32, SL_SIZE = SL_FILT + 2 * OB_FILT };
+enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_HAVE, SL_XPASS, SL_ASM = 16, SL_FILT = 32, SL_SIZE = SL_FILT + 2 * OB_FILT };
+// SL_XPASS: full passes the slice spent outside iterations and inertia rungs (second-order corrections, rebuilds after rejected ones, multiplier re-estimates): the ordering kernel ranks by them too
 // SL_HAVE / SL_ASM: a solve parked right after an accepted trial keeps that trial's assembly -- the scalars here, the stage records in the instance's own buffers, which
 // outlive the launch -- so the resumed solve continues from exactly the state an uninterrupted one has at that point, without assembling again
 struct Slice {
@@ -187,6 +188,7 @@ struct Soc {                // state of the three IPOPT switches (second-order c
     int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
     int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
     int lsq_init;                     // option: least-squares initial multipliers (IPOPT's default initialisation, constr_mult_init_max = 1e3)
+    int nrebuild;                     // Newton systems rebuilt after a rejected correction in this attempt (a full pass each: counted against the slice budget)
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
@@ -1579,6 +1581,12 @@ OBCA_PHASE void ph_soc_fused(double mu, double dc, double alpha, double ay, doub
 // ---- recalc_y = "yes" (ParkingSignedDist.jl:41; IPOPT recalc_y_feas_tol = 1e-6): once the iterate is (nearly) feasible its equality multipliers are replaced by the
 // least-squares estimate -- the same structured solve with H := I, zero constraint right-hand side, gradients in their z-form; only the multiplier part of the solution is used.
 // Cold path: one non-inlined function, every obstacle width inside.  1 = the multipliers were replaced (the assembly at hand is then stale).
+#ifdef OBCA_EMU
+static int g_emu_recalc_fail = 0;      // host test hook: every estimate is attempted (at every accepted iterate) and thrown away
+#define OB_RECALC_FEAS_TOL (g_emu_recalc_fail ? 1e300 : 1e-6)
+#else
+#define OB_RECALC_FEAS_TOL 1e-6        // IPOPT recalc_y_feas_tol
+#endif
 OBCA_PHASE int ph_recalc_y(int init) {      // init = 1: IPOPT's initial multipliers (least-squares estimate at the starting point, kept only if its max-norm is <= constr_mult_init_max = 1e3)
     Shared &sh = g_sh; const Inst &I = sh.inst; const Lay &l = sh.l;
     if (sh.vmc == 0) assemble_obs<2, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else if (sh.vmc == 1) assemble_obs<OB_VMID, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE); else assemble_obs<OB_VMAX, 0, 0, 1>(I, sh, 0.0, 0.0, 0.0, OB_NOFUSE);
@@ -1590,6 +1598,9 @@ OBCA_PHASE int ph_recalc_y(int init) {      // init = 1: IPOPT's initial multipl
     double red[1][OBCA_NL];
     PAR(lane) { double w = 0; for (int i = l.pi + lane; i < l.zxL; i += OB_NT) { const double v = I.d[i], y1 = fabs(I.z[i] + v); w = (v == v && fabs(v) <= 1e300 && w <= 1e300) ? fmax(w, y1) : 1e301; } red[0][LI(lane)] = w; }
     const double ymax = wred_max(red[0]);
+#ifdef OBCA_EMU
+    if (g_emu_recalc_fail && !init) return 0;                                // (host test hook: the estimate is discarded AFTER the records were overwritten)
+#endif
     if (ymax > 1e300 || (init && ymax > 1e3)) return 0;                      // a non-finite entry (or, at the start, an estimate beyond constr_mult_init_max): keep the multipliers
     PAR(lane) { for (int i = l.pi + lane; i < l.zxL; i += OB_NT) I.z[i] += I.d[i]; }
     SYNC();
@@ -1648,7 +1659,7 @@ OBCA_FN int ref_constraints(const Inst &I, Shared &sh, int sd) {
             double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
-            double sn, cs; sincos(in.psi, &sn, &cs);
+            double sn, cs; sincos_bounded(in.psi, &sn, &cs);
             const double r0 = p1 * p1 + p2 * p2 - 1;
             const double r1 = in.mu[0] - in.mu[2] + cs * p1 + sn * p2, r2 = in.mu[1] - in.mu[3] - sn * p1 + cs * p2;
             const double r3 = -(c.g[0] * in.mu[0] + c.g[1] * in.mu[1] + c.g[2] * in.mu[2] + c.g[3] * in.mu[3]) + (in.X + cs * c.off) * p1 +
@@ -1711,6 +1722,7 @@ OBCA_PHASE int ph_soc_try(double tht_first) {
     }
     if (acc) { D.alpha = asoc; D.az = azs; sh.soc.nsoc_acc++; return 1; }
     // not accepted: the records and d hold a correction system -- rebuild the Newton system and direction of this iteration (same point, same delta_w: the same numbers)
+    sh.soc.nrebuild++;
     ph_assemble(D.mu, D.dw, D.dc_val, 0);
     if (sh.A.ok && ph_riccati(o.rho_term)) ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau);
     return 0;
@@ -1719,7 +1731,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     Shared &sh = g_sh; Drv &D = sh.drv;
     gdbl *const st = sl.st;
     const AsmOut &A = sh.A;
-    sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0;
+    sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0; sh.soc.nrebuild = 0;
     D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
     if (sl.resume) {
         D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN]; D.th_max = st[SL_THMAX];
@@ -1735,9 +1747,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     D.dc_mu = -1.0; D.dc_val = 0;
     // D.have_asm = 1: sh.A already holds the assembly of the current iterate, left behind by the accepted trial of the previous iteration (ph_fused)
     for (;;) {
-        if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) >= sl.budget) {   // out of budget: park the loop state, a later launch continues
+        if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc >= sl.budget) {   // out of budget: park the loop state, a later launch continues
             PAR(lane) {
-                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
+                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
                 const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS;                 // (entries beyond the LDS part are in the record already)
                 for (int i = lane; i < 2 * nl; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
             }
@@ -1829,10 +1841,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
         LDS_SYNC();
         D.have_asm = 1;
-        if (sh.soc.recalc_y && sh.A.pinf < 1e-6) { if (ph_recalc_y(0)) D.have_asm = 0; }      // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate; the assembly at hand is of the old ones
+        if (sh.soc.recalc_y && sh.A.pinf < OB_RECALC_FEAS_TOL) { ph_recalc_y(0); D.have_asm = 0; }      // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate.  Whether the estimate is kept or not, the
+                                                                                                // call overwrote the stage / obstacle / Riccati records with the least-squares system: the next iteration assembles afresh
         D.it++;
     }
-    sl.used += D.it + D.nreg - D.p_start;
+    sl.used += D.it + D.nreg - D.p_start + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc;      // (a correction, the rebuild after a rejected one and a multiplier re-estimate are full passes each)
     R.status = D.status; R.iters = D.it; R.nreg = D.nreg; R.obj = D.f; R.pinf = D.pinf; R.dinf = D.dinf; R.mu = D.mu;
 }
 

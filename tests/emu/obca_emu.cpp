@@ -38,8 +38,11 @@ static void setup(int N, const double *prob, Scratch &s) {
 }
 
 extern "C" {
+void emu_sincos(double x, double *s, double *c) { sincos_bounded(x, s, c); }      // the kernels' bounded-range sin / cos (obca_model.h)
+double emu_tan(double x) { return tan_bounded(x); }
 int emu_opts_size() { return (int)sizeof(OptsAbi); }
 int emu_last_recalc() { return g_sh.soc.nrecalc; }
+void emu_force_recalc_failure(int on) { g_emu_recalc_fail = on; }      // every recalc_y estimate is thrown away after its system has overwritten the records (tests/test_emu_cpu.py)
 int emu_last_soc(int *accepted) { if (accepted) *accepted = g_sh.soc.nsoc_acc; return g_sh.soc.nsoc; }      // second-order corrections of the last attempt of the last solve
 
 // one Newton direction at a full primal-dual point (oracle layout); returns inertia-ok.  alpha >= 0: the fused line-search step is run as well --

@@ -330,3 +330,48 @@ def test_ipopt_switches_on_wide_obstacles_follow_the_oracle(oracle, emu, rows):
             assert np.abs(xp - r["xp"]).max() < 1e-7 and np.abs(up - r["up"]).max() < 1e-7 and abs(t - r["t"]) < 1e-9
         done += 1; changed += r["iters"] != r0["iters"]
     assert done >= 3 and changed >= 2
+
+
+def test_bounded_sincos_of_the_kernels_is_accurate(emu):
+    """sincos_bounded / tan_bounded (obca_model.h: Cody-Waite reduction + fdlibm kernels, straight-line) against 80-bit references: <= 1.6 ulp on |x| <= 1e5 (headings, steering
+    and Euler angles are a few radians), tan <= 2.5 ulp on the steering range, exact at 0, NaN in -> NaN out"""
+    emu.emu_tan.restype = C.c_double
+    rng = np.random.default_rng(3)
+    for scale, tol in ((1.0, 1.6), (10.0, 1.6), (1e3, 1.6), (1e5, 1.6)):
+        x = rng.uniform(-scale, scale, 20000); s = np.zeros_like(x); c = np.zeros_like(x); sv, cv = C.c_double(), C.c_double()
+        for i, xi in enumerate(x):
+            emu.emu_sincos(C.c_double(xi), C.byref(sv), C.byref(cv)); s[i] = sv.value; c[i] = cv.value
+        xl = x.astype(np.longdouble); rs, rc = np.sin(xl), np.cos(xl)
+        us = np.abs(s.astype(np.longdouble) - rs) / np.spacing(np.abs(rs.astype(float))); uc = np.abs(c.astype(np.longdouble) - rc) / np.spacing(np.abs(rc.astype(float)))
+        assert us.max() <= tol and uc.max() <= tol, (scale, float(us.max()), float(uc.max()))
+    x = rng.uniform(-0.7, 0.7, 20000); t = np.array([emu.emu_tan(C.c_double(xi)) for xi in x]); rt = np.tan(x.astype(np.longdouble))
+    assert (np.abs(t.astype(np.longdouble) - rt) / np.spacing(np.abs(rt.astype(float)))).max() <= 2.5
+    sv, cv = C.c_double(), C.c_double()
+    emu.emu_sincos(C.c_double(0.0), C.byref(sv), C.byref(cv)); assert sv.value == 0.0 and cv.value == 1.0
+    emu.emu_sincos(C.c_double(float("nan")), C.byref(sv), C.byref(cv)); assert sv.value != sv.value and cv.value != cv.value
+
+
+def test_a_discarded_recalc_y_estimate_leaves_no_stale_records(oracle, emu):
+    """ph_recalc_y overwrites the stage / obstacle / Riccati records with the least-squares system before it knows whether the estimate is kept.  When it is NOT kept (forced here
+    through the emulation's hook: an estimate is attempted at EVERY accepted iterate and discarded after the overwrite) the next iteration must assemble afresh: the solve with recalc_y on and every estimate discarded is then bit for bit the
+    solve without the option (round-3 advisor finding: have_asm used to stay 1 on that path and the stale least-squares records were factorised as the Newton system)."""
+    N = 80; sc = S.BACKWARDS
+    bt = S.make_batch(sc, 4, N, seed=20260925)
+    A, b, v = S.scenario_hrep(sc); v = np.ravel(v).astype(int); nOb, M = len(v), int(v.sum()); L = P.layout(N, nOb, M)
+    o_off = copy_opts(oracle.default_opts()); oo = oracle.default_opts(); oo.recalc_y = 1; o_on = copy_opts(oo)
+    entered = 0
+    for i in range(4):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], S.EGO)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i][:N], lWS, nWS)
+        za = np.zeros_like(z0); ia = np.zeros(8); zb = np.zeros_like(z0); ib = np.zeros(8); zc = np.zeros_like(z0); ic = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(o_off), dp(za), dp(ia))
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(o_on), dp(zc), dp(ic)); entered += emu.emu_last_recalc() > 0
+        emu.emu_force_recalc_failure(1)
+        try:
+            emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(o_on), dp(zb), dp(ib))
+        finally:
+            emu.emu_force_recalc_failure(0)
+        assert int(ia[7]) == int(ib[7]) == 1 and int(ia[1]) == int(ib[1]) and np.array_equal(za, zb), (i, ia, ib)
+    assert entered >= 3          # (the option does reach its estimate on these instances, so the forced failures above were real)
