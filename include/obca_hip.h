@@ -34,27 +34,37 @@ extern "C" {
 typedef struct obca_ctx obca_ctx;
 typedef struct obca_batch obca_batch;
 
-/* Interior-point options; defaults = the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT defaults.
- * What the solver behind them is: IPOPT's Algorithm A (monotone barrier, filter line search, inertia-correction ladder, alpha_for_y = min) on a structured KKT solve.
- * Three IPOPT semantics the reference relies on are switches of the parking kernels, all off by default (as in the CPU checker the parity tests run against):
+/* Interior-point options.  The solver behind them is IPOPT's Algorithm A (monotone barrier, filter line search, inertia-correction ladder, alpha_for_y = min) on a
+ * structured KKT solve, with the option values of the reference's IPOPT call (ParkingSignedDist.jl:41-43) + IPOPT's defaults.
+ * Three IPOPT semantics the reference runs with are switches of the parking kernels:
  *   max_soc  -- the second-order correction (A-5.5..A-5.9 of Waechter & Biegler: up to max_soc corrections with kappa_soc = 0.99 after a rejected first trial step that
- *               did not reduce the constraint violation; IPOPT's own default is 4);
- *   recalc_y -- recalc_y = "yes" (ParkingSignedDist.jl:41): the equality multipliers are replaced by their least-squares estimate (the structured solve with H := I)
- *               whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6.
+ *               did not reduce the constraint violation; IPOPT's default is 4);
+ *   recalc_y -- recalc_y = "yes" (ParkingSignedDist.jl:41, ParkingDist.jl:41): the equality multipliers are replaced by their least-squares estimate (the structured solve
+ *               with H := I) whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6;
  *   lsq_init -- IPOPT's default initial multipliers: the same least-squares estimate at the starting point (constr_mult_init_max = 1e3) instead of y0 = 0.
- * With any of them on, the kernels follow the checker's option of the same name iteration for iteration (tests/test_gpu_parity.py, tests/test_emu_cpu.py).
- * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, gradient-based NLP
- * scaling (half-space rows enter with unit length instead).  On the full bench batches of BASELINE configs 2, 3 and 5 (1 024 + 2 048 + 4 096 instances) the kernels'
- * default results and the checker's WITH the correction and recalc_y switched on have identical exit flags -- every instance is solved either way -- while
- * 70 / 711 / 220 iteration counts differ and, the NLP being non-convex, 0 / a handful / a few instances end in another local solution
- * (profiles/r03_census_soc_recalc_y.txt, tools/parity_census.py --ipopt-options).  DESIGN.md section 2. */
+ * With any of them on, the kernels follow the CPU checker's option of the same name iteration for iteration -- on the FULL bench batches of BASELINE configs 2 / 3 / 5
+ * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0 / 1 / 0 iteration counts differ, tests/test_gpu_parity.py,
+ * profiles/r04_census_gpu_ipopt_options.txt).
+ *
+ * Two option sets, and which one is the default where (round 4, measured on one MI355X, profiles/r04_bench_step1.json, r04_bench_config{3,5}_step1.json):
+ *   obca_reference_opts -- the reference's IPOPT configuration as far as the kernels carry it: max_soc = 4, recalc_y = 1, lsq_init = 1.  The default of the DROP-IN functions
+ *                          that carry the reference's names (Julia: OBCAHip.ParkingSignedDist / ParkingDist; Python: obca_amd.ParkingSignedDist / ParkingDist).
+ *   obca_default_opts   -- the three switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below and what bench.py's `value` runs.
+ * The numbers behind that split: both settings solve every instance of the three bench batches (identical exit flags, every solution passes the a-posteriori checker);
+ * the IPOPT configuration costs 8 / 12 / 16 % more iterations and 12 x the inertia-correction rungs (the least-squares start leaves an indefinite Lagrangian Hessian early on):
+ * 242.5 k -> 183.0 k, 142.6 k -> 108.9 k, 118.3 k -> 89.9 k solves/s on configs 2 / 3 / 5; and 14 of 1 024, 361 of 2 048, 69 of 4 096 instances end in ANOTHER local solution
+ * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
+ * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
+ * throughput entry points the one that is a quarter cheaper; every bench line reports both.
+ * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, gradient-based NLP scaling (half-space rows enter with
+ * unit length instead), the watchdog.  The quadcopter kernel has none of the three switches: its entry points refuse options that set them.  DESIGN.md section 2. */
 typedef struct obca_opts {
     double tol; int max_iter;
     double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
     double dw_min, dw0, dw_max, kw_inc0, kw_inc, kw_dec, dc_bar, kappa_c;
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
-    int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off, the default of obca_default_opts; parking kernels only */
+    int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off (obca_default_opts), 4 in obca_reference_opts; parking kernels only */
     int recalc_y;     /* 1: recalc_y = "yes" as the reference sets it (ParkingSignedDist.jl:41; recalc_y_feas_tol 1e-6): least-squares equality multipliers whenever the
                          iterate's constraint violation is below 1e-6; 0 = off, the default of obca_default_opts; parking kernels only */
     int lsq_init;     /* 1: IPOPT's initial equality multipliers -- the least-squares estimate at the starting point, kept if its max-norm is <= constr_mult_init_max = 1e3;
@@ -75,7 +85,8 @@ int obca_device_count(const obca_ctx *ctx);          /* devices this context dri
 int obca_visible_device_count(void);                 /* HIP devices visible to the process */
 int obca_destroy(obca_ctx *ctx);
 const char *obca_last_error(const obca_ctx *ctx);   /* ctx may be NULL: error of the last failed obca_create */
-int obca_default_opts(obca_opts *o);
+int obca_default_opts(obca_opts *o);      /* throughput defaults (the three IPOPT switches off): what opts == NULL means */
+int obca_reference_opts(obca_opts *o);    /* the reference's IPOPT configuration: max_soc = 4, recalc_y = 1, lsq_init = 1 (see above) */
 int obca_device_name(const obca_ctx *ctx, char *buf, int buflen);
 
 /* ---- synchronous host-pointer API (what the Julia shim calls) ---- */

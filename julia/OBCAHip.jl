@@ -48,9 +48,10 @@ lasterr(c) = unsafe_string(ccall((:obca_last_error, LIB), Cstring, (Ptr{Cvoid},)
 f64(a) = convert(Array{Float64}, a)
 
 """
-Interior-point options: the record `obca_opts` of include/obca_hip.h, field for field.  `default_opts()` = the reference's IPOPT call (ParkingSignedDist.jl:41-43) with the two
-IPOPT semantics the kernels carry as switches OFF; `ipopt_opts()` switches them on as the reference's IPOPT has them (second-order correction: IPOPT's default max_soc = 4;
-recalc_y = "yes": ParkingSignedDist.jl:41; least-squares initial multipliers: IPOPT's default).  Pass as the keyword `opts` of the batched parking calls; `nothing` = the library's defaults.
+Interior-point options: the record `obca_opts` of include/obca_hip.h, field for field.  `ipopt_opts()` = the reference's IPOPT configuration as far as the kernels carry it
+(ParkingSignedDist.jl:41-43 incl. recalc_y = "yes", IPOPT's default second-order correction max_soc = 4 and least-squares initial multipliers): the default of the drop-ins
+`ParkingSignedDist` / `ParkingDist`.  `default_opts()` = the library's throughput defaults (the three switches off: the same solved set, a quarter fewer GPU seconds, 1-18 % of the
+instances of a batch end in another local solution -- include/obca_hip.h has the numbers): the default of the batched calls (`opts=nothing`).
 """
 mutable struct Opts
     tol::Cdouble; max_iter::Cint
@@ -66,7 +67,11 @@ function default_opts()
     ccall((:obca_default_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_default_opts failed")
     return o
 end
-ipopt_opts() = (o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1; o)
+function ipopt_opts()
+    o = Opts()
+    ccall((:obca_reference_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_reference_opts failed")
+    return o
+end
 optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
 
 """
@@ -97,7 +102,7 @@ function ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b
 end
 
 "Drop-in for ParkingSignedDist.jl:29 (one instance): same arguments, same 7-tuple."
-function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS; opts=nothing)      # opts: `ipopt_opts()` = the reference's IPOPT semantics switched on
+function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS; opts=ipopt_opts())      # default: the reference's IPOPT configuration; `default_opts()` = the library's throughput defaults
     xp, up, ts, ef, t, lp, np = ParkingSignedDist_batch(reshape(f64(vec(x0)), 4, 1), reshape(f64(vec(xF)), 4, 1), N, [Float64(Ts)], L, ego,
         XYbounds, nOb, vOb, A, b, reshape(f64(rx)[1:N+1], N + 1, 1), reshape(f64(ry)[1:N+1], N + 1, 1), reshape(f64(ryaw)[1:N+1], N + 1, 1),
         fixTime, reshape(permutedims(f64(xWS)[1:N+1, :]), 4, N + 1, 1), reshape(permutedims(f64(uWS)[1:N, :]), 2, N, 1); opts=opts)
@@ -106,17 +111,17 @@ function ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, 
 end
 
 "Drop-in for ParkingDist.jl:29 (collision-free sibling; entry point obca_parking_dist_batch has the same arguments minus the slack output)."
-function ParkingDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
+function ParkingDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS; opts=ipopt_opts())      # (ParkingDist.jl:41 sets recalc_y = "yes" too)
     M = sum(vOb)
     xp = zeros(4, N + 1); up = zeros(2, N); ts = zeros(N + 1); ef = zeros(Cint, 1); lp = zeros(M, N + 1); np = zeros(4nOb, N + 1)
     t0 = time()
-    rc = ccall((:obca_parking_dist_batch, LIB), Cint,
+    rc = GC.@preserve opts ccall((:obca_parking_dist_batch, LIB), Cint,
                (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
                 Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                ctx().h, 1, N, [Float64(Ts)], L, f64(vec(ego)), f64(vec(XYbounds)), fixTime, f64(vec(x0)), f64(vec(xF)), Cint[nOb], Cint.(vec(vOb)),
                vec(permutedims(f64(A))), f64(vec(b)), f64(rx)[1:N+1], f64(ry)[1:N+1], f64(ryaw)[1:N+1], vec(permutedims(f64(xWS)[1:N+1, :])),
-               vec(permutedims(f64(uWS)[1:N, :])), C_NULL, C_NULL, C_NULL, xp, up, ts, ef, lp, np, C_NULL)
+               vec(permutedims(f64(uWS)[1:N, :])), C_NULL, C_NULL, optsptr(opts), xp, up, ts, ef, lp, np, C_NULL)
     rc == 0 || error("obca_parking_dist_batch failed: " * lasterr(ctx()))
     timeScalep = fixTime == 1 ? ones(1, N + 1) : ts
     return xp, up, timeScalep, Int(ef[1]), time() - t0, lp, np          # ParkingDist.jl:313

@@ -38,7 +38,7 @@ class Opts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("reserved_", C.c_int)]      # max_soc: second-order correction trials per iteration (IPOPT's default: 4); recalc_y: 1 = recalc_y "yes"; both 0 = off (default)
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("reserved_", C.c_int)]      # the three IPOPT switches (include/obca_hip.h): 0 in default_opts(), 4 / 1 / 1 in ipopt_opts()
 
 
 def library_path():
@@ -74,7 +74,7 @@ def _load():
     return lib
 
 
-EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visible_device_count", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_device_name",
+EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visible_device_count", "obca_destroy", "obca_last_error", "obca_default_opts", "obca_reference_opts", "obca_device_name",
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
@@ -100,7 +100,8 @@ def default_opts():
 def ipopt_opts():
     """the reference's IPOPT configuration as far as the kernels carry it: default options + second-order correction (IPOPT's default max_soc = 4), recalc_y = "yes"
     (ParkingSignedDist.jl:41) and IPOPT's least-squares initial multipliers"""
-    o = default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
+    o = Opts()
+    _load().obca_reference_opts(C.byref(o))
     return o
 
 
@@ -372,8 +373,11 @@ def _unpack_parking(B, N, nObs, Ms, xp, up, ts, ef, lp, npp, sl, info):
 
 
 def ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, opts=None, device=0):
-    """Drop-in for ParkingSignedDist.jl:29 (one instance).  Returns (xp, up, timeScalep, exitflag, time, lp, np)."""
+    """Drop-in for ParkingSignedDist.jl:29 (one instance).  Returns (xp, up, timeScalep, exitflag, time, lp, np).
+    opts=None runs the reference's IPOPT configuration (ipopt_opts(): recalc_y = "yes" as ParkingSignedDist.jl:41 sets it, IPOPT's default second-order correction and
+    least-squares initial multipliers); pass default_opts() for the library's throughput defaults (include/obca_hip.h says what the difference costs and changes)."""
     assert int(nOb) == len(np.ravel(vOb))
+    opts = ipopt_opts() if opts is None else opts
     r = parking_signed_dist_batch(np.reshape(x0, (1, 4)), np.reshape(xF, (1, 4)), N, Ts, L, ego, XYbounds, vOb, A, b,
                                   np.reshape(np.ravel(rx)[:N + 1], (1, -1)), np.reshape(np.ravel(ry)[:N + 1], (1, -1)),
                                   np.reshape(np.ravel(ryaw)[:N + 1], (1, -1)), fixTime, np.asarray(xWS, float)[None, :N + 1],
@@ -383,8 +387,10 @@ def ParkingSignedDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, r
 
 
 def ParkingDist(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, opts=None, device=0):
-    """Drop-in for ParkingDist.jl:29 (the collision-free sibling of ParkingSignedDist): same arguments, same 7-tuple."""
+    """Drop-in for ParkingDist.jl:29 (the collision-free sibling of ParkingSignedDist): same arguments, same 7-tuple.  opts=None: the reference's IPOPT configuration
+    (ParkingDist.jl:41 sets recalc_y = "yes" as well), see ParkingSignedDist."""
     assert int(nOb) == len(np.ravel(vOb))
+    opts = ipopt_opts() if opts is None else opts
     r = parking_signed_dist_batch(np.reshape(x0, (1, 4)), np.reshape(xF, (1, 4)), N, Ts, L, ego, XYbounds, vOb, A, b,
                                   np.reshape(np.ravel(rx)[:N + 1], (1, -1)), np.reshape(np.ravel(ry)[:N + 1], (1, -1)),
                                   np.reshape(np.ravel(ryaw)[:N + 1], (1, -1)), fixTime, np.asarray(xWS, float)[None, :N + 1],

@@ -276,7 +276,15 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
-    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->reserved_ = 0;                  /* IPOPT's default max_soc is 4 and the reference sets recalc_y = "yes"; both off here as in the checker the parity tests run against */
+    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->reserved_ = 0;                  /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
+    return 0;
+}
+
+int obca_reference_opts(obca_opts *o) {            /* the reference's IPOPT configuration as far as the kernels carry it */
+    if (obca_default_opts(o)) return -1;
+    o->max_soc = 4;                                    /* IPOPT default max_soc */
+    o->recalc_y = 1;                                   /* recalc_y = "yes", ParkingSignedDist.jl:41 / ParkingDist.jl:41 */
+    o->lsq_init = 1;                                   /* IPOPT default: least-squares initial multipliers, constr_mult_init_max = 1e3 */
     return 0;
 }
 
@@ -890,6 +898,7 @@ int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, cons
 static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     if (!bt->uploaded) { bt->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
+    if (o.max_soc != 0 || o.recalc_y != 0 || o.lsq_init != 0) { bt->err = "quadcopter solve: max_soc / recalc_y / lsq_init are switches of the parking kernels only (obca_hip.h); the quadcopter kernel would ignore them -- refusing instead"; return -1; }
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));

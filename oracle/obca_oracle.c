@@ -69,8 +69,7 @@ void obca_oracle_default_opts(opts_t *o) {
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4;
     o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
-    if (getenv("OBCA_LSQ_INIT")) o->lsq_init = atoi(getenv("OBCA_LSQ_INIT"));
-    o->max_soc = getenv("OBCA_SOC") ? atoi(getenv("OBCA_SOC")) : 0; o->recalc_y = getenv("OBCA_RECALC_Y") ? atoi(getenv("OBCA_RECALC_Y")) : 0;   /* environment: tools/soc_probe.py */
+    o->max_soc = 0; o->recalc_y = 0;                 /* the three IPOPT switches are off by default and set by the caller (never through the environment: a leaked variable would change what the parity tests compare) */
 }
 
 /* ------------------------------------------------------------------ iterate layout (one flat vector) */

@@ -49,7 +49,7 @@ void obca_oracle_quad_default_opts(opts_t *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
-    o->max_soc = getenv("OBCA_QSOC") ? atoi(getenv("OBCA_QSOC")) : 0;
+    o->max_soc = 0;                                 /* second-order correction: an option the caller sets (opts.max_soc), never the environment */
 }
 
 /* model constants, QuadcopterSignedDist.jl:51-62 */
@@ -585,7 +585,7 @@ enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 
 #define RESTORE_AND_CONTINUE do { restore_blocks(M, o, v, y, zL); nrest++; mu = o->mu_init; tau = fmax(o->tau_min, 1 - mu); nf = 0; dw_last = 0; \
         eval_f_theta(M, v, &f, &th, &thinf); th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th); goto next_iter; } while (0)
-static int g_nsoc = 0, g_nsoc_acc = 0;      /* diagnostic: corrections tried / accepted (process-wide) */
+static __thread int g_nsoc = 0, g_nsoc_acc = 0;      /* diagnostic: corrections tried / accepted by the calling thread */
 int obca_oracle_quad_soc_counts(int *acc) { if (acc) *acc = g_nsoc_acc; return g_nsoc; }
 static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, double *zL, double *zU, result_t *res) {
     const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, n = l->n, m = l->m;

@@ -11,26 +11,37 @@ def _init():
             sys.path.insert(0, p)
 
 
+def _opts(O, sw):
+    """oracle options with the three IPOPT switches set explicitly: sw = (max_soc, recalc_y, lsq_init) or None for the defaults (all off)"""
+    o = O.default_opts()
+    if sw:
+        o.max_soc, o.recalc_y, o.lsq_init = (int(v) for v in sw)
+    return o
+
+
+IPOPT = (4, 1, 1)      # the reference's IPOPT configuration: max_soc = 4, recalc_y = "yes", least-squares initial multipliers
+
+
 def _parking_chunk(args):
     _init()
     import numpy as np
     import oracle as O
-    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS) = args
-    out = []
+    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS, sw) = args
+    out = []; o = _opts(O, sw)
     for i in range(len(x0)):
-        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb, A, b, xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i])
+        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb, A, b, xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i], opts=o)
         out.append((lo + i, r["exitflag"], r["iters"], r["obj"], r["xp"], r["up"], r["t"]))
     return out
 
 
-def parking_oracle_all(bt, xWS, workers=None, chunk=8):
+def parking_oracle_all(bt, xWS, workers=None, chunk=8, switches=None):
     """oracle solution of every instance of a shared-obstacle batch: list of (index, exitflag, iters, obj, xp, up, t)"""
     import multiprocessing as mp
     import oracle as O
     O.build()
     B = len(bt["x0"]); N = xWS.shape[1] - 1
     jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"][lo:lo + chunk], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
-             xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk]) for lo in range(0, B, chunk)]
+             xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk], switches) for lo in range(0, B, chunk)]
     workers = workers or min(os.cpu_count() or 1, 64)
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_parking_chunk, jobs)
@@ -64,22 +75,22 @@ def quad_oracle_all(bt, workers=None, chunk=8):
 def _mixed_chunk(args):
     _init()
     import oracle as O
-    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS) = args
-    out = []
+    (lo, x0, xF, N, Ts, L, ego, XYb, vOb, A, b, xWS, uWS, sw) = args
+    out = []; o = _opts(O, sw)
     for i in range(len(x0)):
-        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb[i], A[i], b[i], xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i])
+        r = O.parking_signed_dist(x0[i], xF[i], N, Ts[i], L, ego, XYb, vOb[i], A[i], b[i], xWS[i][:, 0], xWS[i][:, 1], xWS[i][:, 2], 0, xWS[i], uWS[i], opts=o)
         out.append((lo + i, r["exitflag"], r["iters"], r["obj"], r["xp"]))
     return out
 
 
-def mixed_oracle_all(bt, xWS, workers=None, chunk=8):
+def mixed_oracle_all(bt, xWS, workers=None, chunk=8, switches=None):
     """parking oracle on every instance of a batch with per-instance obstacle sets (scenarios.make_mixed_batch)"""
     import multiprocessing as mp
     import oracle as O
     O.build()
     B = len(bt["x0"]); N = xWS.shape[1] - 1
     jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"][lo:lo + chunk], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][lo:lo + chunk],
-             bt["A"][lo:lo + chunk], bt["b"][lo:lo + chunk], xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk]) for lo in range(0, B, chunk)]
+             bt["A"][lo:lo + chunk], bt["b"][lo:lo + chunk], xWS[lo:lo + chunk], bt["uWS"][lo:lo + chunk], switches) for lo in range(0, B, chunk)]
     workers = workers or min(os.cpu_count() or 1, 64)
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_mixed_chunk, jobs)

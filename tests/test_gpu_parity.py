@@ -206,8 +206,16 @@ def test_parking_dist_variant_matches_oracle(OA, oracle):
         assert viol["penetration"] <= 1e-6
     # single-instance wrapper and the exit-flag quirk after two failed attempts (ParkingDist.jl:277-282)
     xp, up, ts, ef, t, lp, npp = OA.ParkingDist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"],
-                                               bt["A"], bt["b"], xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0])
+                                               bt["A"], bt["b"], xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0], opts=OA.default_opts())
     assert ef == 1 and np.abs(xp - out["xp"][0]).max() < 1e-12
+    # ... and with its own default, the reference's IPOPT configuration (ParkingDist.jl:41: recalc_y = "yes"; IPOPT's second-order correction and least-squares start): against the
+    # oracle with the same three options
+    xp, up, ts, ef, t, lp, npp = OA.ParkingDist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"],
+                                               bt["A"], bt["b"], xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0])
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    r = oracle.parking_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                            xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0], opts=oo)
+    assert ef == r["exitflag"] == 1 and np.abs(xp - r["xp"]).max() < TOL_X
     o = OA.default_opts(); o.max_iter = 3
     bad = OA.parking_signed_dist_batch(bt["x0"][:4], bt["xF"][:4], N, bt["Ts"][:4], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
                                        bt["b"], xWS[:4, :, 0], xWS[:4, :, 1], xWS[:4, :, 2], 0, xWS[:4], bt["uWS"][:4], opts=o, dist=True)
@@ -294,9 +302,15 @@ def test_single_instance_wrapper_and_shapes(OA, oracle, backwards):
                                                        backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2],
                                                        0, xWS, uWS)
     assert xp.shape == (4, N + 1) and up.shape == (2, N) and ts.shape == (N + 1,) and lp.shape == (5, N + 1) and npp.shape == (12, N + 1)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1      # the drop-in's default IS the reference's IPOPT configuration (obca_reference_opts)
     r = oracle.parking_signed_dist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
-                                   backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS)
+                                   backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS, opts=oo)
     assert ef == r["exitflag"] == 1 and np.abs(xp - r["xp"]).max() < TOL_X and tm > 0
+    xq = OA.ParkingSignedDist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], 3, backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1],
+                              xWS[:, 2], 0, xWS, uWS, opts=OA.default_opts())[0]      # the throughput defaults: the oracle's defaults
+    r0 = oracle.parking_signed_dist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
+                                    backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS)
+    assert np.abs(xq - r0["xp"]).max() < TOL_X
     l1, n1 = OA.DualMultWS(N, 3, backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], backwards["ego"])
     assert l1.shape == (N + 1, 5) and n1.shape == (N + 1, 12)          # DualMultWS.jl:81-84 returns the transposed shapes
 
@@ -547,9 +561,57 @@ def test_reference_main_jl_call_runs_as_is(OA, oracle, name):
     N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
     A, b, v = S.scenario_hrep(sc); x0, xF = sc["x0"], sc["xF"]; nOb = len(v)
     rx, ry, ryaw = xWS[:, 0].copy(), xWS[:, 1].copy(), xWS[:, 2].copy()
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1      # the drop-ins run the reference's IPOPT configuration by default (obca_reference_opts)
     for fn, ofn in ((OA.ParkingDist, oracle.parking_dist), (OA.ParkingSignedDist, oracle.parking_signed_dist)):
         xp, up, ts, ef, t, lp, npp = fn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, nOb, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
-        r = ofn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
+        r = ofn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS, opts=oo)
         assert ef == r["exitflag"] == 1
         assert xp.shape == (4, N + 1) and up.shape == (2, N)
         assert np.abs(xp - r["xp"]).max() < TOL_X and np.abs(up - r["up"]).max() < TOL_X and abs(float(np.ravel(ts)[0]) - r["t"]) < 1e-9
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("cfg", [2, 3, 5])
+def test_the_reference_ipopt_configuration_at_bench_size_matches_the_oracle_with_the_same_options(OA, cfg):
+    """The reference runs IPOPT with recalc_y = "yes" (ParkingSignedDist.jl:41) and IPOPT's defaults max_soc = 4 and least-squares initial multipliers: obca_reference_opts /
+    obca_amd.ipopt_opts().  With those three switches on in the kernels AND in the oracle: the FULL bench batches of BASELINE configs 2 / 3 / 5 (1 024 / 2 048 / 4 096 instances,
+    rank 0's batch of `bench.py --config c`) -- every exit flag equal, every trajectory to 1e-6 where the iteration counts agree, and the iteration counts themselves equal except
+    where round-off decides an acceptance test on a knife edge (measured in round 4: 0 / 1 / 0 instances; at most 4 tolerated on config 3, none elsewhere).  The test REPORTS the counts."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_pool
+    N = 80
+    bt = S.make_batch(S.BACKWARDS, 1024, N, seed=20260925) if cfg == 2 else (S.make_batch(S.PARALLEL, 2048, N, seed=20260925, goal_jitter=True) if cfg == 3 else S.make_mixed_batch(4096, N, seed=20260925, min_obstacles=1))
+    B = len(bt["x0"])
+    out, xWS = _solve_batch(OA, dict(bt, N=N), opts=OA.ipopt_opts())
+    ref = oracle_pool.mixed_oracle_all(bt, xWS, switches=oracle_pool.IPOPT) if cfg == 5 else oracle_pool.parking_oracle_all(bt, xWS, switches=oracle_pool.IPOPT)
+    assert len(ref) == B
+    off = 0; worst_x = worst_f = 0.0
+    for r in ref:
+        i, ef, it, obj, xp = r[0], r[1], r[2], r[3], r[4]
+        assert out["exitflag"][i] == ef == 1, (i, out["exitflag"][i], ef)
+        if out["iters"][i] != it:
+            off += 1; continue
+        worst_f = max(worst_f, abs(out["obj"][i] - obj) / max(1, abs(obj))); worst_x = max(worst_x, np.abs(out["xp"][i] - xp).max())
+    print("config %d, reference IPOPT configuration on both sides: %d instances, iteration counts differ on %d, worst |dx| %.2e, worst rel. objective %.2e" % (cfg, B, off, worst_x, worst_f))
+    assert off <= (4 if cfg == 3 else 0) and worst_x < TOL_X and worst_f < TOL_F, (off, worst_x, worst_f)
+
+
+def test_parking_dist_with_the_reference_ipopt_configuration_matches_the_oracle(OA, oracle):
+    """ParkingDist (ParkingDist.jl:41 sets recalc_y = "yes" too) with max_soc = 4, recalc_y, lsq_init on both sides: the LSQ / SOC instantiations of the block code in the
+    ParkingDist formulation (norm-row slack s1 and its multiplier) -- 48 instances of the backwards scenario, iteration for iteration"""
+    N, B = 80, 48
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=11)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
+                                       xWS, bt["uWS"], opts=OA.ipopt_opts(), dist=True)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    nsolved = 0
+    for i in range(B):
+        r = oracle.parking_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
+                                xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i], opts=oo)
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"], (i, out["exitflag"][i], r["exitflag"], out["iters"][i], r["iters"])
+        if r["exitflag"] == 1:
+            nsolved += 1
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and np.abs(out["up"][i] - r["up"]).max() < TOL_X
+    assert nsolved >= B - 4

@@ -130,15 +130,15 @@ def test_quad_oracle_reproduces_golden_config4(Q):
         assert np.array_equal(r["xp"], g["xp"][i]) and np.array_equal(r["up"], g["up"][i]) and r["t"] == g["t"][i]
 
 
-def test_quadcopter_second_order_correction_option(monkeypatch):
-    """IPOPT's second-order correction as an option of the quadcopter oracle (environment OBCA_QSOC = max_soc; the reference's quadcopter call runs IPOPT's default, 4): the same
+def test_quadcopter_second_order_correction_option():
+    """IPOPT's second-order correction as an option of the quadcopter oracle (opts.max_soc; the reference's quadcopter call runs IPOPT's default, 4): the same
     solved instances, fewer iterations on most, the same optimum up to the flatness of the cost -- and not worth its passes: the census in DESIGN.md section 9"""
     import oracle_quad as Q
     from obca_amd import scenarios as S
     q = S.make_quad_batch(4, 60, seed=20260925, random_endpoints=True)
     base = [Q.quadcopter_signed_dist(q["x0"][i], q["xF"][i], 60, q["Ts"], q["R"], q["ob"], q["xWS"][i], q["timeWS"]) for i in range(4)]
-    monkeypatch.setenv("OBCA_QSOC", "4")
-    soc = [Q.quadcopter_signed_dist(q["x0"][i], q["xF"][i], 60, q["Ts"], q["R"], q["ob"], q["xWS"][i], q["timeWS"]) for i in range(4)]
+    o = Q.default_opts(); o.max_soc = 4
+    soc = [Q.quadcopter_signed_dist(q["x0"][i], q["xF"][i], 60, q["Ts"], q["R"], q["ob"], q["xWS"][i], q["timeWS"], opts=o) for i in range(4)]
     assert all(r["exitflag"] == 1 for r in base + soc)
     assert sum(r["iters"] for r in soc) < sum(r["iters"] for r in base)
     assert all(abs(a["obj"] - b["obj"]) <= 2e-3 * max(1.0, abs(a["obj"])) for a, b in zip(base, soc))

@@ -39,9 +39,7 @@ def main():
             dx = np.abs(out["xp"][i] - xp).max(); worst = max(worst, dx); wf = max(wf, abs(out["obj"][i] - obj) / max(1, abs(obj)))
             if dx > 1e-6: x_bad += 1
         if "--ipopt-options" in sys.argv:
-            os.environ["OBCA_SOC"] = "4"; os.environ["OBCA_RECALC_Y"] = "1"
-            ref2 = oracle_pool.parking_oracle_all(bt, xWS) if c != 5 else oracle_pool.mixed_oracle_all(bt, xWS)
-            os.environ.pop("OBCA_SOC"); os.environ.pop("OBCA_RECALC_Y")
+            ref2 = oracle_pool.parking_oracle_all(bt, xWS, switches=(4, 1, 0)) if c != 5 else oracle_pool.mixed_oracle_all(bt, xWS, switches=(4, 1, 0))
             efd = itd = 0; wx = wf2 = 0.0; ndiff = 0
             for r in ref2:
                 i, ef, it, obj, xp = r[0], r[1], r[2], r[3], r[4]
@@ -50,11 +48,9 @@ def main():
                     dxi = np.abs(out["xp"][i] - xp).max(); wx = max(wx, dxi); wf2 = max(wf2, abs(out["obj"][i] - obj) / max(1, abs(obj))); ndiff += int(dxi > 1e-3)
             print("config %d vs oracle WITH max_soc=4 + recalc_y: exit-flag differences %d  iteration-count differences %d  instances ending in another local solution (|dx| > 1e-3) %d  worst |dx| %.2e  worst rel. objective difference %.2e" % (c, efd, itd, ndiff, wx, wf2), flush=True)
         if "--gpu-ipopt-options" in sys.argv:      # the kernels WITH their IPOPT switches against the oracle with the same ones: parity at size (round 3: the switches exist on both sides)
-            o = OA.default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
+            o = OA.ipopt_opts()
             out3 = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"], opts=o)
-            os.environ["OBCA_SOC"] = "4"; os.environ["OBCA_RECALC_Y"] = "1"; os.environ["OBCA_LSQ_INIT"] = "1"
-            ref3 = oracle_pool.parking_oracle_all(bt, xWS) if c != 5 else oracle_pool.mixed_oracle_all(bt, xWS)
-            for k_ in ("OBCA_SOC", "OBCA_RECALC_Y", "OBCA_LSQ_INIT"): os.environ.pop(k_)
+            ref3 = oracle_pool.parking_oracle_all(bt, xWS, switches=oracle_pool.IPOPT) if c != 5 else oracle_pool.mixed_oracle_all(bt, xWS, switches=oracle_pool.IPOPT)
             efd = itd = nx = 0; wx = 0.0
             for r in ref3:
                 i, ef, it, obj, xp = r[0], r[1], r[2], r[3], r[4]

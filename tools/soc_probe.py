@@ -1,4 +1,4 @@
-"""Oracle A/B of an IPOPT semantic (second-order correction OBCA_SOC=4, recalc_y OBCA_RECALC_Y=1): exit flags and iteration counts
+"""Oracle A/B of an IPOPT semantic (switches = (max_soc, recalc_y, lsq_init) of the oracle options, set explicitly): exit flags and iteration counts
 on the config-5 distribution (1-10 obstacles) and on config 3 (parallel parking, goal jitter).  python tools/soc_probe.py [B5] [B3]"""
 import os, sys, time
 import numpy as np
@@ -16,18 +16,15 @@ def stats(tag, res):
 
 if __name__ == "__main__":
     B5 = int(sys.argv[1]) if len(sys.argv) > 1 else 512; B3 = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    envs = [dict(), dict(OBCA_SOC="4")] + ([dict(OBCA_RECALC_Y="1"), dict(OBCA_SOC="4", OBCA_RECALC_Y="1")] if "--recalc" in sys.argv else [])
-    if "--lsq" in sys.argv: envs = [dict(), dict(OBCA_LSQ_INIT="1")]
+    envs = [None, (4, 0, 0)] + ([(0, 1, 0), (4, 1, 0)] if "--recalc" in sys.argv else [])
+    if "--lsq" in sys.argv: envs = [None, (0, 0, 1)]
     bt5 = S.make_mixed_batch(B5, 80, seed=20260925, min_obstacles=1) if B5 else None
     bt3 = S.make_batch(S.PARALLEL, B3, 80, seed=20260925, goal_jitter=True) if B3 else None
     out = {}
     for e in envs:
-        for k in ("OBCA_SOC", "OBCA_RECALC_Y", "OBCA_LSQ_INIT"):
-            os.environ.pop(k, None)
-        os.environ.update(e)
         t0 = time.time()
-        if bt5: out[("c5", str(e))] = stats(f"config5 {e}", P.mixed_oracle_all(bt5, bt5["xWS"], workers=8))
-        if bt3: out[("c3", str(e))] = stats(f"config3 {e}", P.parking_oracle_all(bt3, bt3["xWS"], workers=8))
+        if bt5: out[("c5", str(e))] = stats(f"config5 {e}", P.mixed_oracle_all(bt5, bt5["xWS"], workers=8, switches=e))
+        if bt3: out[("c3", str(e))] = stats(f"config3 {e}", P.parking_oracle_all(bt3, bt3["xWS"], workers=8, switches=e))
         print("  %.0f s" % (time.time() - t0), flush=True)
     base = str(envs[0])
     for (c, e), (fl, it) in out.items():
