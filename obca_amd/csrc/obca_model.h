@@ -91,11 +91,6 @@ OBCA_FN void sincos_bounded(double x, double *sp, double *cp) {
 OBCA_FN double tan_bounded(double x) { double s_, c_; sincos_bounded(x, &s_, &c_); return s_ / c_; }      // (steering angles: |x| <= 0.6, cos >= 0.8)
 
 // ---------------------------------------------------------------- bicycle model, vars (psi, v, delta, a, t)
-struct DynOut {
-    double F[4];
-    double dF[4][5];   // d(F_i - x_i)/d(psi,v,delta,a,t)
-};
-
 OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], double t, double F[4]) {
     double tau = c.Ts * t, s = x[3] + 0.5 * tau * u[1], T = tan_bounded(u[0]);
     double phi = x[2] + tau * x[3] * T * (0.5 * c.iL), sn, cs;
@@ -103,57 +98,57 @@ OBCA_FN void dyn_value(const Consts &c, const double x[4], const double u[2], do
     F[0] = x[0] + tau * s * cs; F[1] = x[1] + tau * s * sn; F[2] = x[2] + tau * s * T * c.iL; F[3] = x[3] + tau * u[1];
 }
 
-// first derivatives and  HL = sum_i w_i Hess(F_i)  (5x5, symmetric, full storage)
-OBCA_FN void dyn_derivs(const Consts &c, const double x[4], const double u[2], double t, const double w[4], DynOut &o,
-                        double HL[5][5]) {
-    double Ts = c.Ts, iL = c.iL, i2L = 0.5 * c.iL, v = x[3], a = u[1];
-    double tau = Ts * t, s = v + 0.5 * tau * a, T = tan_bounded(u[0]), Tp = 1 + T * T;
-    double phi = x[2] + tau * v * T * i2L, sn, cs;
-    sincos_bounded(phi, &sn, &cs);
+// First derivatives and HL = sum_i w_i Hess(F_i) of the bicycle map in the variables (psi, v, delta, a, t), with the structure written out.
+// F is a composition through m = (tau, s, phi) [rows X, Y] and (tau, s, T) [row psi] with
+//   dtau = Ts e_t,   ds = e_v + d3 e_a + d4 e_t,   dphi = e_psi + p1 e_v + p2 e_delta + p4 e_t,   dT = Tp e_delta
+// so every Jacobian / Hessian entry is a short closed form; the generic triple products over these mostly-zero vectors (rounds 1-3) cost four times the
+// instructions -- a product with a literal zero cannot be folded by the compiler (0 x inf) -- and kept ~60 more values alive in the stage assembly.
+// Only what the assembly uses is produced: the 16 Jacobian entries that can be non-zero (as_df), and the 14 entries of the symmetric HL that can be non-zero.
+struct Dyn {
+    double F[4];
+    double dX[5], dY[5];      // d(F_X - X), d(F_Y - Y) / d(psi, v, delta, a, t)
+    double dP[4];             // d(F_psi - psi) / d(v, delta, a, t)        (no dependence on psi beyond the identity)
+    double dVa, dVt;          // d(F_v - v) / d(a, t)
+    double h00, h01, h02, h03, h04, h11, h12, h13, h14, h22, h23, h24, h34, h44;      // HL(i, j), i <= j; HL(3, 3) = 0
+};
+OBCA_FN void dyn_derivs(const double Ts, const double iL, const double x[4], const double u[2], double t, const double w[4], Dyn &o) {      // Ts, iL = 1 / L: the caller's (uniform) copies of Consts::Ts, Consts::iL
+    const double i2L = 0.5 * iL, v = x[3], a = u[1];
+    const double tau = Ts * t, s = v + 0.5 * tau * a, T = tan_bounded(u[0]), Tp = 1 + T * T;
+    const double phi = x[2] + tau * v * T * i2L;
+    double sn, cs; sincos_bounded(phi, &sn, &cs);
     o.F[0] = x[0] + tau * s * cs; o.F[1] = x[1] + tau * s * sn; o.F[2] = x[2] + tau * s * T * iL; o.F[3] = v + tau * a;
-    const double dtau[5] = {0, 0, 0, 0, Ts};
-    const double ds[5] = {0, 1, 0, 0.5 * tau, 0.5 * Ts * a};
-    const double dphi[5] = {1, tau * T * i2L, tau * v * Tp * i2L, 0, Ts * v * T * i2L};
-    const double dT[5] = {0, 0, Tp, 0, 0};
-    const double g1[3] = {s * cs, tau * cs, -tau * s * sn};
-    const double g2[3] = {s * sn, tau * sn, tau * s * cs};
-    const double g3[3] = {s * T * iL, tau * T * iL, tau * s * iL};
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-        o.dF[0][i] = g1[0] * dtau[i] + g1[1] * ds[i] + g1[2] * dphi[i];
-        o.dF[1][i] = g2[0] * dtau[i] + g2[1] * ds[i] + g2[2] * dphi[i];
-        o.dF[2][i] = g3[0] * dtau[i] + g3[1] * ds[i] + g3[2] * dT[i];
-        o.dF[3][i] = 0;
-    }
-    o.dF[3][3] = tau; o.dF[3][4] = Ts * a;
-    // second derivatives: Hess(F_i) = sum_ab G_ab dm_a dm_b^T + sum_a g_a Hess(m_a), m = (tau, s, phi) for F_X, F_Y and (tau, s, T)
-    // for F_psi.  Only HL = sum_i w_i Hess(F_i) is needed, so the weights are folded into two quadratic forms.
-    const double G12[3][3] = {{0, w[0] * cs + w[1] * sn, w[0] * (-s * sn) + w[1] * (s * cs)},
-                              {w[0] * cs + w[1] * sn, 0, w[0] * (-tau * sn) + w[1] * (tau * cs)},
-                              {w[0] * (-s * sn) + w[1] * (s * cs), w[0] * (-tau * sn) + w[1] * (tau * cs), w[0] * (-tau * s * cs) + w[1] * (-tau * s * sn)}};
-    const double G3w[3][3] = {{0, w[2] * T * iL, w[2] * s * iL}, {w[2] * T * iL, 0, w[2] * tau * iL}, {w[2] * s * iL, w[2] * tau * iL, 0}};
-    const double gs = w[0] * g1[1] + w[1] * g2[1] + w[2] * g3[1];      // weight of Hess(s)
-    const double gp = w[0] * g1[2] + w[1] * g2[2];                      // weight of Hess(phi)
-    const double gT = w[2] * g3[2];                                     // weight of Hess(T)
-    double U12[3][5], U3[3][5];
-#pragma unroll
-    for (int a_ = 0; a_ < 3; a_++)
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            U12[a_][j] = G12[a_][0] * dtau[j] + G12[a_][1] * ds[j] + G12[a_][2] * dphi[j];
-            U3[a_][j] = G3w[a_][0] * dtau[j] + G3w[a_][1] * ds[j] + G3w[a_][2] * dT[j];
-        }
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-            HL[i][j] = dtau[i] * (U12[0][j] + U3[0][j]) + ds[i] * (U12[1][j] + U3[1][j]) + dphi[i] * U12[2][j] + dT[i] * U3[2][j];
-    // Hess(s): (a,t)=Ts/2 ; Hess(phi): (v,d)=tau Tp/2L, (v,t)=Ts T/2L, (d,d)=tau v T Tp/L, (d,t)=Ts v Tp/2L ; Hess(T): (d,d)=2 T Tp ; Hess(F_v): (a,t)=Ts
-    const double hat = gs * 0.5 * Ts + w[3] * Ts;
-    HL[3][4] += hat; HL[4][3] += hat;
-    const double hvd = gp * tau * Tp * i2L, hvt = gp * Ts * T * i2L, hdt = gp * Ts * v * Tp * i2L;
-    HL[1][2] += hvd; HL[2][1] += hvd; HL[1][4] += hvt; HL[4][1] += hvt; HL[2][4] += hdt; HL[4][2] += hdt;
-    HL[2][2] += gp * tau * v * T * Tp * iL + gT * 2 * T * Tp;
+    const double d3 = 0.5 * tau, d4 = 0.5 * Ts * a;                                   // ds / d(a, t)
+    const double p1 = tau * T * i2L, p2 = tau * v * Tp * i2L, p4 = Ts * v * T * i2L;      // dphi / d(v, delta, t)
+    const double ts = tau * s;
+    const double gX0 = s * cs, gX1 = tau * cs, gX2 = -ts * sn;      // dF_X / d(tau, s, phi)
+    const double gY0 = s * sn, gY1 = tau * sn, gY2 = ts * cs;       // dF_Y / d(tau, s, phi)
+    const double gP0 = s * T * iL, gP1 = tau * T * iL, gP2 = ts * iL;      // dF_psi / d(tau, s, T)
+    o.dX[0] = gX2; o.dX[1] = fma(gX2, p1, gX1); o.dX[2] = gX2 * p2; o.dX[3] = gX1 * d3; o.dX[4] = fma(gX2, p4, fma(gX1, d4, gX0 * Ts));
+    o.dY[0] = gY2; o.dY[1] = fma(gY2, p1, gY1); o.dY[2] = gY2 * p2; o.dY[3] = gY1 * d3; o.dY[4] = fma(gY2, p4, fma(gY1, d4, gY0 * Ts));
+    o.dP[0] = gP1; o.dP[1] = gP2 * Tp; o.dP[2] = gP1 * d3; o.dP[3] = fma(gP1, d4, gP0 * Ts);
+    o.dVa = tau; o.dVt = Ts * a;
+    // second derivatives in m-space, weighted: rows X, Y share (tau, s, phi), row psi has (tau, s, T)
+    const double wc = fma(w[1], sn, w[0] * cs), wsn = fma(w[1], cs, -(w[0] * sn));      // w0 cs + w1 sn;  -w0 sn + w1 cs
+    const double A = wc, Bq = s * wsn, Cq = tau * wsn, Dq = -ts * wc;                   // (tau,s), (tau,phi), (s,phi), (phi,phi)
+    const double E = w[2] * T * iL, Fq = w[2] * s * iL, Gq = w[2] * tau * iL;           // (tau,s), (tau,T), (s,T)
+    const double gs = tau * fma(w[2], T * iL, wc);                                       // weight of Hess(s)
+    const double gp = ts * wsn;                                                          // weight of Hess(phi)
+    const double gT = w[2] * ts * iL;                                                    // weight of Hess(T)
+    const double CD1 = fma(Dq, p1, Cq);                                                  // Cq + Dq p1
+    o.h00 = Dq;
+    o.h01 = CD1;
+    o.h02 = Dq * p2;
+    o.h03 = Cq * d3;
+    o.h04 = fma(Dq, p4, fma(Cq, d4, Bq * Ts));
+    o.h11 = p1 * (Cq + CD1);
+    o.h12 = fma(gp, tau * Tp * i2L, fma(Gq, Tp, p2 * CD1));
+    o.h13 = Cq * p1 * d3;
+    o.h14 = fma(gp, Ts * T * i2L, fma(E + A, Ts, fma(Bq * Ts, p1, fma(Cq, fma(p1, d4, p4), Dq * p1 * p4))));
+    o.h22 = fma(gT, 2 * T * Tp, fma(gp, tau * v * T * Tp * iL, Dq * p2 * p2));
+    o.h23 = d3 * fma(Gq, Tp, Cq * p2);
+    o.h24 = fma(gp, Ts * v * Tp * i2L, fma(Gq * Tp, d4, fma(Fq * Tp, Ts, p2 * fma(Dq, p4, fma(Cq, d4, Bq * Ts)))));
+    o.h34 = fma(w[3], Ts, fma(gs, 0.5 * Ts, d3 * fma(Cq, p4, (A + E) * Ts)));
+    o.h44 = fma(Dq * p4, p4, 2 * fma(Cq * d4, p4, fma(Bq * Ts, p4, (A + E) * Ts * d4)));
 }
 
 // ---------------------------------------------------------------- small dense helpers (compile-time sizes)
@@ -253,7 +248,7 @@ OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
            (in.Y + sn * c.off) * p2 - beta + (c.dist ? 0.0 : in.sl) - OB_DMIN - in.so;   // ParkingDist.jl:207-208: no slack
 }
 
-struct ObsStats { double dmax, pmax, cmax0, cmin, cmax, sumz, sumy; int bad; };   // cmin / cmax: smallest / largest complementarity product s z (the error w.r.t. ANY barrier
+struct ObsStats { double dmax, pmax, cmin, cmax, sumz, sumy; int bad; };   // cmin / cmax: smallest / largest complementarity product s z (the error w.r.t. ANY barrier
                                                                                    // parameter follows from the two: max |s z - mu| = max(|cmax - mu|, |cmin - mu|), rounding is monotone)
 
 struct ObsCond {          // result of the condensation onto the pose
@@ -319,7 +314,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         else { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
         if (MODE == 0) {
             double rz = fabs(jy - in.zm[i]); st->dmax = fmax(st->dmax, rz);
-            double cc = in.mu[i] * in.zm[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
+            double cc = in.mu[i] * in.zm[i]; st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
             st->sumz += fabs(in.zm[i]);
         }
     }
@@ -331,7 +326,7 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
             else { const double il = rcp_nr<RS_>(in.lam[i]); r_lam[i] = jy - mu_b * il; Dlam[i] = in.zl[i] * il + dw; }
             if (MODE == 0) {
                 double rz = fabs(jy - in.zl[i]); st->dmax = fmax(st->dmax, rz);
-                double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
+                double cc = in.lam[i] * in.zl[i]; st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
                 st->sumz += fabs(in.zl[i]);
             }
         } else { r_lam[i] = 0; Dlam[i] = 1; }
@@ -339,8 +334,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     if (MODE == 0) {
         double rz = fabs(-y[3] - in.zso); st->dmax = fmax(st->dmax, rz);
         { const double rzs = c.dist ? fabs(y[0] - in.zs1) : fabs(r_sl); st->dmax = fmax(st->dmax, rzs); }
-        if (c.dist) { const double c1 = in.sl * in.zs1; st->cmax0 = fmax(st->cmax0, fabs(c1)); st->cmin = fmin(st->cmin, c1); st->cmax = fmax(st->cmax, c1); st->sumz += fabs(in.zs1); }
-        double cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
+        if (c.dist) { const double c1 = in.sl * in.zs1; st->cmin = fmin(st->cmin, c1); st->cmax = fmax(st->cmax, c1); st->sumz += fabs(in.zs1); }
+        double cc = in.so * in.zso; st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
         st->sumz += fabs(in.zso);
 #pragma unroll
         for (int r = 0; r < 4; r++) { st->pmax = fmax(st->pmax, fabs(cr[r])); st->sumy += fabs(y[r]); }

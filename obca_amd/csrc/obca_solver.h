@@ -36,6 +36,7 @@
 #define LDS_BARRIER() ((void)0)
 #define OBCA_NLT OB_NT
 #define UNIFORM(x) (x)
+#define UNIFORM_D(x) (x)
 #define OPAQUE(x) ((void)0)
 #define SEAM(x) ((void)0)
 #define OBCA_NL 64          // per-lane variables that live across a SYNC are arrays over the lanes in the emulation
@@ -66,6 +67,7 @@
 // expression into the consumers, or a resumed solve (which assembles the stored point) would walk through different bits than an uninterrupted one
 #define SEAM(x) asm volatile("" : "+v"(x))
 #define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // value known to be wave-uniform: keep it in an SGPR (scalar branches, scalar loop counters)
+#define UNIFORM_D(x) __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)))   // the same for a double: two SGPRs instead of two VGPRs
 #define OBCA_NL 1
 #define LI(lane) 0
 #endif
@@ -194,11 +196,7 @@ struct Soc {                // state of the three IPOPT switches (second-order c
 
 struct alignas(16) Shared {
     double hdr[OB_HDR];
-    // Riccati backward sweep.  Every operand of its dot products is a CONTIGUOUS, 16-byte aligned 6-vector (P rows, the rows of the transposed FA', T', p'), read as three
-    // ds_read_b128: a lone wavefront per SIMD issues 8-byte LDS reads at a fifth of the LDS rate but 16-byte reads at the full rate (MI355X_MICROARCH.md, LDS).
-    alignas(16) double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];     // P (row-major, symmetric), p' (pn[c * 6 + a]: right-hand side c, state a), Qhat (8 x 14 row-major)
-    alignas(16) double Bm[36], sB[24], coef[8], TT[14 * 6];     // border constants, their static parts, (dt, nu), T' (TT[cc * 6 + a])
-    alignas(16) double zero6[6]; double zero, dump, dump4[4];        // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
+    alignas(16) double Bm[36], coef[8];                         // border constants (left by the backward sweep for the border solve), (dt, nu)
     double filt[OB_FILT_LDS][2];
     Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok, upl[OB_NT], ucn[3][OB_NT];      // upl, ucn: which positions of the unpacked stage data a lane serves (init_unpack_table)
@@ -208,11 +206,24 @@ struct alignas(16) Shared {
     Soc soc;
 };
 
-// Dynamic LDS behind `Shared`, sized for the horizon at launch (OB_DYN_LDS_DOUBLES): the closed-loop state trajectory of the forward sweep (s_k = (dx_k, dw_k): the x part of the
-// search direction lives here and nowhere else), and behind it EITHER the double-buffered unpacked stage data of the Riccati backward sweep (2 x OB_STG doubles, SG_* offsets,
-// + a pad slot for lanes without an item) OR the composed closed-loop maps of the stage pairs of the forward sweep (the two sweeps never overlap in time).
+// Dynamic LDS behind `Shared`, sized for the horizon at launch (OB_DYN_LDS_DOUBLES).  Three layouts share it, one per phase of a pass (they never overlap in time):
+//   forward sweep / line search : [ trajectory (N + 2) x 6 | composed closed-loop maps of the stage pairs (N / 2 + 1) x 42 ]      s_k = (dx_k, dw_k): the x part of the search
+//                                 direction lives in the trajectory and nowhere else (direction_*, the fused line search read it)
+//   assembly                    : [ trajectory (still the direction the trial point is formed along) | condensed obstacle sums (N + 1) x 12 ]
+//   backward sweep              : [ per-stage border data N x RIC_BD | two unpacked stage buffers 2 x OB_STG (SG_* offsets, + a pad slot) | operands RicLds ]   -- the trajectory is dead
+//                                 by then (a backward sweep always starts a new direction), so the sweep uses the region from its start
+// Round 3 kept the sweep's operands (2.4 KB) in the static block; with them here the block is 5 KB and seven instances fit a CU's 160 KB instead of six.
 #define OB_STG 200
-#define OB_DYN_LDS_DOUBLES(N) ((size_t)((N) + 2) * 6 + ((size_t)((N) / 2 + 1) * 42 > 2 * OB_STG + (size_t)16 * (N) ? (size_t)((N) / 2 + 1) * 42 : 2 * OB_STG + (size_t)16 * (N)))
+struct alignas(16) RicLds {
+    // Riccati backward sweep.  Every operand of its dot products is a CONTIGUOUS, 16-byte aligned 6-vector (P rows, the rows of the transposed FA', T', p'), read as three
+    // ds_read_b128: a lone wavefront per SIMD issues 8-byte LDS reads at a fifth of the LDS rate but 16-byte reads at the full rate (MI355X_MICROARCH.md, LDS).
+    alignas(16) double Pn[36], pn[6 * OB_NC], Qhat[8 * 14];     // P (row-major, symmetric), p' (pn[c * 6 + a]: right-hand side c, state a), Qhat (8 x 14 row-major)
+    alignas(16) double sB[24], TT[14 * 6];                      // static parts of the border constants, T' (TT[cc * 6 + a])
+    alignas(16) double zero6[6]; double zero, dump, dump4[4];   // constant 0 and a write-only slot: operand / destination of the lanes without an item in the Riccati phases
+};
+#define OB_RICLDS_DOUBLES (sizeof(RicLds) / sizeof(double))
+#define OB_MAX2(a, b) ((a) > (b) ? (a) : (b))
+#define OB_DYN_LDS_DOUBLES(N) OB_MAX2((size_t)((N) + 2) * 6 + OB_MAX2((size_t)((N) / 2 + 1) * 42, (size_t)((N) + 1) * OB_OC), (size_t)16 * (N) + 2 * OB_STG + OB_RICLDS_DOUBLES)
 #ifdef OBCA_EMU
 static Shared g_sh;
 alignas(16) static double g_traj[OB_DYN_LDS_DOUBLES(OB_NMAX)];
@@ -221,7 +232,9 @@ __shared__ Shared g_sh;     // the static LDS block of the workgroup (= one wave
 extern __shared__ __attribute__((aligned(16))) double g_traj[];
 #endif
 
-OBCA_FN double *stg_base(const Shared &sh) { return g_traj + (size_t)(sh.c.N + 2) * 6; }     // stage buffers of the backward sweep / pair maps of the forward sweep
+OBCA_FN double *stg_base(const Shared &sh) { return g_traj + (size_t)(sh.c.N + 2) * 6; }     // pair maps of the forward sweep / condensed obstacle sums of the assembly: behind the trajectory
+OBCA_FN double *ric_sg0(const Shared &sh) { return g_traj + (size_t)sh.c.N * 16; }            // backward sweep: the two stage buffers, behind the per-stage border data (RIC_BD = 16 doubles per stage)
+OBCA_FN RicLds &ric_lds(const Shared &sh) { return *(RicLds *)(ric_sg0(sh) + 2 * OB_STG); }   // backward sweep: its operands, behind the stage buffers
 
 // phase ids of the diagnostic cycle counters
 enum { PF_INIT = 0, PF_ASM_OBS, PF_ASM_STAGE, PF_RIC_BWD, PF_BORDER_CL, PF_FWD_SEQ, PF_BS_STAGE, PF_BS_OBS, PF_TRIAL, PF_APPLY, PF_OTHER, PF_RIC_P1, PF_RIC_P2, PF_N };
@@ -330,6 +343,21 @@ OBCA_FN double red_sum(const double *r) { return red_sum_t<OB_NT>(r); }
 OBCA_FN double red_max(const double *r) { return red_max_t<OB_NT>(r); }
 OBCA_FN double red_min(const double *r) { return red_min_t<OB_NT>(r); }
 
+// *p += v on a double in LDS (ds_add_f64; relaxed, workgroup scope: the instance is one wavefront)
+OBCA_FN void lds_add(double *p, double v) {
+#ifdef OBCA_EMU
+    *p += v;
+#else
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// the per-instance constants the (stage, obstacle) block code reads, copied into scalar registers (as LDS reads they would sit in vector registers for the whole item loop)
+OBCA_FN void obs_consts(const Consts &s_, Consts &c) {
+    c.N = UNIFORM(s_.N); c.nOb = UNIFORM(s_.nOb); c.M = UNIFORM(s_.M); c.dist = UNIFORM(s_.dist); c.fixTime = UNIFORM(s_.fixTime);
+    c.off = UNIFORM_D(s_.off);
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.g[i] = UNIFORM_D(s_.g[i]);
+}
 template <int VM>
 OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int j, ObsIn<VM> &in) {
     const Lay &l = sh.l; const int nOb = sh.c.nOb, M = sh.c.M;
@@ -349,14 +377,19 @@ OBCA_FN void load_obs(const Inst &I, const Shared &sh, const gdbl *z, int k, int
 }
 
 struct B2 { double Sig, gz, gb; };
-OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmn, double &cmx, double &sumz) {
+// (the largest |s z| is not tracked: it is max(|smallest product|, |largest product|), formed once from cmn / cmx where the assembly ends)
+OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &cmn, double &cmx, double &sumz) {
     const double dL = v - lo, dU = hi - v, iL = rcp_nr(dL), iU = rcp_nr(dU);
     B2 r; r.Sig = mult * (zL * iL + zU * iU); r.gz = mult * (-zL + zU); r.gb = mult * mu * (iU - iL);
     double c1 = dL * zL, c2 = dU * zU;
-    c0 = fmax(c0, fabs(c1));
-    c0 = fmax(c0, fabs(c2));
     cmn = fmin(cmn, fmin(c1, c2)); cmx = fmax(cmx, fmax(c1, c2));
     sumz += fabs(zL) + fabs(zU);
+    return r;
+}
+// the same with the running max of |s z| kept by the caller (the quadcopter kernel's stage assembly, obca_quad_solver.h)
+OBCA_FN B2 bound2(double v, double lo, double hi, double zL, double zU, double mu, double mult, double &c0, double &cmn, double &cmx, double &sumz) {
+    const B2 r = bound2(v, lo, hi, zL, zU, mu, mult, cmn, cmx, sumz);
+    c0 = fmax(c0, fmax(fabs((v - lo) * zL), fabs((hi - v) * zU)));
     return r;
 }
 // Barrier sums.  sum_i log(d_i) is evaluated as log(prod_i d_i) over groups of at most G distances: a double-precision log is a ~2k-clock
@@ -422,15 +455,21 @@ struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal
 // SOC = 1: the system of a second-order correction step -- FUSED = 0: condensation with c_soc on the right-hand side; FUSED = 1: the block steps of the trial are those of
 // the correction direction (recomputed with c_soc), the assembly at the trial point is the ordinary one.
 template <int VM, int FUSED, int SOC = 0, int LSQ = 0>      // LSQ = 1 (with FUSED = 0): the blocks of the least-squares multiplier system (obs_block)
-OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa) {
-    const Consts &c = sh.c; const Lay &l = sh.l;
+OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, const FuseArgs &fa_) {
+    const Lay &l = sh.l;
+    Consts c; obs_consts(sh.c, c);            // the constants the block code uses, in scalar registers (see assemble_stage)
+    const double mu = UNIFORM_D(mu_), dw = UNIFORM_D(dw_), dc = UNIFORM_D(dc_);
+    const FuseArgs fa = {UNIFORM_D(fa_.alpha), UNIFORM_D(fa_.ay), UNIFORM_D(fa_.az), UNIFORM_D(fa_.ks), UNIFORM_D(fa_.dw_dir)};
     const int N = c.N, nOb = c.nOb, M = c.M;
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const gdbl *z = I.z; gdbl *zn = I.zn;
     double red[11][OBCA_NL];                 // per-lane partial results, reduced over the wavefront in registers
+    double *ocs = stg_base(sh);              // 12 condensed sums per stage (LDS: the region of the sweeps' buffers, idle during the assembly)
+    PAR(lane) { for (int i = lane; i < (N + 1) * OB_OC; i += OB_NT) ocs[i] = 0.0; }
+    LDS_SYNC();
     // ---- (a) obstacle blocks: one lane per (stage, obstacle)
     PAR(lane) {
-        ObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
+        ObsStats st; st.dmax = st.pmax = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0;
         for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
             int k = it / nOb, j = it - k * nOb;
@@ -481,11 +520,14 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
             }
             ObsCond cd;
             obs_block<0, VM, (SOC && !FUSED) ? 1 : 0, LSQ>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, crs);
-            gdbl *o = I.oc + (size_t)it * OB_OC;
+            // the condensed contribution goes straight into the stage's 12 sums in LDS (rounds 1-3 wrote a record per (stage, obstacle) to HBM and the stage part read nOb of them back:
+            // 72 doubles of traffic per stage and pass).  The lanes of one wavefront that hit the same sum are served in lane order, the rounds in program order: the sums are the same
+            // bits in every run, and the host emulation adds in the same order.
+            double *o = ocs + (size_t)k * OB_OC;
 #pragma unroll
-            for (int i = 0; i < 6; i++) o[i] = cd.Hpp[i];
+            for (int i = 0; i < 6; i++) lds_add(o + i, cd.Hpp[i]);
 #pragma unroll
-            for (int i = 0; i < 3; i++) { o[6 + i] = cd.gz[i]; o[9 + i] = cd.gcorr[i]; }
+            for (int i = 0; i < 3; i++) { lds_add(o + 6 + i, cd.gz[i]); lds_add(o + 9 + i, cd.gcorr[i]); }
             if (!c.dist) fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
             double r[4]; obs_rows<VM>(c, in, r);
             th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
@@ -499,12 +541,12 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
                 bar += log_prod(dd);
             }
         }
-        red[0][LI(lane)] = st.dmax; red[1][LI(lane)] = st.pmax; red[2][LI(lane)] = st.cmax0; red[3][LI(lane)] = st.cmin; red[10][LI(lane)] = st.cmax;
+        red[0][LI(lane)] = st.dmax; red[1][LI(lane)] = st.pmax; red[3][LI(lane)] = st.cmin; red[10][LI(lane)] = st.cmax;
         red[4][LI(lane)] = st.sumz; red[5][LI(lane)] = st.sumy; red[6][LI(lane)] = fsl; red[7][LI(lane)] = th;
         red[8][LI(lane)] = bar; red[9][LI(lane)] = st.bad ? 1.0 : 0.0;
     }
     AsmOut &P = sh.Ap;
-    P.dinf = wred_max(red[0]); P.pinf = wred_max(red[1]); P.cinf0 = wred_max(red[2]); P.cmin = wred_min(red[3]); P.cmax = wred_max(red[10]);
+    P.dinf = wred_max(red[0]); P.pinf = wred_max(red[1]); P.cinf0 = 0; P.cmin = wred_min(red[3]); P.cmax = wred_max(red[10]);
     P.sumz = wred_sum(red[4]); P.sumy = wred_sum(red[5]); P.f = wred_sum(red[6]); P.th1 = wred_sum(red[7]);
     P.bar = wred_sum(red[8]);
     P.ok = !(wred_max(red[9]) > 0.5);
@@ -513,30 +555,47 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu, double dw, doubl
 }
 
 // part (b): one lane per stage; combines with the partial results of part (a)
+// The stage item is written in SECTIONS -- state x_k | condensed obstacle sums | inputs, rate cost, steering row | dynamics | finish -- each of which loads what it needs,
+// folds it into the few accumulators of the stage record and stores what is final, with a scheduling barrier in between: the live set stays below the 256 registers a
+// wavefront has when TWO of them share a SIMD (rounds 1-3 issued every load of the stage up front and kept ~430 registers alive, which fixed the kernel at one wavefront per
+// SIMD).  The loads of a section are issued one section ahead, so a section's arithmetic runs in the shadow of the next one's memory round trip.
+#ifdef OBCA_EMU
+#define SECTION() ((void)0)
+#else
+#define SECTION() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int FUSED, int SOC = 0, int LSQ = 0>      // SOC = 1 (with FUSED = 0): steering and dynamics rows enter the right-hand side with c_soc;  LSQ = 1 (with FUSED = 0, mu = dw = dc = 0):
 // the least-squares multiplier system -- unit Hessian, no second derivatives, zero constraint right-hand side, gradients in their z-form
-OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, double dc, const FuseArgs &fa, AsmOut &out) {
+OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, const FuseArgs &fa_, AsmOut &out) {
     const Consts &c = sh.c; const Lay &l = sh.l;
-    const int N = c.N, nOb = c.nOb, M = c.M;
+    const int N = UNIFORM(c.N), nOb = c.nOb, M = c.M;
     const gdbl *z = I.z, *d = I.d; gdbl *zn = I.zn;
+    // what is the same for every lane lives in scalar registers (as function arguments and LDS reads these values would each hold two of the 256 vector registers)
+    const double mu = UNIFORM_D(mu_), dw = UNIFORM_D(dw_), dc = UNIFORM_D(dc_);
+    const FuseArgs fa = {UNIFORM_D(fa_.alpha), UNIFORM_D(fa_.ay), UNIFORM_D(fa_.az), UNIFORM_D(fa_.ks), 0.0};
+    const double cTs = UNIFORM_D(c.Ts), ciL = UNIFORM_D(c.iL), cwpsi = UNIFORM_D(c.wpsi), cwa = UNIFORM_D(c.wa);
+    const double xl0 = UNIFORM_D(c.xl[0]), xl1 = UNIFORM_D(c.xl[1]), xl3 = UNIFORM_D(c.xl[3]), xu0 = UNIFORM_D(c.xu[0]), xu1 = UNIFORM_D(c.xu[1]), xu3 = UNIFORM_D(c.xu[3]);
+    const int fixT = UNIFORM(c.fixTime);
     // time scale: uniform.  FUSED: the trial value and its bound multipliers, stored by lane 0 below
     double t = z[l.t], ztL = z[l.ztL], ztU = z[l.ztU];
-    if (FUSED && !c.fixTime) {
+    if (FUSED && !fixT) {
         const double dt = sh.coef[0], dL = t - OB_TL, dU = OB_TU - t;
         const double zL = zstep(ztL, dL, dt, mu, fa.az), zU = zstep(ztU, dU, -dt, mu, fa.az);
         t = fma(fa.alpha, dt, t);
         ztL = clampz(zL, t - OB_TL, mu, fa.ks); ztU = clampz(zU, OB_TU - t, mu, fa.ks);
         SEAM(t); SEAM(ztL); SEAM(ztU);
     }
-    const double q = t * c.Ts;
-    const double iq = 1.0 / q, it_ = 1.0 / t;          // uniform: one division each, the stage code multiplies
-    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
+    t = UNIFORM_D(t);
+    const double q = t * cTs;
+    const double iq = UNIFORM_D(1.0 / q), it_ = UNIFORM_D(1.0 / t);          // uniform: one division each, the stage code multiplies
+    double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
+    const double *ocs = stg_base(sh);      // condensed obstacle sums of every stage, 12 doubles each (accumulated by part (a) in LDS)
     double red[13][OBCA_NL];
     // ---- (b) stages: one lane per stage
     PAR(lane) {
-        double dmax = 0, pmax = 0, lc0 = 0, lcmn = 1e300, lcmx = -1e300, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
+        double dmax = 0, pmax = 0, lcmn = 1e300, lcmx = -1e300, lsz = 0, lsy = 0, lf = 0, lth = 0, lbar = 0, lHtt = 0, lgtb = 0, lgtz = 0;
         if (FUSED && lane == 0) {
             zn[l.t] = t; zn[l.ztL] = ztL; zn[l.ztU] = ztU;
 #pragma unroll
@@ -544,128 +603,149 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
         }
         for (int k = lane; k <= N; k += OB_NT) {
             BarAcc ba; bar_init(ba);                  // barrier distances of the stage: x (3 pairs), u (2), steering rate (1)
-            double Hp[36], hz[8], hb[8], Ht[8];     // Hp: packed upper triangle of the symmetric 8x8 stage Hessian (HH(i,j), i<=j)
-#define HH(i, j) Hp[hidx((i), (j))]
-#pragma unroll
-            for (int i = 0; i < 8; i++) hz[i] = hb[i] = Ht[i] = 0;
-#pragma unroll
-            for (int i = 0; i < 36; i++) Hp[i] = 0;
-            // every global load of this stage is issued here, before the first store to the stage record: the record may alias the
-            // iterate as far as the compiler knows, so a load placed after a store would cost its own memory round trip
             const int kc = k < N ? k : N - 1, km = k >= 1 ? k - 1 : 0, kn = k + 1 < N ? k + 1 : kc;
-            double x[4], xn[4], pi[4], pim[4], nu4[4], zxL[4], zxU[4];
+            gdbl *rec = I.as + (size_t)k * OB_AS;
+            double hz[8], hb[8];                      // gradient of the Lagrangian w.r.t. (X, Y, psi, v, w0, w1, delta, a): z-form (dual infeasibility) and barrier form (right-hand side)
+            // ================================================================ section 1: the state x_k
+            double x[4], zxL[4], zxU[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                x[i] = z[l.x + 4 * k + i]; xn[i] = z[l.x + 4 * (kc + 1) + i]; pi[i] = z[l.pi + 4 * kc + i]; pim[i] = z[l.pi + 4 * km + i];
-                nu4[i] = z[l.nu + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i];
-            }
+            for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i]; }
+            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            // (issued one section ahead) section 3: inputs, steering slack, their multipliers
             double u[2] = {z[l.u + 2 * kc], z[l.u + 2 * kc + 1]}, um[2] = {z[l.u + 2 * km], z[l.u + 2 * km + 1]};
-            double un[2] = {z[l.u + 2 * kn], z[l.u + 2 * kn + 1]}, ygn = z[l.yg + kn];
             double zuL[2] = {z[l.zuL + 2 * kc], z[l.zuL + 2 * kc + 1]}, zuU[2] = {z[l.zuU + 2 * kc], z[l.zuU + 2 * kc + 1]};
             double ss = z[l.ss + kc], yg = z[l.yg + kc], zssL = z[l.zssL + kc], zssU = z[l.zssU + kc];
-            double oH[6] = {0, 0, 0, 0, 0, 0}, og[3] = {0, 0, 0}, ogc[3] = {0, 0, 0};     // condensed obstacle contributions of this stage (written by part (a))
-            for (int j = 0; j < nOb; j++) {
-                const gdbl *o = I.oc + (size_t)(k * nOb + j) * OB_OC;
-#pragma unroll
-                for (int i = 0; i < 6; i++) oH[i] += o[i];
-#pragma unroll
-                for (int i = 0; i < 3; i++) { og[i] += o[6 + i]; ogc[i] += o[9 + i]; }
-            }
-            const double rx = I.prob[OB_HDR + k], ry = I.prob[OB_HDR + (N + 1) + k], ryaw = I.prob[OB_HDR + 2 * (N + 1) + k];
+            double du[2] = {0, 0}, dum[2] = {0, 0}, dss = 0, dyg = 0;
+            if (FUSED) { du[0] = d[l.u + 2 * kc]; du[1] = d[l.u + 2 * kc + 1]; dum[0] = d[l.u + 2 * km]; dum[1] = d[l.u + 2 * km + 1]; dss = d[l.ss + kc]; dyg = d[l.yg + kc]; }
             if (FUSED) {
-                // the trial point of this stage and what the assembly needs of its neighbours: x_{k+1}, u_{k-1}, u_{k+1}, pi_{k-1}, yg_{k+1}  (steps: x in LDS, the rest in d)
-                double dpi[4], dpim[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { dpi[i] = d[l.pi + 4 * kc + i]; dpim[i] = d[l.pi + 4 * km + i]; }
-                const double du[2] = {d[l.u + 2 * kc], d[l.u + 2 * kc + 1]}, dum[2] = {d[l.u + 2 * km], d[l.u + 2 * km + 1]}, dun[2] = {d[l.u + 2 * kn], d[l.u + 2 * kn + 1]};
-                const double dygn = d[l.yg + kn], dyg = d[l.yg + kc], dss = d[l.ss + kc];
+                // the trial point of this stage (steps: x in LDS, the rest in d).  Explicit fma wherever a trial value is formed: neighbouring stages (and the obstacle blocks) form
+                // the same value again and a parked solve reads the stored one -- all of them must be the same bits
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const double dx = g_traj[(size_t)k * 6 + i], dxn = g_traj[(size_t)(kc + 1) * 6 + i];
-                    const double v = fma(fa.alpha, dx, x[i]);      // explicit fma wherever a trial value is formed: neighbouring stages (and the obstacle blocks) form the same value again
-                                                                  // and a parked solve reads the stored one -- all of them must be the same bits
+                    const double dx = g_traj[(size_t)k * 6 + i];
+                    const double v = fma(fa.alpha, dx, x[i]);
                     if (i != 2 && k >= 1) {
-                        const double zL = zstep(zxL[i], x[i] - c.xl[i], dx, mu, fa.az), zU = zstep(zxU[i], c.xu[i] - x[i], -dx, mu, fa.az);
-                        zxL[i] = clampz(zL, v - c.xl[i], mu, fa.ks); zxU[i] = clampz(zU, c.xu[i] - v, mu, fa.ks);
+                        const double xlo = i == 0 ? xl0 : (i == 1 ? xl1 : xl3), xhi = i == 0 ? xu0 : (i == 1 ? xu1 : xu3);
+                        const double zL = zstep(zxL[i], x[i] - xlo, dx, mu, fa.az), zU = zstep(zxU[i], xhi - x[i], -dx, mu, fa.az);
+                        zxL[i] = clampz(zL, v - xlo, mu, fa.ks); zxU[i] = clampz(zU, xhi - v, mu, fa.ks);
                     }
-                    x[i] = v; xn[i] = fma(fa.alpha, dxn, xn[i]);
-                    pi[i] = fma(fa.ay, dpi[i], pi[i]); pim[i] = fma(fa.ay, dpim[i], pim[i]); nu4[i] = fma(fa.ay, sh.coef[1 + i], nu4[i]);
+                    x[i] = v;
                     zn[l.x + 4 * k + i] = x[i]; zn[l.zxL + 4 * k + i] = zxL[i]; zn[l.zxU + 4 * k + i] = zxU[i];
+                    SEAM(x[i]); SEAM(zxL[i]); SEAM(zxU[i]);
                 }
+            }
+            lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + cwpsi * (x[2] - ryaw) * (x[2] - ryaw);
+            double Hd[4];                             // diagonal of the state block: tracking cost + bound barrier + delta_w
+            {
+                const double gx[4] = {2e-3 * (x[0] - rx), 2e-3 * (x[1] - ry), 2 * cwpsi * (x[2] - ryaw), 2e-4 * x[3]};
+                const double hx[4] = {2e-3, 2e-3, 2 * cwpsi, 2e-4};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    hz[i] = gx[i]; hb[i] = gx[i];
+                    double Sig = 0;
+                    if (i != 2 && k >= 1) {
+                        const double xlo = i == 0 ? xl0 : (i == 1 ? xl1 : xl3), xhi = i == 0 ? xu0 : (i == 1 ? xu1 : xu3);
+                        B2 b = bound2(x[i], xlo, xhi, zxL[i], zxU[i], mu, 1, lcmn, lcmx, lsz);
+                        Sig = b.Sig; hz[i] += b.gz; hb[i] += LSQ ? b.gz : b.gb;
+                        bar_mul(ba, x[i] - xlo, xhi - x[i]);
+                    }
+                    Hd[i] = LSQ ? 1.0 : hx[i] + Sig + dw;
+                }
+            }
+            SECTION();
+            // ================================================================ section 2: condensed obstacle contributions of this stage (summed over the obstacles by part (a))
+            double H00, H01, H02, H11, H12, H22;
+            {
+                double oc_[12]; const double *os = ocs + (size_t)k * OB_OC;
+#pragma unroll
+                for (int i = 0; i < 12; i++) oc_[i] = os[i];
+                H00 = Hd[0] + oc_[0]; H01 = oc_[1]; H02 = oc_[2]; H11 = Hd[1] + oc_[3]; H12 = oc_[4]; H22 = Hd[2] + oc_[5];
+                rec[AS_H + 0] = H00; rec[AS_H + 1] = H01; rec[AS_H + 2] = H02; rec[AS_H + 3] = H11; rec[AS_H + 4] = H12;      // final: stored now, not carried through the dynamics
+#pragma unroll
+                for (int i = 0; i < 3; i++) { hz[i] += oc_[6 + i]; hb[i] += oc_[6 + i] - oc_[9 + i]; }
+            }
+            double H33 = Hd[3];
+            if (k == N) {
+                // ---- terminal stage: x_N = xF with multiplier nu, costate pi_{N-1}
+                double pi[4], nu4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { pi[i] = z[l.pi + 4 * kc + i]; nu4[i] = z[l.nu + i]; }
+                if (FUSED) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { pi[i] = fma(fa.ay, (double)d[l.pi + 4 * kc + i], pi[i]); nu4[i] = fma(fa.ay, sh.coef[1 + i], nu4[i]); SEAM(pi[i]); SEAM(nu4[i]); }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double e = fabs(x[i] - c.xF[i]); pmax = fmax(pmax, e); lth += e;
+                    const double r = pi[i] + nu4[i];
+                    hz[i] += r; hb[i] += r;
+                    dmax = fmax(dmax, fabs(hz[i]));
+                    lsy += fabs(nu4[i]);
+                }
+                lbar += bar_log(ba);
+                rec[AS_H + 5] = H22; rec[AS_H + 9] = H33;
+                rec[AS_H + 6] = 0.0; rec[AS_H + 7] = 0.0; rec[AS_H + 8] = 0.0;
+#pragma unroll
+                for (int i = 10; i < 19; i++) rec[AS_H + i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { rec[AS_HB + i] = i < 4 ? hb[i] : 0.0; if (i >= 2) rec[AS_HT + i - 2] = 0.0; }
+                continue;
+            }
+            // (issued one section ahead) section 4: costates and the next state
+            double pi[4], pim[4], xn[4], dpi[4], dpim[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { pi[i] = z[l.pi + 4 * kc + i]; pim[i] = z[l.pi + 4 * km + i]; xn[i] = z[l.x + 4 * (kc + 1) + i]; dpi[i] = 0; dpim[i] = 0; }
+            if (FUSED) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { dpi[i] = d[l.pi + 4 * kc + i]; dpim[i] = d[l.pi + 4 * km + i]; }
+            }
+            SECTION();
+            // ================================================================ section 3: inputs u_k, their copy w_k = u_{k-1}, rate cost, bounds, steering-rate row
+            if (FUSED) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const double lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     const double zL = zstep(zuL[i], u[i] - lo, du[i], mu, fa.az), zU = zstep(zuU[i], hi - u[i], -du[i], mu, fa.az), v = fma(fa.alpha, du[i], u[i]);
                     u[i] = v; zuL[i] = clampz(zL, v - lo, mu, fa.ks); zuU[i] = clampz(zU, hi - v, mu, fa.ks);
-                    um[i] = fma(fa.alpha, dum[i], um[i]); un[i] = fma(fa.alpha, dun[i], un[i]);
+                    um[i] = fma(fa.alpha, dum[i], um[i]);
                 }
                 {
                     const double zL = zstep(zssL, ss + OB_SSB, dss, mu, fa.az), zU = zstep(zssU, OB_SSB - ss, -dss, mu, fa.az), v = fma(fa.alpha, dss, ss);
                     ss = v; zssL = clampz(zL, v + OB_SSB, mu, fa.ks); zssU = clampz(zU, OB_SSB - v, mu, fa.ks);
                 }
-                yg = fma(fa.ay, dyg, yg); ygn = fma(fa.ay, dygn, ygn);
-                if (k < N) {
+                yg = fma(fa.ay, dyg, yg);
 #pragma unroll
-                    for (int i = 0; i < 2; i++) { zn[l.u + 2 * k + i] = u[i]; zn[l.zuL + 2 * k + i] = zuL[i]; zn[l.zuU + 2 * k + i] = zuU[i]; }
-                    zn[l.ss + k] = ss; zn[l.zssL + k] = zssL; zn[l.zssU + k] = zssU; zn[l.yg + k] = yg;
+                for (int i = 0; i < 2; i++) { zn[l.u + 2 * k + i] = u[i]; zn[l.zuL + 2 * k + i] = zuL[i]; zn[l.zuU + 2 * k + i] = zuU[i]; }
+                zn[l.ss + k] = ss; zn[l.zssL + k] = zssL; zn[l.zssU + k] = zssU; zn[l.yg + k] = yg;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) zn[l.pi + 4 * k + i] = pi[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) { SEAM(x[i]); SEAM(xn[i]); SEAM(pi[i]); SEAM(pim[i]); SEAM(nu4[i]); SEAM(zxL[i]); SEAM(zxU[i]); }
-#pragma unroll
-                for (int i = 0; i < 2; i++) { SEAM(u[i]); SEAM(um[i]); SEAM(un[i]); SEAM(zuL[i]); SEAM(zuU[i]); }
-                SEAM(ss); SEAM(yg); SEAM(ygn); SEAM(zssL); SEAM(zssU);
+                for (int i = 0; i < 2; i++) { SEAM(u[i]); SEAM(um[i]); SEAM(zuL[i]); SEAM(zuU[i]); }
+                SEAM(ss); SEAM(yg); SEAM(zssL); SEAM(zssU);
             }
-            const double gx[4] = {2e-3 * (x[0] - rx), 2e-3 * (x[1] - ry), 2 * c.wpsi * (x[2] - ryaw), 2e-4 * x[3]};
-            const double hx[4] = {2e-3, 2e-3, 2 * c.wpsi, 2e-4};
-            lf += 1e-4 * x[3] * x[3] + 1e-3 * (x[0] - rx) * (x[0] - rx) + 1e-3 * (x[1] - ry) * (x[1] - ry) + c.wpsi * (x[2] - ryaw) * (x[2] - ryaw);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                hz[i] = gx[i]; hb[i] = gx[i];
-                double Sig = 0;
-                if (i != 2 && k >= 1) {
-                    B2 b = bound2(x[i], c.xl[i], c.xu[i], zxL[i], zxU[i], mu, 1, lc0, lcmn, lcmx, lsz);
-                    Sig = b.Sig; hz[i] += b.gz; hb[i] += LSQ ? b.gz : b.gb;
-                    bar_mul(ba, x[i] - c.xl[i], c.xu[i] - x[i]);
-                }
-                HH(i, i) = LSQ ? 1.0 : hx[i] + Sig + dw;
-            }
-            HH(0, 0) += oH[0]; HH(0, 1) += oH[1]; HH(0, 2) += oH[2]; HH(1, 1) += oH[3]; HH(1, 2) += oH[4]; HH(2, 2) += oH[5];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { hz[i] += og[i]; hb[i] += og[i] - ogc[i]; }
-            gdbl *rec = I.as + (size_t)k * OB_AS;
-            if (k == N) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    double e = fabs(x[i] - c.xF[i]); pmax = fmax(pmax, e); lth += e;
-                    double r = pi[i] + nu4[i];
-                    hz[i] += r; hb[i] += r;
-                    dmax = fmax(dmax, fabs(hz[i]));
-                    lsy += fabs(nu4[i]);
-                }
-            } else {
+            double H44, H46, H55, H57, H66, H77, Ht4, Ht5, Ht6, Ht7;
+            {
                 const double w[2] = {k ? um[0] : 0.0, k ? um[1] : 0.0};
-                const double cu[2] = {0.01, c.wa};
+                const double cu[2] = {0.01, cwa};
                 const double rr = 0.1 * (iq * iq), e1 = u[0] - w[0], e2 = u[1] - w[1], rv = rr * (e1 * e1 + e2 * e2);
-                lf += 0.01 * u[0] * u[0] + c.wa * u[1] * u[1] + rv;
+                lf += 0.01 * u[0] * u[0] + cwa * u[1] * u[1] + rv;
+                double Huu[2], Hww[2] = {0, 0}, Hwu[2] = {0, 0}, Htu[2] = {0, 0}, Htw[2] = {0, 0};
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const double ei = i ? e2 : e1, lo = i ? OB_UL1 : OB_UL0, hi = i ? OB_UU1 : OB_UU0;
                     const double gu = 2 * cu[i] * u[i] + 2 * rr * ei;
-                    hz[6 + i] += gu; hb[6 + i] += gu; hz[4 + i] += -2 * rr * ei; hb[4 + i] += -2 * rr * ei;
-                    B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lc0, lcmn, lcmx, lsz);
+                    hz[6 + i] = gu; hb[6 + i] = gu; hz[4 + i] = -2 * rr * ei; hb[4 + i] = -2 * rr * ei;
+                    B2 b = bound2(u[i], lo, hi, zuL[i], zuU[i], mu, 1, lcmn, lcmx, lsz);
                     hz[6 + i] += b.gz; hb[6 + i] += LSQ ? b.gz : b.gb;
                     bar_mul(ba, u[i] - lo, hi - u[i]);
-                    HH(6 + i, 6 + i) += LSQ ? 1.0 : 2 * cu[i] + 2 * rr + b.Sig + dw;
-                    if (!LSQ) { HH(4 + i, 4 + i) += 2 * rr; HH(4 + i, 6 + i) += -2 * rr; }
-                    if (!c.fixTime && !LSQ) { Ht[6 + i] += -4 * rr * ei * it_; Ht[4 + i] += 4 * rr * ei * it_; }
+                    Huu[i] = LSQ ? 1.0 : 2 * cu[i] + 2 * rr + b.Sig + dw;
+                    if (!LSQ) { Hww[i] = 2 * rr; Hwu[i] = -2 * rr; }
+                    if (!fixT && !LSQ) { Htu[i] = -4 * rr * ei * it_; Htw[i] = 4 * rr * ei * it_; }
                 }
-                if (!c.fixTime) { lgtz += -2 * rv * it_; lgtb += -2 * rv * it_; if (!LSQ) lHtt += 6 * rv * (it_ * it_); }
+                if (!fixT) { lgtz += -2 * rv * it_; lgtb += -2 * rv * it_; if (!LSQ) lHtt += 6 * rv * (it_ * it_); }
+                H44 = Hww[0]; H55 = Hww[1]; H46 = Hwu[0]; H57 = Hwu[1]; H66 = Huu[0]; H77 = Huu[1]; Ht4 = Htw[0]; Ht5 = Htw[1]; Ht6 = Htu[0]; Ht7 = Htu[1];
                 {   // steering-rate row  g=(w0-delta)/(t Ts) - ss = 0, |ss|<=0.6   (ParkingSignedDist.jl:157-174)
                     const double g = (w[0] - u[0]) * iq;
-                    const double gg[3] = {iq, -iq, c.fixTime ? 0.0 : -g * it_};
-                    B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lc0, lcmn, lcmx, lsz);
+                    const double gg[3] = {iq, -iq, fixT ? 0.0 : -g * it_};
+                    B2 b = bound2(ss, -OB_SSB, OB_SSB, zssL, zssU, mu, 1, lcmn, lcmx, lsz);
                     bar_mul(ba, ss + OB_SSB, OB_SSB - ss);
                     lsy += fabs(yg);
                     const double rz = -yg + b.gz, rb = LSQ ? rz : -yg + b.gb;
@@ -674,83 +754,90 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
                     const double Dss = LSQ ? 1.0 : b.Sig + dw, iDss = rcp_nr(Dss), sig = rcp_nr(iDss + dc), rg = (LSQ ? 0.0 : (SOC ? (double)sh.soc.csoc[(l.yg - l.pi) + k] : res)) + rb * iDss;
                     rec[AS_SIG] = sig; rec[AS_RG] = rg; rec[AS_GG] = gg[0]; rec[AS_GG + 1] = gg[1]; rec[AS_GG + 2] = gg[2];
                     rec[AS_DSS] = Dss; rec[AS_RSS] = rb;
-                    const int id[2] = {4, 6};
-#pragma unroll
-                    for (int a_ = 0; a_ < 2; a_++) {
-                        hz[id[a_]] += gg[a_] * yg; hb[id[a_]] += gg[a_] * (yg + sig * rg);
-#pragma unroll
-                        for (int b_ = 0; b_ < 2; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += sig * gg[a_] * gg[b_];
-                        if (!c.fixTime) Ht[id[a_]] += sig * gg[a_] * gg[2] + (LSQ ? 0.0 : yg * (a_ == 0 ? -(iq * it_) : iq * it_));
+                    hz[4] += gg[0] * yg; hb[4] += gg[0] * (yg + sig * rg); hz[6] += gg[1] * yg; hb[6] += gg[1] * (yg + sig * rg);
+                    H44 += sig * gg[0] * gg[0]; H46 += sig * gg[0] * gg[1]; H66 += sig * gg[1] * gg[1];
+                    if (!fixT) {
+                        Ht4 += sig * gg[0] * gg[2] + (LSQ ? 0.0 : yg * -(iq * it_)); Ht6 += sig * gg[1] * gg[2] + (LSQ ? 0.0 : yg * (iq * it_));
+                        lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + (LSQ ? 0.0 : yg * 2 * g * (it_ * it_));
                     }
-                    if (!c.fixTime) { lgtz += gg[2] * yg; lgtb += gg[2] * (yg + sig * rg); lHtt += sig * gg[2] * gg[2] + (LSQ ? 0.0 : yg * 2 * g * (it_ * it_)); }
-                }
-                {   // dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
-                    DynOut dy; double HL[5][5];
-                    dyn_derivs(c, x, u, t, pi, dy, HL);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-#pragma unroll
-                        for (int j = 0; j < 5; j++) if (as_df(i, j) >= 0) rec[AS_DF + as_df(i, j)] = (j == 4 && c.fixTime) ? 0.0 : dy.dF[i][j];
-                        double r = xn[i] - dy.F[i];
-                        rec[AS_DD + i] = LSQ ? 0.0 : (SOC ? -(double)sh.soc.csoc[4 * k + i] : -r); pmax = fmax(pmax, fabs(r)); lth += fabs(r);
-                        lsy += fabs(pi[i]);
-                    }
-                    const int id[4] = {2, 3, 6, 7};
-#pragma unroll
-                    for (int a_ = 0; a_ < 4; a_++) if (!LSQ) {
-#pragma unroll
-                        for (int b_ = 0; b_ < 4; b_++) if (b_ >= a_) HH(id[a_], id[b_]) += -HL[a_][b_];
-                        if (!c.fixTime) Ht[id[a_]] += -HL[a_][4];
-                    }
-                    if (!c.fixTime && !LSQ) lHtt += -HL[4][4];
-                    // J^T pi: x_k rows get +pi_{k-1} - A_k^T pi_k ; u_k rows -B_k^T pi_k ; t gets -Ft^T pi
-                    double ATpi[4] = {pi[0], pi[1], pi[2], pi[3]};
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { ATpi[2] += dy.dF[i][0] * pi[i]; ATpi[3] += dy.dF[i][1] * pi[i]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        double r = (k >= 1 ? pim[i] : 0.0) - ATpi[i];
-                        hz[i] += r; hb[i] += r;
-                        if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        double r = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) r -= dy.dF[j][2 + i] * pi[j];
-                        hz[6 + i] += r; hb[6 + i] += r;
-                    }
-                    if (!c.fixTime) {
-                        double r = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) r += dy.dF[j][4] * pi[j];
-                        lgtz -= r; lgtb -= r;
-                    }
-                }
-                {   // dual infeasibility of u_k: own part + copy part living in stage k+1
-                    double wn[2] = {0, 0};
-                    if (k + 1 < N) {
-                        wn[0] = -2 * rr * (un[0] - u[0]) + iq * ygn;
-                        wn[1] = -2 * rr * (un[1] - u[1]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; i++) { double tot = hz[6 + i] + wn[i]; dmax = fmax(dmax, fabs(tot)); }
                 }
             }
+            rec[AS_H + 12] = H44; rec[AS_H + 13] = H46; rec[AS_H + 14] = H55; rec[AS_H + 15] = H57; rec[AS_HT + 2] = Ht4; rec[AS_HT + 3] = Ht5; rec[AS_HB + 4] = hb[4]; rec[AS_HB + 5] = hb[5];      // final
+            // (issued one section ahead) section 5: the next stage's inputs and steering multiplier, for the part of u_k's dual infeasibility that lives in stage k + 1
+            double un[2] = {z[l.u + 2 * kn], z[l.u + 2 * kn + 1]}, ygn = z[l.yg + kn], dun[2] = {0, 0}, dygn = 0;
+            if (FUSED) { dun[0] = d[l.u + 2 * kn]; dun[1] = d[l.u + 2 * kn + 1]; dygn = d[l.yg + kn]; }
+            SECTION();
+            // ================================================================ section 4: dynamics x_{k+1} - F(x_k,u_k,t) = 0, multiplier pi_k   (ParkingSignedDist.jl:139-155)
+            if (FUSED) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xn[i] = fma(fa.alpha, g_traj[(size_t)(kc + 1) * 6 + i], xn[i]); pi[i] = fma(fa.ay, dpi[i], pi[i]); pim[i] = fma(fa.ay, dpim[i], pim[i]);
+                    zn[l.pi + 4 * k + i] = pi[i];
+                    SEAM(xn[i]); SEAM(pi[i]); SEAM(pim[i]);
+                }
+            }
+            double H23, H26, H27, H36, H37, H67, Ht2, Ht3;
+            {
+                Dyn dy; dyn_derivs(cTs, ciL, x, u, t, pi, dy);
+                const bool ft = fixT;
+#pragma unroll
+                for (int j = 0; j < 5; j++) { rec[AS_DF + as_df(0, j)] = (j == 4 && ft) ? 0.0 : dy.dX[j]; rec[AS_DF + as_df(1, j)] = (j == 4 && ft) ? 0.0 : dy.dY[j]; }
+#pragma unroll
+                for (int j = 1; j < 5; j++) rec[AS_DF + as_df(2, j)] = (j == 4 && ft) ? 0.0 : dy.dP[j - 1];
+                rec[AS_DF + as_df(3, 3)] = dy.dVa; rec[AS_DF + as_df(3, 4)] = ft ? 0.0 : dy.dVt;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double r = xn[i] - dy.F[i];
+                    rec[AS_DD + i] = LSQ ? 0.0 : (SOC ? -(double)sh.soc.csoc[4 * k + i] : -r); pmax = fmax(pmax, fabs(r)); lth += fabs(r);
+                    lsy += fabs(pi[i]);
+                }
+                H23 = 0; H26 = 0; H27 = 0; H36 = 0; H37 = 0; H67 = 0; Ht2 = 0; Ht3 = 0;
+                if (!LSQ) {      // variables (psi, v, delta, a) = positions (2, 3, 6, 7) of the stage vector
+                    H22 += -dy.h00; H23 = -dy.h01; H26 = -dy.h02; H27 = -dy.h03; H33 += -dy.h11; H36 = -dy.h12; H37 = -dy.h13; H66 += -dy.h22; H67 = -dy.h23;
+                    if (!ft) { Ht2 = -dy.h04; Ht3 = -dy.h14; Ht6 += -dy.h24; Ht7 += -dy.h34; lHtt += -dy.h44; }
+                }
+                // J^T pi: x_k rows get +pi_{k-1} - A_k^T pi_k ; u_k rows -B_k^T pi_k ; t gets -Ft^T pi
+                const double ATpi[4] = {pi[0], pi[1], (pi[2] + dy.dX[0] * pi[0]) + dy.dY[0] * pi[1], ((pi[3] + dy.dX[1] * pi[0]) + dy.dY[1] * pi[1]) + dy.dP[0] * pi[2]};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double r = (k >= 1 ? pim[i] : 0.0) - ATpi[i];
+                    hz[i] += r; hb[i] += r;
+                    if (k >= 1 && fabs(hz[i]) > dmax) dmax = fabs(hz[i]);
+                }
+                {
+                    const double r6 = -((dy.dX[2] * pi[0] + dy.dY[2] * pi[1]) + dy.dP[1] * pi[2]);
+                    const double r7 = -(((dy.dX[3] * pi[0] + dy.dY[3] * pi[1]) + dy.dP[2] * pi[2]) + dy.dVa * pi[3]);
+                    hz[6] += r6; hb[6] += r6; hz[7] += r7; hb[7] += r7;
+                }
+                if (!ft) {
+                    const double r = ((dy.dX[4] * pi[0] + dy.dY[4] * pi[1]) + dy.dP[3] * pi[2]) + dy.dVt * pi[3];
+                    lgtz -= r; lgtb -= r;
+                }
+            }
+            SECTION();
+            // ================================================================ section 5: dual infeasibility of u_k (own part + copy part living in stage k+1), barrier, stores
+            {
+                if (FUSED) { un[0] = fma(fa.alpha, dun[0], un[0]); un[1] = fma(fa.alpha, dun[1], un[1]); ygn = fma(fa.ay, dygn, ygn); SEAM(un[0]); SEAM(un[1]); SEAM(ygn); }
+                const double rr = 0.1 * (iq * iq);
+                double wn[2] = {0, 0};
+                if (k + 1 < N) {
+                    wn[0] = -2 * rr * (un[0] - u[0]) + iq * ygn;
+                    wn[1] = -2 * rr * (un[1] - u[1]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { const double tot = hz[6 + i] + wn[i]; dmax = fmax(dmax, fabs(tot)); }
+            }
             lbar += bar_log(ba);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = i; j < 8; j++) if (as_h(i, j) >= 0) rec[AS_H + as_h(i, j)] = HH(i, j);
-#undef HH
-#pragma unroll
-            for (int i = 0; i < 8; i++) { rec[AS_HB + i] = hb[i]; if (i >= 2) rec[AS_HT + i - 2] = Ht[i]; }
+            rec[AS_H + 5] = H22; rec[AS_H + 6] = H23; rec[AS_H + 7] = H26; rec[AS_H + 8] = H27; rec[AS_H + 9] = H33; rec[AS_H + 10] = H36; rec[AS_H + 11] = H37;
+            rec[AS_H + 16] = H66; rec[AS_H + 17] = H67; rec[AS_H + 18] = H77;
+            rec[AS_HB + 0] = hb[0]; rec[AS_HB + 1] = hb[1]; rec[AS_HB + 2] = hb[2]; rec[AS_HB + 3] = hb[3]; rec[AS_HB + 6] = hb[6]; rec[AS_HB + 7] = hb[7];
+            rec[AS_HT + 0] = Ht2; rec[AS_HT + 1] = Ht3; rec[AS_HT + 4] = Ht6; rec[AS_HT + 5] = Ht7;
         }
-        red[0][LI(lane)] = dmax; red[1][LI(lane)] = pmax; red[2][LI(lane)] = lc0; red[3][LI(lane)] = lcmn; red[12][LI(lane)] = lcmx;
+        red[0][LI(lane)] = dmax; red[1][LI(lane)] = pmax; red[3][LI(lane)] = lcmn; red[12][LI(lane)] = lcmx;
         red[4][LI(lane)] = lsz; red[5][LI(lane)] = lsy; red[6][LI(lane)] = lf; red[7][LI(lane)] = lth;
         red[8][LI(lane)] = lbar; red[9][LI(lane)] = lHtt; red[10][LI(lane)] = lgtb; red[11][LI(lane)] = lgtz;
     }
-    dinf = fmax(dinf, wred_max(red[0])); pinf = fmax(pinf, wred_max(red[1])); c0 = fmax(c0, wred_max(red[2])); cmn = fmin(cmn, wred_min(red[3])); cmx = fmax(cmx, wred_max(red[12]));
+    dinf = fmax(dinf, wred_max(red[0])); pinf = fmax(pinf, wred_max(red[1])); cmn = fmin(cmn, wred_min(red[3])); cmx = fmax(cmx, wred_max(red[12]));
     sumz += wred_sum(red[4]); sumy += wred_sum(red[5]); f += wred_sum(red[6]); th1 += wred_sum(red[7]);
     bar += wred_sum(red[8]);
     double Htt = wred_sum(red[9]), gtb = wred_sum(red[10]), gtz = wred_sum(red[11]);
@@ -758,9 +845,9 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
     int nb = 6 * N + 4 * N + 2 * N + (M + (c.dist ? 6 : 5) * nOb) * (N + 1);
     int nm = 4 * N + 4 + N + 4 * nOb * (N + 1);
     if (!c.fixTime) {
-        double d0 = 0, d2 = 0;
-        B2 b = bound2(t, OB_TL, OB_TU, ztL, ztU, mu, N + 1, d0, cmn, cmx, d2);
-        c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(ztL) + fabs(ztU));
+        double d2 = 0;
+        B2 b = bound2(t, OB_TL, OB_TU, ztL, ztU, mu, N + 1, cmn, cmx, d2);
+        sumz += (N + 1) * (fabs(ztL) + fabs(ztU));
         nb += 2 * (N + 1);
         double gf = (N + 1) * (0.5 + 2 * t);
         Htt += LSQ ? 1.0 : 2.0 * (N + 1) + b.Sig + dw;
@@ -769,7 +856,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu, double dw, dou
         bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));
         dinf = fmax(dinf, fabs(gtz));
     } else { Htt = 1.0; gtb = 0; }
-    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
+    out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = fmax(fabs(cmn), fabs(cmx)); out.cmin = cmn; out.cmax = cmx;      // (largest |s z| of all complementarity pairs = the larger of the two extreme products in magnitude) out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = Htt; out.gtb = gtb; out.nb = nb; out.nm = nm;
     PROF(I, FUSED ? PF_APPLY : PF_ASM_STAGE);
 }
@@ -891,9 +978,9 @@ OBCA_FN int ric_qsrc(int oQ, int oSG, int r, int c, int bit, int &sg) {      // 
     return oQ + r * 14 + c;
 }
 OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
-    const double *L = (const double *)&sh;
-    const int oPn = (int)(sh.Pn - L), opn = (int)(sh.pn - L), oQ = (int)(sh.Qhat - L), osB = (int)(sh.sB - L), oT = (int)(sh.TT - L),
-              oSG = (int)(stg_base(sh) - L), oZ = (int)(&sh.zero - L), oZ6 = (int)(sh.zero6 - L), oD = (int)(&sh.dump - L), oD4 = (int)(sh.dump4 - L);
+    const double *L = (const double *)&sh; const RicLds &rl = ric_lds(sh);
+    const int oPn = (int)(rl.Pn - L), opn = (int)(rl.pn - L), oQ = (int)(rl.Qhat - L), osB = (int)(rl.sB - L), oT = (int)(rl.TT - L),
+              oSG = (int)(ric_sg0(sh) - L), oZ = (int)(&rl.zero - L), oZ6 = (int)(rl.zero6 - L), oD = (int)(&rl.dump - L), oD4 = (int)(rl.dump4 - L);
     const int S6[6] = {2, 3, 6, 7, 8, 9}, R8[8] = {0, 1, 4, 5, 10, 11, 12, 13}, I4[4] = {2, 3, 6, 7}, C12[12] = {0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13};
     // A: items 0..35 T[a][cc] = [cc >= 8] p[a][cc-8] + P[a][:] . FA[:][cc] for the six live columns (stored as T'[cc][a]);  36..47 u2[m][b] += FA[:][8+m] . p[:][b];
     //    48..63 Qhat[a][cc] = [H | p][a][cc] + P[a][:] . FA[:][cc] for a = 0, 1 and the copied columns (FA[:][cc] is a unit vector or zero there)
@@ -986,7 +1073,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
     const double idet = rcp_nr(det);
     gdbl *ro = I.rs + (size_t)k * OB_RS;
-    double *bd = sg0 + 2 * OB_STG + (size_t)k * RIC_BD;
+    double *bd = g_traj + (size_t)k * RIC_BD;      // per-stage border data: at the start of the dynamic block (the trajectory is dead during the sweep)
     PAR(lane) {   // phase C
         const RicItem &p = rp[LI(lane)];
         const double x6 = L[p.c_x6 + ((p.c_sg & 1) ? sgo : 0)], x7 = L[p.c_x7 + ((p.c_sg & 2) ? sgo : 0)], q6 = L[p.c_q6 + ((p.c_sg & 4) ? sgo : 0)],
@@ -1012,26 +1099,27 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
     const gdbl *z = I.z;
     double nv[OBCA_NLT][RIC_D];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
-    double *sg0 = stg_base(sh);      // the two stage buffers, behind them the per-stage border data (dynamic LDS)
+    double *sg0 = ric_sg0(sh);       // the two stage buffers (dynamic LDS; in front of them the per-stage border data, behind them the operands)
+    RicLds &rl = ric_lds(sh);
     UnpackPlan plan[OBCA_NLT]; RicItem rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
         stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_item(sh, lane, rp[LI(lane)]);
         stage_unpack_constants(sh, sg0, lane);
-        if (lane == 0) { sh.zero = 0.0; sh.dump = 0.0; }
-        if (lane < 6) sh.zero6[lane] = 0.0;
-        if (lane < 24) sh.sB[lane] = 0.0;                      // the static parts of the bilinear constants accumulate here
+        if (lane == 0) { rl.zero = 0.0; rl.dump = 0.0; }
+        if (lane < 6) rl.zero6[lane] = 0.0;
+        if (lane < 24) rl.sB[lane] = 0.0;                      // the static parts of the bilinear constants accumulate here
         const gdbl *rec = I.as + (size_t)N * OB_AS;
         if (lane < 36) {
             int i = lane / 6, j = lane % 6;
             double v = as_h(i, j) >= 0 ? rec[AS_H + as_h(i, j)] : 0.0;
             if (i == j && i < 4) v += rho;
-            sh.Pn[lane] = v;
+            rl.Pn[lane] = v;
         }
         if (lane < 6) {
             double e = lane < 4 ? (SOC ? -(double)sh.soc.csoc[(l.nu - l.pi) + lane] : -(z[l.x + 4 * N + lane] - c.xF[lane])) : 0.0;
-            sh.pn[0 * 6 + lane] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);      // (p is kept transposed: pn[c * 6 + a])
-            sh.pn[1 * 6 + lane] = lane >= 2 ? rec[AS_HT + lane - 2] : 0.0;
-            for (int cc = 0; cc < 4; cc++) sh.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
+            rl.pn[0 * 6 + lane] = rec[AS_HB + lane] - (lane < 4 ? rho * e : 0.0);      // (p is kept transposed: pn[c * 6 + a])
+            rl.pn[1 * 6 + lane] = lane >= 2 ? rec[AS_HT + lane - 2] : 0.0;
+            for (int cc = 0; cc < 4; cc++) rl.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
         }
     }
     LDS_SYNC();
@@ -1064,7 +1152,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     PAR(lane) {
         if (lane < 63) {
             int a_, b_; pair_of(lane / 3, a_, b_);
-            const double *bd = sg0 + 2 * OB_STG;
+            const double *bd = g_traj;
             double acc = 0;
             for (int kk = lane % 3; kk < N; kk += 3) {
                 const double *r = bd + (size_t)kk * RIC_BD;
@@ -1072,16 +1160,16 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
                 const double n0 = fma(q10, q7b, -(q11 * q6b)), n1 = fma(q10, q6b, -(q00 * q7b));
                 acc = fma(fma(q6a, n0, q7a * n1), idet, acc);
             }
-            sh.TT[lane] = acc;
+            rl.TT[lane] = acc;
         }
     }
     LDS_SYNC();
     PAR(lane) {
         if (lane < 21) {
             int a_, b_; pair_of(lane, a_, b_);
-            double v = (sh.TT[3 * lane] + sh.TT[3 * lane + 1]) + sh.TT[3 * lane + 2];
-            if (a_ < 2) v += b_ < 2 ? sh.sB[a_ * 6 + b_] : sh.sB[12 + a_ * 6 + b_];      // off_a . (P off_b + p_b): u1[a][b], = u2[a][b] for the right-hand sides b >= 2
-            if (b_ < 2) v += sh.sB[12 + b_ * 6 + a_];                                     // off_b . p_a
+            double v = (rl.TT[3 * lane] + rl.TT[3 * lane + 1]) + rl.TT[3 * lane + 2];
+            if (a_ < 2) v += b_ < 2 ? rl.sB[a_ * 6 + b_] : rl.sB[12 + a_ * 6 + b_];      // off_a . (P off_b + p_b): u1[a][b], = u2[a][b] for the right-hand sides b >= 2
+            if (b_ < 2) v += rl.sB[12 + b_ * 6 + a_];                                     // off_b . p_a
             sh.Bm[a_ * 6 + b_] = v; sh.Bm[b_ * 6 + a_] = v;
         }
     }
@@ -1361,9 +1449,12 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
 template <int VM, int DBG, int SOC = 0, int LSQ = 0>      // DBG = 1 (host emulation tests, least-squares multipliers): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
-OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
+OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, double tau_, StepOut &so) {
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const Lay &l = sh.l;
+    Consts c; obs_consts(sh.c, c);
+    const double mu = UNIFORM_D(mu_), dw = UNIFORM_D(dw_), dc = UNIFORM_D(dc_), tau = UNIFORM_D(tau_);
+    const int N = c.N, nOb = c.nOb, M = c.M;
     const gdbl *z = I.z; gdbl *d = I.d;
     double ap = so.ap, az = so.az, gd = so.gd;
     const double dt = sh.coef[0], nu[4] = {sh.coef[1], sh.coef[2], sh.coef[3], sh.coef[4]};

@@ -257,7 +257,7 @@ def test_second_order_correction_in_the_kernels_follows_the_oracle(oracle):
 def test_recalc_y_in_the_kernels_follows_the_oracle(oracle, emu):
     """obca_opts.recalc_y = 1 (recalc_y = "yes", ParkingSignedDist.jl:41): once the accepted iterate's constraint violation is below 1e-6 the equality multipliers are replaced
     by their least-squares estimate -- the structured solve with H := I, zero constraint right-hand side, z-form gradients (template parameter LSQ of the phases).  Against
-    the oracle's option: the same iterations, and the multipliers (pi, nu, y_g, y_o) of the final iterate -- the re-estimated ones -- to 1e-12."""
+    the oracle's option: the same iterations, and the multipliers (pi, nu, y_g, y_o) of the final iterate -- the re-estimated ones -- to 1e-11."""
     import emu_solver as E
     N = 80; sc = S.BACKWARDS
     bt = S.make_batch(sc, 5, N, seed=20260925)
@@ -274,7 +274,7 @@ def test_recalc_y_in_the_kernels_follows_the_oracle(oracle, emu):
         z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i][:N], lWS, nWS); zo = np.zeros_like(z0); info = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
         assert int(info[1]) == r["iters"] and int(info[7]) == r["exitflag"] == 1
-        assert np.abs(zo[ys] - r["zfull"][ys]).max() < 1e-12 and np.abs(zo[:L["nprimal"]] - r["zfull"][:L["nprimal"]]).max() < 1e-9
+        assert np.abs(zo[ys] - r["zfull"][ys]).max() < 1e-11 and np.abs(zo[:L["nprimal"]] - r["zfull"][:L["nprimal"]]).max() < 1e-9
         if emu.emu_last_recalc() > 0:
             n_re += 1
             assert np.abs(r["zfull"][ys] - r0["zfull"][ys]).max() > 0          # the estimate is not the multiplier the iteration carried (it agrees with it to ~1e-9 at the solution)
