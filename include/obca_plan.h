@@ -58,6 +58,17 @@ int obca_plan_collides(double x, double y, double yaw, int nOb, const int *vOb, 
 int obca_plan_astar3d(const double start[3], const double goal[3], int nBox, const double *boxes, double clear, const double room[3],
                       double res, double *path, int cap, int *expansions /* may be NULL */);
 
+/* REFERENCE mode of the quadcopter's path search: QuadcopterNavigation/a_star_3D.jl restated (calc_astar_path :49-154, the 26-neighbour motion model :157-187,
+ * calc_obstacle_map :193-231, get_final_path :233-263), as mainQuadcopter.jl:116-121 calls it.  All lengths in GRID UNITS of `reso` as in the reference (its caller scales
+ * the room by 10 and passes reso = 1.0).  ox, oy, oz: the obstacle POINT lists (nob points; the reference appends the two room corners to them, :196-198 -- done inside).
+ * A cell is blocked when its nearest obstacle point is within VEHICLE_RADIUS / reso = 2.5 / reso (:31, :221-224); the search is A* with the heuristic 1.1 x the Euclidean
+ * distance (H_WEIGHT, :32), node keys as calc_index (:189-191), cells on the room's boundary planes excluded (:118-123).  Ties in the priority queue are broken by
+ * insertion order (Julia's Collections.PriorityQueue leaves them unspecified).  path receives the way-points start .. goal in the caller's units (x reso, :259-261);
+ * returns their number (the reference's length(rx) = N_as + 1), 0 = no path, -1 = bad arguments / cap too small.  *cost (may be NULL): path cost in grid units. */
+int obca_plan_reference_astar3d(const double start[3], const double goal[3], int nob, const double *ox, const double *oy, const double *oz,
+                                const double room_min[3], const double room_max[3], double reso, double *path, int cap, int *expansions /* may be NULL */,
+                                double *cost /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,4 +209,95 @@ int obca_plan_reference_hybrid_astar(const double start[3], const double goal[3]
     return K;
 }
 
+// ---------------------------------------------------------------------------------------------------- QuadcopterNavigation/a_star_3D.jl, restated
+int obca_plan_reference_astar3d(const double start[3], const double goal[3], int nob, const double *ox_, const double *oy_, const double *oz_,
+                                const double room_min[3], const double room_max[3], double reso, double *path, int cap, int *expansions, double *cost_out) {
+    if (!start || !goal || nob < 0 || (nob && (!ox_ || !oy_ || !oz_)) || !room_min || !room_max || !(reso > 0) || !path || cap < 2) return -1;
+    const double H_WEIGHT = 1.1, VEHICLE_RADIUS = 2.5;                                  // :31-32
+    const long sx = jround(start[0] / reso), sy = jround(start[1] / reso), sz = jround(start[2] / reso);      // :74-75
+    const long gx = jround(goal[0] / reso), gy = jround(goal[1] / reso), gz = jround(goal[2] / reso);
+    // calc_obstacle_map :193-231 -- obstacle points in grid units (:78-80), the two room corners appended to the lists (:196-198: they become obstacle points too)
+    std::vector<double> ox(nob + 2), oy(nob + 2), oz(nob + 2);
+    for (int i = 0; i < nob; i++) { ox[i] = ox_[i] / reso; oy[i] = oy_[i] / reso; oz[i] = oz_[i] / reso; }
+    ox[nob] = room_min[0]; ox[nob + 1] = room_max[0]; oy[nob] = room_min[1]; oy[nob + 1] = room_max[1]; oz[nob] = room_min[2]; oz[nob + 1] = room_max[2];
+    const long minx = jround(*std::min_element(ox.begin(), ox.end())), miny = jround(*std::min_element(oy.begin(), oy.end())), minz = jround(*std::min_element(oz.begin(), oz.end()));
+    const long maxx = jround(*std::max_element(ox.begin(), ox.end())), maxy = jround(*std::max_element(oy.begin(), oy.end())), maxz = jround(*std::max_element(oz.begin(), oz.end()));
+    const long xw = maxx - minx, yw = maxy - miny, zw = maxz - minz;
+    if (xw <= 0 || yw <= 0 || zw <= 0 || (double)xw * yw * zw > 2e8) return -1;
+    // obmap[ix][iy][iz] (0-based here) <=> the point (ix + minx, iy + miny, iz + minz); blocked iff the NEAREST obstacle point is within VEHICLE_RADIUS / reso (:221-224).
+    // The reference asks a KD-tree for the nearest point of every cell; the same predicate is evaluated here from the points' side: every point blocks the cells of the
+    // ball around it (606 k cells x 67 k points would be 4e10 distance evaluations the other way round).
+    std::vector<unsigned char> ob((size_t)xw * yw * zw, 0);
+    const double rad = VEHICLE_RADIUS / reso; const long ir = (long)std::ceil(rad);
+    for (size_t p = 0; p < ox.size(); p++) {
+        const long cx = (long)std::floor(ox[p]), cy = (long)std::floor(oy[p]), cz = (long)std::floor(oz[p]);
+        for (long x = cx - ir; x <= cx + ir + 1; x++) { if (x < minx || x >= minx + xw) continue;
+            for (long y = cy - ir; y <= cy + ir + 1; y++) { if (y < miny || y >= miny + yw) continue;
+                for (long z = cz - ir; z <= cz + ir + 1; z++) { if (z < minz || z >= minz + zw) continue;
+                    const double dx = x - ox[p], dy = y - oy[p], dz = z - oz[p];
+                    if (std::sqrt(dx * dx + dy * dy + dz * dz) <= rad) ob[((size_t)(x - minx) * yw + (size_t)(y - miny)) * zw + (size_t)(z - minz)] = 1;
+                } } }
+    }
+    auto index = [&](long x, long y, long z) -> long { return (y - miny) * xw * zw + (x - minx) * zw + (z - minz); };      // calc_index :189-191
+    auto hh = [&](long x, long y, long z) { return std::sqrt((double)(x * x + y * y + z * z)); };                              // h :283-288
+    struct N3 { long x, y, z; double cost; long pind; };
+    std::unordered_map<long, N3> open, closed;
+    typedef std::pair<double, std::pair<long, long>> QE;                                 // (priority, (insertion number, node index))
+    std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+    std::unordered_map<long, double> prio;                                                // current priority of a queued index (pqOpen[ind] = ... replaces it, :136)
+    long seq = 0, nexp = 0;
+    const long sid = index(sx, sy, sz);
+    open[sid] = N3{sx, sy, sz, 0.0, -1};
+    { const double pr = 0.0 + H_WEIGHT * hh(sx - gx, sy - gy, sz - gz); pq.push({pr, {seq++, sid}}); prio[sid] = pr; }
+    // get_motion_model :157-187: the 26 neighbours in the reference's row order, cost = Euclidean length
+    long mot[26][3]; double mc[26]; int nm = 0;
+    for (long dx = -1; dx <= 1; dx++) for (long dy = -1; dy <= 1; dy++) for (long dz = -1; dz <= 1; dz++) {
+        if (!dx && !dy && !dz) continue;
+        mot[nm][0] = dx; mot[nm][1] = dy; mot[nm][2] = dz; mc[nm] = std::sqrt((double)(dx * dx + dy * dy + dz * dz)); nm++;
+    }
+    bool found = false; long goal_id = -1;
+    while (true) {
+        if (open.empty()) break;                                                          // "Error: No open set" :100-103
+        if (pq.empty()) break;
+        const QE top = pq.top(); pq.pop();
+        const long cid = top.second.second;
+        auto itp = prio.find(cid);
+        if (itp == prio.end() || itp->second != top.first || !open.count(cid)) continue;  // a stale entry of an index whose priority was replaced (or that was dequeued already)
+        prio.erase(itp);
+        const N3 cur = open[cid]; nexp++;
+        if (cur.x == gx && cur.y == gy && cur.z == gz) { closed[cid] = cur; found = true; goal_id = cid; break; }      // :109-113
+        open.erase(cid); closed[cid] = cur;
+        for (int i = 0; i < nm; i++) {
+            N3 nd{cur.x + mot[i][0], cur.y + mot[i][1], cur.z + mot[i][2], cur.cost + mc[i], cid};
+            if (nd.x - minx >= xw || nd.x - minx <= 0 || nd.y - miny >= yw || nd.y - miny <= 0 || nd.z - minz >= zw || nd.z - minz <= 0) continue;      // :118-123
+            // obmap[node.x-minx+1, ...] in the reference's 1-based array = the cell of the point (node.x, node.y, node.z) itself
+            if (ob[((size_t)(nd.x - minx) * yw + (size_t)(nd.y - miny)) * zw + (size_t)(nd.z - minz)]) continue;                                    // :126
+            const long ni = index(nd.x, nd.y, nd.z);
+            if (closed.count(ni)) continue;
+            auto ito = open.find(ni);
+            const double pr = nd.cost + H_WEIGHT * hh(nd.x - gx, nd.y - gy, nd.z - gz);
+            if (ito != open.end()) {
+                if (ito->second.cost > nd.cost) { ito->second.cost = nd.cost; ito->second.pind = cid; prio[ni] = pr; pq.push({pr, {seq++, ni}}); }      // :132-139
+            } else { open[ni] = nd; prio[ni] = pr; pq.push({pr, {seq++, ni}}); }
+        }
+    }
+    if (expansions) *expansions = (int)nexp;
+    if (!found) return 0;
+    // get_final_path :233-263
+    std::vector<long> rx(1, gx), ry(1, gy), rz(1, gz);
+    long nid = goal_id;
+    for (;;) {
+        auto it = closed.find(nid); if (it == closed.end()) return 0;
+        const N3 &n = it->second;
+        rx.push_back(n.x); ry.push_back(n.y); rz.push_back(n.z);
+        nid = n.pind;
+        if (rx.back() == sx && ry.back() == sy && rz.back() == sz) break;
+        if (nid < 0) return 0;
+    }
+    const int K = (int)rx.size(); if (K > cap) return -1;
+    for (int i = 0; i < K; i++) { path[3 * i] = rx[K - 1 - i] * reso; path[3 * i + 1] = ry[K - 1 - i] * reso; path[3 * i + 2] = rz[K - 1 - i] * reso; }
+    if (cost_out) *cost_out = closed[goal_id].cost;
+    return K;
+}
+
 }  // extern "C"

@@ -1361,12 +1361,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
             double x[4], zxL[4], zxU[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { x[i] = z[l.x + 4 * k + i]; zxL[i] = z[l.zxL + 4 * k + i]; zxU[i] = z[l.zxU + 4 * k + i]; }
-            const gdbl *ro = I.rs + (size_t)ku * OB_RS, *rec = I.as + (size_t)ku * OB_AS;
-            double cmK[12], cmk0 = 0, cmk1 = 0;                                    // gains K_k and feed-forward kf_k = KF_k . coef (the same sums as the pair lanes of the forward sweep)
-#pragma unroll
-            for (int j = 0; j < 12; j++) cmK[j] = ro[RS_K + j];
-#pragma unroll
-            for (int cc = 0; cc < OB_NC; cc++) { cmk0 += ro[RS_KF + cc] * coef[cc]; cmk1 += ro[RS_KF + OB_NC + cc] * coef[cc]; }
+            const gdbl *rec = I.as + (size_t)ku * OB_AS;
             const double u[2] = {z[l.u + 2 * ku], z[l.u + 2 * ku + 1]};
             const double w[2] = {ku ? z[l.u + 2 * ku - 2] : 0.0, ku ? z[l.u + 2 * ku - 1] : 0.0};
             const double zuL[2] = {z[l.zuL + 2 * ku], z[l.zuL + 2 * ku + 1]}, zuU[2] = {z[l.zuU + 2 * ku], z[l.zuU + 2 * ku + 1]};
@@ -1409,10 +1404,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
                 }
             }
             if (k < N) {
-                double du[2];
-                du[0] = cmk0; du[1] = cmk1;
-#pragma unroll
-                for (int j = 0; j < 6; j++) { du[0] += cmK[j] * s[j]; du[1] += cmK[6 + j] * s[j]; }
+                // du_k = K_k s_k + kf_k is the input copy dw_{k+1} of the NEXT state: the forward sweep formed it already (rows 4, 5 of the closed-loop map), so it is read from the
+                // trajectory instead of being formed again from the gains (rounds 1-3 re-read K and KF here: 24 doubles per stage and pass)
+                const double du[2] = {sn[4], sn[5]};
                 d[l.u + 2 * k] = du[0]; d[l.u + 2 * k + 1] = du[1];
                 if (!c.fixTime) { const double e1 = u[0] - w[0], e2 = u[1] - w[1]; gr += -2 * rr_t * (e1 * e1 + e2 * e2) / t; }
                 const double cu[2] = {0.01, c.wa}, iq = 1.0 / q, rr = 0.1 * (iq * iq);

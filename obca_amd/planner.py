@@ -101,6 +101,49 @@ def reference_warm_start(sc, x0, xF, sampleN=3, motion_step=0.1, a_max=0.3, **kw
     return N, Ts, xWS, uWS[:N], P
 
 
+def reference_quad_obstacle_points():
+    """the obstacle point lists mainQuadcopter.jl:59-105 builds for its A* call (room scaled by 10): the first wall x 20..25, y 0..105, z 6..55 and the second wall x 70..75
+    with its window y 40..50, z 20..30 left open (left, right, top and bottom pieces)"""
+    P = []
+    r = lambda a, b: np.arange(a, b + 1, dtype=float)
+    def block(xs, ys, zs):
+        X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij"); P.append(np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1))
+    block(r(20, 25), r(0, 105), r(6, 55))
+    for xx in r(70, 75):      # (the reference's loop order: per x the four pieces; the order of the points does not enter the search)
+        block([xx], r(0, 40), r(0, 55)); block([xx], r(50, 105), r(0, 55)); block([xx], r(40, 50), r(30, 55)); block([xx], r(40, 50), r(0, 20))
+    Q = np.concatenate(P, axis=0)
+    return Q[:, 0].copy(), Q[:, 1].copy(), Q[:, 2].copy()
+
+
+def reference_astar3d(start, goal, ox, oy, oz, room_min=(0.0, 0.0, 0.0), room_max=(105.0, 105.0, 55.0), reso=1.0):
+    """REFERENCE mode of the quadcopter's search: QuadcopterNavigation/a_star_3D.jl restated (obca_plan_reference_astar3d).  Returns (way-points (K, 3), expansions, cost) or
+    None; K = the reference's length(rx) (its path repeats the goal cell once: get_final_path, a_star_3D.jl:243-250)."""
+    s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()
+    ox = np.ascontiguousarray(ox, float); oy = np.ascontiguousarray(oy, float); oz = np.ascontiguousarray(oz, float)
+    lo = np.ascontiguousarray(room_min, float); hi = np.ascontiguousarray(room_max, float)
+    cap = 8192; path = np.zeros((cap, 3)); nexp = C.c_int(0); cost = C.c_double(0)
+    n = _load().obca_plan_reference_astar3d(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(ox)), ox.ctypes.data_as(_D), oy.ctypes.data_as(_D), oz.ctypes.data_as(_D),
+                                            lo.ctypes.data_as(_D), hi.ctypes.data_as(_D), C.c_double(reso), path.ctypes.data_as(_D), C.c_int(cap), C.byref(nexp), C.byref(cost))
+    if n < 0:
+        raise ValueError("bad arguments")
+    return None if n == 0 else (path[:n].copy(), nexp.value, cost.value)
+
+
+def reference_quad_warm_start(x0=None, xF=None, Ts=0.25):
+    """mainQuadcopter.jl:107-138 as it stands: the A* call on the room scaled by 10 (start / goal = 10 x the positions, grid 1.0), N_as = length(rx) - 1,
+    Ts_as = round(Ts 80 / N_as, 2) (:131), warm start = the way-points / 10 with every other state 0 (:134-136), inputs 0.5 (ignored by the solve), timeWS = 1.
+    Returns (N_as, Ts_as, xWS (N_as + 1, 12), uWS (N_as, 4), way-points in metres) or None."""
+    x0 = S.QUAD_X0 if x0 is None else np.asarray(x0, float); xF = S.QUAD_XF if xF is None else np.asarray(xF, float)
+    ox, oy, oz = reference_quad_obstacle_points()
+    r = reference_astar3d(10.0 * x0[:3], 10.0 * xF[:3], ox, oy, oz)
+    if r is None:
+        return None
+    wp = r[0] / 10.0; N = len(wp) - 1
+    Ts_as = np.round(Ts * 80 / N * 100) / 100
+    xWS = np.zeros((N + 1, 12)); xWS[:, :3] = wp
+    return N, float(Ts_as), xWS, 0.5 * np.ones((N, 4)), wp
+
+
 def reeds_shepp(start, goal, R, step=0.2):
     """shortest Reeds-Shepp path between two poses (x, y, yaw) for turning radius R: returns (path (K,3), dir (K,), word, segment lengths, total)"""
     s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()

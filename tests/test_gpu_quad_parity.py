@@ -90,17 +90,14 @@ def test_quadcopter_dist_variant_matches_oracle(Q):
 
 
 def test_reference_main_call_runs_as_is(Q):
-    """mainQuadcopter.jl's own call sequence: the 3-D A* path on the 1.0 grid from x = 10 to x = 90 gives N_as >= 80 way-points (:116-129), Ts_as is
+    """mainQuadcopter.jl's own call sequence: the 3-D A* path on the 1.0 grid from x = 10 to x = 90 (a_star_3D.jl restated: planner.reference_quad_warm_start), Ts_as
     rounded to two decimals (:131), the warm start stacks the path positions with zeros (:134-136), the boxes are the ones clamped by the plot call
     (SURVEY Q3), and BOTH functions are called with the reference's start lambda = 0.05 (QuadcopterDist :145, QuadcopterSignedDist :152)"""
     import obca_amd
     from obca_amd import scenarios as S, planner as PL, validate as V
-    path = PL.astar3d(S.QUAD_X0[:3], S.QUAD_XF[:3], res=0.1)              # grid resolution 1.0 in the reference's x10 scaled units
-    assert path is not None
-    N_as = len(path) - 1
-    assert 80 <= N_as <= 128, N_as
-    Ts_as = round((0.25 * 80 / N_as) * 100) / 100                        # :131 with Ts = 0.25
-    xWS = np.zeros((N_as + 1, 12)); xWS[:, :3] = path                     # = the reference's 12 x (N_as+1) array, column-major
+    N_as, Ts_as, xWS, uWS_as, path = PL.reference_quad_warm_start()      # a_star_3D.jl restated, on the reference's own point walls (round 4; a stand-in search until then)
+    assert N_as == 99 and Ts_as == 0.2                                    # :129-131: N_as = length(rx) - 1 (the path repeats its goal cell once), Ts_as = round(0.25 * 80 / N_as, 2)
+    assert np.array_equal(path[0], S.QUAD_X0[:3]) and np.array_equal(path[-1], S.QUAD_XF[:3])
     for fn, orc in ((obca_amd.QuadcopterDist, Q.quadcopter_dist), (obca_amd.QuadcopterSignedDist, Q.quadcopter_signed_dist)):
         xp, up, ts, ef, t, lp, status = fn(S.QUAD_X0, S.QUAD_XF, N_as, Ts_as, S.QUAD_R, *S.QUAD_OB, xWS, 0.5 * np.ones((N_as, 4)), 1, dual_ws=False)
         r = orc(Q.X0, Q.XF, N_as, Ts_as, Q.EGO_R, S.QUAD_OB, xWS, 1.0, dual_ws=0)

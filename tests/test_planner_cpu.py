@@ -311,3 +311,50 @@ def test_reference_warm_start_pipeline_matches_main_jl():
         assert np.array_equal(xWS[:, :3], path[::3]) and np.abs(xWS[:, 3]).max() <= vnom + 1e-9
         assert np.abs(uWS[:, 0]).max() <= 0.6 + 1e-9 and np.abs(uWS[:, 1]).max() <= 0.32      # steering lock; the ramps of the smoother take round(v / 0.3 / dt) samples, so their slope is 0.3 up to that rounding (0.3125)
         assert abs(xWS[0, 3]) < 1e-12 or abs(xWS[0, 3]) <= vnom                                        # (the smoother ramps up from rest)
+
+
+def test_reference_astar3d_restated_on_the_reference_call():
+    """QuadcopterNavigation/a_star_3D.jl restated (REFERENCE mode, obca_plan_reference_astar3d) on mainQuadcopter.jl:59-121's own call -- the two point walls, room 105 x 105 x 55,
+    start (10, 10, 30), goal (90, 30, 20), grid 1.0.  The reference ships no output for it, so the pin is (a) the definition, checked independently: every way-point is a cell whose
+    NEAREST obstacle point (the two appended room corners included, :196-198) is farther than VEHICLE_RADIUS = 2.5, strictly inside the room (:118-123), consecutive way-points
+    are 26-neighbours, the path starts on the start cell and ends on the goal cell TWICE (get_final_path pushes the goal and then walks the closed set from the goal, :243-250);
+    (b) weighted A* with H_WEIGHT = 1.1 and a consistent heuristic is at most 1.1 x the optimum: against scipy's Dijkstra on the same 26-connected grid; (c) the numbers the
+    caller derives (:129-131): N_as = 99, Ts_as = 0.2 -- a regression fixture of THIS restatement."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import dijkstra
+    ox, oy, oz = PL.reference_quad_obstacle_points()
+    assert len(ox) == 67494                                             # 6 x 106 x 50 + 6 x (41 x 56 + 56 x 56 + 11 x 26 + 11 x 21)
+    s3, g3 = np.array([10.0, 10.0, 30.0]), np.array([90.0, 30.0, 20.0])
+    wp, nexp, cost = PL.reference_astar3d(s3, g3, ox, oy, oz)
+    assert np.array_equal(wp[0], s3) and np.array_equal(wp[-1], g3) and np.array_equal(wp[-2], g3) and len(wp) == 100
+    st = np.abs(np.diff(wp[:-1], axis=0))
+    assert st.max() == 1.0 and (st.sum(1) >= 1).all()
+    assert abs(np.sqrt((np.diff(wp[:-1], axis=0) ** 2).sum(1)).sum() - cost) < 1e-9
+    pts = np.stack([np.append(ox, [0.0, 105.0]), np.append(oy, [0.0, 105.0]), np.append(oz, [0.0, 55.0])], axis=1)
+    for p in wp:
+        assert np.sqrt(((pts - p) ** 2).sum(1)).min() > 2.5 and (p > 0).all() and (p < [105, 105, 55]).all()
+    # (b) the optimum on the same map: blocked = nearest obstacle point within 2.5, cells x, y, z in 1 .. width - 1
+    X, Y, Z = 105, 105, 55
+    blocked = np.zeros((X, Y, Z), bool)
+    r = 3
+    off = np.array([(a, b, c) for a in range(-r, r + 1) for b in range(-r, r + 1) for c in range(-r, r + 1) if a * a + b * b + c * c <= 6.25])
+    ip = pts.astype(int)                                                # (all obstacle points lie on integer coordinates here)
+    for o in off:
+        q = ip + o; ok = ((q >= 0) & (q < [X, Y, Z])).all(1); blocked[q[ok, 0], q[ok, 1], q[ok, 2]] = True
+    blocked[0] = blocked[:, 0] = blocked[:, :, 0] = True               # (node - min) <= 0 is outside the search (:118-123)
+    idx = np.arange(X * Y * Z).reshape(X, Y, Z); rows, cols, w = [], [], []
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            for c in (-1, 0, 1):
+                if (a, b, c) <= (0, 0, 0):
+                    continue
+                sl = lambda d, n: (slice(max(0, -d), n - max(0, d)), slice(max(0, d), n - max(0, -d)))
+                (xa, xb), (ya, yb), (za, zb) = sl(a, X), sl(b, Y), sl(c, Z)
+                free = ~blocked[xa, ya, za] & ~blocked[xb, yb, zb]
+                rows.append(idx[xa, ya, za][free]); cols.append(idx[xb, yb, zb][free]); w.append(np.full(int(free.sum()), np.sqrt(a * a + b * b + c * c)))
+    G = sp.csr_matrix((np.concatenate(w), (np.concatenate(rows), np.concatenate(cols))), shape=(X * Y * Z, X * Y * Z))
+    d = dijkstra(G, directed=False, indices=idx[10, 10, 30])[idx[90, 30, 20]]
+    assert d <= cost + 1e-9 <= 1.1 * d + 1e-9, (d, cost)
+    # (c) what mainQuadcopter.jl derives from the path
+    N_as, Ts_as, xWS, uWS, wpm = PL.reference_quad_warm_start()
+    assert N_as == 99 and Ts_as == 0.2 and xWS.shape == (100, 12) and np.abs(xWS[:, :3] - wp / 10).max() == 0 and (xWS[:, 3:] == 0).all() and (uWS == 0.5).all()
