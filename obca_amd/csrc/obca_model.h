@@ -16,8 +16,8 @@
 
 #define OB_VMAX 8      // max half-space rows per obstacle (polygons with up to 8 edges; obstHrep.jl:31-102 emits one row per edge)
 #define OB_VMID 4      // the code of a (stage, obstacle) block is instantiated for <= 2, <= OB_VMID and <= OB_VMAX rows
-#define OB_NOBMAX 10
-#define OB_MMAX 40
+#define OB_NOBMAX 16     // obstacles per instance: the header carries 2 NOBMAX + 1 small integers (row counts, row offsets)
+#define OB_MMAX 64       // half-space rows per instance (all obstacles together): 3 doubles of the header each (a1, a2, b)
 
 namespace obca {
 

@@ -84,12 +84,12 @@ typedef __attribute__((address_space(1))) double gdbl;
 namespace obca {
 
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
-#define OB_NMAX 128  // longest horizon (the forward-sweep trajectory lives in LDS)
+#define OB_NMAX 256  // longest horizon: what 64 KB of LDS per workgroup hold (static block + OB_DYN_LDS_DOUBLES(256) x 8 = 5 + 55.7 KB; N = 80 needs 22.7 KB)
 #define OB_AS 60     // doubles per assembled stage record (only the entries that can be non-zero are kept: as_h / as_df below)
 #define OB_RS 74     // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
-#define OB_HDR 168   // doubles of problem header (scalars + A + b) in front of rx, ry, ryaw
-// header indices
+// problem header (doubles, in front of rx, ry, ryaw): 26 scalars, then the obstacle set -- row counts, row offsets, the rows themselves.  It lives in LDS for the whole solve
+// (Shared::hdr): 8 bytes per scalar, 16 per obstacle, 24 per half-space row = 2.0 KB at the limits below, of which a 3-obstacle / 5-row instance uses 0.4 KB.
 #define PH_TS 0
 #define PH_L 1
 #define PH_G 2
@@ -101,11 +101,12 @@ namespace obca {
 #define PH_FIX 23
 #define PH_NOB 24
 #define PH_M 25
-#define PH_VOB 26
-#define PH_DIST 47     // 1: ParkingDist.jl formulation
-#define PH_ROFF 36
-#define PH_A 48
-#define PH_B 128
+#define PH_VOB 26                               // OB_NOBMAX row counts
+#define PH_ROFF (PH_VOB + OB_NOBMAX)            // OB_NOBMAX + 1 row offsets
+#define PH_DIST (PH_ROFF + OB_NOBMAX + 1)       // 1: ParkingDist.jl formulation
+#define PH_A (PH_DIST + 1)                      // 2 x OB_MMAX: (a1, a2) of every row (unit length)
+#define PH_B (PH_A + 2 * OB_MMAX)               // OB_MMAX
+#define OB_HDR (PH_B + OB_MMAX)                 // doubles of problem header in front of rx, ry, ryaw
 // stage record
 #define AS_H 0       // 19 entries of the symmetric 8 x 8 stage Hessian (variables X, Y, psi, v, w0, w1, delta, a): slot as_h(i, j)
 #define AS_HB 19     // gradient (8)

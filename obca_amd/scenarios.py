@@ -320,14 +320,14 @@ def make_quad_batch(B, N=60, seed=20260925, jitter=0.3, random_endpoints=False):
 
 
 # ---------------------------------------------------------------- BASELINE config 5: mixed obstacle counts
-def make_mixed_batch(B, N=80, seed=20260925, max_extra=7, min_obstacles=3, rows=(3, 4)):
+def make_mixed_batch(B, N=80, seed=20260925, max_extra=7, min_obstacles=3, rows=(3, 4), max_rows=40):
     """config-5 style batch: the backwards-parking scenario plus 0..max_extra extra convex obstacles per instance (triangles = 3 rows,
     quadrilaterals = 4 rows, clockwise vertices through obstHrep) placed in the block left of the slot where the car never goes, so every
     instance stays solvable while nOb runs from 3 to 10 and M from 5 to 33: irregular per-instance H-rep packing, 1-4 rows per obstacle.
     min_obstacles=1 (BASELINE.json configs[4] as written: "1-10 obstacles per instance"): the obstacle count is drawn from U{1..10}; counts
     below three keep only the first one / two obstacles of the scenario (left block; both blocks of the slot, no wall above the road).
     rows=(lo, hi): edge count of the extra polygons (default triangles and quadrilaterals; up to OBCA_VMAX = 8 edges; the instance keeps at
-    most OBCA_MMAX = 40 rows in total)."""
+    most max_rows = 40 rows in total by default; OBCA_MMAX = 64, OBCA_NOBMAX = 16 are the library's limits: max_extra = 13, max_rows = 64 reach them)."""
     rng = np.random.default_rng(seed)
     base = make_batch(BACKWARDS, B, N, seed=seed)
     sc = BACKWARDS
@@ -341,7 +341,7 @@ def make_mixed_batch(B, N=80, seed=20260925, max_extra=7, min_obstacles=3, rows=
         for _ in range(nex):
             cx, cy, r = rng.uniform(-13, -4), rng.uniform(2.0, 4.0), rng.uniform(0.3, 0.8)
             nv = int(rng.integers(rows[0], rows[1] + 1))                   # triangle or quadrilateral by default
-            if sum(vOb) - len(vOb) + nv > 40:
+            if sum(vOb) - len(vOb) + nv > max_rows:
                 break
             gap = 0.5 if nv <= 4 else 0.9 * np.pi / nv
             ang = np.sort(rng.uniform(0, 2 * np.pi, nv))[::-1]             # clockwise

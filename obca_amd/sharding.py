@@ -157,7 +157,7 @@ def parking_signed_dist_sharded_ragged(batch, N, L, ego, XYbounds, fixTime, rank
     per-instance lists vOb, A, b.  The instances are dealt to the ranks by (nOb, M) buckets, round-robin (balanced_permutation), the obstacle sets travel with the
     rows (padded to OBCA_NOBMAX / OBCA_MMAX), results come back in the caller's order.  One scatter, one gather."""
     torch, dist = _dist()
-    N1 = N + 1; NOB, MM = 10, 40                                   # OBCA_NOBMAX, OBCA_MMAX (include/obca_hip.h)
+    N1 = N + 1; NOB, MM = 16, 64                                   # OBCA_NOBMAX, OBCA_MMAX (include/obca_hip.h)
     inp = [("x0", 4), ("xF", 4), ("Ts", 1), ("rx", N1), ("ry", N1), ("ryaw", N1), ("xWS", 4 * N1), ("uWS", 2 * N), ("vOb", NOB), ("A", 2 * MM), ("b", MM)]
     outw = [("xp", 4 * N1), ("up", 2 * N), ("timeScale", N1), ("exitflag", 1), ("lp", MM * N1), ("np", 4 * NOB * N1), ("sl", NOB * N1), ("info", 8)]
     Bt = torch.zeros(1, dtype=torch.int64, device=_dev(device))

@@ -32,7 +32,7 @@
 #include <string.h>
 
 #define VMAX 8
-#define NOBMAX 10
+#define NOBMAX 16
 #define NCOL 6 /* right-hand sides through the Riccati: main, t, nu1..nu4 */
 
 typedef struct {

@@ -1,7 +1,7 @@
 """
 Host-side packing of OBCA parking instances into the flat fp64 buffers the HIP solver reads.
 
-  prob[inst] = [ header (OB_HDR=168 doubles: scalars, obstacle H-rep rows) | rx | ry | ryaw ]      (N+1 each)
+  prob[inst] = [ header (OB_HDR = 252 doubles: scalars, obstacle H-rep rows) | rx | ry | ryaw ]      (N+1 each)
   z[inst]    = one primal-dual iterate, stage-contiguous (= the reference's column-major x, u, l, n arrays):
                x 4(N+1) | u 2N | t | lam M(N+1) | mu 4nOb(N+1) | sl nOb(N+1) | so nOb(N+1) | ss N |
                pi 4N | nu 4 | yg N | yo 4nOb(N+1) | bound multipliers ...
@@ -10,8 +10,9 @@ The argument conventions are those of ParkingSignedDist(x0,xF,N,Ts,L,ego,XYbound
 """
 import numpy as np
 
-OB_VMAX, OB_NOBMAX, OB_MMAX, OB_HDR = 8, 10, 40, 168
-PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=36, DIST=47, A=48, B=128)
+OB_VMAX, OB_NOBMAX, OB_MMAX = 8, 16, 64      # obca_model.h
+PH = dict(TS=0, L=1, G=2, OFF=6, XL=7, XU=11, X0=15, XF=19, FIX=23, NOB=24, M=25, VOB=26, ROFF=26 + OB_NOBMAX, DIST=26 + 2 * OB_NOBMAX + 1)      # obca_solver.h: PH_*
+PH["A"] = PH["DIST"] + 1; PH["B"] = PH["A"] + 2 * OB_MMAX; OB_HDR = PH["B"] + OB_MMAX
 LAYOUT_FIELDS = ("x u t lam mu sl so ss pi nu yg yo zxL zxU zuL zuU ztL ztU zlam zmu zso zssL zssU zs1 nprimal len").split()
 
 

@@ -375,3 +375,21 @@ def test_a_discarded_recalc_y_estimate_leaves_no_stale_records(oracle, emu):
             emu.emu_force_recalc_failure(0)
         assert int(ia[7]) == int(ib[7]) == 1 and int(ia[1]) == int(ib[1]) and np.array_equal(za, zb), (i, ia, ib)
     assert entered >= 3          # (the option does reach its estimate on these instances, so the forced failures above were real)
+
+
+def test_instances_at_the_obstacle_and_row_limits_follow_the_oracle(oracle):
+    """OBCA_NOBMAX = 16 obstacles / OBCA_MMAX = 64 half-space rows per instance (round 4; 10 / 40 before): the problem header, the item loops and the row offsets at their limits --
+    the kernel source in the host emulation against the oracle on instances with 14-16 obstacles of 3-4 rows"""
+    import emu_solver as E
+    N = 40
+    bt = S.make_mixed_batch(24, N, seed=5, max_extra=13, rows=(3, 4), max_rows=64)
+    big = [i for i in range(24) if len(bt["vOb"][i]) >= 14][:3]
+    assert len(big) == 3 and max(len(bt["vOb"][i]) for i in big) == 16 and max(int(np.sum(bt["vOb"][i])) for i in big) > 40
+    for i in big:
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        a = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i], bt["b"][i], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r = oracle.parking_signed_dist(*a)
+        e = E.parking_signed_dist_batch(bt["x0"][i:i + 1], bt["xF"][i:i + 1], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i], bt["b"][i],
+                                        xWS[None, :, 0], xWS[None, :, 1], xWS[None, :, 2], 0, xWS[None], bt["uWS"][i:i + 1])
+        assert e["exitflag"][0] == r["exitflag"] == 1 and e["iters"][0] == r["iters"], (i, e["exitflag"][0], r["exitflag"], e["iters"][0], r["iters"])
+        assert np.abs(e["xp"][0] - r["xp"]).max() < 1e-7

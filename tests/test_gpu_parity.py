@@ -72,7 +72,7 @@ def test_every_instance_of_the_benchmark_batch_matches_oracle(OA):
     assert out["iters"][768] + out["info"][768, 6] >= 100          # the straggler that ends the synchronous step is among the compared
 
 
-@pytest.mark.parametrize("N", [33, 101, 128], ids=["odd_horizon", "beyond_the_composed_pairs", "longest_horizon"])
+@pytest.mark.parametrize("N", [33, 101, 128, 256], ids=["odd_horizon", "beyond_the_composed_pairs", "round_3_limit", "longest_horizon"])
 def test_parking_matches_oracle_other_horizons(OA, oracle, N):
     """horizons that exercise the tails of the sweeps: odd N (one leftover stage after the two-stage steps of the forward sweep), N > 96 (more
     stage pairs than the composed-map buffer holds) and OBCA_NMAX itself (every LDS array at its limit)"""
@@ -401,11 +401,11 @@ def test_bad_inputs_fail_loudly_not_crash(OA):
     with pytest.raises(OA.ObcaError):      # 9 rows in one obstacle > OBCA_VMAX
         OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [9], np.zeros((9, 2)), np.zeros(9),
                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
-    with pytest.raises(OA.ObcaError):      # 6 x 7 = 42 rows in one instance > OBCA_MMAX
-        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [7] * 6, np.ones((42, 2)), np.zeros(42),
+    with pytest.raises(OA.ObcaError):      # 10 x 7 = 70 rows in one instance > OBCA_MMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [7] * 10, np.ones((70, 2)), np.zeros(70),
                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
-    with pytest.raises(OA.ObcaError):      # 11 obstacles > OBCA_NOBMAX
-        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [1] * 11, np.ones((11, 2)), np.zeros(11),
+    with pytest.raises(OA.ObcaError):      # 17 obstacles > OBCA_NOBMAX
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [1] * 17, np.ones((17, 2)), np.zeros(17),
                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
     bad = bt["x0"].copy(); bad[0, 0] = np.nan  # NaN input: exitflag 0 for that instance, the other one still solves
     out = OA.parking_signed_dist_batch(bad, bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
@@ -621,3 +621,19 @@ def test_parking_dist_with_the_reference_ipopt_configuration_matches_the_oracle(
     # round 4).  Such an instance cannot be pinned iteration for iteration between two implementations; at most two are tolerated and they are reported.
     print("ParkingDist, reference IPOPT configuration on both sides: %d instances, iteration counts differ on %s" % (B, off))
     assert len(off) <= 2 and nsolved >= B - 4 - len(off)
+
+
+def test_instances_at_the_obstacle_and_row_limits(OA, oracle):
+    """OBCA_NOBMAX = 16 obstacles / OBCA_MMAX = 64 rows per instance through the C ABI (round 4 lifted the limits from 10 / 40): a ragged batch whose instances carry 3-16
+    obstacles of 3-4 rows (up to 60 rows) against the oracle -- exit flags, iteration counts, trajectories"""
+    N, B = 40, 24
+    bt = S.make_mixed_batch(B, N, seed=5, max_extra=13, rows=(3, 4), max_rows=64)
+    assert max(len(v) for v in bt["vOb"]) == 16 and max(int(np.sum(v)) for v in bt["vOb"]) > 40
+    out, xWS = _solve_batch(OA, dict(bt, N=N))
+    for i in range(B):
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i], bt["b"][i],
+                                       xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+        assert out["exitflag"][i] == r["exitflag"] and out["iters"][i] == r["iters"], (i, out["exitflag"][i], r["exitflag"], out["iters"][i], r["iters"])
+        if r["exitflag"] == 1:
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
+    assert (out["exitflag"] == 1).sum() >= B - 2

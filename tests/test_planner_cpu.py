@@ -86,7 +86,7 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp", "obca_plan_reference_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp", "obca_plan_reference_astar3d", "obca_plan_reference_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
 
 
 def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():
