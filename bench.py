@@ -67,21 +67,32 @@ def f_pass_parking(N, blocks_per_stage):
 
 
 def b_pass_parking(N, nOb, M):
-    """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-3 kernel (default build: the obstacle
-    part of the search direction is recomputed, never stored).  Per stage and pass, in doubles; zb = iterate part of the stage's (stage, obstacle) blocks = 2 v + 15 per block
-    (lambda, mu, sl, slack, their multipliers):
+    """ALGORITHMIC HBM bytes per factorisation pass of one parking instance: the streaming model of DESIGN.md section 5 for the round-4 kernel (the obstacle part of the search
+    direction is recomputed, never stored; the condensed obstacle contributions are summed in LDS, never written).  Per stage and pass, in doubles; zb = iterate part of the
+    stage's (stage, obstacle) blocks = 2 v + 15 per block (lambda, mu, sl, slack, their multipliers):
       direction_obs        read zb
-      fused line search    obstacle part: read zb, write zb + condensed records 12 nOb;  stage part: read 26 (iterate) + 8 (step) + 12 nOb (condensed records) + 3 (reference),
-                           write 26 (trial iterate) + 60 (stage record)
+      fused line search    obstacle part: read zb, write zb;  stage part: read 26 (iterate) + 8 (step) + 3 (reference), write 26 (trial iterate) + 60 (stage record)
       backward sweep       read 60, write 72 (Riccati record)
-      forward sweep + stage back-substitution   read 44 + 21 (stage record) + 72 (Riccati record) + 7, write 8 (stage step)
+      forward sweep + stage back-substitution   read 44 + 21 (stage record) + 72 (Riccati record: gains once, value-function rows once) + 7, write 8 (stage step)
     plus 0.16 stand-alone assemblies per pass (first iterate, barrier updates, inertia retries)."""
     N1 = N + 1
     zb = 2.0 * M + 15.0 * nOb
-    rd = N1 * (zb + zb + (26 + 8 + 12 * nOb + 3) + 60 + (44 + 21 + 72 + 7))
-    wr = N1 * ((zb + 12 * nOb) + (26 + 60) + 72 + 8)
-    asm = 0.16 * N1 * ((zb + 26 + 12 * nOb) + (12 * nOb + 60))
+    rd = N1 * (zb + zb + (26 + 8 + 3) + 60 + (44 + 21 + 72 + 7))
+    wr = N1 * (zb + (26 + 60) + 72 + 8)
+    asm = 0.16 * N1 * ((zb + 26) + 60)
     return 8.0 * (rd + wr + asm)
+
+
+def b_iter_quad(N):
+    """ALGORITHMIC HBM bytes per interior-point ITERATION of one quadcopter instance (the streaming model of obca_quad_solver.h; doubles per stage: iterate 190 = 56 primal +
+    22 multipliers + 2 x 56 bound multipliers, packed stage record 288, Riccati record 480 of its 768 slots, condensed box records 5 x 12):
+      once per iteration   forward sweep reads 280 + 56;  stage back-substitution reads 360 (value-function rows of the next stage) and writes 78 (step);  block back-substitution
+                           reads 130, writes 50;  trial evaluation reads 270;  update reads 270, writes 190                                                     = 1 684
+      per backward sweep   reads the stage record 288, writes the Riccati record 480 (1.09 sweeps per iteration: 8 % fail the inertia test on the way)            =   768
+      per assembly         block part reads 130, writes 60;  stage part reads 60 + 60, writes 288 (1.23 assemblies per iteration: rungs of the inertia ladder that are not
+                           skipped on a block hint)                                                                                                              =   598
+    (sweeps and assemblies per iteration: host emulation with counters on six bench instances, docs/HISTORY.md section 9; the kernel reports iterations and rungs only)"""
+    return 8.0 * (N + 1) * (1684 + 1.09 * 768 + 1.23 * 598)
 
 
 F_PASS_QUAD = 60 * 33000 + 305 * 2400 + 61 * 2500 + 1.0e5   # Riccati 16-state sweep + 305 box blocks + stage derivatives + trial evaluations (DESIGN.md section 9)
@@ -622,7 +633,8 @@ def main():
         passes0 = float((out["info"][:, 1] + out["info"][:, 6]).sum())      # passes of ONE launch of rank 0's batch (the launch the HIP events timed)
         k_ms = float(np.median(ipm_ms))
         if quad:
-            f_pass = F_PASS_QUAD; b_pass = None; kernel = "obca_quad_ipm_kernel"
+            f_pass = F_PASS_QUAD; kernel = "obca_quad_ipm_kernel"
+            b_pass = b_iter_quad(N) * float(out["info"][:, 1].sum()) / max(1.0, passes0)      # per pass = per iteration x iterations / passes of this launch
         else:
             if cfg == 5:
                 nb_mean = float(np.mean([len(np.ravel(v)) for v in vOb])); f_pass = f_pass_parking(N, nb_mean)

@@ -28,17 +28,18 @@ extern "C" {
 
 /* Limits of the parking entry points.  The reference has none (obstHrep.jl:31-102 emits one row per polygon edge, main.jl:251 takes whatever horizon the planner gives); here an
  * instance is solved by ONE wavefront whose problem header and sweep buffers live in the CU's LDS, and the (stage, obstacle) block code is compiled for fixed row counts:
- *   OBCA_NMAX   -- horizon.  The sweeps' LDS is sized per launch: 5.6 KB + (27 N + 54) x 8 bytes (23 KB at N = 80, four instances per CU up to N = 160); 256 is what the
- *                  64 KB a workgroup may hold allow.  HBM per instance grows linearly (0.22 MB at N = 80).
+ *   OBCA_NMAX   -- horizon: 128 = two stages for each of the 64 lanes of the forward sweep (one lane per stage pair; a longer horizon needs a second round of pair maps,
+ *                  not built).  The sweeps' LDS is sized per launch: 5.7 KB + (27 N + 54) x 8 bytes (23 KB at N = 80, 33 KB at N = 128: four instances per CU throughout);
+ *                  HBM per instance grows linearly (0.2 MB at N = 80).  The reference's planners give N = 50-110.
  *   OBCA_NOBMAX -- obstacles per instance: 16 bytes of LDS each; the block work is (N + 1) x nOb items on 64 lanes.
  *   OBCA_MMAX   -- half-space rows per instance, all obstacles together: 24 bytes of LDS each (2.0 KB of header at the limits, 0.4 KB used by a 3-obstacle / 5-row instance).
  *   OBCA_VMAX   -- rows of ONE obstacle (polygon edges): the block code exists for <= 2, <= 4 and <= 8 rows (chosen per instance); a 16-row instantiation would keep a
  *                  15 x 15 reduced Hessian per lane in registers and spill most of it -- split such a polygon into convex pieces of <= 8 edges instead.
- * Round 4 lifted them from 128 / 10 / 40 to these values (the header layout and every buffer follow from the constants). */
+ * Round 4 lifted the obstacle and row limits from 10 / 40 to these values (the header layout and every buffer follow from the constants). */
 #define OBCA_VMAX 8      /* max half-space rows per obstacle */
 #define OBCA_MMAX 64     /* max half-space rows per instance (all obstacles together) */
 #define OBCA_NOBMAX 16   /* max obstacles per instance */
-#define OBCA_NMAX 256    /* max horizon (the reference's planners give N ~ 50-110) */
+#define OBCA_NMAX 128    /* max horizon (the reference's planners give N ~ 50-110) */
 
 typedef struct obca_ctx obca_ctx;
 typedef struct obca_batch obca_batch;

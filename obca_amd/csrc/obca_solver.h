@@ -84,7 +84,7 @@ typedef __attribute__((address_space(1))) double gdbl;
 namespace obca {
 
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
-#define OB_NMAX 256  // longest horizon: what 64 KB of LDS per workgroup hold (static block + OB_DYN_LDS_DOUBLES(256) x 8 = 5 + 55.7 KB; N = 80 needs 22.7 KB)
+#define OB_NMAX 128  // longest horizon: the forward sweep gives ONE lane to every pair of stages (direction_main: 64 pairs per wavefront); LDS would allow more (5.7 KB + (27 N + 54) x 8 bytes)
 #define OB_AS 60     // doubles per assembled stage record (only the entries that can be non-zero are kept: as_h / as_df below)
 #define OB_RS 74     // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
@@ -205,6 +205,7 @@ struct alignas(16) Shared {
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     Inst inst; AsmOut A, A2, An, Ap; StepOut S; int vm2, vmc;   // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
     Soc soc;
+    int ft_ok, ft_done;      // ft_ok: the instance's (stage, obstacle) items fit OB_KEEP rounds (first-trial block part merged into the direction phase); ft_done: that part has run for the direction at hand
 };
 
 // Dynamic LDS behind `Shared`, sized for the horizon at launch (OB_DYN_LDS_DOUBLES).  Three layouts share it, one per phase of a pass (they never overlap in time):
@@ -455,8 +456,11 @@ struct FuseArgs { double alpha, ay, az, ks, dw_dir; };   // step lengths (primal
 // part (a): one lane per (stage, obstacle) block; partial results go to sh.Ap
 // SOC = 1: the system of a second-order correction step -- FUSED = 0: condensation with c_soc on the right-hand side; FUSED = 1: the block steps of the trial are those of
 // the correction direction (recomputed with c_soc), the assembly at the trial point is the ordinary one.
-template <int VM, int FUSED, int SOC = 0, int LSQ = 0>      // LSQ = 1 (with FUSED = 0): the blocks of the least-squares multiplier system (obs_block)
-OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, const FuseArgs &fa_) {
+// KEEP = 1 (with FUSED = 1): the block steps were kept in registers by direction_obs<KEEP = 1> of the same phase call (ph_direction2_trial: the first trial of a line search);
+// item lane + 64 r finds its step in keep[r] and is not factorised a second time at the old point.
+#define OB_KEEP 4          // rounds of (stage, obstacle) items whose steps a lane keeps: (N + 1) nOb <= 64 OB_KEEP (N = 80, 3 obstacles: 243 items)
+template <int VM, int FUSED, int SOC = 0, int LSQ = 0, int KEEP = 0>      // LSQ = 1 (with FUSED = 0): the blocks of the least-squares multiplier system (obs_block)
+OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, const FuseArgs &fa_, const ObsStep<VM> (*keep)[OBCA_NL] = nullptr) {
     const Lay &l = sh.l;
     Consts c; obs_consts(sh.c, c);            // the constants the block code uses, in scalar registers (see assemble_stage)
     const double mu = UNIFORM_D(mu_), dw = UNIFORM_D(dw_), dc = UNIFORM_D(dc_);
@@ -472,7 +476,10 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
     PAR(lane) {
         ObsStats st; st.dmax = st.pmax = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0;
-        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
+        const int nit = (N + 1) * nOb;
+#pragma unroll
+        for (int rr = 0; rr < (KEEP ? OB_KEEP : 1); rr++)      // KEEP: the rounds are unrolled so that keep[rr] is a fixed set of registers; otherwise one pass of the plain item loop
+        for (int it = lane + (KEEP ? rr * OB_NT : 0); it < nit; it += (KEEP ? nit : OB_NT)) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             double crs[4] = {0, 0, 0, 0};
@@ -491,7 +498,8 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
 #pragma unroll
                     for (int i = 0; i < 4; i++) { sp.dmu[i] = d[l.mu + 4 * it + i]; sp.dy[i] = d[l.yo + 4 * it + i]; }
                     sp.dsl = d[l.sl + it]; sp.dso = d[l.so + it];
-                } else obs_block<1, VM, SOC>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp, crs);
+                } else if (KEEP) sp = keep[rr][LI(lane)];
+                else obs_block<1, VM, SOC>(c, in, mu, fa.dw_dir, dc, nullptr, nullptr, dp, &sp, crs);
 #pragma unroll
                 for (int i = 0; i < VM; i++) if (i < in.v) {
                     const double v1 = fma(fa.alpha, sp.dlam[i], in.lam[i]), z1 = zstep<RS_>(in.zl[i], in.lam[i], sp.dlam[i], mu, fa.az);
@@ -1443,8 +1451,9 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 }
 
 // part 2: obstacle blocks (re-factorised instead of stored), then t / nu and the step-length and descent scalars
-template <int VM, int DBG, int SOC = 0, int LSQ = 0>      // DBG = 1 (host emulation tests, least-squares multipliers): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
-OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, double tau_, StepOut &so) {
+template <int VM, int DBG, int SOC = 0, int LSQ = 0, int KEEP = 0>      // DBG = 1 (host emulation tests, least-squares multipliers): the obstacle part of the direction is also written to d; SOC = 1: block right-hand sides with c_soc
+// KEEP = 1: the block steps stay in the caller's registers (keep[r] = step of item lane + 64 r) for the first trial of the line search, see assemble_obs<KEEP = 1>
+OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu_, double dw_, double dc_, double tau_, StepOut &so, ObsStep<VM> (*keep)[OBCA_NL] = nullptr) {
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr, obca_model.h)
     const Lay &l = sh.l;
     Consts c; obs_consts(sh.c, c);
@@ -1459,7 +1468,10 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu_, double dw_, do
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr<RS_>(dv) : 1e300; if (cc_ < lap) lap = cc_; }
 #define FTBZ(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr<RS_>(dv) : 1e300; if (cc_ < laz) laz = cc_; }
-        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
+        const int nit = (N + 1) * nOb;
+#pragma unroll
+        for (int rr = 0; rr < (KEEP ? OB_KEEP : 1); rr++)
+        for (int it = lane + (KEEP ? rr * OB_NT : 0); it < nit; it += (KEEP ? nit : OB_NT)) {
             int k = it / nOb, j = it - k * nOb;
             ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
             const double dp[3] = {g_traj[(size_t)k * 6], g_traj[(size_t)k * 6 + 1], g_traj[(size_t)k * 6 + 2]};
@@ -1470,6 +1482,7 @@ OBCA_FN void direction_obs(const Inst &I, Shared &sh, double mu_, double dw_, do
                 for (int r = 0; r < 4; r++) crs[r] = sh.soc.csoc[(l.yo - l.pi) + 4 * it + r];
             }
             obs_block<1, VM, SOC, LSQ>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, crs);
+            if (KEEP) keep[rr][LI(lane)] = st;
             const int r0 = sh.roff[j];
 #pragma unroll
             for (int i = 0; i < VM; i++) if (i < in.v) {
@@ -1605,7 +1618,24 @@ OBCA_PHASE void ph_direction2(double mu, double dw, double dc, double rho, doubl
     direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
     if (sh.S.ok) direction_obs<2, 0>(sh.inst, sh, mu, dw, dc, tau, sh.S);
 }
-OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double tau) {
+// Search direction AND the block part of the first trial of the line search in one call (round 4).  The first trial always takes the fraction-to-the-boundary step lengths, which
+// are known the moment the block back-substitution has been reduced over the wavefront -- so the blocks' steps stay in the lanes' registers (48 doubles for the 4 rounds of a
+// 3-obstacle instance) and the trial point's block part is formed and condensed right away.  Until round 4 the fused line search factorised every block a second time at the old
+// point just to get that step back (a fifth of a pass).  The stage part of the trial follows as ph_fused_stage once the driver has set up the line search; later (backtracking)
+// trials and everything on the cold paths recompute as before.  Bit for bit the numbers of the two-call sequence.
+OBCA_PHASE void ph_direction2_trial(double mu, double dw, double dc, double rho, double tau, double ks) {
+    Shared &sh = g_sh;
+    direction_main(sh.inst, sh, sh.A, mu, dw, dc, rho, tau, sh.S);
+    if (!sh.S.ok) return;
+    ObsStep<2> keep[OB_KEEP][OBCA_NL];
+    direction_obs<2, 0, 0, 0, 1>(sh.inst, sh, mu, dw, dc, tau, sh.S, keep);
+    const FuseArgs fa = {sh.S.ap, fmin(sh.S.ap, sh.S.az), sh.S.az, ks, dw};
+    assemble_obs<2, 1, 0, 0, 1>(sh.inst, sh, mu, 0.0, dc, fa, keep);
+    PAR(lane) { if (lane == 0) sh.ft_done = 1; }
+    LDS_SYNC();
+}
+OBCA_FN void ph_direction(double mu, double dw, double dc, double rho, double tau, double ks_first_trial = 0.0) {      // ks_first_trial > 0: also the block part of the first trial (main path only)
+    if (g_sh.vm2 && g_sh.ft_ok && ks_first_trial > 0) { ph_direction2_trial(mu, dw, dc, rho, tau, ks_first_trial); return; }
     if (g_sh.vm2) { ph_direction2(mu, dw, dc, rho, tau); return; }
     ph_direction_main(mu, dw, dc, rho, tau);
     if (g_sh.S.ok) ph_direction_obs(mu, dw, dc, tau);
@@ -1873,7 +1903,8 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             PROF(sh.inst, PF_OTHER); if (D.tr > 0 || D.mu_changed) PH(ph_assemble(D.mu, D.dw, D.dc_val, 0));
             int a_ = A.ok;
             PROF(sh.inst, PF_OTHER); if (a_) { PH(a_ = ph_riccati(o.rho_term)); }
-            PROF(sh.inst, PF_OTHER); if (a_) { PH(ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau)); a_ = sh.S.ok; }
+            sh.ft_done = 0;
+            PROF(sh.inst, PF_OTHER); if (a_) { PH(ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau, o.kappa_sigma)); a_ = sh.S.ok; }
             if (a_) { D.ok = 1; break; }
             D.nreg++;
             if (D.dw == 0) D.dw = D.dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * D.dw_last);
@@ -1896,7 +1927,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         D.alpha = sh.S.ap; D.acc = 0;
         while (D.alpha >= D.amin) {
             // the trial point z + alpha d goes to the second iterate buffer together with its assembly (mu as is, delta_w = 0: what the next iteration starts from)
-            PROF(sh.inst, PF_OTHER); PH(ph_fused(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw));
+            PROF(sh.inst, PF_OTHER);
+            if (sh.ft_done) { sh.ft_done = 0; PH(ph_fused_stage(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw)); }      // first trial: its block part ran with the direction (ph_direction2_trial)
+            else PH(ph_fused(D.mu, D.dc_val, D.alpha, fmin(D.alpha, D.az), D.az, o.kappa_sigma, D.dw));
             const double ft = sh.An.f, tht = sh.An.th1, pht = ft - D.mu * sh.An.bar, alpha = D.alpha, th = D.th, phi = D.phi, gd = D.gd;
             if (ft == ft && tht == tht && pht == pht && tht < D.th_max) {
                 int okf = 1; const int nf = D.nf;
@@ -1959,6 +1992,7 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
             make_layout(c.N, c.nOb, c.M, sh.l);
             int vmx = 0; for (int j = 0; j < c.nOb; j++) { int v = (int)sh.hdr[PH_VOB + j]; if (v > vmx) vmx = v; }
             sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
+            sh.ft_ok = (c.N + 1) * c.nOb <= OB_KEEP * OB_NT; sh.ft_done = 0;
         }
     }
     init_unpack_table(sh);
