@@ -123,6 +123,7 @@ __global__ __launch_bounds__(1024) void obca_order_kernel(int B, const double *i
 }
 
 // one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
+// (four wavefronts per SIMD for the 2-row class -- 128 registers, 35 spilled -- was measured in round 4: 0.29 ms against 0.25 ms at three wavefronts with 158 registers: not kept)
 template <int VM>
 __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObMax, DevBufs b, double *zdst, size_t s_zdst) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,7 +42,7 @@ def test_quad_batch_parity_and_feasibility(Q):
     out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
     ok = out["exitflag"] == 1
     assert ok.all(), (ok.mean(), out["iters"])
-    for rep in range(4):        # repeated solves are bit-identical (no race between the two wavefronts of an instance)
+    for rep in range(4):        # repeated solves are bit-identical (no race between the lanes of an instance: LDS exchanges with wave-level ordering only)
         o2 = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
         assert np.array_equal(o2["iters"], out["iters"]) and np.abs(o2["xp"] - out["xp"]).max() == 0.0, rep
     # Two fp64 implementations of the same iteration: iteration counts, regularisation counts, objective, time scale and inputs agree tightly.
