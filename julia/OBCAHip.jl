@@ -73,6 +73,12 @@ function ipopt_opts()
     return o
 end
 optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
+"the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (max_soc = 4; recalc_y = \"no\" as QuadcopterSignedDist.jl:29 sets it): default of the quadcopter drop-ins"
+function quadcopter_ipopt_opts()
+    o = Opts()
+    ccall((:obca_quadcopter_reference_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_quadcopter_reference_opts failed")
+    return o
+end
 
 """
     ParkingSignedDist_batch(x0, xF, N, Ts, L, ego, XYbounds, nOb, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS)
@@ -146,23 +152,24 @@ end
 
 Batched form: x0, xF 12xB; Ts, timeWS vectors of length B; ob 6x5xB (ob1..ob5 of every instance back to back, each
 [xmax,ymax,zmax,-xmin,-ymin,-zmin]); xWS 12x(N+1)xB.  Returns (xp 12x(N+1)xB, up 4xNxB, timeScale (N+1)xB, exitflag B, time, lp 30x(N+1)xB,
-status codes B).  dist=true solves the QuadcopterDist formulation (obca_quadcopter_dist_batch).
+status codes B).  dist=true solves the QuadcopterDist formulation (obca_quadcopter_dist_batch).  opts=nothing: the library's throughput defaults
+(obca_quadcopter_default_opts); `quadcopter_ipopt_opts()`: with IPOPT's second-order correction.
 """
-function QuadcopterSignedDist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS; dual_ws::Bool=true, dist::Bool=false)
+function QuadcopterSignedDist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS; dual_ws::Bool=true, dist::Bool=false, opts=nothing)
     B = size(x0, 2)
     xp = zeros(12, N + 1, B); up = zeros(4, N, B); ts = zeros(N + 1, B); ef = zeros(Cint, B); lp = zeros(30, N + 1, B); info = zeros(8, B)
     t0 = time()
     if dist
-        rc = ccall((:obca_quadcopter_dist_batch, LIB), Cint,
+        rc = GC.@preserve opts ccall((:obca_quadcopter_dist_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
                     Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}),
-                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, C_NULL,
+                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, optsptr(opts),
                    xp, up, ts, ef, lp, info)
     else
-        rc = ccall((:obca_quadcopter_signed_dist_batch, LIB), Cint,
+        rc = GC.@preserve opts ccall((:obca_quadcopter_signed_dist_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
                     Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, C_NULL,
+                   ctx().h, B, N, f64(vec(Ts)), Float64(R), f64(x0), f64(xF), f64(ob), f64(xWS), C_NULL, f64(vec(timeWS)), dual_ws ? 1 : 0, optsptr(opts),
                    xp, up, ts, ef, lp, C_NULL, info)
     end
     rc == 0 || error("obca_quadcopter_(signed_)dist_batch failed: " * lasterr(ctx()))
@@ -173,19 +180,19 @@ _quad_status(c) = c == 0 ? "Optimal" : (c == 1 ? "UserLimit" : "Error")
 
 # xWS is 12 x (N+1) in the reference (mainQuadcopter.jl:136 builds [rx'; ry'; rz'; zeros...], QuadcopterSignedDist.jl:201 does setvalue(x, xWS)
 # without a transpose): column-major, that is already the stage-contiguous layout of the C ABI.
-function _quad_one(x0, xF, N, Ts, R, obs, xWS, timeWS, dual_ws, dist)
+function _quad_one(x0, xF, N, Ts, R, obs, xWS, timeWS, dual_ws, dist, opts)
     ob = reshape(f64(vcat(map(vec, obs)...)), 6, 5, 1)               # [xmax,ymax,zmax,-xmin,-ymin,-zmin] per box (:162-166)
     xp, up, ts, ef, t, lp, st = QuadcopterSignedDist_batch(reshape(f64(vec(x0)), 12, 1), reshape(f64(vec(xF)), 12, 1), N, [Float64(Ts)], R, ob,
-        reshape(f64(xWS)[:, 1:N+1], 12, N + 1, 1), [Float64(timeWS)]; dual_ws=dual_ws, dist=dist)
+        reshape(f64(xWS)[:, 1:N+1], 12, N + 1, 1), [Float64(timeWS)]; dual_ws=dual_ws, dist=dist, opts=opts)
     return xp[:, :, 1], up[:, :, 1], ts[:, 1], Int(ef[1]), t, lp[:, :, 1], _quad_status(st[1])
 end
 
 "Drop-in for QuadcopterSignedDist.jl:25 (one instance): same arguments, same 7-tuple (xp, up, timeScalep, exitflag, time, lp, status), :298."
-QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true) =
-    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, false)
+QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true, opts=quadcopter_ipopt_opts()) =
+    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, false, opts)
 
 "Drop-in for QuadcopterDist.jl:25 (call site mainQuadcopter.jl:145): the collision-free sibling, same arguments and 7-tuple (:282)."
-QuadcopterDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true) =
-    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, true)
+QuadcopterDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS; dual_ws::Bool=true, opts=quadcopter_ipopt_opts()) =
+    _quad_one(x0, xF, N, Ts, R, (ob1, ob2, ob3, ob4, ob5), xWS, timeWS, dual_ws, true, opts)
 
 end # module

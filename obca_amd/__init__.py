@@ -6,8 +6,8 @@ device is missing -- there is no CPU fallback.
 """
 from .api import (ObcaError, Context, Batch, ParkingSignedDist, ParkingDist, DualMultWS, parking_signed_dist_batch, dualmult_ws_batch,
                   default_opts, ipopt_opts, warm_restart_opts, library_path, build_library, QuadBatch, QuadcopterSignedDist, QuadcopterDist,
-                  quadcopter_signed_dist_batch, quadcopter_default_opts)
+                  quadcopter_signed_dist_batch, quadcopter_default_opts, quadcopter_ipopt_opts)
 
 __all__ = ["ObcaError", "Context", "Batch", "ParkingSignedDist", "ParkingDist", "DualMultWS", "parking_signed_dist_batch",
            "dualmult_ws_batch", "default_opts", "ipopt_opts", "warm_restart_opts", "library_path", "build_library", "QuadBatch", "QuadcopterSignedDist", "QuadcopterDist",
-           "quadcopter_signed_dist_batch", "quadcopter_default_opts"]
+           "quadcopter_signed_dist_batch", "quadcopter_default_opts", "quadcopter_ipopt_opts"]

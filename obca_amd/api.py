@@ -79,7 +79,7 @@ EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visibl
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
            "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
-           "obca_quadcopter_default_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
+           "obca_quadcopter_default_opts", "obca_quadcopter_reference_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
            "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
 
@@ -437,6 +437,14 @@ def quadcopter_default_opts():
     return o
 
 
+def quadcopter_ipopt_opts():
+    """the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (obca_quadcopter_reference_opts: max_soc = 4; recalc_y = "no" as
+    QuadcopterSignedDist.jl:29 sets it; no least-squares y0): the default of the drop-ins QuadcopterSignedDist / QuadcopterDist"""
+    o = Opts()
+    _load().obca_quadcopter_reference_opts(C.byref(o))
+    return o
+
+
 class QuadBatch:
     """Device-resident batch of quadcopter signed-distance NLPs (obca_quad_batch_* in include/obca_hip.h)."""
 
@@ -537,6 +545,7 @@ def QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, ti
     """Drop-in for QuadcopterSignedDist.jl:25 (one instance; xWS is (N+1,12) here, the reference's is 12 x (N+1) column-major,
     i.e. the same memory).  Returns (xp, up, timeScalep, exitflag, time, lp, status) like :298; uWS is ignored like :202."""
     ob = np.stack([np.ravel(o)[:6] for o in (ob1, ob2, ob3, ob4, ob5)])
+    opts = quadcopter_ipopt_opts() if opts is None else opts      # the drop-in runs the reference's IPOPT configuration; the batched calls default to the throughput options
     r = quadcopter_signed_dist_batch(np.reshape(x0, (1, 12)), np.reshape(xF, (1, 12)), N, Ts, R, ob, np.asarray(xWS, float)[None, :N + 1],
                                      timeWS, dual_ws, opts, device)
     return r["xp"][0], r["up"][0], r["timeScale"][0], int(r["exitflag"][0]), r["time"], r["lp"][0], _QUAD_STATUS[int(r["status"][0])]
@@ -545,6 +554,7 @@ def QuadcopterSignedDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, ti
 def QuadcopterDist(x0, xF, N, Ts, R, ob1, ob2, ob3, ob4, ob5, xWS, uWS, timeWS, opts=None, device=0, dual_ws=True):
     """Drop-in for QuadcopterDist.jl:25 (the collision-free sibling: no slack variable): same arguments and 7-tuple as QuadcopterSignedDist."""
     ob = np.stack([np.ravel(o)[:6] for o in (ob1, ob2, ob3, ob4, ob5)])
+    opts = quadcopter_ipopt_opts() if opts is None else opts      # the drop-in runs the reference's IPOPT configuration; the batched calls default to the throughput options
     r = quadcopter_signed_dist_batch(np.reshape(x0, (1, 12)), np.reshape(xF, (1, 12)), N, Ts, R, ob, np.asarray(xWS, float)[None, :N + 1],
                                      timeWS, dual_ws, opts, device, dist=True)
     return r["xp"][0], r["up"][0], r["timeScale"][0], int(r["exitflag"][0]), r["time"], r["lp"][0], _QUAD_STATUS[int(r["status"][0])]

@@ -183,7 +183,7 @@ struct QDevBufs {
 #ifndef OBCA_QUAD_WAVES_PER_EU
 #define OBCA_QUAD_WAVES_PER_EU 1      // as for the parking kernel
 #endif
-__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o) {
+__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
     if (threadIdx.x == 0) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_ker
     if (threadIdx.x < 16) quad::gq_sh.prof[threadIdx.x] = 0;
 #endif
     __syncthreads();
-    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8);
+    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8, max_soc);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = quad::gq_sh.prof[threadIdx.x];
@@ -802,7 +802,7 @@ static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, i
     hipSetDevice(device);
     quad::QLay l; quad::q_make_layout(N, l);
     QDevBufs &d = bt->d; const size_t N1 = N + 1;
-    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = l.n + l.m; d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
+    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = QDIR_DOUBLES(l);      /* two direction buffers (dv | dy) + the rows of a second-order correction, see QCS */ d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
     size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
     ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
@@ -867,6 +867,11 @@ int obca_quadcopter_default_opts(obca_opts *o) {
     o->max_iter = 3000; o->dw_min = 1e-10;            /* QuadcopterSignedDist.jl:28-31: no max_iter (IPOPT default), min_hessian_perturbation 1e-10 */
     return 0;
 }
+int obca_quadcopter_reference_opts(obca_opts *o) {
+    if (obca_quadcopter_default_opts(o)) return -1;
+    o->max_soc = 4;                                    /* IPOPT default max_soc; recalc_y stays 0: QuadcopterSignedDist.jl:29 sets recalc_y = "no".  (IPOPT's least-squares y0 is not in the quadcopter kernel.) */
+    return 0;
+}
 int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
     if (!ctx || !out) return -1;
     return quad_batch_create_on(ctx, ctx->device, ctx->stream, B, N, out, ctx->err);
@@ -899,11 +904,12 @@ int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, cons
 static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     if (!bt->uploaded) { bt->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
-    if (o.max_soc != 0 || o.recalc_y != 0 || o.lsq_init != 0) { bt->err = "quadcopter solve: max_soc / recalc_y / lsq_init are switches of the parking kernels only (obca_hip.h); the quadcopter kernel would ignore them -- refusing instead"; return -1; }
+    if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
+    if (o.recalc_y != 0 || o.lsq_init != 0) { bt->err = "quadcopter solve: recalc_y / lsq_init are switches of the parking kernels only (obca_hip.h); the quadcopter kernel would ignore them -- refusing instead"; return -1; }
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;

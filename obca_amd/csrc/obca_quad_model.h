@@ -135,12 +135,13 @@ struct QObsStats { double dmax, pmax, cmax0, cmin, cmax, sumz, sumy; int bad; };
 struct QObsStep { double dlam[QL], ds, dso, dy[2]; };
 
 // MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp;
-// MODE 2: inertia of the block only (st->bad)
+// MODE 2: inertia of the block only (st->bad).  crs: the two rows of a second-order correction in place of the constraint values (IPOPT A-5.7), or nullptr
 template <int MODE>
 OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, QObsStats *st,
-                         const double dp[3], QObsStep *step) {
+                         const double dp[3], QObsStep *step, const double *crs = nullptr) {
     double cr[2], q[3];
     q_obs_rows(c, in, cr, q);
+    const double rhs0 = crs ? crs[0] : cr[0], rhs1 = crs ? crs[1] : cr[1];      // right-hand side of the two rows: the constraint values, or the rows of a second-order correction
     const double *y = in.y;
     double g1[QL], g2[QL], Dl[QL], rl[QL];
 #pragma unroll
@@ -171,7 +172,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     }
     // row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2
     const double iT2 = rcp_nr(1e-4 * iDs + iDso + dc);
-    const double r2 = -cr[1] + 0.01 * r_s * iDs - r_so * iDso;
+    const double r2 = -rhs1 + 0.01 * r_s * iDs - r_so * iDso;
     // (lambda, y1) block: Hb = diag(Dl) + 2 y1 D'D + g2 g2'/T2 ; coupling Cp = y2 D' + g2 q'/T2 ; rk
     double Hb[QL * QL], Cp[QL][3], rk[QL + 1];
 #pragma unroll
@@ -187,7 +188,7 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         for (int cI = 0; cI < 3; cI++) Cp[i][cI] = (cI == a ? y[1] * sg : 0.0) + g2[i] * q[cI] * iT2;
         rk[i] = -rl[i] + g2[i] * r2 * iT2;
     }
-    rk[QL] = -cr[0];
+    rk[QL] = -rhs0;
     // Householder Qh g1 = alpha e1, 2x2 pivot on (lam~_0, y1), LDL of the 5x5 reduced Hessian (must be positive definite)
     double hw[QL], nq = 0;
 #pragma unroll

@@ -84,7 +84,7 @@ OBCA_HD void q_make_layout(int N, QLay &l) {
 }
 // direction buffer: dv[n] then dy[m] (same offsets as v / y)
 
-struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R, x0[12], xF[12], ob[30], xWS..., see host packing
+struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc, *d0; };   // d: the direction buffer in use (one of the two behind d0, see QCS)   // prob: Ts, R, x0[12], xF[12], ob[30], xWS..., see host packing
 #define QPH_TS 0
 #define QPH_R 1
 #define QPH_X0 2
@@ -94,6 +94,15 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc; };   // prob: Ts, R
 #define QPH_DWS 57
 #define QPH_DIST 58
 #define QPH_SIZE 64
+// direction memory of an instance, behind d0: two direction buffers (dv | dy, n + m doubles each: a second-order correction is solved into the one the iteration's
+// own direction is not in, so a correction that is rejected costs nothing but its own solve) and the rows of the correction (IPOPT A-5.7: c_soc = alpha c_soc + c(trial);
+// m doubles, numbered like the multipliers)
+#define QDIR(sh, which) ((sh).inst.d0 + (size_t)(which) * ((sh).l.n + (sh).l.m))
+#define QCS(sh) QDIR(sh, 2)
+#define QDIR_DOUBLES(l) (2 * ((l).n + (l).m) + (l).m)
+#define QCS_PI(sh) ((sh).l.pi - (sh).l.n)
+#define QCS_NU(sh) ((sh).l.nu - (sh).l.n)
+#define QCS_YO(sh) ((sh).l.yo - (sh).l.n)
 
 struct QShared {
     QConsts c; QLay l; QInst inst; AsmOut A, A2, Ap; StepOut S; double trial[4];
@@ -107,6 +116,7 @@ struct QShared {
 #endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
+    int soc_on;                        // the system being solved is a second-order correction's: the terminal right-hand side comes from QCS (the assembly / block phases have variants of their own)
     int hintl[QNT];                    // per lane: a box block whose inertia was wrong in an earlier assembly (-1: none), see q_block_bad
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
@@ -149,8 +159,10 @@ OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &
 }
 
 // ---------------------------------------------------------------- assemble, part (a): box blocks
+template <int SOC>      // SOC: the system of a second-order correction (constraint right-hand sides from QCS); a variant of its own, so that the option costs the iterations nothing
 OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
-    const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z;
+    const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z, *cs = QCS(sh);
+    constexpr int soc = SOC;
     QPAR(lane) {
         QObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0; int badit = -1;
@@ -159,7 +171,9 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
             QObsIn in; q_load_obs(sh, z, k, j, in);
             ObsCond cd;
             const int bad0 = st.bad;
-            q_obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr);
+            double crs[2] = {0, 0};
+            if (soc) { crs[0] = cs[QCS_YO(sh) + 2 * it]; crs[1] = cs[QCS_YO(sh) + 2 * it + 1]; }
+            q_obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, soc ? crs : nullptr);
             if (st.bad && !bad0) badit = it;
             gdbl *o = sh.inst.oc + (size_t)it * OB_OC;
 #pragma unroll
@@ -216,9 +230,11 @@ OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
 }
 
 // ---------------------------------------------------------------- assemble, part (b): stages (writes the non-zeros of the dense record)
+template <int SOC>
 OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmOut &out) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
     const double t = z[l.t], tau = t * c.Ts;
+    const gdbl *cs = QCS(sh); constexpr int soc = SOC;
     double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
@@ -273,13 +289,16 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int i = 0; i < QX; i++) { xn[i] = z[l.x + QX * (k + 1) + i]; pim[i] = z[l.pi + QX * km + i]; }
 #pragma unroll
             for (int j = 0; j < QU; j++) { um[j] = z[l.u + QU * km + j]; un[j] = z[l.u + QU * kn + j]; zLu[j] = z[l.zL + l.u + QU * k + j]; zUu[j] = z[l.zU + l.u + QU * k + j]; }
+            double csr[QX];
+#pragma unroll
+            for (int i = 0; i < QX; i++) csr[i] = soc ? cs[QCS_PI(sh) + QX * k + i] : 0.0;
             dyn_g_derivs(c, x, u, pi, g, dg, HG);
             // residual, F columns d / Ft, A, B
 #pragma unroll
             for (int i = 0; i < QX; i++) {
                 const double r = xn[i] - x[i] - tau * g[i];
                 pmax = fmax(pmax, fabs(r)); lth += fabs(r);
-                rec[QR(QSR_F + i * QFC + 16)] = -r; rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
+                rec[QR(QSR_F + i * QFC + 16)] = soc ? -csr[i] : -r; rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) rec[QR(QSR_F + i * QFC + 6 + i)] = tau;
@@ -545,7 +564,7 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
             for (int r = 0; r < 4; r++) {
                 const int i = g + 4 * r; double v = 0.0, w = 0.0;
                 if (i < QX && j < QX) { v = rec[QR(QSR_H + i * QZ + j)]; if (i == j) v += rho; }
-                if (i < QX) { if (j == 0) w = rec[QR(QSR_HC + 2 * i)] - rho * (-(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
+                if (i < QX) { if (j == 0) w = rec[QR(QSR_HC + 2 * i)] - rho * (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
                 PD[r][L_] = v; pnD[r][L_] = w; BmD[r][L_] = 0.0;
             }
         }
@@ -610,7 +629,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         double *S = sh.bord, *col = sh.bord + 169, *colr = col + 13;   // S 12x12 (stride 12)
         PAR64(lane) {
             for (int it = lane; it < 144; it += 64) { int a = it / 12, b_ = it % 12; S[it] = -sh.Bm[(2 + a) * QC + (2 + b_)]; }
-            if (lane < 12) { col[lane] = -sh.Bm[(2 + lane) * QC + 1]; colr[lane] = -((-(z[l.x + QX * N + lane] - c.xF[lane])) - sh.Bm[(2 + lane) * QC + 0]); }
+            if (lane < 12) { col[lane] = -sh.Bm[(2 + lane) * QC + 1]; colr[lane] = -((sh.soc_on ? -QCS(sh)[QCS_NU(sh) + lane] : -(z[l.x + QX * N + lane] - c.xF[lane])) - sh.Bm[(2 + lane) * QC + 0]); }
             if (lane == 0) sh.bord_ok = 1;
         }
         LDS_SYNC();
@@ -782,7 +801,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 const gdbl *rN = sh.inst.as + (size_t)N * QSP;
 #pragma unroll
                 for (int i = 0; i < QX; i++) {
-                    const double e = -(z[l.x + QX * N + i] - c.xF[i]);
+                    const double e = sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]);
                     double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
                     for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
                     dpi[i] = -a_;
@@ -830,10 +849,12 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     QPROF(QPF_BS_STAGE);
 }
 
+template <int SOC>
 OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
     double ap = so.ap, az = so.az, gd = so.gd;
     const double dt = sh.coef[1];
+    const gdbl *cs = QCS(sh); constexpr int soc = SOC;
     QPAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
@@ -843,7 +864,9 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
             QObsIn in; q_load_obs(sh, z, k, j, in);
             const double dp[3] = {d[l.x + QX * k], d[l.x + QX * k + 1], d[l.x + QX * k + 2]};
             QObsStep st;
-            q_obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st);
+            double crs[2] = {0, 0};
+            if (soc) { crs[0] = cs[QCS_YO(sh) + 2 * it]; crs[1] = cs[QCS_YO(sh) + 2 * it + 1]; }
+            q_obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, soc ? crs : nullptr);
 #pragma unroll
             for (int i = 0; i < QL; i++) {
                 d[l.lam + QL * it + i] = st.dlam[i];
@@ -931,6 +954,54 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
     SYNC();
     fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     f = fr; th1 = tr; bar = br;
+}
+
+// ---------------------------------------------------------------- rows of a second-order correction (IPOPT A-5.6 / A-5.7, option max_soc)
+// cs <- a (first ? c(v) : cs) + c(v + a dv):  a = step length of the trial that was just rejected, dv = its direction (still in the direction buffer)
+OBCA_FN void q_soc_rows(QShared &sh, double a, int first) {
+    const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z, *d = sh.inst.d; gdbl *cs = QCS(sh);
+    QPAR(lane) {
+        for (int it = lane; it < (N + 1) * QOB; it += QNT) {
+            const int k = it / QOB, j = it - k * QOB;
+            QObsIn in; q_load_obs(sh, z, k, j, in);
+            double r0[2], rt[2], q[3];
+            if (first) q_obs_rows(c, in, r0, q); else { r0[0] = cs[QCS_YO(sh) + 2 * it]; r0[1] = cs[QCS_YO(sh) + 2 * it + 1]; }
+#pragma unroll
+            for (int i = 0; i < QL; i++) in.lam[i] += a * d[l.lam + QL * it + i];
+            in.s += a * d[l.s + it]; in.so += a * d[l.so + it];
+#pragma unroll
+            for (int i = 0; i < 3; i++) in.p[i] += a * d[l.x + QX * k + i];
+            q_obs_rows(c, in, rt, q);
+            cs[QCS_YO(sh) + 2 * it] = a * r0[0] + rt[0]; cs[QCS_YO(sh) + 2 * it + 1] = a * r0[1] + rt[1];
+        }
+        for (int k = lane; k <= N; k += QNT) {
+            double x[QX], xt[QX];
+#pragma unroll
+            for (int i = 0; i < QX; i++) { x[i] = z[l.x + QX * k + i]; xt[i] = x[i] + a * d[l.x + QX * k + i]; }
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < QX; i++) { const double r0 = first ? x[i] - c.xF[i] : cs[QCS_NU(sh) + i]; cs[QCS_NU(sh) + i] = a * r0 + (xt[i] - c.xF[i]); }
+            } else {
+                double u[QU], ut[QU], g[QX], gt[QX], r0[QX];
+#pragma unroll
+                for (int j = 0; j < QU; j++) { u[j] = z[l.u + QU * k + j]; ut[j] = u[j] + a * d[l.u + QU * k + j]; }
+                const double t0 = z[l.t], tt = t0 + a * d[l.t];
+                if (first) {
+                    dyn_g_value(c, x, u, g);
+#pragma unroll
+                    for (int i = 0; i < QX; i++) r0[i] = z[l.x + QX * (k + 1) + i] - x[i] - t0 * c.Ts * g[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < QX; i++) r0[i] = cs[QCS_PI(sh) + QX * k + i];
+                }
+                dyn_g_value(c, xt, ut, gt);
+#pragma unroll
+                for (int i = 0; i < QX; i++)
+                    cs[QCS_PI(sh) + QX * k + i] = a * r0[i] + (z[l.x + QX * (k + 1) + i] + a * d[l.x + QX * (k + 1) + i] - xt[i] - tt * c.Ts * gt[i]);
+            }
+        }
+    }
+    SYNC();
 }
 
 // ---------------------------------------------------------------- accept the step (generic over the primal vector)
@@ -1070,17 +1141,20 @@ OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_poi
 OBCA_PHASE double qph_min_norm2() { return q_min_norm2(gq_sh); }
 OBCA_PHASE void qph_restore(double bp) { q_restore_blocks(gq_sh, bp); }
 OBCA_PHASE int qph_block_bad(double mu, double dw, double dc) { const int b = q_block_bad(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); return b; }
-OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
-OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
+OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs<0>(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
+OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage<0>(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
 OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
+OBCA_PHASE void qph_soc_assemble(double mu, double dw, double dc) { QShared &sh = gq_sh; QPROF(QPF_OTHER); q_assemble_obs<1>(sh, mu, dw, dc); QPROF(QPF_ASM_OBS); q_assemble_stage<1>(sh, mu, dw, dc, sh.A2); QPROF(QPF_ASM_STAGE); }
 OBCA_PHASE int qph_riccati(double rho) { const int ok = q_riccati_backward(gq_sh, rho); QPROF(QPF_RIC); return ok; }
 OBCA_PHASE void qph_direction_main(double mu, double dw, double dc, double rho, double tau) { QShared &sh = gq_sh; q_direction_main(sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
-OBCA_PHASE void qph_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs(sh, mu, dw, dc, tau, sh.S); QPROF(QPF_BS_OBS); }
+OBCA_PHASE void qph_soc_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs<1>(sh, mu, dw, dc, tau, sh.S); QPROF(QPF_BS_OBS); }
+OBCA_PHASE void qph_direction_obs(double mu, double dw, double dc, double tau) { QShared &sh = gq_sh; q_direction_obs<0>(sh, mu, dw, dc, tau, sh.S); QPROF(QPF_BS_OBS); }
 OBCA_PHASE void qph_trial(double alpha) { QShared &sh = gq_sh; QPROF(QPF_OTHER); q_eval_trial(sh, alpha, sh.trial[0], sh.trial[1], sh.trial[2]); QPROF(QPF_TRIAL); }
+OBCA_PHASE void qph_soc_rows(double a, int first) { q_soc_rows(gq_sh, a, first); QPROF(QPF_OTHER); }
 OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { QPROF(QPF_OTHER); q_apply_step(gq_sh, alpha, ay, az, mu, ks); QPROF(QPF_APPLY); }
 
 // info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
-OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
+OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 0) {
     QShared &sh = gq_sh;
     QPAR(lane) {
         if (lane == 0) {
@@ -1090,12 +1164,13 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
             for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];                          // single-index x[10..12] = stage 1
             for (int i = 0; i < QOB * QL; i++) sh.ob[i] = p[QPH_OB + i];
             q_make_layout(N, sh.l);
+            sh.soc_on = 0; sh.inst.d0 = sh.inst.d;
         }
     }
     SYNC();
     qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS]);
     double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
-    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1, have_hint = 0;
+    int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1, have_hint = 0, dcur = 0;      // dcur: the direction buffer in use
     const AsmOut &A = sh.A;
     double th_min = 0, th_max = 0, f = 0, pinf = 0, dinf = 0;
     double dc_mu = -1.0, dc_val = 0;
@@ -1156,7 +1231,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
         }
         if (!ok) { if (nrest < Q_MAX_RESTORE) Q_RESTORE_AND_CONTINUE; status = ST_ERROR; break; }
         if (dw > 0) dw_last = dw;
-        const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, az = sh.S.az;
+        const double th = A.th1, phi = A.f - mu * A.bar, gd = sh.S.gd, ap0 = sh.S.ap; double az = sh.S.az;
         double amin, pw_th = 0, pw_gd = 0;
         if (gd < 0) { amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd)); pw_th = pow(th, o.s_theta); pw_gd = pow(-gd, o.s_phi); if (th <= th_min) amin = fmin(amin, o.delta * pw_th / pw_gd); }
         else amin = o.gamma_theta;
@@ -1181,6 +1256,51 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info) {
                         break;
                     }
                 }
+            }
+            // second-order correction (IPOPT A-5.5 .. A-5.9, kappa_soc = 0.99) after a rejected FIRST trial step that did not reduce theta.  The correction solves the
+            // iteration's own system with the constraint right-hand sides replaced (same matrix: same regularisation, inertia already right) into the other direction
+            // buffer: a correction that is rejected leaves the iteration's own direction where the backtracking goes on with it.
+            if (max_soc > 0 && alpha == ap0 && ft == ft && tht == tht && tht >= th) {
+                double th_old = 0, th_tr = tht, asoc = alpha, azs = az;
+                for (int ps = 0; ps < max_soc && !acc && (ps == 0 || th_tr <= 0.99 * th_old); ps++) {
+                    th_old = th_tr;
+                    qph_soc_rows(asoc, ps == 0);      // (reads the direction of the trial just rejected: the iteration's own, then the last correction's)
+                    QPAR(lane) { if (lane == 0) { sh.soc_on = 1; sh.inst.d = QDIR(sh, 1 - dcur); } }
+                    SYNC();
+                    qph_soc_assemble(mu, dw, dc);
+                    int a_ = sh.A2.ok;
+                    if (a_) a_ = qph_riccati(o.rho_term);
+                    if (a_) { qph_direction_main(mu, dw, dc, o.rho_term, tau); a_ = sh.S.ok; }
+                    if (a_) qph_soc_direction_obs(mu, dw, dc, tau);
+                    QPAR(lane) { if (lane == 0) sh.soc_on = 0; }
+                    SYNC();
+                    if (!a_) break;
+                    asoc = sh.S.ap; azs = sh.S.az;
+                    qph_trial(asoc);
+                    const double fs = sh.trial[0], ths = sh.trial[1], phs = fs - mu * sh.trial[2];
+                    if (!(fs == fs && ths == ths)) break;
+                    th_tr = ths;
+                    if (ths < th_max && phs == phs) {
+                        int okf = 1;
+                        for (int i = 0; i < nf && okf; i++) if (!(ths < sh.filt[i][0] || phs < sh.filt[i][1])) okf = 0;
+                        if (okf) {
+                            const int sw = gd < 0 && alpha * pw_gd > o.delta * pw_th, armijo = phs <= phi + o.eta_phi * alpha * gd;
+                            if (th <= th_min && sw) { if (armijo) acc = 1; }
+                            else if (ths <= (1 - o.gamma_theta) * th || phs <= phi - o.gamma_phi * th) {
+                                acc = 1;
+                                if (!(sw && armijo) && nf < QFILT) {
+                                    QPAR(lane) { if (lane == 0) { sh.filt[nf][0] = (1 - o.gamma_theta) * th; sh.filt[nf][1] = phi - o.gamma_phi * th; } }
+                                    SYNC();
+                                    nf++;
+                                }
+                            }
+                        }
+                    }
+                    if (acc) { alpha = asoc; az = azs; dcur = 1 - dcur; }      // the correction is the step: its multiplier steps go with it
+                }
+                if (acc) break;
+                QPAR(lane) { if (lane == 0) sh.inst.d = QDIR(sh, dcur); }      // back to the iteration's own direction
+                SYNC();
             }
             alpha *= 0.5;
         }

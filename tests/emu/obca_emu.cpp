@@ -154,7 +154,7 @@ int emu_dualws(int v, const double *a1, const double *a2, const double *b, const
 struct QScratch { double *z, *d, *as, *rs, *oc; };
 static void q_alloc(int N, QScratch &s, quad::QLay &l) {
     quad::q_make_layout(N, l);
-    s.z = (double *)calloc(l.len, 8); s.d = (double *)calloc(l.n + l.m, 8);
+    s.z = (double *)calloc(l.len, 8); s.d = (double *)calloc(QDIR_DOUBLES(l), 8);      // two direction buffers + the rows of a second-order correction
     s.as = (double *)calloc((size_t)(N + 1) * QSP, 8); s.rs = (double *)calloc((size_t)(N + 1) * QRR, 8);
     s.oc = (double *)calloc((size_t)(N + 1) * QOB * OB_OC, 8);
 }
@@ -166,7 +166,7 @@ static void q_setup(int N, const double *prob, QScratch &s) {
     for (int i = 0; i < QX; i++) { c.x0[i] = prob[QPH_X0 + i]; c.xF[i] = prob[QPH_XF + i]; }
     for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];
     for (int i = 0; i < QOB * QL; i++) sh.ob[i] = prob[QPH_OB + i];
-    quad::q_make_layout(N, sh.l);
+    quad::q_make_layout(N, sh.l); sh.soc_on = 0; sh.inst.d0 = s.d;
 }
 int emu_quad_layout(int N, int *out) { quad::QLay l; quad::q_make_layout(N, l); memcpy(out, &l, sizeof l); return (int)(sizeof l / sizeof(int)); }
 
@@ -180,14 +180,14 @@ int emu_quad_newton(int N, const double *prob, const double *zin, double mu, dou
         for (int i = 0; i < 3; i++) { s.as[(size_t)k * QSP + quad::QR(QSR_F + i * QFC + i)] = 1.0; s.as[(size_t)k * QSP + quad::QR(QSR_F + (6 + i) * QFC + 6 + i)] = 1.0; }
         for (int j = 0; j < QU; j++) s.as[(size_t)k * QSP + quad::QR(QSR_F + (QX + j) * QFC + QX + j)] = 1.0;
     }
-    quad::q_assemble_obs(sh, mu, dw, dc);
-    AsmOut A; quad::q_assemble_stage(sh, mu, dw, dc, A);
+    quad::q_assemble_obs<0>(sh, mu, dw, dc);
+    AsmOut A; quad::q_assemble_stage<0>(sh, mu, dw, dc, A);
     int ok = A.ok;
     StepOut S; S.ap = S.az = S.gd = 0; S.ok = 1;
     int fail = ok ? 0 : 1;
     if (ok) { ok = quad::q_riccati_backward(sh, rho); if (!ok) fail = 2; }
     if (ok) { quad::q_direction_main(sh, A, mu, dw, dc, rho, tau, S); ok = S.ok; if (!ok) fail = 3; }
-    if (ok) quad::q_direction_obs(sh, mu, dw, dc, tau, S);
+    if (ok) quad::q_direction_obs<0>(sh, mu, dw, dc, tau, S);
     aux[10] = fail;
     memcpy(dout, s.d, sizeof(double) * (l.n + l.m));
     aux[0] = A.dinf; aux[1] = A.pinf; aux[2] = A.cinf0; aux[3] = cinf_mu(A, mu); aux[4] = A.f; aux[5] = A.th1; aux[6] = A.bar;
@@ -201,7 +201,7 @@ int emu_quad_solve(int N, const double *prob, const void *opts, double *zout, do
     QScratch s; quad::QLay l; q_alloc(N, s, l);
     quad::QShared &sh = quad::gq_sh;
     sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
-    quad::q_solve_instance(N, *(const Opts *)opts, info);
+    quad::q_solve_instance(N, *(const Opts *)opts, info, ((const OptsAbi *)opts)->max_soc);
     memcpy(zout, s.z, sizeof(double) * l.len);
     q_free(s);
     return 0;
