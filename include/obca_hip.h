@@ -159,8 +159,8 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-pha
 typedef struct obca_quad_batch obca_quad_batch;
 int obca_quadcopter_default_opts(obca_opts *o);
 /* the reference's IPOPT configuration for this call as far as the quadcopter kernel carries it: the defaults above + max_soc = 4 (IPOPT's default second-order
- * correction, A-5.5 .. A-5.9; recalc_y stays off -- QuadcopterSignedDist.jl:29 sets recalc_y = "no").  IPOPT's least-squares initial multipliers are NOT in the
- * quadcopter kernel: opts.lsq_init != 0 (and recalc_y != 0) is refused by the quadcopter entry points rather than ignored. */
+ * correction, A-5.5 .. A-5.9) + lsq_init = 1 (IPOPT's default least-squares initial multipliers, kept if <= 1e3); recalc_y stays off -- QuadcopterSignedDist.jl:29
+ * sets recalc_y = "no", and opts.recalc_y != 0 is refused by the quadcopter entry points rather than ignored. */
 int obca_quadcopter_reference_opts(obca_opts *o);
 int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts /* B */, double R, const double *x0 /* 12 x B */,
                                       const double *xF /* 12 x B */, const double *ob /* 6 x 5 x B */, const double *xWS /* 12 x (N+1) x B */,

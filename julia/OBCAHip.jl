@@ -73,7 +73,7 @@ function ipopt_opts()
     return o
 end
 optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
-"the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (max_soc = 4; recalc_y = \"no\" as QuadcopterSignedDist.jl:29 sets it): default of the quadcopter drop-ins"
+"the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (max_soc = 4, least-squares initial multipliers; recalc_y = \"no\" as QuadcopterSignedDist.jl:29 sets it): default of the quadcopter drop-ins"
 function quadcopter_ipopt_opts()
     o = Opts()
     ccall((:obca_quadcopter_reference_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_quadcopter_reference_opts failed")
@@ -153,7 +153,7 @@ end
 Batched form: x0, xF 12xB; Ts, timeWS vectors of length B; ob 6x5xB (ob1..ob5 of every instance back to back, each
 [xmax,ymax,zmax,-xmin,-ymin,-zmin]); xWS 12x(N+1)xB.  Returns (xp 12x(N+1)xB, up 4xNxB, timeScale (N+1)xB, exitflag B, time, lp 30x(N+1)xB,
 status codes B).  dist=true solves the QuadcopterDist formulation (obca_quadcopter_dist_batch).  opts=nothing: the library's throughput defaults
-(obca_quadcopter_default_opts); `quadcopter_ipopt_opts()`: with IPOPT's second-order correction.
+(obca_quadcopter_default_opts); `quadcopter_ipopt_opts()`: with IPOPT's second-order correction and least-squares initial multipliers.
 """
 function QuadcopterSignedDist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS; dual_ws::Bool=true, dist::Bool=false, opts=nothing)
     B = size(x0, 2)

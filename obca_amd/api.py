@@ -438,8 +438,8 @@ def quadcopter_default_opts():
 
 
 def quadcopter_ipopt_opts():
-    """the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (obca_quadcopter_reference_opts: max_soc = 4; recalc_y = "no" as
-    QuadcopterSignedDist.jl:29 sets it; no least-squares y0): the default of the drop-ins QuadcopterSignedDist / QuadcopterDist"""
+    """the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (obca_quadcopter_reference_opts: max_soc = 4, least-squares
+    initial multipliers; recalc_y = "no" as QuadcopterSignedDist.jl:29 sets it): the default of the drop-ins QuadcopterSignedDist / QuadcopterDist"""
     o = Opts()
     _load().obca_quadcopter_reference_opts(C.byref(o))
     return o

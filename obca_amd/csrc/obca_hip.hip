@@ -183,7 +183,7 @@ struct QDevBufs {
 #ifndef OBCA_QUAD_WAVES_PER_EU
 #define OBCA_QUAD_WAVES_PER_EU 1      // as for the parking kernel
 #endif
-__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc) {
+__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc, int lsq_init) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
     if (threadIdx.x == 0) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_ker
     if (threadIdx.x < 16) quad::gq_sh.prof[threadIdx.x] = 0;
 #endif
     __syncthreads();
-    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8, max_soc);
+    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8, max_soc, lsq_init);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = quad::gq_sh.prof[threadIdx.x];
@@ -869,7 +869,8 @@ int obca_quadcopter_default_opts(obca_opts *o) {
 }
 int obca_quadcopter_reference_opts(obca_opts *o) {
     if (obca_quadcopter_default_opts(o)) return -1;
-    o->max_soc = 4;                                    /* IPOPT default max_soc; recalc_y stays 0: QuadcopterSignedDist.jl:29 sets recalc_y = "no".  (IPOPT's least-squares y0 is not in the quadcopter kernel.) */
+    o->max_soc = 4;                                    /* IPOPT default max_soc; recalc_y stays 0: QuadcopterSignedDist.jl:29 sets recalc_y = "no" */
+    o->lsq_init = 1;                                   /* IPOPT default: least-squares initial multipliers, constr_mult_init_max = 1e3 */
     return 0;
 }
 int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
@@ -905,11 +906,11 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     if (!bt->uploaded) { bt->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
-    if (o.recalc_y != 0 || o.lsq_init != 0) { bt->err = "quadcopter solve: recalc_y / lsq_init are switches of the parking kernels only (obca_hip.h); the quadcopter kernel would ignore them -- refusing instead"; return -1; }
+    if (o.recalc_y != 0) { bt->err = "quadcopter solve: recalc_y is a switch of the parking kernels only (the reference's quadcopter call sets recalc_y = \"no\", QuadcopterSignedDist.jl:29); the quadcopter kernel would ignore it -- refusing instead"; return -1; }
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc, o.lsq_init != 0);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;

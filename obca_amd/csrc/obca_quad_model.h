@@ -135,21 +135,24 @@ struct QObsStats { double dmax, pmax, cmax0, cmin, cmax, sumz, sumy; int bad; };
 struct QObsStep { double dlam[QL], ds, dso, dy[2]; };
 
 // MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp;
-// MODE 2: inertia of the block only (st->bad).  crs: the two rows of a second-order correction in place of the constraint values (IPOPT A-5.7), or nullptr
-template <int MODE>
+// MODE 2: inertia of the block only (st->bad).  crs: the two rows of a second-order correction in place of the constraint values (IPOPT A-5.7), or nullptr.
+// LSQ: the block of the least-squares multiplier system (IPOPT's initial multipliers): unit Hessian on every variable, gradients with the bound multipliers themselves,
+// zero constraint right-hand sides, multipliers taken as zero (call with dw = dc = 0)
+template <int MODE, int LSQ = 0>
 OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, QObsStats *st,
                          const double dp[3], QObsStep *step, const double *crs = nullptr) {
     double cr[2], q[3];
     q_obs_rows(c, in, cr, q);
-    const double rhs0 = crs ? crs[0] : cr[0], rhs1 = crs ? crs[1] : cr[1];      // right-hand side of the two rows: the constraint values, or the rows of a second-order correction
-    const double *y = in.y;
+    const double rhs0 = LSQ ? 0.0 : (crs ? crs[0] : cr[0]), rhs1 = LSQ ? 0.0 : (crs ? crs[1] : cr[1]);      // right-hand side of the two rows: the constraint values, or the rows of a second-order correction
+    const double y0_[2] = {0.0, 0.0};
+    const double *y = LSQ ? y0_ : in.y;
     double g1[QL], g2[QL], Dl[QL], rl[QL];
 #pragma unroll
     for (int i = 0; i < QL; i++) {
         const double sg = i < 3 ? 1.0 : -1.0; const int a = i % 3;
         g1[i] = 2 * sg * q[a]; g2[i] = -in.b[i] + sg * in.p[a];
         const double il = rcp_nr(in.lam[i]), gl = 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
-        rl[i] = gl - mu_b * il; Dl[i] = 2e-4 + in.zl[i] * il + dw;
+        rl[i] = LSQ ? gl - in.zl[i] : gl - mu_b * il; Dl[i] = LSQ ? 1.0 : 2e-4 + in.zl[i] * il + dw;
         if (MODE == 0) {
             double rz = fabs(gl - in.zl[i]); st->dmax = fmax(st->dmax, rz);
             double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -159,8 +162,8 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     const double is = rcp_nr(in.s), iso = rcp_nr(in.so);
     const double gs = 1e2 + 2e3 * in.s + 0.01 * y[1], gso = -y[1];
     // QuadcopterDist has no slack variable: it is frozen (1/D_s = 0, no residual), every term below then drops out and ds = 0
-    const double r_s = c.dist ? 0.0 : gs - mu_b * is, r_so = gso - mu_b * iso;
-    const double iDs = c.dist ? 0.0 : rcp_nr(2e3 + in.zs * is + dw), iDso = rcp_nr(in.zso * iso + dw);
+    const double r_s = c.dist ? 0.0 : (LSQ ? gs - in.zs : gs - mu_b * is), r_so = LSQ ? gso - in.zso : gso - mu_b * iso;
+    const double iDs = c.dist ? 0.0 : (LSQ ? 1.0 : rcp_nr(2e3 + in.zs * is + dw)), iDso = LSQ ? 1.0 : rcp_nr(in.zso * iso + dw);
     if (MODE == 0) {
         double rz = c.dist ? 0.0 : fabs(gs - in.zs); st->dmax = fmax(st->dmax, rz);
         rz = fabs(gso - in.zso); st->dmax = fmax(st->dmax, rz);

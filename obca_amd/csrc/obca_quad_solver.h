@@ -116,7 +116,8 @@ struct QShared {
 #endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
-    int soc_on;                        // the system being solved is a second-order correction's: the terminal right-hand side comes from QCS (the assembly / block phases have variants of their own)
+    int soc_on;                        // 1: the system being solved is a second-order correction's, the terminal right-hand side comes from QCS; 2: the least-squares multiplier system,
+                                       // it is zero (the assembly / block phases have variants of their own)
     int hintl[QNT];                    // per lane: a box block whose inertia was wrong in an earlier assembly (-1: none), see q_block_bad
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
@@ -159,10 +160,11 @@ OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &
 }
 
 // ---------------------------------------------------------------- assemble, part (a): box blocks
-template <int SOC>      // SOC: the system of a second-order correction (constraint right-hand sides from QCS); a variant of its own, so that the option costs the iterations nothing
+template <int RHS>      // RHS = 1: the system of a second-order correction (constraint right-hand sides from QCS); 2: the least-squares multiplier system (q_obs_block<.., LSQ>).
+                        // Variants of their own, so that the options cost the iterations nothing
 OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z, *cs = QCS(sh);
-    constexpr int soc = SOC;
+    constexpr int soc = RHS == 1, LSQ = RHS == 2;
     QPAR(lane) {
         QObsStats st; st.dmax = st.pmax = st.cmax0 = st.sumz = st.sumy = 0; st.cmin = 1e300; st.cmax = -1e300; st.bad = 0;
         double fsl = 0, th = 0, bar = 0; int badit = -1;
@@ -173,7 +175,7 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
             const int bad0 = st.bad;
             double crs[2] = {0, 0};
             if (soc) { crs[0] = cs[QCS_YO(sh) + 2 * it]; crs[1] = cs[QCS_YO(sh) + 2 * it + 1]; }
-            q_obs_block<0>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, soc ? crs : nullptr);
+            q_obs_block<0, LSQ>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, soc ? crs : nullptr);
             if (st.bad && !bad0) badit = it;
             gdbl *o = sh.inst.oc + (size_t)it * OB_OC;
 #pragma unroll
@@ -230,11 +232,11 @@ OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
 }
 
 // ---------------------------------------------------------------- assemble, part (b): stages (writes the non-zeros of the dense record)
-template <int SOC>
+template <int RHS>
 OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmOut &out) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z;
     const double t = z[l.t], tau = t * c.Ts;
-    const gdbl *cs = QCS(sh); constexpr int soc = SOC;
+    const gdbl *cs = QCS(sh); constexpr int soc = RHS == 1, LSQ = RHS == 2;
     double dinf = sh.Ap.dinf, pinf = sh.Ap.pinf, c0 = sh.Ap.cinf0, cmn = sh.Ap.cmin, cmx = sh.Ap.cmax, sumz = sh.Ap.sumz, sumy = sh.Ap.sumy, f = sh.Ap.f,
            th1 = sh.Ap.th1, bar = sh.Ap.bar;
     const int ok = sh.Ap.ok;
@@ -248,10 +250,11 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int i = 0; i < QX; i++) {
                 x[i] = z[l.x + QX * k + i];
                 const double gx = i >= 9 ? 2e-4 * x[i] : 0.0;
-                hz[i] = gx; hb[i] = gx; xd[i] = (i >= 9 ? 2e-4 : 0.0) + dw;
+                hz[i] = gx; hb[i] = gx; xd[i] = LSQ ? 1.0 : (i >= 9 ? 2e-4 : 0.0) + dw;
                 if (i >= 9) lf += 1e-4 * x[i] * x[i];
                 if (k >= 1) {
                     B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmn, lcmx, lsz);
+                    if (LSQ) { b.Sig = 0; b.gb = b.gz; }
                     xd[i] += b.Sig; hz[i] += b.gz; hb[i] += b.gb; bar_mul(i < 6 ? ba : bb, x[i] - q_xlb(i, c.dist), q_xub(i, c.dist) - x[i]);
                 }
             }
@@ -298,7 +301,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int i = 0; i < QX; i++) {
                 const double r = xn[i] - x[i] - tau * g[i];
                 pmax = fmax(pmax, fabs(r)); lth += fabs(r);
-                rec[QR(QSR_F + i * QFC + 16)] = soc ? -csr[i] : -r; rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
+                rec[QR(QSR_F + i * QFC + 16)] = LSQ ? 0.0 : (soc ? -csr[i] : -r); rec[QR(QSR_F + i * QFC + 17)] = c.Ts * g[i];
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) rec[QR(QSR_F + i * QFC + 6 + i)] = tau;
@@ -342,11 +345,12 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #pragma unroll
             for (int j = 0; j < QU; j++) {
                 B2 b = bound2(u[j], Q_ULO, Q_UHI, zLu[j], zUu[j], mu, 1, lc0, lcmn, lcmx, lsz);
+                if (LSQ) { b.Sig = 0; b.gb = b.gz; }
                 bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
                 double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
                 lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
                 if (k >= 1) { const double e = um[j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
-                hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = hu + b.Sig + dw;
+                hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = LSQ ? 1.0 : hu + b.Sig + dw;
                 wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - un[j]) : 0.0;     // copy part living in stage k+1
                 const double tot = hzu[j] + wn[j]; dmax = fmax(dmax, fabs(tot));
             }
@@ -366,7 +370,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 }
 #pragma unroll
             for (int j = 0; j < QU; j++) {
-                const double ww = k >= 1 ? 2e-2 : 0.0;
+                const double ww = (k >= 1 && !LSQ) ? 2e-2 : 0.0;
                 rec[QR(QSR_H + (QX + j) * QZ + (QX + j))] = ww; rec[QR(QSR_H + (QX + j) * QZ + (QS + j))] = -ww; rec[QR(QSR_H + (QS + j) * QZ + (QX + j))] = -ww;
             }
             // gradients / t-columns
@@ -390,13 +394,14 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     SYNC();
     double d0 = 0, d2 = 0;
     B2 b = bound2(t, Q_TLO, Q_THI, z[l.zL + l.t], z[l.zU + l.t], mu, N + 1, d0, cmn, cmx, d2);
+    if (LSQ) b.gb = b.gz;
     c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
     const double gf = (N + 1) * (0.25 + 10 * t);
     gtb += gf + b.gb; gtz += gf + b.gz;
     f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     dinf = fmax(dinf, fabs(gtz));
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
-    out.f = f; out.th1 = th1; out.bar = bar; out.Htt = 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
+    out.f = f; out.th1 = th1; out.bar = bar; out.Htt = LSQ ? (double)(N + 1) : 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;      // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model)
     out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2 - (c.dist ? 1 : 0)) * QOB * (N + 1);
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
 }
@@ -629,7 +634,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         double *S = sh.bord, *col = sh.bord + 169, *colr = col + 13;   // S 12x12 (stride 12)
         PAR64(lane) {
             for (int it = lane; it < 144; it += 64) { int a = it / 12, b_ = it % 12; S[it] = -sh.Bm[(2 + a) * QC + (2 + b_)]; }
-            if (lane < 12) { col[lane] = -sh.Bm[(2 + lane) * QC + 1]; colr[lane] = -((sh.soc_on ? -QCS(sh)[QCS_NU(sh) + lane] : -(z[l.x + QX * N + lane] - c.xF[lane])) - sh.Bm[(2 + lane) * QC + 0]); }
+            if (lane < 12) { col[lane] = -sh.Bm[(2 + lane) * QC + 1]; colr[lane] = -((sh.soc_on == 2 ? 0.0 : (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + lane] : -(z[l.x + QX * N + lane] - c.xF[lane]))) - sh.Bm[(2 + lane) * QC + 0]); }
             if (lane == 0) sh.bord_ok = 1;
         }
         LDS_SYNC();
@@ -849,12 +854,12 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     QPROF(QPF_BS_STAGE);
 }
 
-template <int SOC>
+template <int RHS>
 OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, double tau, StepOut &so) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; const gdbl *z = sh.inst.z; gdbl *d = sh.inst.d;
     double ap = so.ap, az = so.az, gd = so.gd;
     const double dt = sh.coef[1];
-    const gdbl *cs = QCS(sh); constexpr int soc = SOC;
+    const gdbl *cs = QCS(sh); constexpr int soc = RHS == 1, LSQ = RHS == 2;
     QPAR(lane) {
         double lap = 1.0, laz = 1.0, lgd = 0, cc_;
 #define FTBP(val, dv) { cc_ = (dv) < 0 ? -tau * (val) * rcp_nr(dv) : 1e300; if (cc_ < lap) lap = cc_; }
@@ -866,7 +871,7 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
             QObsStep st;
             double crs[2] = {0, 0};
             if (soc) { crs[0] = cs[QCS_YO(sh) + 2 * it]; crs[1] = cs[QCS_YO(sh) + 2 * it + 1]; }
-            q_obs_block<1>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, soc ? crs : nullptr);
+            q_obs_block<1, LSQ>(c, in, mu, dw, dc, nullptr, nullptr, dp, &st, soc ? crs : nullptr);
 #pragma unroll
             for (int i = 0; i < QL; i++) {
                 d[l.lam + QL * it + i] = st.dlam[i];
@@ -1144,6 +1149,20 @@ OBCA_PHASE int qph_block_bad(double mu, double dw, double dc) { const int b = q_
 OBCA_PHASE void qph_assemble_obs(double mu, double dw, double dc) { QPROF(QPF_OTHER); q_assemble_obs<0>(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); }
 OBCA_PHASE void qph_assemble_stage(double mu, double dw, double dc, int second) { QShared &sh = gq_sh; q_assemble_stage<0>(sh, mu, dw, dc, second ? sh.A2 : sh.A); QPROF(QPF_ASM_STAGE); }
 OBCA_FN void qph_assemble(double mu, double dw, double dc, int second) { qph_assemble_obs(mu, dw, dc); qph_assemble_stage(mu, dw, dc, second); }
+OBCA_PHASE void qph_lsq_assemble() { QShared &sh = gq_sh; q_assemble_obs<2>(sh, 0.0, 0.0, 0.0); q_assemble_stage<2>(sh, 0.0, 0.0, 0.0, sh.A); QPROF(QPF_INIT); }
+OBCA_PHASE void qph_lsq_direction_obs(double tau) { QShared &sh = gq_sh; q_direction_obs<2>(sh, 0.0, 0.0, 0.0, tau, sh.S); QPROF(QPF_INIT); }
+// y <- the least-squares estimate in the direction buffer if its largest entry is <= constr_mult_init_max = 1e3 (IPOPT's default), else y stays 0
+OBCA_PHASE void qph_lsq_take() {
+    QShared &sh = gq_sh; const QLay &l = sh.l; gdbl *z = sh.inst.z; const gdbl *d = sh.inst.d;
+    QPAR(lane) { double m_ = 0; for (int i = lane; i < l.m; i += QNT) { const double a = fabs(d[l.n + i]); if (a > m_ || a != a) m_ = a; } sh.red[0][lane] = m_; }
+    SYNC();
+    double ymax = 0;
+    for (int i = 0; i < QNT; i++) { const double a = sh.red[0][i]; if (a > ymax || a != a) ymax = a; }
+    SYNC();
+    if (ymax <= 1e3 && ymax == ymax) { QPAR(lane) { for (int i = lane; i < l.m; i += QNT) z[l.n + i] = d[l.n + i]; } }
+    SYNC();
+    QPROF(QPF_INIT);
+}
 OBCA_PHASE void qph_soc_assemble(double mu, double dw, double dc) { QShared &sh = gq_sh; QPROF(QPF_OTHER); q_assemble_obs<1>(sh, mu, dw, dc); QPROF(QPF_ASM_OBS); q_assemble_stage<1>(sh, mu, dw, dc, sh.A2); QPROF(QPF_ASM_STAGE); }
 OBCA_PHASE int qph_riccati(double rho) { const int ok = q_riccati_backward(gq_sh, rho); QPROF(QPF_RIC); return ok; }
 OBCA_PHASE void qph_direction_main(double mu, double dw, double dc, double rho, double tau) { QShared &sh = gq_sh; q_direction_main(sh, sh.A, mu, dw, dc, rho, tau, sh.S); }
@@ -1154,7 +1173,7 @@ OBCA_PHASE void qph_soc_rows(double a, int first) { q_soc_rows(gq_sh, a, first);
 OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { QPROF(QPF_OTHER); q_apply_step(gq_sh, alpha, ay, az, mu, ks); QPROF(QPF_APPLY); }
 
 // info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
-OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 0) {
+OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 0, int lsq_init = 0) {
     QShared &sh = gq_sh;
     QPAR(lane) {
         if (lane == 0) {
@@ -1176,6 +1195,18 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
     double dc_mu = -1.0, dc_val = 0;
     QPAR(lane) { sh.hintl[lane] = -1; }
     SYNC();
+    if (lsq_init) {      // IPOPT's initial multipliers: the least-squares estimate at the starting point through the same structured solve with the Hessian replaced by the identity
+                         // (at the reference's own start, lambda = 0.05, the system is singular: y stays 0)
+        QPAR(lane) { if (lane == 0) sh.soc_on = 2; }
+        SYNC();
+        qph_lsq_assemble();
+        int a_ = sh.A.ok;
+        if (a_) a_ = qph_riccati(0.0);
+        if (a_) { qph_direction_main(0.0, 0.0, 0.0, 0.0, tau); a_ = sh.S.ok; }
+        if (a_) { qph_lsq_direction_obs(tau); qph_lsq_take(); }
+        QPAR(lane) { if (lane == 0) sh.soc_on = 0; }
+        SYNC();
+    }
     if (qph_min_norm2() < 1e-12) { qph_restore(o.bound_push); nrest++; }      // rank-deficient start (the reference's lambda = 0.05): restoration first
     // where IPOPT would enter its restoration phase (line search or inertia correction failed): block restoration, barrier restart, empty filter
 #define Q_USE_HINTS 1

@@ -260,6 +260,8 @@ typedef struct {
     double (*pv)[NC][NS], (*kf)[NC][NU], (*ds)[NC][NS], (*du)[NC][NU], (*pic)[NC][NXS];
     double dinf, pinf, cinf0, cinfmu, sumy, sumz; int nb, nm;
     const double *csoc;      /* second-order correction: constraint values that replace c(v) on the right-hand side (layout pi | nu | yo), or NULL */
+    int lsq;                 /* least-squares multiplier mode (IPOPT's initial multipliers): Hessian := identity on every primal variable, right-hand side := the gradient of
+                                the Lagrangian with the bound multipliers (z-form) and zero for the constraint rows; call with y = 0, dw = dc = rho = 0 */
 } kkt_t;
 static kkt_t *kkt_alloc(const model_t *M) {
     kkt_t *K = xcalloc(1, sizeof *K); int N1 = M->p->N + 1; K->M = M; K->N = M->p->N;
@@ -290,10 +292,12 @@ static bnd_t bound_terms(const model_t *M, int i, const double *v, const double 
 static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double *zL, const double *zU, double mu, double dw, double dc) {
     const model_t *M = K->M; const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, ok = 1;
     double t = v[l->t], tau = t * p->Ts, c0 = 0, cmu = 0, sumz = 0, sumy = 0, dmax = 0, pmax = 0; int nb = 0, nm = 0;
+    const int lsq = K->lsq;
+#define LSQ_B(b) do { if (lsq) (b).gb = (b).gz; } while (0)      /* least-squares mode: the gradient with the bound multipliers themselves */
     {
-        bnd_t b = bound_terms(M, l->t, v, zL, zU, mu, &c0, &cmu, &sumz, &nb);
+        bnd_t b = bound_terms(M, l->t, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
         double gf = (N + 1) * (0.25 + 10 * t);
-        K->Htt = 10.0 * (N + 1) + b.Sig + dw; K->gt_z = gf + b.gz; K->gt_b = gf + b.gb;
+        K->Htt = lsq ? (double)(N + 1) : 10.0 * (N + 1) + b.Sig + dw;      /* (t stands for the N + 1 timeScale variables of the reference's model: N + 1 unit diagonal entries) */ K->gt_z = gf + b.gz; K->gt_b = gf + b.gb;
     }
     for (int k = 0; k <= N; k++) {
         double (*H)[NZ] = K->H[k]; double *hz = K->hz[k], *hb = K->hb[k], *Ht = K->Ht[k];
@@ -302,8 +306,8 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
         for (int i = 0; i < NXS; i++) {
             double gx = (i >= 9) ? 2e-4 * x[i] : 0, hx = (i >= 9) ? 2e-4 : 0, Sig = 0;
             hz[i] = gx; hb[i] = gx;
-            if (k >= 1) { bnd_t b = bound_terms(M, l->x + NXS * k + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb; }
-            H[i][i] = hx + Sig + dw;
+            if (k >= 1) { bnd_t b = bound_terms(M, l->x + NXS * k + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb; }
+            H[i][i] = lsq ? 1.0 : hx + Sig + dw;
         }
         for (int j = 0; j < NOB; j++) {   /* condense the box block onto the position */
             int bo = k * NOB + j; obs_fact *F = &K->of[bo];
@@ -314,19 +318,19 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
             for (int i = 0; i < NL; i++) {
                 double sg = i < 3 ? 1.0 : -1.0; int a = i % 3;
                 F->g1[i] = 2 * sg * F->q[a]; F->g2[i] = -p->ob[j][i] + sg * x[a];
-                bnd_t b = bound_terms(M, l->lam + NL * bo + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb);
+                bnd_t b = bound_terms(M, l->lam + NL * bo + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
                 double gl = 2e-4 * lam[i] + F->g1[i] * yv[0] + F->g2[i] * yv[1];
                 if (fabs(gl + b.gz) > dmax) dmax = fabs(gl + b.gz);
-                rl_b[i] = gl + b.gb; F->Dl[i] = 2e-4 + b.Sig + dw;
+                rl_b[i] = gl + b.gb; F->Dl[i] = lsq ? 1.0 : 2e-4 + b.Sig + dw;
             }
-            { bnd_t b = bound_terms(M, l->s + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); double gs = 1e2 + 2e3 * s + 0.01 * yv[1];
-              if (!p->dist && fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = 2e3 + b.Sig + dw; }
+            { bnd_t b = bound_terms(M, l->s + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); double gs = 1e2 + 2e3 * s + 0.01 * yv[1];
+              if (!p->dist && fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = lsq ? 1.0 : 2e3 + b.Sig + dw; }
             if (p->dist) { F->r_s = 0; F->Ds = INFINITY; }       /* frozen: every 1/Ds term below vanishes, ds = 0 */
-            { bnd_t b = bound_terms(M, l->so + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); double gs = -yv[1];
-              if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_so = gs + b.gb; F->Dso = b.Sig + dw; }
+            { bnd_t b = bound_terms(M, l->so + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); double gs = -yv[1];
+              if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_so = gs + b.gb; F->Dso = lsq ? 1.0 : b.Sig + dw; }
             /* row 2 after eliminating s and so:  g2'dlam + q'dp - T2 dy2 = r2 */
             F->T2 = 1e-4 / F->Ds + 1.0 / F->Dso + dc; F->iT2 = 1.0 / F->T2;
-            F->r2 = -(K->csoc ? K->csoc[l->yo + 2 * bo + 1] : F->c[1]) + 0.01 * F->r_s / F->Ds - F->r_so / F->Dso;
+            F->r2 = -(lsq ? 0.0 : K->csoc ? K->csoc[l->yo + 2 * bo + 1] : F->c[1]) + 0.01 * F->r_s / F->Ds - F->r_so / F->Dso;
             for (int i = 0; i < 3; i++) { hz[i] += F->q[i] * yv[1]; hb[i] += F->q[i] * yv[1]; }
             double Hb[NL * NL];
             for (int i = 0; i < NL; i++) {
@@ -339,7 +343,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 for (int c_ = 0; c_ < 3; c_++) F->Cp[i][c_] = (c_ == a ? yv[1] * sg : 0.0) + F->g2[i] * F->q[c_] * F->iT2;
                 F->rk[i] = -rl_b[i] + F->g2[i] * F->r2 * F->iT2;
             }
-            F->rk[NL] = -(K->csoc ? K->csoc[l->yo + 2 * bo] : F->c[0]);
+            F->rk[NL] = -(lsq ? 0.0 : K->csoc ? K->csoc[l->yo + 2 * bo] : F->c[0]);
             if (!lamblock_factor(F, Hb, F->g1, dc)) { ok = 0; if (getenv("OBCA_DBG")) fprintf(stderr, "lamblock fail k=%d j=%d\n", k, j); }
             double Z[NL + 1][4];
             for (int c_ = 0; c_ < 4; c_++) { double col[NL + 1]; for (int i = 0; i < NL; i++) col[i] = c_ < 3 ? F->Cp[i][c_] : F->rk[i]; col[NL] = c_ < 3 ? 0 : F->rk[NL];
@@ -353,11 +357,11 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
         if (k == N) { for (int i = 0; i < NXS; i++) { double e = fabs(x[i] - p->xF[i]); if (e > pmax) pmax = e; } continue; }
         const double *u = v + l->u + NU * k;
         for (int j = 0; j < NU; j++) {
-            bnd_t b = bound_terms(M, l->u + NU * k + j, v, zL, zU, mu, &c0, &cmu, &sumz, &nb);
+            bnd_t b = bound_terms(M, l->u + NU * k + j, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
             double gu = -2e-3 * (p->wH - u[j]), hu = 2e-3;
             if (k >= 1) { double e = u[j - NU] - u[j]; gu += -2e-2 * e; hu += 2e-2; hz[NXS + j] += 2e-2 * e; hb[NXS + j] += 2e-2 * e;
-                H[NXS + j][NXS + j] += 2e-2; H[NXS + j][NS + j] += -2e-2; H[NS + j][NXS + j] += -2e-2; }
-            hz[NS + j] += gu + b.gz; hb[NS + j] += gu + b.gb; H[NS + j][NS + j] += hu + b.Sig + dw;
+                if (!lsq) { H[NXS + j][NXS + j] += 2e-2; H[NXS + j][NS + j] += -2e-2; H[NS + j][NXS + j] += -2e-2; } }
+            hz[NS + j] += gu + b.gz; hb[NS + j] += gu + b.gb; H[NS + j][NS + j] += lsq ? 1.0 : hu + b.Sig + dw;
         }
         {   /* dynamics x+ - x - t Ts g(x,u) = 0 with multiplier pi_k */
             double g[NXS], dg[NXS][NV], HG[NV][NV]; const double *pi = y + l->pi + NXS * k;
@@ -369,7 +373,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 for (int c_ = 0; c_ < NV; c_++) { int id = VIDX[c_]; if (id < NXS) K->A[k][i][id] += tau * dg[i][c_]; else K->B[k][i][id - NS] += tau * dg[i][c_]; }
                 K->Ft[k][i] = p->Ts * g[i];
                 double r = v[l->x + NXS * (k + 1) + i] - x[i] - tau * g[i];
-                K->dd[k][i] = -(K->csoc ? K->csoc[l->pi + NXS * k + i] : r); if (fabs(r) > pmax) pmax = fabs(r); sumy += fabs(pi[i]);
+                K->dd[k][i] = -(lsq ? 0.0 : K->csoc ? K->csoc[l->pi + NXS * k + i] : r); if (fabs(r) > pmax) pmax = fabs(r); sumy += fabs(pi[i]);
             }
             nm += NXS;
             /* Lagrangian Hessian of -pi'(t Ts g): -tau sum pi_i Hess g_i on the local variables; cross terms with t: -Ts pi'dg */
@@ -382,6 +386,7 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
         }
     }
     for (int i = 0; i < NXS; i++) sumy += fabs(y[l->nu + i]);
+#undef LSQ_B
     K->pinf = pmax; K->cinf0 = c0; K->cinfmu = cmu; K->sumz = sumz; K->sumy = sumy; K->nb = nb; K->nm = nm + NXS; K->dinf = dmax;
     return ok;
 }
@@ -415,7 +420,7 @@ static int kkt_solve(kkt_t *K, const double *v, double dc, double rho, double *d
     double e[NXS];
     memset(K->P[N], 0, sizeof K->P[N]); memset(K->pv[N], 0, sizeof K->pv[N]);
     for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) K->P[N][i][j] = K->H[N][i][j];
-    for (int i = 0; i < NXS; i++) { e[i] = -(K->csoc ? K->csoc[l->nu + i] : v[l->x + NXS * N + i] - p->xF[i]); K->P[N][i][i] += rho; }
+    for (int i = 0; i < NXS; i++) { e[i] = -(K->lsq ? 0.0 : K->csoc ? K->csoc[l->nu + i] : v[l->x + NXS * N + i] - p->xF[i]); K->P[N][i][i] += rho; }
     for (int i = 0; i < NS; i++) { K->pv[N][0][i] = K->hb[N][i]; K->pv[N][1][i] = K->Ht[N][i]; }
     for (int i = 0; i < NXS; i++) { K->pv[N][0][i] -= rho * e[i]; K->pv[N][2 + i][i] = 1.0; }
     for (int k = N - 1; k >= 0; k--) {
@@ -612,6 +617,15 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
     eval_f_theta(M, v, &f, &th, &thinf);
     double th_min = 1e-4 * fmax(1, th), th_max = 1e4 * fmax(1, th);
     int it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0; double last_pinf = 0, last_dinf = 0;
+    if (o->lsq_init) {      /* IPOPT's initial multipliers: least-squares estimate at the starting point, kept if its largest entry is <= constr_mult_init_max = 1e3 (else y = 0);
+                               the same structured solve with the Hessian replaced by the identity.  (At the reference's own start, lambda = 0.05, the system is singular: y stays 0.) */
+        K->lsq = 1;
+        int a = kkt_assemble(K, v, y, zL, zU, 0.0, 0, 0); stage_dual_inf(K, y);
+        if (a) a = kkt_solve(K, v, 0.0, 0.0, dv, dy);
+        K->lsq = 0;
+        if (a) { double ymax = 0; for (int i = 0; i < m; i++) { double q = fabs(dy[i]); if (q > ymax || q != q) ymax = q; }
+                 if (ymax <= 1e3 && ymax == ymax) memcpy(y, dy, sizeof(double) * m); }
+    }
     if (min_norm2(M, v) < 1e-12) {      /* rank-deficient start (the reference's lambda = 0.05): restoration before the first iteration */
         restore_blocks(M, o, v, y, zL); nrest++;
         eval_f_theta(M, v, &f, &th, &thinf); th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th);
@@ -829,6 +843,18 @@ int obca_oracle_quadcopter_signed_dist_full(int N, double Ts, double R, const do
 }
 
 /* test hook: one regularised Newton direction at a full primal-dual point */
+/* the least-squares multiplier estimate at (v, zL, zU) (what lsq_init takes): tests pin it against a dense least-squares solve on the autograd Jacobian */
+int obca_oracle_quad_lsq_multipliers(int N, double Ts, double R, const double *x0, const double *xF, const double *ob, const double *v,
+                                     const double *zL, const double *zU, double *yls, int dist) {
+    prob_t p; model_t M; setup_prob(&p, N, Ts, R, x0, xF, ob, dist); model_init(&M, &p);
+    kkt_t *K = kkt_alloc(&M); const lay_t *l = &M.l;
+    double *y0 = xcalloc(l->m, 8), *dv = xcalloc(l->n, 8);
+    K->lsq = 1;
+    int ok = kkt_assemble(K, v, y0, zL, zU, 0.0, 0, 0); stage_dual_inf(K, y0);
+    if (ok) ok = kkt_solve(K, v, 0.0, 0.0, dv, yls);
+    free(y0); free(dv); kkt_free(K); model_free(&M);
+    return ok;
+}
 int obca_oracle_quad_newton(int N, double Ts, double R, const double *x0, const double *xF, const double *ob, const double *v,
                             const double *y, const double *zL, const double *zU, double mu, double dw, double dc, double rho,
                             double *dv, double *dy, double *errs, int dist) {

@@ -85,6 +85,15 @@ def quadcopter_dist(x0, xF, N, Ts, R, ob, xWS, timeWS=1.0, opts=None, dual_ws=1)
     return quadcopter_signed_dist(x0, xF, N, Ts, R, ob, xWS, timeWS, opts, dual_ws, dist=1)
 
 
+def lsq_multipliers(N, Ts, R, x0, xF, ob, v, zL, zU, dist=0):
+    """(ok, y_ls): the least-squares multiplier estimate the option lsq_init starts from"""
+    a = [_d(q) for q in (x0, xF, np.reshape(ob, (5, 6)), v, zL, zU)]
+    yls = np.zeros(layout(N)["m"])
+    ok = lib().obca_oracle_quad_lsq_multipliers(C.c_int(N), C.c_double(Ts), C.c_double(R), a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], a[5][1],
+                                                yls.ctypes.data_as(_D), C.c_int(int(dist)))
+    return ok, yls
+
+
 def newton(N, Ts, R, x0, xF, ob, v, y, zL, zU, mu, dw, dc, rho=1e3, dist=0):
     a = [_d(q) for q in (x0, xF, np.reshape(ob, (5, 6)), v, y, zL, zU)]
     L = layout(N)

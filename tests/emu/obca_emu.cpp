@@ -201,7 +201,7 @@ int emu_quad_solve(int N, const double *prob, const void *opts, double *zout, do
     QScratch s; quad::QLay l; q_alloc(N, s, l);
     quad::QShared &sh = quad::gq_sh;
     sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
-    quad::q_solve_instance(N, *(const Opts *)opts, info, ((const OptsAbi *)opts)->max_soc);
+    quad::q_solve_instance(N, *(const Opts *)opts, info, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->lsq_init);
     memcpy(zout, s.z, sizeof(double) * l.len);
     q_free(s);
     return 0;

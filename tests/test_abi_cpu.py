@@ -43,7 +43,7 @@ def test_opts_struct_matches_and_defaults(lib):
             assert getattr(o, n) == getattr(oo, n), n      # every option exists under the same name in the checker
     assert o.max_soc == 0 and o.recalc_y == 0 and o.lsq_init == 0 and o.reserved_ == 0
     q = Opts(); assert lib.obca_quadcopter_reference_opts(C.byref(q)) == 0
-    assert q.max_soc == 4 and q.recalc_y == 0 and q.lsq_init == 0 and q.max_iter == 3000 and q.dw_min == 1e-10      # QuadcopterSignedDist.jl:28-31 + IPOPT's default max_soc
+    assert q.max_soc == 4 and q.recalc_y == 0 and q.lsq_init == 1 and q.max_iter == 3000 and q.dw_min == 1e-10      # QuadcopterSignedDist.jl:28-31 (recalc_y = "no") + IPOPT's defaults max_soc, least-squares y0
 
 
 def test_no_cpu_fallback_without_gpu():

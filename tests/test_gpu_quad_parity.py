@@ -26,7 +26,7 @@ def test_quad_shipped_scenario_matches_oracle(Q):
     assert np.array_equal(xWS, Q.warm_start(Q.X0, Q.XF, N, S.QUAD_VIA)) and np.array_equal(S.QUAD_OB, Q.OB_CLAMPED)
     ob = S.QUAD_OB
     xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterSignedDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *ob, xWS, np.zeros((N, 4)), 1.0)
-    oo = Q.default_opts(); oo.max_soc = 4            # the drop-in runs the reference's IPOPT configuration (obca_quadcopter_reference_opts): so does the checker
+    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1            # the drop-in runs the reference's IPOPT configuration (obca_quadcopter_reference_opts): so does the checker
     r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, ob, xWS, 1.0, opts=oo)
     assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
     assert xp.shape == (12, N + 1) and up.shape == (4, N) and lp.shape == (30, N + 1) and ts.shape == (N + 1,)
@@ -79,7 +79,7 @@ def test_quadcopter_dist_variant_matches_oracle(Q):
     N = 60; Ts = S.quad_sample_time(N)
     xWS = S.quad_warm_start(S.QUAD_X0, S.QUAD_XF, N)
     xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *S.QUAD_OB, xWS, None, 1.0)
-    oo = Q.default_opts(); oo.max_soc = 4            # the drop-in's default option set
+    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1            # the drop-in's default option set
     r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, S.QUAD_OB, xWS, 1.0, opts=oo)
     assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
     assert np.abs(xp - r["xp"]).max() < 1e-5 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(ts - r["timeScale"]).max() < 1e-8
@@ -102,7 +102,7 @@ def test_reference_main_call_runs_as_is(Q):
     assert np.array_equal(path[0], S.QUAD_X0[:3]) and np.array_equal(path[-1], S.QUAD_XF[:3])
     for fn, orc in ((obca_amd.QuadcopterDist, Q.quadcopter_dist), (obca_amd.QuadcopterSignedDist, Q.quadcopter_signed_dist)):
         xp, up, ts, ef, t, lp, status = fn(S.QUAD_X0, S.QUAD_XF, N_as, Ts_as, S.QUAD_R, *S.QUAD_OB, xWS, 0.5 * np.ones((N_as, 4)), 1, dual_ws=False)
-        oo = Q.default_opts(); oo.max_soc = 4        # the drop-ins' default option set (IPOPT's second-order correction on)
+        oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1        # the drop-ins' default option set (IPOPT's second-order correction and least-squares y0 on)
         r = orc(Q.X0, Q.XF, N_as, Ts_as, Q.EGO_R, S.QUAD_OB, xWS, 1.0, opts=oo, dual_ws=0)
         assert ef == 1 and r["exitflag"] == 1 and status == "Optimal", (fn.__name__, ef, status)
         assert xp.shape == (12, N_as + 1) and up.shape == (4, N_as) and lp.shape == (30, N_as + 1)
@@ -180,11 +180,11 @@ def test_all_1024_quadcopter_bench_instances_match_oracle(Q):
 
 
 @pytest.mark.timeout(900)
-def test_quadcopter_second_order_correction_matches_oracle_option(Q):
-    """opts.max_soc = 4 (IPOPT's default second-order correction, the option set of obca_quadcopter_reference_opts) in the quadcopter kernel against the oracle
-    run with the same option, on 256 instances of the config-4 distribution: the same bar as the default option set (exit flags equal; same counts -> tight
-    agreement; a branch flipped by round-off -> the same optimum); the option changes the path of most instances (fewer iterations in total) and the kernel
-    still refuses the two switches it does not carry"""
+def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
+    """obca_quadcopter_reference_opts (IPOPT's defaults the reference's call runs with: max_soc = 4, least-squares initial multipliers; recalc_y = "no") in the
+    quadcopter kernel against the oracle run with the same options, on 256 instances of the config-4 distribution: the same bar as the default option set (exit
+    flags equal; same counts -> tight agreement; a branch flipped by round-off -> the same optimum); the options change the path of most instances, each of them
+    alone too, and the kernel still refuses the switch it does not carry"""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import obca_amd, oracle_pool
@@ -192,10 +192,10 @@ def test_quadcopter_second_order_correction_matches_oracle_option(Q):
     B, N = 256, 60
     bt = S.make_quad_batch(B, N, random_endpoints=True)
     o = obca_amd.quadcopter_ipopt_opts()
-    assert o.max_soc == 4 and o.recalc_y == 0 and o.lsq_init == 0 and o.max_iter == 3000
+    assert o.max_soc == 4 and o.recalc_y == 0 and o.lsq_init == 1 and o.max_iter == 3000
     base = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
     out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=o)
-    ref = oracle_pool.quad_oracle_all(bt, max_soc=4)
+    ref = oracle_pool.quad_oracle_all(bt, max_soc=4, lsq_init=1)
     flips = 0
     for (i, ef, it, nreg, obj, up, t) in ref:
         assert out["exitflag"][i] == ef, (i, out["exitflag"][i], ef)
@@ -210,9 +210,17 @@ def test_quadcopter_second_order_correction_matches_oracle_option(Q):
             assert df < 1e-4, (i, df)
     assert flips <= 0.03 * B, flips
     assert (out["exitflag"] == 1).mean() > 0.99
-    assert (out["iters"] != base["iters"]).mean() > 0.5 and out["iters"].sum() < base["iters"].sum()      # the correction is exercised, and does what it is for
-    print("quadcopter max_soc = 4 vs oracle option: %d / %d instances on another branch; iterations %d -> %d" % (flips, B, base["iters"].sum(), out["iters"].sum()))
-    for field in ("recalc_y", "lsq_init"):
-        bad = obca_amd.quadcopter_ipopt_opts(); setattr(bad, field, 1)
-        with pytest.raises(obca_amd.ObcaError):
-            obca_amd.quadcopter_signed_dist_batch(bt["x0"][:2], bt["xF"][:2], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][:2], bt["timeWS"], opts=bad)
+    assert (out["iters"] != base["iters"]).mean() > 0.5      # the options are exercised
+    print("quadcopter IPOPT configuration vs oracle options: %d / %d instances on another branch; iterations %d -> %d" % (flips, B, base["iters"].sum(), out["iters"].sum()))
+    n = 64      # each switch alone, against the oracle with that switch alone
+    for (msoc, lsq) in ((4, 0), (0, 1)):
+        o1 = obca_amd.quadcopter_default_opts(); o1.max_soc = msoc; o1.lsq_init = lsq
+        sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == B else v) for k, v in bt.items()}
+        o1out = obca_amd.quadcopter_signed_dist_batch(sub["x0"], sub["xF"], N, bt["Ts"], bt["R"], bt["ob"], sub["xWS"], bt["timeWS"], opts=o1)
+        r1 = oracle_pool.quad_oracle_all(sub, max_soc=msoc, lsq_init=lsq)
+        same = sum(int(o1out["exitflag"][i] == ef and o1out["iters"][i] == it and o1out["info"][i, 6] == nreg) for (i, ef, it, nreg, obj, up, t) in r1)
+        assert all(o1out["exitflag"][i] == ef for (i, ef, *_r) in r1) and same >= n - 3, (msoc, lsq, same)
+        assert (o1out["iters"] != base["iters"][:n]).mean() > 0.3, (msoc, lsq)
+    bad = obca_amd.quadcopter_ipopt_opts(); bad.recalc_y = 1
+    with pytest.raises(obca_amd.ObcaError):
+        obca_amd.quadcopter_signed_dist_batch(bt["x0"][:2], bt["xF"][:2], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][:2], bt["timeWS"], opts=bad)

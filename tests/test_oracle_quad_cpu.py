@@ -142,3 +142,42 @@ def test_quadcopter_second_order_correction_option():
     assert all(r["exitflag"] == 1 for r in base + soc)
     assert sum(r["iters"] for r in soc) < sum(r["iters"] for r in base)
     assert all(abs(a["obj"] - b["obj"]) <= 2e-3 * max(1.0, abs(a["obj"])) for a, b in zip(base, soc))
+
+
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+def test_quad_least_squares_multipliers_vs_dense_autograd(Q, dist):
+    """opts.lsq_init: IPOPT's initial multipliers = the least-squares estimate  [I J'; J 0] [w; y] = -[grad f - zL + zU; 0]  (identity on every primal variable of the
+    reference's model: the N + 1 timeScale variables the solver carries as one t contribute N + 1 to its diagonal entry).  The oracle's structured solve against a
+    dense solve on the autograd Jacobian; and the option changes the path of a solve, not its optimum"""
+    pytest.importorskip("torch")
+    from nlp_ref_quad import QuadNLP
+    rng = np.random.default_rng(3)
+    N, Ts, R, ob = 7, 0.3, 0.25, Q.OB_CLAMPED
+    x0 = Q.X0.copy(); x0[9:12] = [0.1, -0.2, 0.15]
+    nlp = QuadNLP(x0, Q.XF, N, Ts, R, ob, dist=bool(dist)); L = Q.layout(N); n, m = L["n"], L["m"]
+    xWS = Q.warm_start(x0, Q.XF, N)
+    v = np.zeros(n)
+    X = xWS.copy(); X[1:] += 0.05 * rng.standard_normal((N, 12)); X[1:, 3:6] = 0.1 * rng.standard_normal((N, 3)); X[0] = x0
+    v[L["x"]:L["x"] + 12 * (N + 1)] = X.reshape(-1)
+    v[L["u"]:L["u"] + 4 * N] = rng.uniform(3, 6, 4 * N); v[L["t"]] = 1.1
+    for k, cnt in (("lam", 30), ("s", 5), ("so", 5)):
+        v[L[k]:L[k] + cnt * (N + 1)] = rng.uniform(0.1, 1, cnt * (N + 1))
+    zL = rng.uniform(0.1, 2, n); zU = rng.uniform(0.1, 2, n)
+    ok, yls = Q.lsq_multipliers(N, Ts, R, x0, Q.XF, ob, v, zL, zU, dist=dist)
+    assert ok == 1
+    vv = v[12:]; zLr = zL[12:].copy(); zUr = zU[12:].copy()
+    f, g, c, J, H = nlp.eval_all(vv, np.zeros(m))
+    zLr[~np.isfinite(nlp.lb)] = 0; zUr[~np.isfinite(nlp.ub)] = 0
+    gz = g - nlp.mult * zLr + nlp.mult * zUr
+    K = np.block([[np.diag(nlp.mult.astype(float)), J.T], [J, np.zeros((m, m))]])
+    sol = np.linalg.solve(K, -np.concatenate([gz, np.zeros(m)]))
+    assert np.abs(yls - sol[nlp.n:]).max() < 1e-10 * max(1.0, np.abs(sol[nlp.n:]).max())
+    if not dist:
+        o = Q.default_opts(); o.lsq_init = 1
+        xw = Q.warm_start(Q.X0, Q.XF, 16, [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)])
+        a = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0)
+        b = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0, opts=o)
+        assert a["exitflag"] == 1 and b["exitflag"] == 1 and a["iters"] != b["iters"] and abs(a["obj"] - b["obj"]) < 1e-3 * abs(a["obj"])
+        r0 = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0, opts=o, dual_ws=0)      # the reference's own start: singular system, y stays 0
+        r1 = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0, dual_ws=0)
+        assert r0["exitflag"] == 1 and r0["iters"] == r1["iters"] and r0["obj"] == r1["obj"]
