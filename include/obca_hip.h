@@ -67,14 +67,15 @@ typedef struct obca_batch obca_batch;
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
  * throughput entry points the one that is a quarter cheaper; every bench line reports both.
  * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, gradient-based NLP scaling (half-space rows enter with
- * unit length instead), the watchdog.  The quadcopter kernel has none of the three switches: its entry points refuse options that set them.  DESIGN.md section 2. */
+ * unit length instead), the watchdog.  The quadcopter kernel carries max_soc and lsq_init (obca_quadcopter_reference_opts; its reference call sets recalc_y = "no",
+ * and its entry points refuse an option record that sets recalc_y).  DESIGN.md sections 2, 9. */
 typedef struct obca_opts {
     double tol; int max_iter;
     double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
     double dw_min, dw0, dw_max, kw_inc0, kw_inc, kw_dec, dc_bar, kappa_c;
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
-    int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off (obca_default_opts), 4 in obca_reference_opts; parking kernels only */
+    int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc; its default is 4): 0 = off (obca_default_opts), 4 in obca_reference_opts / obca_quadcopter_reference_opts */
     int recalc_y;     /* 1: recalc_y = "yes" as the reference sets it (ParkingSignedDist.jl:41; recalc_y_feas_tol 1e-6): least-squares equality multipliers whenever the
                          iterate's constraint violation is below 1e-6; 0 = off, the default of obca_default_opts; parking kernels only */
     int lsq_init;     /* 1: IPOPT's initial equality multipliers -- the least-squares estimate at the starting point, kept if its max-norm is <= constr_mult_init_max = 1e3;

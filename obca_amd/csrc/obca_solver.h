@@ -859,7 +859,7 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu_, double dw_, d
         sumz += (N + 1) * (fabs(ztL) + fabs(ztU));
         nb += 2 * (N + 1);
         double gf = (N + 1) * (0.5 + 2 * t);
-        Htt += LSQ ? 1.0 : 2.0 * (N + 1) + b.Sig + dw;
+        Htt += LSQ ? (double)(N + 1) : 2.0 * (N + 1) + b.Sig + dw;      // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model, N + 1 unit diagonal entries)
         gtb += gf + (LSQ ? b.gz : b.gb); gtz += gf + b.gz;
         f += (N + 1) * (0.5 * t + t * t);
         bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));

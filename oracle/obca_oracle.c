@@ -394,7 +394,7 @@ static int kkt_assemble(kkt_t *K, const double *z, double mu, double dw, double 
         bound2(t, TL, TU, z[l->ztL], z[l->ztU], mu, N + 1, &Sig, &gz, &gb, &cmax, &sumz, lsq);
         nb += 2 * (N + 1); sumz += N * (fabs(z[l->ztL]) + fabs(z[l->ztU]));
         double gf = (N + 1) * (0.5 + 2 * t);
-        K->Htt = lsq ? 1.0 : (2.0 * (N + 1) + Sig + dw);
+        K->Htt = lsq ? (double)(N + 1) : (2.0 * (N + 1) + Sig + dw);      /* (least-squares system: t stands for the N + 1 timeScale variables of the reference's model: N + 1 unit diagonal entries) */
         K->gt_z = gf + gz; K->gt_b = gf + gb;
     } else K->Htt = 1.0;
     for (int k = 0; k <= N; k++) {

@@ -192,7 +192,7 @@ def test_newton_direction_vs_dense_autograd(oracle, emu, backwards, dist):
 
 @pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
 def test_least_squares_multipliers_vs_dense_autograd(oracle, emu, backwards, dist):
-    """recalc_y / lsq_init: the least-squares multiplier estimate through the structured solve (unit Hessian on every variable, z-form gradients, zero constraint right-hand
+    """recalc_y / lsq_init: the least-squares multiplier estimate through the structured solve (unit Hessian on every variable of the reference's model, z-form gradients, zero constraint right-hand
     side) == the dense solve of [I J'; J 0](w, y) = (-(grad f - zL + zU), 0) with autograd derivatives -- for the oracle AND for the kernels' phases (host emulation), at a random
     interior point far from a solution"""
     torch = pytest.importorskip("torch")
@@ -236,7 +236,7 @@ def test_least_squares_multipliers_vs_dense_autograd(oracle, emu, backwards, dis
     zL[nlp.isl] = z[L["zs1"]:L["zs1"] + nOb * (N + 1)]
     zL[nlp.iss] = z[L["zssL"]:L["zssL"] + N]; zU[nlp.iss] = z[L["zssU"]:L["zssU"] + N]
     IL = np.isfinite(nlp.lb); IU = np.isfinite(nlp.ub); zL[~IL] = 0; zU[~IU] = 0
-    K = np.block([[np.eye(n), J.T], [J, np.zeros((m, m))]])
+    K = np.block([[np.diag(nlp.mult.astype(float)), J.T], [J, np.zeros((m, m))]])      # identity on every variable of the reference's model: its N + 1 timeScale variables are one t here
     sol = np.linalg.solve(K, -np.concatenate([g - nlp.mult * zL + nlp.mult * zU, np.zeros(m)]))       # y_new = sol[n:] (absolute); the structured solves return y_new - y
     ok, d = oracle.lsq_multipliers(N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, 0, x0, sc["xF"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], z, dist=dist)
     assert ok == 1
