@@ -344,10 +344,11 @@ def ipopt_options_leg(cfg, rows, shared, B, N, nS, local, steps, out_default):
     """the SAME batch solved with the reference's IPOPT configuration switched on (max_soc = 4, recalc_y = "yes", least-squares initial multipliers: obca_amd.ipopt_opts(),
     ParkingSignedDist.jl:41-43 + IPOPT defaults): pipelined rate, iterations / passes, and how many instances end somewhere else than with the default options"""
     import obca_amd
-    o = obca_amd.ipopt_opts()
+    quad = CONFIGS[cfg]["kind"] == "quad"      # (the quadcopter call: obca_quadcopter_reference_opts -- max_soc = 4, least-squares y0; QuadcopterSignedDist.jl:29 sets recalc_y = "no")
+    o = obca_amd.quadcopter_ipopt_opts() if quad else obca_amd.ipopt_opts()
     bs = device_batches(cfg, rows, shared, B, N, nS, local)
     dt = pipelined_rate(bs, steps, nS, opts=o)
-    bs[0].solve(opts=o, sync=True); k_ms = float(bs[0].kernel_ms()[0])
+    bs[0].solve(opts=o, sync=True); k_ms = bs[0].kernel_ms(); k_ms = float(k_ms if quad else k_ms[0])
     out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
     for bq in bs:
         bq.close()
@@ -357,7 +358,7 @@ def ipopt_options_leg(cfg, rows, shared, B, N, nS, local, steps, out_default):
     df = np.abs(out["obj"] - out_default["obj"]) / np.maximum(1.0, np.abs(out_default["obj"]))
     dts = np.abs(out["timeScale"][:, 0] - out_default["timeScale"][:, 0])
     differs = both & ((dx > 1e-3) | (du > 1e-3) | (df > 1e-4) | (dts > 1e-4))
-    return dict(options="max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+    return dict(options="max_soc = 4, recalc_y = no, lsq_init = 1 (obca_amd.quadcopter_ipopt_opts())" if quad else "max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                 validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
                 mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3),
                 exitflag_differs_from_default=int((out["exitflag"] != out_default["exitflag"]).sum()), iterations_differ_from_default=int((out["info"][:, 1] != out_default["info"][:, 1]).sum()),
@@ -574,7 +575,7 @@ def main():
     outs = [bq.download() for bq in batches[:min(nS, a.steps + a.warmup)]]
     out = outs[0]
     ipopt_leg = None; others = None
-    if rank == 0 and world == 1 and not quad and not a.no_ipopt_leg and not a.ipopt_options:
+    if rank == 0 and world == 1 and not a.no_ipopt_leg and not a.ipopt_options:
         ipopt_leg = ipopt_options_leg(cfg, rows, shared, B, N, nS, local, max(8, min(a.steps, 40)), out)
     if rank == 0 and world == 1 and cfg == 2 and not a.no_other_configs:
         others = [other_config_line(c_, local) for c_ in (4, 5)]

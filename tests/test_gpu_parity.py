@@ -642,7 +642,7 @@ def test_instances_at_the_obstacle_and_row_limits(OA, oracle):
 def test_hip_path_lands_on_the_unreformulated_dense_solution_at_N80(OA):
     """tests/golden/dense_N80.npz: the reference's NLP as JuMP hands it to IPOPT (N + 1 time-scale variables, x[:, 1] == x0 kept, bounds as rows with slacks, unnormalised rows with
     gradient-based scaling), solved at N = 80 by a dense Algorithm A that shares nothing with the kernels' structure (oracle/ipm_ref80.py).  The HIP path -- with the reference's
-    IPOPT configuration and with the throughput defaults -- must land on that solution (1e-6); iteration counts are reported, not asserted (tests/test_pin_cpu.py holds the C
+    IPOPT configuration and with the throughput defaults -- must land on that solution (1e-6; the parallel-parking instances at the path's stated 1e-3, all but one); iteration counts are reported, not asserted (tests/test_pin_cpu.py holds the C
     oracle to the same fixture)."""
     g = golden("dense_N80.npz")
     n = len(g["tag"]); N = int(g["N"]); assert n >= 8
@@ -659,8 +659,9 @@ def test_hip_path_lands_on_the_unreformulated_dense_solution_at_N80(OA):
         for name, o in (("reference IPOPT configuration", OA.ipopt_opts()), ("throughput defaults", OA.default_opts())):
             out = OA.parking_signed_dist_batch(g["x0"][idx], g["xF"][idx], N, g["Ts"][idx], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
                                                xWS, g["uWS"][idx], opts=o)
-            same = [bool(out["exitflag"][k] == 1 and np.abs(out["xp"][k] - g["xp"][i]).max() < 1e-6 and np.abs(out["up"][k] - g["up"][i]).max() < 1e-6
-                         and abs(out["timeScale"][k, 0] - g["ts"][i][0]) < 1e-8) for k, i in enumerate(idx)]
+            tx, tt = (1e-3, 1e-4) if tag == "cfg3" else (1e-6, 1e-8)      # config 3 is flat around its solutions: two solves that stop at tol = 1e-5 sit 1e-6 .. 1e-4 apart (tests/test_pin_cpu.py): the path's stated tolerance
+            same = [bool(out["exitflag"][k] == 1 and np.abs(out["xp"][k] - g["xp"][i]).max() < tx and np.abs(out["up"][k] - g["up"][i]).max() < tx
+                         and abs(out["timeScale"][k, 0] - g["ts"][i][0]) < tt) for k, i in enumerate(idx)]
             print("%s, %s: HIP iterations %s, dense iterations %s, same point %s" % (tag, name, out["iters"].tolist(), [int(g["iters"][i]) for i in idx], same))
             if tag in ("cfg2", "cfg5"):
                 assert all(same), (tag, name, same)

@@ -24,7 +24,7 @@ timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/benc
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2> $O/bench_driver_line.err; cut -c1-160 $O/bench_driver_line.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sync -o t -- python $R/bench.py --steps 8 --warmup 2 --streams 1 --sync-steps 4 --no-cpu-baseline --no-pmc --no-host-rate --no-distinct --no-ipopt-leg --no-other-configs > $O/bench_sync_under_rocprof.json 2> $O/stats_sync.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_quad -o t -- python $R/bench.py --config 4 --steps 4 --warmup 1 --streams 1 --sync-steps 2 --no-cpu-baseline --no-pmc --no-host-rate > $O/bench_quad_sync_under_rocprof.json 2> $O/stats_quad.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_quad -o t -- python $R/bench.py --config 4 --steps 4 --warmup 1 --streams 1 --sync-steps 2 --no-cpu-baseline --no-pmc --no-host-rate --no-ipopt-leg > $O/bench_quad_sync_under_rocprof.json 2> $O/stats_quad.err
 for K in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $K --kernel-trace --output-format csv -d $O/pmc_cfg2 -o $K -- python $R/bench.py --pmc-child > /dev/null 2> $O/pmc_cfg2_$K.err
   timeout 300 rocprofv3 --pmc $K --kernel-trace --output-format csv -d $O/pmc_cfg4 -o $K -- python $R/bench.py --config 4 --pmc-child > /dev/null 2> $O/pmc_cfg4_$K.err
@@ -32,6 +32,8 @@ done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_quad_mfma -o mfma -- python $R/bench.py --config 4 --pmc-child > /dev/null 2> $O/pmc_quad_mfma.err
 cd $R
 timeout 600 bash tools/pmc_sq.sh 1024 > $O/pmc_sq.txt 2>&1; tail -22 $O/pmc_sq.txt
+timeout 300 bash tools/pmc_ifetch.sh 1024 > $O/pmc_ifetch.txt 2>&1; tail -16 $O/pmc_ifetch.txt
+timeout 300 python tools/quad_soc_ab.py 1024 2>&1 | tail -1 > $O/quad_ipopt_switches.txt; timeout 300 python tools/quad_soc_ab.py 4096 2>&1 | tail -1 >> $O/quad_ipopt_switches.txt; cat $O/quad_ipopt_switches.txt
 for CF in 3 4 5; do timeout 600 python bench.py --config $CF --no-cpu-baseline --no-host-rate --steps 60 > $O/bench_cfg$CF.json 2> $O/bench_cfg$CF.err; done
 timeout 300 python bench.py --gpus 2 --backend gloo --steps 24 --warmup 4 --no-cpu-baseline --no-pmc --no-host-rate --no-ipopt-leg --no-other-configs --no-distinct > $O/bench_2rank_gloo_selflaunch.json 2> $O/bench_2rank_gloo_selflaunch.err; cut -c1-160 $O/bench_2rank_gloo_selflaunch.json
 for B in 64 1024; do OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py $B > $O/phase_B$B.txt 2>&1; OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/quad_gpu.py $B > $O/quad_phase_B$B.txt 2>&1; done
