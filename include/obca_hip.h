@@ -53,7 +53,7 @@ typedef struct obca_batch obca_batch;
  *               with H := I) whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6;
  *   lsq_init -- IPOPT's default initial multipliers: the same least-squares estimate at the starting point (constr_mult_init_max = 1e3) instead of y0 = 0.
  * With any of them on, the kernels follow the CPU checker's option of the same name iteration for iteration -- on the FULL bench batches of BASELINE configs 2 / 3 / 5
- * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0 / 1 / 0 iteration counts differ, tests/test_gpu_parity.py,
+ * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0 / 2 / 1 iteration counts differ, tests/test_gpu_parity.py,
  * profiles/r04_census_gpu_ipopt_options.txt).
  *
  * Two option sets, and which one is the default where (round 4, measured on one MI355X, profiles/r04_bench_step1.json, r04_bench_config{3,5}_step1.json):
