@@ -224,3 +224,23 @@ def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
     bad = obca_amd.quadcopter_ipopt_opts(); bad.recalc_y = 1
     with pytest.raises(obca_amd.ObcaError):
         obca_amd.quadcopter_signed_dist_batch(bt["x0"][:2], bt["xF"][:2], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][:2], bt["timeWS"], opts=bad)
+
+
+def test_unreformulated_quadcopter_model_accepts_the_hip_solutions_at_N60(Q):
+    """the reference's quadcopter NLP as JuMP states it (oracle/ipm_ref60_quad.py; tests/test_pin_cpu.py: unreformulated_quad_certificate) at the HIP path's solutions of two
+    config-4 instances, with the reference's IPOPT configuration and with the throughput defaults: same objective, rows satisfied, no bound violated, first-order stationarity
+    with correctly signed multipliers -- the reformulations the kernel makes (one t, x_0 eliminated, bounds as bounds) are pinned at the benchmark size"""
+    pytest.importorskip("torch")
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import obca_amd
+    from obca_amd import scenarios as S
+    from test_pin_cpu import unreformulated_quad_certificate
+    N = 60; bt = S.make_quad_batch(8, N, seed=20260925, random_endpoints=True)
+    for name, o in (("reference IPOPT configuration", obca_amd.quadcopter_ipopt_opts()), ("throughput defaults", None)):
+        out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=o)
+        for i in range(2):
+            assert out["exitflag"][i] == 1
+            c = unreformulated_quad_certificate(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], out["xp"][i], out["up"][i], out["timeScale"][i, 0], out["lp"][i], out["slack"][i])
+            print("%s, instance %d: f %.10f (HIP %.10f), |c| %.1e, bound violation %.1e, stationarity %.1e, wrong-sign multiplier %.1e" % (name, i, c["f"], out["obj"][i], c["c"], c["viol"], c["stationarity"], c["wrong_sign"]))
+            assert abs(c["f"] - out["obj"][i]) < 1e-10 * abs(out["obj"][i]) and c["c"] < 1e-4 and c["viol"] == 0 and c["stationarity"] < 1e-3 and c["wrong_sign"] < 1e-6
