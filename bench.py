@@ -357,14 +357,15 @@ def ipopt_options_leg(cfg, rows, shared, B, N, nS, local, steps, out_default):
     du = np.array([np.abs(np.asarray(out["up"][i]) - np.asarray(out_default["up"][i])).max() for i in range(B)])
     df = np.abs(out["obj"] - out_default["obj"]) / np.maximum(1.0, np.abs(out_default["obj"]))
     dts = np.abs(out["timeScale"][:, 0] - out_default["timeScale"][:, 0])
-    differs = both & ((df > 1e-4) | (dts > 1e-4)) if quad else both & ((dx > 1e-3) | (du > 1e-3) | (df > 1e-4) | (dts > 1e-4))
-    return dict(options="max_soc = 4, recalc_y = no, lsq_init = 1 (obca_amd.quadcopter_ipopt_opts())" if quad else "max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+    differs = both & ((df > 2.1e-3) | (dts > 1e-3)) if quad else both & ((dx > 1e-3) | (du > 1e-3) | (df > 1e-4) | (dts > 1e-4))
+    return dict(options="max_soc = 4, recalc_y = no, lsq_init = 1, obj_scaling = 1 (obca_amd.quadcopter_ipopt_opts())" if quad else "max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                 validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
                 mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3),
                 exitflag_differs_from_default=int((out["exitflag"] != out_default["exitflag"]).sum()), iterations_differ_from_default=int((out["info"][:, 1] != out_default["info"][:, 1]).sum()),
                 solution_differs_from_default=int(differs.sum()), worst_dx=float(dx[both].max()) if both.any() else None, worst_rel_objective=float(df[both].max()) if both.any() else None,
-                note=("solution_differs_from_default: instances solved by both settings whose objective differs by more than 1e-4 relative or time scale by 1e-4 (the quadcopter cost has no term on "
-                      "the path: the minimiser is not unique along flat directions and the states of two solves of ONE local solution differ by up to 1e-2, worst_dx is reported only); never `value`") if quad else
+                note=("solution_differs_from_default: instances solved by both settings whose objective differs by more than 2.1e-3 relative or time scale by 1e-3: IPOPT's objective scaling (1 / 21 on "
+                      "this NLP) terminates 21 x looser in unscaled terms than the default options, which do not scale; the cost has no term on the path, so the states of two solves of ONE "
+                      "local solution differ by up to 1e-2 (worst_dx is reported only); never `value`") if quad else
                      "solution_differs_from_default: instances solved by both settings whose states / inputs differ by more than 1e-3, time scale by 1e-4 or objective by 1e-4 relative "
                      "(the path's stated tolerance, SURVEY 8c): the NLP is non-convex, another iteration path may end in another local solution; never `value`")
 

@@ -80,7 +80,10 @@ typedef struct obca_opts {
                          iterate's constraint violation is below 1e-6; 0 = off, the default of obca_default_opts; parking kernels only */
     int lsq_init;     /* 1: IPOPT's initial equality multipliers -- the least-squares estimate at the starting point, kept if its max-norm is <= constr_mult_init_max = 1e3;
                          0 = y0 = 0, the default of obca_default_opts (the reference runs IPOPT's default, i.e. 1); parking kernels only */
-    int reserved_;    /* 0 */
+    int obj_scaling;  /* 1: IPOPT's gradient-based scaling of the objective (nlp_scaling_method default, nlp_scaling_max_gradient = 100): the algorithm runs on sf * f with
+                       * sf = 100 / max(100, |grad f(start)|_inf); dual_inf_tol / compl_inf_tol are tested on the unscaled quantities, the reported objective is unscaled.
+                       * Quadcopter kernel: sf = 100 / 2 100 at the reference's start (the slack penalty 1e2 + 2e3 * 1), set by obca_quadcopter_reference_opts.  Parking kernels: the
+                       * gradient at the reference's start is the slack penalty 1e2 exactly, sf = 1: the field is accepted and changes nothing.  0 = off (the defaults) */
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);
@@ -160,8 +163,9 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-pha
 typedef struct obca_quad_batch obca_quad_batch;
 int obca_quadcopter_default_opts(obca_opts *o);
 /* the reference's IPOPT configuration for this call as far as the quadcopter kernel carries it: the defaults above + max_soc = 4 (IPOPT's default second-order
- * correction, A-5.5 .. A-5.9) + lsq_init = 1 (IPOPT's default least-squares initial multipliers, kept if <= 1e3); recalc_y stays off -- QuadcopterSignedDist.jl:29
- * sets recalc_y = "no", and opts.recalc_y != 0 is refused by the quadcopter entry points rather than ignored. */
+ * correction, A-5.5 .. A-5.9) + lsq_init = 1 (IPOPT's default least-squares initial multipliers, kept if <= 1e3) + obj_scaling = 1 (IPOPT's default gradient-based scaling:
+ * the objective factor 100 / 2 100 on this NLP); recalc_y stays off -- QuadcopterSignedDist.jl:29 sets recalc_y = "no", and opts.recalc_y != 0 is refused by the quadcopter
+ * entry points rather than ignored. */
 int obca_quadcopter_reference_opts(obca_opts *o);
 int obca_quadcopter_signed_dist_batch(obca_ctx *ctx, int B, int N, const double *Ts /* B */, double R, const double *x0 /* 12 x B */,
                                       const double *xF /* 12 x B */, const double *ob /* 6 x 5 x B */, const double *xWS /* 12 x (N+1) x B */,

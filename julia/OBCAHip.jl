@@ -59,7 +59,7 @@ mutable struct Opts
     dw_min::Cdouble; dw0::Cdouble; dw_max::Cdouble; kw_inc0::Cdouble; kw_inc::Cdouble; kw_dec::Cdouble; dc_bar::Cdouble; kappa_c::Cdouble
     gamma_theta::Cdouble; gamma_phi::Cdouble; delta::Cdouble; s_theta::Cdouble; s_phi::Cdouble; eta_phi::Cdouble; gamma_alpha::Cdouble; s_max::Cdouble; kappa_sigma::Cdouble
     constr_viol_tol::Cdouble; dual_inf_tol::Cdouble; compl_inf_tol::Cdouble; rho_term::Cdouble
-    max_soc::Cint; recalc_y::Cint; lsq_init::Cint; reserved_::Cint
+    max_soc::Cint; recalc_y::Cint; lsq_init::Cint; obj_scaling::Cint
     Opts() = new()
 end
 function default_opts()
@@ -73,7 +73,7 @@ function ipopt_opts()
     return o
 end
 optsptr(o) = o === nothing ? C_NULL : pointer_from_objref(o)
-"the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (max_soc = 4, least-squares initial multipliers; recalc_y = \"no\" as QuadcopterSignedDist.jl:29 sets it): default of the quadcopter drop-ins"
+"the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (max_soc = 4, least-squares initial multipliers, gradient-based objective scaling; recalc_y = \"no\" as QuadcopterSignedDist.jl:29 sets it): default of the quadcopter drop-ins"
 function quadcopter_ipopt_opts()
     o = Opts()
     ccall((:obca_quadcopter_reference_opts, LIB), Cint, (Ref{Opts},), o) == 0 || error("obca_quadcopter_reference_opts failed")

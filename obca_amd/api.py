@@ -38,7 +38,7 @@ class Opts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("reserved_", C.c_int)]      # the three IPOPT switches (include/obca_hip.h): 0 in default_opts(), 4 / 1 / 1 in ipopt_opts()
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]      # the three IPOPT switches (include/obca_hip.h): 0 in default_opts(), 4 / 1 / 1 in ipopt_opts()
 
 
 def library_path():
@@ -439,7 +439,7 @@ def quadcopter_default_opts():
 
 def quadcopter_ipopt_opts():
     """the reference's IPOPT configuration of the quadcopter call as far as the kernel carries it (obca_quadcopter_reference_opts: max_soc = 4, least-squares
-    initial multipliers; recalc_y = "no" as QuadcopterSignedDist.jl:29 sets it): the default of the drop-ins QuadcopterSignedDist / QuadcopterDist"""
+    initial multipliers, gradient-based objective scaling; recalc_y = "no" as QuadcopterSignedDist.jl:29 sets it): the default of the drop-ins QuadcopterSignedDist / QuadcopterDist"""
     o = Opts()
     _load().obca_quadcopter_reference_opts(C.byref(o))
     return o

@@ -183,7 +183,7 @@ struct QDevBufs {
 #ifndef OBCA_QUAD_WAVES_PER_EU
 #define OBCA_QUAD_WAVES_PER_EU 1      // as for the parking kernel
 #endif
-__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc, int lsq_init) {
+__global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc, int lsq_init, int obj_scaling) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
     if (threadIdx.x == 0) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_ker
     if (threadIdx.x < 16) quad::gq_sh.prof[threadIdx.x] = 0;
 #endif
     __syncthreads();
-    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8, max_soc, lsq_init);
+    quad::q_solve_instance(N, o, b.info + (size_t)inst * 8, max_soc, lsq_init, obj_scaling);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = quad::gq_sh.prof[threadIdx.x];
@@ -277,7 +277,7 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
-    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->reserved_ = 0;                  /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
+    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->obj_scaling = 0;                  /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
     return 0;
 }
 
@@ -871,6 +871,7 @@ int obca_quadcopter_reference_opts(obca_opts *o) {
     if (obca_quadcopter_default_opts(o)) return -1;
     o->max_soc = 4;                                    /* IPOPT default max_soc; recalc_y stays 0: QuadcopterSignedDist.jl:29 sets recalc_y = "no" */
     o->lsq_init = 1;                                   /* IPOPT default: least-squares initial multipliers, constr_mult_init_max = 1e3 */
+    o->obj_scaling = 1;                                /* IPOPT default: gradient-based scaling; on this NLP it is the objective factor 100 / 2 100 */
     return 0;
 }
 int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
@@ -910,7 +911,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc, o.lsq_init != 0);
+    hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc, o.lsq_init != 0, o.obj_scaling != 0);
     QCHK(bt, hipGetLastError());
     QCHK(bt, hipEventRecord(bt->e1, bt->stream));
     return 0;

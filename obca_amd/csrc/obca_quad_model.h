@@ -35,6 +35,7 @@ namespace quad {
 
 struct QConsts {
     double Ts, R, wH, x0[QX], xF[QX], gyro[3];
+    double sf;      // objective scaling factor (IPOPT's gradient-based scaling, opts.obj_scaling; 1: none): the algorithm runs on sf * f
     int N, dist;    // dist = 1: QuadcopterDist.jl (no slack variable, x[10] in [-1.5, 3]); 0: QuadcopterSignedDist.jl
 };
 OBCA_FN double q_xlb(int i, int dist = 0) { return i < 3 ? 0.0 : (i == 3 ? -3.0 : (i < 6 ? -0.2 : (dist && i == 9 ? -1.5 : -1.0))); }   // :78-94, QuadcopterDist.jl:88
@@ -151,8 +152,8 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     for (int i = 0; i < QL; i++) {
         const double sg = i < 3 ? 1.0 : -1.0; const int a = i % 3;
         g1[i] = 2 * sg * q[a]; g2[i] = -in.b[i] + sg * in.p[a];
-        const double il = rcp_nr(in.lam[i]), gl = 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
-        rl[i] = LSQ ? gl - in.zl[i] : gl - mu_b * il; Dl[i] = LSQ ? 1.0 : 2e-4 + in.zl[i] * il + dw;
+        const double il = rcp_nr(in.lam[i]), gl = c.sf * 2e-4 * in.lam[i] + g1[i] * y[0] + g2[i] * y[1];
+        rl[i] = LSQ ? gl - in.zl[i] : gl - mu_b * il; Dl[i] = LSQ ? 1.0 : c.sf * 2e-4 + in.zl[i] * il + dw;
         if (MODE == 0) {
             double rz = fabs(gl - in.zl[i]); st->dmax = fmax(st->dmax, rz);
             double cc = in.lam[i] * in.zl[i]; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
@@ -160,10 +161,10 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
         }
     }
     const double is = rcp_nr(in.s), iso = rcp_nr(in.so);
-    const double gs = 1e2 + 2e3 * in.s + 0.01 * y[1], gso = -y[1];
+    const double gs = c.sf * (1e2 + 2e3 * in.s) + 0.01 * y[1], gso = -y[1];
     // QuadcopterDist has no slack variable: it is frozen (1/D_s = 0, no residual), every term below then drops out and ds = 0
     const double r_s = c.dist ? 0.0 : (LSQ ? gs - in.zs : gs - mu_b * is), r_so = LSQ ? gso - in.zso : gso - mu_b * iso;
-    const double iDs = c.dist ? 0.0 : (LSQ ? 1.0 : rcp_nr(2e3 + in.zs * is + dw)), iDso = LSQ ? 1.0 : rcp_nr(in.zso * iso + dw);
+    const double iDs = c.dist ? 0.0 : (LSQ ? 1.0 : rcp_nr(c.sf * 2e3 + in.zs * is + dw)), iDso = LSQ ? 1.0 : rcp_nr(in.zso * iso + dw);
     if (MODE == 0) {
         double rz = c.dist ? 0.0 : fabs(gs - in.zs); st->dmax = fmax(st->dmax, rz);
         rz = fabs(gso - in.zso); st->dmax = fmax(st->dmax, rz);

@@ -249,8 +249,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #pragma unroll
             for (int i = 0; i < QX; i++) {
                 x[i] = z[l.x + QX * k + i];
-                const double gx = i >= 9 ? 2e-4 * x[i] : 0.0;
-                hz[i] = gx; hb[i] = gx; xd[i] = LSQ ? 1.0 : (i >= 9 ? 2e-4 : 0.0) + dw;
+                const double gx = i >= 9 ? c.sf * 2e-4 * x[i] : 0.0;
+                hz[i] = gx; hb[i] = gx; xd[i] = LSQ ? 1.0 : (i >= 9 ? c.sf * 2e-4 : 0.0) + dw;
                 if (i >= 9) lf += 1e-4 * x[i] * x[i];
                 if (k >= 1) {
                     B2 b = bound2(x[i], q_xlb(i, c.dist), q_xub(i, c.dist), z[l.zL + l.x + QX * k + i], z[l.zU + l.x + QX * k + i], mu, 1, lc0, lcmn, lcmx, lsz);
@@ -347,11 +347,12 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 B2 b = bound2(u[j], Q_ULO, Q_UHI, zLu[j], zUu[j], mu, 1, lc0, lcmn, lcmx, lsz);
                 if (LSQ) { b.Sig = 0; b.gb = b.gz; }
                 bar_mul(bu, u[j] - Q_ULO, Q_UHI - u[j]);
-                double gu = -2e-3 * (c.wH - u[j]), hu = 2e-3; hzw[j] = 0;
+                const double w2 = c.sf * 2e-2;
+                double gu = -c.sf * 2e-3 * (c.wH - u[j]), hu = c.sf * 2e-3; hzw[j] = 0;
                 lf += 1e-3 * (c.wH - u[j]) * (c.wH - u[j]);
-                if (k >= 1) { const double e = um[j] - u[j]; gu += -2e-2 * e; hu += 2e-2; hzw[j] = 2e-2 * e; lf += 1e-2 * e * e; }
+                if (k >= 1) { const double e = um[j] - u[j]; gu += -w2 * e; hu += w2; hzw[j] = w2 * e; lf += 1e-2 * e * e; }
                 hzu[j] = gu + b.gz - BTpi[j]; hbu[j] = gu + b.gb - BTpi[j]; ud[j] = LSQ ? 1.0 : hu + b.Sig + dw;
-                wn[j] = (k + 1 < N) ? 2e-2 * (u[j] - un[j]) : 0.0;     // copy part living in stage k+1
+                wn[j] = (k + 1 < N) ? w2 * (u[j] - un[j]) : 0.0;     // copy part living in stage k+1
                 const double tot = hzu[j] + wn[j]; dmax = fmax(dmax, fabs(tot));
             }
             // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
@@ -370,7 +371,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                 }
 #pragma unroll
             for (int j = 0; j < QU; j++) {
-                const double ww = (k >= 1 && !LSQ) ? 2e-2 : 0.0;
+                const double ww = (k >= 1 && !LSQ) ? c.sf * 2e-2 : 0.0;
                 rec[QR(QSR_H + (QX + j) * QZ + (QX + j))] = ww; rec[QR(QSR_H + (QX + j) * QZ + (QS + j))] = -ww; rec[QR(QSR_H + (QS + j) * QZ + (QX + j))] = -ww;
             }
             // gradients / t-columns
@@ -396,12 +397,12 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     B2 b = bound2(t, Q_TLO, Q_THI, z[l.zL + l.t], z[l.zU + l.t], mu, N + 1, d0, cmn, cmx, d2);
     if (LSQ) b.gb = b.gz;
     c0 = fmax(c0, d0); sumz += (N + 1) * (fabs(z[l.zL + l.t]) + fabs(z[l.zU + l.t]));
-    const double gf = (N + 1) * (0.25 + 10 * t);
+    const double gf = c.sf * (N + 1) * (0.25 + 10 * t);
     gtb += gf + b.gb; gtz += gf + b.gz;
     f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     dinf = fmax(dinf, fabs(gtz));
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
-    out.f = f; out.th1 = th1; out.bar = bar; out.Htt = LSQ ? (double)(N + 1) : 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;      // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model)
+    out.f = c.sf * f; out.th1 = th1; out.bar = bar; out.Htt = LSQ ? (double)(N + 1) : c.sf * 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;      // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model)
     out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2 - (c.dist ? 1 : 0)) * QOB * (N + 1);
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
 }
@@ -816,7 +817,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
             for (int i = 0; i < QX; i++) {
                 const double dx = s[i];
                 d[l.x + QX * k + i] = dx;
-                if (i >= 9) gd += 2e-4 * xv[i] * dx;
+                if (i >= 9) gd += c.sf * 2e-4 * xv[i] * dx;
                 if (k >= 1) {
                     const double dL = xv[i] - q_xlb(i, c.dist), dU = q_xub(i, c.dist) - xv[i], zL = zLx[i], zU = zUx[i];
                     gd += (-rdiv(mu, dL) + rdiv(mu, dU)) * dx;
@@ -829,8 +830,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 for (int j = 0; j < QU; j++) {
                     const double du = sn[QX + j];        // w_{k+1} = u_k
                     d[l.u + QU * k + j] = du;
-                    double gu = -2e-3 * (c.wH - uv[j]);
-                    if (k >= 1) { const double e = um[j] - uv[j]; gu -= 2e-2 * e; gd += 2e-2 * e * s[QX + j]; }
+                    double gu = -c.sf * 2e-3 * (c.wH - uv[j]);
+                    if (k >= 1) { const double e = um[j] - uv[j]; gu -= c.sf * 2e-2 * e; gd += c.sf * 2e-2 * e * s[QX + j]; }
                     const double dL = uv[j] - Q_ULO, dU = Q_UHI - uv[j], zL = zLu[j], zU = zUu[j];
                     gd += (gu - rdiv(mu, dL) + rdiv(mu, dU)) * du;
                     FTBP(dL, du); FTBP(dU, -du);
@@ -875,12 +876,12 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
 #pragma unroll
             for (int i = 0; i < QL; i++) {
                 d[l.lam + QL * it + i] = st.dlam[i];
-                lgd += (2e-4 * in.lam[i] - rdiv(mu, in.lam[i])) * st.dlam[i];
+                lgd += (c.sf * 2e-4 * in.lam[i] - rdiv(mu, in.lam[i])) * st.dlam[i];
                 FTBP(in.lam[i], st.dlam[i]); FTBZ(in.zl[i], rdiv(mu, in.lam[i]) - in.zl[i] - rdiv(in.zl[i], in.lam[i]) * st.dlam[i]);
             }
             d[l.s + it] = st.ds; d[l.so + it] = st.dso; d[l.yo + 2 * it] = st.dy[0]; d[l.yo + 2 * it + 1] = st.dy[1];
             lgd += -rdiv(mu, in.so) * st.dso;
-            if (!c.dist) { lgd += (1e2 + 2e3 * in.s - rdiv(mu, in.s)) * st.ds; FTBP(in.s, st.ds); FTBZ(in.zs, rdiv(mu, in.s) - in.zs - rdiv(in.zs, in.s) * st.ds); }
+            if (!c.dist) { lgd += (c.sf * (1e2 + 2e3 * in.s) - rdiv(mu, in.s)) * st.ds; FTBP(in.s, st.ds); FTBZ(in.zs, rdiv(mu, in.s) - in.zs - rdiv(in.zs, in.s) * st.ds); }
             FTBP(in.so, st.dso); FTBZ(in.zso, rdiv(mu, in.so) - in.zso - rdiv(in.zso, in.so) * st.dso);
         }
         sh.red[0][lane] = lap; sh.red[1][lane] = laz; sh.red[2][lane] = lgd;
@@ -898,7 +899,7 @@ OBCA_FN void q_direction_obs(QShared &sh, double mu, double dw, double dc, doubl
         const double dzL = rdiv(mu, dL) - zL - rdiv(zL, dL) * dt, dzU = rdiv(mu, dU) - zU + rdiv(zU, dU) * dt;
         cc_ = dzL < 0 ? -tau * zL * rcp_nr(dzL) : 1e300; if (cc_ < az) az = cc_;
         cc_ = dzU < 0 ? -tau * zU * rcp_nr(dzU) : 1e300; if (cc_ < az) az = cc_;
-        gd += ((N + 1) * (0.25 + 10 * t) + (N + 1) * (-rdiv(mu, dL) + rdiv(mu, dU))) * dt;
+        gd += (c.sf * (N + 1) * (0.25 + 10 * t) + (N + 1) * (-rdiv(mu, dL) + rdiv(mu, dU))) * dt;
     }
     so.ap = ap; so.az = az; so.gd = gd;
 }
@@ -958,7 +959,7 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
     double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
     fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
-    f = fr; th1 = tr; bar = br;
+    f = c.sf * fr; th1 = tr; bar = br;
 }
 
 // ---------------------------------------------------------------- rows of a second-order correction (IPOPT A-5.6 / A-5.7, option max_soc)
@@ -1046,7 +1047,7 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
 }
 
 // ---------------------------------------------------------------- starting point
-OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, double timeWS, int dual_ws) {
+OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, double timeWS, int dual_ws, int obj_scaling) {
     const QConsts &c = sh.c; const QLay &l = sh.l; const int N = c.N; gdbl *z = sh.inst.z;
     QPAR(lane) {
         for (int i = lane; i < QX * (N + 1); i += QNT) z[l.x + i] = i < QX ? c.x0[i] : sh.inst.prob[QPH_SIZE + i];   // xWS, :201
@@ -1083,6 +1084,28 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         }
     }
     SYNC();
+    if (obj_scaling) {      // IPOPT's gradient-based scaling of the objective (nlp_scaling_max_gradient = 100): |grad f|_inf at the starting point as given, over the variables of the
+                            // reference's model (each of the N + 1 timeScale variables carries 0.25 + 10 t).  At the reference's start it is the slack penalty: 1e2 + 2e3 = 2 100
+        QPAR(lane) {
+            double g = lane == 0 ? fabs(0.25 + 10 * z[l.t]) : 0.0;
+            for (int i = lane; i < QX * (N + 1); i += QNT) if (i % QX >= 9) g = fmax(g, fabs(2e-4 * z[l.x + i]));
+            for (int i = lane; i < QU * N; i += QNT) {
+                const int k = i / QU;
+                double gu = -2e-3 * (c.wH - z[l.u + i]);
+                if (k >= 1) gu += -2e-2 * (z[l.u + i - QU] - z[l.u + i]);
+                if (k + 1 < N) gu += 2e-2 * (z[l.u + i] - z[l.u + i + QU]);
+                g = fmax(g, fabs(gu));
+            }
+            for (int i = lane; i < QL * QOB * (N + 1); i += QNT) g = fmax(g, fabs(2e-4 * z[l.lam + i]));
+            if (!c.dist) for (int i = lane; i < QOB * (N + 1); i += QNT) g = fmax(g, fabs(1e2 + 2e3 * z[l.s + i]));
+            sh.red[0][lane] = g;
+        }
+        SYNC();
+        const double gm = red_max(sh.red[0]);
+        SYNC();
+        QPAR(lane) { if (lane == 0) sh.c.sf = gm > 100.0 ? 100.0 / gm : 1.0; }
+        SYNC();
+    }
     QPAR(lane) {
         for (int i = lane; i < l.n; i += QNT) {
             if (i < QX) continue;
@@ -1142,7 +1165,7 @@ OBCA_FN void q_restore_blocks(QShared &sh, double bound_push) {
 }
 
 // ---------------------------------------------------------------- phase entry points and driver
-OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws) { q_init_point(gq_sh, bp, bf, tws, dws); QPROF(QPF_INIT); }
+OBCA_PHASE void qph_init(double bp, double bf, double tws, int dws, int osc) { q_init_point(gq_sh, bp, bf, tws, dws, osc); QPROF(QPF_INIT); }
 OBCA_PHASE double qph_min_norm2() { return q_min_norm2(gq_sh); }
 OBCA_PHASE void qph_restore(double bp) { q_restore_blocks(gq_sh, bp); }
 OBCA_PHASE int qph_block_bad(double mu, double dw, double dc) { const int b = q_block_bad(gq_sh, mu, dw, dc); QPROF(QPF_ASM_OBS); return b; }
@@ -1173,12 +1196,12 @@ OBCA_PHASE void qph_soc_rows(double a, int first) { q_soc_rows(gq_sh, a, first);
 OBCA_PHASE void qph_apply(double alpha, double ay, double az, double mu, double ks) { QPROF(QPF_OTHER); q_apply_step(gq_sh, alpha, ay, az, mu, ks); QPROF(QPF_APPLY); }
 
 // info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}; exit flag per QuadcopterSignedDist.jl:229-234,285-288
-OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 0, int lsq_init = 0) {
+OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 0, int lsq_init = 0, int obj_scaling = 0) {
     QShared &sh = gq_sh;
     QPAR(lane) {
         if (lane == 0) {
             QConsts &c = sh.c; const gdbl *p = sh.inst.prob;
-            c.N = N; c.dist = (int)p[QPH_DIST]; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4));
+            c.N = N; c.dist = (int)p[QPH_DIST]; c.Ts = p[QPH_TS]; c.R = p[QPH_R]; c.wH = sqrt((Q_MASS * Q_GRAV) / (Q_KF * 4)); c.sf = 1.0;
             for (int i = 0; i < QX; i++) { c.x0[i] = p[QPH_X0 + i]; c.xF[i] = p[QPH_XF + i]; }
             for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];                          // single-index x[10..12] = stage 1
             for (int i = 0; i < QOB * QL; i++) sh.ob[i] = p[QPH_OB + i];
@@ -1187,7 +1210,8 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
         }
     }
     SYNC();
-    qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS]);
+    qph_init(o.bound_push, o.bound_frac, sh.inst.prob[QPH_TWS], (int)sh.inst.prob[QPH_DWS], obj_scaling);
+    const double sf = sh.c.sf;
     double mu = o.mu_init, tau = fmax(o.tau_min, 1 - mu), dw_last = 0;
     int nf = 0, it = 0, status = ST_USERLIMIT, nreg = 0, nrest = 0, reset_th = 1, have_hint = 0, dcur = 0;      // dcur: the direction buffer in use
     const AsmOut &A = sh.A;
@@ -1226,7 +1250,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
         const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
-        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf <= o.dual_inf_tol && A.cinf0 <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
+        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf / sf <= o.dual_inf_tol && A.cinf0 / sf <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }      // (the three *_tol: IPOPT's tolerances on the UNSCALED problem)
         if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
         if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
         int mu_changed = 0;
@@ -1348,7 +1372,7 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
     SYNC();
     int ef = status == ST_OPTIMAL ? 1 : 0;
     if (!sh.c.dist && ef == 1 && ssum > 1e-3) ef = 2;
-    QPAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f; info[3] = pinf; info[4] = dinf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
+    QPAR(lane) { if (lane == 0) { info[0] = status; info[1] = it; info[2] = f / sf; info[3] = pinf; info[4] = dinf / sf; info[5] = mu; info[6] = nreg; info[7] = ef; } }
     SYNC();
 }
 

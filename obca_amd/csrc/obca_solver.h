@@ -133,7 +133,7 @@ struct Opts {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
-struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, reserved_; };      // obca_opts of the C ABI: the interior-point options + the three IPOPT switches (max_soc: second-order correction trials per iteration,
+struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, obj_scaling; };      // obca_opts of the C ABI: the interior-point options + the three IPOPT switches (max_soc: second-order correction trials per iteration,
                                                           // IPOPT's default 4; recalc_y; lsq_init; all 0 = off by default, as in the checker).  Kept apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
 struct Lay {

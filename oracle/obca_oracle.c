@@ -55,6 +55,7 @@ typedef struct {
     int lsq_init, verbose;
     int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc = 4); 0 = off, the default: see DESIGN.md section 2 for the measured A/B */
     int recalc_y;     /* recalc_y = "yes" (ParkingSignedDist.jl:41): least-squares multipliers once the constraint violation is below 1e-6; 0 = off (default) */
+    int obj_scaling;  /* IPOPT's gradient-based objective scaling: a no-op on this path (|grad f|_inf at the reference's start is the slack penalty, exactly 100: factor 1); the quadcopter oracle applies it */
 } opts_t;
 
 void obca_oracle_default_opts(opts_t *o) {
@@ -69,7 +70,7 @@ void obca_oracle_default_opts(opts_t *o) {
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4;
     o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
-    o->max_soc = 0; o->recalc_y = 0;                 /* the three IPOPT switches are off by default and set by the caller (never through the environment: a leaked variable would change what the parity tests compare) */
+    o->max_soc = 0; o->recalc_y = 0; o->obj_scaling = 0;                 /* the three IPOPT switches are off by default and set by the caller (never through the environment: a leaked variable would change what the parity tests compare) */
 }
 
 /* ------------------------------------------------------------------ iterate layout (one flat vector) */

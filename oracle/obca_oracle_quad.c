@@ -36,7 +36,10 @@ typedef struct {
     double gamma_theta, gamma_phi, delta, s_theta, s_phi, eta_phi, gamma_alpha, s_max, kappa_sigma;
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
     int lsq_init, verbose;
-    int max_soc;      /* second-order correction trials per iteration (IPOPT's default: 4); 0 = off (default; environment OBCA_QSOC: tools/soc_probe.py --quad) */
+    int max_soc;      /* second-order correction trials per iteration (IPOPT's default: 4); 0 = off (default) */
+    int recalc_y_;    /* (slot of the parking oracle's recalc_y: the quadcopter call sets recalc_y = "no") */
+    int obj_scaling;  /* 1: IPOPT's gradient-based scaling of the objective (nlp_scaling_max_gradient = 100): the algorithm runs on sf f with sf = 100 / max(100, |grad f(start)|_inf);
+                         the unscaled tolerances (dual_inf_tol, compl_inf_tol) are tested on the unscaled quantities, the reported objective is unscaled.  0 = off (default) */
 } opts_t;
 
 void obca_oracle_quad_default_opts(opts_t *o) {
@@ -48,7 +51,7 @@ void obca_oracle_quad_default_opts(opts_t *o) {
     o->dc_bar = 1e-7; o->kappa_c = 0.25;            /* jacobian_regularization_value */
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
-    o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
+    o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0; o->recalc_y_ = 0; o->obj_scaling = 0;
     o->max_soc = 0;                                 /* second-order correction: an option the caller sets (opts.max_soc), never the environment */
 }
 
@@ -73,12 +76,12 @@ static const double XLB[NXS] = {0, 0, 0, -3, -0.2, -0.2, -1, -1, -1, -1, -1, -1}
 static const double XUB[NXS] = {10, 10, 5, 3, 0.2, 0.2, 1, 1, 1, 1, 1, 1};
 
 /* iterate: primal v[n], equality multipliers y[m], bound multipliers zL[n], zU[n]; lb/ub/mult are per-variable tables */
-typedef struct { const prob_t *p; lay_t l; double *lb, *ub, *mult; } model_t;
+typedef struct { const prob_t *p; lay_t l; double *lb, *ub, *mult; double sf; /* objective scaling factor (1: none) */ } model_t;
 
 static void *xcalloc(size_t n, size_t s) { void *q = calloc(n ? n : 1, s); if (!q) { fprintf(stderr, "oom\n"); exit(1); } return q; }
 
 static void model_init(model_t *M, const prob_t *p) {
-    M->p = p; make_layout(p->N, &M->l);
+    M->p = p; make_layout(p->N, &M->l); M->sf = 1.0;
     const lay_t *l = &M->l; int N = p->N, n = l->n;
     M->lb = xcalloc(n, 8); M->ub = xcalloc(n, 8); M->mult = xcalloc(n, 8);
     for (int i = 0; i < n; i++) { M->lb[i] = -INFINITY; M->ub[i] = INFINITY; M->mult[i] = 1; }
@@ -90,6 +93,20 @@ static void model_init(model_t *M, const prob_t *p) {
     for (int i = 0; i < NOB * (N + 1); i++) { M->lb[l->s + i] = p->dist ? -INFINITY : 0; M->lb[l->so + i] = 0; }     /* :105; no slack variable in QuadcopterDist: it stays frozen at 0 here */
 }
 static void model_free(model_t *M) { free(M->lb); free(M->ub); free(M->mult); }
+/* |grad f|_inf at v over the variables of the reference's model (QuadcopterSignedDist.jl:66-73; every one of the N + 1 timeScale variables carries 0.25 + 10 t): what IPOPT's
+ * gradient-based scaling looks at.  At the reference's start it is the slack penalty, 1e2 + 2e3 * 1 = 2 100 (scaling factor 100 / 2 100); 10.25 for QuadcopterDist (factor 1). */
+static double objective_gradient_max(const model_t *M, const double *v) {
+    const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N; double g = fabs(0.25 + 10 * v[l->t]);
+    for (int k = 0; k <= N; k++) for (int i = 9; i < 12; i++) g = fmax(g, fabs(2e-4 * v[l->x + NXS * k + i]));
+    for (int k = 0; k < N; k++) for (int j = 0; j < NU; j++) {
+        double gu = -2e-3 * (p->wH - v[l->u + NU * k + j]);
+        if (k >= 1) gu += -2e-2 * (v[l->u + NU * (k - 1) + j] - v[l->u + NU * k + j]);
+        if (k + 1 < N) gu += 2e-2 * (v[l->u + NU * k + j] - v[l->u + NU * (k + 1) + j]);
+        g = fmax(g, fabs(gu)); }
+    for (int i = 0; i < NL * NOB * (N + 1); i++) g = fmax(g, fabs(2e-4 * v[l->lam + i]));
+    if (!p->dist) for (int i = 0; i < NOB * (N + 1); i++) g = fmax(g, fabs(1e2 + 2e3 * v[l->s + i]));
+    return g;
+}
 
 /* -------------------------------------------------------------- dynamics g(x,u) with x+ = x + t Ts g  (:136-156) */
 /* local variable order for derivatives: a4,a5,a6 (angles x[3..5]), r10,r11,r12 (rates x[9..11]), u1..u4  -> 10 vars */
@@ -171,6 +188,7 @@ static void eval_f_theta(const model_t *M, const double *v, double *f, double *t
         for (int i = 0; i < NXS; i++) { double r = fabs(v[l->x + NXS * (k + 1) + i] - x[i] - tau * g[i]); th += r; if (r > ti) ti = r; }
     }
     J += (N + 1) * (0.25 * t + 5 * t * t);
+    /* (J is scaled by M->sf where it is handed out, below) */
     for (int k = 0; k <= N; k++) {
         const double *x = v + l->x + NXS * k;
         J += 1e-4 * (x[9] * x[9] + x[10] * x[10] + x[11] * x[11]);
@@ -183,7 +201,7 @@ static void eval_f_theta(const model_t *M, const double *v, double *f, double *t
         }
     }
     for (int i = 0; i < NXS; i++) { double r = fabs(v[l->x + NXS * N + i] - p->xF[i]); th += r; if (r > ti) ti = r; }
-    *f = J; *th1 = th; if (thinf) *thinf = ti;
+    *f = M->sf * J; *th1 = th; if (thinf) *thinf = ti;
 }
 static double barrier_sum(const model_t *M, const double *v) {
     double s = 0; int n = M->l.n;
@@ -292,19 +310,19 @@ static bnd_t bound_terms(const model_t *M, int i, const double *v, const double 
 static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double *zL, const double *zU, double mu, double dw, double dc) {
     const model_t *M = K->M; const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, ok = 1;
     double t = v[l->t], tau = t * p->Ts, c0 = 0, cmu = 0, sumz = 0, sumy = 0, dmax = 0, pmax = 0; int nb = 0, nm = 0;
-    const int lsq = K->lsq;
+    const int lsq = K->lsq; const double sf = M->sf;
 #define LSQ_B(b) do { if (lsq) (b).gb = (b).gz; } while (0)      /* least-squares mode: the gradient with the bound multipliers themselves */
     {
         bnd_t b = bound_terms(M, l->t, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
-        double gf = (N + 1) * (0.25 + 10 * t);
-        K->Htt = lsq ? (double)(N + 1) : 10.0 * (N + 1) + b.Sig + dw;      /* (t stands for the N + 1 timeScale variables of the reference's model: N + 1 unit diagonal entries) */ K->gt_z = gf + b.gz; K->gt_b = gf + b.gb;
+        double gf = sf * (N + 1) * (0.25 + 10 * t);
+        K->Htt = lsq ? (double)(N + 1) : sf * 10.0 * (N + 1) + b.Sig + dw;      /* (t stands for the N + 1 timeScale variables of the reference's model: N + 1 unit diagonal entries) */ K->gt_z = gf + b.gz; K->gt_b = gf + b.gb;
     }
     for (int k = 0; k <= N; k++) {
         double (*H)[NZ] = K->H[k]; double *hz = K->hz[k], *hb = K->hb[k], *Ht = K->Ht[k];
         memset(H, 0, sizeof K->H[k]); memset(hz, 0, sizeof K->hz[k]); memset(hb, 0, sizeof K->hb[k]); memset(Ht, 0, sizeof K->Ht[k]);
         const double *x = v + l->x + NXS * k;
         for (int i = 0; i < NXS; i++) {
-            double gx = (i >= 9) ? 2e-4 * x[i] : 0, hx = (i >= 9) ? 2e-4 : 0, Sig = 0;
+            double gx = (i >= 9) ? sf * 2e-4 * x[i] : 0, hx = (i >= 9) ? sf * 2e-4 : 0, Sig = 0;
             hz[i] = gx; hb[i] = gx;
             if (k >= 1) { bnd_t b = bound_terms(M, l->x + NXS * k + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); Sig = b.Sig; hz[i] += b.gz; hb[i] += b.gb; }
             H[i][i] = lsq ? 1.0 : hx + Sig + dw;
@@ -319,12 +337,12 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
                 double sg = i < 3 ? 1.0 : -1.0; int a = i % 3;
                 F->g1[i] = 2 * sg * F->q[a]; F->g2[i] = -p->ob[j][i] + sg * x[a];
                 bnd_t b = bound_terms(M, l->lam + NL * bo + i, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
-                double gl = 2e-4 * lam[i] + F->g1[i] * yv[0] + F->g2[i] * yv[1];
+                double gl = sf * 2e-4 * lam[i] + F->g1[i] * yv[0] + F->g2[i] * yv[1];
                 if (fabs(gl + b.gz) > dmax) dmax = fabs(gl + b.gz);
-                rl_b[i] = gl + b.gb; F->Dl[i] = lsq ? 1.0 : 2e-4 + b.Sig + dw;
+                rl_b[i] = gl + b.gb; F->Dl[i] = lsq ? 1.0 : sf * 2e-4 + b.Sig + dw;
             }
-            { bnd_t b = bound_terms(M, l->s + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); double gs = 1e2 + 2e3 * s + 0.01 * yv[1];
-              if (!p->dist && fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = lsq ? 1.0 : 2e3 + b.Sig + dw; }
+            { bnd_t b = bound_terms(M, l->s + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); double gs = sf * (1e2 + 2e3 * s) + 0.01 * yv[1];
+              if (!p->dist && fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_s = gs + b.gb; F->Ds = lsq ? 1.0 : sf * 2e3 + b.Sig + dw; }
             if (p->dist) { F->r_s = 0; F->Ds = INFINITY; }       /* frozen: every 1/Ds term below vanishes, ds = 0 */
             { bnd_t b = bound_terms(M, l->so + bo, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b); double gs = -yv[1];
               if (fabs(gs + b.gz) > dmax) dmax = fabs(gs + b.gz); F->r_so = gs + b.gb; F->Dso = lsq ? 1.0 : b.Sig + dw; }
@@ -358,9 +376,9 @@ static int kkt_assemble(kkt_t *K, const double *v, const double *y, const double
         const double *u = v + l->u + NU * k;
         for (int j = 0; j < NU; j++) {
             bnd_t b = bound_terms(M, l->u + NU * k + j, v, zL, zU, mu, &c0, &cmu, &sumz, &nb); LSQ_B(b);
-            double gu = -2e-3 * (p->wH - u[j]), hu = 2e-3;
-            if (k >= 1) { double e = u[j - NU] - u[j]; gu += -2e-2 * e; hu += 2e-2; hz[NXS + j] += 2e-2 * e; hb[NXS + j] += 2e-2 * e;
-                if (!lsq) { H[NXS + j][NXS + j] += 2e-2; H[NXS + j][NS + j] += -2e-2; H[NS + j][NXS + j] += -2e-2; } }
+            double gu = -sf * 2e-3 * (p->wH - u[j]), hu = sf * 2e-3; const double w2 = sf * 2e-2;
+            if (k >= 1) { double e = u[j - NU] - u[j]; gu += -w2 * e; hu += w2; hz[NXS + j] += w2 * e; hb[NXS + j] += w2 * e;
+                if (!lsq) { H[NXS + j][NXS + j] += w2; H[NXS + j][NS + j] += -w2; H[NS + j][NXS + j] += -w2; } }
             hz[NS + j] += gu + b.gz; hb[NS + j] += gu + b.gb; H[NS + j][NS + j] += lsq ? 1.0 : hu + b.Sig + dw;
         }
         {   /* dynamics x+ - x - t Ts g(x,u) = 0 with multiplier pi_k */
@@ -593,7 +611,7 @@ enum { ST_OPTIMAL = 0, ST_USERLIMIT = 1, ST_ERROR = 2 };
 static __thread int g_nsoc = 0, g_nsoc_acc = 0;      /* diagnostic: corrections tried / accepted by the calling thread */
 int obca_oracle_quad_soc_counts(int *acc) { if (acc) *acc = g_nsoc_acc; return g_nsoc; }
 static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, double *zL, double *zU, result_t *res) {
-    const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, n = l->n, m = l->m;
+    const prob_t *p = M->p; const lay_t *l = &M->l; int N = p->N, n = l->n, m = l->m; const double sf = M->sf;
     kkt_t *K = kkt_alloc(M);
     double *dv = xcalloc(n, 8), *dy = xcalloc(m, 8), *dzL = xcalloc(n, 8), *dzU = xcalloc(n, 8), *vt = xcalloc(n, 8);
     double mu = o->mu_init, tau = fmax(o->tau_min, 1 - mu), dw_last = 0;
@@ -638,7 +656,7 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
         eval_f_theta(M, v, &f, &th, &thinf);
         last_pinf = pinf; last_dinf = dinf;
         if (o->verbose) printf("it %3d f=% .8e pinf=%.2e dinf=%.2e cinf=%.2e mu=%.1e dw=%.1e t=%.4f\n", it, f, pinf, dinf, cinf0, mu, dw_last, v[l->t]);
-        if (E0 <= o->tol && pinf <= o->constr_viol_tol && dinf <= o->dual_inf_tol && cinf0 <= o->compl_inf_tol) { status = ST_OPTIMAL; break; }
+        if (E0 <= o->tol && pinf <= o->constr_viol_tol && dinf / M->sf <= o->dual_inf_tol && cinf0 / M->sf <= o->compl_inf_tol) { status = ST_OPTIMAL; break; }      /* (the three *_tol are IPOPT's tolerances on the UNSCALED problem) */
         if (it >= o->max_iter) { status = ST_USERLIMIT; break; }
         if (!(f == f) || !(pinf == pinf) || !(dinf == dinf)) { status = ST_ERROR; break; }
         for (;;) {
@@ -679,13 +697,13 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
                     if (dv[i] > 0) ap = fmin(ap, tau * d / dv[i]); if (dzU[i] < 0) az = fmin(az, -tau * zU[i] / dzU[i]); }
             }
             (void)wsum;
-            for (int k = 0; k < N; k++) for (int j = 0; j < NU; j++) { const double *u = v + l->u + NU * k; double gu = -2e-3 * (p->wH - u[j]);
-                if (k >= 1) { double e = u[j - NU] - u[j]; gu -= 2e-2 * e; gd += 2e-2 * e * dv[l->u + NU * (k - 1) + j]; }
+            for (int k = 0; k < N; k++) for (int j = 0; j < NU; j++) { const double *u = v + l->u + NU * k; double gu = -sf * 2e-3 * (p->wH - u[j]);
+                if (k >= 1) { double e = u[j - NU] - u[j]; gu -= sf * 2e-2 * e; gd += sf * 2e-2 * e * dv[l->u + NU * (k - 1) + j]; }
                 gd += gu * dv[l->u + NU * k + j]; }
-            gd += (N + 1) * (0.25 + 10 * t) * dv[l->t];
-            for (int k = 0; k <= N; k++) { for (int i = 9; i < 12; i++) gd += 2e-4 * v[l->x + NXS * k + i] * dv[l->x + NXS * k + i];
-                for (int j = 0; j < NOB; j++) { int bo = k * NOB + j; if (!p->dist) gd += (1e2 + 2e3 * v[l->s + bo]) * dv[l->s + bo];
-                    for (int i = 0; i < NL; i++) gd += 2e-4 * v[l->lam + NL * bo + i] * dv[l->lam + NL * bo + i]; } }
+            gd += sf * (N + 1) * (0.25 + 10 * t) * dv[l->t];
+            for (int k = 0; k <= N; k++) { for (int i = 9; i < 12; i++) gd += sf * 2e-4 * v[l->x + NXS * k + i] * dv[l->x + NXS * k + i];
+                for (int j = 0; j < NOB; j++) { int bo = k * NOB + j; if (!p->dist) gd += sf * (1e2 + 2e3 * v[l->s + bo]) * dv[l->s + bo];
+                    for (int i = 0; i < NL; i++) gd += sf * 2e-4 * v[l->lam + NL * bo + i] * dv[l->lam + NL * bo + i]; } }
         }
         double phi = f - mu * barrier_sum(M, v), amin;
         if (gd < 0) { amin = fmin(o->gamma_theta, o->gamma_phi * th / (-gd)); if (th <= th_min) amin = fmin(amin, o->delta * pow(th, o->s_theta) / pow(-gd, o->s_phi)); }
@@ -769,7 +787,7 @@ static void ipm_solve(const model_t *M, const opts_t *o, double *v, double *y, d
         next_iter:;
     }
     eval_f_theta(M, v, &f, &th, &thinf);
-    res->status = status; res->iters = it; res->nreg = nreg; res->obj = f; res->pinf = last_pinf; res->dinf = last_dinf; res->mu = mu; res->t = v[l->t];
+    res->status = status; res->iters = it; res->nreg = nreg; res->obj = f / M->sf; res->pinf = last_pinf; res->dinf = last_dinf / M->sf; res->mu = mu; res->t = v[l->t];
     free(dv); free(dy); free(dzL); free(dzU); free(vt); kkt_free(K);
 }
 
@@ -819,6 +837,7 @@ int obca_oracle_quadcopter_signed_dist(int N, double Ts, double R, const double 
     for (int i = 0; i < NL * NOB * (N + 1); i++) v[l->lam + i] = 0.05;      /* :204-208 */
     if (dual_ws) quad_dual_ws(&p, l, v);
     for (int i = 0; i < NOB * (N + 1); i++) v[l->s + i] = dist ? 0.0 : 1.0; /* :210 */
+    if (o.obj_scaling) { double gm = objective_gradient_max(&M, v); M.sf = gm > 100.0 ? 100.0 / gm : 1.0; }      /* nlp_scaling_method = gradient-based, nlp_scaling_max_gradient = 100 */
     result_t r; ipm_solve(&M, &o, v, y, zL, zU, &r);
     int ef = r.status == ST_OPTIMAL ? 1 : 0;                                /* flag = 1 branch, :229-234 */
     double ssum = 0; for (int i = 0; i < NOB * (N + 1); i++) ssum += v[l->s + i];

@@ -166,7 +166,7 @@ static void q_setup(int N, const double *prob, QScratch &s) {
     for (int i = 0; i < QX; i++) { c.x0[i] = prob[QPH_X0 + i]; c.xF[i] = prob[QPH_XF + i]; }
     for (int i = 0; i < 3; i++) c.gyro[i] = c.x0[9 + i];
     for (int i = 0; i < QOB * QL; i++) sh.ob[i] = prob[QPH_OB + i];
-    quad::q_make_layout(N, sh.l); sh.soc_on = 0; sh.inst.d0 = s.d;
+    quad::q_make_layout(N, sh.l); sh.soc_on = 0; sh.inst.d0 = s.d; c.sf = 1.0;
 }
 int emu_quad_layout(int N, int *out) { quad::QLay l; quad::q_make_layout(N, l); memcpy(out, &l, sizeof l); return (int)(sizeof l / sizeof(int)); }
 
@@ -201,7 +201,7 @@ int emu_quad_solve(int N, const double *prob, const void *opts, double *zout, do
     QScratch s; quad::QLay l; q_alloc(N, s, l);
     quad::QShared &sh = quad::gq_sh;
     sh.inst.prob = prob; sh.inst.z = s.z; sh.inst.d = s.d; sh.inst.as = s.as; sh.inst.rs = s.rs; sh.inst.oc = s.oc;
-    quad::q_solve_instance(N, *(const Opts *)opts, info, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->lsq_init);
+    quad::q_solve_instance(N, *(const Opts *)opts, info, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->lsq_init, ((const OptsAbi *)opts)->obj_scaling);
     memcpy(zout, s.z, sizeof(double) * l.len);
     q_free(s);
     return 0;

@@ -51,22 +51,22 @@ def parking_oracle_all(bt, xWS, workers=None, chunk=8, switches=None):
 def _quad_chunk(args):
     _init()
     import oracle_quad as Q
-    (lo, x0, xF, N, Ts, R, ob, xWS, max_soc, lsq_init) = args
-    out = []; o = Q.default_opts(); o.max_soc = int(max_soc); o.lsq_init = int(lsq_init)
+    (lo, x0, xF, N, Ts, R, ob, xWS, max_soc, lsq_init, obj_scaling) = args
+    out = []; o = Q.default_opts(); o.max_soc = int(max_soc); o.lsq_init = int(lsq_init); o.obj_scaling = int(obj_scaling)
     for i in range(len(x0)):
         r = Q.quadcopter_signed_dist(x0[i], xF[i], N, Ts, R, ob, xWS[i], 1.0, opts=o)
         out.append((lo + i, r["exitflag"], r["iters"], r["nreg"], r["obj"], r["up"], r["t"]))
     return out
 
 
-def quad_oracle_all(bt, workers=None, chunk=8, max_soc=0, lsq_init=0):
-    """quadcopter oracle on every instance of a batch of scenarios.make_quad_batch: list of (index, exitflag, iters, nreg, obj, up, t); max_soc = 4, lsq_init = 1: with IPOPT's
-    second-order correction and least-squares initial multipliers (the option set of obca_quadcopter_reference_opts)"""
+def quad_oracle_all(bt, workers=None, chunk=8, max_soc=0, lsq_init=0, obj_scaling=0):
+    """quadcopter oracle on every instance of a batch of scenarios.make_quad_batch: list of (index, exitflag, iters, nreg, obj, up, t); max_soc = 4, lsq_init = 1, obj_scaling = 1: with IPOPT's
+    second-order correction, least-squares initial multipliers and gradient-based objective scaling (the option set of obca_quadcopter_reference_opts)"""
     import multiprocessing as mp
     import oracle_quad as Q
     Q.lib()
     B = len(bt["x0"]); N = bt["xWS"].shape[1] - 1
-    jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][lo:lo + chunk], max_soc, lsq_init) for lo in range(0, B, chunk)]
+    jobs = [(lo, bt["x0"][lo:lo + chunk], bt["xF"][lo:lo + chunk], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][lo:lo + chunk], max_soc, lsq_init, obj_scaling) for lo in range(0, B, chunk)]
     workers = workers or min(os.cpu_count() or 1, 64)
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_quad_chunk, jobs)

@@ -39,11 +39,11 @@ def test_opts_struct_matches_and_defaults(lib):
     import oracle as O
     oo = O.default_opts()
     for n, _ in Opts._fields_:
-        if n != "reserved_":
+        if True:
             assert getattr(o, n) == getattr(oo, n), n      # every option exists under the same name in the checker
-    assert o.max_soc == 0 and o.recalc_y == 0 and o.lsq_init == 0 and o.reserved_ == 0
+    assert o.max_soc == 0 and o.recalc_y == 0 and o.lsq_init == 0 and o.obj_scaling == 0
     q = Opts(); assert lib.obca_quadcopter_reference_opts(C.byref(q)) == 0
-    assert q.max_soc == 4 and q.recalc_y == 0 and q.lsq_init == 1 and q.max_iter == 3000 and q.dw_min == 1e-10      # QuadcopterSignedDist.jl:28-31 (recalc_y = "no") + IPOPT's defaults max_soc, least-squares y0
+    assert q.max_soc == 4 and q.recalc_y == 0 and q.lsq_init == 1 and q.obj_scaling == 1 and q.max_iter == 3000 and q.dw_min == 1e-10      # QuadcopterSignedDist.jl:28-31 (recalc_y = "no") + IPOPT's defaults max_soc, least-squares y0
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -90,7 +90,8 @@ def test_emu_quadcopter_dist_variant_matches_oracle(Q, emu):
 
 
 def test_emu_quad_ipopt_switches_match_oracle_options(Q, emu):
-    """opts.max_soc = 4 (IPOPT A-5.5 .. A-5.9) and opts.lsq_init (least-squares initial multipliers) -- together obca_quadcopter_reference_opts -- through the device
+    """opts.max_soc = 4 (IPOPT A-5.5 .. A-5.9), opts.lsq_init (least-squares initial multipliers) and opts.obj_scaling (gradient-based objective scaling, factor 100 / 2 100)
+    -- together obca_quadcopter_reference_opts -- through the device
     source against the oracle's options: same iteration and regularisation counts, same optimum, for each switch alone and for both -- and the switches are
     exercised (the counts differ from the solve without them)"""
     from obca_amd import scenarios as S
@@ -98,19 +99,19 @@ def test_emu_quad_ipopt_switches_match_oracle_options(Q, emu):
     L = P.quad_layout(N)
     for i in range(3):
         res = {}
-        for (msoc, lsq) in ((0, 0), (4, 0), (0, 1), (4, 1)):
-            oo = Q.default_opts(); oo.max_soc = msoc; oo.lsq_init = lsq; eo = EOpts()
+        for (msoc, lsq, osc) in ((0, 0, 0), (4, 0, 0), (0, 1, 0), (0, 0, 1), (4, 1, 1)):
+            oo = Q.default_opts(); oo.max_soc = msoc; oo.lsq_init = lsq; oo.obj_scaling = osc; eo = EOpts()
             for f, _ in EOpts._fields_:
                 if hasattr(oo, f):
                     setattr(eo, f, getattr(oo, f))
-            eo.max_soc = msoc; eo.lsq_init = lsq
+            eo.max_soc = msoc; eo.lsq_init = lsq; eo.obj_scaling = osc
             r = Q.quadcopter_signed_dist(q["x0"][i], q["xF"][i], N, q["Ts"], q["R"], q["ob"], q["xWS"][i], q["timeWS"], opts=oo)
             prob = P.pack_quad_problem(q["x0"][i], q["xF"][i], N, q["Ts"], q["R"], q["ob"], q["xWS"][i], q["timeWS"])
             z = np.zeros(L["len"]); info = np.zeros(8)
             emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
-            assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"] and int(info[6]) == r["nreg"], (i, msoc, lsq, info, r["iters"], r["nreg"])
+            assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"] and int(info[6]) == r["nreg"], (i, msoc, lsq, osc, info, r["iters"], r["nreg"])
             assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"]) and abs(z[L["t"]] - r["t"]) < 1e-9
             up = z[L["u"]:L["t"]].reshape(N, 4).T
             assert np.abs(up - r["up"]).max() < 1e-5
-            res[(msoc, lsq)] = int(info[1])
-        assert res[(4, 0)] != res[(0, 0)] and res[(0, 1)] != res[(0, 0)], (i, res)
+            res[(msoc, lsq, osc)] = int(info[1])
+        assert res[(4, 0, 0)] != res[(0, 0, 0)] and res[(0, 1, 0)] != res[(0, 0, 0)] and res[(0, 0, 1)] != res[(0, 0, 0)], (i, res)

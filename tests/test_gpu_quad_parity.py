@@ -26,7 +26,7 @@ def test_quad_shipped_scenario_matches_oracle(Q):
     assert np.array_equal(xWS, Q.warm_start(Q.X0, Q.XF, N, S.QUAD_VIA)) and np.array_equal(S.QUAD_OB, Q.OB_CLAMPED)
     ob = S.QUAD_OB
     xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterSignedDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *ob, xWS, np.zeros((N, 4)), 1.0)
-    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1            # the drop-in runs the reference's IPOPT configuration (obca_quadcopter_reference_opts): so does the checker
+    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1; oo.obj_scaling = 1            # the drop-in runs the reference's IPOPT configuration (obca_quadcopter_reference_opts): so does the checker
     r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, ob, xWS, 1.0, opts=oo)
     assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
     assert xp.shape == (12, N + 1) and up.shape == (4, N) and lp.shape == (30, N + 1) and ts.shape == (N + 1,)
@@ -79,7 +79,7 @@ def test_quadcopter_dist_variant_matches_oracle(Q):
     N = 60; Ts = S.quad_sample_time(N)
     xWS = S.quad_warm_start(S.QUAD_X0, S.QUAD_XF, N)
     xp, up, ts, ef, t, lp, status = obca_amd.QuadcopterDist(S.QUAD_X0, S.QUAD_XF, N, Ts, S.QUAD_R, *S.QUAD_OB, xWS, None, 1.0)
-    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1            # the drop-in's default option set
+    oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1; oo.obj_scaling = 1            # the drop-in's default option set
     r = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, S.QUAD_OB, xWS, 1.0, opts=oo)
     assert ef == 1 and r["exitflag"] == 1 and status == "Optimal"
     assert np.abs(xp - r["xp"]).max() < 1e-5 and np.abs(up - r["up"]).max() < 1e-5 and np.abs(ts - r["timeScale"]).max() < 1e-8
@@ -102,7 +102,7 @@ def test_reference_main_call_runs_as_is(Q):
     assert np.array_equal(path[0], S.QUAD_X0[:3]) and np.array_equal(path[-1], S.QUAD_XF[:3])
     for fn, orc in ((obca_amd.QuadcopterDist, Q.quadcopter_dist), (obca_amd.QuadcopterSignedDist, Q.quadcopter_signed_dist)):
         xp, up, ts, ef, t, lp, status = fn(S.QUAD_X0, S.QUAD_XF, N_as, Ts_as, S.QUAD_R, *S.QUAD_OB, xWS, 0.5 * np.ones((N_as, 4)), 1, dual_ws=False)
-        oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1        # the drop-ins' default option set (IPOPT's second-order correction and least-squares y0 on)
+        oo = Q.default_opts(); oo.max_soc = 4; oo.lsq_init = 1; oo.obj_scaling = 1        # the drop-ins' default option set (IPOPT's second-order correction and least-squares y0 on)
         r = orc(Q.X0, Q.XF, N_as, Ts_as, Q.EGO_R, S.QUAD_OB, xWS, 1.0, opts=oo, dual_ws=0)
         assert ef == 1 and r["exitflag"] == 1 and status == "Optimal", (fn.__name__, ef, status)
         assert xp.shape == (12, N_as + 1) and up.shape == (4, N_as) and lp.shape == (30, N_as + 1)
@@ -181,7 +181,7 @@ def test_all_1024_quadcopter_bench_instances_match_oracle(Q):
 
 @pytest.mark.timeout(900)
 def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
-    """obca_quadcopter_reference_opts (IPOPT's defaults the reference's call runs with: max_soc = 4, least-squares initial multipliers; recalc_y = "no") in the
+    """obca_quadcopter_reference_opts (IPOPT's defaults the reference's call runs with: max_soc = 4, least-squares initial multipliers, gradient-based objective scaling; recalc_y = "no") in the
     quadcopter kernel against the oracle run with the same options, on 256 instances of the config-4 distribution: the same bar as the default option set (exit
     flags equal; same counts -> tight agreement; a branch flipped by round-off -> the same optimum); the options change the path of most instances, each of them
     alone too, and the kernel still refuses the switch it does not carry"""
@@ -192,10 +192,10 @@ def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
     B, N = 256, 60
     bt = S.make_quad_batch(B, N, random_endpoints=True)
     o = obca_amd.quadcopter_ipopt_opts()
-    assert o.max_soc == 4 and o.recalc_y == 0 and o.lsq_init == 1 and o.max_iter == 3000
+    assert o.max_soc == 4 and o.recalc_y == 0 and o.lsq_init == 1 and o.obj_scaling == 1 and o.max_iter == 3000
     base = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
     out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=o)
-    ref = oracle_pool.quad_oracle_all(bt, max_soc=4, lsq_init=1)
+    ref = oracle_pool.quad_oracle_all(bt, max_soc=4, lsq_init=1, obj_scaling=1)
     flips = 0
     for (i, ef, it, nreg, obj, up, t) in ref:
         assert out["exitflag"][i] == ef, (i, out["exitflag"][i], ef)
@@ -213,14 +213,14 @@ def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
     assert (out["iters"] != base["iters"]).mean() > 0.5      # the options are exercised
     print("quadcopter IPOPT configuration vs oracle options: %d / %d instances on another branch; iterations %d -> %d" % (flips, B, base["iters"].sum(), out["iters"].sum()))
     n = 64      # each switch alone, against the oracle with that switch alone
-    for (msoc, lsq) in ((4, 0), (0, 1)):
-        o1 = obca_amd.quadcopter_default_opts(); o1.max_soc = msoc; o1.lsq_init = lsq
+    for (msoc, lsq, osc) in ((4, 0, 0), (0, 1, 0), (0, 0, 1)):
+        o1 = obca_amd.quadcopter_default_opts(); o1.max_soc = msoc; o1.lsq_init = lsq; o1.obj_scaling = osc
         sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == B else v) for k, v in bt.items()}
         o1out = obca_amd.quadcopter_signed_dist_batch(sub["x0"], sub["xF"], N, bt["Ts"], bt["R"], bt["ob"], sub["xWS"], bt["timeWS"], opts=o1)
-        r1 = oracle_pool.quad_oracle_all(sub, max_soc=msoc, lsq_init=lsq)
+        r1 = oracle_pool.quad_oracle_all(sub, max_soc=msoc, lsq_init=lsq, obj_scaling=osc)
         same = sum(int(o1out["exitflag"][i] == ef and o1out["iters"][i] == it and o1out["info"][i, 6] == nreg) for (i, ef, it, nreg, obj, up, t) in r1)
-        assert all(o1out["exitflag"][i] == ef for (i, ef, *_r) in r1) and same >= n - 3, (msoc, lsq, same)
-        assert (o1out["iters"] != base["iters"][:n]).mean() > 0.3, (msoc, lsq)
+        assert all(o1out["exitflag"][i] == ef for (i, ef, *_r) in r1) and same >= n - 3, (msoc, lsq, osc, same)
+        assert (o1out["iters"] != base["iters"][:n]).mean() > 0.3, (msoc, lsq, osc)
     bad = obca_amd.quadcopter_ipopt_opts(); bad.recalc_y = 1
     with pytest.raises(obca_amd.ObcaError):
         obca_amd.quadcopter_signed_dist_batch(bt["x0"][:2], bt["xF"][:2], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][:2], bt["timeWS"], opts=bad)
@@ -239,8 +239,10 @@ def test_unreformulated_quadcopter_model_accepts_the_hip_solutions_at_N60(Q):
     N = 60; bt = S.make_quad_batch(8, N, seed=20260925, random_endpoints=True)
     for name, o in (("reference IPOPT configuration", obca_amd.quadcopter_ipopt_opts()), ("throughput defaults", None)):
         out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=o)
+        tol_s = 1e-3 if o is None else 0.2      # (with IPOPT's objective scaling 1 / 21 the scaled problem is solved to tol, barrier parameter and stationarity are 21 x looser in
+                                                 #  unscaled terms -- IPOPT's own unscaled acceptance is dual_inf_tol = 1 --: measured 0.08)
         for i in range(2):
             assert out["exitflag"][i] == 1
             c = unreformulated_quad_certificate(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], out["xp"][i], out["up"][i], out["timeScale"][i, 0], out["lp"][i], out["slack"][i])
             print("%s, instance %d: f %.10f (HIP %.10f), |c| %.1e, bound violation %.1e, stationarity %.1e, wrong-sign multiplier %.1e" % (name, i, c["f"], out["obj"][i], c["c"], c["viol"], c["stationarity"], c["wrong_sign"]))
-            assert abs(c["f"] - out["obj"][i]) < 1e-10 * abs(out["obj"][i]) and c["c"] < 1e-4 and c["viol"] == 0 and c["stationarity"] < 1e-3 and c["wrong_sign"] < 1e-6
+            assert abs(c["f"] - out["obj"][i]) < 1e-10 * abs(out["obj"][i]) and c["c"] < 1e-4 and c["viol"] == 0 and c["stationarity"] < tol_s and c["wrong_sign"] < 1e-6

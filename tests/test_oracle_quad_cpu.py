@@ -181,3 +181,19 @@ def test_quad_least_squares_multipliers_vs_dense_autograd(Q, dist):
         r0 = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0, opts=o, dual_ws=0)      # the reference's own start: singular system, y stays 0
         r1 = Q.quadcopter_signed_dist(Q.X0, Q.XF, 16, 1.25, Q.EGO_R, Q.OB_CLAMPED, xw, 1.0, dual_ws=0)
         assert r0["exitflag"] == 1 and r0["iters"] == r1["iters"] and r0["obj"] == r1["obj"]
+
+
+def test_quad_gradient_based_objective_scaling_option(Q):
+    """opts.obj_scaling: IPOPT's default nlp_scaling_method (gradient-based, max gradient 100).  On QuadcopterSignedDist the largest objective gradient at the reference's start is
+    the slack penalty 1e2 + 2e3 * 1 = 2 100: the algorithm runs on f / 21 (fewer inertia rungs, termination 21 x looser in unscaled terms: the optimum moves by ~1e-4 relative);
+    on QuadcopterDist (no slack variable) the largest gradient is 0.25 + 10 t = 10.25 < 100: factor 1, the solve must not change by a bit"""
+    N = 30; Ts = round(0.25 * 80 / N * 100) / 100
+    xWS = Q.warm_start(Q.X0, Q.XF, N, [(1.6, 1.4, 0.3), (2.9, 1.9, 0.3), (6.6, 4.5, 2.5), (7.9, 4.5, 2.5)])
+    o = Q.default_opts(); o.obj_scaling = 1
+    a = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    b = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, opts=o)
+    assert a["exitflag"] == 1 and b["exitflag"] == 1 and (a["iters"], a["nreg"]) != (b["iters"], b["nreg"])
+    assert abs(a["obj"] - b["obj"]) < 2e-3 * abs(a["obj"]) and b["obj"] >= a["obj"] - 1e-6 * abs(a["obj"])      # the unscaled objective is what is reported; the looser solve stops a little higher
+    c = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    d = Q.quadcopter_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, opts=o)
+    assert c["exitflag"] == 1 and (c["iters"], c["nreg"], c["obj"]) == (d["iters"], d["nreg"], d["obj"]) and np.array_equal(c["xp"], d["xp"])

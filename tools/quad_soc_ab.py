@@ -1,5 +1,5 @@
-"""quadcopter kernel: time of a synchronous batch solve with the default options, with IPOPT's second-order correction, with its least-squares initial multipliers and
-with both (obca_quadcopter_reference_opts);
+"""quadcopter kernel: time of a synchronous batch solve with the default options, with IPOPT's second-order correction, with its least-squares initial multipliers, with its
+gradient-based objective scaling, and with all three (obca_quadcopter_reference_opts);
 OBCA_HIP_LIBRARY selects the library (same-box A/B against the previous build)"""
 import sys, os, json, time
 import numpy as np
@@ -14,12 +14,13 @@ bt = S.make_quad_batch(B, N, random_endpoints=True)
 qb = QuadBatch(Context(0), B, N)
 qb.upload(bt["x0"], bt["xF"], bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
 res = {}
-for name in ("default", "max_soc4", "lsq_init", "ipopt"):
+for name in ("default", "max_soc4", "lsq_init", "obj_scaling", "ipopt"):
     o = None
     if name != "default":
-        o = obca_amd.quadcopter_ipopt_opts()      # max_soc = 4, lsq_init = 1
-        if name == "max_soc4": o.lsq_init = 0
-        if name == "lsq_init": o.max_soc = 0
+        o = obca_amd.quadcopter_ipopt_opts()      # max_soc = 4, lsq_init = 1, obj_scaling = 1
+        if name == "max_soc4": o.lsq_init = 0; o.obj_scaling = 0
+        if name == "lsq_init": o.max_soc = 0; o.obj_scaling = 0
+        if name == "obj_scaling": o.max_soc = 0; o.lsq_init = 0
     try:
         qb.solve(o)
     except obca_amd.ObcaError as e:
