@@ -66,8 +66,9 @@ typedef struct obca_batch obca_batch;
  * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
  * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, one launch of 1 024: 21.7 k -> 15.9 k solves/s with its two switches.)
- * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, gradient-based NLP scaling (half-space rows enter with
- * unit length instead), the watchdog.  The quadcopter kernel carries max_soc and lsq_init (obca_quadcopter_reference_opts; its reference call sets recalc_y = "no",
+ * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, the watchdog.  IPOPT's gradient-based scaling scales no row
+ * of these NLPs (half-space rows enter with unit length besides) and the objective by 1 (parking) / 100 / 2 100 (quadcopter: opts.obj_scaling).  The quadcopter kernel carries
+ * max_soc, lsq_init and obj_scaling (obca_quadcopter_reference_opts; its reference call sets recalc_y = "no",
  * and its entry points refuse an option record that sets recalc_y).  DESIGN.md sections 2, 9. */
 typedef struct obca_opts {
     double tol; int max_iter;

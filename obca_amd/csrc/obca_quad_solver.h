@@ -410,7 +410,7 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #define QRR_PAD 767                                  // unused slot of the Riccati record: target of dummy stores
 // ---------------------------------------------------------------- Riccati backward sweep on the matrix cores
 // (Round 1 ran the sweep as four LDS / VALU phases: bound by LDS bandwidth, every fp64 FMA of its products read two operands from LDS, 10 k clocks per stage.)  Here the
-// whole recursion of an instance runs on wavefront 0 with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (23 per stage); the stage record is gathered
+// whole recursion of an instance runs on its wavefront (QNT = 64: the instance IS one wavefront; the WAVE0 sections below are written for any QNT) with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (23 per stage); the stage record is gathered
 // from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
 //   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
 //   Register kb of a tile in D layout is the B operand of K-block kb (rows 4 kb .. 4 kb + 3), and the A operand of the TRANSPOSED tile.
@@ -671,7 +671,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     WAVE0_END
     SYNC();
     QPROF(QPF_BORDER);
-    {   // stored ONCE: both wavefronts write the shared slot, it must never hold an intermediate value
+    {   // stored ONCE: every lane writes the shared slot, it must never hold an intermediate value
         const int ok = sh.bord_ok; so.ok = ok;
         if (!ok) return;
     }
@@ -955,7 +955,7 @@ OBCA_FN void q_eval_trial(QShared &sh, double alpha, double &f, double &th1, dou
         sh.red[0][lane] = lf; sh.red[1][lane] = lth; sh.red[2][lane] = lbar;
     }
     SYNC();
-    // finish the values in registers and store each shared slot exactly once (both wavefronts write them; see eval_trial in obca_solver.h)
+    // finish the values in registers and store each shared slot exactly once (every lane writes them; see eval_trial in obca_solver.h)
     double fr = red_sum(sh.red[0]), br = red_sum(sh.red[2]); const double tr = red_sum(sh.red[1]);
     SYNC();
     fr += (N + 1) * (0.25 * t + 5 * t * t); br += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
