@@ -62,10 +62,10 @@ typedef struct obca_batch obca_batch;
  *   obca_default_opts   -- the three switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below and what bench.py's `value` runs.
  * The numbers behind that split: both settings solve every instance of the three bench batches (identical exit flags, every solution passes the a-posteriori checker);
  * the IPOPT configuration costs 6 / 5 / 15 % more iterations and 12 x the inertia-correction rungs (the least-squares start leaves an indefinite Lagrangian Hessian early on):
- * 253.5 k -> 198.1 k, 152.6 k -> 122.0 k, 125.4 k -> 96.6 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
+ * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
  * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
- * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, one launch of 1 024: 21.7 k -> 15.9 k solves/s with its two switches.)
+ * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, pipelined: 36.7 k -> 31.4 k solves/s with its three switches.)
  * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, the watchdog.  IPOPT's gradient-based scaling scales no row
  * of these NLPs (half-space rows enter with unit length besides) and the objective by 1 (parking) / 100 / 2 100 (quadcopter: opts.obj_scaling).  The quadcopter kernel carries
  * max_soc, lsq_init and obj_scaling (obca_quadcopter_reference_opts; its reference call sets recalc_y = "no",
