@@ -1,6 +1,8 @@
-"""Generates tests/golden/dense_quad_N60.npz: the reference's UN-reformulated quadcopter NLP (oracle/ipm_ref60_quad.py) solved by the dense Algorithm A of oracle/ipm_ref80.py on
-instances of the config-4 bench batch (N = 60; the library's closed-form dual start, as bench.py uses it).  Resumable: instances already in the file are kept.
-usage: python tests/golden/make_dense_quad_N60.py [count] [--check]      (--check: one N = 10 instance against the C oracle, nothing written)"""
+"""Dense Algorithm A (oracle/ipm_ref80.py: attempt) on the reference's UN-reformulated quadcopter NLP (oracle/ipm_ref60_quad.py).  NO fixture of it is committed: unlike the parking
+problem (tests/golden/dense_N80.npz) the quadcopter NLP has many local solutions and the dense solve -- another scaling, slacks on every bound -- ends in another one than the
+C oracle (`--check`, N = 10, 13 minutes: dense 26.93, oracle 19.54, both "Optimal", and the un-reformulated model accepts the oracle's point with f = 19.54).  The pin of the
+quadcopter reformulations is therefore the certificate of tests/test_pin_cpu.py (the model evaluated at the returned solutions); this script stays as the way to repeat the
+experiment:  python tests/golden/make_dense_quad_N60.py --check   |   python tests/golden/make_dense_quad_N60.py [count]   (writes tests/golden/dense_quad_N60.npz, ~1 h per instance)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
