@@ -1016,7 +1016,9 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
     // The iterate is updated in place, so the compiler cannot hoist a load over an earlier store (may alias): QAP_R items per lane are processed at a time,
     // all their loads first (indices clamped, the multiplier arrays cover every primal variable), then the arithmetic and the stores -- one memory round trip
     // per chunk instead of one per item (a lone wavefront per SIMD has nothing else to hide the latency with).
+#ifndef QAP_R
 #define QAP_R 6
+#endif
     QPAR(lane) {
         for (int base = 0; base < l.n; base += QAP_R * QNT) {
             double v[QAP_R], dv[QAP_R], zl[QAP_R], zu[QAP_R];
