@@ -49,12 +49,21 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
     const int inst = mode ? b.order[blockIdx.x] : (int)blockIdx.x;
     if (inst < 0 || inst >= B) return;
+#ifdef OBCA_POISON      // diagnostic build: whatever the previous workgroup on this CU left in LDS is replaced by NaNs before anything is initialised
+    {
+        const double nan_ = __longlong_as_double(-1LL);
+        double *w = (double *)&g_sh;
+        for (int i = threadIdx.x; i < (int)(sizeof(Shared) / sizeof(double)); i += OB_NT) w[i] = nan_;
+        for (int i = threadIdx.x; i < (int)OB_DYN_LDS_DOUBLES(N); i += OB_NT) g_traj[i] = nan_;
+        __syncthreads();
+    }
+#endif
     if (threadIdx.x == 0) {
         Inst &I = g_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.zn = (gdbl *)(b.zn + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
-        I.oc = (gdbl *)(b.oc + (size_t)inst * b.s_oc);
+        I.oc = nullptr;
         g_sh.soc.csoc = b.csoc ? (gdbl *)(b.csoc + (size_t)inst * b.s_csoc) : nullptr;
 #ifdef OBCA_PROFILE
         I.tlast = clock64();
@@ -186,6 +195,15 @@ struct QDevBufs {
 __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_kernel(int B, int N, QDevBufs b, Opts o, int max_soc, int lsq_init, int obj_scaling) {
     const int inst = blockIdx.x;
     if (inst >= B) return;
+#ifdef OBCA_POISON
+    {
+        const double nan_ = __longlong_as_double(-1LL);
+        double *w = (double *)&quad::gq_sh;
+        for (int i = threadIdx.x; i < (int)(sizeof(quad::QShared) / sizeof(double)); i += QNT) w[i] = nan_;
+        for (int i = threadIdx.x; i < (N + 2) * (QS + QU); i += QNT) quad::gq_traj[i] = nan_;
+        __syncthreads();
+    }
+#endif
     if (threadIdx.x == 0) {
         quad::QInst &I = quad::gq_sh.inst;
         I.prob = (const gdbl *)(b.prob + (size_t)inst * b.s_prob);
@@ -253,6 +271,19 @@ struct obca_batch {
 
 #define HIPCHK(bt, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (bt)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
 static inline int fin(obca_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
+// Device work buffers never carry what a previous owner of the memory left in them: every allocation is filled once, on the stream of the batch it belongs to (the
+// lanes' streams do not synchronise with the null stream).  The product build clears them; -DOBCA_POISON (diagnostic build, tools/determinism_ragged.py) fills them with
+// the all-ones NaN pattern instead -- and the kernels then also poison their LDS at entry -- so that any read of a value nothing has written yet shows up as NaN in the results.
+#ifdef OBCA_POISON
+#define OBCA_FILL_BYTE 0xFF
+#else
+#define OBCA_FILL_BYTE 0
+#endif
+static hipError_t dev_alloc(void **p, size_t bytes, hipStream_t stream) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    return hipMemsetAsync(*p, OBCA_FILL_BYTE, bytes, stream);
+}
 
 static int pinned_reserve(std::string &err, double **p, size_t *cap, size_t need) {
     if (*cap >= need) return 0;
@@ -419,14 +450,14 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
         d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_csoc = (size_t)(lmax.zxL - lmax.pi);
         size_t tot = 0;
-#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = hipMalloc((void **)&(ptr), by_); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = dev_alloc((void **)&(ptr), by_, bt->stream); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.zn, B * d.s_z); ALLOC(d.d, B * d.s_z);
-        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs); ALLOC(d.oc, B * d.s_oc);
+        ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);      // (d.oc stays null: the condensed obstacle sums of the parking kernel live in LDS since round 4)
         ALLOC(d.info, B * 8); ALLOC(d.dws, B * N1 * bt->nObMax); ALLOC(d.prof, B * 16);
         ALLOC(d.slice, B * SL_SIZE);
         bt->dcap_stage = B * (size_t)lmax.nprimal;                       // nprimal >= the output prefix
         ALLOC(bt->stage, bt->dcap_stage);
-        if (hipMalloc((void **)&d.order, (B + 1) * sizeof(int)) != hipSuccess) { bt->err = "hipMalloc(order) failed"; free_dev(bt); return -2; }
+        if (dev_alloc((void **)&d.order, (B + 1) * sizeof(int), bt->stream) != hipSuccess) { bt->err = "hipMalloc(order) failed"; free_dev(bt); return -2; }
         tot += (B + 1) * sizeof(int);
 #undef ALLOC
         bt->bytes = (long long)tot;
@@ -509,7 +540,7 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     hipSetDevice(bt->device);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
     if (o.max_soc > 0 && !bt->d.csoc) {      // the second-order correction keeps its right-hand-side rows per instance
-        hipError_t e_ = hipMalloc((void **)&bt->d.csoc, (size_t)bt->cap * bt->d.s_csoc * sizeof(double));
+        hipError_t e_ = dev_alloc((void **)&bt->d.csoc, (size_t)bt->cap * bt->d.s_csoc * sizeof(double), bt->stream);
         if (e_ != hipSuccess) { bt->d.csoc = nullptr; bt->err = std::string("hipMalloc(csoc): ") + hipGetErrorString(e_); return -2; }
         bt->bytes += (long long)((size_t)bt->cap * bt->d.s_csoc * sizeof(double));
     }
@@ -599,6 +630,9 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
     const int nchunks = (B + chunk - 1) / chunk;
     const int nw = std::min<int>(nchunks, (int)ctx->slots.size());
     std::atomic<int> next(0);
+    // OBCA_CHUNK_PERM = s (diagnostic, tests/test_gpu_determinism.py): the t-th ticket of the queue is chunk (t + s) mod nchunks for even s, the chunks in descending order
+    // from there for odd s -- which lane (stream, cached batch, staging buffers) solves which chunk must not matter to a single bit of the results
+    int perm = 0; if (const char *e = getenv("OBCA_CHUNK_PERM")) perm = atoi(e) > 0 ? atoi(e) : 0;
     std::vector<int> rcs(nw, 0); std::vector<std::string> errs(nw);
     for (int w = 0; w < nw; w++) {      // lanes get their stream on first use (see obca_create_multi)
         Slot &s = ctx->slots[w];
@@ -608,8 +642,9 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
         Slot &s = ctx->slots[w];
         hipSetDevice(s.device);
         for (;;) {
-            const int c = next.fetch_add(1);
-            if (c >= nchunks) break;
+            const int t = next.fetch_add(1);
+            if (t >= nchunks) break;
+            const int c = !perm ? t : ((perm & 1) ? ((nchunks - 1 - t) + perm) % nchunks : (t + perm) % nchunks);
             const int lo = c * chunk, n = std::min(chunk, B - lo);
             const int rc = fn(s, lo, n, errs[w]);
             if (rc) { rcs[w] = rc; next.store(nchunks); break; }
@@ -804,7 +839,7 @@ static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, i
     QDevBufs &d = bt->d; const size_t N1 = N + 1;
     d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = QDIR_DOUBLES(l);      /* two direction buffers (dv | dy) + the rows of a second-order correction, see QCS */ d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
     size_t tot = 0;
-#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (hipMalloc((void **)&(ptr), by_) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
+#define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (dev_alloc((void **)&(ptr), by_, stream) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
     ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
     ALLOC(d.oc, B * d.s_oc); ALLOC(d.info, (size_t)B * 8); ALLOC(d.prof, (size_t)B * 16); ALLOC(bt->stage, (size_t)B * l.so);
 #undef ALLOC

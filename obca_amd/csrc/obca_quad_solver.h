@@ -570,7 +570,7 @@ OBCA_FN int q_riccati_body_mfma(QShared &sh, double rho) {      // wavefront 0
             for (int r = 0; r < 4; r++) {
                 const int i = g + 4 * r; double v = 0.0, w = 0.0;
                 if (i < QX && j < QX) { v = rec[QR(QSR_H + i * QZ + j)]; if (i == j) v += rho; }
-                if (i < QX) { if (j == 0) w = rec[QR(QSR_HC + 2 * i)] - rho * (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i])); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
+                if (i < QX) { if (j == 0) w = rec[QR(QSR_HC + 2 * i)] - rho * (sh.soc_on == 2 ? 0.0 : (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]))); else if (j >= 2 && j < QC) w = (j - 2 == i) ? 1.0 : 0.0; }
                 PD[r][L_] = v; pnD[r][L_] = w; BmD[r][L_] = 0.0;
             }
         }
@@ -807,7 +807,7 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 const gdbl *rN = sh.inst.as + (size_t)N * QSP;
 #pragma unroll
                 for (int i = 0; i < QX; i++) {
-                    const double e = sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]);
+                    const double e = sh.soc_on == 2 ? 0.0 : (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]));      // (2: the least-squares multiplier system has a zero row there; QCS holds nothing yet)
                     double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
                     for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
                     dpi[i] = -a_;

@@ -345,14 +345,55 @@ OBCA_FN double red_sum(const double *r) { return red_sum_t<OB_NT>(r); }
 OBCA_FN double red_max(const double *r) { return red_max_t<OB_NT>(r); }
 OBCA_FN double red_min(const double *r) { return red_min_t<OB_NT>(r); }
 
-// *p += v on a double in LDS (ds_add_f64; relaxed, workgroup scope: the instance is one wavefront)
-OBCA_FN void lds_add(double *p, double v) {
+// Sum of the condensed contributions (12 doubles) of the obstacles of a stage, in the order of the obstacles -- the sums are the same bits in every run, on every box.
+// Items are stage-major (item = k nOb + j), so the lanes of one round that belong to a stage are neighbours: position p = min(j, lane) within the stage's run of lanes.
+// A running sum walks down the run, one lane per step (wave_shr:1 moves it to the next lane; nOb - 1 uniform steps, all lanes take part in the moves, only the lane whose
+// turn it is adds); the last lane of the run stores the 12 sums.  A stage whose obstacles straddle two rounds is continued: lane 0 of the next round starts from the stored
+// partial sums (LDS traffic of one wavefront is in order, the rounds in program order).  The first obstacle of a stage starts from +0, as the emulation's cleared cell does.
+// (Round 4 used ds_add_f64 here: up to 16 lanes of one instruction on one address, relying on the hardware serving them in lane order -- nothing documents that, fp64 addition
+// is not associative, and the driver's round-4 GPU run saw two runs of the same inputs differ.  tools/micro/lds_atomic_order.hip probes the order)
 #ifdef OBCA_EMU
-    *p += v;
-#else
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+OBCA_FN void obs_sum_ordered(double *ocs, const ObsCond &cd, int k, int j, bool on, int nOb, int lane) {
+    (void)j; (void)nOb; (void)lane;
+    if (!on) return;
+    double *o = ocs + (size_t)k * OB_OC;
+    for (int i = 0; i < 6; i++) o[i] += cd.Hpp[i];
+    for (int i = 0; i < 3; i++) { o[6 + i] += cd.gz[i]; o[9 + i] += cd.gcorr[i]; }
 }
+#else
+OBCA_FN void obs_sum_ordered(double *ocs, const ObsCond &cd, int k, int j, bool on, int nOb, int lane) {
+    double c[OB_OC], run[OB_OC];
+#pragma unroll
+    for (int i = 0; i < 6; i++) c[i] = cd.Hpp[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c[6 + i] = cd.gz[i]; c[9 + i] = cd.gcorr[i]; }
+    double *o = ocs + (size_t)k * OB_OC;
+    const int p = j < lane ? j : lane;
+    LDS_SYNC();                                        // the partial sums the previous round stored are visible (and the compiler keeps the order)
+    const bool cont = on && lane == 0 && j > 0;        // the stage began in the previous round
+#pragma unroll
+    for (int i = 0; i < OB_OC; i++) run[i] = 0.0;
+    if (cont) {
+#pragma unroll
+        for (int i = 0; i < OB_OC; i++) run[i] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < OB_OC; i++) run[i] += c[i];
+    for (int s = 1; s < nOb; s++) {                    // uniform
+        double t[OB_OC];
+#pragma unroll
+        for (int i = 0; i < OB_OC; i++) t[i] = dpp_f64<0x138>(run[i]);      // wave_shr:1 -- lane l receives lane l - 1's running sum
+        if (on && p == s) {
+#pragma unroll
+            for (int i = 0; i < OB_OC; i++) run[i] = t[i] + c[i];
+        }
+    }
+    if (on && (j == nOb - 1 || lane == OB_NT - 1)) {   // end of the stage's run in this round (the last item of all is a last obstacle)
+#pragma unroll
+        for (int i = 0; i < OB_OC; i++) o[i] = run[i];
+    }
+}
+#endif
 // the per-instance constants the (stage, obstacle) block code reads, copied into scalar registers (as LDS reads they would sit in vector registers for the whole item loop)
 OBCA_FN void obs_consts(const Consts &s_, Consts &c) {
     c.N = UNIFORM(s_.N); c.nOb = UNIFORM(s_.nOb); c.M = UNIFORM(s_.M); c.dist = UNIFORM(s_.dist); c.fixTime = UNIFORM(s_.fixTime);
@@ -470,7 +511,9 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
     const gdbl *z = I.z; gdbl *zn = I.zn;
     double red[11][OBCA_NL];                 // per-lane partial results, reduced over the wavefront in registers
     double *ocs = stg_base(sh);              // 12 condensed sums per stage (LDS: the region of the sweeps' buffers, idle during the assembly)
-    PAR(lane) { for (int i = lane; i < (N + 1) * OB_OC; i += OB_NT) ocs[i] = 0.0; }
+#ifdef OBCA_EMU
+    PAR(lane) { for (int i = lane; i < (N + 1) * OB_OC; i += OB_NT) ocs[i] = 0.0; }      // (on the GPU the first obstacle of a stage starts the sum)
+#endif
     LDS_SYNC();
     // ---- (a) obstacle blocks: one lane per (stage, obstacle)
     PAR(lane) {
@@ -479,9 +522,15 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
         const int nit = (N + 1) * nOb;
 #pragma unroll
         for (int rr = 0; rr < (KEEP ? OB_KEEP : 1); rr++)      // KEEP: the rounds are unrolled so that keep[rr] is a fixed set of registers; otherwise one pass of the plain item loop
-        for (int it = lane + (KEEP ? rr * OB_NT : 0); it < nit; it += (KEEP ? nit : OB_NT)) {
-            int k = it / nOb, j = it - k * nOb;
-            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
+        // (the round loop is UNIFORM -- its bounds sit in scalar registers -- and a lane without an item in the last round skips the item code: the ordered sum of the
+        // condensed contributions below exchanges registers between the lanes and needs all of them)
+        for (int it0 = KEEP ? rr * OB_NT : 0; it0 < nit; it0 += (KEEP ? nit : OB_NT)) {
+            const int it = it0 + lane; const bool on = it < nit;
+            int k = 0, j = 0;
+            ObsIn<VM> in; ObsCond cd;
+            if (on) {
+            k = it / nOb; j = it - k * nOb;
+            load_obs<VM>(I, sh, z, k, j, in);
             double crs[4] = {0, 0, 0, 0};
             if (SOC) {
 #pragma unroll
@@ -527,16 +576,12 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
                 for (int i = 0; i < 4; i++) { SEAM(in.mu[i]); SEAM(in.zm[i]); SEAM(in.y[i]); }
                 SEAM(in.so); SEAM(in.zso); SEAM(in.sl); SEAM(in.zs1); SEAM(in.X); SEAM(in.Y); SEAM(in.psi);
             }
-            ObsCond cd;
             obs_block<0, VM, (SOC && !FUSED) ? 1 : 0, LSQ>(c, in, mu, dw, dc, &cd, &st, nullptr, nullptr, crs);
-            // the condensed contribution goes straight into the stage's 12 sums in LDS (rounds 1-3 wrote a record per (stage, obstacle) to HBM and the stage part read nOb of them back:
-            // 72 doubles of traffic per stage and pass).  The lanes of one wavefront that hit the same sum are served in lane order, the rounds in program order: the sums are the same
-            // bits in every run, and the host emulation adds in the same order.
-            double *o = ocs + (size_t)k * OB_OC;
-#pragma unroll
-            for (int i = 0; i < 6; i++) lds_add(o + i, cd.Hpp[i]);
-#pragma unroll
-            for (int i = 0; i < 3; i++) { lds_add(o + 6 + i, cd.gz[i]); lds_add(o + 9 + i, cd.gcorr[i]); }
+            }
+            // the condensed contribution goes into the stage's 12 sums in LDS (rounds 1-3 wrote a record per (stage, obstacle) to HBM and the stage part read nOb of them back:
+            // 72 doubles of traffic per stage and pass), summed over the obstacles in a FIXED order: obs_sum_ordered
+            obs_sum_ordered(ocs, cd, k, j, on, nOb, lane);
+            if (on) {
             if (!c.dist) fsl += 1e2 * in.sl + 1e4 * in.sl * in.sl;
             double r[4]; obs_rows<VM>(c, in, r);
             th += fabs(r[0]) + fabs(r[1]) + fabs(r[2]) + fabs(r[3]);
@@ -548,6 +593,7 @@ OBCA_FN void assemble_obs(const Inst &I, Shared &sh, double mu_, double dw_, dou
                 for (int i = 0; i < 4; i++) dd[VM + i] = in.mu[i];
                 dd[VM + 4] = in.so; dd[VM + 5] = c.dist ? in.sl : 1.0;
                 bar += log_prod(dd);
+            }
             }
         }
         red[0][LI(lane)] = st.dmax; red[1][LI(lane)] = st.pmax; red[3][LI(lane)] = st.cmin; red[10][LI(lane)] = st.cmax;

@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the GPU suite: the parity tests of the SURVEY section-8 rows (HIP path against the oracle / the dense pins) run FIRST, the determinism tests next, the
+# bit-equality tests of the plumbing (chunked host calls, multi-device contexts, ranks) LAST -- `pytest -x` on the driver's box then stops, if it stops, with the parity
+# evidence already on the record.  The sort is stable: the order inside a file is the order written.
+_GPU_FILE_ORDER = {"test_gpu_parity.py": 0, "test_gpu_quad_parity.py": 1, "test_gpu_determinism.py": 2, "test_gpu_multi.py": 9}
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: _GPU_FILE_ORDER.get(os.path.basename(str(it.fspath)), 5))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle as O

@@ -1,0 +1,143 @@
+"""Bit-reproducibility of the HIP path (run with -m gpu).  The driver's round-4 run met two runs of the same inputs that differed in the last bits (ragged batch, two
+chunks in flight on two streams): fp64 sums whose order the hardware chose.  Everything here goes through libobca_hip.so and asserts EQUAL BITS:
+
+  * ragged batches (3-10 and 1-16 obstacles per instance, 1-8 rows per obstacle) solved as one device-resident batch = the same batch cut into chunks of every size over
+    1-4 concurrent worker lanes, fresh and reused lane batches, permuted chunk -> lane assignment, >= 200 host-pointer calls, both option sets;
+  * a batch that is re-solved while other launches run on the same GPU;
+  * the quadcopter path likewise."""
+import os
+import numpy as np
+import pytest
+from obca_amd import scenarios as S
+
+pytestmark = pytest.mark.gpu
+INFO = ("status", "iters", "obj", "pinf", "dinf", "mu", "nreg", "exitflag")
+
+
+@pytest.fixture(scope="module")
+def OA():
+    import obca_amd
+    obca_amd.Context(0).close()
+    return obca_amd
+
+
+def _args(bt, N):
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    return (bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"]), xWS
+
+
+def _resident(OA, bt, N, opts, repeats=3):
+    args, xWS = _args(bt, N)
+    ctx = OA.Context(0)
+    b = OA.Batch(ctx, len(bt["x0"]), N)
+    b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    outs = []
+    for _ in range(repeats):
+        b.solve(opts=opts); outs.append(b.download())
+    b.close(); ctx.close()
+    return outs
+
+
+def _diff(a, b):
+    """what differs between two result tuples of the same batch ('' if nothing does)"""
+    B = len(a["info"]); bad = []
+    if not np.array_equal(a["info"], b["info"]):
+        w = np.argwhere(a["info"] != b["info"])
+        i = int(w[0, 0])
+        bad.append("info of %d instances, first %d: %s" % (len(set(w[:, 0])), i, ", ".join("%s %r|%r" % (INFO[c], a["info"][i, c], b["info"][i, c]) for c in w[w[:, 0] == i, 1])))
+    for k in ("xp", "up", "timeScale"):
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b[k])):
+            d = np.abs(np.asarray(a[k]) - np.asarray(b[k])).reshape(B, -1).max(axis=1)
+            bad.append("%s of %d instances (max %.3e)" % (k, int((d > 0).sum()), d.max()))
+    for k in ("lp", "np", "sl"):
+        nb = sum(0 if np.array_equal(a[k][i], b[k][i]) else 1 for i in range(B))
+        if nb:
+            bad.append("%s of %d instances" % (k, nb))
+    return "; ".join(bad)
+
+
+# (generator arguments, horizon, instances, option set, host-pointer calls): 3-10 obstacles of 3-4 rows (BASELINE config 5 as the bench runs it), 1-16 obstacles of up to 8
+# rows (the library's limits), each under the throughput options and under the reference's IPOPT configuration
+CASES = [("3-10 obstacles, default options", dict(seed=3), 40, 150, "default", 120),
+         ("3-10 obstacles, IPOPT configuration", dict(seed=3), 40, 150, "ipopt", 40),
+         ("1-16 obstacles up to 8 rows, default options", dict(seed=5, min_obstacles=1, max_extra=13, rows=(3, 8), max_rows=64), 40, 120, "default", 60),
+         ("1-16 obstacles up to 8 rows, IPOPT configuration", dict(seed=5, min_obstacles=1, max_extra=13, rows=(3, 8), max_rows=64), 40, 120, "ipopt", 20)]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name,gen,N,B,optset,calls", CASES, ids=[c[0] for c in CASES])
+def test_ragged_batch_same_bits_whatever_the_chunking_and_the_lanes(OA, name, gen, N, B, optset, calls):
+    bt = S.make_mixed_batch(B, N, **gen)
+    opts = OA.ipopt_opts() if optset == "ipopt" else None
+    refs = _resident(OA, bt, N, opts)
+    ref = refs[0]
+    assert (ref["exitflag"] == 1).mean() > 0.85
+    for r in refs[1:]:
+        assert _diff(r, ref) == "", "the resident batch, solved again: " + _diff(r, ref)
+    args, _ = _args(bt, N)
+    rng = np.random.default_rng(17)
+    fixed = [(1000, 2), (37, 3), (20, 4), (64, 1), (75, 2), (11, 4), (50, 3), (B, 1)]      # (1000, 2): the combination of the round-4 failure -- two chunks of B / 2, two lanes
+    failures = []; done = 0; r = 0
+    try:
+        while done < calls:
+            chunk, slots = fixed[r] if r < len(fixed) else (int(rng.integers(5, B + 10)), int(rng.integers(1, 5)))
+            os.environ["OBCA_CHUNK"] = str(chunk); os.environ["OBCA_SLOTS"] = str(slots)
+            ctx = OA.Context(0)
+            for rep in range(3):                                # calls 2, 3: cached lane batches, and another chunk -> lane assignment
+                if rep == 2:
+                    os.environ["OBCA_CHUNK_PERM"] = str(1 + int(rng.integers(0, 7)))
+                out = OA.parking_signed_dist_batch(*args, opts=opts, device=ctx)
+                os.environ.pop("OBCA_CHUNK_PERM", None)
+                d = _diff(out, ref); done += 1
+                if d:
+                    failures.append("chunk %d, %d lanes, call %d: %s" % (chunk, slots, rep, d))
+            ctx.close(); r += 1
+    finally:
+        for k in ("OBCA_CHUNK", "OBCA_SLOTS", "OBCA_CHUNK_PERM"):
+            os.environ.pop(k, None)
+    assert not failures, "%d of %d host-pointer calls differ from the resident batch: %s" % (len(failures), done, " || ".join(failures[:5]))
+
+
+def test_bench_batch_same_bits_with_other_launches_in_flight(OA):
+    """config 2 (1 024 instances, N = 80): four device-resident copies solved concurrently on four streams, eight times over -- every download holds the bits of a lone solve"""
+    N, B = 80, 1024
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    ref = _resident(OA, bt, N, None, repeats=1)[0]
+    args, xWS = _args(bt, N)
+    bs = []
+    for _ in range(4):
+        b = OA.Batch(OA.Context(0), B, N)
+        b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+        bs.append(b)
+    for rnd in range(8):
+        for b in bs:
+            b.solve(sync=False)
+        for i, b in enumerate(bs):
+            b.sync(); d = _diff(b.download(), ref)
+            assert d == "", "round %d, copy %d: %s" % (rnd, i, d)
+    for b in bs:
+        b.close()
+
+
+def test_quadcopter_same_bits_whatever_the_chunking(OA):
+    N, B = 20, 48
+    bt = S.make_quad_batch(B, N, seed=5)
+    keys = ("xp", "up", "timeScale", "exitflag", "lp", "slack", "info")
+    for optset in ("default", "ipopt"):
+        opts = OA.quadcopter_ipopt_opts() if optset == "ipopt" else None
+        ctx = OA.Context(0)
+        qb = OA.QuadBatch(ctx, B, N); qb.upload(bt["x0"], bt["xF"], bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"])
+        qb.solve(opts=opts); ref = qb.download(); qb.solve(opts=opts); again = qb.download(); qb.close(); ctx.close()
+        for k in keys:
+            assert np.array_equal(np.asarray(again[k]), np.asarray(ref[k])), (optset, "resident, solved again", k)
+        try:
+            for chunk, slots in ((7, 4), (48, 1), (13, 2), (5, 3), (24, 2)):
+                os.environ["OBCA_CHUNK"] = str(chunk); os.environ["OBCA_SLOTS"] = str(slots)
+                ctx = OA.Context(0)
+                for rep in range(4):
+                    out = OA.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=opts, device=ctx)
+                    for k in keys:
+                        assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k])), (optset, chunk, slots, rep, k)
+                ctx.close()
+        finally:
+            os.environ.pop("OBCA_CHUNK", None); os.environ.pop("OBCA_SLOTS", None)
