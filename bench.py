@@ -20,17 +20,24 @@ contract says): solve times are heavy-tailed (median 27 factorisation passes, sl
 last instance leaves the GPU idle for half of its duration.  After the timed region the SAME process measures `--sync-steps` synchronous
 steps (one launch alone on the GPU, HIP events on the launch stream): that is the per-launch kernel time the roofline is computed from.
 
+`value` is measured with the REFERENCE's solver configuration (obca_reference_opts: IPOPT's second-order correction max_soc = 4, recalc_y = "yes" as ParkingSignedDist.jl:41
+sets it, least-squares initial multipliers; the quadcopter call: obca_quadcopter_reference_opts).  The library's throughput defaults (those switches off: a fifth fewer passes
+per solve) are the secondary leg `config.fast_options`; `--fast-options` times them instead.
+
 Extra objects in the JSON line:
-  roofline     : dominant kernel (obca_parking_ipm_kernel / obca_quad_ipm_kernel), one launch alone on the GPU, HIP events on its stream.  Two fractions are formed and
-                 `bound` names the larger one: "hbm" = ALGORITHMIC bytes of the launch (the per-pass streaming model of DESIGN.md section 5 -- every array of the
-                 per-instance state times the number of times a factorisation pass reads / writes it -- x the passes the kernel reports) / the launch time / 8 TB/s;
-                 "mfma" = executed fp64 flops (SURVEY 8d Model B) / the launch time / 78.6 TFLOP/s (fp64 vector = fp64 matrix peak).  `traffic` = HBM bytes of one launch
-                 measured in THIS run: bench.py re-runs itself once per counter under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace` (separate passes,
-                 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); null if rocprofv3 is not available (`--no-pmc` skips it).
-                 `pipelined_*` relate the same work to the wall time per pipelined step (device utilisation, not a kernel roofline).
-  cpu_baseline : the CPU oracle (C restatement, NOT IPOPT; gcc -O3 -march=native) on a bounded sample of the same instances, on the box's host cores.
+  roofline     : dominant kernel (obca_parking_ipm_kernel / obca_quad_ipm_kernel), one launch alone on the GPU, HIP events on its stream.  SURVEY 8d Model B (the condensed KKT
+                 solve these kernels are): algorithmic work = executed fp64 flops per factorisation pass x passes reported by the kernel, against 78.6 TFLOP/s (fp64 vector =
+                 matrix peak) -> `bound` "mfma", `achieved`, `frac`; algorithmic HBM bytes = the I/O of the solves only (`algorithmic_bytes_io_only`, ~21.6 KB per solve).
+                 `traffic` = bytes of one launch measured in THIS run: bench.py re-runs itself once per counter under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace`
+                 (separate passes, 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); null if rocprofv3 is not available (`--no-pmc` skips it).
+                 `implementation_*` = the kernel's own streaming model (what the code moves per pass because an instance's 0.2 MB of state does not fit its LDS share; NOT
+                 algorithmic bytes), `traffic_over_io_only` = how far the measured traffic is above the algorithm's; `regime_of_value` relates the same work to the wall time
+                 of a pipelined step (device utilisation in the regime `value` is measured in, not a kernel roofline).
+  cpu_baseline : the CPU oracle (C restatement, NOT IPOPT; gcc -O3 -march=native, oracle/Makefile `native`) on a bounded sample of the same distribution, on the box's host
+                 cores, with the option set of the timed GPU steps.  Every entry of config.other_configs carries its own.
   config       : besides the workload, what a caller of the drop-in sees (never `value`): `host_pointer_solves_per_s` = obca_parking_signed_dist_batch on 16 384
-                 host-array instances, PCIe and (un)packing included (what a Julia ccall gets), `single_batch_sync_solves_per_s` = one batch issued and waited for.
+                 host-array instances, PCIe and (un)packing included (what a Julia ccall gets), `single_batch_sync_solves_per_s` = one batch issued and waited for,
+                 `other_configs` = BASELINE configs 3, 4, 5 at their per-GPU batch sizes (reference options, throughput options, CPU leg).
 """
 import argparse
 import json
@@ -98,7 +105,19 @@ def b_iter_quad(N):
 F_PASS_QUAD = 60 * 33000 + 305 * 2400 + 61 * 2500 + 1.0e5   # Riccati 16-state sweep + 305 box blocks + stage derivatives + trial evaluations
 
 
-def live_pmc_traffic(kernel, cfg, batch):
+IO_BYTES_PER_SOLVE_QUAD = 29.2e3      # quadcopter N = 60, problem data in + result tuple out
+
+
+def io_bytes_parking(N, vOb, ragged):
+    """SURVEY 8d Model B: the HBM bytes the ALGORITHM needs per solve = its I/O (problem data and warm start in: x0, xF, rx, ry, ryaw, xWS, uWS, the H-rep; result tuple out:
+    x, u, timeScale, lambda, mu, sl): 761 doubles in + 1 944 out = 21.6 KB at N = 80 with 3 obstacles / 5 rows; mean over the instances of a ragged batch"""
+    def one(v):
+        v = np.ravel(v); nOb = len(v); M = int(np.sum(v)); N1 = N + 1
+        return 8.0 * ((8 + 3 * N1 + 4 * N1 + 2 * N + 3 * M + nOb + 10) + (4 * N1 + 2 * N + N1 + M * N1 + 4 * nOb * N1))
+    return float(np.mean([one(v) for v in vOb])) if ragged else one(vOb)
+
+
+def live_pmc_traffic(kernel, cfg, batch, fast=False):
     """HBM bytes PER LAUNCH of `kernel`, measured now: this script is run again, once per counter, under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and
     WRITE_SIZE cannot share a pass on gfx950) in its `--pmc-child` mode -- the same batch, one step + one synchronous step, nothing else.  Returns (bytes, note) with
     bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2: FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950, MI355X_MICROARCH.md / HBM, calibrated
@@ -111,7 +130,7 @@ def live_pmc_traffic(kernel, cfg, batch):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="obca_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--config", str(cfg), "--batch", str(batch)]
+               "--config", str(cfg), "--batch", str(batch)] + (["--fast-options"] if fast else [])
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
@@ -134,42 +153,71 @@ def live_pmc_traffic(kernel, cfg, batch):
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle = test infrastructure, used here only as the timed CPU leg)
+CPU_SAMPLE_PER_CORE = {2: 512, 3: 96, 4: 24, 5: 96}      # instances per host core: 2-5 s of oracle work per core and config (the default line carries all four)
+
+
 def _cpu_worker(args):
-    k, per = args
+    """one host core: `per` instances of the config's distribution, one oracle solve at a time, with the option set the GPU steps are timed with"""
+    cfg, k, per, fast, rows, shared = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    from obca_amd import scenarios as S
-    bt = S.make_batch(S.BACKWARDS, per, 80, seed=SEED + 1000 * k)      # worker 0 = the first instances of rank 0's batch
+    N = CONFIGS[cfg]["N"]
+    if rows is None:                                # configs without a planner: worker k draws its own instances (other seeds of the same distribution)
+        rows, shared = make_host_batch(cfg, per, SEED + 1000 * k)
     t0 = time.perf_counter(); ok = 0; its = 0
+    if CONFIGS[cfg]["kind"] == "quad":
+        import oracle_quad as Q
+        o = Q.default_opts()
+        if not fast:
+            o.max_soc = 4; o.lsq_init = 1; o.obj_scaling = 1      # obca_quadcopter_reference_opts
+        for i in range(per):
+            r = Q.quadcopter_signed_dist(rows["x0"][i], rows["xF"][i], N, float(rows["Ts"][i, 0]), shared["R"], shared["ob"], rows["xWS"][i].reshape(N + 1, 12), float(rows["timeWS"][i, 0]), opts=o)
+            ok += int(r["exitflag"] == 1); its += r["iters"]
+        return ok, its, time.perf_counter() - t0
+    import oracle as O
+    o = O.default_opts()
+    if not fast:
+        o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1            # obca_reference_opts
+    vOb, A, b = obstacle_args(cfg, rows, shared, per)
     for i in range(per):
-        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
-        r = O.parking_signed_dist(bt["x0"][i], bt["xF"][i], 80, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"],
-                                  bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
-        ok += r["exitflag"]; its += r["iters"]
+        xWS = rows["xWS"][i].reshape(N + 1, 4); uWS = rows["uWS"][i].reshape(N, 2)
+        r = O.parking_signed_dist(rows["x0"][i], rows["xF"][i], N, float(rows["Ts"][i, 0]), shared["L"], shared["ego"], shared["XYbounds"], vOb[i] if cfg == 5 else vOb,
+                                  A[i] if cfg == 5 else A, b[i] if cfg == 5 else b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS, opts=o)
+        ok += int(r["exitflag"] == 1); its += r["iters"]
     return ok, its, time.perf_counter() - t0
 
 
-def cpu_baseline():
-    """oracle (kind 'port') on the host cores this process may use (<=64), 256 instances of the config-2 distribution per core (~10-15 s each)."""
+def cpu_baseline(cfg, fast=False, rows=None, shared=None):
+    """The oracle (kind 'port': the C restatement of the reference's path, NOT IPOPT) on the host cores this process may use (<= 64), CPU_SAMPLE_PER_CORE[cfg] instances of
+    the config's distribution per core, with the SAME option set the timed GPU steps run (the reference's IPOPT configuration unless --fast-options).  Configs whose warm
+    starts come from a planner (3, 4) take the first instances of the job's own batch (`rows`), the others draw fresh ones per core.  Runs before any HIP context exists in
+    this process (fork)."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    os.environ["OBCA_ORACLE_NATIVE"] = "1"      # the workers time the -O3 -march=native build, compiled here on the machine that runs it (SURVEY 8d)
+    os.environ["OBCA_ORACLE_NATIVE"] = "1"      # the workers time the -O3 -march=native build (oracle/Makefile: `native`), compiled on the machine that runs it (SURVEY 8d)
     O.build_native()
+    quad = CONFIGS[cfg]["kind"] == "quad"
+    if quad:
+        import oracle_quad as Q
+        Q.build_native()
     cores = min(effective_cpus(), 64)            # the threads this process may really use (affinity mask and cgroup quota), not the CPUs the box shows
-    per = 256
+    per = CPU_SAMPLE_PER_CORE[cfg]
+    if rows is not None:
+        per = max(1, min(per, rows["x0"].shape[0] // cores))
     n = per * cores
+    jobs = [(cfg, k, per, fast, None if rows is None else {q: v[k * per:(k + 1) * per] for q, v in rows.items()}, shared) for k in range(cores)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(k, per) for k in range(cores)])
+        res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     ok = sum(r[0] for r in res); its = sum(r[1] for r in res)
     busy = max(r[2] for r in res)
     os.environ.pop("OBCA_ORACLE_NATIVE", None)
     return dict(value=round(ok / busy, 2), unit="solves/s", cores=cores, kind="port",
-                sample=f"{n} instances of the config-2 distribution (seed 20260925+1000k), {per} per core, one oracle/obca_oracle.c solve at a time per core "
-                       f"(CPU restatement of the reference's IPOPT path, not IPOPT itself; gcc -O3 -march=native); "
+                sample=f"{n} instances of the config-{cfg} distribution, {per} per core, one oracle solve at a time per core (oracle/obca_oracle{'_quad' if quad else ''}.c: the CPU "
+                       f"restatement of the reference's IPOPT path, not IPOPT itself; gcc -O3 -march=native), options: "
+                       f"{'library throughput defaults' if fast else 'the reference IPOPT configuration (the option set of the timed GPU steps)'}; "
                        f"{ok}/{n} converged, mean {its / n:.1f} iterations, wall {wall:.1f}s")
 
 
@@ -324,51 +372,84 @@ def pipelined_rate(batches, steps, warmup, opts=None):
     return time.perf_counter() - t0
 
 
-def other_config_line(cfg, local, steps=10, streams=4, seed=SEED):
-    """compact, driver-visible rate of another BASELINE config at its per-GPU batch size: `steps` pipelined steps, every instance validated; warm starts planned before the
-    timed steps (the planner is host code outside the path)"""
-    C_ = CONFIGS[cfg]; N = C_["N"]; B = C_["per_gpu"]
-    t0 = time.perf_counter(); rows, shared = make_host_batch(cfg, B, seed); t_make = time.perf_counter() - t0
-    bs = device_batches(cfg, rows, shared, B, N, streams, local)
-    dt = pipelined_rate(bs, steps, streams)
-    bs[0].solve(sync=True); k_ms = bs[0].kernel_ms(); k_ms = float(k_ms if CONFIGS[cfg]["kind"] == "quad" else k_ms[0])
-    out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
-    for bq in bs:
-        bq.close()
-    return dict(config=cfg, workload=C_["name"], batch_per_gpu=B, steps=steps, streams=streams, solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
-                validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
-                mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3), batch_made_in_s=round(t_make, 2))
-
-
-def ipopt_options_leg(cfg, rows, shared, B, N, nS, local, steps, out_default):
-    """the SAME batch solved with the reference's IPOPT configuration switched on (max_soc = 4, recalc_y = "yes", least-squares initial multipliers: obca_amd.ipopt_opts(),
-    ParkingSignedDist.jl:41-43 + IPOPT defaults): pipelined rate, iterations / passes, and how many instances end somewhere else than with the default options"""
+def config_opts(cfg, fast):
+    """the option record of a config's timed steps: the reference's IPOPT configuration of the call (obca_reference_opts / obca_quadcopter_reference_opts) unless `fast`
+    (None = the library's throughput defaults)"""
     import obca_amd
-    quad = CONFIGS[cfg]["kind"] == "quad"      # (the quadcopter call: obca_quadcopter_reference_opts -- max_soc = 4, least-squares y0; QuadcopterSignedDist.jl:29 sets recalc_y = "no")
-    o = obca_amd.quadcopter_ipopt_opts() if quad else obca_amd.ipopt_opts()
+    if fast:
+        return None
+    return obca_amd.quadcopter_ipopt_opts() if CONFIGS[cfg]["kind"] == "quad" else obca_amd.ipopt_opts()
+
+
+OPTION_NAMES = {("parking", False): "reference IPOPT configuration: max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_reference_opts; ParkingSignedDist.jl:41-43 + IPOPT defaults)",
+                ("parking", True): "library throughput defaults: max_soc = 0, recalc_y = no, y0 = 0 (obca_default_opts)",
+                ("quad", False): "reference IPOPT configuration: max_soc = 4, lsq_init = 1, obj_scaling = 1, recalc_y = no (obca_quadcopter_reference_opts; QuadcopterSignedDist.jl:28-31 + IPOPT defaults)",
+                ("quad", True): "library throughput defaults: max_soc = 0, y0 = 0, no objective scaling (obca_quadcopter_default_opts)"}
+
+
+def other_host_batch(cfg, seed=SEED):
+    """host batch of another BASELINE config at its per-GPU size.  Config 3's warm starts are Hybrid A* plans (host side, ~8 ms each per core): the default line plans 256
+    (start, goal) pairs and repeats them 8 x to fill the 2 048 instances of the batch (`bench.py --config 3` plans all 2 048)."""
+    B = CONFIGS[cfg]["per_gpu"]; t0 = time.perf_counter(); note = None
+    if cfg == 3:
+        rows, shared = make_host_batch(cfg, 256, seed)
+        rows = {k: np.concatenate([v] * (B // 256), axis=0) for k, v in rows.items()}
+        note = "256 planned (start, goal) pairs x 8"
+    else:
+        rows, shared = make_host_batch(cfg, B, seed)
+    return rows, shared, round(time.perf_counter() - t0, 2), note
+
+
+def other_config_line(cfg, local, prepared, cpu, steps=10, streams=4):
+    """compact, driver-visible rate of another BASELINE config at its per-GPU batch size: `steps` pipelined steps with the reference's IPOPT configuration, every instance
+    validated; the same with the library's throughput options beside it; warm starts planned before the timed steps (the planner is host code outside the path)"""
+    C_ = CONFIGS[cfg]; N = C_["N"]; B = C_["per_gpu"]
+    rows, shared, t_make, note = prepared
+    quad = C_["kind"] == "quad"
+    res = {}
+    for fast in (False, True):
+        o = config_opts(cfg, fast)
+        bs = device_batches(cfg, rows, shared, B, N, streams, local)
+        dt = pipelined_rate(bs, steps, streams, opts=o)
+        bs[0].solve(opts=o, sync=True); k_ms = bs[0].kernel_ms(); k_ms = float(k_ms if quad else k_ms[0])
+        out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
+        for bq in bs:
+            bq.close()
+        res[fast] = dict(solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()),
+                         mean_iterations=round(float(out["info"][:, 1].mean()), 2), mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3))
+    line = dict(config=cfg, workload=C_["name"], batch_per_gpu=B, steps=steps, streams=streams, options=OPTION_NAMES[(C_["kind"], False)])
+    line.update(res[False])
+    line.update(batch_made_in_s=t_make, batch_note=note, fast_options=dict(options=OPTION_NAMES[(C_["kind"], True)], **res[True]), cpu_baseline=cpu)
+    return line
+
+
+def options_leg(cfg, rows, shared, B, N, nS, local, steps, out_main, fast):
+    """the SAME batch solved with the OTHER option set (fast = True: the library's throughput defaults, when the timed steps ran the reference's IPOPT configuration; and the
+    other way round): pipelined rate, iterations / passes, and how many instances end somewhere else than with the option set of the timed steps; never `value`"""
+    quad = CONFIGS[cfg]["kind"] == "quad"
+    o = config_opts(cfg, fast)
     bs = device_batches(cfg, rows, shared, B, N, nS, local)
     dt = pipelined_rate(bs, steps, nS, opts=o)
     bs[0].solve(opts=o, sync=True); k_ms = bs[0].kernel_ms(); k_ms = float(k_ms if quad else k_ms[0])
     out = bs[0].download(); ok = validated_mask(cfg, rows, shared, out, N)
     for bq in bs:
         bq.close()
-    both = (out["exitflag"] == 1) & (out_default["exitflag"] == 1)
-    dx = np.array([np.abs(np.asarray(out["xp"][i]) - np.asarray(out_default["xp"][i])).max() for i in range(B)])
-    du = np.array([np.abs(np.asarray(out["up"][i]) - np.asarray(out_default["up"][i])).max() for i in range(B)])
-    df = np.abs(out["obj"] - out_default["obj"]) / np.maximum(1.0, np.abs(out_default["obj"]))
-    dts = np.abs(out["timeScale"][:, 0] - out_default["timeScale"][:, 0])
+    both = (out["exitflag"] == 1) & (out_main["exitflag"] == 1)
+    dx = np.array([np.abs(np.asarray(out["xp"][i]) - np.asarray(out_main["xp"][i])).max() for i in range(B)])
+    du = np.array([np.abs(np.asarray(out["up"][i]) - np.asarray(out_main["up"][i])).max() for i in range(B)])
+    df = np.abs(out["obj"] - out_main["obj"]) / np.maximum(1.0, np.abs(out_main["obj"]))
+    dts = np.abs(out["timeScale"][:, 0] - out_main["timeScale"][:, 0])
     differs = both & ((df > 2.1e-3) | (dts > 1e-3)) if quad else both & ((dx > 1e-3) | (du > 1e-3) | (df > 1e-4) | (dts > 1e-4))
-    return dict(options="max_soc = 4, recalc_y = no, lsq_init = 1, obj_scaling = 1 (obca_amd.quadcopter_ipopt_opts())" if quad else "max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_amd.ipopt_opts())", solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+    return dict(options=OPTION_NAMES[("quad" if quad else "parking", fast)], solves_per_s=round(int(ok.sum()) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
                 validated=int(ok.sum()), exitflag_ok=int((out["exitflag"] == 1).sum()), mean_iterations=round(float(out["info"][:, 1].mean()), 2),
                 mean_passes=round(float((out["info"][:, 1] + out["info"][:, 6]).mean()), 2), kernel_ms_one_launch=round(k_ms, 3),
-                exitflag_differs_from_default=int((out["exitflag"] != out_default["exitflag"]).sum()), iterations_differ_from_default=int((out["info"][:, 1] != out_default["info"][:, 1]).sum()),
-                solution_differs_from_default=int(differs.sum()), worst_dx=float(dx[both].max()) if both.any() else None, worst_rel_objective=float(df[both].max()) if both.any() else None,
-                note=("solution_differs_from_default: instances solved by both settings whose objective differs by more than 2.1e-3 relative or time scale by 1e-3: IPOPT's objective scaling (1 / 21 on "
-                      "this NLP) terminates 21 x looser in unscaled terms than the default options, which do not scale; the cost has no term on the path, so the states of two solves of ONE "
+                exitflag_differs_from_timed_options=int((out["exitflag"] != out_main["exitflag"]).sum()), iterations_differ_from_timed_options=int((out["info"][:, 1] != out_main["info"][:, 1]).sum()),
+                solution_differs_from_timed_options=int(differs.sum()), worst_dx=float(dx[both].max()) if both.any() else None, worst_rel_objective=float(df[both].max()) if both.any() else None,
+                note=("solution_differs: instances solved by both option sets whose objective differs by more than 2.1e-3 relative or time scale by 1e-3: IPOPT's objective scaling (1 / 21 on "
+                      "this NLP) terminates 21 x looser in unscaled terms than the throughput options, which do not scale; the cost has no term on the path, so the states of two solves of ONE "
                       "local solution differ by up to 1e-2 (worst_dx is reported only); never `value`") if quad else
-                     "solution_differs_from_default: instances solved by both settings whose states / inputs differ by more than 1e-3, time scale by 1e-4 or objective by 1e-4 relative "
+                     "solution_differs: instances solved by both option sets whose states / inputs differ by more than 1e-3, time scale by 1e-4 or objective by 1e-4 relative "
                      "(the path's stated tolerance, SURVEY 8c): the NLP is non-convex, another iteration path may end in another local solution; never `value`")
-
 
 
 def single_process(a):
@@ -385,7 +466,7 @@ def single_process(a):
     vOb, A, b = obstacle_args(cfg, rows, shared, B)
     xWS = rows["xWS"].reshape(B, N + 1, 4); uWS = rows["uWS"].reshape(B, N, 2); keep = {}
     call = lambda: obca_amd.parking_signed_dist_batch(rows["x0"], rows["xF"], N, rows["Ts"][:, 0], shared["L"], shared["ego"], shared["XYbounds"], vOb, A, b,
-                                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, uWS, device="all", buffers=keep)
+                                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, uWS, opts=config_opts(cfg, a.fast_options), device="all", buffers=keep)
     for _ in range(max(1, a.warmup // 4)):
         out = call()
     steps = max(1, a.steps // 10)
@@ -425,10 +506,11 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="the Julia route: ONE process drives every visible GPU through a multi-device context (obca_create_multi) and the "
                     "host-pointer entry point; a step = one call on batch x devices host-array instances, PCIe included (parking configs)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the run rocprofv3 wraps (one step + one synchronous step of the same batch, no output)")
-    ap.add_argument("--ipopt-options", action="store_true", help="parking configs: the TIMED steps run the reference's IPOPT configuration (max_soc = 4, recalc_y, least-squares initial "
-                    "multipliers: obca_amd.ipopt_opts()) instead of the library defaults")
-    ap.add_argument("--no-ipopt-leg", action="store_true", help="skip config.ipopt_options (the same batch with the reference's IPOPT configuration switched on)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (compact rates of BASELINE configs 4 and 5)")
+    ap.add_argument("--fast-options", action="store_true", help="the TIMED steps run the library's throughput defaults (no second-order correction, no recalc_y, y0 = 0) instead of "
+                    "the reference's IPOPT configuration (obca_reference_opts / obca_quadcopter_reference_opts), which is what `value` is measured with since round 5")
+    ap.add_argument("--ipopt-options", action="store_true", help="(accepted for old job scripts: the reference's IPOPT configuration is the default now)")
+    ap.add_argument("--no-ipopt-leg", "--no-options-leg", dest="no_ipopt_leg", action="store_true", help="skip config.fast_options (the same batch with the other option set)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (compact rates of BASELINE configs 3, 4 and 5, each with its CPU leg)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.single_process:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (the contract's launch line), so that an 8-GPU run cannot be lost to a missing torchrun
@@ -449,15 +531,22 @@ def main():
     if a.steps < 1:
         raise SystemExit("bench.py: --steps must be >= 1")
     cfg = a.config; C = CONFIGS[cfg]; N = C["N"]; quad = C["kind"] == "quad"
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and cfg == 2:
-        cpu = cpu_baseline()          # before any HIP context exists in this process (fork-safe)
+    fast = bool(a.fast_options)
     rows = shared = None
     B = a.batch or C["per_gpu"]; B_total = B * world
     t_plan0 = time.perf_counter()
     if rank == 0:
         rows, shared = make_host_batch(cfg, B_total, SEED + a.seed_offset, hybrid=(a.warm_start == "hybrid"), world=world)
     t_plan = time.perf_counter() - t_plan0          # (world == 1: the planner runs inside make_host_batch)
+    # ---- CPU legs (the oracle on the host cores), before any HIP context exists in this process (they fork): this config's, and those of the other configs of the default line
+    cpu = None; other_prepared = {}; other_cpu = {}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, fast, rows if needs_planner(cfg, a.warm_start == "hybrid") else None, shared)
+    if rank == 0 and world == 1 and cfg == 2 and not a.no_other_configs:
+        for c_ in (3, 4, 5):
+            other_prepared[c_] = other_host_batch(c_)
+            if not a.no_cpu_baseline:
+                other_cpu[c_] = cpu_baseline(c_, False, other_prepared[c_][0] if needs_planner(c_, False) else None, other_prepared[c_][1])
     import torch
     import obca_amd
     from obca_amd import sharding, validate as V
@@ -503,7 +592,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_opts = obca_amd.ipopt_opts() if (a.ipopt_options and not quad) else None
+    run_opts = config_opts(cfg, fast)      # the reference's IPOPT configuration of the config's call unless --fast-options
     for w in range(a.warmup):
         batches[w % nS].solve(opts=run_opts, sync=False)
     for bq in batches:
@@ -537,7 +626,7 @@ def main():
         for rep_ in range(3):       # the caller keeps its output arrays between calls (fresh ones cost a page fault per 4 KB inside the C call)
             th0 = time.perf_counter()
             ho = obca_amd.parking_signed_dist_batch(hx0, hxF, N, hTs, shared["L"], shared["ego"], shared["XYbounds"], hv, hA, hb,
-                                                    hx[:, :, 0], hx[:, :, 1], hx[:, :, 2], 0, hx, hu, device=local, buffers=keep)
+                                                    hx[:, :, 0], hx[:, :, 1], hx[:, :, 2], 0, hx, hu, opts=run_opts, device=local, buffers=keep)
             th = time.perf_counter() - th0; best = th if best is None else min(best, th); bestc = float(ho["time"]) if bestc is None else min(bestc, float(ho["time"]))
         nok = int((ho["exitflag"] == 1).sum())
         host_rate = dict(instances=B * reps, solves_per_s=round(nok / best, 1), seconds=round(best, 4), c_call_seconds=round(bestc, 4), c_call_solves_per_s=round(nok / bestc, 1),
@@ -555,12 +644,12 @@ def main():
             bq.upload(r2["x0"], r2["xF"], r2["Ts"][:, 0], s2["L"], s2["ego"], s2["XYbounds"], s2["vOb"], s2["A"], s2["b"], x2[:, :, 0], x2[:, :, 1], x2[:, :, 2], 0, x2, u2)
             dbs.append((bq, r2, s2))
         for w_ in range(nS):
-            dbs[w_][0].solve(sync=False)
+            dbs[w_][0].solve(opts=run_opts, sync=False)
         for bq, _, _ in dbs:
             bq.sync()
         torch.cuda.synchronize(); td0 = time.perf_counter()
         for k in range(a.steps):
-            dbs[k % nS][0].solve(sync=False)
+            dbs[k % nS][0].solve(opts=run_opts, sync=False)
         for bq, _, _ in dbs:
             bq.sync()
         torch.cuda.synchronize(); dtd = time.perf_counter() - td0
@@ -577,11 +666,11 @@ def main():
     # ---- results: every copy solved the same inputs and must hold the same bits
     outs = [bq.download() for bq in batches[:min(nS, a.steps + a.warmup)]]
     out = outs[0]
-    ipopt_leg = None; others = None
-    if rank == 0 and world == 1 and not a.no_ipopt_leg and not a.ipopt_options:
-        ipopt_leg = ipopt_options_leg(cfg, rows, shared, B, N, nS, local, max(8, min(a.steps, 40)), out)
+    other_leg = None; others = None
+    if rank == 0 and world == 1 and not a.no_ipopt_leg:
+        other_leg = options_leg(cfg, rows, shared, B, N, nS, local, max(8, min(a.steps, 40)), out, not fast)
     if rank == 0 and world == 1 and cfg == 2 and not a.no_other_configs:
-        others = [other_config_line(c_, local) for c_ in (4, 5)]
+        others = [other_config_line(c_, local, other_prepared[c_], other_cpu.get(c_)) for c_ in (3, 4, 5)]
     same = all(np.array_equal(o["info"], out["info"]) and np.array_equal(np.asarray(o["xp"]), np.asarray(out["xp"])) for o in outs[1:])
     # ---- gather the full result tuple of every instance on rank 0 (one gather), validate there: a solve counts only if exitflag == 1 AND the
     # returned trajectory passes the a-posteriori checker (obca_amd/validate.py, pure numpy, outside the timed region)
@@ -647,33 +736,39 @@ def main():
                 f_pass = f_pass_parking(N, len(np.ravel(vOb))); b_pass = b_pass_parking(N, len(np.ravel(vOb)), int(np.sum(vOb)))
             kernel = "obca_parking_ipm_kernel"
         tflops = passes0 * f_pass / (k_ms * 1e-3) / 1e12
-        traffic, tsrc = (None, "skipped (--no-pmc)") if a.no_pmc or world > 1 else live_pmc_traffic(kernel, cfg, B)
+        traffic, tsrc = (None, "skipped (--no-pmc)") if a.no_pmc or world > 1 else live_pmc_traffic(kernel, cfg, B, fast)
         fp64_frac = tflops / FP64_PEAK_TFLOPS
-        gbs = passes0 * b_pass / (k_ms * 1e-3) / 1e9 if b_pass is not None else None
-        hbm_frac = gbs / HBM_PEAK_GBS if gbs is not None else None
-        hbm_binds = hbm_frac is not None and hbm_frac >= fp64_frac
-        roof = {"bound": "hbm" if hbm_binds else "mfma",
-                "achieved": round(gbs, 1) if hbm_binds else round(tflops, 3), "peak": HBM_PEAK_GBS if hbm_binds else FP64_PEAK_TFLOPS, "unit": "GB/s" if hbm_binds else "TFLOP/s",
-                "frac": round(hbm_frac if hbm_binds else fp64_frac, 5),
+        # SURVEY 8d, Model B (the condensed variant these kernels are): executed flops; HBM bytes = I/O only -- the problem data in and the result tuple out, once per solve
+        io_bytes = B * (IO_BYTES_PER_SOLVE_QUAD if quad else io_bytes_parking(N, vOb, cfg == 5))
+        io_gbs = io_bytes / (k_ms * 1e-3) / 1e9
+        impl_bytes = passes0 * b_pass                                 # what the IMPLEMENTATION streams per launch by its own model: not the algorithm's bytes
+        impl_gbs = impl_bytes / (k_ms * 1e-3) / 1e9
+        step_s = dt / a.steps
+        roof = {"bound": "mfma",
+                "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp64_frac, 5),
                 "traffic": traffic, "traffic_source": tsrc,
-                "bound_detail": "two fractions of one launch alone on the GPU, the larger one is reported: hbm = algorithmic bytes (per-pass streaming model of the per-instance state, "
-                                "DESIGN.md section 5, x passes) / launch time / 8 TB/s; mfma = executed fp64 flops (SURVEY 8d Model B) / launch time / 78.6 TFLOP/s (fp64 vector = matrix peak; "
-                                "the parking kernel issues no MFMA).  Neither roof binds a LONE launch: it ends with its slowest instance (3-4 x the mean number of passes) and the sweeps of an "
-                                "instance are chains of dependent LDS round trips; see pipelined_* for the device under the pipelined load `value` is measured at",
-                "fp64_tflops": round(tflops, 3), "fp64_frac": round(fp64_frac, 5),
-                "hbm_algorithmic_gbs": round(gbs, 1) if gbs is not None else None, "hbm_algorithmic_frac": round(hbm_frac, 5) if hbm_frac is not None else None,
-                "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_ms_all": [round(x, 3) for x in ipm_ms],
+                "bound_detail": "SURVEY 8d Model B (condensed KKT solve): ALGORITHMIC work = executed fp64 flops per factorisation pass x the passes the kernel reports; algorithmic HBM bytes = the "
+                                "I/O of the solves only (algorithmic_bytes_io_only), a fraction ~1e-4 of the HBM roof -- so the flop roof is the one `frac` is quoted on: fp64 vector = fp64 matrix "
+                                "peak 78.6 TFLOP/s (the parking kernel issues no MFMA; the quadcopter sweep does).  `frac` is for ONE launch alone on the GPU (HIP events = rocprofv3 --stats); "
+                                "a lone launch ends with its slowest instance (3-4 x the mean number of passes), see `regime_of_value` for the pipelined load `value` is measured at",
+                "model": "SURVEY 8d Model B", "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_ms_all": [round(x, 3) for x in ipm_ms],
                 "kernel_timing": "HIP events on the launch stream around the interior-point launches of ONE synchronous step of rank 0's batch, measured in this process after the "
                                  "timed region (median of %d); nothing else runs on the GPU" % len(ipm_ms),
-                "passes_per_launch": int(passes0), "flops_per_pass_model": f_pass, "bytes_per_pass_model": b_pass,
-                "pipelined_tflops": round(passes0 * f_pass / (dt / a.steps) / 1e12, 3), "pipelined_fp64_frac": round(passes0 * f_pass / (dt / a.steps) / 1e12 / FP64_PEAK_TFLOPS, 5),
-                "pipelined_note": "the same work / (timed wall time / steps) with %d steps in flight: device utilisation of the timed region, not a kernel roofline" % nS}
-        if b_pass is not None:
-            roof.update(pipelined_hbm_algorithmic_gbs=round(passes0 * b_pass / (dt / a.steps) / 1e9, 1), pipelined_hbm_algorithmic_frac=round(passes0 * b_pass / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5))
-        if traffic is not None:     # measured HBM bytes of one launch over the kernel time / the pipelined step time of THIS run
-            roof.update(hbm_measured_gbs_one_launch=round(traffic / (k_ms * 1e-3) / 1e9, 1), hbm_measured_frac_one_launch=round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        hbm_measured_gbs_pipelined=round(traffic / (dt / a.steps) / 1e9, 1), hbm_measured_frac_pipelined=round(traffic / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                        traffic_over_algorithmic=round(traffic / (passes0 * b_pass), 3) if b_pass is not None else None)
+                "passes_per_launch": int(passes0), "flops_per_pass_model": f_pass, "fp64_tflops": round(tflops, 3), "fp64_frac": round(fp64_frac, 5),
+                "algorithmic_bytes_io_only": int(io_bytes), "hbm_io_only_gbs": round(io_gbs, 3), "hbm_io_only_frac": round(io_gbs / HBM_PEAK_GBS, 7),
+                "implementation_bytes": int(impl_bytes), "implementation_bytes_per_pass_model": b_pass, "implementation_hbm_gbs": round(impl_gbs, 1),
+                "implementation_hbm_frac": round(impl_gbs / HBM_PEAK_GBS, 5),
+                "implementation_note": "implementation_* = the kernel's own streaming model (every array of the per-instance state x the times a factorisation pass reads / writes it, DESIGN.md "
+                                       "section 5): what the code moves because an instance's state (0.2 MB) does not fit the LDS share of its CU, NOT algorithmic bytes.  The working set of a "
+                                       "resident batch (1 024 x 0.2 MB = 205 MB) is about the size of the 256 MiB Infinity Cache and FETCH_SIZE / WRITE_SIZE count fabric requests including MALL "
+                                       "hits (MI355X_MICROARCH.md, HBM), so much of `traffic` never reaches HBM and the 8 TB/s roof does not bind it",
+                "regime_of_value": {"note": "the same work over the wall time of a pipelined step (%d launches in flight): device utilisation in the regime `value` is measured in, not a kernel roofline" % nS,
+                                    "fp64_tflops": round(passes0 * f_pass / step_s / 1e12, 3), "fp64_frac": round(passes0 * f_pass / step_s / 1e12 / FP64_PEAK_TFLOPS, 5),
+                                    "implementation_hbm_gbs": round(impl_bytes / step_s / 1e9, 1), "implementation_hbm_frac": round(impl_bytes / step_s / 1e9 / HBM_PEAK_GBS, 5)}}
+        if traffic is not None:     # measured bytes of one launch over the kernel time / the pipelined step time of THIS run
+            roof.update(traffic_over_io_only=round(traffic / io_bytes, 1), traffic_over_implementation_model=round(traffic / impl_bytes, 3),
+                        traffic_gbs_one_launch=round(traffic / (k_ms * 1e-3) / 1e9, 1), traffic_frac_of_hbm_peak_one_launch=round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roof["regime_of_value"].update(traffic_gbs=round(traffic / step_s / 1e9, 1), traffic_frac_of_hbm_peak=round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4))
         if not quad:
             sched = batches[0].last_schedule()
             roof.update(ipm_launches_per_step=sched[0], slice_passes=sched[1], dualws_kernel_ms=round(float(np.median(dws_ms)), 3))
@@ -696,8 +791,8 @@ def main():
                                    "every rank for its own slice; end_to_end = validated solves of one batch / (planning + one step): the planner, not the solve, bounds a "
                                    "pipeline that plans every instance afresh; never `value`"},
                        "distinct_batches": distinct,
-                       "options": "obca_amd.ipopt_opts(): max_soc = 4, recalc_y = yes, lsq_init = 1" if run_opts is not None else "library defaults (obca_default_opts)",
-                       "ipopt_options": ipopt_leg,
+                       "options": OPTION_NAMES[(C["kind"], fast)],
+                       ("reference_options" if fast else "fast_options"): other_leg,
                        "other_configs": others,
                        "host_pointer": host_rate,
                        "host_pointer_note": "obca_parking_signed_dist_batch on host arrays (the entry point the Julia shim binds): packing, PCIe both ways, kernels, unpacking; never `value`"},

@@ -17,7 +17,8 @@ extern "C" {
  * opts (NULL = defaults): {xy resolution 0.25, yaw resolution [deg] 7.5, primitive length 0.6, max steer 0.6, steer samples per side 2,
  *   collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance [deg] 8, reverse cost 1.5, switch cost 2.0, steer cost 0.3,
  *   max expansions 400000, analytic expansion (1: try the shortest Reeds-Shepp curve to the goal from expanded nodes, as the reference does) 1,
- *   steer-change cost per radian 0.2}  (14 doubles).
+ *   steer-change cost per radian 0.2, weight of the heuristic 1 (hybrid_a_star.jl:64 H_COST), Reeds-Shepp length as a second heuristic 0 (hybrid_a_star.jl:58)}
+ *   (16 doubles; 14 until round 4).
  * Output: path[3k..3k+2] = x, y, yaw of node k (0.2 m apart), dir[k] = +1 / -1 (motion that led to the node), at most cap nodes.
  * Returns the number of nodes (>= 2); 0 = no path; -1 = bad arguments / cap too small; -2 = start or goal pose collides. */
 int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,

@@ -74,6 +74,13 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
 #endif
     __syncthreads();
     solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init);
+#ifdef OBCA_HWID      // diagnostic build (tools/determinism_hw.py): where the instance ran -- HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID -- read back
+                      // through obca_batch_debug_phase_cycles, slots 14 / 15; a result that differs between two runs can then be laid beside the hardware unit that produced it
+    if (threadIdx.x == 0) {
+        b.prof[(size_t)inst * 16 + 14] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        b.prof[(size_t)inst * 16 + 15] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <queue>
 #include <unordered_map>
 #include <vector>
@@ -260,7 +261,8 @@ extern "C" {
  * (M x 2), b).  ego = [front, left, rear, right] extents from the rear axle (main.jl:73), L = wheelbase, XYbounds = [xmin,xmax,ymin,ymax].
  * opts (may be NULL) = {xy resolution 0.25, yaw resolution deg 7.5, primitive length 0.6, max steer 0.6, #steer samples per side 2,
  *                       collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance deg 8, reverse cost 1.5, switch cost 2.0,
- *                       steer cost 0.3, max expansions 400000, analytic (Reeds-Shepp) expansion 1}.
+ *                       steer cost 0.3, max expansions 400000, analytic (Reeds-Shepp) expansion 1, steer-change cost 0.2, heuristic weight 1,
+ *                       Reeds-Shepp heuristic 0}  (16 doubles).
  * Output: path[3 * k] = x, y, yaw of the k-th node and dir[k] = +1 / -1 (motion that led to the node), up to cap nodes.
  * Returns the number of nodes (>= 2), 0 if no path was found, -1 on bad arguments, -2 if the start or the goal collides.
  */
@@ -272,6 +274,8 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
     const int nst = opts ? (int)opts[4] : 2; const double margin = opts ? opts[5] : 0.1, gtol = opts ? opts[6] : 0.3, ytol = (opts ? opts[7] : 8.0) * M_PI / 180;
     const double crev = opts ? opts[8] : 1.5, csw = opts ? opts[9] : 2.0, cst = opts ? opts[10] : 0.3; const long maxexp = opts ? (long)opts[11] : 400000;
     const double analytic = opts ? opts[12] : 1.0;
+    const double hweight = opts ? opts[14] : 1.0;       // weight of the heuristic (hybrid_a_star.jl:64 H_COST; > 1: greedier search, fewer expansions, longer paths)
+    const bool rs_heur = opts ? opts[15] != 0.0 : false; // max(grid heuristic, Reeds-Shepp length) as the heuristic (hybrid_a_star.jl:58 USE_NONHOLONOMIC_WITHOUT_OBSTACLE_HEURISTIC)
     const double cchg = opts ? opts[13] : 0.2;          // steer-change cost per radian (hybrid_a_star.jl:63 STEER_CHANGE_COST)       // analytic (Reeds-Shepp) expansion towards the goal, hybrid_a_star.jl:193-214: 0 = off,
                                                          // else the fraction of the steering lock its arcs use (1 = the reference's full lock)
     World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
@@ -308,7 +312,13 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
         const int ix = std::min(nx - 1, std::max(0, (int)std::lround((x - w.xmin) / res))), iy = std::min(ny - 1, std::max(0, (int)std::lround((y - w.ymin) / res)));
         const double h2 = hmap[(size_t)iy * nx + ix] < 1e8f ? hmap[(size_t)iy * nx + ix] : std::hypot(x - goal[0], y - goal[1]) + 5.0;
         const double Rmin = L / std::tan(smax);
-        return std::max(h2, Rmin * std::fabs(wrap(yaw - goal[2])) * 0.5);
+        double h = std::max(h2, Rmin * std::fabs(wrap(yaw - goal[2])) * 0.5);
+        if (rs_heur) {      // length of the shortest Reeds-Shepp curve to the goal: what the car needs at least, obstacles ignored (hybrid_a_star.jl:58, 542: max(c_h_dp, c_h_rs))
+            const double dx = goal[0] - x, dy = goal[1] - y, c = std::cos(yaw), s_ = std::sin(yaw);
+            const rs::Path p = rs::shortest((c * dx + s_ * dy) / Rmin, (-s_ * dx + c * dy) / Rmin, wrap(goal[2] - yaw));
+            if (p.n > 0) h = std::max(h, Rmin * p.total);
+        }
+        return hweight * h;
     };
     const int nyaw = (int)std::ceil(2 * M_PI / yres);
     auto key = [&](double x, double y, double yaw) -> long long {

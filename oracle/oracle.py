@@ -29,19 +29,22 @@ def build():
     return so
 
 
-def build_native():
-    """-O3 -march=native build for bench.py's cpu_baseline leg, compiled on the machine that times it (oracle/_native/, not tracked).  The parity
-    tests keep the portable -O2 build: -march=native lets gcc contract into FMAs, which moves the last bits of the iterates."""
+def native_dir():
+    """oracle/_native/<hash of the CPU model>: one native build per CPU model -- a copy made on another machine (the tree travels to the GPU box) must not be picked up"""
     import hashlib
-    try:      # one build per CPU model: a copy made on another machine (the tree travels to the GPU box) must not be picked up
+    try:
         cpu = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
     except OSError:
         cpu = []
-    d = os.path.join(_HERE, "_native", hashlib.sha1("".join(cpu).encode()).hexdigest()[:12]); os.makedirs(d, exist_ok=True)
-    so = os.path.join(d, "libobca_oracle.so"); src = os.path.join(_HERE, "obca_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-w", "-shared", "-o", so, src, "-lm"])
-    return so
+    return os.path.join(_HERE, "_native", hashlib.sha1("".join(cpu).encode()).hexdigest()[:12])
+
+
+def build_native():
+    """-O3 -march=native build for bench.py's cpu_baseline leg, compiled on the machine that times it (`make native`, oracle/Makefile holds both flag sets).
+    The parity tests keep the portable -O2 build: -march=native lets gcc contract into FMAs, which moves the last bits of the iterates."""
+    d = native_dir()
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native", "NATIVE_DIR=" + d])
+    return os.path.join(d, "libobca_oracle.so")
 
 
 def lib():

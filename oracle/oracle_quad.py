@@ -17,12 +17,22 @@ X0 = np.array([1, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]); XF = np.array([9, 3, 2, 0
 EGO_R = 0.25
 
 
+def build_native():
+    """the -O3 -march=native build bench.py's cpu_baseline leg times (oracle.build_native: `make native`)"""
+    import oracle as _O
+    _O.build_native()
+    return os.path.join(_O.native_dir(), "libobca_oracle_quad.so")
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libobca_oracle_quad.so"); src = os.path.join(_HERE, "obca_oracle_quad.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        if os.environ.get("OBCA_ORACLE_NATIVE") == "1":
+            so = build_native()
+        else:
+            so = os.path.join(_HERE, "libobca_oracle_quad.so"); src = os.path.join(_HERE, "obca_oracle_quad.c")
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, "-s"])
         _LIB = C.CDLL(so)
     return _LIB
 
