@@ -5,9 +5,9 @@ The HIP library is the only compute path: importing works anywhere, but every so
 device is missing -- there is no CPU fallback.
 """
 from .api import (ObcaError, Context, Batch, ParkingSignedDist, ParkingDist, DualMultWS, parking_signed_dist_batch, dualmult_ws_batch,
-                  default_opts, ipopt_opts, warm_restart_opts, library_path, build_library, QuadBatch, QuadcopterSignedDist, QuadcopterDist,
+                  default_opts, ipopt_opts, warm_restart_opts, selftest, library_path, build_library, QuadBatch, QuadcopterSignedDist, QuadcopterDist,
                   quadcopter_signed_dist_batch, quadcopter_default_opts, quadcopter_ipopt_opts)
 
 __all__ = ["ObcaError", "Context", "Batch", "ParkingSignedDist", "ParkingDist", "DualMultWS", "parking_signed_dist_batch",
-           "dualmult_ws_batch", "default_opts", "ipopt_opts", "warm_restart_opts", "library_path", "build_library", "QuadBatch", "QuadcopterSignedDist", "QuadcopterDist",
+           "dualmult_ws_batch", "default_opts", "ipopt_opts", "warm_restart_opts", "selftest", "library_path", "build_library", "QuadBatch", "QuadcopterSignedDist", "QuadcopterDist",
            "quadcopter_signed_dist_batch", "quadcopter_default_opts", "quadcopter_ipopt_opts"]

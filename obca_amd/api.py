@@ -84,6 +84,31 @@ EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visibl
            "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
 
 
+def selftest(device=0, repeats=4, opts=None):
+    """Does this GPU reproduce its own results?  The config-2 bench batch (1 024 instances, N = 80: every SIMD of the chip holds one) is solved `repeats` times as one
+    device-resident batch and every download is compared bit for bit with the first.  Returns a dict: `differing` = (instance, run) pairs that differ, `instances`,
+    `runs`, `solved`, `device`.  The kernels contain no atomics and no order-dependent reductions: on sound hardware `differing` is 0 -- 29 of the
+    30 MI355X leased in round 5 behaved so over thousands of solves; on the thirtieth every result of every process differed from run to run."""
+    from . import scenarios as S
+    N, B = 80, 1024
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    ctx = device if isinstance(device, Context) else Context(device)
+    b = Batch(ctx, B, N)
+    b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    ref = None; bad = 0
+    for _ in range(max(2, repeats)):
+        b.solve(opts=opts); o = b.download()
+        if ref is None:
+            ref = o; continue
+        bad += int(((o["info"] != ref["info"]).any(axis=1) | (np.abs(o["xp"] - ref["xp"]).reshape(B, -1).max(axis=1) > 0)).sum())
+    name = ctx.name()
+    b.close()
+    if not isinstance(device, Context):
+        ctx.close()
+    return dict(differing=bad, instances=B, runs=max(2, repeats), solved=int((ref["exitflag"] == 1).sum()), device=name)
+
+
 def warm_restart_opts():
     """options for a solve that starts from a (shifted) previous solution: small initial barrier and bound push, so the interior point
     does not first walk away from the active bounds (16 instead of 47 iterations on the config-2 batch)"""

@@ -2012,6 +2012,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     }
     sl.used += D.it + D.nreg - D.p_start + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc;      // (a correction, the rebuild after a rejected one and a multiplier re-estimate are full passes each)
     R.status = D.status; R.iters = D.it; R.nreg = D.nreg; R.obj = D.f; R.pinf = D.pinf; R.dinf = D.dinf; R.mu = D.mu;
+#if defined(OBCA_PROFILE) && !defined(OBCA_EMU)      // diagnostic counters of the IPOPT switches (slots behind the phase clocks): corrections tried / accepted, rebuilds, multiplier re-estimates
+    if (LANE0) { sh.prof[13] += sh.soc.nsoc; sh.prof[14] += sh.soc.nrebuild + 1e-3 * sh.soc.nsoc_acc; sh.prof[15] += sh.soc.nrecalc; }
+#endif
 }
 
 // Full solve of one instance (pointers already in g_sh.inst): first attempt, and on Error/UserLimit one re-solve from the last

@@ -353,3 +353,67 @@ def make_mixed_batch(B, N=80, seed=20260925, max_extra=7, min_obstacles=3, rows=
         vl.append(np.asarray(vOb) - 1); Al.append(A); bl.append(b)
     base.update(vOb=vl, A=Al, b=bl)
     return base
+
+
+def make_corridor_batch(B, N=80, seed=20260925, n_extra=(3, 7), clearance=(0.0, 0.2)):
+    """config-5 style batch whose extra obstacles BIND: the backwards-parking scenario plus n_extra[0]..n_extra[1] wedges per instance that narrow the road from its two
+    sides -- triangles standing on the upper wall (y = 11) or on the blocks beside the slot (y = 5), sloped rows through obstHrep -- with their tips `clearance` metres
+    beside the car body of the instance's own warm start, on alternating sides along the path.  The corridor stays one piece (no obstacle to pass on either side), the
+    warm start threads it, and the optimum -- shorter, smoother -- leans on the tips: separation rows are active where `make_mixed_batch`'s decoys never are.  A wedge is
+    kept only if no pose of the warm start overlaps it (separating-axis test; a negative clearance[0] lets the tips intrude that far into the warm start's swept body).
+    nOb runs from 3 to 3 + n_extra[1] (wedges that would block a later pose of the path are dropped), M = 5 + 3 per wedge.
+    Measured on the oracle with the reference's IPOPT configuration, 64 instances (round 5): clearance (0, 0.2): 64 / 64 solved in 45 iterations (decoys: 41), 0.23 wedges
+    touched per solution; tips intruding up to 0.05 / 0.15 / 0.3 m into the warm start: 50 / 44 / 23 of 64 solved, 110-155 iterations -- a warm start that penetrates
+    several obstacles is beyond this interior point without IPOPT's restoration phase, which is why the default keeps the warm start clear."""
+    rng = np.random.default_rng(seed)
+    base = make_batch(BACKWARDS, B, N, seed=seed)
+    sc = BACKWARDS
+    f, l, r, rt = EGO                                      # front, left, rear, right extents from the rear axle
+    vl, Al, bl = [], [], []
+
+    def touches(poly, xs, ys, yaws, margin):
+        """does the car rectangle at any pose overlap the convex polygon (separating axes: the car's two axes and the polygon's edge normals; vertices clockwise)"""
+        P = np.asarray(poly)
+        c, s = np.cos(yaws), np.sin(yaws)
+        u = c[:, None] * (P[None, :, 0] - xs[:, None]) + s[:, None] * (P[None, :, 1] - ys[:, None])       # polygon vertices in the car frames
+        w = -s[:, None] * (P[None, :, 0] - xs[:, None]) + c[:, None] * (P[None, :, 1] - ys[:, None])
+        apart = (u.min(1) > f + margin) | (u.max(1) < -r - margin) | (w.min(1) > l + margin) | (w.max(1) < -rt - margin)
+        corners = np.array([[f, l], [-r, l], [-r, -rt], [f, -rt]])
+        cx = xs[:, None] + c[:, None] * corners[None, :, 0] - s[:, None] * corners[None, :, 1]
+        cy = ys[:, None] + s[:, None] * corners[None, :, 0] + c[:, None] * corners[None, :, 1]
+        n = len(P)
+        for e in range(n):
+            p, q = P[e], P[(e + 1) % n]
+            nx, ny = -(q[1] - p[1]), (q[0] - p[0])         # outward normal of a clockwise edge
+            nn = np.hypot(nx, ny); nx, ny = nx / nn, ny / nn
+            apart |= (nx * (cx - p[0]) + ny * (cy - p[1])).min(1) > margin
+        return bool((~apart).any())
+
+    for i in range(B):
+        xs, ys, yaws = base["xWS"][i, :, 0], base["xWS"][i, :, 1], base["xWS"][i, :, 2]
+        lOb = [list(map(list, o)) for o in sc["lOb"]]; vOb = list(sc["vOb"])
+        nex = int(rng.integers(n_extra[0], n_extra[1] + 1))
+        road = np.flatnonzero((ys > 6.2) & (np.abs(np.sin(yaws)) < 0.5))      # poses driving along the road; the slot's own walls bind further down
+        ks = np.sort(rng.choice(road, size=min(nex, len(road)), replace=False)) if len(road) else []
+        up = rng.random() < 0.5
+        for k in ks:
+            for attempt in range(10):
+                clr = rng.uniform(*clearance); hw = rng.uniform(0.35, 0.8)
+                xt = xs[k] + np.cos(yaws[k]) * rng.uniform(0.0, 3.0) + rng.uniform(-0.3, 0.3)
+                if abs(xt) < 2.2 and not up:               # not in front of the slot's mouth
+                    continue
+                if up:                                      # wedge hanging from the upper wall, tip above the car's left / upper side
+                    yt = max(ys[k], ys[min(k + 3, N)]) + max(l, rt) + clr + 0.35 * abs(np.sin(yaws[k])) * f
+                    pts = [[xt - hw, 10.97], [xt + hw + 1e-3, 10.97], [xt + 2e-3, yt]]          # clockwise
+                    ok = yt < 10.6
+                else:                                       # wedge standing on the blocks beside the slot
+                    yt = min(ys[k], ys[min(k + 3, N)]) - max(l, rt) - clr - 0.35 * abs(np.sin(yaws[k])) * f
+                    pts = [[xt + hw + 1e-3, 5.03], [xt - hw, 5.03], [xt + 2e-3, yt]]            # clockwise
+                    ok = yt > 5.4
+                if ok and XYBOUNDS[0] + 1 < xt - hw and xt + hw < XYBOUNDS[1] - 1 and not touches(pts, xs, ys, yaws, min(0.0, clearance[0]) - 0.02):
+                    lOb.append(pts + [pts[0]]); vOb.append(4); up = not up
+                    break
+        A, b = obst_hrep(len(vOb), vOb, lOb)
+        vl.append(np.asarray(vOb) - 1); Al.append(A); bl.append(b)
+    base.update(vOb=vl, A=Al, b=bl)
+    return base

@@ -15,14 +15,53 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# Order of the GPU suite: the parity tests of the SURVEY section-8 rows (HIP path against the oracle / the dense pins) run FIRST, the determinism tests next, the
-# bit-equality tests of the plumbing (chunked host calls, multi-device contexts, ranks) LAST -- `pytest -x` on the driver's box then stops, if it stops, with the parity
-# evidence already on the record.  The sort is stable: the order inside a file is the order written.
-_GPU_FILE_ORDER = {"test_gpu_parity.py": 0, "test_gpu_quad_parity.py": 1, "test_gpu_determinism.py": 2, "test_gpu_multi.py": 9}
+# Order of the GPU suite: the parity tests of the SURVEY section-8 rows (HIP path against the oracle / the dense pins) run FIRST -- within them the ones on small batches
+# before the ones that fill the machine --, the determinism tests next, the bit-equality tests of the plumbing (chunked host calls, multi-device contexts, ranks) LAST:
+# `pytest -x` on the driver's box then stops, if it stops, with the parity evidence already on the record.  The sort is stable: ties keep the order written.
+_GPU_FILE_ORDER = {"test_gpu_parity.py": 0, "test_gpu_quad_parity.py": 1, "test_gpu_determinism.py": 3, "test_gpu_multi.py": 4}
+# tests whose batches fill the GPU (>= 640 one-wavefront workgroups): after every small-batch parity test of both kernels.  (One of the thirty boxes leased in round 5 did
+# not reproduce its own results; what it got wrong grew with the work done per test)
+_GPU_LARGE = ("bench_batch", "benchmark_batch", "full_size", "two_launch", "batches_in_flight", "bench_size", "all_1024", "config5_with_binding")
+
+
+def _gpu_key(item):
+    f = os.path.basename(str(item.fspath))
+    k = _GPU_FILE_ORDER.get(f, 9)
+    if k <= 1 and any(t in item.name for t in _GPU_LARGE):
+        k = 2
+    return k
 
 
 def pytest_collection_modifyitems(config, items):
-    items.sort(key=lambda it: _GPU_FILE_ORDER.get(os.path.basename(str(it.fspath)), 5))
+    items.sort(key=_gpu_key)
+
+
+_SELFTEST = {}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """after a GPU run: does this GPU reproduce its own results?  (obca_amd.selftest: the 1 024-instance bench batch solved four times, compared bit for bit.)  The line
+    goes into the terminal summary, so that a failed bit-equality test can be read beside it."""
+    if not any(it.get_closest_marker("gpu") for it in session.items):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        import obca_amd
+        _SELFTEST.update(obca_amd.selftest(0, repeats=4))
+    except Exception as e:      # noqa: BLE001 -- a diagnostic must not change the outcome of the run
+        _SELFTEST.update(error=repr(e))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _SELFTEST:
+        if "error" in _SELFTEST:
+            terminalreporter.write_line("obca self-test of this GPU could not run: " + _SELFTEST["error"])
+        else:
+            terminalreporter.write_line("obca self-test of this GPU (%s): %d runs of the %d-instance bench batch, %d solved, %d (instance, run) results differ from the first run%s"
+                                        % (_SELFTEST["device"], _SELFTEST["runs"], _SELFTEST["instances"], _SELFTEST["solved"], _SELFTEST["differing"],
+                                           "" if _SELFTEST["differing"] == 0 else "  <-- THIS GPU DOES NOT REPRODUCE ITS OWN RESULTS (DESIGN.md section 11)"))
 
 
 @pytest.fixture(scope="session")

@@ -317,3 +317,25 @@ def test_oracle_solves_the_reference_main_jl_call(oracle, name):
     assert r20["exitflag"] == 1 and r10["exitflag"] == 1
     ts = np.full(N + 1, r20["t"])
     assert K.parking_constraints_ref(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, len(v), v, A, b, r20["xp"], r20["up"], r20["lp"], r20["np"], ts, 0, 0) == 1
+
+
+def test_corridor_batch_binding_obstacles_are_well_formed_and_solvable(oracle):
+    """scenarios.make_corridor_batch: wedges on the road's two sides (sloped rows through obstHrep), none overlapping a pose of the warm start; the oracle solves the
+    instances with the reference's IPOPT configuration and the solutions pass the full checker"""
+    from obca_amd import scenarios as S, validate as V
+    N, B = 80, 6
+    bt = S.make_corridor_batch(B, N, seed=11)
+    assert all(len(v) >= 3 and (np.asarray(v) >= 1).all() for v in bt["vOb"]) and max(len(v) for v in bt["vOb"]) > 3
+    for i in range(B):
+        A, b = bt["A"][i], bt["b"][i]
+        assert A.shape == (int(np.sum(bt["vOb"][i])), 2) and np.isfinite(A).all() and np.isfinite(b).all()
+        if len(A) > 5:
+            assert (np.abs(A[5:]).max(axis=1) > 0).all() and np.any(np.abs(A[5:, 0]) != 0)      # sloped rows [-s 1] / [s -1] (obstHrep.jl:73-86)
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+        r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS,
+                                       bt["uWS"][i], opts=oo)
+        assert r["exitflag"] == 1
+        ok, why = V.validate_parking(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], np.ravel(bt["vOb"][i]), A, b, r["xp"], r["up"], r["timeScale"],
+                                     r["lp"], r["np"], r["sl"], tol=1e-4)[:2]
+        assert ok, why

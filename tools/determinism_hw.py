@@ -52,6 +52,31 @@ def run(B, N, reps, opts=None, tag=""):
     return nbad
 
 
+def run_copies(B, N, rounds, opts=None, tag=""):
+    """bench.py's regime: four device-resident copies of one batch on four contexts / streams, solved concurrently, every download compared with a lone solve"""
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    bs = []
+    for _ in range(4):
+        b = OA.Batch(OA.Context(0), B, N)
+        b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+        bs.append(b)
+    bs[0].solve(opts=opts); ref = bs[0].download(); nbad = 0
+    for r in range(rounds):
+        for k in range(8):
+            bs[k % 4].solve(opts=opts, sync=False)
+        for i, b in enumerate(bs):
+            b.sync(); o = b.download(); u = hw(b, B)
+            dif = np.flatnonzero((o["info"] != ref["info"]).any(axis=1) | (np.abs(o["xp"] - ref["xp"]).reshape(B, -1).max(axis=1) > 0))
+            nbad += len(dif)
+            if len(dif):
+                print("  %s round %d copy %d: %d instances differ from the lone solve: %s" % (tag, r, i, len(dif), ", ".join("%d [%s] iters %d|%d" % (j, unit(u, j), o["iters"][j], ref["iters"][j]) for j in dif[:12])), flush=True)
+    for b in bs:
+        b.close()
+    print("%s B %d N %d: 4 copies x %d rounds, %d differing (instance, download) pairs" % (tag, B, N, rounds, nbad), flush=True)
+    return nbad
+
+
 print(os.environ.get("OBCA_HIP_LIBRARY", "default library"))
 for cmd in (["rocm-smi", "--showproductname", "--showfwinfo", "--showcomputepartition", "--showmemorypartition", "--showclocks", "--showrasinfo", "all", "--showperflevel", "--showpower", "--showtemp"],
             ["rocminfo"]):
@@ -67,4 +92,6 @@ tot += run(1024, 80, max(2, R // 2), opts=OA.ipopt_opts(), tag="config 2, IPOPT 
 for B in (64, 128, 256, 512, 768):
     tot += run(B, 80, max(2, R // 2), tag="smaller batch")
 tot += run(2048, 80, 3, tag="two-launch schedule")
+tot += run_copies(1024, 80, 3, tag="four copies in flight")
+tot += run_copies(1024, 80, 3, opts=OA.ipopt_opts(), tag="four copies in flight, IPOPT configuration")
 print("TOTAL differing (instance, run) pairs", tot)

@@ -3,8 +3,9 @@
 # exchange probes on every CU (tools/micro/cu_consistency), the solver with the unit each instance ran on (tools/determinism_hw.py), NaN-poisoned buffers, the round-4 library
 T=$1; mkdir -p gpurun_out/r5d
 O=$PWD/gpurun_out/r5d; C=$PWD/obca_amd/csrc
-( cd tools/micro && timeout 120 ./cu_consistency 4 ) > $O/cu_$T.txt 2>&1
-OBCA_HIP_LIBRARY=$C/variants/libobca_hip_hwid.so timeout 300 python tools/determinism_hw.py 6 > $O/hw_$T.txt 2>&1
+# (job B's failures began ~20 s into a sustained load: the probes run long enough to bring the GPU to its working temperature and power state)
+( cd tools/micro && timeout 200 ./cu_consistency 400 ) > $O/cu_$T.txt 2>&1
+OBCA_HIP_LIBRARY=$C/variants/libobca_hip_hwid.so timeout 300 python tools/determinism_hw.py 60 > $O/hw_$T.txt 2>&1
 grep -E "Uuid: +GPU" $O/hw_$T.txt; tail -n 1 $O/cu_$T.txt; tail -n 1 $O/hw_$T.txt
 if ! grep -q "TOTAL differing (instance, run) pairs 0" $O/hw_$T.txt || ! grep -q " 0 deviating" $O/cu_$T.txt; then
   echo "=== box with differing results: deeper probes"
