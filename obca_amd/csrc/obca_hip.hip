@@ -6,7 +6,8 @@
 //   obca_quad_ipm_kernel    : the same for the quadcopter NLP (obca_quad_solver.h).
 //   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
-//   prob  header+rx,ry,ryaw   [411]      z, zn  primal-dual iterate and the line search's trial point (they swap) [6797 each]      d  stage part of the search direction [~650 used]
+//   prob  header+rx,ry,ryaw   [411]      z, zn  primal-dual iterate and the line search's
+//   trial point (they swap) [6797 each]      d  stage part of the search direction [~650 used]
 //   as    assembled stage records (N+1) x 88 [7128]     rs  Riccati records (N+1) x 116 [9396]
 //   oc    condensed obstacle records (N+1) x nOb x 12 [2916]   (the forward-sweep trajectory and the composed stage-pair maps live in LDS)
 #include <hip/hip_runtime.h>
@@ -31,7 +32,8 @@ static_assert(OBCA_VMAX == OB_VMAX && OBCA_NOBMAX == OB_NOBMAX && OBCA_NMAX == O
 struct DevBufs {
     double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
     double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
-    double *csoc; size_t s_csoc;                     // second-order correction (opts.max_soc > 0): the corrected right-hand-side rows of every instance; allocated at the first such solve
+    // second-order correction (opts.max_soc > 0): the corrected right-hand-side rows of every instance; allocated at the first such solve
+    double *csoc; size_t s_csoc;
     int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
     size_t s_prob, s_z, s_as, s_rs, s_oc;   // strides in doubles
 };
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     __syncthreads();
     solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init);
 #ifdef OBCA_HWID      // diagnostic build (tools/determinism_hw.py): where the instance ran -- HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID -- read back
-                      // through obca_batch_debug_phase_cycles, slots 14 / 15; a result that differs between two runs can then be laid beside the hardware unit that produced it
+                      // through obca_batch_debug_phase_cycles, slots 14 / 15; a result that differs
+                      // between two runs can then be laid beside the hardware unit that produced it
     if (threadIdx.x == 0) {
         b.prof[(size_t)inst * 16 + 14] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         b.prof[(size_t)inst * 16 + 15] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -89,8 +92,10 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
 
 // instances resident per CU: registers allow 4 x OBCA_IPM_WAVES_PER_EU, LDS (static Shared + the horizon-sized dynamic part) may allow fewer -- ask the runtime
 static int parking_resident_per_cu(int N) {
-    static std::atomic<int> cache[OB_NMAX + 1];          // 0 = not asked yet.  Worker lanes of several devices call this concurrently: atomics (the answer depends on the
-                                                         // code object and the horizon only -- every device of a context is a gfx950 with 160 KB of LDS per CU, obca_create_multi checks)
+    // 0 = not asked yet.  Worker lanes of several devices call this concurrently: atomics (the answer depends on the
+    static std::atomic<int> cache[OB_NMAX + 1];
+                                                         // code object and the horizon only -- every device of a context is
+                                                         // a gfx950 with 160 KB of LDS per CU, obca_create_multi checks)
     if (N < 0 || N > OB_NMAX) return OBCA_RESIDENT_PER_CU;
     int n = cache[N].load(std::memory_order_relaxed);
     if (!n) {
@@ -102,7 +107,8 @@ static int parking_resident_per_cu(int N) {
 
 // difficulty class of a parked instance (0..63, higher = dispatched earlier)
 __device__ inline int obca_slice_class(const double *st) {
-    const int nreg = (int)st[SL_NREG] + (int)st[SL_NREGPREV] + (int)st[SL_XPASS];      // inertia rungs so far + the correction / re-estimate passes of the IPOPT switches
+    // inertia rungs so far + the correction / re-estimate passes of the IPOPT switches
+    const int nreg = (int)st[SL_NREG] + (int)st[SL_NREGPREV] + (int)st[SL_XPASS];
     const double pinf = st[SL_PINF];
     int c = 8 * (nreg < 7 ? nreg : 7);
     // within the same retry count: the constraint violation that is left, one class per decade from 1e-6 up
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(1024) void obca_order_kernel(int B, const double *i
 }
 
 // one lane per (instance, stage, obstacle); writes lam/mu into the iterate buffer `z` (instance layout) and d into dws
-// (four wavefronts per SIMD for the 2-row class -- 128 registers, 35 spilled -- was measured in round 4: 0.29 ms against 0.25 ms at three wavefronts with 158 registers: not kept)
+// (four wavefronts per SIMD for the 2-row class -- 128 registers, 35 spilled -- was measured
+// in round 4: 0.29 ms against 0.25 ms at three wavefronts with 158 registers: not kept)
 template <int VM>
 __global__ __launch_bounds__(256) void obca_dualws_kernel(int B, int N, int nObMax, DevBufs b, double *zdst, size_t s_zdst) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,7 +276,8 @@ struct obca_batch {
     DevBufs d; double *stage;                               // stage: dense device staging of the PCIe transfers
     double *h_prob, *h_zin, *h_zout, *h_info; size_t hcap_prob, hcap_zin, hcap_zout, hcap_info, dcap_stage;   // pinned host staging
     std::vector<int> nOb, M, obOff, rowOff;                 // per instance; offsets into the caller's packed obstacle arrays
-    std::vector<double> rowLen;                             // |a_r| of every half-space row of the uploaded instances (index: row offset - rowOff[0]), see batch_upload_range
+    // |a_r| of every half-space row of the uploaded instances (index: row offset - rowOff[0]), see batch_upload_range
+    std::vector<double> rowLen;
     int fixTime;
     hipEvent_t e0, e1, e2;
     long long bytes;
@@ -278,9 +286,12 @@ struct obca_batch {
 
 #define HIPCHK(bt, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (bt)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
 static inline int fin(obca_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
-// Device work buffers never carry what a previous owner of the memory left in them: every allocation is filled once, on the stream of the batch it belongs to (the
-// lanes' streams do not synchronise with the null stream).  The product build clears them; -DOBCA_POISON (diagnostic build, tools/determinism_ragged.py) fills them with
-// the all-ones NaN pattern instead -- and the kernels then also poison their LDS at entry -- so that any read of a value nothing has written yet shows up as NaN in the results.
+// Device work buffers never carry what a previous owner of the memory left in them:
+// every allocation is filled once, on the stream of the batch it belongs to (the
+// lanes' streams do not synchronise with the null stream).  The product build clears
+// them; -DOBCA_POISON (diagnostic build, tools/determinism_ragged.py) fills them with
+// the all-ones NaN pattern instead -- and the kernels then also poison their LDS at entry
+// -- so that any read of a value nothing has written yet shows up as NaN in the results.
 #ifdef OBCA_POISON
 #define OBCA_FILL_BYTE 0xFF
 #else
@@ -315,7 +326,8 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
-    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->obj_scaling = 0;                  /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
+    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->obj_scaling = 0;
+                     /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
     return 0;
 }
 
@@ -391,7 +403,8 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     if (B < 1 || N < 0 || N > OBCA_NMAX) { err = "obca_batch_create: need B>=1, 0<=N<=OBCA_NMAX"; return -1; }
     obca_batch *bt = new obca_batch();
     bt->ctx = ctx; bt->device = device; bt->stream = stream;
-    bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0; bt->zlen = 0; bt->fixTime = 0; bt->vmax = 0;
+    bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->have_duals = 0; bt->nObMax = 0; bt->MMax = 0; bt->bytes = 0; bt->dist = 0; bt->sliced = 0;
+    bt->zlen = 0; bt->fixTime = 0; bt->vmax = 0;
     memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr; bt->dcap_stage = 0;
     bt->h_prob = bt->h_zin = bt->h_zout = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_zin = bt->hcap_zout = bt->hcap_info = 0;
     hipSetDevice(device);
@@ -494,10 +507,13 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         for (int j = 0; j < no; j++) { const int v = in.vOb[bt->obOff[i] + j]; p[PH_VOB + j] = v; p[PH_ROFF + j] = ro; ro += v; }
         p[PH_ROFF + no] = ro;
         const size_t r0 = bt->rowOff[i];
-        // The solve runs on unit-length half-space rows a_r / |a_r|, b_r / |a_r| (the same obstacle; lambda_r scales with |a_r|, A'lam and b'lam do not change) and
+        // The solve runs on unit-length half-space rows a_r / |a_r|, b_r / |a_r| (the
+        // same obstacle; lambda_r scales with |a_r|, A'lam and b'lam do not change) and
         // hands lambda back in the caller's scaling.  obstHrep.jl:57-86 leaves the rows of a sloped edge unnormalised ([-s 1]: |a| up to 1e3 for a steep edge);
-        // IPOPT's default gradient-based NLP scaling stands between such rows and the reference's solves.  Without either 1.2-1.9 % of the config-5 instances -- all of
-        // them with a row of |a| > 100 -- failed and the iteration counts had a tail up to 400; with unit rows all solve in at most 80.  The
+        // IPOPT's default gradient-based NLP scaling stands between such rows and the
+        // reference's solves.  Without either 1.2-1.9 % of the config-5 instances -- all of
+        // them with a row of |a| > 100 -- failed and the iteration counts had a tail up
+        // to 400; with unit rows all solve in at most 80.  The
         // reference's own scenarios have rows of length 1: nothing changes for them, bit for bit.
         double *rl = bt->rowLen.data() + (r0 - (size_t)bt->rowOff[0]);
         for (int r = 0; r < m; r++) {
@@ -514,7 +530,8 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         if (in.uWS) memcpy(z + l.u, in.uWS + (size_t)g * 2 * N, sizeof(double) * 2 * N); else memset(z + l.u, 0, sizeof(double) * 2 * N);
         z[l.t] = 1.0;                                                 /* ParkingSignedDist.jl:214 */
         if (duals) {
-            for (int k = 0; k < N1; k++) for (int r = 0; r < m; r++) z[l.lam + k * m + r] = in.lWS[r0 * N1 + (size_t)k * m + r] * rl[r];      // caller's row scaling -> unit rows
+            // caller's row scaling -> unit rows
+            for (int k = 0; k < N1; k++) for (int r = 0; r < m; r++) z[l.lam + k * m + r] = in.lWS[r0 * N1 + (size_t)k * m + r] * rl[r];
             memcpy(z + l.mu, in.nWS + (size_t)bt->obOff[i] * 4 * N1, sizeof(double) * 4 * no * N1);
             if ((size_t)l.sl < W) memset(z + l.sl, 0, sizeof(double) * (W - l.sl));      // a smaller instance's layout ends before the widest one's
         }
@@ -531,7 +548,8 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
 static int launch_dualws(obca_batch *bt, double *zdst) {
     long long tot = (long long)bt->B * (bt->N + 1) * bt->nObMax;
     int blocks = (int)((tot + 255) / 256);
-    if (bt->vmax <= 2) hipLaunchKernelGGL(obca_dualws_kernel<2>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);      // (the sub-problem is sized by the template: the reference's scenarios have <= 2 rows per obstacle)
+    // (the sub-problem is sized by the template: the reference's scenarios have <= 2 rows per obstacle)
+    if (bt->vmax <= 2) hipLaunchKernelGGL(obca_dualws_kernel<2>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     else if (bt->vmax <= OB_VMID) hipLaunchKernelGGL(obca_dualws_kernel<OB_VMID>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     else hipLaunchKernelGGL(obca_dualws_kernel<OB_VMAX>, dim3(blocks), dim3(256), 0, bt->stream, bt->B, bt->N, bt->nObMax, bt->d, zdst, bt->d.s_z);
     HIPCHK(bt, hipGetLastError());
@@ -555,7 +573,8 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
     HIPCHK(bt, hipEventRecord(bt->e0, bt->stream));
     if (!bt->have_duals || dualws_only) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
-    if (!bt->have_duals && !dualws_only) { static const int rep = getenv("OBCA_DUALWS_REPEAT") ? atoi(getenv("OBCA_DUALWS_REPEAT")) : 0;      // diagnostic: marginal cost of the DualMultWS launch in a pipelined run
+    // diagnostic: marginal cost of the DualMultWS launch in a pipelined run
+    if (!bt->have_duals && !dualws_only) { static const int rep = getenv("OBCA_DUALWS_REPEAT") ? atoi(getenv("OBCA_DUALWS_REPEAT")) : 0;
         for (int r = 0; r < rep; r++) { int rc = launch_dualws(bt, d.z); if (rc) return rc; } }
     HIPCHK(bt, hipEventRecord(bt->e1, bt->stream));
     if (dualws_only) { HIPCHK(bt, hipEventRecord(bt->e2, bt->stream)); return 0; }
@@ -568,7 +587,8 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     int budget = 6;
     if (const char *e = getenv("OBCA_SLICE_PASSES")) budget = atoi(e);
     const bool slice_only = getenv("OBCA_SLICE_ONLY") && atoi(getenv("OBCA_SLICE_ONLY"));
-    const size_t dyn_lds = OB_DYN_LDS_DOUBLES(bt->N) * sizeof(double);      // forward-sweep trajectory + stage buffers / pair maps, sized for the horizon (obca_solver.h)
+    // forward-sweep trajectory + stage buffers / pair maps, sized for the horizon (obca_solver.h)
+    const size_t dyn_lds = OB_DYN_LDS_DOUBLES(bt->N) * sizeof(double);
     const int slots = parking_resident_per_cu(bt->N) * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
     bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
@@ -637,7 +657,8 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
     const int nchunks = (B + chunk - 1) / chunk;
     const int nw = std::min<int>(nchunks, (int)ctx->slots.size());
     std::atomic<int> next(0);
-    // OBCA_CHUNK_PERM = s (diagnostic, tests/test_gpu_determinism.py): the t-th ticket of the queue is chunk (t + s) mod nchunks for even s, the chunks in descending order
+    // OBCA_CHUNK_PERM = s (diagnostic, tests/test_gpu_determinism.py): the t-th ticket of
+    // the queue is chunk (t + s) mod nchunks for even s, the chunks in descending order
     // from there for odd s -- which lane (stream, cached batch, staging buffers) solves which chunk must not matter to a single bit of the results
     int perm = 0; if (const char *e = getenv("OBCA_CHUNK_PERM")) perm = atoi(e) > 0 ? atoi(e) : 0;
     std::vector<int> rcs(nw, 0); std::vector<std::string> errs(nw);
@@ -723,7 +744,8 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   
     if (!bt || !out) return -1;
     hipSetDevice(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
-        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_batch_debug_phase_cycles: copy failed"; return -2; }
+        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_batch_debug_phase_cycles: copy failed";
+        return -2; }
     return 0;
 }
 int obca_batch_set_formulation(obca_batch *bt, int dist) { if (!bt) return -1; bt->dist = dist ? 1 : 0; return 0; }   /* before obca_batch_upload */
@@ -839,12 +861,14 @@ static void qfree_dev(obca_quad_batch *bt) {
 static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B, int N, obca_quad_batch **out, std::string &err) {
     if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { err = "obca_quad_batch_create: need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
     obca_quad_batch *bt = new obca_quad_batch();
-    bt->ctx = ctx; bt->device = device; bt->stream = stream; bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0; memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr;
+    bt->ctx = ctx; bt->device = device; bt->stream = stream; bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0;
+    memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr;
     bt->h_prob = bt->h_z = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_z = bt->hcap_info = 0;
     hipSetDevice(device);
     quad::QLay l; quad::q_make_layout(N, l);
     QDevBufs &d = bt->d; const size_t N1 = N + 1;
-    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = QDIR_DOUBLES(l);      /* two direction buffers (dv | dy) + the rows of a second-order correction, see QCS */ d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
+    d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = QDIR_DOUBLES(l);
+         /* two direction buffers (dv | dy) + the rows of a second-order correction, see QCS */ d.s_as = N1 * QSP; d.s_rs = N1 * QRR; d.s_oc = N1 * QOB * OB_OC;
     size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); if (dev_alloc((void **)&(ptr), by_, stream) != hipSuccess) { err = "obca_quad_batch_create: hipMalloc failed"; qfree_dev(bt); delete bt; return -2; } tot += by_; } while (0)
     ALLOC(d.prob, B * d.s_prob); ALLOC(d.z, B * d.s_z); ALLOC(d.d, B * d.s_d); ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);
@@ -931,7 +955,8 @@ int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 1
     if (!bt || !out) return -1;
     hipSetDevice(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
-        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_quad_batch_debug_phase_cycles: copy failed"; return -2; }
+        hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_quad_batch_debug_phase_cycles: copy failed";
+        return -2; }
     return 0;
 }
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }

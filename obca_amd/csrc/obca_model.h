@@ -26,8 +26,10 @@ namespace obca {
 // (tools/micro/lds_barrier_latency.hip: (724 - 440) / 6 clocks per fma of a chain).  Measured on MI355X over 80 binades: 1.00 ulp, the same as two Newton steps
 // (tools/micro/rcp_accuracy.hip, profiles/r03_rcp_accuracy.txt).  For the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN,
 // and those are rejected by the positivity tests next to every use.  The host emulation divides.
-// RS = 0: the two-Newton-step form (five dependent operations, the same 1.00 ulp).  The (stage, obstacle) code instantiated for more than two rows per obstacle keeps it:
-// there the register allocation of the short form costs more than its shorter chain gains (same-box A/B on BASELINE config 5: 3.5 % fewer solves/s with the short form in
+// RS = 0: the two-Newton-step form (five dependent operations, the same 1.00 ulp).  The
+// (stage, obstacle) code instantiated for more than two rows per obstacle keeps it:
+// there the register allocation of the short form costs more than its shorter chain
+// gains (same-box A/B on BASELINE config 5: 3.5 % fewer solves/s with the short form in
 // those instantiations, while config 2 -- two rows -- gains 3.7 % from it; profiles/r03_ab_reciprocal_and_early_quu.txt).
 template <int RS = 1>
 OBCA_FN double rcp_nr(double d) {
@@ -65,11 +67,16 @@ struct Consts {               // uniform per instance
 #define OB_DMIN 0.05
 
 // ---------------------------------------------------------------- sin / cos of a bounded angle
-// The library's sincos (ocml: Payne-Hanek reduction for arbitrary arguments, table-free kernels, ~235 instructions per call on gfx950) is a fifth of the instructions of an
-// obstacle item (tools/isa_lines.py: two calls per item in the fused line search, one in the back-substitution) and this kernel is within 1.6 x of its instruction-issue roof in
-// those phases.  Headings, steering and Euler angles of these problems are a few radians: Cody-Waite reduction by pi/2 in three FMA steps (exact to
-// 1e-33 |n|) and the fdlibm kernels on [-pi/4, pi/4] -- ~45 instructions, straight-line, <= 1.6 ulp for |x| <= 1e5 (the library: <= 1); the quadrant is an int: valid for
-// |x| < 3e9, not-a-number and infinity come back as not-a-number.  (No branch to the library for larger arguments: the compiler would inline that path into every caller
+// The library's sincos (ocml: Payne-Hanek reduction for arbitrary arguments, table-free
+// kernels, ~235 instructions per call on gfx950) is a fifth of the instructions of an
+// obstacle item (tools/isa_lines.py: two calls per item in the fused line search, one in
+// the back-substitution) and this kernel is within 1.6 x of its instruction-issue roof in
+// those phases.  Headings, steering and Euler angles of these
+// problems are a few radians: Cody-Waite reduction by pi/2 in three FMA steps (exact to
+// 1e-33 |n|) and the fdlibm kernels on [-pi/4, pi/4] -- ~45 instructions, straight-line,
+// <= 1.6 ulp for |x| <= 1e5 (the library: <= 1); the quadrant is an int: valid for
+// |x| < 3e9, not-a-number and infinity come back as not-a-number.  (No branch to the
+// library for larger arguments: the compiler would inline that path into every caller
 // and the phases would pay its registers.)
 OBCA_FN void sincos_bounded(double x, double *sp, double *cp) {
     const double n = rint(x * 6.36619772367581382433e-01);                 // 2 / pi
@@ -111,7 +118,8 @@ struct Dyn {
     double dVa, dVt;          // d(F_v - v) / d(a, t)
     double h00, h01, h02, h03, h04, h11, h12, h13, h14, h22, h23, h24, h34, h44;      // HL(i, j), i <= j; HL(3, 3) = 0
 };
-OBCA_FN void dyn_derivs(const double Ts, const double iL, const double x[4], const double u[2], double t, const double w[4], Dyn &o) {      // Ts, iL = 1 / L: the caller's (uniform) copies of Consts::Ts, Consts::iL
+// Ts, iL = 1 / L: the caller's (uniform) copies of Consts::Ts, Consts::iL
+OBCA_FN void dyn_derivs(const double Ts, const double iL, const double x[4], const double u[2], double t, const double w[4], Dyn &o) {
     const double i2L = 0.5 * iL, v = x[3], a = u[1];
     const double tau = Ts * t, s = v + 0.5 * tau * a, T = tan_bounded(u[0]), Tp = 1 + T * T;
     const double phi = x[2] + tau * v * T * i2L;
@@ -211,8 +219,10 @@ OBCA_FN void chol2_solve(const double Lc[3], double &b0, double &b1) {
 template <int VM>
 OBCA_FN void hh_apply(int v, const double *w, double beta, double *x) {   // x <- (I - beta w w') x, beta = 2 / (w'w): w is NOT normalised
     double s = 0;                                                         // (a square root and a division less on the dependent chain)
-    // No predicate on i < v: the callers' w is zero beyond the obstacle's v rows and their x finite there (the rows an obstacle does not have enter every block matrix as
-    // identity rows), so those terms are exact zeros -- the same bits as with the predicate, which cost two selects per term (140 of an obstacle item's 2 500 instructions).
+    // No predicate on i < v: the callers' w is zero beyond the obstacle's v rows and their
+    // x finite there (the rows an obstacle does not have enter every block matrix as
+    // identity rows), so those terms are exact zeros -- the same bits as with the predicate,
+    // which cost two selects per term (140 of an obstacle item's 2 500 instructions).
     (void)v;
 #pragma unroll
     for (int i = 0; i < VM; i++) s += w[i] * x[i];
@@ -238,7 +248,8 @@ template <int VM>
 OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }      // (rows beyond in.v: a = b = 0, lam = 1 -- load_obs -- exact zeros, no predicate needed)
+    // (rows beyond in.v: a = b = 0, lam = 1 -- load_obs -- exact zeros, no predicate needed)
+    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
     double sn, cs;
     sincos_bounded(in.psi, &sn, &cs);
     r[0] = p1 * p1 + p2 * p2 - 1 + (c.dist ? in.sl : 0.0);          // ParkingDist.jl:200: <= 1 (its slack is kept in the sl slot)
@@ -248,8 +259,10 @@ OBCA_FN void obs_rows(const Consts &c, const ObsIn<VM> &in, double r[4]) {
            (in.Y + sn * c.off) * p2 - beta + (c.dist ? 0.0 : in.sl) - OB_DMIN - in.so;   // ParkingDist.jl:207-208: no slack
 }
 
-struct ObsStats { double dmax, pmax, cmin, cmax, sumz, sumy; int bad; };   // cmin / cmax: smallest / largest complementarity product s z (the error w.r.t. ANY barrier
-                                                                                   // parameter follows from the two: max |s z - mu| = max(|cmax - mu|, |cmin - mu|), rounding is monotone)
+// cmin / cmax: smallest / largest complementarity product s z (the error w.r.t. ANY barrier
+struct ObsStats { double dmax, pmax, cmin, cmax, sumz, sumy; int bad; };
+                                                                                   // parameter follows from the two: max |s z - mu| =
+                                                                                   // max(|cmax - mu|, |cmin - mu|), rounding is monotone)
 
 struct ObsCond {          // result of the condensation onto the pose
     double Hpp[6];        // symmetric 3x3: 00 01 02 11 12 22
@@ -260,10 +273,13 @@ template <int VM>
 struct ObsStep { double dlam[VM], dmu[4], dsl, dso, dy[4]; };
 
 // MODE 0: condense (fills cond, stats) ; MODE 1: back-substitute for a given pose step dp (fills step)
-// SOC = 1 (second-order correction, IPOPT A-5.5..A-5.9): the right-hand side takes the four row values from crs (c_soc = alpha c(z) + c(z + alpha d)) instead of
+// SOC = 1 (second-order correction, IPOPT A-5.5..A-5.9): the right-hand side takes
+// the four row values from crs (c_soc = alpha c(z) + c(z + alpha d)) instead of
 // the rows at z; the violation statistics keep the true rows.
-// LSQ = 1 (least-squares multipliers, IPOPT recalc_y / eq. (36) of Waechter & Biegler): Hessian := identity on every variable of the block, no second derivatives, no
-// regularisation, zero constraint right-hand side, stationarity residuals in their z-form (bound multipliers instead of mu / distance); call with mu_b = dw = dc = 0.
+// LSQ = 1 (least-squares multipliers, IPOPT recalc_y / eq. (36) of Waechter & Biegler):
+// Hessian := identity on every variable of the block, no second derivatives, no
+// regularisation, zero constraint right-hand side, stationarity residuals in their
+// z-form (bound multipliers instead of mu / distance); call with mu_b = dw = dc = 0.
 template <int MODE, int VM, int SOC = 0, int LSQ = 0>
 OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double dw, double dc, ObsCond *cond, ObsStats *st,
                        const double dp[3], ObsStep<VM> *step, const double *crs = nullptr) {
@@ -271,7 +287,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     constexpr int RS_ = VM <= 2 ? 1 : 0;       // which reciprocal form (rcp_nr)
     double p1 = 0, p2 = 0, beta = 0;
 #pragma unroll
-    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }      // (rows beyond v: a = b = 0, lam = 1 -- load_obs)
+    // (rows beyond v: a = b = 0, lam = 1 -- load_obs)
+    for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; beta += in.b[i] * in.lam[i]; }
     double sn, cs;
     sincos_bounded(in.psi, &sn, &cs);
     const double off = c.off;
@@ -308,8 +325,10 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
     double iDmu[4], r_mu[4], Dlam[VM], r_lam[VM];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const double jy = (i == 0 ? y[1] : (i == 1 ? y[2] : (i == 2 ? -y[1] : -y[2]))) + Jmu[2][i] * y[3];      // Jmu' y with the 0 / +-1 entries of Jmu written out (a product with a literal
-                                                                                                                    // zero cannot be folded by the compiler -- 0 x inf -- and cost two operations each)
+        // Jmu' y with the 0 / +-1 entries of Jmu written out (a product with a literal
+        const double jy = (i == 0 ? y[1] : (i == 1 ? y[2] : (i == 2 ? -y[1] : -y[2]))) + Jmu[2][i] * y[3];
+                                                                                                                    // zero cannot be folded by the compiler --
+                                                                                                                    // 0 x inf -- and cost two operations each)
         if (LSQ) { r_mu[i] = jy - in.zm[i]; iDmu[i] = 1.0; }
         else { const double im = rcp_nr<RS_>(in.mu[i]); r_mu[i] = jy - mu_b * im; iDmu[i] = rcp_nr<RS_>(in.zm[i] * im + dw); }
         if (MODE == 0) {
@@ -341,7 +360,8 @@ OBCA_FN void obs_block(const Consts &c, const ObsIn<VM> &in, double mu_b, double
         for (int r = 0; r < 4; r++) { st->pmax = fmax(st->pmax, fabs(cr[r])); st->sumy += fabs(y[r]); }
     }
     // rows 2..4 after eliminating so, sl, mu:   Jl dlam + Jp dpose - T dy = r234
-    // T = Jmu diag(1 / D_mu) Jmu' + delta_c I with Jmu = [1 0 -1 0; 0 1 0 -1; -g'] written out (same terms in the same order as the triple loop over its entries; the loop
+    // T = Jmu diag(1 / D_mu) Jmu' + delta_c I with Jmu = [1 0 -1 0; 0 1 0 -1; -g'] written
+    // out (same terms in the same order as the triple loop over its entries; the loop
     // multiplied by the literal zeros, which the compiler may not fold: 62 + 40 operations per block against 25)
     double Tm[9];
     {

@@ -38,7 +38,8 @@ struct QConsts {
     double sf;      // objective scaling factor (IPOPT's gradient-based scaling, opts.obj_scaling; 1: none): the algorithm runs on sf * f
     int N, dist;    // dist = 1: QuadcopterDist.jl (no slack variable, x[10] in [-1.5, 3]); 0: QuadcopterSignedDist.jl
 };
-OBCA_FN double q_xlb(int i, int dist = 0) { return i < 3 ? 0.0 : (i == 3 ? -3.0 : (i < 6 ? -0.2 : (dist && i == 9 ? -1.5 : -1.0))); }   // :78-94, QuadcopterDist.jl:88
+// :78-94, QuadcopterDist.jl:88
+OBCA_FN double q_xlb(int i, int dist = 0) { return i < 3 ? 0.0 : (i == 3 ? -3.0 : (i < 6 ? -0.2 : (dist && i == 9 ? -1.5 : -1.0))); }
 OBCA_FN double q_xub(int i, int dist = 0) { return i < 2 ? 10.0 : (i == 2 ? 5.0 : (i == 3 ? 3.0 : (i < 6 ? 0.2 : (dist && i == 9 ? 3.0 : 1.0)))); }
 // stage-vector index of the local derivative variables
 OBCA_FN int q_vidx(int a) { return a < 3 ? 3 + a : (a < 6 ? 6 + a : QS + (a - 6)); }
@@ -89,7 +90,8 @@ OBCA_FN void dyn_g_derivs(const QConsts &c, const double *x, const double *u, co
     for (int j = 0; j < 4; j++) { dg[3][6 + j] = 2 * kap * u[j] * E7; dg[4][6 + j] = 2 * kap * u[j] * E8; dg[5][6 + j] = 2 * kap * u[j] * E9; }
     dg[6][6 + 1] = 2 * Q_ARM * Q_KF * u[1] * (1.0 / Q_I1); dg[6][6 + 3] = -2 * Q_ARM * Q_KF * u[3] * (1.0 / Q_I1);
     dg[7][6 + 2] = 2 * Q_ARM * Q_KF * u[2] * (1.0 / Q_I2); dg[7][6 + 0] = -2 * Q_ARM * Q_KF * u[0] * (1.0 / Q_I2);
-    dg[8][6 + 0] = 2 * Q_KM * u[0] * (1.0 / Q_I3); dg[8][6 + 1] = -2 * Q_KM * u[1] * (1.0 / Q_I3); dg[8][6 + 2] = 2 * Q_KM * u[2] * (1.0 / Q_I3); dg[8][6 + 3] = -2 * Q_KM * u[3] * (1.0 / Q_I3);
+    dg[8][6 + 0] = 2 * Q_KM * u[0] * (1.0 / Q_I3); dg[8][6 + 1] = -2 * Q_KM * u[1] * (1.0 / Q_I3); dg[8][6 + 2] = 2 * Q_KM * u[2] * (1.0 / Q_I3);
+    dg[8][6 + 3] = -2 * Q_KM * u[3] * (1.0 / Q_I3);
 #pragma unroll
     for (int i = 0; i < 55; i++) HG[i] = 0;
 #define QSYM(i, j, v) HG[q_pidx((i), (j))] += (v)
@@ -137,14 +139,16 @@ struct QObsStep { double dlam[QL], ds, dso, dy[2]; };
 
 // MODE 0: condense onto the position (cond: Hpp[6] sym 3x3, gz[3] = q*y2, gcorr[3]); MODE 1: back-substitute for the step dp;
 // MODE 2: inertia of the block only (st->bad).  crs: the two rows of a second-order correction in place of the constraint values (IPOPT A-5.7), or nullptr.
-// LSQ: the block of the least-squares multiplier system (IPOPT's initial multipliers): unit Hessian on every variable, gradients with the bound multipliers themselves,
+// LSQ: the block of the least-squares multiplier system (IPOPT's initial multipliers):
+// unit Hessian on every variable, gradients with the bound multipliers themselves,
 // zero constraint right-hand sides, multipliers taken as zero (call with dw = dc = 0)
 template <int MODE, int LSQ = 0>
 OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double dw, double dc, ObsCond *cond, QObsStats *st,
                          const double dp[3], QObsStep *step, const double *crs = nullptr) {
     double cr[2], q[3];
     q_obs_rows(c, in, cr, q);
-    const double rhs0 = LSQ ? 0.0 : (crs ? crs[0] : cr[0]), rhs1 = LSQ ? 0.0 : (crs ? crs[1] : cr[1]);      // right-hand side of the two rows: the constraint values, or the rows of a second-order correction
+    // right-hand side of the two rows: the constraint values, or the rows of a second-order correction
+    const double rhs0 = LSQ ? 0.0 : (crs ? crs[0] : cr[0]), rhs1 = LSQ ? 0.0 : (crs ? crs[1] : cr[1]);
     const double y0_[2] = {0.0, 0.0};
     const double *y = LSQ ? y0_ : in.y;
     double g1[QL], g2[QL], Dl[QL], rl[QL];
@@ -168,7 +172,8 @@ OBCA_FN void q_obs_block(const QConsts &c, const QObsIn &in, double mu_b, double
     if (MODE == 0) {
         double rz = c.dist ? 0.0 : fabs(gs - in.zs); st->dmax = fmax(st->dmax, rz);
         rz = fabs(gso - in.zso); st->dmax = fmax(st->dmax, rz);
-        double cc = c.dist ? 0.0 : in.s * in.zs; st->cmax0 = fmax(st->cmax0, fabs(cc)); if (!c.dist) { st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc); }
+        double cc = c.dist ? 0.0 : in.s * in.zs; st->cmax0 = fmax(st->cmax0, fabs(cc));
+        if (!c.dist) { st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc); }
         cc = in.so * in.zso; st->cmax0 = fmax(st->cmax0, fabs(cc)); st->cmin = fmin(st->cmin, cc); st->cmax = fmax(st->cmax, cc);
         st->sumz += (c.dist ? 0.0 : fabs(in.zs)) + fabs(in.zso);
         st->pmax = fmax(st->pmax, fabs(cr[0])); st->pmax = fmax(st->pmax, fabs(cr[1]));

@@ -1,5 +1,7 @@
-// obca_quad_solver.h -- one quadcopter signed-distance NLP instance (QuadcopterSignedDist.jl) solved by ONE wavefront (64-thread workgroup), four instances per CU
-// (round 1 / early round 2: two wavefronts per instance, two instances per CU -- but the stage-parallel phases have 61 items and both sweeps run on one wavefront,
+// obca_quad_solver.h -- one quadcopter signed-distance NLP instance (QuadcopterSignedDist.jl)
+// solved by ONE wavefront (64-thread workgroup), four instances per CU
+// (round 1 / early round 2: two wavefronts per instance, two instances per CU --
+// but the stage-parallel phases have 61 items and both sweeps run on one wavefront,
 // so the second wavefront idled three quarters of the time; with the MFMA sweep an instance needs neither its lanes nor the LDS they came with).
 //
 // Same programming model, interior-point algorithm and phase structure as obca_solver.h (parking); what differs is the model
@@ -29,8 +31,10 @@ namespace quad {
 #define QQC (QZ + QC)                // columns of the extended matrix (34)
 
 // ---------------------------------------------------------------- physical layout of the stage record
-// The logical stage record is dense (QSR = 736 doubles: H 20x20 | Fh 16x18 | hc 20x2) but only 291 of its entries are ever non-zero.  In HBM it is stored PACKED
-// (QSP = 288 doubles): QR(o) maps a logical offset o to its slot (structural zeros share one slot that holds 0, the constant 1 of the identity entries another).
+// The logical stage record is dense (QSR = 736 doubles: H 20x20 | Fh 16x18 | hc
+// 20x2) but only 291 of its entries are ever non-zero.  In HBM it is stored PACKED
+// (QSP = 288 doubles): QR(o) maps a logical offset o to its slot (structural zeros
+// share one slot that holds 0, the constant 1 of the identity entries another).
 // The kernels are limited by HBM traffic: the dense record cost 5.9 KB per stage and pass to read and -- written 8 bytes at a time into a
 // sparse pattern -- 32 bytes per non-zero to write.  The -DOBCA_QUAD_RICCATI_LDS variant keeps the dense record (its sweep copies records into LDS wholesale).
 #define QP_LOC 0        // H[v][v'] over the 10 local variables (angles, rates, inputs)
@@ -84,7 +88,8 @@ OBCA_HD void q_make_layout(int N, QLay &l) {
 }
 // direction buffer: dv[n] then dy[m] (same offsets as v / y)
 
-struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc, *d0; };   // d: the direction buffer in use (one of the two behind d0, see QCS)   // prob: Ts, R, x0[12], xF[12], ob[30], xWS..., see host packing
+// d: the direction buffer in use (one of the two behind d0, see QCS)   // prob: Ts, R, x0[12], xF[12], ob[30], xWS..., see host packing
+struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc, *d0; };
 #define QPH_TS 0
 #define QPH_R 1
 #define QPH_X0 2
@@ -94,8 +99,10 @@ struct QInst { const gdbl *prob; gdbl *z, *d, *as, *rs, *oc, *d0; };   // d: the
 #define QPH_DWS 57
 #define QPH_DIST 58
 #define QPH_SIZE 64
-// direction memory of an instance, behind d0: two direction buffers (dv | dy, n + m doubles each: a second-order correction is solved into the one the iteration's
-// own direction is not in, so a correction that is rejected costs nothing but its own solve) and the rows of the correction (IPOPT A-5.7: c_soc = alpha c_soc + c(trial);
+// direction memory of an instance, behind d0: two direction buffers (dv | dy, n +
+// m doubles each: a second-order correction is solved into the one the iteration's
+// own direction is not in, so a correction that is rejected costs nothing but its own
+// solve) and the rows of the correction (IPOPT A-5.7: c_soc = alpha c_soc + c(trial);
 // m doubles, numbered like the multipliers)
 #define QDIR(sh, which) ((sh).inst.d0 + (size_t)(which) * ((sh).l.n + (sh).l.m))
 #define QCS(sh) QDIR(sh, 2)
@@ -116,13 +123,16 @@ struct QShared {
 #endif
     double filt[QFILT][2];
     int ric_ok, bord_ok;
-    int soc_on;                        // 1: the system being solved is a second-order correction's, the terminal right-hand side comes from QCS; 2: the least-squares multiplier system,
+    // 1: the system being solved is a second-order correction's, the terminal right-hand side comes from QCS; 2: the least-squares multiplier system,
+    int soc_on;
                                        // it is zero (the assembly / block phases have variants of their own)
     int hintl[QNT];                    // per lane: a box block whose inertia was wrong in an earlier assembly (-1: none), see q_block_bad
     double prof[16]; long long tlast;      // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
 };
-// The forward-sweep trajectory ((N + 2) x 16 doubles) and, behind it, kf_k(coef) (N x 4) live in dynamic LDS behind the static block: the launch sizes it for the
-// batch's horizon (N = 60: 9.9 KB, four instances per CU).  It is addressed through the array itself, never through a pointer kept in memory: a loaded pointer is
+// The forward-sweep trajectory ((N + 2) x 16 doubles) and, behind it, kf_k(coef)
+// (N x 4) live in dynamic LDS behind the static block: the launch sizes it for the
+// batch's horizon (N = 60: 9.9 KB, four instances per CU).  It is addressed through
+// the array itself, never through a pointer kept in memory: a loaded pointer is
 // "generic", its accesses become flat_load / flat_store, and a flat access waits for vmcnt(0) -- for every HBM gather in flight -- before it returns.
 #ifdef OBCA_EMU
 static QShared gq_sh;
@@ -160,7 +170,8 @@ OBCA_FN void q_load_obs(const QShared &sh, const gdbl *z, int k, int j, QObsIn &
 }
 
 // ---------------------------------------------------------------- assemble, part (a): box blocks
-template <int RHS>      // RHS = 1: the system of a second-order correction (constraint right-hand sides from QCS); 2: the least-squares multiplier system (q_obs_block<.., LSQ>).
+// RHS = 1: the system of a second-order correction (constraint right-hand sides from QCS); 2: the least-squares multiplier system (q_obs_block<.., LSQ>).
+template <int RHS>
                         // Variants of their own, so that the options cost the iterations nothing
 OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const int N = c.N; const gdbl *z = sh.inst.z, *cs = QCS(sh);
@@ -209,9 +220,12 @@ OBCA_FN void q_assemble_obs(QShared &sh, double mu, double dw, double dc) {
     SYNC();
 }
 
-// Inertia of remembered box blocks at a given delta_w.  IPOPT tries delta_w = 0 in every iteration and climbs a ladder of regularisations until the inertia is right;
-// on this problem most iterations fail the first rung(s) at the block level (the norm row |A'lam|^2 == 1 makes a lambda block indefinite whenever its multiplier is
-// negative), and mostly in blocks that failed an iteration earlier.  Every lane remembers the block it last saw fail (hintl) and re-tests just that block: if any of
+// Inertia of remembered box blocks at a given delta_w.  IPOPT tries delta_w = 0 in
+// every iteration and climbs a ladder of regularisations until the inertia is right;
+// on this problem most iterations fail the first rung(s) at the block level (the
+// norm row |A'lam|^2 == 1 makes a lambda block indefinite whenever its multiplier is
+// negative), and mostly in blocks that failed an iteration earlier.  Every lane
+// remembers the block it last saw fail (hintl) and re-tests just that block: if any of
 // them still fails, the rung is known to fail without being assembled, and the solve moves up the ladder exactly as it would have.
 OBCA_FN int q_block_bad(QShared &sh, double mu, double dw, double dc) {
     const QConsts &c = sh.c; const gdbl *z = sh.inst.z;
@@ -275,7 +289,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
                     rec[QR(QSR_H + i * QZ + i)] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
                     rec[QR(QSR_HC + 2 * i)] = hb[i]; rec[QR(QSR_HC + 2 * i + 1)] = 0.0;
                 }
-                rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2]; rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
+                rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2];
+                rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
                 rec[QR(QSR_H + 1 * QZ + 2)] = Hpos[4]; rec[QR(QSR_H + 2 * QZ + 1)] = Hpos[4];
                 lbar += bar_log(ba) + bar_log(bb);
                 continue;
@@ -285,7 +300,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             for (int j = 0; j < QU; j++) u[j] = z[l.u + QU * k + j];
 #pragma unroll
             for (int i = 0; i < QX; i++) { pi[i] = z[l.pi + QX * k + i]; lsy += fabs(pi[i]); }
-            // everything else the stage reads from the iterate, before the first store into the record (a load behind a store that may alias waits for its own round trip)
+            // everything else the stage reads from the iterate, before the first store into
+            // the record (a load behind a store that may alias waits for its own round trip)
             double xn[QX], pim[QX], um[QU], un[QU], zLu[QU], zUu[QU];
             const int km = k >= 1 ? k - 1 : 0, kn = k + 1 < N ? k + 1 : k;
 #pragma unroll
@@ -358,7 +374,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
             // write H: x diagonal + position block, local 10x10 block (-tau HG), w/u coupling
 #pragma unroll
             for (int i = 0; i < QX; i++) rec[QR(QSR_H + i * QZ + i)] = xd[i] + (i < 3 ? Hpos[i == 0 ? 0 : (i == 1 ? 3 : 5)] : 0.0);
-            rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2]; rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
+            rec[QR(QSR_H + 0 * QZ + 1)] = Hpos[1]; rec[QR(QSR_H + 1 * QZ + 0)] = Hpos[1]; rec[QR(QSR_H + 0 * QZ + 2)] = Hpos[2];
+            rec[QR(QSR_H + 2 * QZ + 0)] = Hpos[2];
             rec[QR(QSR_H + 1 * QZ + 2)] = Hpos[4]; rec[QR(QSR_H + 2 * QZ + 1)] = Hpos[4];
 #pragma unroll
             for (int a = 0; a < QV; a++)
@@ -372,7 +389,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
 #pragma unroll
             for (int j = 0; j < QU; j++) {
                 const double ww = (k >= 1 && !LSQ) ? c.sf * 2e-2 : 0.0;
-                rec[QR(QSR_H + (QX + j) * QZ + (QX + j))] = ww; rec[QR(QSR_H + (QX + j) * QZ + (QS + j))] = -ww; rec[QR(QSR_H + (QS + j) * QZ + (QX + j))] = -ww;
+                rec[QR(QSR_H + (QX + j) * QZ + (QX + j))] = ww; rec[QR(QSR_H + (QX + j) * QZ + (QS + j))] = -ww;
+                rec[QR(QSR_H + (QS + j) * QZ + (QX + j))] = -ww;
             }
             // gradients / t-columns
 #pragma unroll
@@ -389,7 +407,8 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
         sh.red[8][lane] = lbar; sh.red[10][lane] = lgtb; sh.red[11][lane] = lgtz;
     }
     SYNC();
-    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmn = fmin(cmn, red_min(sh.red[3])); cmx = fmax(cmx, red_max(sh.red[12]));
+    dinf = fmax(dinf, red_max(sh.red[0])); pinf = fmax(pinf, red_max(sh.red[1])); c0 = fmax(c0, red_max(sh.red[2])); cmn = fmin(cmn, red_min(sh.red[3]));
+    cmx = fmax(cmx, red_max(sh.red[12]));
     sumz += red_sum(sh.red[4]); sumy += red_sum(sh.red[5]); f += red_sum(sh.red[6]); th1 += red_sum(sh.red[7]); bar += red_sum(sh.red[8]);
     double gtb = red_sum(sh.red[10]), gtz = red_sum(sh.red[11]);
     SYNC();
@@ -402,28 +421,36 @@ OBCA_FN void q_assemble_stage(QShared &sh, double mu, double dw, double dc, AsmO
     f += (N + 1) * (0.25 * t + 5 * t * t); bar += (N + 1) * log((t - Q_TLO) * (Q_THI - t));
     dinf = fmax(dinf, fabs(gtz));
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = c0; out.cmin = cmn; out.cmax = cmx; out.sumy = sumy; out.sumz = sumz;
-    out.f = c.sf * f; out.th1 = th1; out.bar = bar; out.Htt = LSQ ? (double)(N + 1) : c.sf * 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;      // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model)
+    // (least-squares system: t stands for the N + 1 timeScale variables of the reference's model)
+    out.f = c.sf * f; out.th1 = th1; out.bar = bar; out.Htt = LSQ ? (double)(N + 1) : c.sf * 10.0 * (N + 1) + b.Sig + dw; out.gtb = gtb;
     out.nb = 2 * QX * N + 2 * QU * N + 2 * (N + 1) + (QL + 2 - (c.dist ? 1 : 0)) * QOB * (N + 1);
     out.nm = QX * N + QX + 2 * QOB * (N + 1);
 }
 
 #define QRR_PAD 767                                  // unused slot of the Riccati record: target of dummy stores
 // ---------------------------------------------------------------- Riccati backward sweep on the matrix cores
-// (Round 1 ran the sweep as four LDS / VALU phases: bound by LDS bandwidth, every fp64 FMA of its products read two operands from LDS, 10 k clocks per stage.)  Here the
-// whole recursion of an instance runs on its wavefront (QNT = 64: the instance IS one wavefront; the WAVE0 sections below are written for any QNT) with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (23 per stage); the stage record is gathered
+// (Round 1 ran the sweep as four LDS / VALU phases: bound by LDS bandwidth, every fp64
+// FMA of its products read two operands from LDS, 10 k clocks per stage.)  Here the
+// whole recursion of an instance runs on its wavefront (QNT = 64: the instance IS one wavefront; the WAVE0 sections below are
+// written for any QNT) with 16 x 16 fp64 tiles in registers and v_mfma_f64_16x16x4_f64 (23 per stage); the stage record is gathered
 // from HBM straight into operand layout (software-pipelined QMD stages ahead), nothing but the symmetrisation of P goes through LDS.
-//   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
+//   lane = 16 g + j.  wv_mfma(C, a, b): C[i][n] += sum_{k<4} a(lane (k, i)) * b(lane
+//   (k, n));  accumulator register r of lane (g, j) = C[g + 4 r][j] ("D layout").
 //   Register kb of a tile in D layout is the B operand of K-block kb (rows 4 kb .. 4 kb + 3), and the A operand of the TRANSPOSED tile.
 // Tiles (rows x columns; x = 12 states, w = copy of u_{k-1} (4), u = 4 inputs, rhs = main, t, nu_1..12):
 //   PD   (x,w) x (x,w)  value function, symmetric         pnD  (x,w) x rhs
 //   FXD0 FX[:, x|u columns]   FXD1 FX[:, d|Ft] (columns 0, 1)         FX = [A B d Ft; 0 I 0 0] is the 16 x 18 block of the stage record
 //   Th0 = PD FXD0                         (x,w) x (x|u)          Th1 = pnD + PD FXD1                        (x,w) x rhs
 //   Q0  = H + FXD0' Th0                   (x,u) x (x|u)          Q1  = hc + FXD0' Th1                       (x,u) x rhs
-//   (the rows of a tile follow the columns of FXD0: x in registers 0..2, u in register 3.  The rows / columns of the input copy w carry no product -- F has zero
-//   columns there -- and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww, gradient hc[w]; they are written over register 3 once the u rows are used up.)
+//   (the rows of a tile follow the columns of FXD0: x in registers 0..2, u in register
+//   3.  The rows / columns of the input copy w carry no product -- F has zero
+//   columns there -- and are known in closed form: H[w_j][w_j] = ww, H[w_j][u_j] = -ww,
+//   gradient hc[w]; they are written over register 3 once the u rows are used up.)
 //   Quu = Q0[u rows][u columns]: LDL' (uniform);  every lane solves the gains of its own column (x | w columns and the rhs columns)
-//   P' = Q0(x rows | closed-form w rows) + Q[., u] K    p' = Q1 + Q[., u] Kf    (Q[., u] = transpose of the u rows / the closed-form w rows), P' symmetrised through LDS
-//   border constants  Bm += FXD1' (Th1 + pnD) + Q1[u rows]' Kf   (the static parts off_a.(P off_b + p_b) + off_b.p_a -- the last one as its transpose, the tile is symmetrised
+//   P' = Q0(x rows | closed-form w rows) + Q[., u] K    p' = Q1 + Q[., u] Kf    (Q[.,
+//   u] = transpose of the u rows / the closed-form w rows), P' symmetrised through LDS
+//   border constants  Bm += FXD1' (Th1 + pnD) + Q1[u rows]' Kf   (the static parts off_a.(P
+//   off_b + p_b) + off_b.p_a -- the last one as its transpose, the tile is symmetrised
 //   at the end -- and the gain part, all into one accumulator tile)
 //   23 MFMAs per stage (a v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 clocks on gfx950: fp64 matrix rate = fp64 vector rate).
 #if defined(OBCA_PROFILE) && !defined(OBCA_EMU)
@@ -458,14 +485,16 @@ OBCA_FN void qm_gather(const gdbl *rec, const QMPlan &p, double (&v)[QMG]) {
 template <int PIPE>
 OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[OBCA_NLT], double (&PD)[4][OBCA_NLT], double (&pnD)[4][OBCA_NLT], double (&BmD)[4][OBCA_NLT],
                                  double (&nv)[OBCA_NLT][QMD][QMG], const int slot, const double (*raw)[QMG], double (&seg)[4], long long &segt) {
-    // Tiles (row = lane group + 4 register, column = lane & 15): Q0 = [H | .] + [A B; 0 I]' Th0 and Q1 = hc + [A B; 0 I]' Th1 have the x rows in registers 0..2 and
+    // Tiles (row = lane group + 4 register, column = lane & 15): Q0 = [H | .] + [A B;
+    // 0 I]' Th0 and Q1 = hc + [A B; 0 I]' Th1 have the x rows in registers 0..2 and
     // the u rows in register 3; the rows of the input copy w carry no product (F has zero columns there) and are filled in closed form below.
     double FXD0[4][OBCA_NLT], FXD1[4][OBCA_NLT], Th0[4][OBCA_NLT], Th1[4][OBCA_NLT];
     double Q0[4][OBCA_NLT], Q1[4][OBCA_NLT], ww[OBCA_NLT], hw[OBCA_NLT];
     PAR64(lane) {
         const int L_ = LI(lane); const QMPlan &p = plan[L_];
         double v[QMG];
-        // The prefetched operands are MOVED out of the slot's registers (a real v_mov: a plain assignment is only a rename, the old values would stay live in the
+        // The prefetched operands are MOVED out of the slot's registers (a real v_mov:
+        // a plain assignment is only a rename, the old values would stay live in the
         // slot's registers for the whole stage, the re-issued gathers would land elsewhere and the copy back at the loop edge would wait for them -- vmcnt(3)
         // after every pair of stages, measured) so that the gathers of the stage QMD ahead return straight into the registers they are consumed from.
 #pragma unroll
@@ -477,7 +506,8 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
             v[e] = PIPE ? nv[L_][slot][e] : raw[L_][e];
 #endif
         }
-        if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSP, p, nv[L_][slot]); }      // re-issue the slot (clamped, unconditional)
+        // re-issue the slot (clamped, unconditional)
+        if (PIPE) { const int kl = k - QMD > 0 ? k - QMD : 0; qm_gather(sh.inst.as + (size_t)kl * QSP, p, nv[L_][slot]); }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             FXD0[r][L_] = v[r]; FXD1[r][L_] = v[4 + r];
@@ -487,7 +517,8 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
     }
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) { wv_mfma(Th0, PD[kb], FXD0[kb]); wv_mfma(Th1, PD[kb], FXD1[kb]); }
-    // static parts of the border constants, FXD1' Th1 + pnD' FXD1 (pnD: still the next stage's p): the second product is the transpose of FXD1' pnD and the accumulator
+    // static parts of the border constants, FXD1' Th1 + pnD' FXD1 (pnD: still the next
+    // stage's p): the second product is the transpose of FXD1' pnD and the accumulator
     // tile is symmetrised when the sweep ends (sh.Bm = (B + B') / 2), so FXD1' (Th1 + pnD) carries both -- four products per stage instead of eight
     double Tb[4][OBCA_NLT];
     PAR64(lane) {
@@ -524,10 +555,13 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
         ldl_solve<QU>(QU, Lq, b0); ldl_solve<QU>(QU, Lq, b1);
         const double k0 = g == 0 ? b0[0] : (g == 1 ? b0[1] : (g == 2 ? b0[2] : b0[3])), k1 = g == 0 ? b1[0] : (g == 1 ? b1[1] : (g == 2 ? b1[2] : b1[3]));
         Bk0[L_] = k0; Bk1[L_] = j < QC ? k1 : 0.0;
-        Aq[L_] = j < QX ? Q0[3][L_] : (j - QX == g ? -wwu : 0.0);                // Q[row][u_g]: transpose of the u rows for the x rows, closed form for the w rows
+        // Q[row][u_g]: transpose of the u rows for the x rows, closed form for the w rows
+        Aq[L_] = j < QX ? Q0[3][L_] : (j - QX == g ? -wwu : 0.0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) Sn[r][L_] = j < QX ? (r < 3 ? Q0[r][L_] : 0.0) : ((g + 4 * r) == j ? wwu : 0.0);      // w rows / columns of [H | .]: ww on the (w, w) diagonal, nothing else
-        Qu1[L_] = Q1[3][L_]; Q1[3][L_] = hw[L_];                                  // u rows of the right-hand sides go to the border constants, register 3 becomes the w rows (hc only)
+        // w rows / columns of [H | .]: ww on the (w, w) diagonal, nothing else
+        for (int r = 0; r < 4; r++) Sn[r][L_] = j < QX ? (r < 3 ? Q0[r][L_] : 0.0) : ((g + 4 * r) == j ? wwu : 0.0);
+        // u rows of the right-hand sides go to the border constants, register 3 becomes the w rows (hc only)
+        Qu1[L_] = Q1[3][L_]; Q1[3][L_] = hw[L_];
         ro[QRR_K + g * QS + j] = k0;                                              // gains: row g, column j of the 4 x 16 / 4 x 14 blocks
         ro[j < QC ? QRR_KF + g * QC + j : QRR_PAD] = k1;
     }
@@ -538,7 +572,8 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
     PAR64(lane) {
         const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 17 + j] = Sn[r][L_];       // row stride 17: the transposed read below would hit one LDS bank 16 times with stride 16
+        // row stride 17: the transposed read below would hit one LDS bank 16 times with stride 16
+        for (int r = 0; r < 4; r++) tr[(g + 4 * r) * 17 + j] = Sn[r][L_];
     }
     LDS_SYNC();
     PAR64(lane) {
@@ -676,13 +711,20 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
         if (!ok) return;
     }
     const double dt = sh.coef[1];
-    // ---- forward recursion:  u_k = K_k s_k + kf_k(coef),  x_{k+1} = A_k x_k + B_k u_k + d_k + dt Ft_k,  w_{k+1} = u_k  (s = (x, w); no closed-loop matrices are formed).
-    // A chain of N dependent steps, so what counts is the latency of one step.  Lane 4 i + c owns chunk c (four terms) of row i: the 16 terms of a gain row / the 12 + 4
-    // terms of a state row are summed inside a quad of lanes (two DPP exchanges), the four inputs reach every lane through v_readlane, and the new state goes to the LDS
-    // trajectory -- one LDS round trip per stage, every LDS operand a 16-byte read.  What does not depend on the state is taken out of the chain: kf_k(coef) for all stages
-    // is formed stage-parallel beforehand (LDS, behind the trajectory), and the stage data (the first 12 rows of the dense FX block, 216 doubles of the stage record, and
-    // the gains K, 64 doubles of the Riccati record) is gathered from HBM QFWD stages ahead, five values per lane through offsets tabulated once per sweep, into a
-    // double-buffered LDS slot.  (Round 2: two LDS phases per stage with 16- and 18-term sums on 8 + 12 lanes, 8-byte LDS reads, record offsets recomputed for every
+    // ---- forward recursion:  u_k = K_k s_k + kf_k(coef),  x_{k+1} = A_k x_k + B_k u_k
+    // + d_k + dt Ft_k,  w_{k+1} = u_k  (s = (x, w); no closed-loop matrices are formed).
+    // A chain of N dependent steps, so what counts is the latency of one step.  Lane 4
+    // i + c owns chunk c (four terms) of row i: the 16 terms of a gain row / the 12 + 4
+    // terms of a state row are summed inside a quad of lanes (two DPP exchanges), the
+    // four inputs reach every lane through v_readlane, and the new state goes to the LDS
+    // trajectory -- one LDS round trip per stage, every LDS operand a 16-byte read.  What
+    // does not depend on the state is taken out of the chain: kf_k(coef) for all stages
+    // is formed stage-parallel beforehand (LDS, behind the trajectory), and the stage
+    // data (the first 12 rows of the dense FX block, 216 doubles of the stage record, and
+    // the gains K, 64 doubles of the Riccati record) is gathered from HBM QFWD stages
+    // ahead, five values per lane through offsets tabulated once per sweep, into a
+    // double-buffered LDS slot.  (Round 2: two LDS phases per stage with 16- and 18-term
+    // sums on 8 + 12 lanes, 8-byte LDS reads, record offsets recomputed for every
     // gathered value, chunks of three stages gathered one chunk ahead: 1 800 clocks per stage alone, 2 700 with four instances per CU.)
 #ifndef QFWD
 #define QFWD 6                       // stages the gathers run ahead
@@ -694,7 +736,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     {
         double *ring = &sh.red[0][0];
         double *kfc = QTRAJ(sh) + (size_t)(N + 2) * QS;          // kf_k(coef): N x 4, behind the trajectory (dynamic LDS)
-        int fo[OBCA_NL][QFW_PER];                              // per lane: where its values of a stage live (>= 0: stage record, < 0: -1 - offset in the Riccati record)
+        // per lane: where its values of a stage live (>= 0: stage record, < 0: -1 - offset in the Riccati record)
+        int fo[OBCA_NL][QFW_PER];
         double nvf[OBCA_NL][QFWD][QFW_PER];
         QPAR(lane) {
             const int L_ = LI(lane);
@@ -755,7 +798,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
     }
     SYNC();
     QPROF(QPF_FWD);
-    // ---- costate increments of the stages with a Riccati record behind them, d pi_k = -(P_{k+1} s_{k+1} + p_{k+1} coef): one (stage, row) item per lane, so that
+    // ---- costate increments of the stages with a Riccati record behind them, d pi_k
+    // = -(P_{k+1} s_{k+1} + p_{k+1} coef): one (stage, row) item per lane, so that
     // consecutive lanes read consecutive rows of the records (with one STAGE per lane every load of the 360 values touched 64 different lines); three items per
     // lane in flight, all loads before the first store (d may alias the records as far as the compiler knows)
     QPAR(lane) {
@@ -807,7 +851,8 @@ OBCA_FN void q_direction_main(QShared &sh, const AsmOut &A, double mu, double dw
                 const gdbl *rN = sh.inst.as + (size_t)N * QSP;
 #pragma unroll
                 for (int i = 0; i < QX; i++) {
-                    const double e = sh.soc_on == 2 ? 0.0 : (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]));      // (2: the least-squares multiplier system has a zero row there; QCS holds nothing yet)
+                    // (2: the least-squares multiplier system has a zero row there; QCS holds nothing yet)
+                    const double e = sh.soc_on == 2 ? 0.0 : (sh.soc_on ? -QCS(sh)[QCS_NU(sh) + i] : -(z[l.x + QX * N + i] - c.xF[i]));
                     double a_ = (rN[QR(QSR_HC + 2 * i)] - rho * e) + sh.coef[2 + i];
                     for (int j = 0; j < QX; j++) a_ += (rN[QR(QSR_H + i * QZ + j)] + (i == j ? rho : 0.0)) * sn[j];
                     dpi[i] = -a_;
@@ -1023,7 +1068,8 @@ OBCA_FN void q_apply_step(QShared &sh, double alpha, double ay, double az, doubl
         for (int base = 0; base < l.n; base += QAP_R * QNT) {
             double v[QAP_R], dv[QAP_R], zl[QAP_R], zu[QAP_R];
 #pragma unroll
-            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.n ? i : 0; v[r] = z[ic]; dv[r] = d[ic]; zl[r] = z[l.zL + ic]; zu[r] = ic < l.lam ? z[l.zU + ic] : 0.0; }      // (only x, u, t have upper bounds)
+            // (only x, u, t have upper bounds)
+            for (int r = 0; r < QAP_R; r++) { const int i = base + lane + QNT * r, ic = i < l.n ? i : 0; v[r] = z[ic]; dv[r] = d[ic]; zl[r] = z[l.zL + ic]; zu[r] = ic < l.lam ? z[l.zU + ic] : 0.0; }
 #pragma unroll
             for (int r = 0; r < QAP_R; r++) {
                 const int i = base + lane + QNT * r;
@@ -1066,7 +1112,8 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         for (int k = lane; k <= N; k += QNT) {
             gdbl *rec = sh.inst.as + (size_t)k * QSP;
             for (int i = 0; i < 3; i++) { rec[QR(QSR_F + i * QFC + i)] = 1.0; rec[QR(QSR_F + (6 + i) * QFC + (6 + i))] = 1.0; }
-            for (int j = 0; j < QU; j++) rec[QR(QSR_F + (QX + j) * QFC + QX + j)] = 1.0;          // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
+            // the copy rows w+ = u of FX   // the other diagonal entries are rewritten every pass
+            for (int j = 0; j < QU; j++) rec[QR(QSR_F + (QX + j) * QFC + QX + j)] = 1.0;
         }
         for (int it = lane; it < (N + 1) * QOB; it += QNT) {
             const int k = it / QOB, j = it - k * QOB;
@@ -1086,8 +1133,10 @@ OBCA_FN void q_init_point(QShared &sh, double bound_push, double bound_frac, dou
         }
     }
     SYNC();
-    if (obj_scaling) {      // IPOPT's gradient-based scaling of the objective (nlp_scaling_max_gradient = 100): |grad f|_inf at the starting point as given, over the variables of the
-                            // reference's model (each of the N + 1 timeScale variables carries 0.25 + 10 t).  At the reference's start it is the slack penalty: 1e2 + 2e3 = 2 100
+    // IPOPT's gradient-based scaling of the objective (nlp_scaling_max_gradient = 100): |grad f|_inf at the starting point as given, over the variables of the
+    if (obj_scaling) {
+                            // reference's model (each of the N + 1 timeScale variables carries 0.25 + 10
+                            // t).  At the reference's start it is the slack penalty: 1e2 + 2e3 = 2 100
         QPAR(lane) {
             double g = lane == 0 ? fabs(0.25 + 10 * z[l.t]) : 0.0;
             for (int i = lane; i < QX * (N + 1); i += QNT) if (i % QX >= 9) g = fmax(g, fabs(2e-4 * z[l.x + i]));
@@ -1221,7 +1270,8 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
     double dc_mu = -1.0, dc_val = 0;
     QPAR(lane) { sh.hintl[lane] = -1; }
     SYNC();
-    if (lsq_init) {      // IPOPT's initial multipliers: the least-squares estimate at the starting point through the same structured solve with the Hessian replaced by the identity
+    // IPOPT's initial multipliers: the least-squares estimate at the starting point through the same structured solve with the Hessian replaced by the identity
+    if (lsq_init) {
                          // (at the reference's own start, lambda = 0.05, the system is singular: y stays 0)
         QPAR(lane) { if (lane == 0) sh.soc_on = 2; }
         SYNC();
@@ -1252,7 +1302,8 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
         f = A.f; pinf = A.pinf; dinf = A.dinf;
         const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max, sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
         const double E0 = fmax(A.dinf / sd, fmax(A.pinf, A.cinf0 / sc));
-        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf / sf <= o.dual_inf_tol && A.cinf0 / sf <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }      // (the three *_tol: IPOPT's tolerances on the UNSCALED problem)
+        // (the three *_tol: IPOPT's tolerances on the UNSCALED problem)
+        if (E0 <= o.tol && A.pinf <= o.constr_viol_tol && A.dinf / sf <= o.dual_inf_tol && A.cinf0 / sf <= o.compl_inf_tol) { status = ST_OPTIMAL; break; }
         if (it >= o.max_iter) { status = ST_USERLIMIT; break; }
         if (!(A.f == A.f) || !(A.pinf == A.pinf) || !(A.dinf == A.dinf)) { status = ST_ERROR; break; }
         int mu_changed = 0;
@@ -1314,8 +1365,10 @@ OBCA_FN void q_solve_instance(int N, const Opts &o, double *info, int max_soc = 
                     }
                 }
             }
-            // second-order correction (IPOPT A-5.5 .. A-5.9, kappa_soc = 0.99) after a rejected FIRST trial step that did not reduce theta.  The correction solves the
-            // iteration's own system with the constraint right-hand sides replaced (same matrix: same regularisation, inertia already right) into the other direction
+            // second-order correction (IPOPT A-5.5 .. A-5.9, kappa_soc = 0.99) after a
+            // rejected FIRST trial step that did not reduce theta.  The correction solves the
+            // iteration's own system with the constraint right-hand sides replaced (same
+            // matrix: same regularisation, inertia already right) into the other direction
             // buffer: a correction that is rejected leaves the iteration's own direction where the backtracking goes on with it.
             if (max_soc > 0 && alpha == ap0 && ft == ft && tht == tht && tht >= th) {
                 double th_old = 0, th_tr = tht, asoc = alpha, azs = az;
