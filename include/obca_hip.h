@@ -84,7 +84,8 @@ typedef struct obca_opts {
     int obj_scaling;  /* 1: IPOPT's gradient-based scaling of the objective (nlp_scaling_method default, nlp_scaling_max_gradient = 100): the algorithm runs on sf * f with
                        * sf = 100 / max(100, |grad f(start)|_inf); dual_inf_tol / compl_inf_tol are tested on the unscaled quantities, the reported objective is unscaled.
                        * Quadcopter kernel: sf = 100 / 2 100 at the reference's start (the slack penalty 1e2 + 2e3 * 1), set by obca_quadcopter_reference_opts.  Parking kernels: the
-                       * gradient at the reference's start is the slack penalty 1e2 exactly, sf = 1: the field is accepted and changes nothing.  0 = off (the defaults) */
+                       * gradient at the reference's own start is the slack penalty 1e2 exactly (sf = 1), but a caller's start (small Ts, jumpy uWS, supplied slacks) can exceed it
+                       * and the parking kernels do not scale: the parking entry points REFUSE obj_scaling = 1 (rc -1) instead of ignoring it.  0 = off (the defaults) */
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);

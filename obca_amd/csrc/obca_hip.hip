@@ -564,6 +564,11 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     hipSetDevice(bt->device);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
+    // IPOPT's objective scaling is 1 on the parking NLP only at the reference's own start
+    // (gradient = the slack penalty 1e2); a caller's start with a larger gradient would
+    // be scaled by IPOPT and is not by these kernels: the switch is refused here rather
+    // than silently ignored (the quadcopter entry points refuse recalc_y the same way)
+    if (o.obj_scaling != 0) { bt->err = "opts.obj_scaling is carried by the quadcopter kernel only (obca_quadcopter_reference_opts); the parking entry points take 0"; return -1; }
     if (o.max_soc > 0 && !bt->d.csoc) {      // the second-order correction keeps its right-hand-side rows per instance
         hipError_t e_ = dev_alloc((void **)&bt->d.csoc, (size_t)bt->cap * bt->d.s_csoc * sizeof(double), bt->stream);
         if (e_ != hipSuccess) { bt->d.csoc = nullptr; bt->err = std::string("hipMalloc(csoc): ") + hipGetErrorString(e_); return -2; }

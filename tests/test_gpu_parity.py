@@ -407,6 +407,10 @@ def test_bad_inputs_fail_loudly_not_crash(OA):
     with pytest.raises(OA.ObcaError):      # 17 obstacles > OBCA_NOBMAX
         OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], [1] * 17, np.ones((17, 2)), np.zeros(17),
                                      xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+    with pytest.raises(OA.ObcaError):      # objective scaling is a switch of the quadcopter kernel: refused on the parking path, not ignored
+        o = OA.default_opts(); o.obj_scaling = 1
+        OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS,
+                                     bt["uWS"], opts=o)
     bad = bt["x0"].copy(); bad[0, 0] = np.nan  # NaN input: exitflag 0 for that instance, the other one still solves
     out = OA.parking_signed_dist_batch(bad, bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
                                        xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
