@@ -233,10 +233,12 @@ def velo_smooth(v, amax, Ts):
 # search settings per scenario: the 6 m bay of the parallel scenario leaves 0.65 m at either end of the car, which needs a fine grid;
 # nominal speeds follow the reference's sampling times (0.6 s and 0.9 s per 0.3 m of path, main.jl:46-50,66 and the scenario tables)
 SCENARIO_OPTS = {"backwards": (dict(), 0.5),
-                 "parallel": (dict(step=0.2, xy_res=0.1, yaw_res_deg=3.0, margin=0.02, max_expansions=2000000, rs_heuristic=1, h_weight=2.5, switch_cost=3.0), 0.25)}
-# (round 5: the Reeds-Shepp length as a second heuristic -- hybrid_a_star.jl:58 has the switch -- with the heuristic weighted 2.5 -- hybrid_a_star.jl:64 H_COST -- and a switch
-#  cost of 3 cuts the search of a parallel-parking start from 64 k to 9 k expansions, 5.5 x less planning time; the NLP takes 5 % more iterations from these warm starts
-#  (128 instances on the oracle with the reference's IPOPT configuration: 39.7 against 37.6 iterations, all solved either way))
+                 "parallel": (dict(step=0.2, xy_res=0.1, yaw_res_deg=3.0, margin=0.02, max_expansions=2000000, rs_heuristic=1, h_weight=1.5), 0.25)}
+# (round 5: the Reeds-Shepp length as a second heuristic -- hybrid_a_star.jl:58 has the switch -- and the heuristic weighted 1.5 -- hybrid_a_star.jl:64 H_COST -- halve the
+#  planning time of a parallel-parking start (64 k -> 21 k expansions) and leave the NLP as it was: 512 instances on the oracle, throughput / reference options: 36.6 / 38.6
+#  iterations against 36.4 / 38.1, longest solve 200 / 175 passes against 193 / 183.  Heavier weights plan faster still -- weight 2.5 with a switch cost of 3: 4.1 x less time --
+#  but their paths carry more direction switches and the hardest NLP of a batch then takes 350-400 passes instead of ~190, which a batched solve waits for: not the default;
+#  `warm_start_many(..., h_weight=2.5, switch_cost=3.0)` for a pipeline that is bound by the planner.)
 
 
 def warm_start(sc, x0, xF, N, smooth=False, **kw):
