@@ -50,6 +50,10 @@ def pytest_sessionfinish(session, exitstatus):
             return
         import obca_amd
         _SELFTEST.update(obca_amd.selftest(0, repeats=4))
+        try:
+            _SELFTEST["device"] += ", uuid %s" % torch.cuda.get_device_properties(0).uuid
+        except Exception:      # noqa: BLE001 -- older torch: no uuid
+            pass
     except Exception as e:      # noqa: BLE001 -- a diagnostic must not change the outcome of the run
         _SELFTEST.update(error=repr(e))
 
@@ -62,6 +66,17 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             terminalreporter.write_line("obca self-test of this GPU (%s): %d runs of the %d-instance bench batch, %d solved, %d (instance, run) results differ from the first run%s"
                                         % (_SELFTEST["device"], _SELFTEST["runs"], _SELFTEST["instances"], _SELFTEST["solved"], _SELFTEST["differing"],
                                            "" if _SELFTEST["differing"] == 0 else "  <-- THIS GPU DOES NOT REPRODUCE ITS OWN RESULTS (DESIGN.md section 11)"))
+
+
+def gpu_verdict():
+    """one line for the message of a failed bit-equality assertion: what the GPU the test ran on does with identical inputs (obca_amd.selftest, ~0.1 s)"""
+    try:
+        import obca_amd
+        r = obca_amd.selftest(0, repeats=3)
+        return " [self-test of this GPU right after the failure: %d (instance, run) results of %d x %d differ from the first run%s]" % (
+            r["differing"], r["runs"] - 1, r["instances"], "" if r["differing"] == 0 else ": THIS GPU DOES NOT REPRODUCE ITS OWN RESULTS, DESIGN.md section 11")
+    except Exception as e:      # noqa: BLE001
+        return " [self-test could not run: %r]" % e
 
 
 @pytest.fixture(scope="session")

@@ -1,5 +1,7 @@
 """Bit-reproducibility of the HIP path (run with -m gpu).  The driver's round-4 run met two runs of the same inputs that differed in the last bits (ragged batch, two
-chunks in flight on two streams): fp64 sums whose order the hardware chose.  Everything here goes through libobca_hip.so and asserts EQUAL BITS:
+chunks in flight on two streams).  The kernels hold no atomic and no order-dependent sum, so on sound hardware equal inputs give equal bits, whatever the
+chunking, the lanes and the load; round 5 traced the failures to single boxes of the pool that do not reproduce their own results -- a failure here carries
+the verdict of obca_amd.selftest() on the GPU it ran on.  Everything goes through libobca_hip.so and asserts EQUAL BITS:
 
   * ragged batches (3-10 and 1-16 obstacles per instance, 1-8 rows per obstacle) solved as one device-resident batch = the same batch cut into chunks of every size over
     1-4 concurrent worker lanes, fresh and reused lane batches, permuted chunk -> lane assignment, >= 200 host-pointer calls, both option sets;
@@ -8,6 +10,7 @@ chunks in flight on two streams): fp64 sums whose order the hardware chose (DESI
 import os
 import numpy as np
 import pytest
+from conftest import gpu_verdict
 from obca_amd import scenarios as S
 
 pytestmark = pytest.mark.gpu
@@ -73,7 +76,7 @@ def test_ragged_batch_same_bits_whatever_the_chunking_and_the_lanes(OA, name, ge
     ref = refs[0]
     assert (ref["exitflag"] == 1).mean() > 0.85
     for r in refs[1:]:
-        assert _diff(r, ref) == "", "the resident batch, solved again: " + _diff(r, ref)
+        assert _diff(r, ref) == "", "the resident batch, solved again: " + _diff(r, ref) + gpu_verdict()
     args, _ = _args(bt, N)
     rng = np.random.default_rng(17)
     fixed = [(1000, 2), (37, 3), (20, 4), (64, 1), (75, 2), (11, 4), (50, 3), (B, 1)]      # (1000, 2): the combination of the round-4 failure -- two chunks of B / 2, two lanes
@@ -95,7 +98,7 @@ def test_ragged_batch_same_bits_whatever_the_chunking_and_the_lanes(OA, name, ge
     finally:
         for k in ("OBCA_CHUNK", "OBCA_SLOTS", "OBCA_CHUNK_PERM"):
             os.environ.pop(k, None)
-    assert not failures, "%d of %d host-pointer calls differ from the resident batch: %s" % (len(failures), done, " || ".join(failures[:5]))
+    assert not failures, "%d of %d host-pointer calls differ from the resident batch: %s" % (len(failures), done, " || ".join(failures[:5])) + gpu_verdict()
 
 
 def test_bench_batch_same_bits_with_other_launches_in_flight(OA):
@@ -114,7 +117,7 @@ def test_bench_batch_same_bits_with_other_launches_in_flight(OA):
             b.solve(sync=False)
         for i, b in enumerate(bs):
             b.sync(); d = _diff(b.download(), ref)
-            assert d == "", "round %d, copy %d: %s" % (rnd, i, d)
+            assert d == "", "round %d, copy %d: %s" % (rnd, i, d) + gpu_verdict()
     for b in bs:
         b.close()
 

@@ -7,7 +7,7 @@ import os
 import sys
 import numpy as np
 import pytest
-from conftest import ROOT
+from conftest import ROOT, gpu_verdict
 from obca_amd import scenarios as S
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +31,10 @@ def _resident(OA, bt, N):
 
 
 def _same(a, b, B):
-    assert np.array_equal(a["exitflag"], b["exitflag"]) and np.array_equal(a["info"], b["info"])
+    if not (np.array_equal(a["exitflag"], b["exitflag"]) and np.array_equal(a["info"], b["info"])):
+        w = np.argwhere(a["info"] != b["info"])
+        raise AssertionError("info rows of %d instances differ (first: instance %d, %s | %s)" % (len(set(w[:, 0])), int(w[0, 0]) if len(w) else -1,
+                             a["info"][w[0, 0]].tolist() if len(w) else "", b["info"][w[0, 0]].tolist() if len(w) else "") + gpu_verdict())
     for k in ("xp", "up", "timeScale"):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
     for k in ("lp", "np", "sl"):
