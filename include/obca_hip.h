@@ -53,16 +53,18 @@ typedef struct obca_batch obca_batch;
  *               with H := I) whenever the accepted iterate's constraint violation is below recalc_y_feas_tol = 1e-6;
  *   lsq_init -- IPOPT's default initial multipliers: the same least-squares estimate at the starting point (constr_mult_init_max = 1e3) instead of y0 = 0.
  * With any of them on, the kernels follow the CPU checker's option of the same name iteration for iteration -- on the FULL bench batches of BASELINE configs 2 / 3 / 5
- * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0 / 2 / 1 iteration counts differ, tests/test_gpu_parity.py,
- * profiles/r04_census_gpu_ipopt_options.txt).
+ * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0-2 iteration counts differ per batch, tests/test_gpu_parity.py,
+ * profiles/r04_census_gpu_ipopt_options.txt; which switch moves a solve into another local solution and what each costs: profiles/r05_options_census.txt).
  *
- * Two option sets, and which one is the default where (round 4, measured on one MI355X, profiles/r04_bench_step1.json, r04_bench_config{3,5}_step1.json):
+ * Two option sets, and which one is the default where (measured on one MI355X: round 4 profiles/r04_steps/r04_bench_step1.json, r04_bench_config{3,5}.json; round 5
+ * profiles/r05_bench.json, r05_bench_config{3,5}.json):
  *   obca_reference_opts -- the reference's IPOPT configuration as far as the kernels carry it: max_soc = 4, recalc_y = 1, lsq_init = 1.  The default of the DROP-IN functions
  *                          that carry the reference's names (Julia: OBCAHip.ParkingSignedDist / ParkingDist; Python: obca_amd.ParkingSignedDist / ParkingDist).
- *   obca_default_opts   -- the three switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below and what bench.py's `value` runs.
+ *   obca_default_opts   -- the three switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below.  (bench.py's `value` runs
+ *                          obca_reference_opts since round 5; the throughput set is its secondary leg config.fast_options.)
  * The numbers behind that split: both settings solve every instance of the three bench batches (identical exit flags, every solution passes the a-posteriori checker);
  * the IPOPT configuration costs 6 / 5 / 15 % more iterations and 12 x the inertia-correction rungs (the least-squares start leaves an indefinite Lagrangian Hessian early on):
- * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
+ * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json; round 5: 247.0 k -> 200.7 k on config 2); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
  * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
  * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, pipelined: 36.7 k -> 31.4 k solves/s with its three switches.)

@@ -6,10 +6,10 @@
 //   obca_quad_ipm_kernel    : the same for the quadcopter NLP (obca_quad_solver.h).
 //   obca_dualws_kernel      : one lane per (instance, stage, obstacle) convex sub-problem of DualMultWS (obca_model.h).
 // Memory (per instance, fp64, all in HBM; sizes for N=80, 3 obstacles / 5 rows in brackets):
-//   prob  header+rx,ry,ryaw   [411]      z, zn  primal-dual iterate and the line search's
+//   prob  header+rx,ry,ryaw   [495]      z, zn  primal-dual iterate and the line search's
 //   trial point (they swap) [6797 each]      d  stage part of the search direction [~650 used]
-//   as    assembled stage records (N+1) x 88 [7128]     rs  Riccati records (N+1) x 116 [9396]
-//   oc    condensed obstacle records (N+1) x nOb x 12 [2916]   (the forward-sweep trajectory and the composed stage-pair maps live in LDS)
+//   as    assembled stage records (N+1) x 60 [4860]     rs  Riccati records N x 74 [5920]      slice  state of a parked solve [480]
+//   (the condensed obstacle sums, the forward-sweep trajectory and the composed stage-pair maps live in LDS; `oc` is used by the quadcopter kernel only)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
