@@ -195,7 +195,7 @@ struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
 struct Sol { gdbl *home; Slice sl; Result R; int att, it_prev, nreg_prev, ef, iters, nreg, retry; };      // state of solve_instance (wave-uniform, in LDS)
 struct Drv {                // state of the interior-point driver (wave-uniform; see ipm_attempt)
     double mu, tau, dw, dw_last, dc_mu, dc_val, th_min, th_max, f, pinf, dinf, sd, sc, cm, th, phi, gd, az, pw_th, pw_gd, amin, alpha;
-    int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc;
+    int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc, xpass0;
 };
 // state of the three IPOPT switches (second-order correction, recalc_y, least-squares initial multipliers: cold paths); at the END of Shared, so that
 struct Soc {
