@@ -195,7 +195,7 @@ struct Result { int status, iters, nreg; double obj, pinf, dinf, mu; };
 struct Sol { gdbl *home; Slice sl; Result R; int att, it_prev, nreg_prev, ef, iters, nreg, retry; };      // state of solve_instance (wave-uniform, in LDS)
 struct Drv {                // state of the interior-point driver (wave-uniform; see ipm_attempt)
     double mu, tau, dw, dw_last, dc_mu, dc_val, th_min, th_max, f, pinf, dinf, sd, sc, cm, th, phi, gd, az, pw_th, pw_gd, amin, alpha;
-    int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc, xpass0;
+    int nf, it, nreg, status, p_start, have_asm, mu_changed, ok, tr, acc;
 };
 // state of the three IPOPT switches (second-order correction, recalc_y, least-squares initial multipliers: cold paths); at the END of Shared, so that
 struct Soc {
@@ -206,6 +206,9 @@ struct Soc {
     int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
     int lsq_init;                     // option: least-squares initial multipliers (IPOPT's default initialisation, constr_mult_init_max = 1e3)
     int nrebuild;                     // Newton systems rebuilt after a rejected correction in this attempt (a full pass each: counted against the slice budget)
+    int xpass0;                       // correction / rebuild / re-estimate passes of EARLIER slices of this attempt (SL_XPASS is cumulative like SL_NREG).  (Kept here, at the end of
+                                      // Shared: one more int in Drv moved everything behind it by 8 bytes, off the 16-byte boundaries the phases read `c`, `A*`, `inst` at -- 3.5 %
+                                      // of `value`, profiles/r05_ab_lds_alignment.txt)
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 
@@ -213,13 +216,15 @@ struct alignas(16) Shared {
     double hdr[OB_HDR];
     alignas(16) double Bm[36], coef[8];                         // border constants (left by the backward sweep for the border solve), (dt, nu)
     double filt[OB_FILT_LDS][2];
+    // (Layout note, round 5, profiles/r05_ab_lds_alignment.txt: one more int in Drv -- `sol`, `o`, `roff` .. `Ap` 8 bytes further back -- cost 3.5 % of `value`; so did putting every
+    //  member on a 16-byte boundary; where the dynamic block behind `Shared` starts (0-240 bytes of padding) made no difference.  New wave-uniform state goes to the END, into Soc.)
     Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
     // upl, ucn: which positions of the unpacked stage data a lane serves (init_unpack_table)
-    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok, upl[OB_NT], ucn[3][OB_NT];
+    int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok; int upl[OB_NT], ucn[3][OB_NT];
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)
-    Inst inst; AsmOut A, A2, An, Ap; StepOut S; int vm2, vmc;
+    Inst inst; AsmOut A; AsmOut A2; AsmOut An; AsmOut Ap; StepOut S; int vm2, vmc;
     Soc soc;
     // ft_ok: the instance's (stage, obstacle) items fit OB_KEEP rounds (first-trial block part
     // merged into the direction phase); ft_done: that part has run for the direction at hand

@@ -351,9 +351,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     const AsmOut &A = sh.A;
     sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0; sh.soc.nrebuild = 0;
     D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
-    D.xpass0 = 0;      // correction / rebuild / re-estimate passes of earlier slices of this attempt (SL_XPASS is cumulative like SL_NREG: the ordering kernel ranks by both)
+    sh.soc.xpass0 = 0;      // (SL_XPASS is cumulative over the slices of an attempt like SL_NREG: the ordering kernel ranks by both)
     if (sl.resume) {
-        D.xpass0 = (int)st[SL_XPASS];
+        sh.soc.xpass0 = (int)st[SL_XPASS];
         D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN];
         D.th_max = st[SL_THMAX];
         D.pinf = st[SL_PINF];
@@ -372,7 +372,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         // out of budget: park the loop state, a later launch continues
         if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc >= sl.budget) {
             PAR(lane) {
-                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = D.xpass0 + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
+                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.xpass0 + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
                 const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS;                 // (entries beyond the LDS part are in the record already)
                 for (int i = lane; i < 2 * nl; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
             }
