@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, job K: the last binary (SL_XPASS cumulative, corridor test reframed): reproducibility probes, GPU suite, smoke, the driver's 20-step bench line
+# round 5, job K: the last binary (SL_XPASS cumulative and kept at the end of the LDS block, corridor test reframed): reproducibility probes, GPU suite, smoke, the driver's 20-step bench line
 mkdir -p gpurun_out/r5k
 O=$PWD/gpurun_out/r5k; C=$PWD/obca_amd/csrc
 rocminfo | grep -E "Uuid: +GPU" > $O/uuid.txt; cat $O/uuid.txt
