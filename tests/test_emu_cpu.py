@@ -144,7 +144,7 @@ def test_emu_exit_flag_after_failed_attempts_follows_the_reference(oracle, emu, 
     assert r["status"] == 1 and int(info[0]) == 1 and int(info[1]) == r["iters"] == 6
     assert r["exitflag"] == int(info[7]) == (1 if dist else 0)
     # the acceptance test itself: C restatement == the verbatim Python restatement, on an optimal and on an unfinished solution
-    import checkers as K
+    from obca_amd import validate as K
     ro = oracle.parking_signed_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"],
                                     xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][0], lWS, nWS, dist=dist)
     for sol in (ro, r):

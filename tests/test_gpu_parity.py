@@ -158,7 +158,7 @@ def test_least_squares_initial_multipliers_match_the_oracle_option(OA, oracle):
 
 def test_parking_matches_oracle_config3_parallel(OA, oracle):
     """BASELINE config 3: parallel parking, 4 obstacles / 6 half-space rows, Hybrid A* warm starts (golden fixture + a fresh batch)"""
-    import checkers as K
+    from obca_amd import validate as K
     g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
     A, b, v = S.scenario_hrep(S.PARALLEL)
     fresh = S.make_batch(S.PARALLEL, 32, N, seed=7)                 # (the planner's worker processes are spawned: safe next to a live HIP runtime)
@@ -184,7 +184,7 @@ def test_parking_matches_oracle_config3_parallel(OA, oracle):
 
 def test_parking_dist_variant_matches_oracle(OA, oracle):
     """ParkingDist: no penetration slack, |A'lam|^2 <= 1 with its own slack, 0.5 a^2, its own exit-flag logic"""
-    import checkers as K
+    from obca_amd import validate as K
     N, B = 80, 48
     bt = S.make_batch(S.BACKWARDS, B, N)
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
@@ -226,7 +226,7 @@ def test_full_size_properties_config2(OA):
     """B=1024 (BASELINE config 2): size-independent properties -- every converged instance passes the reference's own
     acceptance test (ParkingConstraints.jl @5e-5) and the full checker; boundary conditions hold exactly; solving twice is
     deterministic."""
-    import checkers as K
+    from obca_amd import validate as K
     N, B = 80, 1024
     bt = S.make_batch(S.BACKWARDS, B, N)
     out, _ = _solve_batch(OA, bt)
@@ -593,7 +593,7 @@ def test_reference_main_jl_call_runs_as_is(OA, oracle, name):
     hybrid_a_star.jl restated), the speed profile / veloSmooth / steering / every-third-sample warm start of main.jl:216-252, the horizon the path length gives
     (N = 64 / 60), then ParkingDist (main.jl:258) and ParkingSignedDist (:269) from that warm start -- both against the oracle"""
     from obca_amd import planner as PL
-    import checkers as K
+    from obca_amd import validate as K
     sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
     N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
     A, b, v = S.scenario_hrep(sc); x0, xF = sc["x0"], sc["xF"]; nOb = len(v)

@@ -84,7 +84,7 @@ def test_oracle_reproduces_golden(oracle, name, scn):
 
 
 def test_reference_checker_accepts_oracle_solutions(oracle):
-    import checkers as K
+    from obca_amd import validate as K
     g = golden("oracle_cfg2.npz")
     B, N = int(g["B"]), int(g["N"])
     bt = S.make_batch(S.BACKWARDS, B, N)
@@ -100,7 +100,7 @@ def test_reference_checker_accepts_oracle_solutions(oracle):
 
 def test_oracle_config3_parallel_parking_golden_and_reference_checker(oracle):
     """BASELINE config 3: the parallel scenario (4 obstacles, main.jl:151-162) from Hybrid A* warm starts stored in the fixture"""
-    import checkers as K
+    from obca_amd import validate as K
     g = golden("oracle_cfg3.npz"); B, N = int(g["B"]), int(g["N"])
     A, b, v = S.scenario_hrep(S.PARALLEL)
     assert len(v) == 4 and int(v.sum()) == 6                                   # SURVEY 8: nOb = 4, M = 6
@@ -310,7 +310,7 @@ def test_half_space_rows_of_any_length_describe_the_same_problem(oracle, backwar
 def test_oracle_solves_the_reference_main_jl_call(oracle, name):
     """BASELINE config 1 on the CPU side: warm start of main.jl:216-252 from the REFERENCE-mode search (hybrid_a_star.jl restated, its own point-cloud obstacles),
     horizon from the path length, ParkingDist then ParkingSignedDist; both reach exit flag 1 and the collision-free solution passes the reference's acceptance test"""
-    import checkers as K
+    from obca_amd import validate as K
     from obca_amd import planner as PL
     sc = S.BACKWARDS if name == "backwards" else S.PARALLEL
     N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
