@@ -78,7 +78,7 @@ EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visibl
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
-           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles",
+           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles", "obca_debug_leave_pattern",
            "obca_quadcopter_default_opts", "obca_quadcopter_reference_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
            "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
@@ -174,6 +174,11 @@ class Context:
         buf = C.create_string_buffer(256)
         _load().obca_device_name(self._h, buf, 256)
         return buf.value.decode()
+
+    def debug_leave_pattern(self, mask=4, value=1e30):
+        """diagnostic (include/obca_hip.h: obca_debug_leave_pattern): fill what later workgroups inherit on a SIMD / CU -- bit 0 vector registers, 1 accumulation registers,
+        2 the CUs' LDS (with the double `value`), 3 scratch -- on every device of the context; the solves that follow must return the same bits"""
+        self._check(_load().obca_debug_leave_pattern(self._h, C.c_int(int(mask)), C.c_double(float(value))), "obca_debug_leave_pattern")
 
     def close(self):
         if self._h:

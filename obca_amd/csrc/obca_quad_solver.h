@@ -68,7 +68,10 @@ OBCA_FN int QR(int o) {
     return QR_ZERO;
 }
 
-#ifdef OBCA_EMU
+#if defined(OBCA_EMU) && defined(OBCA_EMU_RACE)
+#define QPAR(lane) for (int lane = 0; (race::lane = lane) < QNT; ++lane)      // (see PAR in obca_solver.h)
+#define QNLT QNT
+#elif defined(OBCA_EMU)
 #define QPAR(lane) for (int lane = 0; lane < QNT; ++lane)
 #define QNLT QNT
 #else

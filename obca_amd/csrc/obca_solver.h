@@ -25,14 +25,25 @@
 #define OBCA_FN static inline
 #define OBCA_HD static inline
 #define OBCA_PHASE static
+#ifdef OBCA_EMU_RACE      // hazard-detecting build of the emulation (tests/test_emu_sanitize.py): PAR publishes the lane at work, the synchronisation points count epochs, and every
+                          // access to a per-instance HBM buffer goes through `gdbl` below -- a word that one lane writes and another lane reads or writes before the next point
+                          // at which the wavefront's global stores are known to have landed (SYNC, VM_DRAIN) is reported
+namespace race { extern int lane; void sync(int drains_global_memory); void rd(const void *p); void wr(const void *p); }
+#define PAR(lane) for (int lane = 0; (race::lane = lane) < OB_NT; ++lane)
+#define PAR64(lane) for (int lane = 0; (race::lane = lane) < 64; ++lane)
+#define SYNC() race::sync(1)
+#define LDS_SYNC() race::sync(0)
+#define VM_DRAIN() race::sync(1)
+#else
 #define PAR(lane) for (int lane = 0; lane < OB_NT; ++lane)
 #define PAR64(lane) for (int lane = 0; lane < 64; ++lane)       // inside a WAVE0 section
-#define WAVE0_BEGIN {
-#define WAVE0_END }
 #define SYNC() ((void)0)
-#define LANE0 1
 #define LDS_SYNC() ((void)0)
 #define VM_DRAIN() ((void)0)
+#endif
+#define WAVE0_BEGIN {
+#define WAVE0_END }
+#define LANE0 1
 #define LDS_BARRIER() ((void)0)
 #define OBCA_NLT OB_NT
 #define UNIFORM(x) (x)
@@ -51,13 +62,21 @@
 #define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
 #define WAVE0_END }
+#ifdef OBCA_DRAIN      // diagnostic (tools/job_r5t.sh): every synchronisation point of the wavefront also waits for its outstanding global loads / stores
+#define SYNC() do { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); } while (0)
+#else
 #define SYNC() __syncthreads()
+#endif
 #define LANE0 (threadIdx.x == 0)
 // The workgroup is ONE wavefront: its LDS operations execute in program order, so lanes only need the compiler to keep that
 // order (wavefront-scope fences emit no instruction).  Unlike __syncthreads() this does not drain outstanding global loads,
 // which lets the software-pipelined HBM gathers of the sequential sweeps stay in flight across phases.  Use it only where the
 // cross-lane traffic of the surrounding phases goes through LDS.
+#ifdef OBCA_DRAIN
+#define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
 #define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 #define VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   // s_waitcnt vmcnt(0): all outstanding global loads / stores of this wave
 // workgroup barrier for phases that exchange data through LDS only: unlike __syncthreads() it does not drain the global-memory counter
 #define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
@@ -75,7 +94,17 @@
 // Pointers into the per-instance HBM buffers carry the global address space explicitly: they are kept in LDS (Shared::inst),
 // and a pointer loaded from memory would otherwise be "generic" -> flat_load/flat_store, whose completion is tied to the LDS
 // counter (lgkmcnt) and would serialise every LDS read behind the outstanding HBM gathers.
-#ifdef OBCA_EMU
+#if defined(OBCA_EMU) && defined(OBCA_EMU_RACE)
+struct gdbl {      // a double in a per-instance HBM buffer whose loads and stores are logged with the lane that issued them
+    double v;
+    operator double() const { race::rd(this); return v; }
+    gdbl &operator=(double x) { race::wr(this); v = x; return *this; }
+    gdbl &operator=(const gdbl &o) { const double x = o; return *this = x; }
+    gdbl &operator+=(double x) { const double y = *this; return *this = y + x; }
+    gdbl &operator-=(double x) { const double y = *this; return *this = y - x; }
+    gdbl &operator*=(double x) { const double y = *this; return *this = y * x; }
+};
+#elif defined(OBCA_EMU)
 typedef double gdbl;
 #else
 typedef __attribute__((address_space(1))) double gdbl;

@@ -461,8 +461,13 @@ OBCA_FN void assemble_stage(const Inst &I, Shared &sh, double mu_, double dw_, d
         bar += (N + 1) * log((t - OB_TL) * (OB_TU - t));
         dinf = fmax(dinf, fabs(gtz));
     } else { Htt = 1.0; gtb = 0; }
-    // (largest |s z| of all complementarity pairs = the larger of the two extreme products in magnitude) out.sumy = sumy; out.sumz = sumz;
+    // (cinf0: the largest |s z| of all complementarity pairs = the larger of the two extreme products in magnitude)
     out.ok = ok; out.dinf = dinf; out.pinf = pinf; out.cinf0 = fmax(fabs(cmn), fabs(cmx)); out.cmin = cmn; out.cmax = cmx;
+    // the multiplier sums behind IPOPT's scaling factors s_d, s_c of the termination test (ipm_attempt).  From round 4 until the end of round 5 these two stores sat at the end of
+    // a comment: the driver read whatever the LDS words held.  Zeros, NaNs and the previous workgroup's own leftovers give s_d = s_c = 1, which is also what the sums give
+    // for nearly every instance -- so parity held; a large positive pattern left by ANOTHER kernel (another process on the GPU, or a workgroup of another horizon whose dynamic block
+    // lay there) ends the solve early.  DESIGN.md section 11.
+    out.sumy = sumy; out.sumz = sumz;
     out.f = f; out.th1 = th1; out.bar = bar; out.Htt = Htt; out.gtb = gtb; out.nb = nb; out.nm = nm;
     PROF(I, FUSED ? PF_APPLY : PF_ASM_STAGE);
 }

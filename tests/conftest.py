@@ -89,13 +89,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def emu():
     """host emulation of the HIP solver (tests/emu/obca_emu.cpp): kernel logic on the CPU, test-only."""
-    import ctypes as C
-    src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu.so")
-    deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
-    return C.CDLL(so)
+    import emu_solver
+    return emu_solver.load()      # (built aside and renamed into place: xdist workers may build at once)
 
 
 @pytest.fixture(scope="session")

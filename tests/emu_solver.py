@@ -20,13 +20,28 @@ class EOpts(C.Structure):
         [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]
 
 
-def load():
+_VARIANTS = {None: ("libobca_emu.so", ["-O1"]),
+             "race": ("libobca_emu_race.so", ["-O0", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_RACE"]),      # cross-lane hazards through HBM (tests/test_emu_sanitize.py)
+             "asan": ("libobca_emu_asan.so", ["-O1", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_ASAN", "-fsanitize=address"])}      # exact buffer sizes under AddressSanitizer
+_loaded = {}
+
+
+def build(variant=None):
+    name, flags = _VARIANTS[variant]
     src = os.path.join(ROOT, "tests", "emu", "obca_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libobca_emu.so")
+    so = os.path.join(ROOT, "tests", "emu", name)
     deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
-    return C.CDLL(so)
+        tmp = so + ".%d.tmp" % os.getpid()                  # (several xdist workers may build at once: compile aside, rename into place)
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, src, "-ldl"])
+        os.replace(tmp, so)
+    return so
+
+
+def load(variant=None):
+    if variant not in _loaded:
+        _loaded[variant] = C.CDLL(build(variant))
+    return _loaded[variant]
 
 
 def default_opts():
@@ -59,7 +74,7 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
             cs, sn = np.cos(rwi[k]), np.sin(rwi[k]); r0 = 0
             for j, vj in enumerate(v):
                 a1 = np.ascontiguousarray(An[r0:r0 + vj, 0]); a2 = np.ascontiguousarray(An[r0:r0 + vj, 1]); bj = np.ascontiguousarray(bn[r0:r0 + vj])
-                lam = np.zeros(4); mu = np.zeros(4); d = C.c_double(0)
+                lam = np.zeros(8); mu = np.zeros(4); d = C.c_double(0)
                 emu.emu_dualws(C.c_int(int(vj)), dp(a1), dp(a2), dp(bj), dp(g), C.c_double(rxi[k] + off * cs), C.c_double(ryi[k] + off * sn),
                                C.c_double(cs), C.c_double(sn), dp(lam), dp(mu), C.byref(d))
                 lWS[k, r0:r0 + vj] = lam[:vj]; nWS[k, 4 * j:4 * j + 4] = mu; r0 += vj
@@ -73,13 +88,13 @@ def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry
     return dict(xp=xp, up=up, timeScale=ts, exitflag=ef, lp=lps, np=nps, sl=sls, info=info, iters=info[:, 1].astype(int), obj=info[:, 2], status=info[:, 0].astype(int), nsoc=nsoc)
 
 
-def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, dist=False, **_):
+def quadcopter_signed_dist_batch(x0, xF, N, Ts, R, ob, xWS, timeWS, dual_ws=True, dist=False, max_soc=0, lsq_init=0, obj_scaling=0, **_):
     """the quadcopter kernel source (obca_quad_solver.h) as a host emulation, with the signature of obca_amd.quadcopter_signed_dist_batch"""
     emu = load()
     x0 = np.reshape(x0, (-1, 12)); B = x0.shape[0]; xF = np.reshape(xF, (-1, 12)); L = P.quad_layout(N); N1 = N + 1
     Tsv = np.broadcast_to(np.asarray(Ts, float), (B,)); tw = np.broadcast_to(np.asarray(timeWS, float), (B,))
     xp = np.zeros((B, 12, N1)); up = np.zeros((B, 4, N)); ts = np.zeros((B, N1)); ef = np.zeros(B, np.int32); info = np.zeros((B, 8)); lp = np.zeros((B, 30, N1)); sl = np.zeros((B, 5, N1))
-    eo = default_opts(); eo.max_iter = 3000; eo.dw_min = 1e-10            # QuadcopterSignedDist.jl:28-31 (obca_quadcopter_default_opts)
+    eo = default_opts(); eo.max_iter = 3000; eo.dw_min = 1e-10; eo.max_soc = int(max_soc); eo.lsq_init = int(lsq_init); eo.obj_scaling = int(obj_scaling)            # QuadcopterSignedDist.jl:28-31 (obca_quadcopter_default_opts)
     for i in range(B):
         prob = P.pack_quad_problem(x0[i], xF[i], N, Tsv[i], R, ob, np.asarray(xWS[i], float).reshape(N1, 12), tw[i], dual_ws=int(bool(dual_ws)), dist=int(bool(dist)))
         z = np.zeros(L["len"])

@@ -399,3 +399,54 @@ def test_instances_at_the_obstacle_and_row_limits_follow_the_oracle(oracle):
                                         xWS[None, :, 0], xWS[None, :, 1], xWS[None, :, 2], 0, xWS[None], bt["uWS"][i:i + 1])
         assert e["exitflag"][0] == r["exitflag"] == 1 and e["iters"][0] == r["iters"], (i, e["exitflag"][0], r["exitflag"], e["iters"][0], r["iters"])
         assert np.abs(e["xp"][0] - r["xp"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("s_max", [1e-2, 1e-4], ids=["s_max_0.01", "s_max_0.0001"])
+def test_termination_scaling_factors_in_the_kernels_follow_the_oracle(oracle, emu, backwards, s_max):
+    """IPOPT's s_d, s_c (mean multiplier magnitude over s_max, at least 1) scale the optimality error of the termination test.  With the default s_max = 100 both are 1 on nearly
+    every instance, which is why parity never noticed that the kernels' multiplier sums were not stored (round 4 - round 5); a small s_max makes them bite:
+    the solve then ends earlier, at the same iteration as the oracle's."""
+    N, B = 20, 3
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    v = bt["vOb"]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+    oo = oracle.default_opts(); oo.s_max = s_max; eo = copy_opts(oo)
+    o1 = oracle.default_opts()
+    fewer = 0
+    for i in range(B):
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        args = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
+        r = oracle.parking_signed_dist(*args, opts=oo); r1 = oracle.parking_signed_dist(*args, opts=o1)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
+        zo = np.zeros_like(z0); info = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
+        xp, up, t, lp, npp, sl = P.unpack_solution(zo, N, nOb, M)
+        assert int(info[7]) == r["exitflag"] == 1 and int(info[1]) == r["iters"], (i, info[1], r["iters"], r1["iters"])
+        assert np.abs(xp - r["xp"]).max() < 1e-8 and abs(info[2] - r["obj"]) < 1e-9 * max(1.0, abs(r["obj"]))
+        fewer += r["iters"] < r1["iters"]
+    assert fewer >= 1          # the factors were active: with them the oracle itself stops earlier than with s_max = 100
+
+
+def test_a_solve_reads_nothing_it_has_not_written_whatever_the_pattern(emu, backwards):
+    """The work buffers in HBM, the static and the dynamic LDS block are filled with a pattern before the solve (OBCA_EMU_POISON, tests/emu/obca_emu.cpp): the result keeps its
+    bits.  NaN alone is not enough -- it passes through fmax / fmin and fails every comparison silently, which is how a read of two never-written LDS words survived the NaN
+    poisoning of round 5 and was found only when another process's kernels left large finite numbers there."""
+    import os
+    N, B = 20, 2
+    bt = S.make_batch(S.BACKWARDS, B, N)
+    import emu_solver as E
+    def solve(**kw):
+        xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+        return E.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"], **kw)
+    try:
+        for kw in (dict(), dict(max_soc=4, recalc_y=1, lsq_init=1), dict(dist=True)):
+            os.environ.pop("OBCA_EMU_POISON", None)
+            ref = solve(**kw)
+            assert (ref["exitflag"] == 1).all()
+            for value in ("nan", "1e30", "-1e30", "1e-30", "0.5", "-3.0", "1e300"):
+                os.environ["OBCA_EMU_POISON"] = "7"; os.environ["OBCA_EMU_POISON_VALUE"] = value
+                o = solve(**kw)
+                assert np.array_equal(o["info"], ref["info"]) and np.array_equal(o["xp"], ref["xp"]) and np.array_equal(o["up"], ref["up"]), (kw, value, o["iters"], ref["iters"])
+    finally:
+        os.environ.pop("OBCA_EMU_POISON", None); os.environ.pop("OBCA_EMU_POISON_VALUE", None)
