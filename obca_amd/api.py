@@ -85,10 +85,12 @@ EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visibl
 
 
 def selftest(device=0, repeats=4, opts=None):
-    """Does this GPU reproduce its own results?  The config-2 bench batch (1 024 instances, N = 80: every SIMD of the chip holds one) is solved `repeats` times as one
-    device-resident batch and every download is compared bit for bit with the first.  Returns a dict: `differing` = (instance, run) pairs that differ, `instances`,
-    `runs`, `solved`, `device`.  The kernels contain no atomics and no order-dependent reductions: on sound hardware `differing` is 0 -- 29 of the
-    30 MI355X leased in round 5 behaved so over thousands of solves; on the thirtieth every result of every process differed from run to run."""
+    """Does this GPU return the same bits for the same inputs, whatever ran on it before?  The config-2 bench batch (1 024 instances, N = 80: every SIMD of the chip holds one) is
+    solved `repeats` times as one device-resident batch and every download is compared bit for bit with the first; then a kernel leaves a large finite pattern in the LDS of every
+    CU (obca_debug_leave_pattern) and the batch is solved once more.  Returns a dict: `differing` = (instance, run) pairs that differ, `after_pattern` = instances that differ
+    after the pattern, `instances`, `runs`, `solved`, `device`.  Both counts are 0: the kernels contain no atomics and no order-dependent reductions, and read nothing they have not
+    written (DESIGN.md sections 3 and 11 -- until the end of round 5 two LDS words of the parking kernels were read unwritten, and results changed with what other kernels had
+    left there, e.g. when another process shared the GPU)."""
     from . import scenarios as S
     N, B = 80, 1024
     bt = S.make_batch(S.BACKWARDS, B, N)
@@ -96,17 +98,22 @@ def selftest(device=0, repeats=4, opts=None):
     ctx = device if isinstance(device, Context) else Context(device)
     b = Batch(ctx, B, N)
     b.upload(bt["x0"], bt["xF"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"])
+
+    def differing(o, ref):
+        return int(((o["info"] != ref["info"]).any(axis=1) | (np.abs(o["xp"] - ref["xp"]).reshape(B, -1).max(axis=1) > 0)).sum())
     ref = None; bad = 0
     for _ in range(max(2, repeats)):
         b.solve(opts=opts); o = b.download()
         if ref is None:
             ref = o; continue
-        bad += int(((o["info"] != ref["info"]).any(axis=1) | (np.abs(o["xp"] - ref["xp"]).reshape(B, -1).max(axis=1) > 0)).sum())
+        bad += differing(o, ref)
+    ctx.debug_leave_pattern(4, 1e30)
+    b.solve(opts=opts); after = differing(b.download(), ref)
     name = ctx.name()
     b.close()
     if not isinstance(device, Context):
         ctx.close()
-    return dict(differing=bad, instances=B, runs=max(2, repeats), solved=int((ref["exitflag"] == 1).sum()), device=name)
+    return dict(differing=bad, after_pattern=after, instances=B, runs=max(2, repeats), solved=int((ref["exitflag"] == 1).sum()), device=name)
 
 
 def warm_restart_opts():

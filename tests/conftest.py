@@ -16,11 +16,11 @@ def pytest_configure(config):
 
 
 # Order of the GPU suite: the parity tests of the SURVEY section-8 rows (HIP path against the oracle / the dense pins) run FIRST -- within them the ones on small batches
-# before the ones that fill the machine --, the determinism tests next, the bit-equality tests of the plumbing (chunked host calls, multi-device contexts, ranks) LAST:
+# before the ones that fill the machine --, the determinism tests next, the bit-equality tests of the plumbing (chunked host calls, multi-device contexts, ranks) after them, the
+# tests that leave foreign patterns on the CUs (written at the very end of round 5, when no GPU time was left to run them) LAST:
 # `pytest -x` on the driver's box then stops, if it stops, with the parity evidence already on the record.  The sort is stable: ties keep the order written.
-_GPU_FILE_ORDER = {"test_gpu_parity.py": 0, "test_gpu_quad_parity.py": 1, "test_gpu_determinism.py": 3, "test_gpu_multi.py": 4}
-# tests whose batches fill the GPU (>= 640 one-wavefront workgroups): after every small-batch parity test of both kernels.  (One of the thirty boxes leased in round 5 did
-# not reproduce its own results; what it got wrong grew with the work done per test)
+_GPU_FILE_ORDER = {"test_gpu_parity.py": 0, "test_gpu_quad_parity.py": 1, "test_gpu_determinism.py": 3, "test_gpu_multi.py": 4, "test_gpu_history.py": 5}
+# tests whose batches fill the GPU (>= 640 one-wavefront workgroups): after every small-batch parity test of both kernels
 _GPU_LARGE = ("bench_batch", "benchmark_batch", "full_size", "two_launch", "batches_in_flight", "bench_size", "all_1024", "config5_with_binding")
 
 
@@ -40,7 +40,7 @@ _SELFTEST = {}
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """after a GPU run: does this GPU reproduce its own results?  (obca_amd.selftest: the 1 024-instance bench batch solved four times, compared bit for bit.)  The line
+    """after a GPU run: same inputs, same bits?  (obca_amd.selftest: the 1 024-instance bench batch solved four times and once more after a foreign pattern was left in LDS.)  The line
     goes into the terminal summary, so that a failed bit-equality test can be read beside it."""
     if not any(it.get_closest_marker("gpu") for it in session.items):
         return
@@ -63,9 +63,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         if "error" in _SELFTEST:
             terminalreporter.write_line("obca self-test of this GPU could not run: " + _SELFTEST["error"])
         else:
-            terminalreporter.write_line("obca self-test of this GPU (%s): %d runs of the %d-instance bench batch, %d solved, %d (instance, run) results differ from the first run%s"
-                                        % (_SELFTEST["device"], _SELFTEST["runs"], _SELFTEST["instances"], _SELFTEST["solved"], _SELFTEST["differing"],
-                                           "" if _SELFTEST["differing"] == 0 else "  <-- THIS GPU DOES NOT REPRODUCE ITS OWN RESULTS (DESIGN.md section 11)"))
+            terminalreporter.write_line("obca self-test of this GPU (%s): %d runs of the %d-instance bench batch, %d solved, %d (instance, run) results differ from the first run, "
+                                        "%d differ after a foreign pattern was left in the CUs' LDS%s"
+                                        % (_SELFTEST["device"], _SELFTEST["runs"], _SELFTEST["instances"], _SELFTEST["solved"], _SELFTEST["differing"], _SELFTEST.get("after_pattern", -1),
+                                           "" if _SELFTEST["differing"] == 0 and _SELFTEST.get("after_pattern", 0) == 0 else "  <-- SAME INPUTS, OTHER BITS (DESIGN.md section 11)"))
 
 
 def gpu_verdict():
@@ -73,8 +74,8 @@ def gpu_verdict():
     try:
         import obca_amd
         r = obca_amd.selftest(0, repeats=3)
-        return " [self-test of this GPU right after the failure: %d (instance, run) results of %d x %d differ from the first run%s]" % (
-            r["differing"], r["runs"] - 1, r["instances"], "" if r["differing"] == 0 else ": THIS GPU DOES NOT REPRODUCE ITS OWN RESULTS, DESIGN.md section 11")
+        return " [self-test of this GPU right after the failure: %d (instance, run) results of %d x %d differ from the first run, %d after a foreign pattern in LDS%s]" % (
+            r["differing"], r["runs"] - 1, r["instances"], r["after_pattern"], "" if r["differing"] == 0 and r["after_pattern"] == 0 else ": SAME INPUTS, OTHER BITS -- DESIGN.md section 11")
     except Exception as e:      # noqa: BLE001
         return " [self-test could not run: %r]" % e
 

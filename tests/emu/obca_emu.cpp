@@ -149,6 +149,13 @@ static void emu_poison(int N, int len, Scratch &s, double *st) {
     }
     if (m & 4) for (size_t i = 0; i < OB_DYN_LDS_DOUBLES(N); i++) g_traj[i] = nan_;
 }
+static void emu_poison_lds_only(int N) {      // the LDS part of emu_poison (a resumed launch: the HBM buffers carry the parked solve)
+    const char *e = getenv("OBCA_EMU_POISON"); const int m = e ? atoi(e) : 0;
+    if (!m) return;
+    const char *pv = getenv("OBCA_EMU_POISON_VALUE"); const double v = pv ? atof(pv) : NAN;
+    if (m & 2) { double *w = (double *)&g_sh; for (size_t i = 0; i < sizeof(Shared) / sizeof(double); i++) w[i] = v; }
+    if (m & 4) for (size_t i = 0; i < OB_DYN_LDS_DOUBLES(N); i++) g_traj[i] = v;
+}
 int emu_solve(int N, const double *prob, const double *zinit, int len, const void *opts, double *zout, double *info) {
     Scratch s; alloc_scratch(N, len, s);
     { double *st0 = (double *)calloc(SL_SIZE, 8); emu_poison(N, len, s, st0); free(st0); }
@@ -175,6 +182,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     int launches = 0;
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
+        if (mode == 0) emu_poison(N, len, s, st); else { Scratch none = s; emu_poison_lds_only(N); (void)none; }      // (OBCA_EMU_POISON: every launch meets a foreign pattern in LDS)
         Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc;
         solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init);
         launches++;
@@ -244,6 +252,12 @@ int emu_quad_newton(int N, const double *prob, const double *zin, double mu, dou
 int emu_quad_solve(int N, const double *prob, const void *opts, double *zout, double *info) {
     QScratch s; quad::QLay l; q_alloc(N, s, l);
     quad::QShared &sh = quad::gq_sh;
+    if (const char *e = getenv("OBCA_EMU_POISON")) {      // as emu_poison: 1 the work buffers in "HBM", 2 the static LDS block of the quadcopter solver
+        const int m = atoi(e); const char *pv = getenv("OBCA_EMU_POISON_VALUE"); const double v = pv ? atof(pv) : NAN;
+        if (m & 1) { for (size_t i = 0; i < (size_t)QDIR_DOUBLES(l); i++) s.d[i] = v; for (size_t i = 0; i < (size_t)(N + 1) * QSP; i++) s.as[i] = v;
+                     for (size_t i = 0; i < (size_t)(N + 1) * QRR; i++) s.rs[i] = v; for (size_t i = 0; i < (size_t)(N + 1) * QOB * OB_OC; i++) s.oc[i] = v; for (int i = 0; i < l.len; i++) s.z[i] = v; }
+        if (m & 2) { double *w = (double *)&sh; for (size_t i = 0; i < sizeof(quad::QShared) / sizeof(double); i++) w[i] = v; }
+    }
     sh.inst.prob = (const gdbl *)prob; sh.inst.z = (gdbl *)s.z; sh.inst.d = (gdbl *)s.d; sh.inst.as = (gdbl *)s.as; sh.inst.rs = (gdbl *)s.rs; sh.inst.oc = (gdbl *)s.oc;
     emu_race_begin();
     emu_race_buffer("quad z", s.z, l.len, 0, -1); emu_race_buffer("quad d", s.d, QDIR_DOUBLES(l), 0, -1); emu_race_buffer("quad as", s.as, (long)(N + 1) * QSP, QSP, -1);

@@ -1,12 +1,17 @@
-"""Bit-reproducibility of the HIP path (run with -m gpu).  The driver's round-4 run met two runs of the same inputs that differed in the last bits (ragged batch, two
-chunks in flight on two streams).  The kernels hold no atomic and no order-dependent sum, so on sound hardware equal inputs give equal bits, whatever the
-chunking, the lanes and the load; round 5 traced the failures to single boxes of the pool that do not reproduce their own results -- a failure here carries
-the verdict of obca_amd.selftest() on the GPU it ran on.  Everything goes through libobca_hip.so and asserts EQUAL BITS:
+"""Same inputs, same bits (run with -m gpu).  The driver's round-4 run met two runs of the same inputs that differed in the last bits (ragged batch, two chunks in flight on two
+streams); round 5 found results that changed whenever another process ran kernels on the same GPU.  One cause: the parking kernels read two LDS words
+they never wrote -- the multiplier sums behind IPOPT's termination scaling factors, whose stores had slipped into a comment -- so a solve ended early whenever ANOTHER kernel had
+left large numbers there (a foreign process, or a workgroup of another horizon whose dynamic LDS block lay at that place).  The kernels hold no atomic and no order-dependent
+sum and read nothing they have not written; everything here goes through libobca_hip.so and asserts EQUAL BITS:
 
   * ragged batches (3-10 and 1-16 obstacles per instance, 1-8 rows per obstacle) solved as one device-resident batch = the same batch cut into chunks of every size over
     1-4 concurrent worker lanes, fresh and reused lane batches, permuted chunk -> lane assignment, >= 200 host-pointer calls, both option sets;
   * a batch that is re-solved while other launches run on the same GPU;
-  * the quadcopter path likewise."""
+  * (tests/test_gpu_history.py: a batch that is re-solved after a kernel has left a pattern in the registers, the LDS and the scratch memory of every CU, and after batches of
+    other horizons and of the other solver have run in between;)
+  * the quadcopter path likewise.
+
+A failure carries the verdict of obca_amd.selftest() on the GPU it ran on."""
 import os
 import numpy as np
 import pytest
