@@ -58,7 +58,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
     // mode 0: fresh solve of instance blockIdx.x from the iterate the host prepared in z;  mode 2: the same, but the workgroup first copies its instance's START iterate z0 -> z itself
-    // (the launch is then IDEMPOTENT: a workgroup that is executed again -- see DESIGN.md section 11 -- starts from the same point and writes the same results);  mode 1: resume
+    // (the launch is then IDEMPOTENT: a workgroup that were executed again would start from the same point -- a diagnostic of the round-5 search; OBCA_IDEMPOTENT=1);  mode 1: resume
     const int inst = mode == 1 ? b.order[blockIdx.x] : (int)blockIdx.x;
     if (inst < 0 || inst >= B) return;
     if (mode == 2) {

@@ -66,3 +66,19 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp_, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "obca_oracle" not in src, f
                 assert "libobca_emu" not in src, f
+
+
+def test_no_statement_hides_at_the_end_of_a_comment():
+    """From round 4 to the end of round 5 the line `... out.cmax = cmx;      // (largest |s z| ...) out.sumy = sumy; out.sumz = sumz;` kept two stores of the parking kernels'
+    assembly inside a comment (DESIGN.md section 11).  No line of the kernel, host or oracle sources may end a `//` comment with what reads like a statement."""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stmt = re.compile(r"//.*[\)\.;] +[A-Za-z_][A-Za-z_0-9\.\[\]>-]* *[-+*/|&]?= *[^=].*;\s*$|//.*[\)\.;] +(if|for|while|return|break|continue)\b.*[;}]\s*$|//.*[\)\.] +[A-Za-z_][A-Za-z_0-9:]*\(.*\);\s*$")
+    files = [f for pat in ("obca_amd/csrc/*.h", "obca_amd/csrc/*.hip", "obca_amd/csrc/*.cpp", "oracle/*.c", "oracle/*.h", "tests/emu/*.cpp", "include/*.h") for f in glob.glob(os.path.join(root, pat))]
+    assert len(files) >= 10
+    hits = []
+    for f in files:
+        for n, line in enumerate(open(f, errors="replace"), 1):
+            if stmt.search(line):
+                hits.append("%s:%d: %s" % (os.path.relpath(f, root), n, line.strip()[-120:]))
+    assert not hits, "\n".join(hits)

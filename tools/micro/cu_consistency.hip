@@ -1,7 +1,8 @@
 // cu_consistency.hip -- does every compute unit of this GPU compute the same bits, run after run?
 //
 // Round 5 met ONE leased MI355X (of seven) on which the solver's results differed between two runs of the same inputs whenever a batch filled the machine (>= 640
-// one-wavefront workgroups), while five other boxes were bit-reproducible over thousands of solves.  This probe separates a defect of a hardware unit from a defect of the
+// one-wavefront workgroups), while five other boxes were bit-reproducible over thousands of solves.  (What that box had met: foreign leftovers in LDS, read by two never-stored
+// sums of the parking kernels -- DESIGN.md section 11.  The probe stays as a unit check.)  This probe separates a defect of a hardware unit from a defect of the
 // code pattern: 1 024 workgroups of one wavefront each (256 VGPRs + 40 KB of LDS: four per CU, one per SIMD, as the solver's) all run the SAME deterministic work on the
 // SAME inputs, in five categories that mirror what the solver does; every workgroup reports a checksum per category and the unit it ran on (XCC, SE, CU, SIMD).  Any
 // checksum that deviates from the majority names the category and the unit.
