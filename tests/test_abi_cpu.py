@@ -82,3 +82,11 @@ def test_no_statement_hides_at_the_end_of_a_comment():
             if stmt.search(line):
                 hits.append("%s:%d: %s" % (os.path.relpath(f, root), n, line.strip()[-120:]))
     assert not hits, "\n".join(hits)
+
+
+def test_diagnostic_entry_points_refuse_null_handles(lib):
+    """(argument checks only: no device is touched)"""
+    lib.obca_debug_leave_pattern.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    assert lib.obca_debug_leave_pattern(None, 4, 1e30) == -1
+    lib.obca_batch_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.obca_batch_debug_phase_cycles(None, None) == -1
