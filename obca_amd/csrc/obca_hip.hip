@@ -70,7 +70,10 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     }
 #ifdef OBCA_POISON      // diagnostic build: whatever the previous workgroup on this CU left in LDS is replaced by NaNs before anything is initialised
     {
-        const double nan_ = __longlong_as_double(-1LL);
+#ifndef OBCA_POISON_VALUE      // (NaN hides behind fmax / fmin and every comparison: build with -DOBCA_POISON_VALUE=1e30 as well)
+#define OBCA_POISON_VALUE __longlong_as_double(-1LL)
+#endif
+        const double nan_ = OBCA_POISON_VALUE;
         double *w = (double *)&g_sh;
 #ifndef OBCA_POISON_PARTS
 #define OBCA_POISON_PARTS 15      // bit 0: HBM work buffers, 1: the static LDS block, 2: the dynamic LDS block, 3: the guard behind it (bisecting builds set a subset)
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(QNT, OBCA_QUAD_WAVES_PER_EU) void obca_quad_ipm_ker
     if (inst >= B) return;
 #ifdef OBCA_POISON
     {
-        const double nan_ = __longlong_as_double(-1LL);
+        const double nan_ = OBCA_POISON_VALUE;
         double *w = (double *)&quad::gq_sh;
         for (int i = threadIdx.x; i < (int)(sizeof(quad::QShared) / sizeof(double)); i += QNT) w[i] = nan_;
         for (int i = threadIdx.x; i < (N + 2) * (QS + QU); i += QNT) quad::gq_traj[i] = nan_;
