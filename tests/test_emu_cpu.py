@@ -401,8 +401,9 @@ def test_instances_at_the_obstacle_and_row_limits_follow_the_oracle(oracle):
         assert np.abs(e["xp"][0] - r["xp"]).max() < 1e-7
 
 
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
 @pytest.mark.parametrize("s_max", [1e-2, 1e-4], ids=["s_max_0.01", "s_max_0.0001"])
-def test_termination_scaling_factors_in_the_kernels_follow_the_oracle(oracle, emu, backwards, s_max):
+def test_termination_scaling_factors_in_the_kernels_follow_the_oracle(oracle, emu, backwards, s_max, dist):
     """IPOPT's s_d, s_c (mean multiplier magnitude over s_max, at least 1) scale the optimality error of the termination test.  With the default s_max = 100 both are 1 on nearly
     every instance, which is why parity never noticed that the kernels' multiplier sums were not stored (round 4 - round 5); a small s_max makes them bite:
     the solve then ends earlier, at the same iteration as the oracle's."""
@@ -416,8 +417,8 @@ def test_termination_scaling_factors_in_the_kernels_follow_the_oracle(oracle, em
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
         lWS, nWS, _ = oracle.dualmult_ws(N, v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
         args = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i], lWS, nWS)
-        r = oracle.parking_signed_dist(*args, opts=oo); r1 = oracle.parking_signed_dist(*args, opts=o1)
-        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+        r = oracle.parking_signed_dist(*args, opts=oo, dist=dist); r1 = oracle.parking_signed_dist(*args, opts=o1, dist=dist)
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], v, bt["A"], bt["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
         z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=bt["A"])
         zo = np.zeros_like(z0); info = np.zeros(8)
         emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(zo), dp(info))
