@@ -115,3 +115,23 @@ def test_emu_quad_ipopt_switches_match_oracle_options(Q, emu):
             assert np.abs(up - r["up"]).max() < 1e-5
             res[(msoc, lsq, osc)] = int(info[1])
         assert res[(4, 0, 0)] != res[(0, 0, 0)] and res[(0, 1, 0)] != res[(0, 0, 0)] and res[(0, 0, 1)] != res[(0, 0, 0)], (i, res)
+
+
+@pytest.mark.parametrize("s_max", [1e-2, 1e-4], ids=["s_max_0.01", "s_max_0.0001"])
+def test_quad_termination_scaling_factors_follow_the_oracle(Q, emu, s_max):
+    """IPOPT's s_d, s_c made active by a small s_max (with the default 100 they are 1 on these instances): kernel source and oracle stop at the same iteration -- the check that
+    found nothing wrong here and would have found the parking kernels' never-stored sums (tests/test_emu_cpu.py)"""
+    N = 16; Ts = round(0.25 * 80 / N * 100) / 100
+    xWS = Q.warm_start(Q.X0, Q.XF, N, VIA)
+    oo = Q.default_opts(); oo.s_max = s_max; eo = EOpts()
+    for f, _ in EOpts._fields_:
+        if hasattr(oo, f):
+            setattr(eo, f, getattr(oo, f))
+    r = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, opts=oo)
+    r1 = Q.quadcopter_signed_dist(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0)
+    L = P.quad_layout(N); prob = P.pack_quad_problem(Q.X0, Q.XF, N, Ts, Q.EGO_R, Q.OB_CLAMPED, xWS, 1.0, dual_ws=1)
+    z = np.zeros(L["len"]); info = np.zeros(8)
+    emu.emu_quad_solve(C.c_int(N), dp(prob), C.byref(eo), dp(z), dp(info))
+    assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"], (info[1], r["iters"], r1["iters"])
+    assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"])
+    assert r["iters"] != r1["iters"]         # the factors were active (they also enter the barrier update: the count may go either way)
