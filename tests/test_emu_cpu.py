@@ -451,3 +451,43 @@ def test_a_solve_reads_nothing_it_has_not_written_whatever_the_pattern(emu, back
                 assert np.array_equal(o["info"], ref["info"]) and np.array_equal(o["xp"], ref["xp"]) and np.array_equal(o["up"], ref["up"]), (kw, value, o["iters"], ref["iters"])
     finally:
         os.environ.pop("OBCA_EMU_POISON", None); os.environ.pop("OBCA_EMU_POISON_VALUE", None)
+
+
+def test_random_problems_keep_their_bits_under_finite_poison(emu):
+    """The check above on 36 seeded random draws of (horizon, scenario incl. 1-16 obstacles of up to 8 rows, formulation, fixed / variable time, option set, iteration limit
+    small enough to end the first attempt -> retry path): the pattern 1e30 / -1e30 in work buffers and LDS leaves info, states and inputs unchanged."""
+    import os
+    import emu_solver as E
+    rng = np.random.default_rng(20260926)
+    d0 = E.default_opts
+    checked = 0
+    try:
+        for draw in range(36):
+            N = int(rng.choice([5, 8, 13, 21, 34, 55])); kind = int(rng.integers(0, 3)); dist = bool(rng.integers(0, 2)); fix = int(rng.integers(0, 2))
+            kw = dict(max_soc=4, recalc_y=1, lsq_init=1) if rng.integers(0, 2) else dict()
+            max_iter = int(rng.choice([200, 200, 6]))
+            if kind == 2:
+                bt = S.make_mixed_batch(2, N, seed=int(rng.integers(1, 1000)), min_obstacles=1, max_extra=13, rows=(3, 8), max_rows=64); v, A, b = bt["vOb"][1], bt["A"][1], bt["b"][1]; i = 1
+            else:
+                bt = S.make_batch(S.BACKWARDS if kind == 0 else S.PARALLEL, 2, N, seed=int(rng.integers(1, 1000))); v, A, b = bt["vOb"], bt["A"], bt["b"]; i = 1
+            xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]; sl = slice(i, i + 1); Ts = np.broadcast_to(bt["Ts"], (2,))[sl]
+
+            def patched(max_iter=max_iter):
+                o = d0(); o.max_iter = max_iter; return o
+            E.default_opts = patched
+
+            def solve():
+                return E.parking_signed_dist_batch(bt["x0"][sl], bt["xF"][sl], N, Ts, bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[sl, :, 0], xWS[sl, :, 1], xWS[sl, :, 2], fix, xWS[sl], bt["uWS"][sl],
+                                                   dist=dist, **kw)
+            os.environ.pop("OBCA_EMU_POISON", None)
+            ref = solve()
+            for value in ("1e30", "-1e30"):
+                os.environ["OBCA_EMU_POISON"] = "7"; os.environ["OBCA_EMU_POISON_VALUE"] = value
+                o = solve()
+                assert np.array_equal(o["info"], ref["info"], equal_nan=True) and np.array_equal(o["xp"], ref["xp"], equal_nan=True) and np.array_equal(o["up"], ref["up"], equal_nan=True), \
+                    (draw, N, kind, dist, fix, kw, max_iter, value, o["info"], ref["info"])
+            checked += 1
+    finally:
+        E.default_opts = d0
+        os.environ.pop("OBCA_EMU_POISON", None); os.environ.pop("OBCA_EMU_POISON_VALUE", None)
+    assert checked == 36

@@ -135,3 +135,26 @@ def test_quad_termination_scaling_factors_follow_the_oracle(Q, emu, s_max):
     assert r["exitflag"] == 1 and info[7] == 1 and int(info[1]) == r["iters"], (info[1], r["iters"], r1["iters"])
     assert abs(info[2] - r["obj"]) < 1e-9 * abs(r["obj"])
     assert r["iters"] != r1["iters"]         # the factors were active (they also enter the barrier update: the count may go either way)
+
+
+def test_quad_solves_keep_their_bits_under_finite_poison(emu):
+    """tests/emu/obca_emu.cpp fills the quadcopter solver's work buffers and its LDS block with a pattern before the solve (OBCA_EMU_POISON): horizons, formulations and switches
+    drawn at random, 1e30 / -1e30 / NaN leave every bit of the result (NaN alone would not do: it hides behind fmax)"""
+    import os
+    import emu_solver as E
+    from obca_amd import scenarios as S
+    rng = np.random.default_rng(20260926)
+    try:
+        for draw in range(10):
+            N = int(rng.choice([8, 12, 16, 21])); q = S.make_quad_batch(2, N, seed=int(rng.integers(1, 1000)))
+            kw = dict(max_soc=4, lsq_init=1, obj_scaling=1) if rng.integers(0, 2) else dict()
+            kw["dist"] = bool(rng.integers(0, 2)); kw["dual_ws"] = bool(rng.integers(0, 2))
+            solve = lambda: E.quadcopter_signed_dist_batch(q["x0"][1:], q["xF"][1:], N, q["Ts"], q["R"], q["ob"], q["xWS"][1:], q["timeWS"], **kw)
+            os.environ.pop("OBCA_EMU_POISON", None)
+            ref = solve()
+            for value in ("1e30", "-1e30", "nan"):
+                os.environ["OBCA_EMU_POISON"] = "3"; os.environ["OBCA_EMU_POISON_VALUE"] = value
+                o = solve()
+                assert np.array_equal(o["info"], ref["info"], equal_nan=True) and np.array_equal(o["xp"], ref["xp"], equal_nan=True), (draw, N, kw, value, o["info"], ref["info"])
+    finally:
+        os.environ.pop("OBCA_EMU_POISON", None); os.environ.pop("OBCA_EMU_POISON_VALUE", None)
