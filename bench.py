@@ -672,6 +672,14 @@ def main():
     if rank == 0 and world == 1 and cfg == 2 and not a.no_other_configs:
         others = [other_config_line(c_, local, other_prepared[c_], other_cpu.get(c_)) for c_ in (3, 4, 5)]
     same = all(np.array_equal(o["info"], out["info"]) and np.array_equal(np.asarray(o["xp"]), np.asarray(out["xp"])) for o in outs[1:])
+    # ---- and the same bits after a kernel has left a large pattern in the registers, LDS and scratch of every CU (until the end of round 5 the parking
+    # kernels' termination test read LDS words nothing had written).  A report in `config`, never a condition of the line.
+    try:
+        batches[0].ctx.debug_leave_pattern(15, 1e30)
+        batches[0].solve(opts=run_opts, sync=True); o_ = batches[0].download()
+        after_pattern = bool(np.array_equal(o_["info"], out["info"]) and np.array_equal(np.asarray(o_["xp"]), np.asarray(out["xp"])))
+    except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the line
+        after_pattern = "not run: %r" % (e,)
     # ---- gather the full result tuple of every instance on rank 0 (one gather), validate there: a solve counts only if exitflag == 1 AND the
     # returned trajectory passes the a-posteriori checker (obca_amd/validate.py, pure numpy, outside the timed region)
     T = lambda x: np.transpose(np.asarray(x), (0, 2, 1)).reshape(B, -1)
@@ -780,7 +788,7 @@ def main():
                        "sharding": f"one host batch of {B_total} instances made on rank 0, scattered over {world} rank(s) (one scatter), solved device-resident, full result tuples "
                                    f"gathered on rank 0 (one gather) and validated there; no collective inside the timed region",
                        "streams": nS, "timed_region_s": round(dt, 3), "converged": conv_all, "exitflag_ok": conv_flag, "instances": B_total,
-                       "exitflag2": int((ef == 2).sum()), "copies_bit_identical": bool(same), "mean_iterations": round(float(iters.mean()), 2), "max_iterations": int(iters.max()),
+                       "exitflag2": int((ef == 2).sum()), "copies_bit_identical": bool(same), "same_bits_after_foreign_pattern_on_the_cus": after_pattern, "mean_iterations": round(float(iters.mean()), 2), "max_iterations": int(iters.max()),
                        "p95_iterations": float(np.percentile(iters, 95)), "mean_passes": round(passes_all / B_total, 2),
                        "single_batch_sync_solves_per_s": round(conv_all / world / float(np.median(sync_s)), 1),
                        "single_batch_sync_note": "one batch issued and waited for (reset + DualMultWS + interior point, inputs resident): what a caller without several batches in flight gets",
