@@ -47,7 +47,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
+    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_diag.h", "obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
            [os.path.join(_HERE, "..", "include", "obca_hip.h"), os.path.abspath(__file__)]      # (this file holds the compile flags)
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(s) for s in srcs):
         return _LIBPATH
