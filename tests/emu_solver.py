@@ -22,6 +22,7 @@ class EOpts(C.Structure):
 
 _VARIANTS = {None: ("libobca_emu.so", ["-O1"]),
              "race": ("libobca_emu_race.so", ["-O0", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_RACE"]),      # cross-lane hazards through HBM (tests/test_emu_sanitize.py)
+             "ubsan": ("libobca_emu_ubsan.so", ["-O1", "-g", "-fsanitize=undefined,bounds-strict", "-fno-sanitize-recover=undefined"]),      # index / shift / overflow checks
              "asan": ("libobca_emu_asan.so", ["-O1", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_ASAN", "-fsanitize=address"])}      # exact buffer sizes under AddressSanitizer
 _loaded = {}
 

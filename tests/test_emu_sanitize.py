@@ -1,4 +1,4 @@
-"""The solver source under two checking builds of the host emulation (tests/emu/obca_emu.cpp); no GPU needed.
+"""The solver source under three checking builds of the host emulation (tests/emu/obca_emu.cpp); no GPU needed.
 
   race   -DOBCA_EMU_RACE: every load and store of a per-instance HBM buffer is logged with the lane that issued it.  The lanes of an instance hand data to each other through
          HBM (stage records, Riccati records, the direction); unlike LDS traffic, global loads and stores of one wavefront are not ordered against each other, so a word that one
@@ -7,7 +7,10 @@
   asan   -DOBCA_EMU_ASAN -fsanitize=address: the per-instance buffers have exactly the sizes the HIP host code gives them (obca_hip.hip: batch_create) and the dynamic LDS block
          ends where the launch's does -- an access one double beyond any of them aborts the run.
 
-Both run full solves: uniform and ragged obstacle sets, both option sets (the second-order correction and the least-squares multipliers have phases of their own), the
+  ubsan  -fsanitize=undefined,bounds-strict: an index beyond a member array of the LDS structs (the filter, the reduction scratch, the unpack tables ...), a signed overflow, a bad
+         shift aborts the run.
+
+All run full solves: uniform and ragged obstacle sets, both option sets (the second-order correction and the least-squares multipliers have phases of their own), the
 minimum-distance formulation, and the quadcopter solver."""
 import ctypes as C
 import os
@@ -95,3 +98,14 @@ def test_no_access_beyond_the_sizes_the_host_code_allocates():
     assert r.returncode == 0, r.stderr[-3000:]
     solved = [l for l in r.stdout.splitlines() if l.startswith("SOLVED")]
     assert len(solved) >= 20, r.stdout[-2000:]
+
+
+@pytest.mark.timeout(1800)
+def test_no_undefined_behaviour_in_the_solver_source():
+    ub = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(ub) or not os.path.exists(ub):
+        pytest.skip("no UndefinedBehaviorSanitizer runtime next to gcc")
+    r = _run("ubsan", env=dict(LD_PRELOAD=ub, UBSAN_OPTIONS="print_stacktrace=1"))
+    assert "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("SOLVED")]) >= 20, r.stdout[-2000:]
