@@ -383,6 +383,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         D.have_asm = 0;
         if (D.it == 0) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); }
         D.f = A.f; D.pinf = A.pinf; D.dinf = A.dinf;
+#ifdef OBCA_EMU      // OBCA_EMU_TRACE=1: one line per iteration in the format of the oracle's `verbose` option (oracle/obca_oracle.c), so that two traces can be laid side by side
+        if (getenv("OBCA_EMU_TRACE")) printf("it %3d f=% .8e pinf=%.2e dinf=%.2e cinf=%.2e mu=%.1e dw=%.1e t=%.4f\n", D.it, A.f, A.pinf, A.dinf, A.cinf0, D.mu, D.dw_last, (double)sh.inst.z[sh.l.t]);
+#endif
         {
             const double sd = fmax(o.s_max, (A.sumy + A.sumz) / (A.nm + A.nb)) / o.s_max;
             const double sc = fmax(o.s_max, A.sumz / A.nb) / o.s_max;
@@ -466,6 +469,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             }
             D.alpha = 0.5 * alpha;
         }
+#ifdef OBCA_EMU
+        if (getenv("OBCA_EMU_TRACE")) printf("   ls: alpha_max %.3e accepted %.3e soc %d dw %.1e nreg %d\n", sh.S.ap, D.acc ? D.alpha : 0.0, sh.soc.nsoc_acc, D.dw, D.nreg);
+#endif
         if (!D.acc) { D.status = ST_ERROR; break; }   // IPOPT would enter restoration here
         // accepted: the trial buffer becomes the iterate, its assembly the current one
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
