@@ -522,3 +522,31 @@ def test_random_problems_the_kernels_follow_the_oracle(oracle):
         elif r["exitflag"] == 1:
             solved += 1; worst = max(worst, float(np.abs(e["xp"][0] - r["xp"]).max()))
     assert off <= 1 and solved >= 110 and worst < 1e-6, (off, solved, worst)
+
+
+def test_random_problems_sliced_solves_are_bit_identical(oracle, emu):
+    """the two-launch schedule on 80 seeded random draws of (horizon, scenario, formulation, option set, slice length 1-11 passes, iteration limit small enough to cut inside the
+    retry attempt): the solve parked and resumed launch after launch returns the bits of the uninterrupted one (600 such draws were run once in round 5: none differed)"""
+    import emu_solver as E
+    launches_total = 0
+    for seed in range(5000, 5080):
+        rng = np.random.default_rng(seed)
+        N = int(rng.choice([8, 13, 20, 33, 48])); kind = int(rng.integers(0, 3)); dist = int(rng.integers(0, 2)) if kind != 2 else 0
+        ref = bool(rng.integers(0, 2)); budget = int(rng.integers(1, 12)); max_iter = int(rng.choice([3000, 3000, 7, 12]))
+        if kind == 2:
+            bt = S.make_mixed_batch(2, N, seed=int(rng.integers(1, 10000)), min_obstacles=1, max_extra=13, rows=(3, 8), max_rows=64); v, A, b = np.asarray(bt["vOb"][1]), bt["A"][1], bt["b"][1]
+        else:
+            bt = S.make_batch(S.BACKWARDS if kind == 0 else S.PARALLEL, 2, N, seed=int(rng.integers(1, 10000))); v, A, b = bt["vOb"], bt["A"], bt["b"]
+        i = 1; nOb = len(v); M = int(np.sum(v)); L = P.layout(N, nOb, M)
+        eo = E.default_opts(); eo.max_iter = max_iter
+        if ref:
+            eo.max_soc = 4; eo.recalc_y = 1; eo.lsq_init = 1
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]; Ts = float(np.broadcast_to(bt["Ts"], (2,))[i])
+        lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+        prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, Ts, bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
+        z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=A)
+        za = np.zeros_like(z0); ia = np.zeros(8); zb = np.zeros_like(z0); ib = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(za), dp(ia))
+        launches_total += emu.emu_solve_sliced(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), C.c_int(budget), dp(zb), dp(ib))
+        assert np.array_equal(ia, ib, equal_nan=True) and np.array_equal(za, zb, equal_nan=True), (seed, N, kind, dist, ref, budget, max_iter, ia, ib)
+    assert launches_total > 800
