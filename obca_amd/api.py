@@ -89,8 +89,8 @@ def selftest(device=0, repeats=4, opts=None):
     solved `repeats` times as one device-resident batch and every download is compared bit for bit with the first; then a kernel leaves a large finite pattern in the LDS of every
     CU (obca_debug_leave_pattern) and the batch is solved once more.  Returns a dict: `differing` = (instance, run) pairs that differ, `after_pattern` = instances that differ
     after the pattern, `instances`, `runs`, `solved`, `device`.  Both counts are 0: the kernels contain no atomics and no order-dependent reductions, and read nothing they have not
-    written (DESIGN.md sections 3 and 11 -- until the end of round 5 two LDS words of the parking kernels were read unwritten, and results changed with what other kernels had
-    left there, e.g. when another process shared the GPU)."""
+    written (DESIGN.md sections 3 and 11 -- until the end of round 5 the multiplier sums of the parking kernels' termination test were read from LDS unwritten, and results changed with what other
+    kernels had left there, e.g. when another process shared the GPU)."""
     from . import scenarios as S
     N, B = 80, 1024
     bt = S.make_batch(S.BACKWARDS, B, N)
