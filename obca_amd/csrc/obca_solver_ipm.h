@@ -383,7 +383,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         D.have_asm = 0;
         if (D.it == 0) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); }
         D.f = A.f; D.pinf = A.pinf; D.dinf = A.dinf;
-#ifdef OBCA_EMU      // OBCA_EMU_TRACE=1: one line per iteration in the format of the oracle's `verbose` option (oracle/obca_oracle.c), so that two traces can be laid side by side
+#ifdef OBCA_EMU      // OBCA_EMU_TRACE=1: one line per iteration in the format of the CPU checker's `verbose` option (test infrastructure), so that two traces can be laid side by side
         if (getenv("OBCA_EMU_TRACE")) printf("it %3d f=% .8e pinf=%.2e dinf=%.2e cinf=%.2e mu=%.1e dw=%.1e t=%.4f\n", D.it, A.f, A.pinf, A.dinf, A.cinf0, D.mu, D.dw_last, (double)sh.inst.z[sh.l.t]);
 #endif
         {
