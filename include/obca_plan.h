@@ -12,23 +12,34 @@
 extern "C" {
 #endif
 
+#define OBCA_PLAN_NOPTS 16      /* options the search knows (below) */
+
 /* Hybrid A* from start (x, y, yaw) to goal.  ego = [front, left, rear, right] extents from the rear axle (main.jl:73), L = wheelbase,
  * XYbounds = [xmin, xmax, ymin, ymax] of the rear-axle position.
- * opts (NULL = defaults): {xy resolution 0.25, yaw resolution [deg] 7.5, primitive length 0.6, max steer 0.6, steer samples per side 2,
+ * opts (NULL = defaults), nopts = how many doubles the caller's array holds (0 .. OBCA_PLAN_NOPTS; options beyond it keep their defaults, nothing beyond it is read):
+ *   {xy resolution 0.25, yaw resolution [deg] 7.5, primitive length 0.6, max steer 0.6, steer samples per side 2,
  *   collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance [deg] 8, reverse cost 1.5, switch cost 2.0, steer cost 0.3,
  *   max expansions 400000, analytic expansion (1: try the shortest Reeds-Shepp curve to the goal from expanded nodes, as the reference does) 1,
- *   steer-change cost per radian 0.2, weight of the heuristic 1 (hybrid_a_star.jl:64 H_COST), Reeds-Shepp length as a second heuristic 0 (hybrid_a_star.jl:58)}
- *   (16 doubles; 14 until round 4).
+ *   steer-change cost per radian 0.2, weight of the heuristic 1 (hybrid_a_star.jl:64 H_COST; must be positive and finite),
+ *   Reeds-Shepp length as a second heuristic 0 (hybrid_a_star.jl:58)}.
  * Output: path[3k..3k+2] = x, y, yaw of node k (0.2 m apart), dir[k] = +1 / -1 (motion that led to the node), at most cap nodes.
- * Returns the number of nodes (>= 2); 0 = no path; -1 = bad arguments / cap too small; -2 = start or goal pose collides. */
+ * Returns the number of nodes (>= 2); 0 = no path; -1 = bad arguments (nopts out of range, heuristic weight <= 0 or not finite) / cap too small; -2 = start or goal pose collides. */
+int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                            const double ego[4], double L, const double XYbounds[4], const double *opts, int nopts, double *path, int *dir, int cap,
+                            int *expansions /* may be NULL */);
+/* The entry point of rounds 1-4: opts (NULL = defaults) is an array of exactly the FIRST 14 options above; heuristic weight 1, no Reeds-Shepp heuristic. */
 int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
                            const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
                            int *expansions /* may be NULL */);
 
 /* The same search for B independent (start, goal) pairs in one obstacle field, on `threads` host threads (0 = one per hardware thread) inside the library: what a rank
  * calls for its slice of a batch before the solve (main.jl:216-252 plans one instance; a batch of 2 048 parallel-parking starts takes ~0.2 core-seconds each).
- * starts / goals: B x 3; paths: B x cap x 3; dirs: B x cap; counts[i] = what obca_plan_hybrid_astar returns for pair i; expansions (may be NULL): B.
+ * starts / goals: B x 3; paths: B x cap x 3; dirs: B x cap; counts[i] = what obca_plan_hybrid_astar2 returns for pair i; expansions (may be NULL): B.
  * Returns 0, or -1 on bad arguments. */
+int obca_plan_hybrid_astar_batch2(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
+                                  const double ego[4], double L, const double XYbounds[4], const double *opts, int nopts, double *paths, int *dirs, int cap,
+                                  int *counts, int *expansions /* may be NULL */, int threads);
+/* rounds 1-4 form: opts = the first 14 options */
 int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
                                  const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
                                  int *counts, int *expansions /* may be NULL */, int threads);

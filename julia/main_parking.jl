@@ -31,12 +31,12 @@ function obstHrep(nOb, vOb, lOb)
 end
 
 "Hybrid A* through the C ABI of libobca_plan.so: returns path (K x 3), dir (K)"
-function hybrid_astar(x0, xF, vObMPC, A, b, ego, L, XYbounds; opts=C_NULL)
-    cap = 20000; path = zeros(3, cap); dir = zeros(Cint, cap)
-    n = ccall((:obca_plan_hybrid_astar, PLAN), Cint,
-              (Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cint}),
+function hybrid_astar(x0, xF, vObMPC, A, b, ego, L, XYbounds; opts=Float64[])      # opts: the first length(opts) options of include/obca_plan.h (empty = defaults)
+    cap = 20000; path = zeros(3, cap); dir = zeros(Cint, cap); o = Float64.(vec(opts))
+    n = ccall((:obca_plan_hybrid_astar2, PLAN), Cint,
+              (Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cint}),
               Float64.(x0[1:3]), Float64.(xF[1:3]), length(vObMPC), Cint.(vec(vObMPC)), vec(permutedims(Float64.(A))), Float64.(b), Float64.(ego), L,
-              Float64.([XYbounds[1], XYbounds[2], XYbounds[3], XYbounds[4]]), opts, path, dir, cap, C_NULL)
+              Float64.([XYbounds[1], XYbounds[2], XYbounds[3], XYbounds[4]]), o, length(o), path, dir, cap, C_NULL)
     n > 0 || error("Hybrid A*: no path ($n)")
     return permutedims(path[:, 1:n]), dir[1:n]
 end

@@ -48,14 +48,11 @@ def library_path():
 def build_library(force=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_diag.h", "obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
-           [os.path.join(_HERE, "..", "include", "obca_hip.h"), os.path.abspath(__file__)]      # (this file holds the compile flags)
+           [os.path.join(_HERE, "..", "include", "obca_hip.h"), os.path.join(_HERE, "buildflags.py")]      # (that file holds the compile flags)
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(s) for s in srcs):
         return _LIBPATH
-    # -fno-optimize-sibling-calls: the phases of the solve are non-inlined local device functions that use the whole register file.  LLVM drops the
-    # callee-saved-register saves of such functions (every caller is known) only if no call site is marked `tail`, and -O3 marks them all; with the
-    # flag the 112 VGPR + ~150 AGPR saves / restores per phase call disappear: 0.23 MB less scratch traffic per factorisation pass, 140 k -> 154 k solves/s.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-optimize-sibling-calls",
-           "-I" + os.path.join(_HERE, "..", "include"), "-o", _LIBPATH, os.path.join(_CSRC, "obca_hip.hip")]
+    from .buildflags import HIPCC      # the flags (warnings are errors) and why: obca_amd/buildflags.py
+    cmd = HIPCC + ["-o", _LIBPATH, os.path.join(_CSRC, "obca_hip.hip")]
     subprocess.check_call(cmd)
     return _LIBPATH
 

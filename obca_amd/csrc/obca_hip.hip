@@ -311,6 +311,10 @@ struct obca_batch {
 };
 
 #define HIPCHK(bt, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (bt)->err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+// The device index of a context / batch was validated when the context was created (obca_create: hipSetDevice checked there); later calls only select it again,
+// and whatever they then launch or copy reports its own error.  Release paths ignore the status of hipFree & co. on purpose -- `(void)` says so at each site
+// (the library builds with -Wall -Wextra -Werror: an ignored status is a compile error).
+static inline void use_device(int device) { (void)hipSetDevice(device); }
 static inline int fin(obca_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
 // Device work buffers never carry what a previous owner of the memory left in them:
 // every allocation is filled once, on the stream of the batch it belongs to (the
@@ -331,7 +335,7 @@ static hipError_t dev_alloc(void **p, size_t bytes, hipStream_t stream) {
 
 static int pinned_reserve(std::string &err, double **p, size_t *cap, size_t need) {
     if (*cap >= need) return 0;
-    if (*p) hipHostFree(*p);
+    if (*p) (void)hipHostFree(*p);
     *p = nullptr; *cap = 0;
     if (hipHostMalloc((void **)p, need * sizeof(double), hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return -2; }
     *cap = need;
@@ -403,7 +407,7 @@ int obca_create_multi(obca_ctx **out, const int *devices, int ndev) {
         c->slots.push_back(sl);
     }
     c->device = c->slots[0].device; c->stream = c->slots[0].stream;
-    hipSetDevice(c->device);
+    use_device(c->device);
     *out = c;
     return 0;
 }
@@ -416,7 +420,7 @@ int obca_destroy(obca_ctx *c) {
     for (auto &s : c->slots) {
         if (s.pb) obca_batch_destroy(s.pb);
         if (s.qb) obca_quad_batch_destroy(s.qb);
-        if (s.stream) { hipSetDevice(s.device); hipStreamDestroy(s.stream); }
+        if (s.stream) { use_device(s.device); (void)hipStreamDestroy(s.stream); }
     }
     delete c; return 0;
 }
@@ -433,15 +437,15 @@ static int batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B,
     bt->zlen = 0; bt->fixTime = 0; bt->vmax = 0;
     memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr; bt->dcap_stage = 0;
     bt->h_prob = bt->h_zin = bt->h_zout = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_zin = bt->hcap_zout = bt->hcap_info = 0;
-    hipSetDevice(device);
+    use_device(device);
     if (hipEventCreate(&bt->e0) != hipSuccess || hipEventCreate(&bt->e1) != hipSuccess || hipEventCreate(&bt->e2) != hipSuccess) { err = "hipEventCreate failed"; delete bt; return -2; }
     *out = bt;
     return 0;
 }
 static void free_dev(obca_batch *bt) {
     double **ps[] = {&bt->d.prob, &bt->d.z0, &bt->d.z, &bt->d.zn, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.dws, &bt->d.prof, &bt->d.slice, &bt->d.csoc, &bt->stage};
-    for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
-    if (bt->d.order) hipFree(bt->d.order); bt->d.order = nullptr;
+    for (auto p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (bt->d.order) (void)hipFree(bt->d.order); bt->d.order = nullptr;
     bt->dcap_stage = 0;
 }
 
@@ -482,7 +486,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
     }
     bt->obOff[n] = in.obOff[lo + n]; bt->rowOff[n] = in.rowOff[lo + n];
     bt->rowLen.assign((size_t)(bt->rowOff[n] - bt->rowOff[0]), 1.0);
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     const size_t B = bt->cap;
     if (!bt->uploaded || nObMax > bt->nObMax || MMax > bt->MMax) {       // (a cached batch keeps the largest shape it has seen)
         // (re)allocation: the batch counts as empty until every buffer exists -- a failed hipMalloc must leave a state the next call can recover from,
@@ -588,7 +592,7 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     if (!dualws_only && bt->N < 2) { bt->err = "obca_batch_solve: the NLP needs a horizon N>=2"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_default_opts(&o);
     Opts ko; memcpy(&ko, &o, sizeof ko);
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
     // IPOPT's objective scaling is 1 on the parking NLP only at the reference's own start
     // (gradient = the slack penalty 1e2); a caller's start with a larger gradient would
@@ -664,7 +668,7 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
 static int batch_download_range(obca_batch *bt, const ParkOut &o, int lo) {
     const int B = bt->B, N = bt->N, N1 = N + 1;
     const DevBufs &d = bt->d;
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     Lay lmax; make_layout(N, bt->nObMax, bt->MMax, lmax);
     const size_t W = (size_t)lmax.so;                       // outputs are a prefix of the iterate: x, u, t, lam, mu, sl
     const bool want_z = o.xp || o.up || o.ts || o.lp || o.np || o.slp || o.lWS || o.nWS;
@@ -719,7 +723,7 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
     }
     auto work = [&](int w) {
         Slot &s = ctx->slots[w];
-        hipSetDevice(s.device);
+        use_device(s.device);
         for (;;) {
             const int t = next.fetch_add(1);
             if (t >= nchunks) break;
@@ -736,7 +740,7 @@ static int run_chunks(obca_ctx *ctx, int B, int chunk, F &&fn /* int(Slot &, int
         work(0);
         for (auto &t : th) t.join();
     }
-    hipSetDevice(ctx->device);
+    use_device(ctx->device);
     for (int w = 0; w < nw; w++) if (rcs[w]) { ctx->err = errs[w]; return rcs[w]; }
     return 0;
 }
@@ -785,15 +789,15 @@ int obca_batch_create(obca_ctx *ctx, int B, int N, obca_batch **out) {
 }
 int obca_batch_destroy(obca_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->device);
-    free_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1); hipEventDestroy(bt->e2);
+    use_device(bt->device);
+    free_dev(bt); (void)hipEventDestroy(bt->e0); (void)hipEventDestroy(bt->e1); (void)hipEventDestroy(bt->e2);
     double **hs[] = {&bt->h_prob, &bt->h_zin, &bt->h_zout, &bt->h_info};
-    for (auto p : hs) if (*p) hipHostFree(*p);
+    for (auto p : hs) if (*p) (void)hipHostFree(*p);
     delete bt; return 0;
 }
 int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
         hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_batch_debug_phase_cycles: copy failed";
         return -2; }
@@ -806,10 +810,10 @@ int obca_debug_leave_pattern(obca_ctx *ctx, int mask, double value) {      /* di
         if (hipSetDevice(dev) != hipSuccess || hipMalloc((void **)&sink, 256) != hipSuccess) { ctx->err = "obca_debug_leave_pattern: no device memory"; return -2; }
         launch_dirty(0, ctx->cus, mask, value, sink);
         const hipError_t e = hipDeviceSynchronize();
-        hipFree(sink);
+        (void)hipFree(sink);
         if (e != hipSuccess) { ctx->err = std::string("obca_debug_leave_pattern: ") + hipGetErrorString(e); return -2; }
     }
-    hipSetDevice(ctx->device);
+    use_device(ctx->device);
     return 0;
 }
 int obca_batch_set_formulation(obca_batch *bt, int dist) { if (!bt) return -1; bt->dist = dist ? 1 : 0; return 0; }   /* before obca_batch_upload */
@@ -833,7 +837,7 @@ int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new)
     obca_ctx *ctx = bt->ctx;
     if (!bt->uploaded) { ctx->err = "obca_batch_shift_warm_start: nothing uploaded"; return -1; }
     if (shift < 0 || shift > bt->N) { ctx->err = "obca_batch_shift_warm_start: shift out of range 0..N"; return -1; }
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     double *dx0 = nullptr;
     if (x0_new) {   // staged through the (idle) device staging buffer of the batch: nothing to free on the error paths
         if (pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return fin(bt, -2);
@@ -848,7 +852,7 @@ int obca_batch_shift_warm_start(obca_batch *bt, int shift, const double *x0_new)
 }
 int obca_batch_sync(obca_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess) { bt->ctx->err = "obca_batch_sync: hipStreamSynchronize failed"; return -2; }
     return 0;
 }
@@ -919,8 +923,8 @@ struct obca_quad_batch {
 static inline int qfin(obca_quad_batch *bt, int rc) { if (rc) bt->ctx->err = bt->err; return rc; }
 static void qfree_dev(obca_quad_batch *bt) {
     double **ps[] = {&bt->d.prob, &bt->d.z, &bt->d.d, &bt->d.as, &bt->d.rs, &bt->d.oc, &bt->d.info, &bt->d.prof};
-    for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
-    if (bt->stage) hipFree(bt->stage); bt->stage = nullptr;
+    for (auto p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (bt->stage) (void)hipFree(bt->stage); bt->stage = nullptr;
 }
 static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, int B, int N, obca_quad_batch **out, std::string &err) {
     if (B < 1 || N < 2 || N > OBCA_QUAD_NMAX) { err = "obca_quad_batch_create: need B>=1, 2<=N<=OBCA_QUAD_NMAX"; return -1; }
@@ -928,7 +932,7 @@ static int quad_batch_create_on(obca_ctx *ctx, int device, hipStream_t stream, i
     bt->ctx = ctx; bt->device = device; bt->stream = stream; bt->B = B; bt->cap = B; bt->N = N; bt->uploaded = 0; bt->bytes = 0;
     memset(&bt->d, 0, sizeof bt->d); bt->stage = nullptr;
     bt->h_prob = bt->h_z = bt->h_info = nullptr; bt->hcap_prob = bt->hcap_z = bt->hcap_info = 0;
-    hipSetDevice(device);
+    use_device(device);
     quad::QLay l; quad::q_make_layout(N, l);
     QDevBufs &d = bt->d; const size_t N1 = N + 1;
     d.s_prob = QPH_SIZE + QX * N1; d.s_z = l.len; d.s_d = QDIR_DOUBLES(l);
@@ -959,7 +963,7 @@ static int quad_upload_range(obca_quad_batch *bt, const QuadIn &in, int lo, int 
         memcpy(p + QPH_OB, in.ob + (size_t)QOB * QL * g, sizeof(double) * QOB * QL);
         memcpy(p + QPH_SIZE, in.xWS + (size_t)QX * N1 * g, sizeof(double) * QX * N1);
     }
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     QCHK(bt, hipMemcpyAsync(d.prob, bt->h_prob, (size_t)n * d.s_prob * sizeof(double), hipMemcpyHostToDevice, bt->stream));
     bt->uploaded = 1;
     return 0;
@@ -968,7 +972,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts);
 static int quad_download_range(obca_quad_batch *bt, const QuadOut &o, int lo) {
     const int B = bt->B, N = bt->N, N1 = N + 1; const QDevBufs &d = bt->d;
     quad::QLay l; quad::q_make_layout(N, l);
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     const size_t W = (size_t)l.so;                          // outputs are a prefix of the iterate: x, u, t, lam, s
     if (pinned_reserve(bt->err, &bt->h_z, &bt->hcap_z, (size_t)bt->cap * W) || pinned_reserve(bt->err, &bt->h_info, &bt->hcap_info, (size_t)bt->cap * 8)) return -2;
     hipLaunchKernelGGL(obca_gather_rows_kernel, dim3(B, (unsigned)((W + 1023) / 1024)), dim3(256), 0, bt->stream, bt->stage, W, (const double *)d.z, d.s_z);
@@ -1010,14 +1014,14 @@ int obca_quad_batch_create(obca_ctx *ctx, int B, int N, obca_quad_batch **out) {
 }
 int obca_quad_batch_destroy(obca_quad_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->device); qfree_dev(bt); hipEventDestroy(bt->e0); hipEventDestroy(bt->e1);
+    use_device(bt->device); qfree_dev(bt); (void)hipEventDestroy(bt->e0); (void)hipEventDestroy(bt->e1);
     double **hs[] = {&bt->h_prob, &bt->h_z, &bt->h_info};
-    for (auto p : hs) if (*p) hipHostFree(*p);
+    for (auto p : hs) if (*p) (void)hipHostFree(*p);
     delete bt; return 0;
 }
 int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
     if (!bt || !out) return -1;
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
         hipMemcpy(out, bt->d.prof, (size_t)bt->B * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { bt->ctx->err = "obca_quad_batch_debug_phase_cycles: copy failed";
         return -2; }
@@ -1040,7 +1044,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
     if (o.recalc_y != 0) { bt->err = "quadcopter solve: recalc_y is a switch of the parking kernels only (the reference's quadcopter call sets recalc_y = \"no\", QuadcopterSignedDist.jl:29); the quadcopter kernel would ignore it -- refusing instead"; return -1; }
     Opts ko; memcpy(&ko, &o, sizeof ko);
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     QCHK(bt, hipEventRecord(bt->e0, bt->stream));
     hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(bt->B), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, bt->B, bt->N, bt->d, ko, o.max_soc, o.lsq_init != 0, o.obj_scaling != 0);
     QCHK(bt, hipGetLastError());
@@ -1067,7 +1071,7 @@ extern "C" {
 int obca_quad_batch_solve(obca_quad_batch *bt, const obca_opts *opts) { if (!bt) return -1; return qfin(bt, quad_solve(bt, opts)); }
 int obca_quad_batch_sync(obca_quad_batch *bt) {
     if (!bt) return -1;
-    hipSetDevice(bt->device);
+    use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess) { bt->ctx->err = "obca_quad_batch_sync: hipStreamSynchronize failed"; return -2; }
     return 0;
 }

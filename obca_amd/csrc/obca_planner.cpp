@@ -262,14 +262,20 @@ extern "C" {
  * opts (may be NULL) = {xy resolution 0.25, yaw resolution deg 7.5, primitive length 0.6, max steer 0.6, #steer samples per side 2,
  *                       collision margin 0.1, goal xy tolerance 0.3, goal yaw tolerance deg 8, reverse cost 1.5, switch cost 2.0,
  *                       steer cost 0.3, max expansions 400000, analytic (Reeds-Shepp) expansion 1, steer-change cost 0.2, heuristic weight 1,
- *                       Reeds-Shepp heuristic 0}  (16 doubles).
+ *                       Reeds-Shepp heuristic 0}  (the first nopts of these 16 doubles; the rest keep their defaults).
  * Output: path[3 * k] = x, y, yaw of the k-th node and dir[k] = +1 / -1 (motion that led to the node), up to cap nodes.
  * Returns the number of nodes (>= 2), 0 if no path was found, -1 on bad arguments, -2 if the start or the goal collides.
  */
-int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
-                           const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
-                           int *expansions) {
+int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                            const double ego[4], double L, const double XYbounds[4], const double *opts_in, int nopts, double *path, int *dir, int cap,
+                            int *expansions) {
     if (!start || !goal || nOb < 0 || !vOb || !A || !b || !ego || !XYbounds || !path || !dir || cap < 2) return -1;
+    if (opts_in && (nopts < 0 || nopts > OBCA_PLAN_NOPTS)) return -1;
+    // the caller's first nopts options over the defaults: an array of the 14 options of rounds 1-4 leaves the two newer ones at 1 / 0 and nothing is read beyond its end
+    double optbuf[OBCA_PLAN_NOPTS] = {0.25, 7.5, 0.6, 0.6, 2, 0.1, 0.3, 8.0, 1.5, 2.0, 0.3, 400000, 1.0, 0.2, 1.0, 0.0};
+    for (int i = 0; opts_in && i < nopts; i++) optbuf[i] = opts_in[i];
+    const double *opts = optbuf;
+    if (!(opts[14] > 0.0) || !std::isfinite(opts[14])) return -1;      // heuristic weight: positive and finite (0, negative or NaN would silently corrupt the search order)
     const double res = opts ? opts[0] : 0.25, yres = (opts ? opts[1] : 7.5) * M_PI / 180, step = opts ? opts[2] : 0.6, smax = opts ? opts[3] : 0.6;
     const int nst = opts ? (int)opts[4] : 2; const double margin = opts ? opts[5] : 0.1, gtol = opts ? opts[6] : 0.3, ytol = (opts ? opts[7] : 8.0) * M_PI / 180;
     const double crev = opts ? opts[8] : 1.5, csw = opts ? opts[9] : 2.0, cst = opts ? opts[10] : 0.3; const long maxexp = opts ? (long)opts[11] : 400000;
@@ -422,10 +428,11 @@ int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb,
 /* Shortest Reeds-Shepp path from start to goal (x, y, yaw) for turning radius R, sampled every `step` metres: path[3k..] = pose k,
  * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5, may be NULL) their signed
  * lengths in metres.  Returns the number of samples (start and goal included), -1 on bad arguments / cap too small. */
-int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
-                                 const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
-                                 int *counts, int *expansions, int threads) {
+int obca_plan_hybrid_astar_batch2(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
+                                  const double ego[4], double L, const double XYbounds[4], const double *opts, int nopts, double *paths, int *dirs, int cap,
+                                  int *counts, int *expansions, int threads) {
     if (B < 0 || !starts || !goals || !paths || !dirs || !counts || cap < 2) return -1;
+    if (opts && (nopts < 0 || nopts > OBCA_PLAN_NOPTS)) return -1;
     unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > (unsigned)B) nt = (unsigned)(B > 0 ? B : 1);
@@ -433,8 +440,8 @@ int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goal
     auto work = [&]() {
         for (int i = next.fetch_add(1); i < B; i = next.fetch_add(1)) {
             int ne = 0;
-            counts[i] = obca_plan_hybrid_astar(starts + 3 * (size_t)i, goals + 3 * (size_t)i, nOb, vOb, A, b, ego, L, XYbounds, opts, paths + 3 * (size_t)cap * i,
-                                               dirs + (size_t)cap * i, cap, &ne);
+            counts[i] = obca_plan_hybrid_astar2(starts + 3 * (size_t)i, goals + 3 * (size_t)i, nOb, vOb, A, b, ego, L, XYbounds, opts, nopts, paths + 3 * (size_t)cap * i,
+                                                dirs + (size_t)cap * i, cap, &ne);
             if (expansions) expansions[i] = ne;
         }
     };
@@ -443,6 +450,19 @@ int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goal
     work();
     for (auto &t : pool) t.join();
     return 0;
+}
+
+// The entry points of rounds 1-4 took an option array WITHOUT a length, documented as 14 doubles; round 5 read two more (heuristic weight, Reeds-Shepp heuristic) from the same
+// pointer -- an out-of-bounds read for every caller built against the old header.  They keep the 14-double meaning (weight 1, no Reeds-Shepp heuristic); the *2 forms carry the length.
+int obca_plan_hybrid_astar(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                           const double ego[4], double L, const double XYbounds[4], const double *opts, double *path, int *dir, int cap,
+                           int *expansions) {
+    return obca_plan_hybrid_astar2(start, goal, nOb, vOb, A, b, ego, L, XYbounds, opts, 14, path, dir, cap, expansions);
+}
+int obca_plan_hybrid_astar_batch(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
+                                 const double ego[4], double L, const double XYbounds[4], const double *opts, double *paths, int *dirs, int cap,
+                                 int *counts, int *expansions, int threads) {
+    return obca_plan_hybrid_astar_batch2(B, starts, goals, nOb, vOb, A, b, ego, L, XYbounds, opts, 14, paths, dirs, cap, counts, expansions, threads);
 }
 
 int obca_plan_reeds_shepp(const double start[3], const double goal[3], double R, double step, double *path, int *dir, int cap, char *word,

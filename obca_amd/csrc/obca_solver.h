@@ -58,8 +58,8 @@ namespace race { extern int lane; void sync(int drains_global_memory); void rd(c
 // Phase entry points are real (non-inlined) device functions: each gets its own register allocation, so the unrolled
 // per-lane model code of one phase cannot force spills into the latency-critical sequential sweeps of another.
 #define OBCA_PHASE static __device__ __noinline__
-#define PAR(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
-#define PAR64(lane) for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define PAR(lane) for ([[maybe_unused]] int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)      // (a region that only uses LI(lane) = 0 leaves `lane` unused)
+#define PAR64(lane) for ([[maybe_unused]] int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
 #define WAVE0_END }
 #ifdef OBCA_DRAIN      // diagnostic (tools/job_r5t.sh): every synchronisation point of the wavefront also waits for its outstanding global loads / stores

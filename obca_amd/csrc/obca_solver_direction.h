@@ -7,7 +7,7 @@
 // SOC = 1: the terminal row enters with c_soc;  LSQ = 1: with zero (least-squares multiplier system; call with mu = dw = dc = rho = 0)
 template <int SOC = 0, int LSQ = 0>
 OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double mu, double dw, double dc, double rho, double tau, StepOut &so) {
-    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
+    const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N;
     const gdbl *z = I.z; gdbl *d = I.d;
     int ok = 1;     // kept in a register and stored ONCE: both wavefronts write the shared slot, so it must never hold an intermediate value
     // ---- 5x5 border in (dt, nu): all entries are bilinear constants of the Riccati value function

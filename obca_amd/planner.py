@@ -21,7 +21,8 @@ _lib = None
 
 def build_library(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_SRC_REF)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC, _SRC_REF])
+        from .buildflags import GXX
+        subprocess.check_call(GXX + ["-O2", "-pthread", "-I" + os.path.join(_HERE, "..", "include"), "-o", _LIB, _SRC, _SRC_REF])
     return _LIB
 
 
@@ -53,9 +54,9 @@ def hybrid_astar(start, goal, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbounds=S.
     cap = 20000; path = np.zeros((cap, 3)); dr = np.zeros(cap, np.int32); nexp = C.c_int(0)
     s = np.ascontiguousarray(start, float)[:3].copy(); g = np.ascontiguousarray(goal, float)[:3].copy()
     e = np.ascontiguousarray(ego, float); xy = np.ascontiguousarray(XYbounds, float)
-    n = _load().obca_plan_hybrid_astar(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
-                                       b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D),
-                                       path.ctypes.data_as(_D), dr.ctypes.data_as(_I), C.c_int(cap), C.byref(nexp))
+    n = _load().obca_plan_hybrid_astar2(s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
+                                        b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D), C.c_int(len(opts)),
+                                        path.ctypes.data_as(_D), dr.ctypes.data_as(_I), C.c_int(cap), C.byref(nexp))
     if n < 0:
         raise ValueError({-1: "bad arguments", -2: "start or goal pose collides"}[n])
     if n == 0:
@@ -277,9 +278,9 @@ def hybrid_astar_many(starts, goals, vOb, A, b, ego=S.EGO, L=S.L_WHEELBASE, XYbo
     s = np.ascontiguousarray(np.asarray(starts, float)[:, :3]); g = np.ascontiguousarray(np.asarray(goals, float)[:, :3]); B = len(s)
     e = np.ascontiguousarray(ego, float); xy = np.ascontiguousarray(XYbounds, float)
     paths = np.zeros((B, cap, 3)); dirs = np.zeros((B, cap), np.int32); cnt = np.zeros(B, np.int32); nexp = np.zeros(B, np.int32)
-    rc = _load().obca_plan_hybrid_astar_batch(C.c_int(B), s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
-                                              b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D),
-                                              paths.ctypes.data_as(_D), dirs.ctypes.data_as(_I), C.c_int(cap), cnt.ctypes.data_as(_I), nexp.ctypes.data_as(_I), C.c_int(int(threads or 0)))
+    rc = _load().obca_plan_hybrid_astar_batch2(C.c_int(B), s.ctypes.data_as(_D), g.ctypes.data_as(_D), C.c_int(len(vOb)), vOb.ctypes.data_as(_I), A.ctypes.data_as(_D),
+                                               b.ctypes.data_as(_D), e.ctypes.data_as(_D), C.c_double(L), xy.ctypes.data_as(_D), opts.ctypes.data_as(_D), C.c_int(len(opts)),
+                                               paths.ctypes.data_as(_D), dirs.ctypes.data_as(_I), C.c_int(cap), cnt.ctypes.data_as(_I), nexp.ctypes.data_as(_I), C.c_int(int(threads or 0)))
     if rc != 0:
         raise ValueError("bad arguments")
     out = []

@@ -330,6 +330,7 @@ static void hh_apply(int v, const double *w, double *x) { /* x <- (I - 2 w w^T) 
 }
 /* factor [[Hb, q],[q^T, -dc]]; returns 1 iff inertia is (v, 1, 0) */
 static int lamblock_factor(obs_fact *F, int v, const double *Hb /* v x v full */, const double *q, double dc) {
+    if (v < 1 || v > VMAX) return 0;      /* (callers pass the row count of an obstacle, checked at entry; stated here for the compiler's bounds analysis) */
     double nq = 0; for (int i = 0; i < v; i++) nq += q[i] * q[i];
     nq = sqrt(nq);
     double alpha = q[0] > 0 ? -nq : nq, w[VMAX], nw = 0;

@@ -21,7 +21,7 @@ class EOpts(C.Structure):
 
 
 _VARIANTS = {None: ("libobca_emu.so", ["-O1"]),
-             "race": ("libobca_emu_race.so", ["-O0", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_RACE"]),      # cross-lane hazards through HBM (tests/test_emu_sanitize.py)
+             "race": ("libobca_emu_race.so", ["-O0", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_RACE", "-Wno-frame-address"]),      # cross-lane hazards through HBM (tests/test_emu_sanitize.py)
              "ubsan": ("libobca_emu_ubsan.so", ["-O1", "-g", "-fsanitize=undefined,bounds-strict", "-fno-sanitize-recover=undefined"]),      # index / shift / overflow checks
              "asan": ("libobca_emu_asan.so", ["-O1", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_ASAN", "-fsanitize=address"])}      # exact buffer sizes under AddressSanitizer
 _loaded = {}
@@ -34,7 +34,8 @@ def build(variant=None):
     deps = [src] + [os.path.join(ROOT, "obca_amd", "csrc", f) for f in ("obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
         tmp = so + ".%d.tmp" % os.getpid()                  # (several xdist workers may build at once: compile aside, rename into place)
-        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, src, "-ldl"])
+        from obca_amd.buildflags import GXX                  # warnings are errors here too (obca_amd/buildflags.py)
+        subprocess.check_call(GXX + flags + ["-o", tmp, src, "-ldl"])
         os.replace(tmp, so)
     return so
 

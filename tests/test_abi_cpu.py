@@ -84,6 +84,32 @@ def test_no_statement_hides_at_the_end_of_a_comment():
     assert not hits, "\n".join(hits)
 
 
+def test_device_sources_compile_without_a_single_warning():
+    """The fence for the bug class of DESIGN.md section 11: `hipcc -Wall` prints the two lost stores of round 4 as "variable 'sumz' set but not used".  The product's flags
+    (obca_amd/buildflags.py) make warnings errors; this test runs the front end over the kernel and host sources with those flags (device + host pass, every template the
+    kernels instantiate; -fsyntax-only: seconds) for the product and for each build variant that changes kernel code, and wants the compiler to say NOTHING."""
+    import subprocess
+    from obca_amd.buildflags import HIPCC, WARN
+    assert "-Werror" in WARN and "-Wall" in WARN and "-Wextra" in WARN and not any(f.startswith("-Wno-unused-but-set") or f in ("-w", "-Wno-unused-variable", "-Wno-uninitialized") for f in HIPCC)
+    src = os.path.join(ROOT, "obca_amd", "csrc", "obca_hip.hip")
+    base = [f for f in HIPCC if f not in ("-shared", "-fPIC")] + ["-fsyntax-only", "-Wno-unused-command-line-argument"]
+    for variant in ([], ["-DOBCA_PROFILE"], ["-DOBCA_POISON"]):
+        r = subprocess.run(base + variant + [src], capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stdout.strip() and not r.stderr.strip(), (variant, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_the_warning_fence_sees_a_lost_store(tmp_path):
+    """...and the fence works: the round-4 line, with the two stores back inside the comment, does not compile."""
+    import shutil, subprocess
+    from obca_amd.buildflags import HIPCC
+    csrc = tmp_path / "csrc"; shutil.copytree(os.path.join(ROOT, "obca_amd", "csrc"), csrc, ignore=shutil.ignore_patterns("*.so", "variants"))
+    f = csrc / "obca_solver_assemble.h"; txt = f.read_text()
+    assert txt.count("    out.sumy = sumy; out.sumz = sumz;\n") == 1
+    f.write_text(txt.replace("    out.sumy = sumy; out.sumz = sumz;\n", "    // out.sumy = sumy; out.sumz = sumz;\n"))
+    r = subprocess.run([x for x in HIPCC if x not in ("-shared", "-fPIC")] + ["-fsyntax-only", "-Wno-unused-command-line-argument", str(csrc / "obca_hip.hip")], capture_output=True, text=True)
+    assert r.returncode != 0 and "set but not used" in r.stderr, r.stderr[-1500:]
+
+
 def test_diagnostic_entry_points_refuse_null_handles(lib):
     """(argument checks only: no device is touched)"""
     lib.obca_debug_leave_pattern.argtypes = [C.c_void_p, C.c_int, C.c_double]

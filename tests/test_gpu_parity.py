@@ -17,6 +17,18 @@ def OA():
     return obca_amd
 
 
+def _census(name, text):
+    """the counts the tolerant tests print also go to gpurun_out/ (merged back from the GPU box; the ones to be judged are copied to profiles/)"""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_census_%s.txt" % name), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+
+
 def _solve_batch(OA, bt, fixTime=0, lWS=None, nWS=None, opts=None):
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
     return OA.parking_signed_dist_batch(bt["x0"], bt["xF"], bt["N"], bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"],
@@ -154,6 +166,36 @@ def test_least_squares_initial_multipliers_match_the_oracle_option(OA, oracle):
             if r["exitflag"] == 1:
                 assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and abs(out["obj"][i] - r["obj"]) < TOL_F * abs(r["obj"])
         assert (out["iters"] != base["iters"]).sum() >= B // 2          # the initial estimate changes the path of most instances
+
+
+@pytest.mark.parametrize("dist", [0, 1], ids=["signed_dist", "dist"])
+@pytest.mark.parametrize("s_max", [1e-2, 1e-4], ids=["s_max_0.01", "s_max_0.0001"])
+def test_termination_scaling_factors_active_on_the_gpu_follow_the_oracle(OA, oracle, s_max, dist):
+    """GPU twin of tests/test_emu_cpu.py::test_termination_scaling_factors_in_the_kernels_follow_the_oracle.  IPOPT's s_d, s_c (mean multiplier magnitude over s_max, at
+    least 1) scale the optimality error of the termination test (the test ParkingSignedDist.jl:41-43's `tol` belongs to).  With the default s_max = 100 both are 1 on every
+    instance of the bench batches, which is why parity never noticed that the parking kernels' multiplier sums were not stored from round 4 to the end of round 5 (DESIGN.md
+    section 11).  A small s_max makes them bite: through the C ABI, both option sets, both formulations -- the kernels stop at the oracle's iteration, at the oracle's point."""
+    N, B = 40, 24
+    bt = S.make_batch(S.BACKWARDS, B, N, seed=7)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    for ref_opts in (0, 1):
+        o = OA.ipopt_opts() if ref_opts else OA.default_opts(); o.s_max = s_max
+        oo = oracle.default_opts(); oo.s_max = s_max
+        if ref_opts:
+            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+        o1 = oracle.default_opts()
+        if ref_opts:
+            o1.max_soc = 4; o1.recalc_y = 1; o1.lsq_init = 1
+        out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
+                                           xWS, bt["uWS"], opts=o, dist=bool(dist))
+        fewer = 0
+        for i in range(B):
+            a = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], 0, xWS[i], bt["uWS"][i])
+            r = oracle.parking_signed_dist(*a, opts=oo, dist=dist); r1 = oracle.parking_signed_dist(*a, opts=o1, dist=dist)
+            assert out["exitflag"][i] == r["exitflag"] == 1 and out["iters"][i] == r["iters"], (ref_opts, i, out["exitflag"][i], r["exitflag"], out["iters"][i], r["iters"], r1["iters"])
+            assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X and abs(out["obj"][i] - r["obj"]) < TOL_F * max(1.0, abs(r["obj"]))
+            fewer += r["iters"] < r1["iters"]
+        assert fewer >= B // 4, (ref_opts, fewer)      # the factors WERE active: with them the oracle itself stops earlier than with s_max = 100
 
 
 def test_parking_matches_oracle_config3_parallel(OA, oracle):
@@ -525,17 +567,22 @@ def test_config5_with_binding_obstacles_matches_oracle(OA):
     assert max(len(v) for v in bt["vOb"]) >= 6 and min(len(v) for v in bt["vOb"]) >= 3
     out, xWS = _solve_batch(OA, dict(bt, N=N), opts=OA.ipopt_opts())
     ref = oracle_pool.mixed_oracle_all(bt, xWS, switches=oracle_pool.IPOPT)
-    nit = nef = 0; worst = 0.0; nsame = 0; same_point = 0
+    nit = nef = 0; worst = 0.0; nsame = 0; same_point = 0; other = []
     for (i, ef, it, obj, xp) in ref:
         nef += int(out["exitflag"][i] != ef)
         if out["iters"][i] != it:
-            nit += 1; same_point += int(ef == 1 and out["exitflag"][i] == 1 and abs(out["obj"][i] - obj) < 1e-4 * max(1.0, abs(obj)))
+            nit += 1
+            if ef == 1 and out["exitflag"][i] == 1:      # both sides solved it after another number of iterations: the same point (objective 1e-4), or another local solution -- listed
+                df = abs(out["obj"][i] - obj) / max(1.0, abs(obj))
+                if df < 1e-4: same_point += 1
+                else: other.append((i, int(out["iters"][i]), it, float(df)))
             continue
         if ef == 1 and out["exitflag"][i] == 1:
             nsame += 1; worst = max(worst, np.abs(out["xp"][i] - xp).max())
     ngpu = int((out["exitflag"] == 1).sum()); nora = sum(1 for r in ref if r[1] == 1)
-    print("corridor batch (binding obstacles), reference IPOPT configuration: solved %d (GPU) / %d (oracle) of %d; exit flags differ on %d; iteration counts differ on %d (%d of them "
-          "reach the oracle's objective to 1e-4); where they agree (%d solved): worst |dx| %.2e" % (ngpu, nora, B, nef, nit, same_point, nsame, worst))
+    msg = ("corridor batch (binding obstacles), reference IPOPT configuration: solved %d (GPU) / %d (oracle) of %d; exit flags differ on %d; iteration counts differ on %d (%d of them "
+           "reach the oracle's objective to 1e-4, %d solved on both sides end elsewhere: %s); where they agree (%d solved): worst |dx| %.2e" % (ngpu, nora, B, nef, nit, same_point, len(other), other, nsame, worst))
+    print(msg); _census("corridor", msg)
     assert ngpu >= 0.93 * B and nora >= 0.93 * B and nef <= 0.03 * B and nit <= 0.15 * B and worst < 1e-5, (ngpu, nora, nef, nit, worst)
 
 
@@ -557,7 +604,7 @@ def test_every_instance_of_the_config3_bench_batch_matches_oracle(OA):
         assert out["exitflag"][i] == ef == 1, (i, out["exitflag"][i], ef)
         df = abs(out["obj"][i] - obj) / max(1, abs(obj)); dx = np.abs(out["xp"][i] - xp).max()
         if out["iters"][i] != it:      # a knife-edge acceptance test went the other way: reported, bounded in number, and the solve must still end at the oracle's objective (1e-4)
-            off.append((i, int(out["iters"][i]), it, float(dx), float(df))); assert df < 1e-4, off[-1]
+            off.append((i, int(out["iters"][i]), it, float(dx), float(df))); assert df < 1e-4 and dx < 1e-3, off[-1]
             continue
         worst_f = max(worst_f, df); worst_x = max(worst_x, dx)
     print("config 3 bench batch against the oracle: iteration counts differ on", off, "; where they agree: worst |dx| %.2e, worst rel. objective %.2e" % (worst_x, worst_f))
@@ -624,19 +671,21 @@ def test_the_reference_ipopt_configuration_at_bench_size_matches_the_oracle_with
     out, xWS = _solve_batch(OA, dict(bt, N=N), opts=OA.ipopt_opts())
     ref = oracle_pool.mixed_oracle_all(bt, xWS, switches=oracle_pool.IPOPT) if cfg == 5 else oracle_pool.parking_oracle_all(bt, xWS, switches=oracle_pool.IPOPT)
     assert len(ref) == B
-    off = 0; flat = []; worst_x = worst_f = 0.0
+    off = 0; offs = []; flat = []; worst_x = worst_f = 0.0
     for r in ref:
         i, ef, it, obj, xp = r[0], r[1], r[2], r[3], r[4]
         assert out["exitflag"][i] == ef == 1, (i, out["exitflag"][i], ef)
-        if out["iters"][i] != it:
-            off += 1; continue
         df = abs(out["obj"][i] - obj) / max(1, abs(obj)); dx = np.abs(out["xp"][i] - xp).max()
+        if out["iters"][i] != it:      # a knife-edge acceptance test went the other way: counted, bounded in number -- and the solve must still end at the oracle's point (objective 1e-4, states 1e-3: SURVEY 8c)
+            off += 1; offs.append((i, int(out["iters"][i]), it, float(dx), float(df))); assert df < 1e-4 and dx < 1e-3, offs[-1]
+            continue
         if dx >= 1e-5:      # a flat direction around the solution: the same iterations, the same objective, the states further apart than usual -- counted with the knife edges
             flat.append((i, float(dx), float(df))); assert dx < 1e-3 and df < 1e-6, flat[-1]
             continue
         worst_f = max(worst_f, df); worst_x = max(worst_x, dx)
-    print("config %d, reference IPOPT configuration on both sides: %d instances, iteration counts differ on %d, flat-direction instances %s, elsewhere worst |dx| %.2e, worst rel. objective %.2e"
-          % (cfg, B, off, flat, worst_x, worst_f))
+    msg = ("config %d, reference IPOPT configuration on both sides: %d instances, iteration counts differ on %d %s, flat-direction instances %s, elsewhere worst |dx| %.2e, worst rel. objective %.2e"
+           % (cfg, B, off, offs, flat, worst_x, worst_f))
+    print(msg); _census("reference_options_config%d" % cfg, msg)
     # (flat directions around a solution: two fp64 implementations that take the same number of iterations stop up to a few 1e-6 apart in the states at 2e-8 in the objective;
     #  round 5, Hybrid A* warm starts with more direction switches: one instance of 2 048 at 1.7e-4 in the states and 1.4e-8 in the objective)
     assert off + len(flat) <= 4 and worst_x < 1e-5 and worst_f < 1e-7, (off, flat, worst_x, worst_f)

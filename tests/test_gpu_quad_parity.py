@@ -226,6 +226,37 @@ def test_quadcopter_ipopt_configuration_matches_oracle_options(Q):
         obca_amd.quadcopter_signed_dist_batch(bt["x0"][:2], bt["xF"][:2], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][:2], bt["timeWS"], opts=bad)
 
 
+@pytest.mark.parametrize("s_max", [1e-2, 1e-4], ids=["s_max_0.01", "s_max_0.0001"])
+def test_quad_termination_scaling_factors_active_on_the_gpu_follow_the_oracle(Q, s_max):
+    """GPU twin of tests/test_emu_quad_cpu.py::test_quad_termination_scaling_factors_follow_the_oracle: IPOPT's s_d, s_c made active by a small s_max (with the default 100 they
+    are 1 on these instances), through the C ABI, default and reference option sets: kernel and oracle stop at the same iteration at the same objective (the quadcopter kernel
+    always stored its multiplier sums; this is the check that would have found the parking kernels' lost stores).  One instance of twelve may take
+    another branch at an inertia test decided by round-off, as in test_quad_batch_parity_and_feasibility; it must still reach the oracle's objective."""
+    import obca_amd
+    from obca_amd import scenarios as S
+    B, N = 12, 20
+    bt = S.make_quad_batch(B, N)
+    for ref_opts in (0, 1):
+        o = obca_amd.quadcopter_ipopt_opts() if ref_opts else obca_amd.quadcopter_default_opts(); o.s_max = s_max
+        oo = Q.default_opts(); oo.s_max = s_max; o1 = Q.default_opts()
+        if ref_opts:
+            for x in (oo, o1):
+                x.max_soc = 4; x.lsq_init = 1; x.obj_scaling = 1
+        out = obca_amd.quadcopter_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"], bt["timeWS"], opts=o)
+        flips = []; active = 0
+        for i in range(B):
+            r = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0, opts=oo)
+            r1 = Q.quadcopter_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"], bt["R"], bt["ob"], bt["xWS"][i], 1.0, opts=o1)
+            assert out["exitflag"][i] == r["exitflag"] == 1, (ref_opts, i, out["exitflag"][i], r["exitflag"])
+            active += r["iters"] != r1["iters"]
+            if out["iters"][i] != r["iters"] or out["info"][i, 6] != r["nreg"]:
+                flips.append((i, int(out["iters"][i]), r["iters"])); assert abs(out["obj"][i] - r["obj"]) < 1e-4 * abs(r["obj"]), flips[-1]
+                continue
+            assert abs(out["obj"][i] - r["obj"]) < 1e-8 * abs(r["obj"]) and abs(out["timeScale"][i, 0] - r["t"]) < 1e-8 and np.abs(out["up"][i] - r["up"]).max() < 1e-4, (ref_opts, i)
+        assert len(flips) <= 1, (ref_opts, flips)
+        assert active >= B - 2, (ref_opts, active)      # the factors were active (they also enter the barrier update: the count may go either way)
+
+
 def test_unreformulated_quadcopter_model_accepts_the_hip_solutions_at_N60(Q):
     """the reference's quadcopter NLP as JuMP states it (oracle/ipm_ref60_quad.py; tests/test_pin_cpu.py: unreformulated_quad_certificate) at the HIP path's solutions of two
     config-4 instances, with the reference's IPOPT configuration and with the throughput defaults: same objective, rows satisfied, no bound violated, first-order stationarity

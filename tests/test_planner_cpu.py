@@ -86,7 +86,45 @@ def test_planner_library_exports_every_symbol_of_its_header():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "obca_plan.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(obca_plan_[a-z_0-9]+)\s*\(", txt)))
     lib = C.CDLL(PL.build_library())
-    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar_batch", "obca_plan_reeds_shepp", "obca_plan_reference_astar3d", "obca_plan_reference_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+    assert syms == ["obca_plan_astar3d", "obca_plan_collides", "obca_plan_hybrid_astar", "obca_plan_hybrid_astar2", "obca_plan_hybrid_astar_batch", "obca_plan_hybrid_astar_batch2",
+                    "obca_plan_reeds_shepp", "obca_plan_reference_astar3d", "obca_plan_reference_hybrid_astar"] and all(hasattr(lib, s) for s in syms)
+
+
+def test_option_arrays_carry_their_length_and_the_old_entry_point_reads_fourteen():
+    """Round 5 made obca_plan_hybrid_astar read opts[14], opts[15] from an array documented as 14 doubles (an out-of-bounds read for every older caller).  Now: the *2 entry points
+    take the length; the old symbol reads 14 options and searches with weight 1 / no Reeds-Shepp heuristic -- checked with a 14-double array that ENDS at the end of its buffer's
+    readable values (two poison doubles behind it must not matter); a heuristic weight of 0, a negative one, NaN and a bad length are refused."""
+    import ctypes as C
+    lib = C.CDLL(PL.build_library()); D = C.POINTER(C.c_double); I = C.POINTER(C.c_int)
+    sc = S.BACKWARDS; A, b, v = S.scenario_hrep(sc); v = np.ascontiguousarray(v, np.int32); A = np.ascontiguousarray(A, float); b = np.ascontiguousarray(b, float)
+    s = np.array(sc["x0"][:3], float); g = np.array(sc["xF"][:3], float); e = np.ascontiguousarray(S.EGO, float); xy = np.ascontiguousarray(S.XYBOUNDS, float)
+    od = dict(PL.DEFAULT_OPTS); od.update(PL.SCENARIO_OPTS[sc["name"]][0])
+    o16 = np.array([od[k] for k in PL.DEFAULT_OPTS], float); assert len(o16) == 16
+    cap = 4096
+
+    def run(fn, opts, nopts=None):
+        path = np.zeros((cap, 3)); dr = np.zeros(cap, np.int32); ne = C.c_int(0)
+        a = [s.ctypes.data_as(D), g.ctypes.data_as(D), C.c_int(len(v)), v.ctypes.data_as(I), A.ctypes.data_as(D), b.ctypes.data_as(D), e.ctypes.data_as(D), C.c_double(S.L_WHEELBASE), xy.ctypes.data_as(D),
+             opts.ctypes.data_as(D) if opts is not None else None]
+        if nopts is not None: a.append(C.c_int(nopts))
+        n = getattr(lib, fn)(*a, path.ctypes.data_as(D), dr.ctypes.data_as(I), C.c_int(cap), C.byref(ne))
+        return n, path[:max(n, 0)].copy(), ne.value
+    w1 = o16.copy(); w1[14] = 1.0; w1[15] = 0.0
+    n_ref, p_ref, e_ref = run("obca_plan_hybrid_astar2", w1, 16)
+    assert n_ref >= 2
+    for tail in (1e300, -1.0, np.nan):      # what lies behind a 14-double array must not be read
+        buf = np.concatenate([w1[:14], [tail, tail]])
+        n, p, ne = run("obca_plan_hybrid_astar", buf)
+        assert n == n_ref and ne == e_ref and np.array_equal(p, p_ref), tail
+        n, p, ne = run("obca_plan_hybrid_astar2", buf, 14)
+        assert n == n_ref and ne == e_ref and np.array_equal(p, p_ref), tail
+    n15, _, e15 = run("obca_plan_hybrid_astar2", np.concatenate([w1[:14], [1.5]]), 15)
+    assert n15 >= 2 and e15 != e_ref                     # fifteen options: the weight is taken (another search order)
+    for bad in (0.0, -2.0, np.nan, np.inf):
+        w = w1.copy(); w[14] = bad
+        assert run("obca_plan_hybrid_astar2", w, 16)[0] == -1, bad
+    assert run("obca_plan_hybrid_astar2", w1, 17)[0] == -1 and run("obca_plan_hybrid_astar2", w1, -1)[0] == -1
+    assert run("obca_plan_hybrid_astar2", None, 0)[0] >= 2
 
 
 def test_astar3d_waypoints_clear_the_boxes_and_warm_start_the_quadcopter_nlp():

@@ -4,9 +4,9 @@
 #   poison  -DOBCA_POISON [-DOBCA_POISON_VALUE]   work buffers and the kernels' LDS filled with a pattern at entry: NaN (default) AND 1e30 -- NaN hides behind fmax
 #   drain   -DOBCA_DRAIN                         s_waitcnt vmcnt(0) at every synchronisation point of the parking kernel
 R=$(cd "$(dirname "$0")/.." && pwd); V=$R/obca_amd/csrc/variants; mkdir -p $V
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -fno-optimize-sibling-calls -I$R/include"
-hipcc $F -DOBCA_HWID -o $V/libobca_hip_hwid.so $R/obca_amd/csrc/obca_hip.hip &
-hipcc $F -DOBCA_POISON -o $V/libobca_hip_poison.so $R/obca_amd/csrc/obca_hip.hip &
-hipcc $F -DOBCA_POISON -DOBCA_POISON_VALUE=1e30 -o $V/libobca_hip_poison_1e30.so $R/obca_amd/csrc/obca_hip.hip &
-hipcc $F -DOBCA_DRAIN -o $V/libobca_hip_drain.so $R/obca_amd/csrc/obca_hip.hip &
+cd $R; HIPCC=$(python -m obca_amd.buildflags hipcc)      # warnings are errors in the variants too
+$HIPCC -DOBCA_HWID -o $V/libobca_hip_hwid.so $R/obca_amd/csrc/obca_hip.hip &
+$HIPCC -DOBCA_POISON -o $V/libobca_hip_poison.so $R/obca_amd/csrc/obca_hip.hip &
+$HIPCC -DOBCA_POISON -DOBCA_POISON_VALUE=1e30 -o $V/libobca_hip_poison_1e30.so $R/obca_amd/csrc/obca_hip.hip &
+$HIPCC -DOBCA_DRAIN -o $V/libobca_hip_drain.so $R/obca_amd/csrc/obca_hip.hip &
 wait; ls -la $V

@@ -3,9 +3,12 @@
 Companion of tools/isa_mix.py; read next to profiles/r03_pmc_sq_counters.txt."""
 import collections, os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from obca_amd.buildflags import HIPCC      # the product's flags
 fn = sys.argv[1] if len(sys.argv) > 1 else "ph_fused2"; which = int(sys.argv[2]) if len(sys.argv) > 2 else 0; top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 d = tempfile.mkdtemp()
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-optimize-sibling-calls", "-I" + R + "/include", "-save-temps",
+subprocess.run(HIPCC + [ "-save-temps", "-Wno-error",      # (the preprocessed intermediate loses the macro provenance some warnings are silenced by)
+      
                 "-gline-tables-only", "-o", "t.so", R + "/obca_amd/csrc/obca_hip.hip"], cwd=d, stderr=subprocess.DEVNULL, check=True)
 L = open(os.path.join(d, "obca_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
 files = {}

@@ -3,11 +3,14 @@
 ceil((N + 1) / 64) times).  Read next to the SQ counters of tools/pmc_sq.sh (profiles/r03_pmc_sq_counters.txt): which share of the issued VALU instructions is fp64 arithmetic."""
 import collections, os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from obca_amd.buildflags import HIPCC      # the product's flags
 args = sys.argv[1:]; extra = []
 if "--" in args: i = args.index("--"); extra = args[i + 1:]; args = args[:i]
 want = args or ["ph_fused2", "ph_direction2", "ph_riccati"]
 d = tempfile.mkdtemp()
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-optimize-sibling-calls", "-I" + R + "/include", "-save-temps", "-o", "t.so",
+subprocess.run(HIPCC + [ "-save-temps", "-Wno-error",      # (the preprocessed intermediate loses the macro provenance some warnings are silenced by)
+       "-o", "t.so",
                 R + "/obca_amd/csrc/obca_hip.hip"] + extra, cwd=d, stderr=subprocess.DEVNULL, check=True)
 lines = open(os.path.join(d, "obca_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
 

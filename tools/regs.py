@@ -1,9 +1,12 @@
 """Per-function register / scratch usage of the gfx950 code object (hipcc -save-temps assembly): python tools/regs.py [extra hipcc flags...]"""
 import os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from obca_amd.buildflags import HIPCC      # the product's flags
 d = tempfile.mkdtemp()
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-optimize-sibling-calls", "-I" + R + "/include",
-       "-save-temps", "-o", "t.so", R + "/obca_amd/csrc/obca_hip.hip"] + sys.argv[1:]
+cmd = HIPCC + [
+       "-save-temps", "-Wno-error",      # (the preprocessed intermediate loses the macro provenance some warnings are silenced by)
+       "-o", "t.so", R + "/obca_amd/csrc/obca_hip.hip"] + sys.argv[1:]
 subprocess.run(cmd, cwd=d, stderr=subprocess.DEVNULL, check=True)
 s = open(os.path.join(d, "obca_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 name = None; rows = []
