@@ -20,10 +20,13 @@ class EOpts(C.Structure):
         [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]
 
 
-_VARIANTS = {None: ("libobca_emu.so", ["-O1"]),
-             "race": ("libobca_emu_race.so", ["-O0", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_RACE", "-Wno-frame-address"]),      # cross-lane hazards through HBM (tests/test_emu_sanitize.py)
-             "ubsan": ("libobca_emu_ubsan.so", ["-O1", "-g", "-fsanitize=undefined,bounds-strict", "-fno-sanitize-recover=undefined"]),      # index / shift / overflow checks
-             "asan": ("libobca_emu_asan.so", ["-O1", "-g", "-fno-omit-frame-pointer", "-DOBCA_EMU_ASAN", "-fsanitize=address"])}      # exact buffer sizes under AddressSanitizer
+_VARIANTS = {None: ("libobca_emu.so", ["-O1"])}
+try:      # the checking builds of the emulation (race log, UBSan, ASan: tests/test_emu_sanitize.py) -- CPU only; their flag table lives in its own file, which like that test is
+          # listed in .gpurunignore: sanitizer builds have no business on the GPU box
+    from emu_sanitize_variants import VARIANTS as _SAN
+    _VARIANTS.update(_SAN)
+except ImportError:
+    pass
 _loaded = {}
 
 
