@@ -554,11 +554,11 @@ def test_every_instance_of_the_config5_bench_batch_matches_oracle(OA):
 def test_config5_with_binding_obstacles_matches_oracle(OA):
     """config-5 variant whose extra obstacles narrow the road beside the car (scenarios.make_corridor_batch: wedges with sloped rows standing on the walls, tips 0-0.2 m
     beside the warm start's body -- the optimum leans on them where make_mixed_batch's decoys are never near): 256 instances under the reference's IPOPT configuration
-    against the oracle with the same options.  These are HARD solves (40-350 iterations, many inertia rungs): two roundings of the same algorithm part ways on about a tenth
-    of them -- the host emulation of the kernels against the oracle: 16 of 128, the GPU: 26 of 256 -- mostly to the same point after another number of iterations, a few
-    into another local solution.  (Half of that was not rounding: these instances carry large multipliers, IPOPT's termination scaling factors exceed 1 on them, and until the
-    end of round 5 the kernels' factors were 1 -- DESIGN.md section 11.  With the sums stored the emulation parts from the oracle on 7 of 128; the GPU has not run since.)  So the test pins what can be pinned: where the iteration counts agree the trajectories agree to 1e-5; the exit flags agree on >= 97 %;
-    both sides solve >= 93 %; the iteration counts differ on <= 15 %; and it REPORTS the counts."""
+    against the oracle with the same options.  These are HARD solves (40-350 iterations, many inertia rungs, large multipliers: IPOPT's termination scaling factors exceed 1
+    on them) and two roundings of the same algorithm part ways on a few per cent of them, mostly to the same point after another number of iterations.  Measured on the
+    GPU in round 6 (profiles/r06_parity_census_corridor.txt; the library with the multiplier sums stored): 250 / 250 of 256 solved, exit flags equal on
+    all 256, iteration counts differ on 12 (4.7 %; 26 before the fix), 10 of those end at the oracle's objective to 1e-4 and 2 in another local solution; where the counts
+    agree the trajectories agree to 1.1e-7.  The bounds below are those numbers plus a margin; the test REPORTS the counts."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import oracle_pool
@@ -583,7 +583,7 @@ def test_config5_with_binding_obstacles_matches_oracle(OA):
     msg = ("corridor batch (binding obstacles), reference IPOPT configuration: solved %d (GPU) / %d (oracle) of %d; exit flags differ on %d; iteration counts differ on %d (%d of them "
            "reach the oracle's objective to 1e-4, %d solved on both sides end elsewhere: %s); where they agree (%d solved): worst |dx| %.2e" % (ngpu, nora, B, nef, nit, same_point, len(other), other, nsame, worst))
     print(msg); _census("corridor", msg)
-    assert ngpu >= 0.93 * B and nora >= 0.93 * B and nef <= 0.03 * B and nit <= 0.15 * B and worst < 1e-5, (ngpu, nora, nef, nit, worst)
+    assert ngpu >= 0.95 * B and nora >= 0.95 * B and nef <= 3 and nit <= 0.08 * B and len(other) <= 5 and worst < 1e-6, (ngpu, nora, nef, nit, other, worst)
 
 
 @pytest.mark.timeout(1200)
