@@ -675,7 +675,8 @@ def main():
     # ---- and the same bits after a kernel has left a large pattern in the registers, LDS and scratch of every CU (until the end of round 5 the parking
     # kernels' termination test read LDS words nothing had written).  A report in `config`, never a condition of the line.
     try:
-        batches[0].ctx.debug_leave_pattern(15, 1e30)
+        from obca_amd import diag      # (a diagnostic library of its own, libobca_diag.so: nothing of it is in the product library)
+        diag.leave_pattern(batches[0].ctx, 15, 1e30)
         batches[0].solve(opts=run_opts, sync=True); o_ = batches[0].download()
         after_pattern = bool(np.array_equal(o_["info"], out["info"]) and np.array_equal(np.asarray(o_["xp"]), np.asarray(out["xp"])))
     except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the line

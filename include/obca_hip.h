@@ -152,11 +152,9 @@ int obca_batch_last_schedule(const obca_batch *bt, int *ipm_launches, int *slice
 int obca_batch_download(obca_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *np,
                         double *slp, double *info);
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes);
-int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16; per-phase shader cycles, zero unless built with -DOBCA_PROFILE */);
-/* Diagnostic: run a kernel on every device of the context that fills what a later workgroup inherits from its predecessor on a SIMD / CU with a pattern -- mask bit 0: vector
- * registers, 1: accumulation registers, 2: the CUs' LDS (the 64-bit pattern `value`; NaN = all ones), 3: scratch memory -- and wait for it.  Results of the solves that follow
- * must not depend on it (tests/test_gpu_determinism.py).  No counterpart in the reference. */
-int obca_debug_leave_pattern(obca_ctx *ctx, int mask, double value);
+#ifdef OBCA_PROFILE      /* profiling build only (libobca_hip_prof.so: per-phase shader clocks, tools/phase_profile.py); not an entry point of the product library */
+int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */);
+#endif
 
 /* ---- quadcopter path:  QuadcopterSignedDist(x0,xF,N,Ts,R,ob1,ob2,ob3,ob4,ob5,xWS,uWS,timeWS)
  *      QuadcopterNavigation/QuadcopterSignedDist.jl:25-298 (call site mainQuadcopter.jl:152).
@@ -196,7 +194,9 @@ int obca_quad_batch_kernel_ms(obca_quad_batch *bt, float *ipm_ms);
 int obca_quad_batch_download(obca_quad_batch *bt, double *xp, double *up, double *timeScale, int *exitflag, double *lp, double *slack,
                              double *info);
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes);
-int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16; zero unless built with -DOBCA_PROFILE */);
+#ifdef OBCA_PROFILE
+int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */);
+#endif
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_diag.h", "obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
+    srcs = [os.path.join(_CSRC, f) for f in ("obca_hip.hip", "obca_solver.h", "obca_solver_lanes.h", "obca_solver_assemble.h", "obca_solver_riccati.h", "obca_solver_direction.h", "obca_solver_ipm.h", "obca_model.h", "obca_quad_solver.h", "obca_quad_model.h")] + \
            [os.path.join(_HERE, "..", "include", "obca_hip.h"), os.path.join(_HERE, "buildflags.py")]      # (that file holds the compile flags)
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(_LIBPATH) >= os.path.getmtime(s) for s in srcs):
         return _LIBPATH
@@ -75,17 +75,17 @@ EXPORTS = ["obca_create", "obca_create_multi", "obca_device_count", "obca_visibl
            "obca_dualmult_ws_batch", "obca_parking_signed_dist_batch", "obca_parking_dist_batch", "obca_batch_create", "obca_batch_destroy",
            "obca_batch_set_formulation", "obca_batch_shift_warm_start",
            "obca_batch_upload", "obca_batch_solve", "obca_batch_sync", "obca_batch_kernel_ms", "obca_batch_last_schedule", "obca_batch_download",
-           "obca_batch_scratch_bytes", "obca_batch_debug_phase_cycles", "obca_debug_leave_pattern",
+           "obca_batch_scratch_bytes",
            "obca_quadcopter_default_opts", "obca_quadcopter_reference_opts", "obca_quadcopter_signed_dist_batch", "obca_quadcopter_dist_batch", "obca_quad_batch_create", "obca_quad_batch_destroy",
            "obca_quad_batch_upload", "obca_quad_batch_solve", "obca_quad_batch_sync", "obca_quad_batch_kernel_ms",
-           "obca_quad_batch_download", "obca_quad_batch_scratch_bytes", "obca_quad_batch_debug_phase_cycles"]
+           "obca_quad_batch_download", "obca_quad_batch_scratch_bytes"]
 
 
 def selftest(device=0, repeats=4, opts=None):
     """Does this GPU return the same bits for the same inputs, whatever ran on it before?  The config-2 bench batch (1 024 instances, N = 80: every SIMD of the chip holds one) is
     solved `repeats` times as one device-resident batch and every download is compared bit for bit with the first; then a kernel leaves a large finite pattern in the LDS of every
-    CU (obca_debug_leave_pattern) and the batch is solved once more.  Returns a dict: `differing` = (instance, run) pairs that differ, `after_pattern` = instances that differ
-    after the pattern, `instances`, `runs`, `solved`, `device`.  Both counts are 0: the kernels contain no atomics and no order-dependent reductions, and read nothing they have not
+    CU (obca_amd.diag.leave_pattern, libobca_diag.so) and the batch is solved once more.  Returns a dict: `differing` = (instance, run) pairs that differ, `after_pattern` = instances that differ
+    after the pattern, `pattern_units` = per device (compute units the pattern kernel ran on, units that got the four workgroups which cover their whole LDS), `instances`, `runs`, `solved`, `device`.  Both counts are 0: the kernels contain no atomics and no order-dependent reductions, and read nothing they have not
     written (DESIGN.md sections 3 and 11 -- until the end of round 5 the multiplier sums of the parking kernels' termination test were read from LDS unwritten, and results changed with what other
     kernels had left there, e.g. when another process shared the GPU)."""
     from . import scenarios as S
@@ -104,13 +104,14 @@ def selftest(device=0, repeats=4, opts=None):
         if ref is None:
             ref = o; continue
         bad += differing(o, ref)
-    ctx.debug_leave_pattern(4, 1e30)
+    from . import diag
+    reach = diag.leave_pattern(ctx, 4, 1e30)      # (a diagnostic library of its own: libobca_diag.so)
     b.solve(opts=opts); after = differing(b.download(), ref)
     name = ctx.name()
     b.close()
     if not isinstance(device, Context):
         ctx.close()
-    return dict(differing=bad, after_pattern=after, instances=B, runs=max(2, repeats), solved=int((ref["exitflag"] == 1).sum()), device=name)
+    return dict(differing=bad, after_pattern=after, pattern_units=reach, instances=B, runs=max(2, repeats), solved=int((ref["exitflag"] == 1).sum()), device=name)
 
 
 def warm_restart_opts():
@@ -178,11 +179,6 @@ class Context:
         buf = C.create_string_buffer(256)
         _load().obca_device_name(self._h, buf, 256)
         return buf.value.decode()
-
-    def debug_leave_pattern(self, mask=4, value=1e30):
-        """diagnostic (include/obca_hip.h: obca_debug_leave_pattern): fill what later workgroups inherit on a SIMD / CU -- bit 0 vector registers, 1 accumulation registers,
-        2 the CUs' LDS (with the double `value`), 3 scratch -- on every device of the context; the solves that follow must return the same bits"""
-        self._check(_load().obca_debug_leave_pattern(self._h, C.c_int(int(mask)), C.c_double(float(value))), "obca_debug_leave_pattern")
 
     def close(self):
         if self._h:
@@ -308,8 +304,10 @@ class Batch:
         return a.value, b.value
 
     def phase_cycles(self):
-        """(B,16) per-phase shader-cycle counters of the last solve; all zero unless the library was built with -DOBCA_PROFILE."""
+        """(B,16) per-phase shader-cycle counters of the last solve: exists in the profiling build only (OBCA_HIP_LIBRARY=.../libobca_hip_prof.so, tools/phase_profile.py)."""
         out = np.zeros((self.B, 16))
+        if not hasattr(_load(), "obca_batch_debug_phase_cycles"):
+            raise ObcaError("phase_cycles(): the loaded library is not the -DOBCA_PROFILE build")
         self.ctx._check(_load().obca_batch_debug_phase_cycles(self._h, out.ctypes.data_as(_D)), "obca_batch_debug_phase_cycles")
         return out
 
@@ -517,6 +515,8 @@ class QuadBatch:
 
     def phase_cycles(self):
         out = np.zeros((self.B, 16))
+        if not hasattr(_load(), "obca_quad_batch_debug_phase_cycles"):
+            raise ObcaError("phase_cycles(): the loaded library is not the -DOBCA_PROFILE build")
         self.ctx._check(_load().obca_quad_batch_debug_phase_cycles(self._h, out.ctypes.data_as(_D)), "obca_quad_batch_debug_phase_cycles")
         return out
 

@@ -1,11 +1,14 @@
-// obca_diag.h -- diagnostic kernel of libobca_hip.so (included by obca_hip.hip; not on any product path unless OBCA_DIRTY is set or obca_debug_leave_pattern is called)
-#pragma once
+// obca_diag.hip -- libobca_diag.so: a DIAGNOSTIC library of its own (tests, obca_amd.selftest() and bench.py's bit-equality line load it explicitly through
+// obca_amd/diag.py; the product library libobca_hip.so does not contain, link or call any of it -- include/obca_diag.h).
+//
+// obca_diag_leave_pattern: a kernel that leaves a bit pattern in everything a following workgroup inherits from its predecessor on the same SIMD / CU -- mask bit 0: the vector
+// registers, bit 1: the accumulation registers, bit 2: the CU's LDS (the 64-bit pattern `value`), bit 3: scratch memory.  A solver must not care: whatever it reads, it has
+// written.  Round 5: the parking kernels' results changed when ANOTHER PROCESS shared the GPU -- two stores of the stage assembly had been lost and four LDS words were read
+// unwritten.  A NaN pattern found nothing (the words went through fmax()); a large finite one finds it (tests/test_gpu_history.py).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "../../include/obca_diag.h"
 
-// Diagnostic (obca_debug_leave_pattern; OBCA_DIRTY=mask [OBCA_DIRTY_VALUE=double] in the environment, tools/determinism_dirty.py): a kernel that leaves a bit pattern in
-// everything a following workgroup inherits from its predecessor on the same SIMD / CU -- bit 0: the vector registers, bit 1: the accumulation registers, bit 2: the CU's LDS
-// (the 64-bit pattern `value`), bit 3: scratch memory.  The solver must not care: whatever it reads, it has written.  Round 5: its results changed when ANOTHER PROCESS shared
-// the GPU.  The NaN pattern this kernel left at first found nothing -- the word that was read before it was written went through fmax(); a large finite one finds it
-// (tests/test_gpu_determinism.py).
 __global__ __launch_bounds__(64, 1) void obca_dirty_kernel(int mask, unsigned lo, unsigned hi, unsigned *sink) {
     extern __shared__ unsigned dirty_lds[];      // 40 KB: four workgroups cover the 160 KB of a CU
     const unsigned nanw = lo;
@@ -282,12 +285,43 @@ __global__ __launch_bounds__(64, 1) void obca_dirty_kernel(int mask, unsigned lo
         for (int i = 0; i < 224; i++) asm volatile("" :: "v"(v[i]));
     }
     if (acc == 12345u) sink[0] = acc;
+    // where this workgroup ran: XCC_ID (bits 0..3 of the register) in front of HW_ID's CU / shader-array / shader-engine fields (bits 8..15)
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        sink[64 + blockIdx.x] = ((xcc & 0xf) << 8) | ((hw >> 8) & 0xff);
+    }
 }
 
-static void launch_dirty(hipStream_t stream, int cus, int mask, double value, unsigned *sink) {
-    static bool attr = ((void)hipFuncSetAttribute((const void *)obca_dirty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40960), true); (void)attr;
+
+// The pattern reaches a CU's whole LDS only if four of the 40 KB workgroups land on it; the dispatcher usually places them so, nothing guarantees it.  The kernel therefore
+// records where its workgroups ran (HW_ID: CU, shader array, shader engine; XCC_ID) and the call reports how many (XCC, SE, SA, CU) units saw how many workgroups.
+extern "C" int obca_diag_leave_pattern(int device, int mask, double value, int *units_covered, int *units_with_four) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -1;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return -2;
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, nwg = 4 * cus;
+    unsigned *sink = nullptr;
+    if (hipMalloc((void **)&sink, (size_t)(64 + nwg) * sizeof(unsigned)) != hipSuccess) return -2;
+    if (hipMemset(sink, 0, (size_t)(64 + nwg) * sizeof(unsigned)) != hipSuccess) { (void)hipFree(sink); return -2; }
+    if (hipFuncSetAttribute((const void *)obca_dirty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40960) != hipSuccess) { (void)hipFree(sink); return -2; }
     unsigned long long bits; memcpy(&bits, &value, 8);
     if (value != value) bits = ~0ULL;
-    hipLaunchKernelGGL(obca_dirty_kernel, dim3(4 * (cus > 0 ? cus : 256)), dim3(64), 40960, stream, mask, (unsigned)bits, (unsigned)(bits >> 32), sink);
+    hipLaunchKernelGGL(obca_dirty_kernel, dim3(nwg), dim3(64), 40960, 0, mask, (unsigned)bits, (unsigned)(bits >> 32), sink);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned *where = new unsigned[nwg];
+    if (e == hipSuccess) e = hipMemcpy(where, sink + 64, (size_t)nwg * sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(sink);
+    int covered = 0, four = 0;
+    if (e == hipSuccess) {
+        // unit key (12 bits): XCC_ID | SE_ID, SH_ID, CU_ID of HW_ID
+        int count[1 << 12]; memset(count, 0, sizeof count);
+        for (int i = 0; i < nwg; i++) count[where[i] & 0xfff]++;
+        for (int k = 0; k < (1 << 12); k++) { covered += count[k] > 0; four += count[k] >= 4; }
+    }
+    delete[] where;
+    if (units_covered) *units_covered = covered;
+    if (units_with_four) *units_with_four = four;
+    return e == hipSuccess ? 0 : -2;
 }
-

@@ -24,9 +24,6 @@
 #include "../../include/obca_hip.h"
 
 using namespace obca;
-#ifndef OBCA_IDEMPOTENT_DEFAULT
-#define OBCA_IDEMPOTENT_DEFAULT 0      // measured alone: bit-identical to the rounds 1-5 sequence; it does not remove the dependence on GPU sharing and its cost is unmeasured: off
-#endif
 #ifdef OBCA_POISON
 #ifndef OBCA_LDS_GUARD
 #define OBCA_LDS_GUARD 1024      // doubles (8 KB) of NaN guard behind the dynamic LDS block of the poisoned build
@@ -57,17 +54,8 @@ struct DevBufs {
 __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc, int recalc_y, int lsq_init) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
-    // mode 0: fresh solve of instance blockIdx.x from the iterate the host prepared in z;  mode 2: the same, but the workgroup first copies its instance's START iterate z0 -> z itself
-    // (the launch is then IDEMPOTENT: a workgroup that were executed again would start from the same point -- a diagnostic of the round-5 search; OBCA_IDEMPOTENT=1);  mode 1: resume
     const int inst = mode == 1 ? b.order[blockIdx.x] : (int)blockIdx.x;
     if (inst < 0 || inst >= B) return;
-    if (mode == 2) {
-        const double *src = b.z0 + (size_t)inst * b.s_z; double *dst = b.z + (size_t)inst * b.s_z;
-        for (int i = threadIdx.x; i < (int)b.s_z; i += OB_NT) dst[i] = src[i];
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // the copy has landed before any lane reads what another lane copied
-        __syncthreads();
-        mode = 0;
-    }
 #ifdef OBCA_POISON      // diagnostic build: whatever the previous workgroup on this CU left in LDS is replaced by NaNs before anything is initialised
     {
 #ifndef OBCA_POISON_VALUE      // (NaN hides behind fmax / fmin and every comparison: build with -DOBCA_POISON_VALUE=1e30 as well)
@@ -100,14 +88,6 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
 #endif
     __syncthreads();
     solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init);
-#ifdef OBCA_HWID      // diagnostic build (tools/determinism_hw.py): where the instance ran -- HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID -- read back
-                      // through obca_batch_debug_phase_cycles, slots 14 / 15; a result that differs
-                      // between two runs can then be laid beside the hardware unit that produced it
-    if (threadIdx.x == 0) {
-        b.prof[(size_t)inst * 16 + 14] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        b.prof[(size_t)inst * 16 + 15] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-#endif
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
@@ -277,7 +257,6 @@ __global__ __launch_bounds__(256) void obca_gather_rows_kernel(double *dst, size
         dst[i * W + j] = src[i * ss + j];
 }
 
-#include "obca_diag.h"      // obca_dirty_kernel / launch_dirty: leave a pattern in what a later workgroup inherits on a CU (obca_debug_leave_pattern, OBCA_DIRTY)
 
 // ------------------------------------------------------------------------------------------------ host side
 // A context drives one or several devices.  Every device has OBCA_SLOTS worker lanes ("slots": a HIP stream, a cached chunk-sized batch
@@ -605,25 +584,10 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
         bt->bytes += (long long)((size_t)bt->cap * bt->d.s_csoc * sizeof(double));
     }
     const DevBufs &d = bt->d;
-    // IDEMPOTENT launches (round 5): when another process shares the GPU, workgroups of a launch are executed more than once; a kernel that advances its own
-    // input in place then starts its second execution from where the first one left off (fewer iterations, other last bits: the "non-determinism" of rounds 4 / 5).  So the start
-    // iterate lives in z0 and is never modified by the solve: DualMultWS writes its multipliers INTO z0 (the same values every time), the interior-point workgroup copies its
-    // instance z0 -> z at entry (kernel mode 2) and iterates on z / zn.  OBCA_IDEMPOTENT=0 restores the rounds 1-5a sequence (reset z <- z0 by a copy, DualMultWS into z).
-    static const int idem = getenv("OBCA_IDEMPOTENT") ? atoi(getenv("OBCA_IDEMPOTENT")) : OBCA_IDEMPOTENT_DEFAULT;
-    const bool idem_now = idem && !dualws_only;
-    if (!idem_now) {
-      static const int reset_memcpy = getenv("OBCA_RESET_MEMCPY") ? atoi(getenv("OBCA_RESET_MEMCPY")) : 1;      // 1 = the runtime's device-to-device copy, 0 = a copy kernel
-      if (reset_memcpy) HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
-      else { hipLaunchKernelGGL(obca_gather_rows_kernel, dim3(bt->B, (unsigned)((d.s_z + 1023) / 1024)), dim3(256), 0, bt->stream, d.z, d.s_z, (const double *)d.z0, d.s_z); HIPCHK(bt, hipGetLastError()); } }
-    double *const dualws_dst = idem_now ? d.z0 : d.z;
-    static const int sync_between = getenv("OBCA_SYNC_BETWEEN") ? atoi(getenv("OBCA_SYNC_BETWEEN")) : 0;      // diagnostic: the host waits for the stream between the kernels of a solve
-    if (sync_between) HIPCHK(bt, hipStreamSynchronize(bt->stream));
+    // a solve starts from the uploaded iterate: reset z <- z0 (device-to-device), DualMultWS writes its multipliers into z
+    HIPCHK(bt, hipMemcpyAsync(d.z, d.z0, (size_t)bt->B * d.s_z * sizeof(double), hipMemcpyDeviceToDevice, bt->stream));
     HIPCHK(bt, hipEventRecord(bt->e0, bt->stream));
-    if (!bt->have_duals || dualws_only) { int rc = launch_dualws(bt, dualws_dst); if (rc) return rc; }
-    if (sync_between) HIPCHK(bt, hipStreamSynchronize(bt->stream));
-    // diagnostic: marginal cost of the DualMultWS launch in a pipelined run
-    if (!bt->have_duals && !dualws_only) { static const int rep = getenv("OBCA_DUALWS_REPEAT") ? atoi(getenv("OBCA_DUALWS_REPEAT")) : 0;
-        for (int r = 0; r < rep; r++) { int rc = launch_dualws(bt, dualws_dst); if (rc) return rc; } }
+    if (!bt->have_duals || dualws_only) { int rc = launch_dualws(bt, d.z); if (rc) return rc; }
     HIPCHK(bt, hipEventRecord(bt->e1, bt->stream));
     if (dualws_only) { HIPCHK(bt, hipEventRecord(bt->e2, bt->stream)); return 0; }
     // Two-launch schedule.  The kernel keeps a fixed number of instances resident; a larger batch is dispatched in blockIdx
@@ -642,15 +606,15 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     const size_t dyn_lds = OB_DYN_LDS_DOUBLES(bt->N) * sizeof(double);
 #endif
     const int slots = parking_resident_per_cu(bt->N) * (bt->ctx->cus > 0 ? bt->ctx->cus : 256);
-    bt->sliced = (budget > 0 && (bt->B > slots || slice_only)) ? budget : 0;   // 0: single launch, else the slice length
-    { static const int dirty = getenv("OBCA_DIRTY") ? atoi(getenv("OBCA_DIRTY")) : 0;      // diagnostic, see obca_dirty_kernel
-      static const double dirty_value = getenv("OBCA_DIRTY_VALUE") ? atof(getenv("OBCA_DIRTY_VALUE")) : __builtin_nan("");
-      if (dirty) launch_dirty(bt->stream, bt->ctx->cus, dirty, dirty_value, (unsigned *)bt->d.order); }
+    // OBCA_SLICE_ALWAYS=1 (tuning knob): the two-launch schedule also for a batch that fits the machine -- with several batches in flight the workgroups of a launch start as
+    // slots free up, in blockIdx order, and the ranking lets the long solves of a batch start first
+    const bool slice_always = getenv("OBCA_SLICE_ALWAYS") && atoi(getenv("OBCA_SLICE_ALWAYS"));
+    bt->sliced = (budget > 0 && (bt->B > slots || slice_only || slice_always)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, idem_now ? 2 : 0, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
         HIPCHK(bt, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, idem_now ? 2 : 0, budget, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
         HIPCHK(bt, hipGetLastError());
         if (!slice_only) {
             hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
@@ -795,7 +759,8 @@ int obca_batch_destroy(obca_batch *bt) {
     for (auto p : hs) if (*p) (void)hipHostFree(*p);
     delete bt; return 0;
 }
-int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
+#ifdef OBCA_PROFILE      /* the per-phase clocks exist in the profiling build only (libobca_hip_prof.so, tools/phase_profile.py): not an entry point of the product */
+int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   
     if (!bt || !out) return -1;
     use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
@@ -803,19 +768,7 @@ int obca_batch_debug_phase_cycles(obca_batch *bt, double *out /* B x 16 */) {   
         return -2; }
     return 0;
 }
-int obca_debug_leave_pattern(obca_ctx *ctx, int mask, double value) {      /* diagnostic: see obca_dirty_kernel.  Runs to completion on every device of the context. */
-    if (!ctx) return -1;
-    for (int dev : ctx->devices) {
-        unsigned *sink = nullptr;
-        if (hipSetDevice(dev) != hipSuccess || hipMalloc((void **)&sink, 256) != hipSuccess) { ctx->err = "obca_debug_leave_pattern: no device memory"; return -2; }
-        launch_dirty(0, ctx->cus, mask, value, sink);
-        const hipError_t e = hipDeviceSynchronize();
-        (void)hipFree(sink);
-        if (e != hipSuccess) { ctx->err = std::string("obca_debug_leave_pattern: ") + hipGetErrorString(e); return -2; }
-    }
-    use_device(ctx->device);
-    return 0;
-}
+#endif
 int obca_batch_set_formulation(obca_batch *bt, int dist) { if (!bt) return -1; bt->dist = dist ? 1 : 0; return 0; }   /* before obca_batch_upload */
 int obca_batch_scratch_bytes(const obca_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 
@@ -1019,7 +972,8 @@ int obca_quad_batch_destroy(obca_quad_batch *bt) {
     for (auto p : hs) if (*p) (void)hipHostFree(*p);
     delete bt; return 0;
 }
-int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   /* non-zero only in -DOBCA_PROFILE builds */
+#ifdef OBCA_PROFILE
+int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 16 */) {   
     if (!bt || !out) return -1;
     use_device(bt->device);
     if (hipStreamSynchronize(bt->stream) != hipSuccess ||
@@ -1027,6 +981,7 @@ int obca_quad_batch_debug_phase_cycles(obca_quad_batch *bt, double *out /* B x 1
         return -2; }
     return 0;
 }
+#endif
 int obca_quad_batch_scratch_bytes(const obca_quad_batch *bt, long long *bytes) { if (!bt || !bytes) return -1; *bytes = bt->bytes; return 0; }
 int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, const double *x0, const double *xF, const double *ob,
                            const double *xWS, const double *timeWS, int dual_ws, int dist) {

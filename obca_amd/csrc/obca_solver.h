@@ -62,21 +62,13 @@ namespace race { extern int lane; void sync(int drains_global_memory); void rd(c
 #define PAR64(lane) for ([[maybe_unused]] int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define WAVE0_BEGIN if (threadIdx.x < 64) {      // sequential sweeps run on the first wavefront; the others wait at the next SYNC()
 #define WAVE0_END }
-#ifdef OBCA_DRAIN      // diagnostic (tools/job_r5t.sh): every synchronisation point of the wavefront also waits for its outstanding global loads / stores
-#define SYNC() do { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); } while (0)
-#else
 #define SYNC() __syncthreads()
-#endif
 #define LANE0 (threadIdx.x == 0)
 // The workgroup is ONE wavefront: its LDS operations execute in program order, so lanes only need the compiler to keep that
 // order (wavefront-scope fences emit no instruction).  Unlike __syncthreads() this does not drain outstanding global loads,
 // which lets the software-pipelined HBM gathers of the sequential sweeps stay in flight across phases.  Use it only where the
 // cross-lane traffic of the surrounding phases goes through LDS.
-#ifdef OBCA_DRAIN
-#define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#else
 #define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#endif
 #define VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   // s_waitcnt vmcnt(0): all outstanding global loads / stores of this wave
 // workgroup barrier for phases that exchange data through LDS only: unlike __syncthreads() it does not drain the global-memory counter
 #define LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)

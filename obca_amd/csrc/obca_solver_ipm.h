@@ -417,6 +417,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             sh.ft_done = 0;
             PROF(sh.inst, PF_OTHER); if (a_) { PH(ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau, o.kappa_sigma)); a_ = sh.S.ok; }
             if (a_) { D.ok = 1; break; }
+#ifdef OBCA_EMU
+            if (getenv("OBCA_EMU_TRACE")) printf("   rung: it %d dw %.1e failed in %s (riccati stage %d)\n", D.it, D.dw, !A.ok ? "assembly" : (!sh.ric_ok ? "riccati" : "border"), g_emu_ric_fail_stage);
+#endif
             D.nreg++;
             if (D.dw == 0) D.dw = D.dw_last == 0 ? o.dw0 : fmax(o.dw_min, o.kw_dec * D.dw_last);
             else D.dw *= (D.dw_last == 0 ? o.kw_inc0 : o.kw_inc);

@@ -206,6 +206,9 @@ OBCA_FN void ld6(const double *q, double (&v)[6]) {
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
 #endif
 }
+#ifdef OBCA_EMU
+static int g_emu_ric_fail_stage = -1;      // host trace (OBCA_EMU_TRACE): the stage at which the last failed sweep met its first wrong pivot
+#endif
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicItem (&rp)[OBCA_NLT],
                           double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0) {
@@ -236,6 +239,9 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     PROF_FINE(I, PF_RIC_P1);
     const double det = q00 * q11 - q10 * q10;
     const int ok = UNIFORM((q00 > 0) && (det > 0) ? 1 : 0);        // (no early exit; after a failed pivot the rest of the group runs on garbage)
+#ifdef OBCA_EMU
+    if (!ok && g_emu_ric_fail_stage < 0) g_emu_ric_fail_stage = k;
+#endif
     const double idet = rcp_nr(det);
     gdbl *ro = I.rs + (size_t)k * OB_RS;
     double *bd = g_traj + (size_t)k * RIC_BD;      // per-stage border data: at the start of the dynamic block (the trajectory is dead during the sweep)
@@ -288,6 +294,9 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         }
     }
     LDS_SYNC();
+#ifdef OBCA_EMU
+    g_emu_ric_fail_stage = -1;
+#endif
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1, ok = 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0 && ok; k--) {

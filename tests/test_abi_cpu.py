@@ -18,6 +18,7 @@ def lib():
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "obca_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef OBCA_PROFILE.*?#endif", "", txt, flags=re.S)      # (declared for the profiling build only: not exported by the product library)
     return sorted(set(re.findall(r"\b(obca_[a-z_0-9]+)\s*\(", txt)))
 
 
@@ -110,9 +111,15 @@ def test_the_warning_fence_sees_a_lost_store(tmp_path):
     assert r.returncode != 0 and "set but not used" in r.stderr, r.stderr[-1500:]
 
 
-def test_diagnostic_entry_points_refuse_null_handles(lib):
-    """(argument checks only: no device is touched)"""
-    lib.obca_debug_leave_pattern.argtypes = [C.c_void_p, C.c_int, C.c_double]
-    assert lib.obca_debug_leave_pattern(None, 4, 1e30) == -1
-    lib.obca_batch_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
-    assert lib.obca_batch_debug_phase_cycles(None, None) == -1
+def test_diagnostics_are_not_in_the_product_library(lib):
+    """the pattern kernel lives in libobca_diag.so (include/obca_diag.h), the per-phase clocks in the -DOBCA_PROFILE build: the product library exports neither"""
+    import subprocess
+    from obca_amd import diag
+    for s_ in ("obca_debug_leave_pattern", "obca_batch_debug_phase_cycles", "obca_quad_batch_debug_phase_cycles", "obca_diag_leave_pattern"):
+        assert not hasattr(lib, s_), s_
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib._name], capture_output=True, text=True).stdout
+    assert "dirty_kernel" not in syms and "debug" not in syms
+    d = C.CDLL(diag.build_library())
+    assert hasattr(d, "obca_diag_leave_pattern")
+    d.obca_diag_leave_pattern.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    assert d.obca_diag_leave_pattern(-1, 4, 1e30, None, None) == -1      # (argument check only: no device is touched)

@@ -2,7 +2,7 @@
 LDS words they never wrote (the multiplier sums behind IPOPT's termination scaling factors: their stores had slipped into a comment).  With zeros, NaNs or the previous
 parking workgroup's own leftovers there the solve is the right one; with large numbers left by ANOTHER kernel -- a foreign process on the GPU, a workgroup of another horizon whose
 dynamic LDS block lay at that place -- it ends about five iterations early.  That is what the driver's round-4 run and two of the boxes leased in round 5 met.
-These tests leave such patterns on purpose, through obca_debug_leave_pattern (include/obca_hip.h), and interleave batches of other shapes.  The same check runs on the CPU
+These tests leave such patterns on purpose, through the diagnostic library libobca_diag.so (include/obca_diag.h, obca_amd/diag.py -- not part of the product library), and interleave batches of other shapes.  The same check runs on the CPU
 against the emulation (tests/test_emu_cpu.py: finite poison patterns) -- registers and the GPU-only code paths can only be covered here."""
 import numpy as np
 import pytest
@@ -26,8 +26,9 @@ PATTERNS = [(1e30, "large"), (-1e30, "large_negative"), (0.5, "small"), (float("
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("value", [p[0] for p in PATTERNS], ids=[p[1] for p in PATTERNS])
 def test_results_do_not_depend_on_what_other_kernels_left_on_the_compute_units(OA, value):
-    """obca_debug_leave_pattern fills the LDS of every CU (mask 4), then registers + LDS + scratch (mask 15), with `value`; the solves that follow return the bits of the solve
+    """obca_diag_leave_pattern (libobca_diag.so) fills the LDS of every CU (mask 4), then registers + LDS + scratch (mask 15), with `value`; the solves that follow return the bits of the solve
     before it.  (Until the end of round 5 a large pattern ended the parking solves ~5 iterations early: DESIGN.md section 11.  NaN alone never showed it: it passes through fmax.)"""
+    from obca_amd import diag
     for N, B, optset in ((40, 1024, "default"), (80, 512, "ipopt")):
         bt = S.make_batch(S.BACKWARDS, B, N)
         opts = OA.ipopt_opts() if optset == "ipopt" else None
@@ -38,7 +39,8 @@ def test_results_do_not_depend_on_what_other_kernels_left_on_the_compute_units(O
         b.solve(opts=opts); ref = b.download()
         assert (ref["exitflag"] == 1).mean() > 0.95
         for mask in (4, 15):
-            ctx.debug_leave_pattern(mask, value)
+            reach = diag.leave_pattern(ctx, mask, value)
+            assert reach[0][1] >= 0.9 * reach[0][0] > 0, reach      # the pattern kernel reached the machine: (nearly) every compute unit ran the four workgroups that cover its LDS
             b.solve(opts=opts); d = _diff(b.download(), ref)
             assert d == "", "N %d, %s options, pattern %r in %s: %s" % (N, optset, value, "LDS" if mask == 4 else "registers, LDS and scratch", d) + gpu_verdict()
         b.close(); ctx.close()
@@ -47,7 +49,7 @@ def test_results_do_not_depend_on_what_other_kernels_left_on_the_compute_units(O
     ctx = OA.Context(0)
     qb = OA.QuadBatch(ctx, B, N); qb.upload(q["x0"], q["xF"], q["Ts"], q["R"], q["ob"], q["xWS"], q["timeWS"])
     qb.solve(); ref = qb.download()
-    ctx.debug_leave_pattern(15, value)
+    diag.leave_pattern(ctx, 15, value)
     qb.solve(); o = qb.download()
     for k in ("xp", "up", "timeScale", "exitflag", "lp", "slack", "info"):
         assert np.array_equal(np.asarray(o[k]), np.asarray(ref[k])), ("quadcopter", value, k)

@@ -5,6 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 HIPCC=$(python -m obca_amd.buildflags hipcc); GXX=$(python -m obca_amd.buildflags gxx)
 $HIPCC -o $R/obca_amd/csrc/libobca_hip.so $R/obca_amd/csrc/obca_hip.hip &
 $HIPCC -DOBCA_PROFILE -o $R/obca_amd/csrc/libobca_hip_prof.so $R/obca_amd/csrc/obca_hip.hip &
+$HIPCC -o $R/obca_amd/csrc/libobca_diag.so $R/obca_amd/csrc/obca_diag.hip &
 $GXX -O1 -o $R/tests/emu/libobca_emu.so $R/tests/emu/obca_emu.cpp &
 make -C $R/oracle -s &
 $GXX -O2 -pthread -I$R/include -o $R/obca_amd/csrc/libobca_plan.so $R/obca_amd/csrc/obca_planner.cpp $R/obca_amd/csrc/obca_planner_ref.cpp &

@@ -14,6 +14,7 @@
 #   sq           SQ counter groups of the parking kernel (tools/pmc_sq.sh) ; mfma: the quadcopter kernel's MFMA counters
 #   phase        per-phase clocks of the parking kernel, -DOBCA_PROFILE build, B = 64 and 1024, both option sets ; phase5 / quadphase likewise for config 5 / the quadcopter kernel
 #   census       tools/options_census.py 2 3 5
+#   sched        scheduling experiments: --streams 4 / 6 / 8 / 12; OBCA_SLICE_ALWAYS=1 with slices of 4 / 8 passes
 #   gloo2        bench.py --gpus 2 --backend gloo (two ranks on the one GPU)
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -41,6 +42,9 @@ for STEP in "$@"; do
     bench) timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; summ $O/bench.json ;;
     bench20) timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2> $O/bench_driver_line.err; summ $O/bench_driver_line.json ;;
     quick) timeout 300 python bench.py --steps 40 --warmup 8 $LEAN > $O/bench_quick.json 2> $O/bench_quick.err; summ $O/bench_quick.json ;;
+    sched) # scheduling experiments on the pipelined default line: more streams in flight; the two-launch schedule forced for resident batches (OBCA_SLICE_ALWAYS)
+      for S in 4 6 8 12; do timeout 300 python bench.py --steps 60 --warmup 12 --streams $S $LEAN > $O/bench_streams$S.json 2> $O/bench_streams$S.err; echo "streams $S"; summ $O/bench_streams$S.json; done
+      for S in 4 8; do for P in 4 8; do OBCA_SLICE_ALWAYS=1 OBCA_SLICE_PASSES=$P timeout 300 python bench.py --steps 60 --warmup 12 --streams $S $LEAN > $O/bench_slice${P}_streams$S.json 2> $O/bench_slice${P}_streams$S.err; echo "sliced $P passes, streams $S"; summ $O/bench_slice${P}_streams$S.json; done; done ;;
     cfg3|cfg4|cfg5) CF=${STEP#cfg}; timeout 900 python bench.py --config $CF --no-host-rate --steps 60 > $O/bench_cfg$CF.json 2> $O/bench_cfg$CF.err; summ $O/bench_cfg$CF.json ;;
     stats) cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sync -o t -- python $R/bench.py --steps 8 --warmup 2 --streams 1 --sync-steps 4 $LEAN > $O/bench_sync_under_rocprof.json 2> $O/stats_sync.err
