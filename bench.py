@@ -176,7 +176,7 @@ def _cpu_worker(args):
     import oracle as O
     o = O.default_opts()
     if not fast:
-        o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1            # obca_reference_opts
+        o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1; o.restoration = 1            # obca_reference_opts
     vOb, A, b = obstacle_args(cfg, rows, shared, per)
     for i in range(per):
         xWS = rows["xWS"][i].reshape(N + 1, 4); uWS = rows["uWS"][i].reshape(N, 2)
@@ -381,7 +381,7 @@ def config_opts(cfg, fast):
     return obca_amd.quadcopter_ipopt_opts() if CONFIGS[cfg]["kind"] == "quad" else obca_amd.ipopt_opts()
 
 
-OPTION_NAMES = {("parking", False): "reference IPOPT configuration: max_soc = 4, recalc_y = yes, lsq_init = 1 (obca_reference_opts; ParkingSignedDist.jl:41-43 + IPOPT defaults)",
+OPTION_NAMES = {("parking", False): "reference IPOPT configuration: max_soc = 4, recalc_y = yes, lsq_init = 1, block restoration = 1 (obca_reference_opts; ParkingSignedDist.jl:41-43 + IPOPT defaults)",
                 ("parking", True): "library throughput defaults: max_soc = 0, recalc_y = no, y0 = 0 (obca_default_opts)",
                 ("quad", False): "reference IPOPT configuration: max_soc = 4, lsq_init = 1, obj_scaling = 1, recalc_y = no (obca_quadcopter_reference_opts; QuadcopterSignedDist.jl:28-31 + IPOPT defaults)",
                 ("quad", True): "library throughput defaults: max_soc = 0, y0 = 0, no objective scaling (obca_quadcopter_default_opts)"}

@@ -88,6 +88,18 @@ typedef struct obca_opts {
                        * Quadcopter kernel: sf = 100 / 2 100 at the reference's start (the slack penalty 1e2 + 2e3 * 1), set by obca_quadcopter_reference_opts.  Parking kernels: the
                        * gradient at the reference's own start is the slack penalty 1e2 exactly (sf = 1), but a caller's start (small Ts, jumpy uWS, supplied slacks) can exceed it
                        * and the parking kernels do not scale: the parking entry points REFUSE obj_scaling = 1 (rc -1) instead of ignoring it.  0 = off (the defaults) */
+    int restoration;  /* Block feasibility restoration, the stand-in for IPOPT's restoration phase (which the reference leans on: ParkingSignedDist.jl:228-231).  DualMultWS returns
+                       * lambda = mu = 0 for a pose that touches or penetrates an obstacle (distance 0), and the signed-distance NLP started there has |A'lam|^2 = 0 against the equality
+                       * |A'lam|^2 == 1 with a vanishing row gradient: a rank-deficient start the interior point does not leave.  A (stage, obstacle) block with |A'lam|^2 < 1/4 gets
+                       * the feasible dual of the obstacle's best edge (lam = e_s, mu = the non-negative split of -R'a_s; the separation row then holds the signed distance along that
+                       * edge normal, its penalised slack absorbs a penetration).  1: at the start of an attempt AND where IPOPT would enter restoration (failed line search, inertia
+                       * ladder exhausted; then also: barrier restart, empty filter; at most 3 per attempt); 2: the latter only (test knob); 0 = off (obca_default_opts).
+                       * obca_reference_opts sets 1.  An instance whose warm start stays clear of every obstacle at every stage has no degenerate block and is solved to the same bits with
+                       * or without.  Planned warm starts do graze obstacles (distance 0 at a stage): 29 of the 1 024 config-2 bench instances, 23 of 1 024 (config 5), 77 of 512
+                       * (config 3: the Hybrid A* path touches a corner) carry such a block.  Measured on the oracle: config 2 / 5: the same solutions, the longest solve of the batch
+                       * 74 -> 64 iterations; config 3: 60 of 512 instances end in ANOTHER local solution (58 of them lower in the objective) after 37 instead of 55 iterations;
+                       * 64 corridor instances whose wedges intrude 0.05 / 0.15 / 0.3 m into the warm start's body: 57 / 45 / 29 solved without, 64 / 64 / 63 with.
+                       * The quadcopter kernel always carried its own block restoration (the reference's start lambda = 0.05 is rank-deficient); it ignores this field. */
 } obca_opts;
 
 int obca_create(obca_ctx **out, int device);
@@ -104,7 +116,7 @@ int obca_visible_device_count(void);                 /* HIP devices visible to t
 int obca_destroy(obca_ctx *ctx);
 const char *obca_last_error(const obca_ctx *ctx);   /* ctx may be NULL: error of the last failed obca_create */
 int obca_default_opts(obca_opts *o);      /* throughput defaults (the three IPOPT switches off): what opts == NULL means */
-int obca_reference_opts(obca_opts *o);    /* the reference's IPOPT configuration: max_soc = 4, recalc_y = 1, lsq_init = 1 (see above) */
+int obca_reference_opts(obca_opts *o);    /* the reference's IPOPT configuration: max_soc = 4, recalc_y = 1, lsq_init = 1, restoration = 1 (see above) */
 int obca_device_name(const obca_ctx *ctx, char *buf, int buflen);
 
 /* ---- synchronous host-pointer API (what the Julia shim calls) ---- */

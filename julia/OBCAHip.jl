@@ -59,7 +59,7 @@ mutable struct Opts
     dw_min::Cdouble; dw0::Cdouble; dw_max::Cdouble; kw_inc0::Cdouble; kw_inc::Cdouble; kw_dec::Cdouble; dc_bar::Cdouble; kappa_c::Cdouble
     gamma_theta::Cdouble; gamma_phi::Cdouble; delta::Cdouble; s_theta::Cdouble; s_phi::Cdouble; eta_phi::Cdouble; gamma_alpha::Cdouble; s_max::Cdouble; kappa_sigma::Cdouble
     constr_viol_tol::Cdouble; dual_inf_tol::Cdouble; compl_inf_tol::Cdouble; rho_term::Cdouble
-    max_soc::Cint; recalc_y::Cint; lsq_init::Cint; obj_scaling::Cint
+    max_soc::Cint; recalc_y::Cint; lsq_init::Cint; obj_scaling::Cint; restoration::Cint
     Opts() = new()
 end
 function default_opts()

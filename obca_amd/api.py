@@ -38,7 +38,7 @@ class Opts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]      # the three IPOPT switches (include/obca_hip.h): 0 in default_opts(), 4 / 1 / 1 in ipopt_opts()
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int), ("restoration", C.c_int)]      # the IPOPT switches (include/obca_hip.h): 0 in default_opts(), 4 / 1 / 1 in ipopt_opts()
 
 
 def library_path():
@@ -129,7 +129,7 @@ def default_opts():
 
 def ipopt_opts():
     """the reference's IPOPT configuration as far as the kernels carry it: default options + second-order correction (IPOPT's default max_soc = 4), recalc_y = "yes"
-    (ParkingSignedDist.jl:41) and IPOPT's least-squares initial multipliers"""
+    (ParkingSignedDist.jl:41), IPOPT's least-squares initial multipliers, and the block feasibility restoration that stands in for IPOPT's restoration phase (restoration = 1)"""
     o = Opts()
     _load().obca_reference_opts(C.byref(o))
     return o

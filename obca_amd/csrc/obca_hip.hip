@@ -51,7 +51,7 @@ struct DevBufs {
 #define OBCA_IPM_WAVES_PER_EU 1
 #endif
 #define OBCA_RESIDENT_PER_CU (4 * OBCA_IPM_WAVES_PER_EU)   // parking instances (one wavefront each) resident per CU
-__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc, int recalc_y, int lsq_init) {
+__global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm_kernel(int B, int N, DevBufs b, Opts o, int mode, int budget, int max_soc, int recalc_y, int lsq_init, int restoration) {
     // mode 0: fresh solve of instance blockIdx.x (at most `budget` factorisation passes if budget > 0); mode 1: continue the parked solves in
     // the order the ordering kernel chose (workgroups are dispatched in blockIdx order, so the expected stragglers start first)
     const int inst = mode == 1 ? b.order[blockIdx.x] : (int)blockIdx.x;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = mode ? b.prof[(size_t)inst * 16 + threadIdx.x] : 0.0;   // counters add up over the slices
 #endif
     __syncthreads();
-    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init);
+    solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init, restoration);
 #ifdef OBCA_PROFILE
     __syncthreads();
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
@@ -335,7 +335,7 @@ int obca_default_opts(obca_opts *o) {
     o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta = 1; o->s_theta = 1.1; o->s_phi = 2.3;
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4; o->rho_term = 1e3;
-    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->obj_scaling = 0;
+    o->max_soc = 0; o->recalc_y = 0; o->lsq_init = 0; o->obj_scaling = 0; o->restoration = 0;
                      /* throughput defaults: the three IPOPT switches off (obca_reference_opts switches them on; obca_hip.h has the numbers behind the choice) */
     return 0;
 }
@@ -345,6 +345,7 @@ int obca_reference_opts(obca_opts *o) {            /* the reference's IPOPT conf
     o->max_soc = 4;                                    /* IPOPT default max_soc */
     o->recalc_y = 1;                                   /* recalc_y = "yes", ParkingSignedDist.jl:41 / ParkingDist.jl:41 */
     o->lsq_init = 1;                                   /* IPOPT default: least-squares initial multipliers, constr_mult_init_max = 1e3 */
+    o->restoration = 1;                                /* IPOPT has a restoration phase; the kernels carry a block feasibility restoration in its place (obca_hip.h) */
     return 0;
 }
 
@@ -573,6 +574,7 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     Opts ko; memcpy(&ko, &o, sizeof ko);
     use_device(bt->device);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
+    if (o.restoration < 0 || o.restoration > 2) { bt->err = "opts.restoration must be 0, 1 or 2"; return -1; }
     // IPOPT's objective scaling is 1 on the parking NLP only at the reference's own start
     // (gradient = the slack penalty 1e2); a caller's start with a larger gradient would
     // be scaled by IPOPT and is not by these kernels: the switch is refused here rather
@@ -611,15 +613,15 @@ static int batch_solve(obca_batch *bt, const obca_opts *opts, int dualws_only) {
     const bool slice_always = getenv("OBCA_SLICE_ALWAYS") && atoi(getenv("OBCA_SLICE_ALWAYS"));
     bt->sliced = (budget > 0 && (bt->B > slots || slice_only || slice_always)) ? budget : 0;   // 0: single launch, else the slice length
     if (!bt->sliced) {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0, o.restoration);
         HIPCHK(bt, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
+        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 0, budget, o.max_soc, o.recalc_y != 0, o.lsq_init != 0, o.restoration);
         HIPCHK(bt, hipGetLastError());
         if (!slice_only) {
             hipLaunchKernelGGL(obca_order_kernel, dim3(1), dim3(1024), 0, bt->stream, bt->B, (const double *)d.info, (const double *)d.slice, d.order);
             HIPCHK(bt, hipGetLastError());
-            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0);
+            hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(bt->B), dim3(OB_NT), dyn_lds, bt->stream, bt->B, bt->N, bt->d, ko, 1, 0, o.max_soc, o.recalc_y != 0, o.lsq_init != 0, o.restoration);
             HIPCHK(bt, hipGetLastError());
         }
     }
@@ -997,6 +999,7 @@ static int quad_solve(obca_quad_batch *bt, const obca_opts *opts) {
     if (!bt->uploaded) { bt->err = "obca_quad_batch_solve: nothing uploaded"; return -1; }
     obca_opts o; if (opts) o = *opts; else obca_quadcopter_default_opts(&o);
     if (o.max_soc < 0 || o.max_soc > 16) { bt->err = "opts.max_soc must be in 0 .. 16"; return -1; }
+    if (o.restoration < 0 || o.restoration > 2) { bt->err = "opts.restoration must be 0, 1 or 2"; return -1; }
     if (o.recalc_y != 0) { bt->err = "quadcopter solve: recalc_y is a switch of the parking kernels only (the reference's quadcopter call sets recalc_y = \"no\", QuadcopterSignedDist.jl:29); the quadcopter kernel would ignore it -- refusing instead"; return -1; }
     Opts ko; memcpy(&ko, &o, sizeof ko);
     use_device(bt->device);

@@ -156,7 +156,7 @@ struct Opts {
     double constr_viol_tol, dual_inf_tol, compl_inf_tol, rho_term;
 };
 // obca_opts of the C ABI: the interior-point options + the three IPOPT switches (max_soc: second-order correction trials per iteration,
-struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, obj_scaling; };
+struct OptsAbi { Opts o; int max_soc, recalc_y, lsq_init, obj_scaling, restoration; };
                                                           // IPOPT's default 4; recalc_y; lsq_init; all 0 = off by default, as in the checker).  Kept
                                                           // apart so that the options' place in LDS (Shared::o) is what the phases were tuned with.
 
@@ -200,9 +200,10 @@ struct Inst {              // uniform: pointers of this instance
     mutable long long tlast;           // diagnostic builds (-DOBCA_PROFILE): time stamp of the previous phase boundary
 };
 
-enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_HAVE, SL_XPASS, SL_ASM = 16, SL_FILT = 32, SL_SIZE = SL_FILT + 2 * OB_FILT };
+enum { SL_ATT = 0, SL_IT, SL_NF, SL_NREG, SL_MU, SL_DWLAST, SL_THMIN, SL_THMAX, SL_ITPREV, SL_NREGPREV, SL_PINF, SL_HAVE, SL_XPASS, SL_NREST, SL_ASM = 16, SL_FILT = 32, SL_SIZE = SL_FILT + 2 * OB_FILT };
 // SL_XPASS: full passes the slice spent outside iterations and inertia rungs (second-order corrections,
 // rebuilds after rejected ones, multiplier re-estimates): the ordering kernel ranks by them too
+// SL_NREST: block restorations of this attempt so far (+ 16 if the filter thresholds are to be re-initialised by the next assembly)
 // SL_HAVE / SL_ASM: a solve parked right after an accepted trial keeps that trial's
 // assembly -- the scalars here, the stage records in the instance's own buffers, which
 // outlive the launch -- so the resumed solve continues from exactly the state an uninterrupted one has at that point, without assembling again
@@ -230,6 +231,8 @@ struct Soc {
     int xpass0;                       // correction / rebuild / re-estimate passes of EARLIER slices of this attempt (SL_XPASS is cumulative like SL_NREG).  (Kept here, at the end of
                                       // Shared: one more int in Drv moved everything behind it by 8 bytes, off the 16-byte boundaries the phases read `c`, `A*`, `inst` at -- 3.5 %
                                       // of `value`, profiles/r05_ab_lds_alignment.txt)
+    // option restoration (block feasibility restoration: restore_blocks, obca_solver_ipm.h); restorations of this attempt; 1: the next assembly re-initialises theta_min / theta_max
+    int restoration, nrest, reset_th;
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 

@@ -8,7 +8,64 @@ OBCA_FN double push2(double v, double lo, double hi, double k1, double k2) {
     if (v > hi - pu) v = hi - pu;
     return v;
 }
-struct PushOpts { double bound_push, bound_frac; };
+// Block feasibility restoration: a stand-in for what IPOPT's restoration phase does for this model's one structural degeneracy (obca_opts.restoration; the quadcopter kernel's
+// q_restore_blocks is its sibling).  DualMultWS (DualMultWS.jl:52-73) returns lambda = mu = 0 for a pose whose car rectangle touches or penetrates the obstacle -- the distance is 0
+// and the dual of |A'lam| <= 1 is free to vanish -- and the signed-distance NLP started there has |A'lam|^2 = 0 against the EQUALITY |A'lam|^2 == 1 (ParkingSignedDist.jl:196) with
+// a vanishing row gradient 2 A A'lam: a rank-deficient start the interior point does not leave.  A block (stage k, obstacle j) with |A'lam|^2 < 1/4 is DEGENERATE; it gets the
+// feasible dual of the obstacle's best edge:   lam = e_s,  s = argmax_i d_i,  d_i = a_i . c - b_i - (g_1 |a_i . e_psi| + g_2 |a_i . e_perp|)   (unit rows; c: centre of the car),
+// mu = the non-negative split of -R'a_s.  Then |A'lam| = 1 and G'mu + R'A'lam = 0 hold exactly and the separation row takes the value d_s (the signed distance along that edge
+// normal: negative when the pose penetrates, absorbed by the row's penalised slack as the reference intends).  mid = 1 (inside a solve): the other multipliers take the bound
+// push, the row's slack its value, the block's bound multipliers 1 and its equality multipliers 0.  Returns the number of blocks repaired (wave-uniform).
+template <int VM>
+OBCA_FN int restore_blocks(const Inst &I, Shared &sh, int mid, double bound_push) {
+    const Lay &l = sh.l; Consts c; obs_consts(sh.c, c);
+    const int N = c.N, nOb = c.nOb, M = c.M; gdbl *z = I.z;
+    double red[1][OBCA_NL];
+    PAR(lane) {
+        double cnt = 0;
+        for (int it = lane; it < (N + 1) * nOb; it += OB_NT) {
+            const int k = it / nOb, j = it - k * nOb, r0 = sh.roff[j];
+            ObsIn<VM> in; load_obs<VM>(I, sh, z, k, j, in);
+            double p1 = 0, p2 = 0;
+#pragma unroll
+            for (int i = 0; i < VM; i++) { p1 += in.a1[i] * in.lam[i]; p2 += in.a2[i] * in.lam[i]; }      // (rows beyond in.v: a = 0)
+            if (p1 * p1 + p2 * p2 < 0.25) {
+                double sn, cs; sincos_bounded(in.psi, &sn, &cs);
+                const double cx = in.X + cs * c.off, cy = in.Y + sn * c.off;
+                double best = -1e300, be1 = 0, be2 = 0; int s_ = 0;
+#pragma unroll
+                for (int i = 0; i < VM; i++) if (i < in.v) {
+                    const double e1 = cs * in.a1[i] + sn * in.a2[i], e2 = -sn * in.a1[i] + cs * in.a2[i];
+                    const double d_ = in.a1[i] * cx + in.a2[i] * cy - in.b[i] - (c.g[0] * fabs(e1) + c.g[1] * fabs(e2));
+                    if (d_ > best) { best = d_; s_ = i; be1 = e1; be2 = e2; }
+                }
+                const double lo = mid ? bound_push : 0.0;
+#pragma unroll
+                for (int i = 0; i < VM; i++) if (i < in.v) { in.lam[i] = i == s_ ? 1.0 : lo; z[l.lam + k * M + r0 + i] = in.lam[i]; }
+                in.mu[0] = fmax(-be1, lo); in.mu[1] = fmax(-be2, lo); in.mu[2] = fmax(be1, lo); in.mu[3] = fmax(be2, lo);
+#pragma unroll
+                for (int i = 0; i < 4; i++) z[l.mu + 4 * it + i] = in.mu[i];
+                if (mid) {
+                    in.so = 0; double r[4]; obs_rows<VM>(c, in, r);
+                    if (c.dist) { z[l.sl + it] = fmax(-(r[0] - in.sl), bound_push); z[l.zs1 + it] = 1.0; }
+                    z[l.so + it] = fmax(r[3], bound_push); z[l.zso + it] = 1.0;
+#pragma unroll
+                    for (int i = 0; i < VM; i++) if (i < in.v) z[l.zlam + k * M + r0 + i] = 1.0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { z[l.zmu + 4 * it + i] = 1.0; z[l.yo + 4 * it + i] = 0.0; }
+                }
+                cnt += 1.0;
+            }
+        }
+        red[0][LI(lane)] = cnt;
+    }
+    const double n_ = wred_sum(red[0]);
+    SYNC();
+    return (int)n_;
+}
+#define OB_MAX_RESTORE 3      // restorations per attempt
+
+struct PushOpts { double bound_push, bound_frac; int restore; };
 template <int VM>
 OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = c.N, nOb = c.nOb, M = c.M;
@@ -20,6 +77,7 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
         for (int i = l.zxL + lane; i < l.len; i += OB_NT) z[i] = 1.0;
     }
     SYNC();
+    if (o.restore) restore_blocks<VM>(I, sh, 0, o.bound_push);      // degenerate blocks of the warm start (DualMultWS at a touching / penetrating pose): before the slacks take their values
     const double q = z[l.t] * c.Ts;
     PAR(lane) {   // slacks take the row values at the (un-pushed) warm start
         for (int k = lane; k < N; k += OB_NT) z[l.ss + k] = ((k ? z[l.u + 2 * k - 2] : 0.0) - z[l.u + 2 * k]) / q;
@@ -56,8 +114,9 @@ OBCA_FN void init_point(const Inst &I, Shared &sh, const PushOpts &o) {
 // ---------------------------------------------------------------- phase entry points (non-inlined; state lives in g_sh)
 // the per-lane (stage, obstacle) code exists in three sizes (VM = 2, OB_VMID, OB_VMAX rows); an instance uses the smallest that holds its widest obstacle
 #define VM_CALL(F, ...) do { if (g_sh.vmc == 0) F<2>(__VA_ARGS__); else if (g_sh.vmc == 1) F<OB_VMID>(__VA_ARGS__); else F<OB_VMAX>(__VA_ARGS__); } while (0)
+OBCA_PHASE int ph_restore(double bound_push) { Shared &sh = g_sh; int n_ = 0; if (sh.vmc == 0) n_ = restore_blocks<2>(sh.inst, sh, 1, bound_push); else if (sh.vmc == 1) n_ = restore_blocks<OB_VMID>(sh.inst, sh, 1, bound_push); else n_ = restore_blocks<OB_VMAX>(sh.inst, sh, 1, bound_push); return n_; }
 OBCA_PHASE void ph_init(double bound_push, double bound_frac) {
-    Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac}; PROF(sh.inst, PF_OTHER);
+    Shared &sh = g_sh; PushOpts po = {bound_push, bound_frac, sh.soc.restoration == 1}; PROF(sh.inst, PF_OTHER);
     VM_CALL(init_point, sh.inst, sh, po);
     PROF(sh.inst, PF_INIT);
 }
@@ -352,8 +411,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0; sh.soc.nrebuild = 0;
     D.mu = o.mu_init; D.dw_last = 0; D.nf = 0; D.it = 0; D.nreg = 0; D.th_min = 0; D.th_max = 0; D.f = 0; D.pinf = 0; D.dinf = 0; D.status = ST_USERLIMIT;
     sh.soc.xpass0 = 0;      // (SL_XPASS is cumulative over the slices of an attempt like SL_NREG: the ordering kernel ranks by both)
+    sh.soc.nrest = 0; sh.soc.reset_th = 0;
     if (sl.resume) {
-        sh.soc.xpass0 = (int)st[SL_XPASS];
+        sh.soc.xpass0 = (int)st[SL_XPASS]; sh.soc.nrest = (int)st[SL_NREST] & 15; sh.soc.reset_th = ((int)st[SL_NREST] >> 4) & 1;
         D.it = (int)st[SL_IT]; D.nf = (int)st[SL_NF]; D.nreg = (int)st[SL_NREG]; D.mu = st[SL_MU]; D.dw_last = st[SL_DWLAST]; D.th_min = st[SL_THMIN];
         D.th_max = st[SL_THMAX];
         D.pinf = st[SL_PINF];
@@ -372,7 +432,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         // out of budget: park the loop state, a later launch continues
         if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc >= sl.budget) {
             PAR(lane) {
-                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.xpass0 + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
+                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.xpass0 + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; st[SL_NREST] = sh.soc.nrest + 16 * sh.soc.reset_th; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
                 const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS;                 // (entries beyond the LDS part are in the record already)
                 for (int i = lane; i < 2 * nl; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
             }
@@ -381,7 +441,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         if (D.mu != D.dc_mu) { D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
         PROF(sh.inst, PF_OTHER); if (!D.have_asm) PH(ph_assemble(D.mu, 0.0, D.dc_val, 0));
         D.have_asm = 0;
-        if (D.it == 0) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); }
+        if (D.it == 0 || sh.soc.reset_th) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); sh.soc.reset_th = 0; }
         D.f = A.f; D.pinf = A.pinf; D.dinf = A.dinf;
 #ifdef OBCA_EMU      // OBCA_EMU_TRACE=1: one line per iteration in the format of the CPU checker's `verbose` option (test infrastructure), so that two traces can be laid side by side
         if (getenv("OBCA_EMU_TRACE")) printf("it %3d f=% .8e pinf=%.2e dinf=%.2e cinf=%.2e mu=%.1e dw=%.1e t=%.4f\n", D.it, A.f, A.pinf, A.dinf, A.cinf0, D.mu, D.dw_last, (double)sh.inst.z[sh.l.t]);
@@ -425,7 +485,10 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             else D.dw *= (D.dw_last == 0 ? o.kw_inc0 : o.kw_inc);
             if (D.dw > o.dw_max) break;
         }
-        if (!D.ok) { D.status = ST_ERROR; break; }
+        // where IPOPT would enter its restoration phase (inertia ladder exhausted here, failed line search below): repair the degenerate obstacle blocks -- if there are
+        // any -- restart the barrier, empty the filter and go on (obca_opts.restoration; restore_blocks above)
+#define OB_RESTORE_AND_CONTINUE { sh.soc.nrest++; sh.soc.reset_th = 1; D.mu = o.mu_init; D.tau = fmax(o.tau_min, 1 - D.mu); D.nf = 0; D.dw_last = 0; D.have_asm = 0; continue; }
+        if (!D.ok) { if (sh.soc.restoration && sh.soc.nrest < OB_MAX_RESTORE && ph_restore(o.bound_push) > 0) OB_RESTORE_AND_CONTINUE; D.status = ST_ERROR; break; }
         if (D.dw > 0) D.dw_last = D.dw;
         {
             const double th = A.th1, gd = sh.S.gd;
@@ -433,7 +496,11 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             double amin;
             if (gd < 0) {
                 amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
-                D.pw_th = pow(th, o.s_theta); D.pw_gd = pow(-gd, o.s_phi);      // once per iteration (also the switching condition of every trial)
+                // once per iteration (also the switching condition of every trial).  A pow is a ~3k-clock dependent chain and the two are independent: lane 0 forms the
+                // first, lane 1 the second, side by side in one instruction stream (the same operations on the same operands as two scalar calls: the same bits)
+                double pw_[OBCA_NL];
+                PAR(lane) { const double bs_ = (lane & 1) ? -gd : th, ex_ = (lane & 1) ? o.s_phi : o.s_theta; pw_[LI(lane)] = pow(bs_, ex_); }
+                D.pw_th = WV_READLANE(pw_, 0); D.pw_gd = WV_READLANE(pw_, 1);
                 if (th <= D.th_min) amin = fmin(amin, o.delta * D.pw_th / D.pw_gd);
             } else amin = o.gamma_theta;
             D.amin = amin * o.gamma_alpha;
@@ -475,7 +542,8 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 #ifdef OBCA_EMU
         if (getenv("OBCA_EMU_TRACE")) printf("   ls: alpha_max %.3e accepted %.3e soc %d dw %.1e nreg %d\n", sh.S.ap, D.acc ? D.alpha : 0.0, sh.soc.nsoc_acc, D.dw, D.nreg);
 #endif
-        if (!D.acc) { D.status = ST_ERROR; break; }   // IPOPT would enter restoration here
+        if (!D.acc) { if (sh.soc.restoration && sh.soc.nrest < OB_MAX_RESTORE && ph_restore(o.bound_push) > 0) OB_RESTORE_AND_CONTINUE; D.status = ST_ERROR; break; }   // IPOPT would enter restoration here
+#undef OB_RESTORE_AND_CONTINUE
         // accepted: the trial buffer becomes the iterate, its assembly the current one
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
         LDS_SYNC();
@@ -498,12 +566,12 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
 // iterate (ParkingSignedDist.jl:256-290).  info[8] = {status, iterations, objective, pinf, dinf, mu, #regularisations, exitflag}
 // Slicing: `st` is the instance's slice record, mode 1 resumes from it, budget > 0 limits the passes of this launch (info[0] = 3 when the
 // solve was parked; the iterate buffer then holds the point to continue from).
-OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0, int recalc_y = 0, int lsq_init = 0) {
+OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = nullptr, int mode = 0, int budget = 0, int max_soc = 0, int recalc_y = 0, int lsq_init = 0, int restoration = 0) {
     Shared &sh = g_sh;
     PAR(lane) {
         for (int i = lane; i < OB_HDR; i += OB_NT) sh.hdr[i] = sh.inst.prob[i];
         // (Shared::soc.csoc is set by the caller, like the pointers of Shared::inst)
-        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; sh.soc.recalc_y = recalc_y; sh.soc.lsq_init = lsq_init; }
+        if (lane == 0) { sh.o = o_arg; sh.soc.max_soc = sh.soc.csoc ? max_soc : 0; sh.soc.recalc_y = recalc_y; sh.soc.lsq_init = lsq_init; sh.soc.restoration = restoration; }
     }
     SYNC();
     PAR(lane) {

@@ -56,6 +56,8 @@ typedef struct {
     int max_soc;      /* second-order correction trials per iteration (IPOPT max_soc = 4); 0 = off, the default: see DESIGN.md section 2 for the measured A/B */
     int recalc_y;     /* recalc_y = "yes" (ParkingSignedDist.jl:41): least-squares multipliers once the constraint violation is below 1e-6; 0 = off (default) */
     int obj_scaling;  /* IPOPT's gradient-based objective scaling: a no-op on this path (|grad f|_inf at the reference's start is the slack penalty, exactly 100: factor 1); the quadcopter oracle applies it */
+    int restoration;  /* stand-in for IPOPT's restoration phase on degenerate obstacle blocks (restore_blocks below): 0 = off (default); 1 = at the start of an attempt and where IPOPT would
+                         enter restoration (failed line search / inertia ladder exhausted); 2 = the latter only (test knob); obca_reference_opts of the HIP library sets 1 */
 } opts_t;
 
 void obca_oracle_default_opts(opts_t *o) {
@@ -70,7 +72,7 @@ void obca_oracle_default_opts(opts_t *o) {
     o->eta_phi = 1e-8; o->gamma_alpha = 0.05; o->s_max = 100; o->kappa_sigma = 1e10;
     o->constr_viol_tol = 1e-4; o->dual_inf_tol = 1; o->compl_inf_tol = 1e-4;
     o->rho_term = 1e3; o->lsq_init = 0; o->verbose = 0;
-    o->max_soc = 0; o->recalc_y = 0; o->obj_scaling = 0;                 /* the three IPOPT switches are off by default and set by the caller (never through the environment: a leaked variable would change what the parity tests compare) */
+    o->max_soc = 0; o->recalc_y = 0; o->obj_scaling = 0; o->restoration = 0;                 /* the three IPOPT switches are off by default and set by the caller (never through the environment: a leaked variable would change what the parity tests compare) */
 }
 
 /* ------------------------------------------------------------------ iterate layout (one flat vector) */
@@ -983,6 +985,48 @@ static void reset_bound_mults(const prob_t *p, const lay_t *l, const opts_t *o, 
 #undef CL
 }
 
+/* Block feasibility restoration: a stand-in for what IPOPT's restoration phase does for this model's one structural degeneracy (opts.restoration; the quadcopter oracle's
+ * restore_blocks is its sibling).  DualMultWS (DualMultWS.jl:52-73) returns lambda = mu = 0 for a pose whose car rectangle touches or penetrates the obstacle -- the distance
+ * is 0 and the dual of |A'lam| <= 1 is free to vanish -- and the signed-distance NLP started there has |A'lam|^2 = 0 against the EQUALITY |A'lam|^2 == 1
+ * (ParkingSignedDist.jl:196) with a vanishing row gradient 2 A A'lam: a rank-deficient start the interior point does not leave (the multipliers stay near 0, the separation
+ * row cannot grip the pose).  A block (stage k, obstacle j) with |A'lam|^2 < 1/4 is DEGENERATE; it gets the feasible dual of the obstacle's best edge instead:
+ *     lam = e_s,  s = argmax_i d_i,  d_i = a_i . c - b_i - (g_1 |a_i . e_psi| + g_2 |a_i . e_perp|)      (rows of unit length; c: centre of the car rectangle)
+ *     mu = the non-negative split of -R'a_s: (max(-e1, 0), max(-e2, 0), max(e1, 0), max(e2, 0)),  e = R'a_s
+ * i.e. |A'lam| = 1, G'mu + R'A'lam = 0 hold exactly and the separation row takes the value d_s (the signed distance along that edge normal: negative when the pose penetrates,
+ * absorbed by the row's penalised slack sl as the reference intends).  mid = 1 (inside a solve): the other multipliers take the bound push, the row's slack so its value,
+ * the block's bound multipliers 1 and its equality multipliers 0.  Returns the number of blocks repaired. */
+static int restore_blocks(const prob_t *p, const lay_t *l, const opts_t *o, double *z, int mid) {
+    int N = p->N, nOb = p->nOb, M = p->M, nrep = 0;
+    for (int k = 0; k <= N; k++) for (int j = 0; j < nOb; j++) {
+        const double *Aj = p->A + 2 * p->roff[j], *bj = p->b + p->roff[j]; const int v = p->vOb[j], bo = k * nOb + j;
+        double *lam = z + l->lam + k * M + p->roff[j], *mu = z + l->mu + 4 * bo; const double *x = z + l->x + 4 * k;
+        double p1 = 0, p2 = 0;
+        for (int i = 0; i < v; i++) { p1 += Aj[2 * i] * lam[i]; p2 += Aj[2 * i + 1] * lam[i]; }
+        if (p1 * p1 + p2 * p2 >= 0.25) continue;
+        const double cs = cos(x[2]), sn = sin(x[2]), cx = x[0] + cs * p->off, cy = x[1] + sn * p->off;
+        double best = -1e300, be1 = 0, be2 = 0; int s = 0;
+        for (int i = 0; i < v; i++) {
+            const double a1 = Aj[2 * i], a2 = Aj[2 * i + 1], e1 = cs * a1 + sn * a2, e2 = -sn * a1 + cs * a2;
+            const double d = a1 * cx + a2 * cy - bj[i] - (p->g[0] * fabs(e1) + p->g[1] * fabs(e2));
+            if (d > best) { best = d; s = i; be1 = e1; be2 = e2; }
+        }
+        const double lo = mid ? o->bound_push : 0.0;
+        for (int i = 0; i < v; i++) lam[i] = i == s ? 1.0 : lo;
+        mu[0] = fmax(-be1, lo); mu[1] = fmax(-be2, lo); mu[2] = fmax(be1, lo); mu[3] = fmax(be2, lo);
+        if (mid) {
+            double c[4];
+            obs_rows(p, j, x, lam, mu, z[l->sl + bo], 0.0, c, NULL);
+            if (p->dist) { z[l->sl + bo] = fmax(-(c[0] - z[l->sl + bo]), o->bound_push); z[l->zs1 + bo] = 1.0; }
+            z[l->so + bo] = fmax(c[3], o->bound_push); z[l->zso + bo] = 1.0;
+            for (int i = 0; i < v; i++) z[l->zlam + k * M + p->roff[j] + i] = 1.0;
+            for (int i = 0; i < 4; i++) { z[l->zmu + 4 * bo + i] = 1.0; z[l->yo + 4 * bo + i] = 0.0; }
+        }
+        nrep++;
+    }
+    return nrep;
+}
+#define MAX_RESTORE 3      /* restorations per attempt */
+
 #define FILT_MAX 512
 
 static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *z, result_t *res) {
@@ -996,6 +1040,8 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
     /* initial point: x_0 = x0, x_N stays at the warm start (pulled to xF by the Newton step), bounds pushed */
     for (int i = 0; i < 4; i++) z[l->x + i] = p->x0[i];
     z[l->t] = p->fixTime ? 1.0 : z[l->t];
+    int nrest = 0;
+    if (o->restoration == 1) restore_blocks(p, l, o, z, 0);      /* degenerate blocks of the warm start (DualMultWS at a touching / penetrating pose): before the slacks take their values */
     /* slacks take the row values (ParkingSignedDist.jl gives them no start; IPOPT uses s = d(x)) */
     {
         double q = z[l->t] * p->Ts;
@@ -1072,7 +1118,10 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             else dw *= (dw_last == 0 ? o->kw_inc0 : o->kw_inc);
             if (dw > o->dw_max) break;
         }
-        if (!ok) { status = ST_ERROR; break; }
+        /* where IPOPT would enter its restoration phase: repair the degenerate obstacle blocks (if there are any), restart the barrier, empty the filter */
+#define RESTORE_AND_CONTINUE { nrest++; mu = o->mu_init; tau = fmax(o->tau_min, 1 - mu); nf = 0; dw_last = 0; eval_f_theta(p, l, z, &f, &th, &thinf); \
+                               th_min = 1e-4 * fmax(1, th); th_max = 1e4 * fmax(1, th); continue; }
+        if (!ok) { if (o->restoration && nrest < MAX_RESTORE && restore_blocks(p, l, o, z, 1) > 0) RESTORE_AND_CONTINUE; status = ST_ERROR; break; }
         if (dw > 0) dw_last = dw;
         double ap, az;
         frac_to_boundary(p, l, z, d, tau, &ap, &az);
@@ -1146,7 +1195,8 @@ static void ipm_solve(const prob_t *p, const lay_t *l, const opts_t *o, double *
             alpha *= 0.5;
         }
         if (o->verbose > 1) printf("   ls: alpha_max %.3e accepted %.3e trials %d\n", ap, alpha, ntrial);
-        if (!acc) { status = ST_ERROR; break; } /* IPOPT would enter restoration here */
+        if (!acc) { if (o->restoration && nrest < MAX_RESTORE && restore_blocks(p, l, o, z, 1) > 0) RESTORE_AND_CONTINUE; status = ST_ERROR; break; } /* IPOPT would enter restoration here */
+#undef RESTORE_AND_CONTINUE
         for (int i = 0; i < l->nprimal; i++) z[i] += alpha * d[i];
         double ay = fmin(alpha, az); /* alpha_for_y = "min" (ParkingSignedDist.jl:41) */
         for (int i = l->pi; i < l->zxL; i++) z[i] += ay * d[i];

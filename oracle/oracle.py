@@ -18,7 +18,7 @@ class Opts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("lsq_init", C.c_int), ("verbose", C.c_int), ("max_soc", C.c_int), ("recalc_y", C.c_int), ("obj_scaling", C.c_int)]
+        [("lsq_init", C.c_int), ("verbose", C.c_int), ("max_soc", C.c_int), ("recalc_y", C.c_int), ("obj_scaling", C.c_int), ("restoration", C.c_int)]
 
 
 def build():

@@ -167,7 +167,7 @@ int emu_solve(int N, const double *prob, const double *zinit, int len, const voi
     emu_race_buffer("as", s.as, (long)(N + 1) * OB_AS, OB_AS, -1); emu_race_buffer("rs", s.rs, (long)(N + 1) * OB_RS, OB_RS, RS_PAD);
     emu_race_buffer("csoc", s.csoc, g_csoc_len ? g_csoc_len : len, 0, -1); emu_race_buffer("slice record", st, SL_SIZE, 0, -1);
     struct RaceOff { ~RaceOff() { emu_race_end(); } } race_off_;
-    solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, 0, 0, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init);
+    solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, 0, 0, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init, ((const OptsAbi *)opts)->restoration);
     free(st);
     memcpy(zout, s.z, sizeof(double) * len);
     free_scratch(s);
@@ -184,7 +184,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
         if (mode == 0) emu_poison(N, len, s, st); else { Scratch none = s; emu_poison_lds_only(N); (void)none; }      // (OBCA_EMU_POISON: every launch meets a foreign pattern in LDS)
         Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc;
-        solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init);
+        solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init, ((const OptsAbi *)opts)->restoration);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
     }

@@ -17,7 +17,7 @@ class EOpts(C.Structure):
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int), ("restoration", C.c_int)]
 
 
 _VARIANTS = {None: ("libobca_emu.so", ["-O1"])}
@@ -61,14 +61,14 @@ def default_opts():
     return o
 
 
-def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, dist=False, max_soc=0, recalc_y=0, lsq_init=0, **_):
+def parking_signed_dist_batch(x0, xF, N, Ts, L, ego, XYbounds, vOb, A, b, rx, ry, ryaw, fixTime, xWS, uWS, dist=False, max_soc=0, recalc_y=0, lsq_init=0, restoration=0, **_):
     emu = load()
     x0 = np.reshape(x0, (-1, 4)); B = x0.shape[0]
     v = np.ravel(vOb).astype(int); nOb, M = len(v), int(v.sum()); Lz = P.layout(N, nOb, M)
     A = np.asarray(A, float).reshape(M, 2); b = np.ravel(np.asarray(b, float)); ego = np.ravel(np.asarray(ego, float))
     rl = P.row_lengths(A); An = A / rl[:, None]; bn = b / rl          # the kernels see unit-length rows (obca_hip.hip: batch_upload_range); lambda comes back rescaled
     g = np.array([(ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2, (ego[0] + ego[2]) / 2, (ego[1] + ego[3]) / 2]); off = (ego[0] + ego[2]) / 2 - ego[2]
-    eo = default_opts(); eo.max_soc = int(max_soc); eo.recalc_y = int(recalc_y); eo.lsq_init = int(lsq_init); nsoc = np.zeros((B, 3), int)
+    eo = default_opts(); eo.max_soc = int(max_soc); eo.recalc_y = int(recalc_y); eo.lsq_init = int(lsq_init); eo.restoration = int(restoration); nsoc = np.zeros((B, 3), int)
     Tsv = np.broadcast_to(np.asarray(Ts, float), (B,))
     xp = np.zeros((B, 4, N + 1)); up = np.zeros((B, 2, N)); ts = np.zeros((B, N + 1)); ef = np.zeros(B, np.int32); info = np.zeros((B, 8))
     lps, nps, sls = [], [], []

@@ -12,14 +12,15 @@ def _init():
 
 
 def _opts(O, sw):
-    """oracle options with the three IPOPT switches set explicitly: sw = (max_soc, recalc_y, lsq_init) or None for the defaults (all off)"""
+    """oracle options with the IPOPT switches set explicitly: sw = (max_soc, recalc_y, lsq_init[, restoration]) or None for the defaults (all off)"""
     o = O.default_opts()
     if sw:
-        o.max_soc, o.recalc_y, o.lsq_init = (int(v) for v in sw)
+        o.max_soc, o.recalc_y, o.lsq_init = (int(v) for v in sw[:3])
+        o.restoration = int(sw[3]) if len(sw) > 3 else 0
     return o
 
 
-IPOPT = (4, 1, 1)      # the reference's IPOPT configuration: max_soc = 4, recalc_y = "yes", least-squares initial multipliers
+IPOPT = (4, 1, 1, 1)      # the reference's IPOPT configuration as obca_reference_opts sets it: max_soc = 4, recalc_y = "yes", least-squares initial multipliers, block restoration
 
 
 def _parking_chunk(args):

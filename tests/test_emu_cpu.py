@@ -14,7 +14,7 @@ class EOpts(C.Structure):      # obca::Opts (obca_solver.h); every field but the
         [(n, C.c_double) for n in ("mu_init kappa_eps kappa_mu theta_mu tau_min bound_push bound_frac dw_min dw0 dw_max "
                                    "kw_inc0 kw_inc kw_dec dc_bar kappa_c gamma_theta gamma_phi delta s_theta s_phi eta_phi "
                                    "gamma_alpha s_max kappa_sigma constr_viol_tol dual_inf_tol compl_inf_tol rho_term").split()] + \
-        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int)]
+        [("max_soc", C.c_int), ("recalc_y", C.c_int), ("lsq_init", C.c_int), ("obj_scaling", C.c_int), ("restoration", C.c_int)]
 
 
 def copy_opts(oo):
@@ -314,7 +314,7 @@ def test_ipopt_switches_on_wide_obstacles_follow_the_oracle(oracle, emu, rows):
     and least-squares phases (the other switch tests run on <= 2 rows) against the oracle with the same options"""
     N = 24
     bt = S.make_mixed_batch(8, N, seed=23, rows=rows, max_extra=4)
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; eo = copy_opts(oo)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1; eo = copy_opts(oo)
     base = oracle.default_opts()
     done = changed = 0
     for i in range(8):
@@ -441,7 +441,7 @@ def test_a_solve_reads_nothing_it_has_not_written_whatever_the_pattern(emu, back
         xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
         return E.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0, xWS, bt["uWS"], **kw)
     try:
-        for kw in (dict(), dict(max_soc=4, recalc_y=1, lsq_init=1), dict(dist=True)):
+        for kw in (dict(), dict(max_soc=4, recalc_y=1, lsq_init=1, restoration=1), dict(dist=True)):
             os.environ.pop("OBCA_EMU_POISON", None)
             ref = solve(**kw)
             assert (ref["exitflag"] == 1).all()
@@ -464,7 +464,7 @@ def test_random_problems_keep_their_bits_under_finite_poison(emu):
     try:
         for draw in range(36):
             N = int(rng.choice([5, 8, 13, 21, 34, 55])); kind = int(rng.integers(0, 3)); dist = bool(rng.integers(0, 2)); fix = int(rng.integers(0, 2))
-            kw = dict(max_soc=4, recalc_y=1, lsq_init=1) if rng.integers(0, 2) else dict()
+            kw = dict(max_soc=4, recalc_y=1, lsq_init=1, restoration=1) if rng.integers(0, 2) else dict()
             max_iter = int(rng.choice([200, 200, 6]))
             if kind == 2:
                 bt = S.make_mixed_batch(2, N, seed=int(rng.integers(1, 1000)), min_obstacles=1, max_extra=13, rows=(3, 8), max_rows=64); v, A, b = bt["vOb"][1], bt["A"][1], bt["b"][1]; i = 1
@@ -502,7 +502,7 @@ def test_random_problems_the_kernels_follow_the_oracle(oracle):
     for seed in range(1000, 1120):
         rng = np.random.default_rng(seed)
         N = int(rng.choice([10, 20, 33, 48, 64, 80, 100])); kind = int(rng.integers(0, 3)); dist = bool(rng.integers(0, 2)) if kind != 2 else False; fix = int(rng.integers(0, 4) == 0)
-        ref = bool(rng.integers(0, 2)); kw = dict(max_soc=4, recalc_y=1, lsq_init=1) if ref else dict()
+        ref = bool(rng.integers(0, 2)); kw = dict(max_soc=4, recalc_y=1, lsq_init=1, restoration=1) if ref else dict()
         if kind == 2:
             bt = S.make_mixed_batch(2, N, seed=int(rng.integers(1, 10000)), min_obstacles=1, max_extra=int(rng.choice([7, 13])), rows=(3, 8) if rng.integers(0, 2) else (3, 4), max_rows=64)
             v, A, b = bt["vOb"][1], bt["A"][1], bt["b"][1]
@@ -513,7 +513,7 @@ def test_random_problems_the_kernels_follow_the_oracle(oracle):
                                         dist=dist, **kw)
         oo = oracle.default_opts()
         if ref:
-            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, float(Ts[i]), bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], fix, xWS[i], bt["uWS"][i],
                                        opts=oo, dist=int(dist))
         assert int(e["exitflag"][0]) == r["exitflag"], (seed, N, kind, dist, fix, ref)
@@ -540,7 +540,7 @@ def test_random_problems_sliced_solves_are_bit_identical(oracle, emu):
         i = 1; nOb = len(v); M = int(np.sum(v)); L = P.layout(N, nOb, M)
         eo = E.default_opts(); eo.max_iter = max_iter
         if ref:
-            eo.max_soc = 4; eo.recalc_y = 1; eo.lsq_init = 1
+            eo.max_soc = 4; eo.recalc_y = 1; eo.lsq_init = 1; eo.restoration = 1
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]; Ts = float(np.broadcast_to(bt["Ts"], (2,))[i])
         lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
         prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, Ts, bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, dist=dist)
@@ -550,3 +550,39 @@ def test_random_problems_sliced_solves_are_bit_identical(oracle, emu):
         launches_total += emu.emu_solve_sliced(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), C.c_int(budget), dp(zb), dp(ib))
         assert np.array_equal(ia, ib, equal_nan=True) and np.array_equal(za, zb, equal_nan=True), (seed, N, kind, dist, ref, budget, max_iter, ia, ib)
     assert launches_total > 800
+
+
+def test_block_restoration_in_the_kernels_follows_the_oracle(oracle):
+    """obca_opts.restoration in the kernel source (restore_blocks, obca_solver_ipm.h) against the oracle's: corridor instances whose wedges intrude 0.15 m into the warm start
+    (DualMultWS gives lambda = 0 on the penetrating poses: degenerate blocks), reference configuration with the restoration at the start -- solved on both sides, the same
+    iteration counts (one knife edge in six tolerated: these are 60-120 iteration solves; measured on the first 12 instances: 11 equal, one 117 against 115 to the same objective), the same trajectories; and a sliced solve (parked every 5 passes) keeps the bits."""
+    import emu_solver as E
+    N, B = 80, 64
+    bt = S.make_corridor_batch(B, N, seed=11, clearance=(-0.15, 0.2))
+    same = 0
+    for i in (0, 1, 2, 3, 4, 6):          # (every one of them has degenerate blocks at its start; 2 fails without the restoration)
+        xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+        oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
+        a = (bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i], bt["b"][i], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, bt["uWS"][i])
+        r = oracle.parking_signed_dist(*a, opts=oo)
+        e = E.parking_signed_dist_batch(bt["x0"][i:i + 1], bt["xF"][i:i + 1], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], bt["A"][i], bt["b"][i],
+                                        xWS[None, :, 0], xWS[None, :, 1], xWS[None, :, 2], 0, xWS[None], bt["uWS"][i:i + 1], max_soc=4, recalc_y=1, lsq_init=1, restoration=1)
+        assert e["exitflag"][0] == r["exitflag"] == 1, (i, e["exitflag"][0], r["exitflag"])
+        if e["iters"][0] == r["iters"]:
+            same += 1; assert np.abs(e["xp"][0] - r["xp"]).max() < 1e-7, i
+        else:
+            assert abs(e["obj"][0] - r["obj"]) < 1e-4 * max(1.0, abs(r["obj"])), (i, e["iters"][0], r["iters"])
+    assert same >= 5, same
+    # parked and resumed: the restoration count and the pending threshold reset travel in the slice record
+    i = 13; v = np.asarray(bt["vOb"][i]); A, b = bt["A"][i], bt["b"][i]; nOb = len(v); M = int(v.sum()); L = P.layout(N, nOb, M)
+    xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
+    lWS, nWS, _ = oracle.dualmult_ws(N, v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], bt["ego"])
+    prob = P.pack_problem(bt["x0"][i], bt["xF"][i], N, float(bt["Ts"][i]), bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0)
+    z0 = P.pack_start(N, nOb, M, xWS, bt["uWS"][i], lWS, nWS, A=A)
+    emu = E.load()
+    for mode in (1, 2):
+        eo = E.default_opts(); eo.max_soc = 4; eo.recalc_y = 1; eo.lsq_init = 1; eo.restoration = mode
+        za = np.zeros_like(z0); ia = np.zeros(8); zb = np.zeros_like(z0); ib = np.zeros(8)
+        emu.emu_solve(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), dp(za), dp(ia))
+        emu.emu_solve_sliced(C.c_int(N), dp(prob), dp(z0), C.c_int(L["len"]), C.byref(eo), C.c_int(5), dp(zb), dp(ib))
+        assert ia[7] == 1 and np.array_equal(ia, ib) and np.array_equal(za, zb), (mode, ia, ib)

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = dict(max_soc=4, recalc_y=1, lsq_init=1)
+REF = dict(max_soc=4, recalc_y=1, lsq_init=1, restoration=1)
 
 # the full solves both builds run; executed in a child process (the ASan runtime has to be loaded first, and a report of the race build is per process)
 CHILD = r'''
@@ -32,7 +32,7 @@ from obca_amd import scenarios as S
 variant = %(variant)r
 lib = E.load(variant)
 E.load = lambda variant=None: lib
-REF = dict(max_soc=4, recalc_y=1, lsq_init=1)
+REF = dict(max_soc=4, recalc_y=1, lsq_init=1, restoration=1)
 done = []
 
 def parking(tag, bt, N, idx, **kw):

@@ -182,7 +182,7 @@ def test_termination_scaling_factors_active_on_the_gpu_follow_the_oracle(OA, ora
         o = OA.ipopt_opts() if ref_opts else OA.default_opts(); o.s_max = s_max
         oo = oracle.default_opts(); oo.s_max = s_max
         if ref_opts:
-            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
         o1 = oracle.default_opts()
         if ref_opts:
             o1.max_soc = 4; o1.recalc_y = 1; o1.lsq_init = 1
@@ -254,7 +254,7 @@ def test_parking_dist_variant_matches_oracle(OA, oracle):
     # oracle with the same three options
     xp, up, ts, ef, t, lp, npp = OA.ParkingDist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], 3, bt["vOb"],
                                                bt["A"], bt["b"], xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0])
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
     r = oracle.parking_dist(bt["x0"][0], bt["xF"][0], N, bt["Ts"][0], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
                             xWS[0, :, 0], xWS[0, :, 1], xWS[0, :, 2], 0, xWS[0], bt["uWS"][0], opts=oo)
     assert ef == r["exitflag"] == 1 and np.abs(xp - r["xp"]).max() < TOL_X
@@ -344,7 +344,7 @@ def test_single_instance_wrapper_and_shapes(OA, oracle, backwards):
                                                        backwards["vOb"], backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2],
                                                        0, xWS, uWS)
     assert xp.shape == (4, N + 1) and up.shape == (2, N) and ts.shape == (N + 1,) and lp.shape == (5, N + 1) and npp.shape == (12, N + 1)
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1      # the drop-in's default IS the reference's IPOPT configuration (obca_reference_opts)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1      # the drop-in's default IS the reference's IPOPT configuration (obca_reference_opts)
     r = oracle.parking_signed_dist(x0, sc["xF"], N, Ts, backwards["L"], backwards["ego"], backwards["XYb"], backwards["vOb"],
                                    backwards["A"], backwards["b"], xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS, uWS, opts=oo)
     assert ef == r["exitflag"] == 1 and np.abs(xp - r["xp"]).max() < TOL_X and tm > 0
@@ -497,7 +497,7 @@ def test_ipopt_switches_on_wide_obstacles_match_the_oracle_options(OA, oracle):
     N, B = 40, 24
     bt = S.make_mixed_batch(B, N, seed=11, rows=(5, 8), max_extra=4)
     o = OA.default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
     out, xWS = _solve_batch(OA, dict(bt, N=N), opts=o)
     base, _ = _solve_batch(OA, dict(bt, N=N))
     for i in range(B):
@@ -586,6 +586,41 @@ def test_config5_with_binding_obstacles_matches_oracle(OA):
     assert ngpu >= 0.95 * B and nora >= 0.95 * B and nef <= 3 and nit <= 0.08 * B and len(other) <= 5 and worst < 1e-6, (ngpu, nora, nef, nit, other, worst)
 
 
+def test_block_restoration_on_warm_starts_that_penetrate_the_obstacles(OA):
+    """obca_opts.restoration through the C ABI (obca_reference_opts sets it): 64 corridor instances whose wedges intrude up to 0.15 m INTO the warm start's swept body --
+    DualMultWS (on the device) returns lambda = mu = 0 on the penetrating poses, the signed-distance NLP started there is rank-deficient, and without IPOPT's restoration phase
+    45 of the 64 solve (oracle).  With the block restoration: the GPU solves >= 60, agrees with the oracle's exit flag on every instance but 2, with its
+    iteration count on >= 80 % (60-120 iteration solves; where the counts agree the trajectories agree to 1e-6, elsewhere both reach the same objective), and switching the
+    option off through the ABI reproduces the failures.  REPORTS the counts (profiles/r06_parity_census_restoration.txt)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_pool
+    N, B = 80, 64
+    bt = S.make_corridor_batch(B, N, seed=11, clearance=(-0.15, 0.2))
+    o = OA.ipopt_opts(); assert o.restoration == 1
+    out, xWS = _solve_batch(OA, dict(bt, N=N), opts=o)
+    o0 = OA.ipopt_opts(); o0.restoration = 0
+    out0, _ = _solve_batch(OA, dict(bt, N=N), opts=o0)
+    ref = oracle_pool.mixed_oracle_all(bt, xWS, switches=oracle_pool.IPOPT)
+    nef = nit = 0; worst = 0.0; elsewhere = []
+    for (i, ef, it, obj, xp) in ref:
+        nef += int(out["exitflag"][i] != ef)
+        if ef == 1 and out["exitflag"][i] == 1:
+            if out["iters"][i] == it: worst = max(worst, np.abs(out["xp"][i] - xp).max())
+            else:
+                nit += 1
+                if abs(out["obj"][i] - obj) > 1e-4 * max(1.0, abs(obj)): elsewhere.append((i, int(out["iters"][i]), it))
+    ngpu, n0, nora = int((out["exitflag"] == 1).sum()), int((out0["exitflag"] == 1).sum()), sum(1 for r in ref if r[1] == 1)
+    msg = ("corridor batch with wedges intruding 0.15 m into the warm start, reference configuration: solved %d (GPU, block restoration) / %d (oracle, the same) / %d (GPU, restoration = 0) of %d; "
+           "exit flags differ from the oracle's on %d; iteration counts differ on %d (%d of them end elsewhere: %s); where they agree worst |dx| %.2e; mean iterations %.0f (restoration) against %.0f (without)"
+           % (ngpu, nora, n0, B, nef, nit, len(elsewhere), elsewhere, worst, out["iters"].mean(), out0["iters"].mean()))
+    print(msg); _census("restoration", msg)
+    assert ngpu >= 60 and nora >= 60 and n0 <= 52 and nef <= 2 and nit <= 0.2 * B and len(elsewhere) <= 3 and worst < 1e-6, msg
+    bad = OA.ipopt_opts(); bad.restoration = 7
+    with pytest.raises(OA.ObcaError):
+        _solve_batch(OA, dict(bt, N=N), opts=bad)
+
+
 @pytest.mark.timeout(1200)
 def test_every_instance_of_the_config3_bench_batch_matches_oracle(OA):
     """BASELINE config 3 at size -- rank 0's batch of `bench.py --config 3`: 2 048 parallel-parking instances (4 obstacles / 6 rows, randomised start and goal, Hybrid A*
@@ -646,7 +681,7 @@ def test_reference_main_jl_call_runs_as_is(OA, oracle, name):
     N, Ts, xWS, uWS, path = PL.reference_warm_start(sc, sc["x0"], sc["xF"])
     A, b, v = S.scenario_hrep(sc); x0, xF = sc["x0"], sc["xF"]; nOb = len(v)
     rx, ry, ryaw = xWS[:, 0].copy(), xWS[:, 1].copy(), xWS[:, 2].copy()
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1      # the drop-ins run the reference's IPOPT configuration by default (obca_reference_opts)
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1      # the drop-ins run the reference's IPOPT configuration by default (obca_reference_opts)
     for fn, ofn in ((OA.ParkingDist, oracle.parking_dist), (OA.ParkingSignedDist, oracle.parking_signed_dist)):
         xp, up, ts, ef, t, lp, npp = fn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, nOb, v, A, b, rx, ry, ryaw, 0, xWS, uWS)
         r = ofn(x0, xF, N, Ts, S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, rx, ry, ryaw, 0, xWS, uWS, opts=oo)
@@ -699,7 +734,7 @@ def test_parking_dist_with_the_reference_ipopt_configuration_matches_the_oracle(
     xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
     out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
                                        xWS, bt["uWS"], opts=OA.ipopt_opts(), dist=True)
-    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+    oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
     nsolved = 0; off = []
     for i in range(B):
         r = oracle.parking_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"],
@@ -750,7 +785,8 @@ def test_hip_path_lands_on_the_unreformulated_dense_solution_at_N80(OA):
             js = [int(g["idx"][i]) for i in idx]; v = [np.ravel(b5["vOb"][j]).astype(int) for j in js]; A = [np.asarray(b5["A"][j], float) for j in js]; b = [np.asarray(b5["b"][j], float) for j in js]
         else:
             A, b, v = S.scenario_hrep(sc)
-        for name, o in (("reference IPOPT configuration", OA.ipopt_opts()), ("throughput defaults", OA.default_opts())):
+        ref_o = OA.ipopt_opts(); ref_o.restoration = 0      # (the dense solve carries IPOPT's three switches and no block restoration)
+        for name, o in (("reference IPOPT configuration", ref_o), ("throughput defaults", OA.default_opts())):
             out = OA.parking_signed_dist_batch(g["x0"][idx], g["xF"][idx], N, g["Ts"][idx], S.L_WHEELBASE, S.EGO, S.XYBOUNDS, v, A, b, xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
                                                xWS, g["uWS"][idx], opts=o)
             tx, tt = (1e-3, 1e-4) if tag == "cfg3" else (1e-6, 1e-8)      # config 3 is flat around its solutions: two solves that stop at tol = 1e-5 sit 1e-6 .. 1e-4 apart (tests/test_pin_cpu.py): the path's stated tolerance

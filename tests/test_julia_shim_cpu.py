@@ -75,4 +75,4 @@ def test_julia_options_record_mirrors_the_header():
     src = open(os.path.join(ROOT, "julia", "OBCAHip.jl")).read()
     jl = re.search(r"mutable struct Opts\n(.*?)\n\s*Opts\(\) = new\(\)", src, flags=re.S).group(1)
     j_fields = [(m.group(1), JL[m.group(2)]) for m in re.finditer(r"(\w+)::(Cdouble|Cint)", jl)]
-    assert j_fields == c_fields and len(c_fields) == 34 and c_fields[-4:] == [("max_soc", "int"), ("recalc_y", "int"), ("lsq_init", "int"), ("obj_scaling", "int")]
+    assert j_fields == c_fields and len(c_fields) == 35 and c_fields[-5:] == [("max_soc", "int"), ("recalc_y", "int"), ("lsq_init", "int"), ("obj_scaling", "int"), ("restoration", "int")]

@@ -337,10 +337,33 @@ def test_corridor_batch_binding_obstacles_are_well_formed_and_solvable(oracle):
         if len(A) > 5:
             assert (np.abs(A[5:]).max(axis=1) > 0).all() and np.any(np.abs(A[5:, 0]) != 0)      # sloped rows [-s 1] / [s -1] (obstHrep.jl:73-86)
         xWS = bt["xWS"][i].copy(); xWS[0] = bt["x0"][i]
-        oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1
+        oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
         r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"][i], A, b, xWS[:, 0], xWS[:, 1], xWS[:, 2], 0, xWS,
                                        bt["uWS"][i], opts=oo)
         assert r["exitflag"] == 1
         ok, why = V.validate_parking(bt["x0"][i], bt["xF"][i], N, bt["Ts"][i], bt["L"], bt["ego"], bt["XYbounds"], np.ravel(bt["vOb"][i]), A, b, r["xp"], r["up"], r["timeScale"],
                                      r["lp"], r["np"], r["sl"], tol=1e-4)[:2]
         assert ok, why
+
+
+def test_block_restoration_solves_warm_starts_that_penetrate_the_obstacles():
+    """opts.restoration (stand-in for IPOPT's restoration phase, which the reference leans on: ParkingSignedDist.jl:228-231).  DualMultWS returns lambda = mu = 0 at a pose that
+    penetrates an obstacle; the signed-distance NLP started there is rank-deficient (|A'lam|^2 = 0 against == 1) and this interior point does not leave it.  Corridor
+    instances whose wedges intrude 0.05 / 0.15 m into the warm start's swept body, reference configuration, 64 each: without the restoration 57 / 45 solve, with it (degenerate
+    blocks get the feasible dual of their obstacle's best edge) 64 / 64 in fewer iterations; with the mid-solve trigger alone (restoration = 2, a test knob) >= 60.  And it
+    changes NOTHING where no block is degenerate: the bench batch of config 2 solves to the same bits with and without."""
+    import oracle_pool
+    from obca_amd import scenarios as S
+    N, B = 80, 64
+    for intr, need_on, most_off in ((0.05, 60, 60), (0.15, 50, 50)):
+        bt = S.make_corridor_batch(B, N, seed=11, clearance=(-intr, 0.2))
+        xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+        off = oracle_pool.mixed_oracle_all(bt, xWS, switches=(4, 1, 1, 0)); on = oracle_pool.mixed_oracle_all(bt, xWS, switches=(4, 1, 1, 1)); mid = oracle_pool.mixed_oracle_all(bt, xWS, switches=(4, 1, 1, 2))
+        n_off, n_on, n_mid = (sum(1 for r in x if r[1] == 1) for x in (off, on, mid))
+        it_off, it_on = np.mean([r[2] for r in off]), np.mean([r[2] for r in on])
+        print("corridor, tips intruding %.2f m: solved %d without / %d with the block restoration (%d with its mid-solve trigger alone) of %d; mean iterations %.0f -> %.0f" % (intr, n_off, n_on, n_mid, B, it_off, it_on))
+        assert n_on >= need_on + 2 and n_on > n_off and n_off < most_off and n_mid >= n_on - 6 and it_on < it_off, (intr, n_off, n_on, n_mid)
+    bt = S.make_batch(S.BACKWARDS, 64, N)
+    xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]
+    a = oracle_pool.parking_oracle_all(bt, xWS, switches=(4, 1, 1, 0)); b = oracle_pool.parking_oracle_all(bt, xWS, switches=(4, 1, 1, 1))
+    assert all(x[1] == y[1] == 1 and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]) for x, y in zip(a, b))
