@@ -185,7 +185,7 @@ def test_termination_scaling_factors_active_on_the_gpu_follow_the_oracle(OA, ora
             oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
         o1 = oracle.default_opts()
         if ref_opts:
-            o1.max_soc = 4; o1.recalc_y = 1; o1.lsq_init = 1
+            o1.max_soc = 4; o1.recalc_y = 1; o1.lsq_init = 1; o1.restoration = 1
         out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, bt["Ts"], bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], 0,
                                            xWS, bt["uWS"], opts=o, dist=bool(dist))
         fewer = 0
@@ -496,7 +496,7 @@ def test_ipopt_switches_on_wide_obstacles_match_the_oracle_options(OA, oracle):
     through the C ABI against the oracle with the same options"""
     N, B = 40, 24
     bt = S.make_mixed_batch(B, N, seed=11, rows=(5, 8), max_extra=4)
-    o = OA.default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1
+    o = OA.default_opts(); o.max_soc = 4; o.recalc_y = 1; o.lsq_init = 1; o.restoration = 1
     oo = oracle.default_opts(); oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
     out, xWS = _solve_batch(OA, dict(bt, N=N), opts=o)
     base, _ = _solve_batch(OA, dict(bt, N=N))

@@ -77,6 +77,7 @@ for f in glob.glob(sys.argv[1] + "/pmc_quad_mfma/**/*counter_collection.csv", re
 PY
       ;;
     phase) for B in 64 1024; do OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py $B > $O/phase_B$B.txt 2>&1; OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py $B ipopt > $O/phase_B${B}_reference_options.txt 2>&1; done; cat $O/phase_B1024_reference_options.txt; head -3 $O/phase_B1024.txt; head -3 $O/phase_B64_reference_options.txt ;;
+    phaseab) for V in ipopt ipopt-norestore; do OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py 1024 $V > $O/phase_B1024_$V.txt 2>&1; head -5 $O/phase_B1024_$V.txt | cut -c1-600; done ;;
     phase5) OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 300 python tools/phase_profile5.py > $O/phase_config5.txt 2>&1; cat $O/phase_config5.txt ;;
     census) timeout 900 python tools/options_census.py 2 3 5 > $O/options_census.txt 2>&1; cat $O/options_census.txt ;;
     gloo2) timeout 300 python bench.py --gpus 2 --backend gloo --steps 24 --warmup 4 $LEAN > $O/bench_2rank_gloo_selflaunch.json 2> $O/bench_2rank_gloo_selflaunch.err; summ $O/bench_2rank_gloo_selflaunch.json ;;
