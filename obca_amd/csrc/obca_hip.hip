@@ -38,7 +38,7 @@ struct DevBufs {
     double *prob, *z0, *z, *zn, *d, *as, *rs, *oc, *info, *dws, *prof;     // zn: the second iterate buffer of the fused line search (obca_solver.h)
     double *slice;                                   // slice records (SL_SIZE doubles per instance) of the two-launch schedule
     // second-order correction (opts.max_soc > 0): the corrected right-hand-side rows of every instance; allocated at the first such solve
-    double *csoc; size_t s_csoc;
+    double *csoc; size_t s_csoc, o_csoc;      // per instance: [ direction of a correction, o_csoc doubles (indexed like d: the layout's offsets below zxL) | the rows c_soc ]
     int *order;                                      // B instance indices in dispatch order (-1: nothing left to do), then the class counters
     size_t s_prob, s_z, s_as, s_rs, s_oc;   // strides in doubles
 };
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
         I.z = (gdbl *)(b.z + (size_t)inst * b.s_z); I.zn = (gdbl *)(b.zn + (size_t)inst * b.s_z); I.d = (gdbl *)(b.d + (size_t)inst * b.s_z);
         I.as = (gdbl *)(b.as + (size_t)inst * b.s_as); I.rs = (gdbl *)(b.rs + (size_t)inst * b.s_rs);
         I.oc = nullptr;
-        g_sh.soc.csoc = b.csoc ? (gdbl *)(b.csoc + (size_t)inst * b.s_csoc) : nullptr;
+        g_sh.soc.dsoc = b.csoc ? (gdbl *)(b.csoc + (size_t)inst * b.s_csoc) : nullptr;
+        g_sh.soc.csoc = b.csoc ? (gdbl *)(b.csoc + (size_t)inst * b.s_csoc + b.o_csoc) : nullptr;
 #ifdef OBCA_PROFILE
         I.tlast = clock64();
 #endif
@@ -478,7 +479,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         bt->zlen = lmax.len;
         DevBufs &d = bt->d;
         d.s_prob = OB_HDR + 3 * (size_t)N1; d.s_z = lmax.len; d.s_as = (size_t)N1 * OB_AS; d.s_rs = (size_t)N1 * OB_RS;
-        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.s_csoc = (size_t)(lmax.zxL - lmax.pi);
+        d.s_oc = (size_t)N1 * bt->nObMax * OB_OC; d.o_csoc = (size_t)lmax.zxL; d.s_csoc = d.o_csoc + (size_t)(lmax.zxL - lmax.pi);
         size_t tot = 0;
 #define ALLOC(ptr, cnt) do { size_t by_ = (size_t)(cnt) * sizeof(double); hipError_t e_ = dev_alloc((void **)&(ptr), by_, bt->stream); if (e_ != hipSuccess) { bt->err = std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(e_); free_dev(bt); return -2; } tot += by_; } while (0)
         ALLOC(d.prob, B * d.s_prob); ALLOC(d.z0, B * d.s_z); ALLOC(d.z, B * d.s_z); ALLOC(d.zn, B * d.s_z); ALLOC(d.d, B * d.s_z);

@@ -227,12 +227,15 @@ struct Soc {
     int max_soc, nsoc, nsoc_acc;      // option; corrections tried / accepted in this attempt (diagnostic)
     int recalc_y, nrecalc;            // option recalc_y = "yes"; multiplier re-estimates in this attempt (diagnostic)
     int lsq_init;                     // option: least-squares initial multipliers (IPOPT's default initialisation, constr_mult_init_max = 1e3)
-    int nrebuild;                     // Newton systems rebuilt after a rejected correction in this attempt (a full pass each: counted against the slice budget)
+    int nrebuild;                     // corrections rejected in this attempt (rounds 4-5 rebuilt the Newton system after each: a full pass; since round 6 the direction is kept)
     int xpass0;                       // correction / rebuild / re-estimate passes of EARLIER slices of this attempt (SL_XPASS is cumulative like SL_NREG).  (Kept here, at the end of
                                       // Shared: one more int in Drv moved everything behind it by 8 bytes, off the 16-byte boundaries the phases read `c`, `A*`, `inst` at -- 3.5 %
                                       // of `value`, profiles/r05_ab_lds_alignment.txt)
     // option restoration (block feasibility restoration: restore_blocks, obca_solver_ipm.h); restorations of this attempt; 1: the next assembly re-initialises theta_min / theta_max
     int restoration, nrest, reset_th;
+    // a correction writes ITS direction to a buffer of its own (dsoc) so that a rejected one leaves the iteration's direction where the backtracking goes on with it
+    // (rounds 4-5 let it overwrite d and rebuilt the Newton system afterwards: a full pass per rejected correction); what the correction's phases overwrite besides: kept here
+    gdbl *dsoc; double coef_keep[5]; StepOut S_keep;
 };
 #define OB_FILT_LDS 32     // filter entries kept in LDS; the (rare) rest lives in the instance's slice record
 

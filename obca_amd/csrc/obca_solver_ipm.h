@@ -363,6 +363,10 @@ OBCA_PHASE int ph_soc_try(double tht_first) {
     Shared &sh = g_sh; Drv &D = sh.drv; const Opts &o = sh.o; gdbl *const st = sh.sol.sl.st;
     const double alpha = D.alpha, th = D.th, phi = D.phi, gd = D.gd;
     double th_old = 0, th_tr = tht_first, asoc = alpha, azs = D.az; int acc = 0;
+    // the correction's direction goes to its own buffer; (dt, nu) and the step scalars of the iteration's direction are kept aside
+    gdbl *const d_iter = sh.inst.d;
+    PAR(lane) { if (lane == 0) { sh.inst.d = sh.soc.dsoc; for (int i = 0; i < 5; i++) sh.soc.coef_keep[i] = sh.coef[i]; sh.soc.S_keep = sh.S; } }
+    LDS_SYNC();
     for (int ps = 0; ps < sh.soc.max_soc && !acc && (ps == 0 || th_tr <= 0.99 * th_old); ps++) {
         th_old = th_tr;
         ph_soc_accumulate(asoc, ps == 0);
@@ -396,12 +400,23 @@ OBCA_PHASE int ph_soc_try(double tht_first) {
             }
         }
     }
-    if (acc) { D.alpha = asoc; D.az = azs; sh.soc.nsoc_acc++; return 1; }
-    // not accepted: the records and d hold a correction system -- rebuild the Newton
-    // system and direction of this iteration (same point, same delta_w: the same numbers)
-    sh.soc.nrebuild++;
-    ph_assemble(D.mu, D.dw, D.dc_val, 0);
-    if (sh.A.ok && ph_riccati(o.rho_term)) ph_direction(D.mu, D.dw, D.dc_val, o.rho_term, D.tau);
+    if (acc) { PAR(lane) { if (lane == 0) sh.inst.d = d_iter; } LDS_SYNC(); D.alpha = asoc; D.az = azs; sh.soc.nsoc_acc++; return 1; }
+    // not accepted: the backtracking goes on along the iteration's own direction.  Its stage part sits untouched in d; its x part -- the forward sweep's trajectory in LDS, which
+    // the correction's sweep overwrote -- is a copy of entries of d (direction_main: d.x[k] = s_k[0..3], d.u[k] = s_{k+1}[4..5]) and is put back from there; (dt, nu) and the step
+    // scalars come back from where they were kept.  The stage / Riccati records hold the correction's system, which nothing reads before the next assembly overwrites them.
+    sh.soc.nrebuild++;      // (the count of rejected corrections; no pass of its own since round 6)
+    {
+        const Lay &l = sh.l; const int N = sh.c.N; const gdbl *d = d_iter;
+        PAR(lane) {
+            if (lane == 0) { sh.inst.d = d_iter; for (int i = 0; i < 5; i++) sh.coef[i] = sh.soc.coef_keep[i]; sh.S = sh.soc.S_keep; }
+            for (int k = lane; k <= N; k += OB_NT) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) g_traj[(size_t)k * 6 + i] = d[l.x + 4 * k + i];
+                g_traj[(size_t)k * 6 + 4] = k ? (double)d[l.u + 2 * (k - 1)] : 0.0; g_traj[(size_t)k * 6 + 5] = k ? (double)d[l.u + 2 * (k - 1) + 1] : 0.0;
+            }
+        }
+        SYNC();
+    }
     return 0;
 }
 OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
@@ -430,9 +445,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     // D.have_asm = 1: sh.A already holds the assembly of the current iterate, left behind by the accepted trial of the previous iteration (ph_fused)
     for (;;) {
         // out of budget: park the loop state, a later launch continues
-        if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc >= sl.budget) {
+        if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrecalc >= sl.budget) {
             PAR(lane) {
-                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.xpass0 + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc; st[SL_NREST] = sh.soc.nrest + 16 * sh.soc.reset_th; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
+                if (lane == 0) { st[SL_IT] = D.it; st[SL_NF] = D.nf; st[SL_NREG] = D.nreg; st[SL_MU] = D.mu; st[SL_DWLAST] = D.dw_last; st[SL_THMIN] = D.th_min; st[SL_THMAX] = D.th_max; st[SL_PINF] = D.pinf; st[SL_HAVE] = D.have_asm; st[SL_XPASS] = sh.soc.xpass0 + sh.soc.nsoc + sh.soc.nrecalc; st[SL_NREST] = sh.soc.nrest + 16 * sh.soc.reset_th; if (D.have_asm) asm_pack(st + SL_ASM, sh.A); }
                 const int nl = D.nf < OB_FILT_LDS ? D.nf : OB_FILT_LDS;                 // (entries beyond the LDS part are in the record already)
                 for (int i = lane; i < 2 * nl; i += OB_NT) st[SL_FILT + i] = (&sh.filt[0][0])[i];
             }
@@ -554,8 +569,8 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
                                                                                                 // the least-squares system: the next iteration assembles afresh
         D.it++;
     }
-    // (a correction, the rebuild after a rejected one and a multiplier re-estimate are full passes each)
-    sl.used += D.it + D.nreg - D.p_start + sh.soc.nsoc + sh.soc.nrebuild + sh.soc.nrecalc;
+    // (a correction and a multiplier re-estimate are full passes each)
+    sl.used += D.it + D.nreg - D.p_start + sh.soc.nsoc + sh.soc.nrecalc;
     R.status = D.status; R.iters = D.it; R.nreg = D.nreg; R.obj = D.f; R.pinf = D.pinf; R.dinf = D.dinf; R.mu = D.mu;
 #if defined(OBCA_PROFILE) && !defined(OBCA_EMU)      // diagnostic counters of the IPOPT switches (slots behind the phase clocks): corrections tried / accepted, rebuilds, multiplier re-estimates
     if (LANE0) { sh.prof[13] += sh.soc.nsoc; sh.prof[14] += sh.soc.nrebuild + 1e-3 * sh.soc.nsoc_acc; sh.prof[15] += sh.soc.nrecalc; }

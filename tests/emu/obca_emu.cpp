@@ -23,7 +23,7 @@ void emu_race_begin() {} void emu_race_buffer(const char *, const void *, long, 
 static int g_csoc_len = 0;      // doubles of the c_soc buffer (0: as long as the iterate; the HIP host code allocates zxL - pi of the batch's largest layout)
 extern "C" void emu_set_csoc_len(int n) { g_csoc_len = n; }
 
-struct Scratch { double *z, *zn, *d, *as, *rs, *oc, *csoc; };
+struct Scratch { double *z, *zn, *d, *as, *rs, *oc, *csoc, *dsoc; };
 static void alloc_scratch(int N, int len, Scratch &s) {
 #ifdef OBCA_EMU_ASAN      // the dynamic LDS block of a launch ends at OB_DYN_LDS_DOUBLES(N): whatever lies behind it in the emulation's static array is out of bounds
     ASAN_UNPOISON_MEMORY_REGION(g_traj, sizeof g_traj); memset(g_traj, 0, sizeof g_traj);
@@ -31,13 +31,13 @@ static void alloc_scratch(int N, int len, Scratch &s) {
 #endif
     s.z = (double *)calloc(len, 8); s.zn = (double *)calloc(len, 8); s.d = (double *)calloc(len, 8);
     s.as = (double *)calloc((size_t)(N + 1) * OB_AS, 8); s.rs = (double *)calloc((size_t)(N + 1) * OB_RS, 8);
-    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.csoc = (double *)calloc(g_csoc_len ? g_csoc_len : len, 8);      // (c_soc: the equality rows, fewer than len)
+    s.oc = (double *)calloc((size_t)(N + 1) * OB_NOBMAX * OB_OC, 8); s.csoc = (double *)calloc(g_csoc_len ? g_csoc_len : len, 8); s.dsoc = (double *)calloc(len, 8);      // (c_soc: the equality rows, fewer than len)
 }
-static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.csoc); }
+static void free_scratch(Scratch &s) { free(s.z); free(s.zn); free(s.d); free(s.as); free(s.rs); free(s.oc); free(s.csoc); free(s.dsoc); }
 
 static void setup(int N, const double *prob, Scratch &s) {
     Shared &sh = g_sh; Inst &I = sh.inst;
-    I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc;
+    I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc; g_sh.soc.dsoc = (gdbl *)s.dsoc;
     for (int i = 0; i < OB_HDR; i++) sh.hdr[i] = prob[i];
     for (int i = 0; i <= OB_NOBMAX; i++) sh.roff[i] = (int)sh.hdr[PH_ROFF + i];
     for (int i = 0; i < OB_NOBMAX; i++) sh.vOb[i] = (int)sh.hdr[PH_VOB + i];
@@ -138,6 +138,7 @@ static void emu_poison(int N, int len, Scratch &s, double *st) {
     if (m & 1) {
         for (int i = 0; i < len; i++) { s.zn[i] = nan_; s.d[i] = nan_; }
         for (int i = 0; i < (g_csoc_len ? g_csoc_len : len); i++) s.csoc[i] = nan_;
+        for (int i = 0; i < len; i++) s.dsoc[i] = nan_;
         for (size_t i = 0; i < (size_t)(N + 1) * OB_AS; i++) s.as[i] = nan_;
         for (size_t i = 0; i < (size_t)(N + 1) * OB_RS; i++) s.rs[i] = nan_;
         for (int i = 0; i < SL_SIZE; i++) st[i] = nan_;
@@ -160,12 +161,12 @@ int emu_solve(int N, const double *prob, const double *zinit, int len, const voi
     Scratch s; alloc_scratch(N, len, s);
     { double *st0 = (double *)calloc(SL_SIZE, 8); emu_poison(N, len, s, st0); free(st0); }
     memcpy(s.z, zinit, sizeof(double) * len);
-    Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc;
+    Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc; g_sh.soc.dsoc = (gdbl *)s.dsoc;
     double *st = (double *)calloc(SL_SIZE, 8);
     emu_race_begin();
     emu_race_buffer("iterate buffer A", s.z, len, 0, -1); emu_race_buffer("iterate buffer B", s.zn, len, 0, -1); emu_race_buffer("d", s.d, len, 0, -1);
     emu_race_buffer("as", s.as, (long)(N + 1) * OB_AS, OB_AS, -1); emu_race_buffer("rs", s.rs, (long)(N + 1) * OB_RS, OB_RS, RS_PAD);
-    emu_race_buffer("csoc", s.csoc, g_csoc_len ? g_csoc_len : len, 0, -1); emu_race_buffer("slice record", st, SL_SIZE, 0, -1);
+    emu_race_buffer("csoc", s.csoc, g_csoc_len ? g_csoc_len : len, 0, -1); emu_race_buffer("dsoc", s.dsoc, len, 0, -1); emu_race_buffer("slice record", st, SL_SIZE, 0, -1);
     struct RaceOff { ~RaceOff() { emu_race_end(); } } race_off_;
     solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, 0, 0, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init, ((const OptsAbi *)opts)->restoration);
     free(st);
@@ -183,7 +184,7 @@ int emu_solve_sliced(int N, const double *prob, const double *zinit, int len, co
     for (int mode = 0;; mode = 1) {
         memset(&g_sh, 0, sizeof g_sh);                       // nothing survives a launch but HBM: the iterate and the slice record
         if (mode == 0) emu_poison(N, len, s, st); else { Scratch none = s; emu_poison_lds_only(N); (void)none; }      // (OBCA_EMU_POISON: every launch meets a foreign pattern in LDS)
-        Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc;
+        Inst &I = g_sh.inst; I.prob = (const gdbl *)prob; I.z = (gdbl *)s.z; I.zn = (gdbl *)s.zn; I.d = (gdbl *)s.d; I.as = (gdbl *)s.as; I.rs = (gdbl *)s.rs; I.oc = (gdbl *)s.oc; g_sh.soc.csoc = (gdbl *)s.csoc; g_sh.soc.dsoc = (gdbl *)s.dsoc;
         solve_instance(N, ((const OptsAbi *)opts)->o, info, (gdbl *)st, mode, budget, ((const OptsAbi *)opts)->max_soc, ((const OptsAbi *)opts)->recalc_y, ((const OptsAbi *)opts)->lsq_init, ((const OptsAbi *)opts)->restoration);
         launches++;
         if ((int)info[0] != ST_SUSPENDED || launches > 100000) break;
