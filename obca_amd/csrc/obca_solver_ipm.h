@@ -511,11 +511,10 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             double amin;
             if (gd < 0) {
                 amin = fmin(o.gamma_theta, o.gamma_phi * th / (-gd));
-                // once per iteration (also the switching condition of every trial).  A pow is a ~3k-clock dependent chain and the two are independent: lane 0 forms the
-                // first, lane 1 the second, side by side in one instruction stream (the same operations on the same operands as two scalar calls: the same bits)
-                double pw_[OBCA_NL];
-                PAR(lane) { const double bs_ = (lane & 1) ? -gd : th, ex_ = (lane & 1) ? o.s_phi : o.s_theta; pw_[LI(lane)] = pow(bs_, ex_); }
-                D.pw_th = WV_READLANE(pw_, 0); D.pw_gd = WV_READLANE(pw_, 1);
+                // once per iteration (also the switching condition of every trial).  (Round 6 measured the two pows side by side in two lanes of one call: SLOWER -- the driver's
+                // clocks per pass 23.7 k -> 29.9 k, `value` -2.5 %: with wave-uniform arguments the library pow takes scalar branches around its special cases, with per-lane
+                // arguments it executes them all.  profiles/r06_ab_pow_in_two_lanes.txt)
+                D.pw_th = pow(th, o.s_theta); D.pw_gd = pow(-gd, o.s_phi);
                 if (th <= D.th_min) amin = fmin(amin, o.delta * D.pw_th / D.pw_gd);
             } else amin = o.gamma_theta;
             D.amin = amin * o.gamma_alpha;
