@@ -13,8 +13,9 @@
  *
  * PARITY UNPINNED: the reference ships no golden vectors for this path and Julia/IPOPT cannot run here.
  * The oracle is pinned instead by (i) known-answer geometry for DualMultWS, (ii) derivative checks against
- * autograd, (iii) a dense independent IPM (oracle/ipm_dense.py) and (iv) the reference's own feasibility
- * checker restated in oracle/checkers.py.
+ * autograd, (iii) dense independent solvers (oracle/ipm_dense.py at N = 8 / 24; oracle/ipm_ref80.py: the reference's
+ * UN-reformulated NLP at N = 80, tests/golden/dense_N80.npz) and (iv) the reference's own feasibility checker
+ * (ParkingConstraints.jl) restated in obca_amd/validate.py and in ref_constraints() below.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this file.
  *
