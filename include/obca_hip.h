@@ -54,21 +54,22 @@ typedef struct obca_batch obca_batch;
  *   lsq_init -- IPOPT's default initial multipliers: the same least-squares estimate at the starting point (constr_mult_init_max = 1e3) instead of y0 = 0.
  * With any of them on, the kernels follow the CPU checker's option of the same name iteration for iteration -- on the FULL bench batches of BASELINE configs 2 / 3 / 5
  * (1 024 + 2 048 + 4 096 instances, all three switches on both sides: every exit flag equal, 0-2 iteration counts differ per batch, tests/test_gpu_parity.py,
- * profiles/r04_census_gpu_ipopt_options.txt; which switch moves a solve into another local solution and what each costs: profiles/r05_options_census.txt).
+ * profiles/r06_parity_census_reference_options_config{2,3,5}.txt; which switch moves a solve into another local solution and what each costs: profiles/r06_options_census.txt).
  *
  * Two option sets, and which one is the default where (measured on one MI355X: round 4 profiles/r04_steps/r04_bench_step1.json, r04_bench_config{3,5}.json; round 5
  * profiles/r05_bench.json, r05_bench_config{3,5}.json):
- *   obca_reference_opts -- the reference's IPOPT configuration as far as the kernels carry it: max_soc = 4, recalc_y = 1, lsq_init = 1.  The default of the DROP-IN functions
+ *   obca_reference_opts -- the reference's IPOPT configuration as far as the kernels carry it: max_soc = 4, recalc_y = 1, lsq_init = 1, restoration = 1.  The default of the DROP-IN functions
  *                          that carry the reference's names (Julia: OBCAHip.ParkingSignedDist / ParkingDist; Python: obca_amd.ParkingSignedDist / ParkingDist).
- *   obca_default_opts   -- the three switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below.  (bench.py's `value` runs
+ *   obca_default_opts   -- the switches off: the library's THROUGHPUT defaults, what a NULL `opts` means in every entry point below.  (bench.py's `value` runs
  *                          obca_reference_opts since round 5; the throughput set is its secondary leg config.fast_options.)
  * The numbers behind that split: both settings solve every instance of the three bench batches (identical exit flags, every solution passes the a-posteriori checker);
  * the IPOPT configuration costs 6 / 5 / 15 % more iterations and 12 x the inertia-correction rungs (the least-squares start leaves an indefinite Lagrangian Hessian early on):
- * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json; round 5: 247.6 k -> 201.3 k on config 2); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
+ * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json; round 6: 244.9 k -> 202.9 k, 147.9 k -> 119.1 k, 121.3 k -> 93.4 k, profiles/r06_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
  * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
  * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, pipelined: 36.7 k -> 31.4 k solves/s with its three switches.)
- * NOT in the kernels: a general restoration phase (the quadcopter kernel has a block restoration), kappa_d damping, the watchdog.  IPOPT's gradient-based scaling scales no row
+ * NOT in the kernels: IPOPT's GENERAL restoration phase (both kernels carry a block feasibility restoration in its place: `restoration` below; the quadcopter kernel's is always
+ * on), kappa_d damping (the dense un-reformulated pin oracle/ipm_ref80.py carries it and lands on the same solutions to 1e-6: it does not move them), the watchdog.  IPOPT's gradient-based scaling scales no row
  * of these NLPs (half-space rows enter with unit length besides) and the objective by 1 (parking) / 100 / 2 100 (quadcopter: opts.obj_scaling).  The quadcopter kernel carries
  * max_soc, lsq_init and obj_scaling (obca_quadcopter_reference_opts; its reference call sets recalc_y = "no",
  * and its entry points refuse an option record that sets recalc_y).  DESIGN.md sections 2, 9. */

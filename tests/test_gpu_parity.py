@@ -392,6 +392,30 @@ def test_mixed_obstacle_counts_ragged_batch(OA, oracle):
             assert np.abs(out["xp"][i] - r["xp"]).max() < TOL_X
 
 
+def test_ordered_obstacle_sums_across_round_boundaries_follow_the_oracle(OA, oracle):
+    """The GPU build of obs_sum_ordered (a running sum that walks down the lanes of a stage with wave_shr:1 moves, continued across the rounds of 64 items) has no twin in the host
+    emulation, whose PAR loop cannot shift between lanes (advisor, round 5).  So it is pinned here, end to end: instances with 3, 5, 7, 10, 13 and 16 obstacles at horizons where
+    (N + 1) nOb is not a multiple of 64 -- stages straddle round boundaries at every possible position, the last round is partial -- against the oracle, iteration for iteration:
+    a wrong or mis-ordered obstacle sum changes the Newton direction of its stage and with it every iterate."""
+    seen = set()
+    for N, seed in ((20, 3), (37, 4), (50, 5), (64, 6)):
+        bt = S.make_mixed_batch(40, N, seed=seed, min_obstacles=1, max_extra=13, rows=(3, 4), max_rows=64)
+        pick = {}
+        for i, v in enumerate(bt["vOb"]):
+            n = len(v)
+            if n in (3, 5, 7, 10, 13, 16) and n not in pick and ((N + 1) * n) % 64 != 0: pick[n] = i
+        idx = sorted(pick.values()); assert len(idx) >= 3, (N, pick)
+        sub = {k: ([v[i] for i in idx] if isinstance(v, list) else (v[idx] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == 40 else v)) for k, v in bt.items()}
+        out, xWS = _solve_batch(OA, dict(sub, N=N))
+        for q, i in enumerate(idx):
+            r = oracle.parking_signed_dist(sub["x0"][q], sub["xF"][q], N, sub["Ts"][q], sub["L"], sub["ego"], sub["XYbounds"], sub["vOb"][q], sub["A"][q], sub["b"][q],
+                                           xWS[q, :, 0], xWS[q, :, 1], xWS[q, :, 2], 0, xWS[q], sub["uWS"][q])
+            assert out["exitflag"][q] == r["exitflag"] == 1 and out["iters"][q] == r["iters"], (N, len(sub["vOb"][q]), out["iters"][q], r["iters"])
+            assert np.abs(out["xp"][q] - r["xp"]).max() < TOL_X and abs(out["obj"][q] - r["obj"]) < TOL_F * max(1.0, abs(r["obj"]))
+            seen.add(len(sub["vOb"][q]))
+    assert len(seen) >= 5, seen
+
+
 def test_config5_mixed_obstacle_counts_up_to_the_limits(OA, oracle):
     """BASELINE config 5 (reduced batch): 3..10 obstacles with 1..4 half-space rows each per instance, M up to 33, in ONE launch"""
     N, B = 80, 96
@@ -586,17 +610,18 @@ def test_config5_with_binding_obstacles_matches_oracle(OA):
     assert ngpu >= 0.95 * B and nora >= 0.95 * B and nef <= 3 and nit <= 0.08 * B and len(other) <= 5 and worst < 1e-6, (ngpu, nora, nef, nit, other, worst)
 
 
-def test_block_restoration_on_warm_starts_that_penetrate_the_obstacles(OA):
-    """obca_opts.restoration through the C ABI (obca_reference_opts sets it): 64 corridor instances whose wedges intrude up to 0.15 m INTO the warm start's swept body --
-    DualMultWS (on the device) returns lambda = mu = 0 on the penetrating poses, the signed-distance NLP started there is rank-deficient, and without IPOPT's restoration phase
-    45 of the 64 solve (oracle).  With the block restoration: the GPU solves >= 60, agrees with the oracle's exit flag on every instance but 2, with its
-    iteration count on >= 80 % (60-120 iteration solves; where the counts agree the trajectories agree to 1e-6, elsewhere both reach the same objective), and switching the
-    option off through the ABI reproduces the failures.  REPORTS the counts (profiles/r06_parity_census_restoration.txt)."""
+@pytest.mark.parametrize("intr,need,most_off", [(0.05, 60, 62), (0.15, 60, 52), (0.3, 56, 40)], ids=["0.05m", "0.15m", "0.30m"])
+def test_block_restoration_on_warm_starts_that_penetrate_the_obstacles(OA, intr, need, most_off):
+    """obca_opts.restoration through the C ABI (obca_reference_opts sets it): 64 corridor instances whose wedges intrude up to 0.05 / 0.15 / 0.3 m INTO the warm start's swept
+    body -- DualMultWS (on the device) returns lambda = mu = 0 on the penetrating poses, the signed-distance NLP started there is rank-deficient, and without IPOPT's restoration
+    phase 57 / 45 / 29 of the 64 solve (oracle).  With the block restoration (oracle: 64 / 64 / 63): the GPU solves >= 60 / 60 / 56, agrees with the oracle's
+    exit flag on every instance but 2, with its iteration count on >= 75 % (60-200 iteration solves; where the counts agree the trajectories agree to 1e-6, elsewhere nearly all
+    reach the same objective), and switching the option off through the ABI reproduces the failures.  REPORTS the counts (profiles/r06_parity_census_restoration_*.txt)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import oracle_pool
     N, B = 80, 64
-    bt = S.make_corridor_batch(B, N, seed=11, clearance=(-0.15, 0.2))
+    bt = S.make_corridor_batch(B, N, seed=11, clearance=(-intr, 0.2))
     o = OA.ipopt_opts(); assert o.restoration == 1
     out, xWS = _solve_batch(OA, dict(bt, N=N), opts=o)
     o0 = OA.ipopt_opts(); o0.restoration = 0
@@ -611,14 +636,15 @@ def test_block_restoration_on_warm_starts_that_penetrate_the_obstacles(OA):
                 nit += 1
                 if abs(out["obj"][i] - obj) > 1e-4 * max(1.0, abs(obj)): elsewhere.append((i, int(out["iters"][i]), it))
     ngpu, n0, nora = int((out["exitflag"] == 1).sum()), int((out0["exitflag"] == 1).sum()), sum(1 for r in ref if r[1] == 1)
-    msg = ("corridor batch with wedges intruding 0.15 m into the warm start, reference configuration: solved %d (GPU, block restoration) / %d (oracle, the same) / %d (GPU, restoration = 0) of %d; "
+    msg = ("corridor batch with wedges intruding %.2f m into the warm start, reference configuration: solved %d (GPU, block restoration) / %d (oracle, the same) / %d (GPU, restoration = 0) of %d; "
            "exit flags differ from the oracle's on %d; iteration counts differ on %d (%d of them end elsewhere: %s); where they agree worst |dx| %.2e; mean iterations %.0f (restoration) against %.0f (without)"
-           % (ngpu, nora, n0, B, nef, nit, len(elsewhere), elsewhere, worst, out["iters"].mean(), out0["iters"].mean()))
-    print(msg); _census("restoration", msg)
-    assert ngpu >= 60 and nora >= 60 and n0 <= 52 and nef <= 2 and nit <= 0.2 * B and len(elsewhere) <= 3 and worst < 1e-6, msg
-    bad = OA.ipopt_opts(); bad.restoration = 7
-    with pytest.raises(OA.ObcaError):
-        _solve_batch(OA, dict(bt, N=N), opts=bad)
+           % (intr, ngpu, nora, n0, B, nef, nit, len(elsewhere), elsewhere, worst, out["iters"].mean(), out0["iters"].mean()))
+    print(msg); _census("restoration_%.2fm" % intr, msg)
+    assert ngpu >= need and nora >= need and n0 <= most_off and nef <= 2 and nit <= 0.25 * B and len(elsewhere) <= 4 and worst < 1e-6, msg
+    if intr == 0.15:
+        bad = OA.ipopt_opts(); bad.restoration = 7
+        with pytest.raises(OA.ObcaError):
+            _solve_batch(OA, dict(bt, N=N), opts=bad)
 
 
 @pytest.mark.timeout(1200)
