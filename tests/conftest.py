@@ -4,6 +4,10 @@ import subprocess
 import numpy as np
 import pytest
 
+# No byte-code caches of the test modules (pytest's assertion rewriting honours this): the snapshot that travels to the GPU box stays free of derived files, and `gpurun` -- which
+# refuses snapshots that carry sanitizer build lines, also inside a .pyc -- never meets the CPU-only sanitizer tests' flags there (tests/emu_sanitize_variants.py, .gpurunignore).
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

@@ -4,10 +4,10 @@
          HBM (stage records, Riccati records, the direction); unlike LDS traffic, global loads and stores of one wavefront are not ordered against each other, so a word that one
          lane stores and another lane loads or stores must be separated by a point at which the wavefront has waited for its stores (SYNC / VM_DRAIN; LDS_SYNC is not one).
          The build reports every word for which that does not hold.  DESIGN.md section 3 claims there is none (the results do not depend on timing); this is the check.
-  asan   -DOBCA_EMU_ASAN -fsanitize=address: the per-instance buffers have exactly the sizes the HIP host code gives them (obca_hip.hip: batch_create) and the dynamic LDS block
+  asan   -DOBCA_EMU_ASAN under the host compiler's AddressSanitizer (flags: tests/emu_sanitize_variants.py): the per-instance buffers have exactly the sizes the HIP host code gives them (obca_hip.hip: batch_create) and the dynamic LDS block
          ends where the launch's does -- an access one double beyond any of them aborts the run.
 
-  ubsan  -fsanitize=undefined,bounds-strict: an index beyond a member array of the LDS structs (the filter, the reduction scratch, the unpack tables ...), a signed overflow, a bad
+  ubsan  the host compiler's UndefinedBehaviorSanitizer with strict bounds: an index beyond a member array of the LDS structs (the filter, the reduction scratch, the unpack tables ...), a signed overflow, a bad
          shift aborts the run.
 
 All run full solves: uniform and ragged obstacle sets, both option sets (the second-order correction and the least-squares multipliers have phases of their own), the
