@@ -254,6 +254,76 @@ static inline void advance_sc(char ty, double s, double &x, double &y, double &y
 }
 }  // namespace rs
 
+// ---------------------------------------------------------------- non-holonomic-WITH-obstacles heuristic on a lattice (round 6)
+// Cost-to-go of the search's own motion model -- arcs of the same curvatures, the same reverse / steering / direction-switch costs -- on a coarse (x, y, yaw, direction of arrival)
+// lattice, obstacles included (every cell-centre pose is collision-tested once), by ONE backward Dijkstra from the goal.  The reference's search has the two halves of this --
+// holonomic WITH obstacles (a_star.jl distance map) and non-holonomic WITHOUT (Reeds-Shepp length, hybrid_a_star.jl:58) -- and takes their maximum; in a parking bay neither sees
+// that the car must shunt, and the search pays with tens of thousands of expansions.  With this table the forward search expands little more than the nodes of its path.  The
+// table depends on the obstacle field and the goal, not on the start: a BATCH of searches in one field whose goals lie within a metre of each other shares one table (each
+// instance looks it up shifted by its goal's offset from the table's; the analytic expansion finishes the last metres exactly) -- obca_plan_hybrid_astar_batch2.
+struct NhTable {
+    double res = 0, yres = 0, xmin = 0, ymin = 0, gx = 0, gy = 0, gyaw = 0; int nx = 0, ny = 0, nyaw = 0;
+    std::vector<float> h;      // [cell * 2 + (arrived driving forwards ? 0 : 1)]
+    long long cells() const { return (long long)nx * ny * nyaw; }
+    long long cell(double x, double y, double yaw) const {
+        const long long ix = (long long)std::floor((x - xmin) / res), iy = (long long)std::floor((y - ymin) / res);
+        if (ix < 0 || iy < 0 || ix >= nx || iy >= ny) return -1;
+        long long ia = (long long)std::floor((wrap(yaw) + M_PI) / yres); if (ia >= nyaw) ia = nyaw - 1; if (ia < 0) ia = 0;
+        return (iy * nx + ix) * nyaw + ia;
+    }
+    // cost-to-go of the pose for a car that arrived there driving in direction dir (0: start of a path: the cheaper of the two); < 0: not in the table
+    double lookup(double x, double y, double yaw, int dir) const {
+        const long long k = cell(x, y, yaw); if (k < 0) return -1.0;
+        const float a = h[(size_t)k * 2], b_ = h[(size_t)k * 2 + 1], v = dir > 0 ? a : (dir < 0 ? b_ : std::min(a, b_));
+        return v < 1e8f ? (double)v : -1.0;
+    }
+};
+static void build_nh_table(const World &w, const double goal[3], double res, double yres, double smax, int nst, double L, double crev, double csw, double cst, double gtol, double ytol, NhTable &T) {
+    T.res = res; T.yres = yres; T.xmin = w.xmin; T.ymin = w.ymin; T.gx = goal[0]; T.gy = goal[1]; T.gyaw = goal[2];
+    T.nx = (int)std::ceil((w.xmax - w.xmin) / res) + 1; T.ny = (int)std::ceil((w.ymax - w.ymin) / res) + 1; T.nyaw = (int)std::ceil(2 * M_PI / yres);
+    const long long nc = T.cells();
+    T.h.assign((size_t)nc * 2, 1e9f);
+    std::vector<uint8_t> free_((size_t)nc, 0);
+    std::vector<double> cyaw(T.nyaw), syaw(T.nyaw);
+    for (int ia = 0; ia < T.nyaw; ia++) { const double a = -M_PI + (ia + 0.5) * yres; cyaw[ia] = std::cos(a); syaw[ia] = std::sin(a); }
+    for (int iy = 0; iy < T.ny; iy++) for (int ix = 0; ix < T.nx; ix++) for (int ia = 0; ia < T.nyaw; ia++)
+        free_[(size_t)(((long long)iy * T.nx + ix) * T.nyaw + ia)] = !collides_cs(w, w.xmin + (ix + 0.5) * res, w.ymin + (iy + 0.5) * res, cyaw[ia], syaw[ia]);
+    const double lstep = 1.5 * res;                                  // an arc long enough to leave its cell
+    std::vector<double> kappa(2 * nst + 1), ecost(2 * nst + 1);
+    for (int si = -nst; si <= nst; si++) { kappa[si + nst] = std::tan(smax * si / nst) / L; ecost[si + nst] = cst * std::fabs(smax * si / nst) * lstep; }
+    typedef std::pair<float, long long> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+    // the goal: every free cell whose centre lies within the search's own goal tolerances
+    for (int iy = 0; iy < T.ny; iy++) for (int ix = 0; ix < T.nx; ix++) {
+        const double cx = w.xmin + (ix + 0.5) * res, cy = w.ymin + (iy + 0.5) * res;
+        if (std::hypot(cx - goal[0], cy - goal[1]) > std::max(gtol, res)) continue;
+        for (int ia = 0; ia < T.nyaw; ia++) {
+            if (std::fabs(wrap(-M_PI + (ia + 0.5) * yres - goal[2])) > std::max(ytol, yres)) continue;
+            const long long k = ((long long)iy * T.nx + ix) * T.nyaw + ia; if (!free_[(size_t)k]) continue;
+            for (int di = 0; di < 2; di++) { T.h[(size_t)k * 2 + di] = 0.f; pq.push({0.f, k * 2 + di}); }
+        }
+    }
+    while (!pq.empty()) {
+        const QE e = pq.top(); pq.pop();
+        if (e.first > T.h[(size_t)e.second]) continue;
+        const long long k = e.second >> 1; const int di = (int)(e.second & 1), d = di ? -1 : 1;      // state: in cell k, having ARRIVED driving in direction d
+        const int ia = (int)(k % T.nyaw); const long long cxy = k / T.nyaw; const int ix = (int)(cxy % T.nx), iy = (int)(cxy / T.nx);
+        const double x1 = w.xmin + (ix + 0.5) * res, y1 = w.ymin + (iy + 0.5) * res, yaw1 = -M_PI + (ia + 0.5) * yres, s1 = syaw[ia], c1 = cyaw[ia];
+        // predecessors: the poses from which the arc (d, steer) ends here = this pose driven along (-d, steer)
+        for (int si = -nst; si <= nst; si++) {
+            const double kap = kappa[si + nst], ds = -d * lstep; double x0, y0, yaw0;
+            if (std::fabs(kap) < 1e-9) { x0 = x1 + ds * c1; y0 = y1 + ds * s1; yaw0 = yaw1; }
+            else { yaw0 = yaw1 + ds * kap; x0 = x1 + (std::sin(yaw0) - s1) / kap; y0 = y1 - (std::cos(yaw0) - c1) / kap; }
+            const long long kp = T.cell(x0, y0, yaw0);
+            if (kp < 0 || kp == k || !free_[(size_t)kp]) continue;
+            const float base = e.first + (float)(lstep * (d > 0 ? 1.0 : crev) + ecost[si + nst]);
+            for (int dp = 0; dp < 2; dp++) {                         // the predecessor state: arrived at kp driving in direction (dp ? -1 : +1), then drives d
+                const float c = base + (dp != di ? (float)csw : 0.f);
+                if (c < T.h[(size_t)kp * 2 + dp]) { T.h[(size_t)kp * 2 + dp] = c; pq.push({c, kp * 2 + dp}); }
+            }
+        }
+    }
+}
+
 extern "C" {
 
 /*
@@ -266,13 +336,13 @@ extern "C" {
  * Output: path[3 * k] = x, y, yaw of the k-th node and dir[k] = +1 / -1 (motion that led to the node), up to cap nodes.
  * Returns the number of nodes (>= 2), 0 if no path was found, -1 on bad arguments, -2 if the start or the goal collides.
  */
-int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
-                            const double ego[4], double L, const double XYbounds[4], const double *opts_in, int nopts, double *path, int *dir, int cap,
-                            int *expansions) {
+static int hybrid_astar_impl(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                             const double ego[4], double L, const double XYbounds[4], const double *opts_in, int nopts, double *path, int *dir, int cap,
+                             int *expansions, const NhTable *shared) {
     if (!start || !goal || nOb < 0 || !vOb || !A || !b || !ego || !XYbounds || !path || !dir || cap < 2) return -1;
     if (opts_in && (nopts < 0 || nopts > OBCA_PLAN_NOPTS)) return -1;
-    // the caller's first nopts options over the defaults: an array of the 14 options of rounds 1-4 leaves the two newer ones at 1 / 0 and nothing is read beyond its end
-    double optbuf[OBCA_PLAN_NOPTS] = {0.25, 7.5, 0.6, 0.6, 2, 0.1, 0.3, 8.0, 1.5, 2.0, 0.3, 400000, 1.0, 0.2, 1.0, 0.0};
+    // the caller's first nopts options over the defaults: an array of the 14 options of rounds 1-4 leaves the newer ones at their defaults and nothing is read beyond its end
+    double optbuf[OBCA_PLAN_NOPTS] = {0.25, 7.5, 0.6, 0.6, 2, 0.1, 0.3, 8.0, 1.5, 2.0, 0.3, 400000, 1.0, 0.2, 1.0, 0.0, 0.0, 7.5};
     for (int i = 0; opts_in && i < nopts; i++) optbuf[i] = opts_in[i];
     const double *opts = optbuf;
     if (!(opts[14] > 0.0) || !std::isfinite(opts[14])) return -1;      // heuristic weight: positive and finite (0, negative or NaN would silently corrupt the search order)
@@ -282,6 +352,8 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
     const double analytic = opts ? opts[12] : 1.0;
     const double hweight = opts ? opts[14] : 1.0;       // weight of the heuristic (hybrid_a_star.jl:64 H_COST; > 1: greedier search, fewer expansions, longer paths)
     const bool rs_heur = opts ? opts[15] != 0.0 : false; // max(grid heuristic, Reeds-Shepp length) as the heuristic (hybrid_a_star.jl:58 USE_NONHOLONOMIC_WITHOUT_OBSTACLE_HEURISTIC)
+    const double nh_res = opts[16], nh_yres = opts[17] * M_PI / 180;      // lattice of the non-holonomic-with-obstacles heuristic (xy cell [m], 0 = off; yaw cell): build_nh_table
+    if (nh_res < 0 || !std::isfinite(nh_res) || (nh_res > 0 && (nh_res < 0.05 || !(nh_yres > 1e-3)))) return -1;
     const double cchg = opts ? opts[13] : 0.2;          // steer-change cost per radian (hybrid_a_star.jl:63 STEER_CHANGE_COST)       // analytic (Reeds-Shepp) expansion towards the goal, hybrid_a_star.jl:193-214: 0 = off,
                                                          // else the fraction of the steering lock its arcs use (1 = the reference's full lock)
     World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0);
@@ -314,7 +386,13 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
             }
         }
     }
-    auto heur = [&](double x, double y, double yaw) {
+    // the lattice heuristic: the batch's shared table (looked up shifted by this goal's offset from the table's goal) or one built for this search
+    NhTable own; const NhTable *nh = nullptr; double nh_dx = 0, nh_dy = 0;
+    if (nh_res > 0) {
+        if (shared && shared->res == nh_res && std::hypot(goal[0] - shared->gx, goal[1] - shared->gy) <= 1.5 && std::fabs(wrap(goal[2] - shared->gyaw)) <= 1e-9) { nh = shared; nh_dx = goal[0] - shared->gx; nh_dy = goal[1] - shared->gy; }
+        else { build_nh_table(w, goal, nh_res, nh_yres, smax, nst, L, crev, csw, cst, gtol, ytol, own); nh = &own; }
+    }
+    auto heur = [&](double x, double y, double yaw, int dir_in) {
         const int ix = std::min(nx - 1, std::max(0, (int)std::lround((x - w.xmin) / res))), iy = std::min(ny - 1, std::max(0, (int)std::lround((y - w.ymin) / res)));
         const double h2 = hmap[(size_t)iy * nx + ix] < 1e8f ? hmap[(size_t)iy * nx + ix] : std::hypot(x - goal[0], y - goal[1]) + 5.0;
         const double Rmin = L / std::tan(smax);
@@ -324,6 +402,7 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
             const rs::Path p = rs::shortest((c * dx + s_ * dy) / Rmin, (-s_ * dx + c * dy) / Rmin, wrap(goal[2] - yaw));
             if (p.n > 0) h = std::max(h, Rmin * p.total);
         }
+        if (nh) { const double hn = nh->lookup(x - nh_dx, y - nh_dy, yaw, dir_in); if (hn >= 0) h = std::max(h, hn); }
         return hweight * h;
     };
     const int nyaw = (int)std::ceil(2 * M_PI / yres);
@@ -341,7 +420,7 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
     auto cell = [&](double x, double y, double yaw) -> long long { const long long k = key(x, y, yaw); return k >= 0 && k < ncell ? k : -1; };
     typedef std::pair<double, int> QE; std::priority_queue<QE, std::vector<QE>, std::greater<QE>> open;
     nodes.push_back({start[0], start[1], wrap(start[2]), 0.0, -1, 0, 0});
-    open.push({heur(start[0], start[1], start[2]), 0}); { const long long k = cell(start[0], start[1], start[2]); if (k >= 0) { best[(size_t)k] = 0.0; touched.push_back(k); } }
+    open.push({heur(start[0], start[1], start[2], 0), 0}); { const long long k = cell(start[0], start[1], start[2]); if (k >= 0) { best[(size_t)k] = 0.0; touched.push_back(k); } }
     long nexp = 0; int found = -1;
     const int sub = std::max(1, (int)std::ceil(step / 0.2));
     const double Rmin = L / std::tan(smax * (analytic > 0 ? std::min(1.0, analytic) : 1.0));
@@ -396,7 +475,7 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
                 if (best[(size_t)k] == 1e300) touched.push_back(k);
                 best[(size_t)k] = g;
                 nodes.push_back({x, y, wrap(yaw), g, e.second, (int8_t)d, (int8_t)si});
-                open.push({g + heur(x, y, yaw), (int)nodes.size() - 1});
+                open.push({g + heur(x, y, yaw, d), (int)nodes.size() - 1});
             }
     }
     if (expansions) *expansions = (int)nexp;
@@ -428,11 +507,38 @@ int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb
 /* Shortest Reeds-Shepp path from start to goal (x, y, yaw) for turning radius R, sampled every `step` metres: path[3k..] = pose k,
  * dir[k] = +1 / -1.  word (>= 6 chars, may be NULL) receives the segment types ("LSR", "LRSLR", ...), seglen (5, may be NULL) their signed
  * lengths in metres.  Returns the number of samples (start and goal included), -1 on bad arguments / cap too small. */
+int obca_plan_hybrid_astar2(const double start[3], const double goal[3], int nOb, const int *vOb, const double *A, const double *b,
+                            const double ego[4], double L, const double XYbounds[4], const double *opts, int nopts, double *path, int *dir, int cap,
+                            int *expansions) {
+    return hybrid_astar_impl(start, goal, nOb, vOb, A, b, ego, L, XYbounds, opts, nopts, path, dir, cap, expansions, nullptr);
+}
+
 int obca_plan_hybrid_astar_batch2(int B, const double *starts, const double *goals, int nOb, const int *vOb, const double *A, const double *b,
                                   const double ego[4], double L, const double XYbounds[4], const double *opts, int nopts, double *paths, int *dirs, int cap,
                                   int *counts, int *expansions, int threads) {
     if (B < 0 || !starts || !goals || !paths || !dirs || !counts || cap < 2) return -1;
     if (opts && (nopts < 0 || nopts > OBCA_PLAN_NOPTS)) return -1;
+    // the lattice heuristic (options 16, 17) is a property of the obstacle field and the goal: ONE table for the batch, built around the goal in the middle of the batch's goals
+    NhTable table; const NhTable *shared = nullptr;
+    if (B > 0 && opts && nopts > 16 && opts[16] > 0 && nOb >= 0 && vOb && A && b && ego && XYbounds) {
+        double o_[OBCA_PLAN_NOPTS] = {0.25, 7.5, 0.6, 0.6, 2, 0.1, 0.3, 8.0, 1.5, 2.0, 0.3, 400000, 1.0, 0.2, 1.0, 0.0, 0.0, 7.5};
+        for (int i = 0; i < nopts; i++) o_[i] = opts[i];
+        if (std::isfinite(o_[16]) && o_[16] >= 0.05 && o_[17] > 0.05 && (int)o_[4] >= 0) {
+            std::vector<double> gxs(B), gys(B);
+            for (int i = 0; i < B; i++) { gxs[i] = goals[3 * (size_t)i]; gys[i] = goals[3 * (size_t)i + 1]; }
+            std::nth_element(gxs.begin(), gxs.begin() + B / 2, gxs.end()); std::nth_element(gys.begin(), gys.begin() + B / 2, gys.end());
+            const double gref[3] = {gxs[B / 2], gys[B / 2], goals[2]};
+            World w; w.nOb = nOb; w.v.assign(vOb, vOb + nOb); w.off.assign(nOb + 1, 0); bool ok_ = true;
+            for (int j = 0; j < nOb; j++) { if (vOb[j] < 1) ok_ = false; w.off[j + 1] = w.off[j] + vOb[j]; }
+            if (ok_) {
+                w.A.assign(A, A + 2 * w.off[nOb]); w.b.assign(b, b + w.off[nOb]);
+                w.xmin = XYbounds[0]; w.xmax = XYbounds[1]; w.ymin = XYbounds[2]; w.ymax = XYbounds[3];
+                std::memcpy(w.ego, ego, sizeof w.ego); w.margin = o_[5]; w.finish();
+                build_nh_table(w, gref, o_[16], o_[17] * M_PI / 180, o_[3], (int)o_[4], L, o_[8], o_[9], o_[10], o_[6], o_[7] * M_PI / 180, table);
+                shared = &table;
+            }
+        }
+    }
     unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > (unsigned)B) nt = (unsigned)(B > 0 ? B : 1);
@@ -440,8 +546,8 @@ int obca_plan_hybrid_astar_batch2(int B, const double *starts, const double *goa
     auto work = [&]() {
         for (int i = next.fetch_add(1); i < B; i = next.fetch_add(1)) {
             int ne = 0;
-            counts[i] = obca_plan_hybrid_astar2(starts + 3 * (size_t)i, goals + 3 * (size_t)i, nOb, vOb, A, b, ego, L, XYbounds, opts, nopts, paths + 3 * (size_t)cap * i,
-                                                dirs + (size_t)cap * i, cap, &ne);
+            counts[i] = hybrid_astar_impl(starts + 3 * (size_t)i, goals + 3 * (size_t)i, nOb, vOb, A, b, ego, L, XYbounds, opts, nopts, paths + 3 * (size_t)cap * i,
+                                          dirs + (size_t)cap * i, cap, &ne, shared);
             if (expansions) expansions[i] = ne;
         }
     };

@@ -35,7 +35,7 @@ def _load():
 
 DEFAULT_OPTS = dict(xy_res=0.25, yaw_res_deg=7.5, step=0.6, max_steer=0.6, steer_samples=2, margin=0.1, goal_xy_tol=0.3,
                     goal_yaw_tol_deg=8.0, reverse_cost=1.5, switch_cost=2.0, steer_cost=0.3, max_expansions=400000, analytic=0.85, steer_change_cost=0.2,
-                    h_weight=1.0, rs_heuristic=0)
+                    h_weight=1.0, rs_heuristic=0, nh_res=0.0, nh_yaw_res_deg=7.5)
 # the cost constants of the reference's search (hybrid_a_star.jl:60-63: SB_COST 10, BACK_COST 0, STEER_CHANGE_COST 10, STEER_COST 0; arc length x 1 forwards, x BACK_COST
 # backwards -- a tiny positive value here keeps reverse arcs from being free, which an A* with a consistent heuristic needs), its grids (:46-54: 0.3 m, 5 deg, 5 steer
 # commands) and its full-lock analytic expansion: `hybrid_astar(..., **REFERENCE_COSTS)` / `warm_start(..., **REFERENCE_COSTS)`

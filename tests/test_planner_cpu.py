@@ -99,7 +99,7 @@ def test_option_arrays_carry_their_length_and_the_old_entry_point_reads_fourteen
     sc = S.BACKWARDS; A, b, v = S.scenario_hrep(sc); v = np.ascontiguousarray(v, np.int32); A = np.ascontiguousarray(A, float); b = np.ascontiguousarray(b, float)
     s = np.array(sc["x0"][:3], float); g = np.array(sc["xF"][:3], float); e = np.ascontiguousarray(S.EGO, float); xy = np.ascontiguousarray(S.XYBOUNDS, float)
     od = dict(PL.DEFAULT_OPTS); od.update(PL.SCENARIO_OPTS[sc["name"]][0])
-    o16 = np.array([od[k] for k in PL.DEFAULT_OPTS], float); assert len(o16) == 16
+    o16 = np.array([od[k] for k in PL.DEFAULT_OPTS], float)[:16]; assert len(PL.DEFAULT_OPTS) == 18
     cap = 4096
 
     def run(fn, opts, nopts=None):
@@ -123,7 +123,8 @@ def test_option_arrays_carry_their_length_and_the_old_entry_point_reads_fourteen
     for bad in (0.0, -2.0, np.nan, np.inf):
         w = w1.copy(); w[14] = bad
         assert run("obca_plan_hybrid_astar2", w, 16)[0] == -1, bad
-    assert run("obca_plan_hybrid_astar2", w1, 17)[0] == -1 and run("obca_plan_hybrid_astar2", w1, -1)[0] == -1
+    assert run("obca_plan_hybrid_astar2", np.concatenate([w1, [0.0, 7.5, 1.0]]), 19)[0] == -1 and run("obca_plan_hybrid_astar2", w1, -1)[0] == -1
+    assert run("obca_plan_hybrid_astar2", np.concatenate([w1, [-1.0, 7.5]]), 18)[0] == -1      # a negative lattice cell
     assert run("obca_plan_hybrid_astar2", None, 0)[0] >= 2
 
 
@@ -396,3 +397,31 @@ def test_reference_astar3d_restated_on_the_reference_call():
     # (c) what mainQuadcopter.jl derives from the path
     N_as, Ts_as, xWS, uWS, wpm = PL.reference_quad_warm_start()
     assert N_as == 99 and Ts_as == 0.2 and xWS.shape == (100, 12) and np.abs(xWS[:, :3] - wp / 10).max() == 0 and (xWS[:, 3:] == 0).all() and (uWS == 0.5).all()
+
+
+def test_lattice_heuristic_plans_are_valid_and_cheaper_to_find():
+    """options 16, 17 (round 6): the non-holonomic-with-obstacles cost-to-go on a coarse (x, y, yaw, direction) lattice as a third heuristic -- one backward Dijkstra per batch.
+    24 parallel-parking searches with randomised starts and goals: every plan collision-free and at its goal as with the default heuristics, in fewer expansions; one shared table
+    serves goals a metre apart (the batch call) and gives exactly what a table of the search's own gives when the goal is the table's."""
+    sc = S.PARALLEL; A, b, v = S.scenario_hrep(sc)
+    rng = np.random.default_rng(7); B = 24
+    x0 = np.stack([rng.uniform(-10, 10, B), rng.uniform(6.5, 9.5, B), rng.uniform(-0.2, 0.2, B)], 1)
+    xF = np.stack([rng.uniform(-1.85, -0.85, B), np.full(B, 4.0), np.zeros(B)], 1)
+    o = dict(PL.SCENARIO_OPTS["parallel"][0])
+    base = PL.hybrid_astar_many(x0, xF, v, A, b, threads=4, **o)
+    nh = PL.hybrid_astar_many(x0, xF, v, A, b, threads=4, **dict(o, nh_res=0.25, nh_yaw_res_deg=7.5, rs_heuristic=0, h_weight=1.5))
+    nb = ne = 0
+    for i in range(B):
+        assert (base[i] is None) == (nh[i] is None), i
+        if nh[i] is None:
+            continue
+        path, dr, nexp = nh[i]
+        assert np.allclose(path[0], x0[i]) and np.hypot(*(path[-1, :2] - xF[i, :2])) <= 0.3 + 1e-9 and abs((path[-1, 2] - xF[i, 2] + np.pi) % (2 * np.pi) - np.pi) <= np.deg2rad(8) + 1e-9
+        assert not any(PL.collides(p, v, A, b) for p in path[::3])
+        nb += base[i][2]; ne += nexp
+    assert ne < 0.7 * nb, (ne, nb)
+    # the single call builds its own table: for the batch's median goal the two are the same search
+    gm = np.array([np.partition(xF[:, 0], B // 2)[B // 2], 4.0, 0.0]); k = int(np.argmin(np.abs(xF[:, 0] - gm[0])))
+    if nh[k] is not None and abs(xF[k, 0] - gm[0]) < 1e-12:
+        one = PL.hybrid_astar(x0[k], xF[k], v, A, b, **dict(o, nh_res=0.25, nh_yaw_res_deg=7.5, rs_heuristic=0, h_weight=1.5))
+        assert one[2] == nh[k][2] and np.array_equal(one[0], nh[k][0])
