@@ -643,6 +643,19 @@ def test_block_restoration_on_warm_starts_that_penetrate_the_obstacles(OA, intr,
     # (iteration counts: measured 4 / 9 / 18 of 64 differ at 0.05 / 0.15 / 0.3 m -- the deeper the intrusion the longer and the more chaotic the solves, 58 / 75 / 112 iterations)
     assert ngpu >= need and nora >= need and n0 <= most_off and nef <= 2 and nit <= (0.35 if intr > 0.2 else 0.25) * B and len(elsewhere) <= 4 and worst < 1e-6, msg
     if intr == 0.15:
+        # parked and resumed (the two-launch schedule forced on this small batch): the restoration count and the pending threshold reset travel in the slice record -- same bits;
+        # with the mid-solve trigger alone (restoration = 2) as well, where restorations happen INSIDE the solves
+        import os
+        for mode in (1, 2):
+            om = OA.ipopt_opts(); om.restoration = mode
+            one, _ = _solve_batch(OA, dict(bt, N=N), opts=om)
+            os.environ["OBCA_SLICE_ALWAYS"] = "1"; os.environ["OBCA_SLICE_PASSES"] = "5"
+            try:
+                two, _ = _solve_batch(OA, dict(bt, N=N), opts=om)
+            finally:
+                os.environ.pop("OBCA_SLICE_ALWAYS", None); os.environ.pop("OBCA_SLICE_PASSES", None)
+            assert np.array_equal(one["info"], two["info"]) and np.array_equal(np.asarray(one["xp"]), np.asarray(two["xp"])), mode
+            if mode == 2: assert (one["exitflag"] == 1).sum() >= 58
         bad = OA.ipopt_opts(); bad.restoration = 7
         with pytest.raises(OA.ObcaError):
             _solve_batch(OA, dict(bt, N=N), opts=bad)
