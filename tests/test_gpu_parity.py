@@ -416,6 +416,43 @@ def test_ordered_obstacle_sums_across_round_boundaries_follow_the_oracle(OA, ora
     assert len(seen) >= 5, seen
 
 
+@pytest.mark.timeout(900)
+def test_random_problems_on_the_gpu_follow_the_oracle(OA, oracle):
+    """GPU twin of tests/test_emu_cpu.py::test_random_problems_the_kernels_follow_the_oracle: 60 seeded random draws of (horizon 10-100, backwards / parallel / 1-16 obstacles of
+    up to 8 rows, formulation, fixed or variable time, option set incl. the block restoration), 6 instances each, through the C ABI against the oracle: exit flags equal, iteration
+    counts equal on all but a handful (knife edges; their solves must end at the oracle's objective), trajectories to 1e-6 where the counts agree."""
+    off = []; worst = 0.0; solved = 0; total = 0
+    for seed in range(3000, 3060):
+        rng = np.random.default_rng(seed)
+        N = int(rng.choice([10, 20, 33, 48, 64, 80, 100])); kind = int(rng.integers(0, 3)); dist = bool(rng.integers(0, 2)) if kind != 2 else False; fix = int(rng.integers(0, 4) == 0)
+        ref = bool(rng.integers(0, 2)); B = 6
+        if kind == 2:
+            bt = S.make_mixed_batch(B, N, seed=int(rng.integers(1, 10000)), min_obstacles=1, max_extra=int(rng.choice([7, 13])), rows=(3, 8) if rng.integers(0, 2) else (3, 4), max_rows=64)
+        else:
+            bt = S.make_batch(S.BACKWARDS if kind == 0 else S.PARALLEL, B, N, seed=int(rng.integers(1, 10000)))
+        xWS = bt["xWS"].copy(); xWS[:, 0, :] = bt["x0"]; Ts = np.broadcast_to(bt["Ts"], (B,))
+        o = OA.ipopt_opts() if ref else OA.default_opts()
+        out = OA.parking_signed_dist_batch(bt["x0"], bt["xF"], N, Ts, bt["L"], bt["ego"], bt["XYbounds"], bt["vOb"], bt["A"], bt["b"], xWS[:, :, 0], xWS[:, :, 1], xWS[:, :, 2], fix, xWS, bt["uWS"],
+                                           opts=o, dist=dist)
+        oo = oracle.default_opts()
+        if ref:
+            oo.max_soc = 4; oo.recalc_y = 1; oo.lsq_init = 1; oo.restoration = 1
+        for i in range(B):
+            v, A, b = (bt["vOb"][i], bt["A"][i], bt["b"][i]) if kind == 2 else (bt["vOb"], bt["A"], bt["b"])
+            r = oracle.parking_signed_dist(bt["x0"][i], bt["xF"][i], N, float(Ts[i]), bt["L"], bt["ego"], bt["XYbounds"], v, A, b, xWS[i, :, 0], xWS[i, :, 1], xWS[i, :, 2], fix, xWS[i], bt["uWS"][i],
+                                           opts=oo, dist=int(dist))
+            total += 1
+            assert int(out["exitflag"][i]) == r["exitflag"], (seed, i, N, kind, dist, fix, ref, int(out["exitflag"][i]), r["exitflag"])
+            if int(out["iters"][i]) != r["iters"]:
+                off.append((seed, i, int(out["iters"][i]), r["iters"]))
+                if r["exitflag"] == 1: assert abs(out["obj"][i] - r["obj"]) < 1e-4 * max(1.0, abs(r["obj"])), off[-1]
+            elif r["exitflag"] == 1:
+                solved += 1; worst = max(worst, float(np.abs(out["xp"][i] - r["xp"]).max()))
+    msg = "random problems on the GPU against the oracle: %d instances in 60 draws, %d solved with equal iteration counts (worst |dx| %.2e), iteration counts differ on %s" % (total, solved, worst, off)
+    print(msg); _census("random_problems", msg)
+    assert len(off) <= 4 and solved >= 0.9 * total and worst < TOL_X, msg
+
+
 def test_config5_mixed_obstacle_counts_up_to_the_limits(OA, oracle):
     """BASELINE config 5 (reduced batch): 3..10 obstacles with 1..4 half-space rows each per instance, M up to 33, in ONE launch"""
     N, B = 80, 96
