@@ -351,6 +351,11 @@ OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 
 // kept: the state in registers between the calls and copied to / from LDS around each call -- the register allocator then spills MORE, 277 scratch stores / 571
 // loads in the kernel body against 96 / 279.)
 #define PH(call) call
+#ifdef OBCA_PROFILE_DRV      // (with -DOBCA_PROFILE: the driver's clocks split three ways -- slots ric_p1 / ric_p2 of the phase profile: line-search set-up, acceptance; the rest stays in `other`)
+#define PROF_DRV(I, id) PROF(I, id)
+#else
+#define PROF_DRV(I, id) ((void)0)
+#endif
 // Second-order correction after the FIRST trial step of an iteration was rejected without
 // reducing theta (IPOPT A-5.5..A-5.9, kappa_soc = 0.99): up to max_soc steps that
 // solve the system of the iterate again with c_soc = alpha c(z) + c(trial) on the right-hand
@@ -520,6 +525,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             D.amin = amin * o.gamma_alpha;
         }
         D.alpha = sh.S.ap; D.acc = 0;
+        PROF_DRV(sh.inst, PF_RIC_P1);
         while (D.alpha >= D.amin) {
             // the trial point z + alpha d goes to the second iterate buffer together with
             // its assembly (mu as is, delta_w = 0: what the next iteration starts from)
@@ -562,6 +568,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         PAR(lane) { if (lane == 0) { Inst &I = sh.inst; gdbl *t_ = I.z; I.z = I.zn; I.zn = t_; sh.A = sh.An; } }
         LDS_SYNC();
         D.have_asm = 1;
+        PROF_DRV(sh.inst, PF_RIC_P2);
         // recalc_y = "yes": least-squares multipliers at a (nearly) feasible iterate.  Whether the estimate is kept or not, the
         if (sh.soc.recalc_y && sh.A.pinf < OB_RECALC_FEAS_TOL) { ph_recalc_y(0); D.have_asm = 0; }
                                                                                                 // call overwrote the stage / obstacle / Riccati records with
