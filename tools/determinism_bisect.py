@@ -1,4 +1,4 @@
-"""Where do two runs of the same inputs part ways when the GPU is shared?  (run next to heavy co-runners: tools/job_r5x.sh)
+"""Where do two runs of the same inputs part ways when the GPU is shared?  (round 5: run next to heavy co-runners; the job script is in the git history, docs/HISTORY.md "Round 5 detail")
   1. DualMultWS alone (obca_dualmult_ws_batch), repeated: lam / mu / d bit for bit;
   2. the interior point cut off after K factorisation passes (OBCA_SLICE_PASSES=K, OBCA_SLICE_ONLY=1: every instance parks with its iterate in place), repeated, for K = 1, 2, 4, 8, 16:
      which of x, u, t, lambda, mu, sl / info differ, on how many instances."""
