@@ -176,7 +176,7 @@ OBCA_FN void direction_main(const Inst &I, Shared &sh, const AsmOut &A, double m
 #pragma unroll
                     for (int cc = 0; cc < OB_NC; cc++) a_ += r1[RS_PV + i * OB_NC + cc] * coef[cc];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) a_ += r1[RS_PX + i * 6 + j] * sn[j];
+                    for (int j = 0; j < 6; j++) a_ += r1[RS_PX + (j < i ? j * 6 + i : i * 6 + j)] * sn[j];      // (rows 0..3 of the symmetric P: the sweep stores entry (i, j) of the 4 x 4 block once, at (min, max))
                     dpi[i] = -a_;
                 }
             } else if (k < N) {   // terminal cost-to-go: P_N = H_N(+rho), p_N = (hb_N - rho e, Ht_N, e_i)   (rs[N] is not written)

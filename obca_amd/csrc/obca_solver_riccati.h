@@ -124,7 +124,7 @@ struct RicItem {      // offsets in doubles from the start of Shared
     int a_a, a_b, a_i, a_j, a_d, a_sg;
     int b_a, b_b, b_i, b_j, b_d, b_sg;      //          value live in the stage buffer (its parity offset is added at run time); phase B likewise
     // phase C: see riccati_stage (c_sg: bits 0..4 = x6, x7, q6, q7, base live in the stage buffer)
-    int c_x6, c_x7, c_q6, c_q7, c_base, c_sg, c_d1, c_d2, c_bd, c_rv, c_rv2, c_rk0, c_rk1;
+    int c_x6, c_x7, c_q6, c_q7, c_base, c_sg, c_d1, c_d2, c_bd, c_rv, c_rk0, c_rk1, c_dump;
 };
 #define RIC_BD 16       // per stage: Qhat_u (rows 6, 7) of the six right-hand sides, then q00, q10, q11, 1 / det
 // where phase C finds Qhat[r][c]: rows / columns 4, 5 are [H | hc] in the stage buffer
@@ -166,9 +166,9 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
     p.b_i = p.b_d = osB + m * 6 + b_; }
     // C: value = base + (X6 n0 + X7 n1) / det with (n0, n1) = adj(Quu) applied to rows 6, 7 of the item's column of Qhat
     //    items 0..20 P[i][cc], i <= cc (stored twice);  21..56 p[i][c] (stored transposed);  the items (0, c) carry the gains of their column
-    p.c_x6 = oZ; p.c_x7 = oZ; p.c_q6 = oZ; p.c_q7 = oZ; p.c_base = oZ; p.c_sg = 0; p.c_d1 = oD; p.c_d2 = oD; p.c_bd = -1; p.c_rv = RS_PAD; p.c_rv2 = RS_PAD;
+    p.c_x6 = oZ; p.c_x7 = oZ; p.c_q6 = oZ; p.c_q7 = oZ; p.c_base = oZ; p.c_sg = 0; p.c_d1 = oD; p.c_d2 = oD; p.c_bd = -1; p.c_rv = RS_PAD;
     p.c_rk0 = RS_PAD; p.c_rk1 = RS_PAD;
-    (void)oD4;
+    p.c_dump = oD4;
     if (lane < 57) {
         int r, i, cc;
         if (lane < 21) { r = 0; pair_of(lane, i, cc); } else { r = 1; i = (lane - 21) / 6; cc = (lane - 21) % 6; }
@@ -179,7 +179,7 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
         else {
             p.c_d1 = oPn + i * 6 + cc; if (i != cc) p.c_d2 = oPn + cc * 6 + i;
             if (i < 4) p.c_rv = RS_PX + i * 6 + cc;                              // rows 0..3 of P go to HBM (the costate recovery reads them)
-            if (cc < 4 && i != cc) p.c_rv2 = RS_PX + cc * 6 + i;
+            // (round 6: the mirror entry (cc, i) of rows 0..3 is no longer stored a second time -- the one reader, direction_main's costate, takes (min, max) -- one store per lane and stage less)
             if (i == 0) { p.c_rk0 = RS_K + cc; p.c_rk1 = RS_K + 6 + cc; }
         }
     }
@@ -211,7 +211,7 @@ static int g_emu_ric_fail_stage = -1;      // host trace (OBCA_EMU_TRACE): the s
 #endif
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicItem (&rp)[OBCA_NLT],
-                          double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0) {
+                          double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0, const gdbl *const as_base, gdbl *const rs_base) {
     double *L = (double *)&sh;
     const int sgo = (k & 1) * OB_STG;         // which of the two stage buffers holds stage k
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
@@ -243,7 +243,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     if (!ok && g_emu_ric_fail_stage < 0) g_emu_ric_fail_stage = k;
 #endif
     const double idet = rcp_nr(det);
-    gdbl *ro = I.rs + (size_t)k * OB_RS;
+    gdbl *ro = rs_base + (size_t)k * OB_RS;      // (as_base, rs_base: the instance's record buffers, read from LDS once per sweep -- not once per stage behind the stage's own LDS writes)
     double *bd = g_traj + (size_t)k * RIC_BD;      // per-stage border data: at the start of the dynamic block (the trajectory is dead during the sweep)
     PAR(lane) {   // phase C
         const RicItem &p = rp[LI(lane)];
@@ -254,11 +254,12 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         if (PIPE) {
             const int kp = k > 0 ? k - 1 : 0, kl = k - 1 - RIC_D > 0 ? k - 1 - RIC_D : 0;
             stage_unpack_store(sg0 + (kp & 1) * OB_STG, plan[LI(lane)], nv[LI(lane)][slot]);
-            stage_unpack_load(I.as + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
+            stage_unpack_load(as_base + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
         L[p.c_d1] = v; L[p.c_d2] = v;
-        if (p.c_bd >= 0) { bd[p.c_bd] = q6; bd[p.c_bd + 1] = q7; if (p.c_bd == 0) { bd[12] = q00; bd[13] = q10; bd[14] = q11; bd[15] = idet; } }
-        ro[p.c_rv] = v; ro[p.c_rv2] = v; ro[p.c_rk0] = (double)(n0 * idet); ro[p.c_rk1] = (double)(n1 * idet);
+        // border data of the stage, without a branch around the stores (every lane stores: the lanes without an entry to the write-only slot dump4)
+        { double *b1 = p.c_bd >= 0 ? bd + p.c_bd : L + p.c_dump, *b2 = p.c_bd == 0 ? bd + 12 : L + p.c_dump; b1[0] = q6; b1[1] = q7; b2[0] = q00; b2[1] = q10; b2[2] = q11; b2[3] = idet; }
+        ro[p.c_rv] = v; ro[p.c_rk0] = (double)(n0 * idet); ro[p.c_rk1] = (double)(n1 * idet);
     }
     LDS_SYNC();
     PROF_FINE(I, PF_RIC_P2);
@@ -268,7 +269,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
 template <int SOC = 0>      // SOC = 1: the terminal row enters with c_soc
 OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
-    const gdbl *z = I.z;
+    const gdbl *z = I.z; const gdbl *const as_base = I.as; gdbl *const rs_base = I.rs;
     double nv[OBCA_NLT][RIC_D];   // software pipeline, RIC_D stages deep; the slot of a stage is fixed by the unrolled loop below
     double *sg0 = ric_sg0(sh);       // the two stage buffers (dynamic LDS; in front of them the per-stage border data, behind them the operands)
     RicLds &rl = ric_lds(sh);
@@ -300,16 +301,16 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     // head: N mod RIC_D stages with synchronous gathers, so that the pipelined loop below runs whole groups of RIC_D stages
     int k = N - 1, ok = 1;
     for (; k >= 0 && (k + 1) % RIC_D != 0 && ok; k--) {
-        PAR(lane) { double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
+        PAR(lane) { double v; stage_unpack_load(as_base + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
         LDS_SYNC();
-        ok = riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0);
+        ok = riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0, as_base, rs_base);
     }
     if (ok && k >= 0) {
         PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
-            double v; stage_unpack_load(I.as + (size_t)k * OB_AS, plan[LI(lane)], v);
+            double v; stage_unpack_load(as_base + (size_t)k * OB_AS, plan[LI(lane)], v);
             stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v);
 #pragma unroll
-            for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(I.as + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
+            for (int j = 0; j < RIC_D; j++) { const int st = k - 1 - j > 0 ? k - 1 - j : 0; stage_unpack_load(as_base + (size_t)st * OB_AS, plan[LI(lane)], nv[LI(lane)][(j + 1) % RIC_D]); }
 #ifndef OBCA_EMU
 #pragma unroll
             for (int j = 0; j < RIC_D; j++) asm volatile("" : "+v"(nv[0][j]));
@@ -318,7 +319,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         LDS_SYNC();
         for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
-            for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0);
+            for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0, as_base, rs_base);
         }
     }
     if (!ok) { PROF(I, PF_RIC_BWD); return 0; }
