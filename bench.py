@@ -14,7 +14,8 @@ its slice, the K timed steps run device-resident (inputs in HBM before the timed
 DualMultWS kernel + interior-point kernel(s)), afterwards the full result tuples are gathered on rank 0 (one gather) and validated there.
 No collective touches the solve.  `value` counts CONVERGED and VALIDATED solves of all ranks per second.
 
-Steps are PIPELINED: every rank keeps --streams (default 4) device-resident copies of its batch, each on its own HIP stream, and step k runs
+Steps are PIPELINED: every rank keeps --streams (default 16) device-resident copies of its batch, each on its own HIP stream and -- GPU_MAX_HW_QUEUES=16, set below
+unless the caller set it: the runtime's default of 4 serialises streams that share a hardware queue -- its own hardware queue, and step k runs
 on copy k mod streams without a host synchronisation between steps (the K timed steps are bracketed by barrier + synchronize as the
 contract says): solve times are heavy-tailed (median 27 factorisation passes, slowest of a batch 100-300), so a step that waits for its
 last instance leaves the GPU idle for half of its duration.  After the timed region the SAME process measures `--sync-steps` synchronous
@@ -44,6 +45,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before anything initialises the HIP runtime: one hardware queue per stream of the pipelined steps (obca_amd/api.py)
 
 import numpy as np
 
@@ -400,7 +403,7 @@ def other_host_batch(cfg, seed=SEED):
     return rows, shared, round(time.perf_counter() - t0, 2), note
 
 
-def other_config_line(cfg, local, prepared, cpu, steps=10, streams=4):
+def other_config_line(cfg, local, prepared, cpu, steps=16, streams=8):
     """compact, driver-visible rate of another BASELINE config at its per-GPU batch size: `steps` pipelined steps with the reference's IPOPT configuration, every instance
     validated; the same with the library's throughput options beside it; warm starts planned before the timed steps (the planner is host code outside the path)"""
     C_ = CONFIGS[cfg]; N = C_["N"]; B = C_["per_gpu"]
@@ -495,7 +498,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the BASELINE batch size of the config / 8 GPUs; config 2: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one GPU for a functional test)")
-    ap.add_argument("--streams", type=int, default=4, help="device-resident copies of the batch, each on its own HIP stream (1 = synchronous steps)")
+    ap.add_argument("--streams", type=int, default=16, help="device-resident copies of the batch, each on its own HIP stream (1 = synchronous steps)")
     ap.add_argument("--sync-steps", type=int, default=6, help="synchronous steps measured after the timed region for the per-launch kernel time of the roofline")
     ap.add_argument("--warm-start", default="primitive", choices=["primitive", "hybrid"], help="config 2 only: line/arc/line primitives (default) or the reference's "
                     "pipeline main.jl:216-248 -- Hybrid A* path, velocity smoother, resampling (planned on the host cores before the timed region)")

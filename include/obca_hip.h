@@ -106,7 +106,7 @@ typedef struct obca_opts {
 int obca_create(obca_ctx **out, int device);
 /* A context over several GPUs of the node ("the context owns devices and streams"): devices = NULL or ndev <= 0 takes every
  * visible device.  The host-pointer entry points below cut their batch into chunks and hand them to the devices through a work queue
- * (solve times are heavy-tailed: a static slice per device would wait for the unluckiest one); every device runs OBCA_SLOTS (default 4)
+ * (solve times are heavy-tailed: a static slice per device would wait for the unluckiest one); every device runs OBCA_SLOTS (default 8, at most 16)
  * chunks at a time on streams of their own, so that the PCIe transfers and the host-side packing of one chunk overlap the solves of the
  * others.  Instances are independent: no collective touches the data path.  Results do not depend on the device count, the chunk size
  * (OBCA_CHUNK, default = the 1 024 instances resident on one GPU: four per CU) or the slot count: every instance is solved by one workgroup either way.

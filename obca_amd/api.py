@@ -64,6 +64,10 @@ def _load():
     if not os.path.exists(_LIBPATH):
         raise ObcaError(f"{_LIBPATH} is missing: build it with obca_amd.build_library() / __graft_entry__.build(); "
                         "there is no CPU fallback")
+    # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and serialises the launches that share one: with more than four
+    # batches in flight the extra streams bought nothing (rounds 3-6: 4 / 8 / 12 streams gave the same rate).  16 queues: +6 % on config 2, +8 % on config 3 with 16
+    # batches in flight (profiles/r06_hw_queues.txt).  Read by the runtime at its first call in the process; a value the caller has set stays.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = C.CDLL(_LIBPATH)
     lib.obca_last_error.restype = C.c_char_p
     lib.obca_last_error.argtypes = [C.c_void_p]

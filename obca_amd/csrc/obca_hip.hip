@@ -88,9 +88,19 @@ __global__ __launch_bounds__(OB_NT, OBCA_IPM_WAVES_PER_EU) void obca_parking_ipm
     if (threadIdx.x < 16) g_sh.prof[threadIdx.x] = mode ? b.prof[(size_t)inst * 16 + threadIdx.x] : 0.0;   // counters add up over the slices
 #endif
     __syncthreads();
+#if defined(OBCA_PROFILE) && !defined(OBCA_PROFILE_FINE)      // slots 11, 12 (the per-stage counters of the FINE build): when the workgroup started and ended on the constant 100 MHz clock (tools/load_profile.py: residency, shader clock rate)
+    if (threadIdx.x == 0 && mode == 0) g_sh.prof[11] = (double)wall_clock64();
+#endif
     solve_instance(N, o, b.info + (size_t)inst * 8, (gdbl *)(b.slice + (size_t)inst * SL_SIZE), mode, budget, max_soc, recalc_y, lsq_init, restoration);
 #ifdef OBCA_PROFILE
     __syncthreads();
+#ifndef OBCA_PROFILE_FINE
+    if (threadIdx.x == 0 && mode == 0) {      // slot 12: resident time + (which SIMD of which CU of which XCD: XCC_ID << 12 | HW_ID[15:4]) / 65536 in the fraction
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_sh.prof[12] = ((double)wall_clock64() - g_sh.prof[11]) + (double)(((xcc & 15u) << 12) | ((hw >> 4) & 0xfffu)) / 65536.0;
+    }
+    __syncthreads();
+#endif
     if (threadIdx.x < 16) b.prof[(size_t)inst * 16 + threadIdx.x] = g_sh.prof[threadIdx.x];
 #endif
 }
@@ -361,8 +371,8 @@ int obca_create_multi(obca_ctx **out, const int *devices, int ndev) {
     std::vector<int> devs;
     if (!devices || ndev <= 0) { for (int i = 0; i < n; i++) devs.push_back(i); }
     else devs.assign(devices, devices + ndev);
-    int nslot = 4;                                       // worker lanes per device (OBCA_SLOTS)
-    if (const char *ev = getenv("OBCA_SLOTS")) { nslot = atoi(ev); if (nslot < 1) nslot = 1; if (nslot > 8) nslot = 8; }
+    int nslot = 8;                                       // worker lanes per device (OBCA_SLOTS; 4 until round 6: with 16 hardware queues 8 lanes give +2.6 % on the host-pointer call)
+    if (const char *ev = getenv("OBCA_SLOTS")) { nslot = atoi(ev); if (nslot < 1) nslot = 1; if (nslot > 16) nslot = 16; }
     // every device is validated before anything is created, so that a bad index cannot leave a half-built context (or a leaked stream) behind
     std::vector<hipDeviceProp_t> props(devs.size());
     for (size_t di = 0; di < devs.size(); di++) {

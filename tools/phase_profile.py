@@ -16,7 +16,7 @@ out = b.download(); pc = b.phase_cycles()
 names = "init asm_obs asm_stage ric_bwd border_cl fwd_seq bs_stage bs_obs trial apply other ric_p1 ric_p2".split()
 passes = out['info'][:, 1] + out['info'][:, 6]
 print('kernel ms', b.kernel_ms(), 'B', B, 'mean iters', out['iters'].mean(), 'mean passes', passes.mean(), 'max passes', passes.max())
-tot = pc[:, :len(names)].sum(1)
+tot = pc[:, :11].sum(1)      # (slots 11, 12: per-stage counters of the FINE build, else the residency stamps tools/load_profile.py reads)
 slow = int(np.argmax(tot)); print('slowest instance %d: iterations %d, inertia rungs %d, total cycles %.0f; per phase:' % (slow, out['info'][slow, 1], out['info'][slow, 6], tot[slow]), {n: int(pc[slow, i]) for i, n in enumerate(names)}, 'soc/rebuild/recalc', pc[slow, 13:16].tolist())
 print('cycles per pass: mean %.0f  (slowest instance %.0f total cycles = %.1f ms @2.4GHz)' % ((tot / passes).mean(), tot.max(), tot.max() / 2.4e6))
 print('options:', 'reference IPOPT configuration' if opts is not None else 'throughput defaults', '| per solve: second-order corrections tried %.2f, Newton systems rebuilt %.2f, multiplier re-estimates %.2f' % (pc[:, 13].mean(), np.floor(pc[:, 14]).mean(), pc[:, 15].mean()))
