@@ -561,7 +561,10 @@ def main():
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            local = local % max(1, torch.cuda.device_count())          # functional test: ranks may share a device
+            ndev_ = max(1, torch.cuda.device_count())
+            local = local % ndev_          # functional test: ranks may share a device
+            if world > ndev_:              # ... and then share its hardware queues: 16 batches in flight per DEVICE, not per rank (32 queues on one GPU measured worse than 4)
+                a.streams = max(1, a.streams // ((world + ndev_ - 1) // ndev_))
             torch.cuda.set_device(local)
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     rows, shared = scatter_job(rows, shared, B_total, rank, world, dist, a.backend)

@@ -14,6 +14,11 @@
 module OBCAHip
 
 const LIB = get(ENV, "OBCA_HIP_LIBRARY", joinpath(@__DIR__, "..", "obca_amd", "csrc", "libobca_hip.so"))
+# One hardware queue per stream: the HIP runtime's default of four serialises streams that share one (the worker lanes of the host-pointer entry points, several contexts
+# in flight).  Read by the runtime at its first call in the process; a value the caller has set stays.  (INTEGRATION.md, profiles/r06_hw_queues.txt)
+function __init__()
+    haskey(ENV, "GPU_MAX_HW_QUEUES") || (ENV["GPU_MAX_HW_QUEUES"] = "16")
+end
 
 mutable struct Context
     h::Ptr{Cvoid}
