@@ -184,18 +184,20 @@ OBCA_FN void ric_item(const Shared &sh, int lane, RicItem &p) {
         }
     }
 }
-// four contiguous, 16-byte aligned doubles from LDS: two ds_read_b128
-OBCA_FN void ld4(const double *q, double (&v)[4]) {
+// One phase-A / phase-B item: i1 + i2 + a . b with a, b four contiguous, 16-byte aligned doubles each (two ds_read_b128), i1, i2 one double each.  All six reads are issued
+// and have arrived before the first fma: the compiler otherwise issues them in two groups with the first two fma between them (ISA of round 6: reads, wait, fma, fma, reads,
+// wait, ...) and a phase pays two LDS round trips instead of one.  The `asm` is a scheduling fence on the six loaded values, no code.
+OBCA_FN double ric_item_value(const double *pa, const double *pb, const double *pi, const double *pj) {
 #ifdef OBCA_EMU
-    for (int i = 0; i < 4; i++) v[i] = q[i];
+    return fma(pa[1], pb[1], fma(pa[0], pb[0], *pi)) + fma(pa[3], pb[3], fma(pa[2], pb[2], *pj));
 #else
-    const double2 *q2 = (const double2 *)__builtin_assume_aligned(q, 16);
-    const double2 a = q2[0], b = q2[1];
-    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    typedef double v2d __attribute__((ext_vector_type(2)));      // (a native vector: one 128-bit register operand of the fence)
+    const v2d *a2 = (const v2d *)__builtin_assume_aligned(pa, 16), *b2 = (const v2d *)__builtin_assume_aligned(pb, 16);
+    v2d a0 = a2[0], a1 = a2[1], b0 = b2[0], b1 = b2[1]; double i1 = *pi, i2 = *pj;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(i1), "+v"(i2));
+    return fma(a0.y, b0.y, fma(a0.x, b0.x, i1)) + fma(a1.y, b1.y, fma(a1.x, b1.x, i2));
 #endif
 }
-// i1 + i2 + a . b over four terms, three dependent operations deep (two chains of two fma, one add)
-OBCA_FN double dot4_two(double i1, double i2, const double (&a)[4], const double (&b)[4]) { return fma(a[1], b[1], fma(a[0], b[0], i1)) + fma(a[3], b[3], fma(a[2], b[2], i2)); }
 // six contiguous, 16-byte aligned doubles from LDS: three ds_read_b128
 OBCA_FN void ld6(const double *q, double (&v)[6]) {
 #ifdef OBCA_EMU
@@ -218,15 +220,13 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     // knows; reads that follow a write would wait for their own round trip).
     PAR(lane) {   // phase A
         const RicItem &p = rp[LI(lane)];
-        double A[4], B[4]; ld4(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), A); ld4(L + p.a_b + ((p.a_sg & 2) ? sgo : 0), B);
-        L[p.a_d] = dot4_two(L[p.a_i + ((p.a_sg & 4) ? sgo : 0)], L[p.a_j], A, B);
+        L[p.a_d] = ric_item_value(L + p.a_a + ((p.a_sg & 1) ? sgo : 0), L + p.a_b + ((p.a_sg & 2) ? sgo : 0), L + p.a_i + ((p.a_sg & 4) ? sgo : 0), L + p.a_j);
     }
     LDS_SYNC();
     double vB[OBCA_NLT];
     PAR(lane) {   // phase B
         const RicItem &p = rp[LI(lane)];
-        double A[4], B[4]; ld4(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), A); ld4(L + p.b_b, B);
-        vB[LI(lane)] = dot4_two(L[p.b_i + ((p.b_sg & 4) ? sgo : 0)], L[p.b_j], A, B);
+        vB[LI(lane)] = ric_item_value(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), L + p.b_b, L + p.b_i + ((p.b_sg & 4) ? sgo : 0), L + p.b_j);
         L[p.b_d] = vB[LI(lane)];
     }
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse
