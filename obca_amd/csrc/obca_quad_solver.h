@@ -581,9 +581,16 @@ OBCA_FN int q_riccati_stage_mfma(QShared &sh, const int k, const QMPlan (&plan)[
     LDS_SYNC();
     PAR64(lane) {
         const int L_ = LI(lane), g = lane >> 4, j = lane & 15;
+        // the four transposed entries are read together (the compiler otherwise reads two, waits, works, reads two, waits: a second LDS round trip per stage)
+        double t_[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) t_[r] = tr[j * 17 + (g + 4 * r)];
+#ifndef OBCA_EMU
+        asm volatile("" : "+v"(t_[0]), "+v"(t_[1]), "+v"(t_[2]), "+v"(t_[3]));
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const double v = 0.5 * (Sn[r][L_] + tr[j * 17 + (g + 4 * r)]);
+            const double v = 0.5 * (Sn[r][L_] + t_[r]);
             PD[r][L_] = v; pnD[r][L_] = j < QC ? Q1[r][L_] : 0.0;
             if (r < 3) { ro[QRR_PX + (g + 4 * r) * QS + j] = v; ro[j < QC ? QRR_PV + (g + 4 * r) * QC + j : QRR_PAD] = pnD[r][L_]; }      // rows 0..11 of P / p
         }

@@ -350,7 +350,19 @@ OBCA_PHASE int ph_ref_constraints(int sd) { Shared &sh = g_sh; return sh.vmc == 
 // ~100-clock read where the value is needed and nothing at a call.  (Measured and not
 // kept: the state in registers between the calls and copied to / from LDS around each call -- the register allocator then spills MORE, 277 scratch stores / 571
 // loads in the kernel body against 96 / 279.)
+// pow of the driver as a call: inlined, the ~40 polynomial coefficients of the library routine were hoisted out of the iteration loop as loop invariants, did not survive the
+// phase calls in registers, and were kept in SCRATCH -- 18 spill stores before the loop and a scratch load per coefficient at every evaluation (ISA of round 6).
+OBCA_PHASE double ob_pow(double x, double y) { return pow(x, y); }
+// PH: after a phase call nothing loaded before it is assumed still valid (a compiler-level memory clobber, no code): the optimiser knows which LDS words a phase
+// writes, hoisted the loads of the option record and of other loop-invariant words out of the iteration loop -- and, every phase using the whole register file, had
+// to keep them in SCRATCH: a spill store at the hoist, a scratch load (a memory round trip) at every use.  Re-reading LDS where the value is needed is the cheaper miss.
+#ifdef OBCA_EMU
 #define PH(call) call
+#define OB_NOHOIST() ((void)0)
+#else
+#define PH(call) do { call; asm volatile("" ::: "memory"); } while (0)
+#define OB_NOHOIST() asm volatile("" ::: "memory")
+#endif
 #ifdef OBCA_PROFILE_DRV      // (with -DOBCA_PROFILE: the driver's clocks split three ways -- slots ric_p1 / ric_p2 of the phase profile: line-search set-up, acceptance; the rest stays in `other`)
 #define PROF_DRV(I, id) PROF(I, id)
 #else
@@ -424,8 +436,10 @@ OBCA_PHASE int ph_soc_try(double tht_first) {
     }
     return 0;
 }
-OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
-    Shared &sh = g_sh; Drv &D = sh.drv;
+// (a call, not inlined into solve_instance's two sites -- first attempt and retry --: the driver's code is in the kernel once, 30 KB less on the instruction cache two CUs share;
+//  its operands are named through g_sh here, so that they stay LDS accesses)
+OBCA_PHASE void ipm_attempt() {
+    Shared &sh = g_sh; Drv &D = sh.drv; const Opts &o = sh.o; Result &R = sh.sol.R; Slice &sl = sh.sol.sl;
     gdbl *const st = sl.st;
     const AsmOut &A = sh.A;
     sh.soc.nsoc = 0; sh.soc.nsoc_acc = 0; sh.soc.nrecalc = 0; sh.soc.nrebuild = 0;
@@ -449,6 +463,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
     D.dc_mu = -1.0; D.dc_val = 0;
     // D.have_asm = 1: sh.A already holds the assembly of the current iterate, left behind by the accepted trial of the previous iteration (ph_fused)
     for (;;) {
+        OB_NOHOIST();
         // out of budget: park the loop state, a later launch continues
         if (sl.budget > 0 && sl.used + (D.it + D.nreg - D.p_start) + sh.soc.nsoc + sh.soc.nrecalc >= sl.budget) {
             PAR(lane) {
@@ -458,7 +473,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
             }
             D.status = ST_SUSPENDED; break;
         }
-        if (D.mu != D.dc_mu) { D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
+        if (D.mu != D.dc_mu) { D.dc_val = o.dc_bar * ob_pow(D.mu, o.kappa_c); D.dc_mu = D.mu; }   // a pow is a ~3k-clock dependent chain: keep it while mu stays
         PROF(sh.inst, PF_OTHER); if (!D.have_asm) PH(ph_assemble(D.mu, 0.0, D.dc_val, 0));
         D.have_asm = 0;
         if (D.it == 0 || sh.soc.reset_th) { D.th_min = 1e-4 * fmax(1.0, A.th1); D.th_max = 1e4 * fmax(1.0, A.th1); sh.soc.reset_th = 0; }
@@ -481,9 +496,9 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
         for (;;) {
             const double Emu = fmax(D.dinf / D.sd, fmax(D.pinf, D.cm / D.sc));
             if (Emu <= o.kappa_eps * D.mu && D.mu > o.tol / 10) {
-                D.mu = fmax(o.tol / 10, fmin(o.kappa_mu * D.mu, pow(D.mu, o.theta_mu)));
+                D.mu = fmax(o.tol / 10, fmin(o.kappa_mu * D.mu, ob_pow(D.mu, o.theta_mu)));
                 D.tau = fmax(o.tau_min, 1 - D.mu); D.nf = 0; D.mu_changed = 1;
-                D.dc_val = o.dc_bar * pow(D.mu, o.kappa_c); D.dc_mu = D.mu;
+                D.dc_val = o.dc_bar * ob_pow(D.mu, o.kappa_c); D.dc_mu = D.mu;
                 // complementarity error w.r.t. the new mu: from the extreme products of the assembly at hand (round 2 re-assembled for it)
                 D.cm = cinf_mu(A, D.mu);
             } else break;
@@ -519,7 +534,7 @@ OBCA_FN void ipm_attempt(const Opts &o, Result &R, Slice &sl) {
                 // once per iteration (also the switching condition of every trial).  (Round 6 measured the two pows side by side in two lanes of one call: SLOWER -- the driver's
                 // clocks per pass 23.7 k -> 29.9 k, `value` -2.5 %: with wave-uniform arguments the library pow takes scalar branches around its special cases, with per-lane
                 // arguments it executes them all.  profiles/r06_ab_pow_in_two_lanes.txt)
-                D.pw_th = pow(th, o.s_theta); D.pw_gd = pow(-gd, o.s_phi);
+                D.pw_th = ob_pow(th, o.s_theta); D.pw_gd = ob_pow(-gd, o.s_phi);
                 if (th <= D.th_min) amin = fmin(amin, o.delta * D.pw_th / D.pw_gd);
             } else amin = o.gamma_theta;
             D.amin = amin * o.gamma_alpha;
@@ -616,7 +631,7 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
     // (this function's own state lives in LDS as well -- Shared::sol -- for the reason given at ipm_attempt)
-    Sol &X = sh.sol; const Opts &o = sh.o;
+    Sol &X = sh.sol;
     X.home = sh.inst.z;
     X.sl.st = st; X.sl.resume = mode == 1; X.sl.budget = budget; X.sl.used = 0;
     X.att = 0; X.it_prev = 0; X.nreg_prev = 0;
@@ -624,7 +639,7 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
     X.R.status = ST_ERROR; X.R.iters = 0; X.R.nreg = 0; X.R.obj = X.R.pinf = X.R.dinf = X.R.mu = 0;
     X.ef = 0; X.iters = 0; X.nreg = 0; X.retry = X.att;
     if (X.att == 0) {
-        ipm_attempt(o, X.R, X.sl);
+        ipm_attempt();
         X.iters = X.R.iters; X.nreg = X.R.nreg;
         if (X.R.status != ST_SUSPENDED) {
             X.ef = (X.R.status == ST_OPTIMAL); X.retry = !X.ef;
@@ -633,7 +648,7 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
         }
     }
     if (X.retry && X.R.status != ST_SUSPENDED) {
-        ipm_attempt(o, X.R, X.sl);
+        ipm_attempt();
         X.iters = X.it_prev + X.R.iters; X.nreg = X.nreg_prev + X.R.nreg;
         if (X.R.status == ST_OPTIMAL) X.ef = 1;
         else if (X.R.status != ST_SUSPENDED) { const int feas = ph_ref_constraints(sh.c.dist ? 0 : 1); X.ef = sh.c.dist ? !feas : feas; }
