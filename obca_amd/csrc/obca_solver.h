@@ -106,6 +106,12 @@ namespace obca {
 
 #define OB_NC 6      // Riccati right-hand sides: main, t, nu1..nu4
 #define OB_NMAX 128  // longest horizon: the forward sweep gives ONE lane to every pair of stages (direction_main: 64 pairs per wavefront); LDS would allow more (5.7 KB + (27 N + 54) x 8 bytes)
+#define OB_RIT_FIELDS 25
+#ifdef OBCA_EMU
+typedef int ob_rit_t;        // (host emulation: static and dynamic LDS are two host arrays, their distance does not fit 16 bits)
+#else
+typedef short ob_rit_t;      // offsets in doubles within the workgroup's LDS (< 8 192)
+#endif
 #define OB_AS 60     // doubles per assembled stage record (only the entries that can be non-zero are kept: as_h / as_df below)
 #define OB_RS 74     // doubles per Riccati stage record
 #define OB_OC 12     // doubles per condensed obstacle record
@@ -248,6 +254,9 @@ struct alignas(16) Shared {
     Drv drv; Sol sol; Opts o;      // (the options too: as kernel arguments they would sit in ~60 SGPRs that are spilled around every phase call)
     // upl, ucn: which positions of the unpacked stage data a lane serves (init_unpack_table)
     int roff[OB_NOBMAX + 1], vOb[OB_NOBMAX], ric_ok; int upl[OB_NT], ucn[3][OB_NT];
+    // the Riccati sweep's per-lane operand table (RicItem, obca_solver_riccati.h): the same for every sweep of a solve, built once by solve_instance (round 6: it was rebuilt
+    // by every sweep, ~1 100 instructions of index arithmetic per lane); [field][lane], so that a field is one conflict-free read
+    ob_rit_t rit[OB_RIT_FIELDS][OB_NT];
     Consts c; Lay l;
     double prof[16];           // diagnostic per-phase cycle counters (-DOBCA_PROFILE)
     // vmc: row class of the instance's widest obstacle (0: <= 2, 1: <= OB_VMID, 2: <= OB_VMAX)   // phase inputs/outputs (wave-uniform, exchanged through LDS)

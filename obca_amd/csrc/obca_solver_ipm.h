@@ -628,6 +628,8 @@ OBCA_FN void solve_instance(int N, const Opts &o_arg, double *info, gdbl *st = n
     }
     init_unpack_table(sh);
     SYNC();
+    init_ric_table(sh);
+    SYNC();
     // exit flag: ParkingSignedDist.jl:256-290 (Optimal -> 1; else one retry from the last iterate; if that fails too the reference's own
     // acceptance test decides) and ParkingDist.jl:245-289 (the test runs before the retry; after a failed retry it is inverted)
     // (this function's own state lives in LDS as well -- Shared::sol -- for the reason given at ipm_attempt)

@@ -266,6 +266,24 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
     return ok;
 }
 
+// the table in LDS (Shared::rit): written once per solve, read back by every sweep
+#define RIC_ITEM_FIELDS(X) X(a_a) X(a_b) X(a_i) X(a_j) X(a_d) X(a_sg) X(b_a) X(b_b) X(b_i) X(b_j) X(b_d) X(b_sg) \
+                           X(c_x6) X(c_x7) X(c_q6) X(c_q7) X(c_base) X(c_sg) X(c_d1) X(c_d2) X(c_bd) X(c_rv) X(c_rk0) X(c_rk1) X(c_dump)
+OBCA_FN void init_ric_table(Shared &sh) {      // after Consts::N is set (the stage buffers sit behind N x 16 doubles of border data)
+    PAR(lane) {
+        RicItem p; ric_item(sh, lane, p); int f = 0;
+#define X(n) sh.rit[f++][lane] = (ob_rit_t)p.n;
+        RIC_ITEM_FIELDS(X)
+#undef X
+        static_assert(sizeof(RicItem) == OB_RIT_FIELDS * sizeof(int), "RIC_ITEM_FIELDS must list every field of RicItem");
+    }
+}
+OBCA_FN void ric_item_cached(const Shared &sh, int lane, RicItem &p) {
+    int f = 0;
+#define X(n) p.n = sh.rit[f++][lane];
+    RIC_ITEM_FIELDS(X)
+#undef X
+}
 template <int SOC = 0>      // SOC = 1: the terminal row enters with c_soc
 OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     const Consts &c = sh.c; const Lay &l = sh.l; const int N = UNIFORM(c.N);
@@ -275,7 +293,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     RicLds &rl = ric_lds(sh);
     UnpackPlan plan[OBCA_NLT]; RicItem rp[OBCA_NLT];
     PAR(lane) {   // terminal cost-to-go
-        stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_item(sh, lane, rp[LI(lane)]);
+        stage_unpack_plan(sh, lane, plan[LI(lane)]); ric_item_cached(sh, lane, rp[LI(lane)]);
         stage_unpack_constants(sh, sg0, lane);
         if (lane == 0) { rl.zero = 0.0; rl.dump = 0.0; }
         if (lane < 6) rl.zero6[lane] = 0.0;

@@ -51,6 +51,7 @@ static void setup(int N, const double *prob, Scratch &s) {
     int vmx = 0; for (int j = 0; j < c.nOb; j++) if (sh.vOb[j] > vmx) vmx = sh.vOb[j];
     sh.vm2 = vmx <= 2; sh.vmc = vmx <= 2 ? 0 : (vmx <= OB_VMID ? 1 : 2);
     init_unpack_table(sh);
+    init_ric_table(sh);
 }
 
 extern "C" {
