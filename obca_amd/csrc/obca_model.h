@@ -22,8 +22,8 @@
 namespace obca {
 
 // Reciprocal for the latency-critical pivots: v_rcp_f64 (good to 2^-24.4) refined as r (1 + e + e^2) with e = 1 - d r: FOUR dependent instructions (two Newton
-// steps are five, the IEEE division sequence with its scaling and fix-up eleven), and a dependent fp64 instruction costs a lone wavefront ~47 clocks
-// (tools/micro/lds_barrier_latency.hip: (724 - 440) / 6 clocks per fma of a chain).  Measured on MI355X over 80 binades: 1.00 ulp, the same as two Newton steps
+// steps are five, the IEEE division sequence with its scaling and fix-up eleven), and every link of such a chain is exposed on a wavefront that is alone on its SIMD
+// (a dependent v_fma_f64 8 clocks, v_rcp_f64 ~20: tools/micro/fp64_dependent_latency.hip, round 6; round 3 had read 47 per link off tools/micro/lds_barrier_latency.hip).  Measured on MI355X over 80 binades: 1.00 ulp, the same as two Newton steps
 // (tools/micro/rcp_accuracy.hip, profiles/r03_rcp_accuracy.txt).  For the normal-range, strictly positive pivots it is used on; a zero or NaN pivot gives NaN,
 // and those are rejected by the positivity tests next to every use.  The host emulation divides.
 // RS = 0: the two-Newton-step form (five dependent operations, the same 1.00 ulp).  The

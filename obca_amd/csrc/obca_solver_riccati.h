@@ -96,8 +96,8 @@ OBCA_FN void ldv(const double *q, double (&v)[NV]) {
 // phase, wave-local LDS ordering in between (no cross-wavefront synchronisation: the
 // instance IS one wavefront).  Every lane runs the SAME straight-line code in every phase:
 // what differs between the item kinds of a phase is only where the operands live, and that is a per-lane table of LDS offsets built once per sweep (RicItem).
-// A phase costs what its one wavefront ISSUES (a 16-byte LDS read ~16 clocks, a dependent
-// fp64 operation ~47: profiles/r03_ab_reciprocal_and_early_quu.txt), so the items are
+// A phase costs what its one wavefront ISSUES (a 16-byte LDS read ~16 clocks, an fp64 operation 4, 8 if it depends on the one before: tools/micro/fp64_dependent_latency.hip)
+// plus one LDS round trip, so the items are
 // cut down to the products that are not structure (rounds 1-3 computed all 96 / 124 / 93 entries, two per lane):
 //   * FA = [F | off] has the unit columns 0, 1 (X, Y), the zero columns 4, 5 (the input
 //     copy w: x+ does not depend on it) and 10..13 (the nu right-hand sides): the columns

@@ -4,7 +4,7 @@
 C=$PWD/obca_amd/csrc; NEW=${1:-libobca_hip.so}; OLD=${2:-variants/libobca_hip_prev.so}
 LEAN="--no-cpu-baseline --no-pmc --no-host-rate --no-distinct --no-ipopt-leg --no-other-configs"
 for r in 1 2 3; do for V in $NEW $OLD; do OBCA_HIP_LIBRARY=$C/$V timeout 300 python bench.py --steps 60 --warmup 12 $LEAN 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V', 'value', d['value'], 'lone launch ms', d['roofline']['kernel_ms'])"; done; done
-if [ -n "$3" ]; then for V in $3 $4; do echo "== $V"; OBCA_HIP_LIBRARY=$C/$V timeout 200 python tools/phase_profile.py 1024 ipopt 2>&1 | grep -E "kernel ms|cycles per pass|^other|^ric_bwd|^border_cl|^fwd_seq|^bs_stage"; done; fi
+if [ -n "$3" ]; then for V in $3 $4; do echo "== $V"; OBCA_HIP_LIBRARY=$C/$V timeout 200 python tools/phase_profile.py 1024 ipopt 2>&1 | grep -E "kernel ms|cycles per pass|^other|^ric_bwd|^border_cl|^fwd_seq|^bs_|^trial|^apply|^asm"; done; fi
 python - "$C/$NEW" "$C/$OLD" <<'PY'
 import os, sys, subprocess, numpy as np
 code = r'''

@@ -15,6 +15,7 @@
 #   phase        per-phase clocks of the parking kernel, -DOBCA_PROFILE build, B = 64 and 1024, both option sets ; phase5 / quadphase likewise for config 5 / the quadcopter kernel
 #   census       tools/options_census.py 2 3 5
 #   sched        scheduling experiments: --streams 4 / 6 / 8 / 12; OBCA_SLICE_ALWAYS=1 with slices of 4 / 8 passes
+#   micro        the micro-benchmarks behind DESIGN.md section 5 (fp64 dependent latency, the sweep's phase pattern with 1-3 chains, the parking stage on MFMA tiles)
 #   queues       GPU_MAX_HW_QUEUES x --streams on the pipelined line ; slots: residency of the SIMDs (tools/load_profile.py, slot_timeline.py), phase clocks against residency ; icache: tools/pmc_icache.sh
 #   gloo2        bench.py --gpus 2 --backend gloo (two ranks on the one GPU)
 TAG=$1; shift
@@ -74,6 +75,7 @@ PY
       for QS in "4 4 48" "16 16 96"; do set -- $QS; GPU_MAX_HW_QUEUES=$1 OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/load_profile.py $2 $3 > $O/load_profile_q$1_s$2.txt 2>&1; head -22 $O/load_profile_q$1_s$2.txt; done
       for K in 4 8 16; do GPU_MAX_HW_QUEUES=16 OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/slot_timeline.py $K > $O/slot_timeline_$K.txt 2>&1; head -8 $O/slot_timeline_$K.txt; done
       for B in 64 256 512 1024; do echo "== $B instances (of 1 024 SIMDs) in one launch"; OBCA_HIP_LIBRARY=$C/libobca_hip_prof.so timeout 200 python tools/phase_profile.py $B ipopt 2>&1 | grep -v "slowest instance\|options:\|ric_p"; done > $O/phase_clocks_against_residency.txt 2>&1; cat $O/phase_clocks_against_residency.txt ;;
+    micro) for M in fp64_dependent_latency riccati_two_chains parking_stage_mfma; do (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o /tmp/$M $M.hip 2>/dev/null) && timeout 120 /tmp/$M > $O/micro_$M.txt 2>&1; head -30 $O/micro_$M.txt; done ;;
     icache) timeout 900 bash tools/pmc_icache.sh 1024 > $O/pmc_icache_B1024.txt 2>&1; timeout 900 bash tools/pmc_icache.sh 256 > $O/pmc_icache_B256.txt 2>&1; tail -26 $O/pmc_icache_B1024.txt; tail -26 $O/pmc_icache_B256.txt ;;
     sq) timeout 600 bash tools/pmc_sq.sh 1024 > $O/pmc_sq.txt 2>&1; tail -24 $O/pmc_sq.txt ;;
     mfma) cd /tmp; timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_quad_mfma -o mfma -- python $R/bench.py --config 4 --pmc-child > /dev/null 2> $O/pmc_quad_mfma.err; cd $R
