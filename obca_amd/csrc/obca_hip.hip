@@ -496,7 +496,7 @@ static int batch_upload_range(obca_batch *bt, const ParkIn &in, int lo, int n) {
         ALLOC(d.as, B * d.s_as); ALLOC(d.rs, B * d.s_rs);      // (d.oc stays null: the condensed obstacle sums of the parking kernel live in LDS since round 4)
         ALLOC(d.info, B * 8); ALLOC(d.dws, B * N1 * bt->nObMax); ALLOC(d.prof, B * 16);
         ALLOC(d.slice, B * SL_SIZE);
-        ALLOC(d.csoc, B * d.s_csoc);      // (rows + direction of a second-order correction: with the other buffers since round 6 -- allocated by the first solve that asked for corrections, it put a hipMalloc into that solve)
+        ALLOC(d.csoc, B * d.s_csoc);      // (rows + direction of a second-order correction: with the other buffers since round 6 -- allocated by the first solve that asked for corrections, it put a 60 MB hipMalloc into that solve: profiles/r06_first_solve_costs.txt)
         bt->dcap_stage = B * (size_t)lmax.nprimal;                       // nprimal >= the output prefix
         ALLOC(bt->stage, bt->dcap_stage);
         if (dev_alloc((void **)&d.order, (B + 1) * sizeof(int), bt->stream) != hipSuccess) { bt->err = "hipMalloc(order) failed"; free_dev(bt); return -2; }
@@ -795,15 +795,6 @@ int obca_batch_upload(obca_batch *bt, const double *Ts, double L, const double e
     ParkIn in = {Ts, L, ego, XYb, fixTime, x0, xF, nOb, vOb, A, b, rx, ry, ryaw, xWS, uWS, lWS, nWS, {}, {}};
     if (int rc = park_prefix(bt->err, bt->cap, nOb, vOb, in)) { bt->ctx->err = "obca_batch_upload: " + bt->err; return rc; }
     int rc = batch_upload_range(bt, in, 0, bt->cap);
-    // The first launch of the interior-point kernel on a stream makes the runtime set up the scratch memory of the stream's hardware queue (milliseconds, once per queue): an
-    // empty launch (no instance: every workgroup returns at its first line) does it here, where the caller waits anyway, instead of inside the batch's first solve.  (On
-    // average nothing -- 201-203 k against 204-205 k solves/s over 20 steps -- but one run in ten of the driver's 20-step line, which warms 5 of its 16 batches, lost a third
-    // of its rate to these first-solve costs: profiles/r06_first_solve_costs.txt.)
-    if (!rc) {
-        Opts ko; obca_opts od; obca_default_opts(&od); memcpy(&ko, &od, sizeof ko);
-        hipLaunchKernelGGL(obca_parking_ipm_kernel, dim3(1), dim3(OB_NT), OB_DYN_LDS_DOUBLES(bt->N) * sizeof(double), bt->stream, 0, bt->N, bt->d, ko, 0, 0, 0, 0, 0, 0);
-        if (hipGetLastError() != hipSuccess) { bt->err = "obca_batch_upload: priming launch failed"; rc = -2; }
-    }
     if (!rc && hipStreamSynchronize(bt->stream) != hipSuccess) { bt->err = "obca_batch_upload: stream sync failed"; rc = -2; }
     return fin(bt, rc);
 }
@@ -1012,11 +1003,6 @@ int obca_quad_batch_upload(obca_quad_batch *bt, const double *Ts, double R, cons
     if (!Ts || !x0 || !xF || !ob || !xWS || !timeWS) { bt->ctx->err = "obca_quad_batch_upload: NULL argument"; return -1; }
     QuadIn in = {Ts, R, x0, xF, ob, xWS, timeWS, dual_ws, dist};
     int rc = quad_upload_range(bt, in, 0, bt->cap);
-    if (!rc) {      // an empty launch sets up the scratch memory of the stream's hardware queue here instead of in the first solve (see obca_batch_upload)
-        Opts ko; obca_opts od; obca_quadcopter_default_opts(&od); memcpy(&ko, &od, sizeof ko);
-        hipLaunchKernelGGL(obca_quad_ipm_kernel, dim3(1), dim3(QNT), (size_t)(bt->N + 2) * (QS + QU) * sizeof(double), bt->stream, 0, bt->N, bt->d, ko, 0, 0, 0);
-        if (hipGetLastError() != hipSuccess) { bt->err = "obca_quad_batch_upload: priming launch failed"; rc = -2; }
-    }
     if (!rc && hipStreamSynchronize(bt->stream) != hipSuccess) { bt->err = "obca_quad_batch_upload: stream sync failed"; rc = -2; }
     return qfin(bt, rc);
 }
