@@ -213,7 +213,7 @@ static int g_emu_ric_fail_stage = -1;      // host trace (OBCA_EMU_TRACE): the s
 #endif
 template <int PIPE>
 OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPlan (&plan)[OBCA_NLT], const RicItem (&rp)[OBCA_NLT],
-                          double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0, const gdbl *const as_base, gdbl *const rs_base) {
+                          double (&nv)[OBCA_NLT][RIC_D], const int slot, double *sg0, const gdbl *const as_base, gdbl *const rs_base, const int (&bdo)[OBCA_NLT][6]) {
     double *L = (double *)&sh;
     const int sgo = (k & 1) * OB_STG;         // which of the two stage buffers holds stage k
     // In every phase all LDS reads are issued before the first LDS write of the phase (a write may alias a later read as far as the compiler
@@ -228,6 +228,7 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
         const RicItem &p = rp[LI(lane)];
         vB[LI(lane)] = ric_item_value(L + p.b_a + ((p.b_sg & 1) ? sgo : 0), L + p.b_b, L + p.b_i + ((p.b_sg & 4) ? sgo : 0), L + p.b_j);
         L[p.b_d] = vB[LI(lane)];
+        L[bdo[LI(lane)][2] + k * bdo[LI(lane)][3]] = vB[LI(lane)];      // border data of the stage: the lanes that formed q00, q10, q11 leave them there themselves (the others: dump slot)
     }
     // Quu = [q00 q10; q10 q11] must be positive definite (q00 > 0, det > 0).  Its inverse
     // is adj(Quu) / det: ONE division.  The three entries come straight out of the
@@ -244,7 +245,6 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
 #endif
     const double idet = rcp_nr(det);
     gdbl *ro = rs_base + (size_t)k * OB_RS;      // (as_base, rs_base: the instance's record buffers, read from LDS once per sweep -- not once per stage behind the stage's own LDS writes)
-    double *bd = g_traj + (size_t)k * RIC_BD;      // per-stage border data: at the start of the dynamic block (the trajectory is dead during the sweep)
     PAR(lane) {   // phase C
         const RicItem &p = rp[LI(lane)];
         const double x6 = L[p.c_x6 + ((p.c_sg & 1) ? sgo : 0)], x7 = L[p.c_x7 + ((p.c_sg & 2) ? sgo : 0)], q6 = L[p.c_q6 + ((p.c_sg & 4) ? sgo : 0)],
@@ -257,8 +257,9 @@ OBCA_FN int riccati_stage(const Inst &I, Shared &sh, const int k, const UnpackPl
             stage_unpack_load(as_base + (size_t)kl * OB_AS, plan[LI(lane)], nv[LI(lane)][slot]);
         }
         L[p.c_d1] = v; L[p.c_d2] = v;
-        // border data of the stage, without a branch around the stores (every lane stores: the lanes without an entry to the write-only slot dump4)
-        { double *b1 = p.c_bd >= 0 ? bd + p.c_bd : L + p.c_dump, *b2 = p.c_bd == 0 ? bd + 12 : L + p.c_dump; b1[0] = q6; b1[1] = q7; b2[0] = q00; b2[1] = q10; b2[2] = q11; b2[3] = idet; }
+        // border data of the stage (RIC_BD doubles at the start of the dynamic block: the trajectory is dead during the sweep), without a branch around the stores and without
+        // per-stage address selection: every lane stores to offset + k x stride of its own (bdo, built once per sweep); the lanes without an entry have stride 0 and the write-only slot dump4
+        { double *b1 = L + bdo[LI(lane)][0] + k * bdo[LI(lane)][1]; b1[0] = q6; b1[1] = q7; L[bdo[LI(lane)][4] + k * bdo[LI(lane)][5]] = idet; }
         ro[p.c_rv] = v; ro[p.c_rk0] = (double)(n0 * idet); ro[p.c_rk1] = (double)(n1 * idet);
     }
     LDS_SYNC();
@@ -312,6 +313,14 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
             for (int cc = 0; cc < 4; cc++) rl.pn[(2 + cc) * 6 + lane] = (lane == cc) ? 1.0 : 0.0;
         }
     }
+    int bdo[OBCA_NLT][6];      // border-data slots of the lane: (offset, stride per stage) of its (q6, q7) pair, of its Quu entry (lanes 28, 40, 41), of 1 / det (lane 0)
+    PAR(lane) {
+        const RicItem &p = rp[LI(lane)]; const int oTr = (int)(g_traj - (double *)&sh), own = lane == 28 ? 12 : (lane == 40 ? 13 : (lane == 41 ? 14 : -1));
+        int (&b)[6] = bdo[LI(lane)];
+        b[0] = p.c_bd >= 0 ? oTr + p.c_bd : p.c_dump; b[1] = p.c_bd >= 0 ? RIC_BD : 0;
+        b[2] = own >= 0 ? oTr + own : p.c_dump;        b[3] = own >= 0 ? RIC_BD : 0;
+        b[4] = lane == 0 ? oTr + 15 : p.c_dump;        b[5] = lane == 0 ? RIC_BD : 0;
+    }
     LDS_SYNC();
 #ifdef OBCA_EMU
     g_emu_ric_fail_stage = -1;
@@ -321,7 +330,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
     for (; k >= 0 && (k + 1) % RIC_D != 0 && ok; k--) {
         PAR(lane) { double v; stage_unpack_load(as_base + (size_t)k * OB_AS, plan[LI(lane)], v); stage_unpack_store(sg0 + (k & 1) * OB_STG, plan[LI(lane)], v); }
         LDS_SYNC();
-        ok = riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0, as_base, rs_base);
+        ok = riccati_stage<0>(I, sh, k, plan, rp, nv, 0, sg0, as_base, rs_base, bdo);
     }
     if (ok && k >= 0) {
         PAR(lane) {   // unpack stage k; start the gathers of stages k-1 .. k-RIC_D; enter the loop with nothing in flight
@@ -337,7 +346,7 @@ OBCA_FN int riccati_body(const Inst &I, Shared &sh, double rho) {   // all lanes
         LDS_SYNC();
         for (int kb = k; kb >= RIC_D - 1 && ok; kb -= RIC_D) {
 #pragma unroll
-            for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0, as_base, rs_base);
+            for (int ju = 0; ju < RIC_D; ju++) ok &= riccati_stage<1>(I, sh, kb - ju, plan, rp, nv, (ju + 1) % RIC_D, sg0, as_base, rs_base, bdo);
         }
     }
     if (!ok) { PROF(I, PF_RIC_BWD); return 0; }
