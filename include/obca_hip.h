@@ -64,7 +64,7 @@ typedef struct obca_batch obca_batch;
  *                          obca_reference_opts since round 5; the throughput set is its secondary leg config.fast_options.)
  * The numbers behind that split: both settings solve every instance of the three bench batches (identical exit flags, every solution passes the a-posteriori checker);
  * the IPOPT configuration costs 6 / 5 / 15 % more iterations and 12 x the inertia-correction rungs (the least-squares start leaves an indefinite Lagrangian Hessian early on):
- * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json; round 6, sixteen batches in flight: 278.0 k -> 228.6 k, 164.2 k -> 135.1 k, 129.5 k -> 99.3 k, profiles/r06_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
+ * 254.5 k -> 197.7 k, 152.9 k -> 123.0 k, 125.6 k -> 97.2 k solves/s on configs 2 / 3 / 5 (profiles/r04_bench*.json; round 6, sixteen batches in flight: 287.9 k -> 232.3 k, 165.1 k -> 136.8 k, 131.4 k -> 99.8 k, profiles/r06_bench*.json); and 13 of 1 024, 288 of 2 048, 58 of 4 096 instances end in ANOTHER local solution
  * of the non-convex NLP than with the switches off (states / inputs beyond 1e-3, or the objective beyond 1e-4 relative: bench.py, config.ipopt_options).  Neither set of local
  * solutions can be checked against IPOPT itself here (no Julia / IPOPT in the image): the drop-ins run the configuration that is the reference's by construction, the
  * throughput entry points the one that is a fifth cheaper; every bench line reports both.  (Quadcopter, pipelined: 36.7 k -> 31.4 k solves/s with its three switches.)
