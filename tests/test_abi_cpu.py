@@ -123,3 +123,16 @@ def test_diagnostics_are_not_in_the_product_library(lib):
     assert hasattr(d, "obca_diag_leave_pattern")
     d.obca_diag_leave_pattern.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
     assert d.obca_diag_leave_pattern(-1, 4, 1e30, None, None) == -1      # (argument check only: no device is touched)
+
+
+def test_loading_the_library_asks_for_one_hardware_queue_per_stream():
+    """obca_amd.api._load() sets GPU_MAX_HW_QUEUES=16 before the HIP runtime's first call unless the caller set a value (the runtime's default of 4 serialises
+    the streams that share a queue: profiles/r06_hw_queues.txt); a value the caller has set stays."""
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r); pre = os.environ.get('GPU_MAX_HW_QUEUES'); "
+            "from obca_amd import api; api._load(); print(pre, os.environ.get('GPU_MAX_HW_QUEUES'))") % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["None", "16"], out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["6", "6"], out
